@@ -1,0 +1,6 @@
+"""CPU parity oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product (reinforcementlearning.jl_amd/) never imports it and has no CPU fallback.
+"""
+from .binding import *  # noqa: F401,F403

@@ -1,0 +1,97 @@
+/* rlo_buffer.c -- CircularArraySARTSTraces-style replay ring + BatchSampler index draw.
+ * TEST INFRASTRUCTURE ONLY (see rl_oracle.h).
+ *
+ * The arithmetic lives in un-vendored packages (ReinforcementLearningTrajectories compat "0.4",
+ * CircularArrayBuffers compat "0.1.12": RLCore/Project.toml:9,20,30,40) -- PARITY UNPINNED.
+ * Anchors in the reference tree: constructor form RLCore/test/policies/q_based_policy.jl:41-47,
+ * push protocol RLCore/policies/agent/agent_base.jl:45-59, trace order agent_srt_cache.jl:30-40,
+ * length semantics RLCore/test/policies/agent.jl:27-34 (0 after the first state, 1 after the
+ * first transition), multiplexed next_state = state[i+1] (q_based_policy.jl:62-94).
+ *
+ * Published algorithm restated: each trace is a ring over its last dimension; `push!` writes the
+ * frame after the newest, overwriting the oldest when full; logical index i (0 = oldest) lives at
+ * physical (head + i) mod frames.  The state trace has capacity+1 frames, action/reward/terminal
+ * have capacity frames; transition i = (state[i], action[i], reward[i], terminal[i], state[i+1]).
+ * Vector-env extension: one frame = one vec-step of n_env transitions, stored SoA.
+ */
+#include "rl_oracle.h"
+#include <string.h>
+
+void rlo_ring_init(rlo_ring* rb, int64_t capacity, int64_t n_env, int64_t obs_dim, float* state,
+                   int32_t* action, float* reward, uint8_t* terminal) {
+    rb->capacity = capacity;
+    rb->n_env = n_env;
+    rb->obs_dim = obs_dim;
+    rb->head_sa = rb->len_sa = rb->head_rt = rb->len_rt = 0;
+    rb->state = state;
+    rb->action = action;
+    rb->reward = reward;
+    rb->terminal = terminal;
+}
+
+static void push_state_frame(rlo_ring* rb, const float* obs) {
+    int64_t frames = rb->capacity + 1;
+    int64_t fsz = rb->obs_dim * rb->n_env;
+    int64_t phys;
+    if (rb->len_sa < frames) {
+        phys = (rb->head_sa + rb->len_sa) % frames;
+        rb->len_sa += 1;
+    } else {
+        phys = rb->head_sa; /* overwrite the oldest, then it becomes the newest */
+        rb->head_sa = (rb->head_sa + 1) % frames;
+    }
+    memcpy(rb->state + phys * fsz, obs, sizeof(float) * (size_t)fsz);
+}
+
+void rlo_ring_push_state(rlo_ring* rb, const float* obs) { push_state_frame(rb, obs); }
+
+void rlo_ring_push_transition(rlo_ring* rb, const float* next_obs, const int32_t* action,
+                              const float* reward, const uint8_t* terminal) {
+    int64_t frames = rb->capacity;
+    int64_t n = rb->n_env;
+    int64_t phys;
+    if (rb->len_rt < frames) {
+        phys = (rb->head_rt + rb->len_rt) % frames;
+        rb->len_rt += 1;
+    } else {
+        phys = rb->head_rt;
+        rb->head_rt = (rb->head_rt + 1) % frames;
+    }
+    memcpy(rb->action + phys * n, action, sizeof(int32_t) * (size_t)n);
+    memcpy(rb->reward + phys * n, reward, sizeof(float) * (size_t)n);
+    memcpy(rb->terminal + phys * n, terminal, (size_t)n);
+    push_state_frame(rb, next_obs);
+}
+
+int64_t rlo_ring_length(const rlo_ring* rb) { return rb->len_rt; }
+
+/* BatchSampler: inds = rand(rng, 1:length(traces), batchsize) (with replacement).  Stand-in draw:
+ * 64-bit word (w0:w1) of Philox(seed, idx = b, t = draw_ctr, SAMPLER) scaled by multiply-high. */
+void rlo_ring_sample_indices(const rlo_ring* rb, int64_t batch, uint64_t seed, uint32_t draw_ctr,
+                             int64_t* flat_idx) {
+    uint64_t total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
+    for (int64_t b = 0; b < batch; ++b) {
+        uint32_t w[4];
+        rlo_philox4x32_10(seed, (uint32_t)b, 0, draw_ctr, RLO_TAG_SAMPLER, w);
+        uint64_t x = ((uint64_t)w[0] << 32) | (uint64_t)w[1];
+        flat_idx[b] = (int64_t)(((unsigned __int128)x * (unsigned __int128)total) >> 64);
+    }
+}
+
+void rlo_ring_gather(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, float* s,
+                     int32_t* a, float* r, uint8_t* term, float* s_next) {
+    int64_t n = rb->n_env, d = rb->obs_dim;
+    for (int64_t b = 0; b < batch; ++b) {
+        int64_t li = flat_idx[b] / n, e = flat_idx[b] % n;
+        int64_t ps = (rb->head_sa + li) % (rb->capacity + 1);
+        int64_t pn = (rb->head_sa + li + 1) % (rb->capacity + 1);
+        int64_t pt = (rb->head_rt + li) % rb->capacity;
+        for (int64_t k = 0; k < d; ++k) {
+            s[k * batch + b] = rb->state[(ps * d + k) * n + e];
+            s_next[k * batch + b] = rb->state[(pn * d + k) * n + e];
+        }
+        a[b] = rb->action[pt * n + e];
+        r[b] = rb->reward[pt * n + e];
+        term[b] = rb->terminal[pt * n + e];
+    }
+}

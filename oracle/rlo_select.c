@@ -1,0 +1,171 @@
+/* rlo_select.c -- integer action selection: find_all_max, findmax, eps schedules, eps-greedy,
+ * Gumbel-max categorical.  TEST INFRASTRUCTURE ONLY (see rl_oracle.h).
+ * Pinned on RLCore/test/utils/base.jl:2-14 and
+ * RLCore/test/policies/explorers/epsilon_greedy_explorer.jl:7-19,45-57,60-73
+ * (tests/golden/select.json).
+ */
+#include "rl_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+
+/* find_all_max(x) / find_all_max(x, mask)  RLCore/utils/basic.jl:91-114 */
+int64_t rlo_find_all_max_f64(const double* x, int64_t n, const uint8_t* mask, double* vmax,
+                             int64_t* idx_out) {
+    int have = 0;
+    double v = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue; /* :112 maximum(view(x, mask)) */
+        if (!have) {
+            v = x[i];
+            have = 1;
+        } else if (!isnan(v) && (isnan(x[i]) || x[i] > v)) {
+            v = x[i]; /* Julia's maximum propagates NaN */
+        }
+    }
+    if (!have) return 0;
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        if (x[i] == v) idx_out[c++] = i; /* :96,:113 (NaN == NaN is false, as in Julia) */
+    }
+    if (vmax) *vmax = v;
+    return c;
+}
+
+/* findmax(A)[2]: first index of the maximum; NaN counts as maximal (Base.findmax semantics,
+ * "NaN is treated as greater than all other values").  findmax_masked (:117-118) replaces
+ * masked-out entries by typemin(T) = -Inf before the search. */
+#define DEFINE_FINDMAX(T, SFX)                                                \
+    int64_t rlo_findmax_##SFX(const T* x, int64_t n, const uint8_t* mask) {   \
+        int64_t best = 0;                                                     \
+        T bv = (mask && !mask[0]) ? (T)-INFINITY : x[0];                      \
+        for (int64_t i = 1; i < n; ++i) {                                     \
+            T xi = (mask && !mask[i]) ? (T)-INFINITY : x[i];                  \
+            if (isnan(bv)) break;                                             \
+            if (isnan(xi) || xi > bv) {                                       \
+                bv = xi;                                                      \
+                best = i;                                                     \
+            }                                                                 \
+        }                                                                     \
+        return best;                                                          \
+    }
+DEFINE_FINDMAX(double, f64)
+DEFINE_FINDMAX(float, f32)
+
+/* get_eps  RLCore/policies/explorers/epsilon_greedy_explorer.jl:69-88 (all Float64) */
+double rlo_get_eps(int kind, double eps_stable, double eps_init, int64_t warmup_steps,
+                   int64_t decay_steps, int64_t step) {
+    if (kind == 0) { /* :linear  :69-78 */
+        if (step <= warmup_steps) return eps_init;
+        if (step >= warmup_steps + decay_steps) return eps_stable;
+        int64_t steps_left = warmup_steps + decay_steps - step;
+        return eps_stable + (double)steps_left / (double)decay_steps * (eps_init - eps_stable);
+    }
+    /* :exp  :80-88 */
+    if (step <= warmup_steps) return eps_init;
+    int64_t n = step - warmup_steps;
+    double scale = eps_init - eps_stable;
+    return eps_stable + scale * exp(-1.0 * (double)n / (double)decay_steps);
+}
+
+/* plan!(s::EpsilonGreedyExplorer, values[, mask])  :102-131, one column per env.
+ * Draw order of the reference: u = rand(rng) first, then (only on the branch taken) an index draw.
+ * Counter-based stand-in: one Philox block per (env, step): (w0,w1) -> u, w2 -> random branch index,
+ * w3 -> tie-break index. */
+int rlo_eps_greedy_select_f32(const float* values, int64_t na, int64_t n, const uint8_t* mask,
+                              double eps, int is_break_tie, uint64_t seed, uint32_t env_id_base,
+                              uint32_t step, int32_t* actions) {
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)na);
+    int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)na);
+    if (!tmp || !idx) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* q = values + i * na;
+        const uint8_t* mk = mask ? mask + i * na : 0;
+        uint32_t w[4];
+        rlo_philox4x32_10(seed, env_id_base + (uint32_t)i, 0, step, RLO_TAG_EXPLORE, w);
+        double u = rlo_u01_f64(w[0], w[1]);
+        int32_t a;
+        if (u >= eps) { /* greedy branch  :105,:111,:121,:130 */
+            if (is_break_tie) {
+                for (int64_t k = 0; k < na; ++k) tmp[k] = (double)q[k];
+                int64_t c = rlo_find_all_max_f64(tmp, na, mk, 0, idx);
+                a = (c > 0) ? (int32_t)idx[rlo_randint(w[3], (uint32_t)c)] : 0;
+            } else {
+                a = (int32_t)rlo_findmax_f32(q, na, mk);
+            }
+        } else { /* random branch: rand(rng, 1:n) or rand(rng, findall(mask)) */
+            if (mk) {
+                int64_t c = 0;
+                for (int64_t k = 0; k < na; ++k)
+                    if (mk[k]) idx[c++] = k;
+                a = (c > 0) ? (int32_t)idx[rlo_randint(w[2], (uint32_t)c)] : 0;
+            } else {
+                a = (int32_t)rlo_randint(w[2], (uint32_t)na);
+            }
+        }
+        actions[i] = a;
+    }
+    free(tmp);
+    free(idx);
+    return 0;
+}
+
+/* prob(s, values[, mask])  :141-194 */
+int rlo_eps_greedy_prob_f64(const double* values, int64_t na, const uint8_t* mask, double eps,
+                            int is_break_tie, double* probs) {
+    int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)na);
+    if (!idx) return -1;
+    int64_t nlegal = 0;
+    for (int64_t k = 0; k < na; ++k) nlegal += (!mask || mask[k]) ? 1 : 0;
+    for (int64_t k = 0; k < na; ++k)
+        probs[k] = (!mask || mask[k]) ? eps / (double)nlegal : 0.0; /* :143,:163,:179-180 */
+    if (is_break_tie) {
+        int64_t c = rlo_find_all_max_f64(values, na, mask, 0, idx);
+        for (int64_t j = 0; j < c; ++j) probs[idx[j]] += (1 - eps) / (double)c; /* :145-147 */
+    } else {
+        probs[rlo_findmax_f64(values, na, mask)] += 1 - eps; /* :164,:192 */
+    }
+    free(idx);
+    return 0;
+}
+
+/* sample_categorical  RLCore/utils/networks.jl:425-432 (mask: logits .+= ifelse(mask, 0, typemin) :466-468)
+ *   log_probs = logsoftmax(logits, dims = 1)            (Float32, NNlib: x - max - log(sum(exp(x - max))))
+ *   gumbels   = -log.(-log.(rand(rng, size...))) .+ log_probs   (rand -> Float64, so Float64)
+ *   z         = argmax over dim 1 (first maximal index)
+ */
+int rlo_categorical_sample_f32(const float* logits, int64_t na, int64_t n, const uint8_t* mask,
+                               uint64_t seed, uint32_t env_id_base, uint32_t step,
+                               int32_t* actions, float* logp_out) {
+    float* lp = (float*)malloc(sizeof(float) * (size_t)na);
+    if (!lp) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* l = logits + i * na;
+        const uint8_t* mk = mask ? mask + i * na : 0;
+        float mx = -INFINITY;
+        for (int64_t k = 0; k < na; ++k) {
+            lp[k] = (mk && !mk[k]) ? -INFINITY : l[k];
+            if (lp[k] > mx) mx = lp[k];
+        }
+        float se = 0.0f;
+        for (int64_t k = 0; k < na; ++k) se += expf(lp[k] - mx);
+        float lse = logf(se);
+        for (int64_t k = 0; k < na; ++k) lp[k] = (lp[k] - mx) - lse;
+        int64_t best = 0;
+        double bg = 0;
+        for (int64_t k = 0; k < na; ++k) {
+            uint32_t w[4];
+            rlo_philox4x32_10(seed, env_id_base + (uint32_t)i, (uint32_t)(k / 2), step, RLO_TAG_GUMBEL, w);
+            double u = (k & 1) ? rlo_u01_f64(w[2], w[3]) : rlo_u01_f64(w[0], w[1]);
+            double g = -log(-log(u)) + (double)lp[k];
+            if (k == 0 || g > bg) {
+                bg = g;
+                best = k;
+            }
+        }
+        actions[i] = (int32_t)best;
+        if (logp_out) logp_out[i] = lp[best];
+    }
+    free(lp);
+    return 0;
+}
