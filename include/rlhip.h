@@ -1,0 +1,384 @@
+/*
+ * rlhip.h -- C ABI of librlhip.so: the MI355X-native rollout + learner hot path for
+ * ReinforcementLearning.jl (vectorised classic-control env step -> replay ring push/gather ->
+ * GAE / TD target / Huber / Adam -> gradient hand-off to the all-reduce).
+ *
+ * The reference has NO foreign-function boundary (it is 100 % Julia, zero `ccall`; SURVEY.md
+ * section 0), so each entry point below names the Julia function(s) it replaces; the `ccall`
+ * stubs a maintainer would add are in INTEGRATION.md and reinforcementlearning.jl_amd/julia/RLHip.jl.
+ * Reference paths are relative to /root/reference/src/ :
+ *   RLEnvs = ReinforcementLearningEnvironments/src/environments/examples
+ *   RLCore = ReinforcementLearningCore/src
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs.  No torch / HIP types in any signature
+ *     (a stream is an opaque `void*` holding a hipStream_t; NULL = the default stream).
+ *   - every function returns int32: 0 = RLHIP_OK, < 0 = error; message via rlhip_last_error().
+ *   - all data pointers are DEVICE pointers unless the name ends in `_host`.  Calls enqueue on the
+ *     given stream and return immediately (no implicit sync) unless documented otherwise.
+ *   - indices are 0-based (Julia glue adds/subtracts 1: actions 1..na <-> 0..na-1).
+ *   - layouts are SoA: a per-env quantity q with D components is stored as q[d * n + i]
+ *     (component-major, env index i contiguous) so that one wavefront lane per env reads coalesced.
+ *     Time-major trajectories: x[(t * D + d) * n + i].
+ *   - random draws follow the Philox4x32-10 specification in DESIGN.md (ctr = {idx, blk, t, tag},
+ *     key = seed); `env_id_base` offsets idx so shards on different GPUs own disjoint streams and
+ *     results do not depend on the number of GPUs.
+ */
+#ifndef RLHIP_H
+#define RLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLHIP_OK 0
+#define RLHIP_EINVAL (-1) /* bad argument (the reference would throw AssertionError / ArgumentError / MethodError) */
+#define RLHIP_EHIP (-2)   /* a HIP runtime call failed */
+#define RLHIP_ENODEV (-3) /* no gfx950 device visible */
+
+#define RLHIP_ABI_VERSION 1
+
+typedef void* rlhip_stream_t; /* hipStream_t */
+typedef void* rlhip_event_t;  /* hipEvent_t  */
+
+/* ------------------------------------------------------------------------------ runtime -- */
+int32_t rlhip_abi_version(void);
+const char* rlhip_last_error(void);
+int32_t rlhip_device_count(int32_t* n_out);
+int32_t rlhip_set_device(int32_t device);
+/* device arch name, e.g. "gfx950:sramecc+:xnack-" (host buffer) */
+int32_t rlhip_device_name(int32_t device, char* name_host, int32_t cap);
+
+/* Device memory / streams / events for hosts that own no GPU allocator (the Julia glue).  A host
+ * that already has one (PyTorch-ROCm here) passes its own pointers and stream instead. */
+int32_t rlhip_malloc(void** ptr_out, size_t bytes);
+int32_t rlhip_free(void* ptr);
+int32_t rlhip_memset(void* ptr, int32_t value, size_t bytes, rlhip_stream_t stream);
+int32_t rlhip_memcpy_h2d(void* dst, const void* src_host, size_t bytes, rlhip_stream_t stream); /* syncs stream */
+int32_t rlhip_memcpy_d2h(void* dst_host, const void* src, size_t bytes, rlhip_stream_t stream); /* syncs stream */
+int32_t rlhip_memcpy_d2d(void* dst, const void* src, size_t bytes, rlhip_stream_t stream);
+int32_t rlhip_stream_create(rlhip_stream_t* stream_out);
+int32_t rlhip_stream_destroy(rlhip_stream_t stream);
+int32_t rlhip_stream_sync(rlhip_stream_t stream);
+int32_t rlhip_event_create(rlhip_event_t* event_out);
+int32_t rlhip_event_destroy(rlhip_event_t event);
+int32_t rlhip_event_record(rlhip_event_t event, rlhip_stream_t stream);
+/* syncs on `stop`, returns milliseconds between the two recorded events */
+int32_t rlhip_event_elapsed_ms(rlhip_event_t start, rlhip_event_t stop, float* ms_out);
+
+/* Philox uniforms U[0,1) (24-bit, Float32) -- synthetic data / weight init helper.
+ * out[i] = u01(word (i % 4) of Philox(seed, idx = i / 4, blk = 0, t, tag)). */
+int32_t rlhip_fill_uniform_f32(float* out, int64_t n, uint64_t seed, uint32_t t, uint32_t tag,
+                               rlhip_stream_t stream);
+/* keyed permutation of [0, n) (the `shuffle(rng, 1:n)` stand-in): out[i] = perm_epoch(i) */
+int32_t rlhip_permutation(uint32_t* out, uint32_t n, uint64_t seed, uint32_t epoch,
+                          rlhip_stream_t stream);
+
+/* --------------------------------------------------------------------------------- envs -- */
+#define RLHIP_ENV_CARTPOLE 0    /* RLEnvs/CartPoleEnv.jl */
+#define RLHIP_ENV_PENDULUM 1    /* RLEnvs/PendulumEnv.jl */
+#define RLHIP_ENV_MOUNTAINCAR 2 /* RLEnvs/MountainCarEnv.jl */
+
+/* CartPoleEnv(; kwargs...)  RLEnvs/CartPoleEnv.jl:22-32,74-79 -- Float64 as typed by the caller */
+typedef struct {
+    double gravity, masscart, masspole, halflength, forcemag, dt, thetathreshold_deg, xthreshold;
+    int64_t max_steps;
+    int32_t continuous; /* 0: action int32 in {0,1} (Julia 1,2); 1: action of type T in [-1,1] */
+} rlhip_cartpole_cfg;
+
+/* PendulumEnv(; kwargs...)  RLEnvs/PendulumEnv.jl:41-53 */
+typedef struct {
+    double max_speed, max_torque, g, m, l, dt;
+    int64_t max_steps;
+    int32_t continuous; /* 1: torque of type T; 0: int32 index in 0..n_actions-1 */
+    int32_t n_actions;
+} rlhip_pendulum_cfg;
+
+/* MountainCarEnv(; kwargs...)  RLEnvs/MountainCarEnv.jl:19-40,67-81 */
+typedef struct {
+    double min_pos, max_pos, max_speed, goal_pos, goal_velocity, power, gravity;
+    int64_t max_steps;
+    int32_t continuous;
+} rlhip_mountaincar_cfg;
+
+int32_t rlhip_cartpole_default(rlhip_cartpole_cfg* cfg_host);
+int32_t rlhip_pendulum_default(rlhip_pendulum_cfg* cfg_host);
+int32_t rlhip_mountaincar_default(rlhip_mountaincar_cfg* cfg_host, int32_t continuous);
+
+/* SoA state of n env instances (device arrays, caller-owned).
+ *   s[k]    T[n]   state component k (cartpole: x, xdot, theta, thetadot; pendulum: theta, thetadot;
+ *                  mountaincar: x, v)
+ *   t       i32[n] step counter of the running episode
+ *   done    u8[n]  is_terminated(env) after the LAST act!
+ *   reward  T[n]   reward(env) after the last act!
+ *   episode u32[n] number of resets so far (Philox time counter of the next reset)          */
+typedef struct {
+    void* s[4];
+    int32_t* t;
+    uint8_t* done;
+    void* reward;
+    uint32_t* episode;
+} rlhip_env_state;
+
+int32_t rlhip_env_obs_dim(int32_t kind);   /* cartpole 4, pendulum 3 (sin, cos, thetadot), mountaincar 2 */
+int32_t rlhip_env_state_dim(int32_t kind); /* cartpole 4, pendulum 2, mountaincar 2 */
+
+/* reset!(env)   CartPoleEnv.jl:98-104, PendulumEnv.jl:84-92, MountainCarEnv.jl:99-105.
+ * mask == NULL: reset every env (reset!(env; is_force = true) of the vector env); otherwise only
+ * where mask[i] != 0 (reset!(env) of the vector env = "reset the terminated ones", pass st->done). */
+int32_t rlhip_env_reset(int32_t kind, int32_t is_f64, const void* cfg_host,
+                        const rlhip_env_state* st_host, int64_t n, uint64_t seed,
+                        uint32_t env_id_base, const uint8_t* mask, rlhip_stream_t stream);
+
+/* act!(env, a) = _step! + reward + is_terminated for every env in one launch
+ *   CartPoleEnv.jl:106-140,:84-85; PendulumEnv.jl:94-122; MountainCarEnv.jl:107-135,:95.
+ * actions: i32[n] (discrete, 0-based) or T[n] (continuous).
+ * auto_reset != 0: the MultiThreadEnv protocol -- reward/done of the finished step stay visible and a
+ *   terminated env immediately starts a fresh episode inside the same kernel.
+ * last_obs (nullable): T[obs_dim * n] receives the observation BEFORE the auto-reset.
+ * obs_out  (nullable): T[obs_dim * n] receives state(env) AFTER the step (and auto-reset).       */
+int32_t rlhip_env_step(int32_t kind, int32_t is_f64, const void* cfg_host,
+                       const rlhip_env_state* st_host, int64_t n, const void* actions,
+                       int32_t auto_reset, uint64_t seed, uint32_t env_id_base, void* last_obs,
+                       void* obs_out, rlhip_stream_t stream);
+
+/* state(env)  CartPoleEnv.jl:86, PendulumEnv.jl:70,82, MountainCarEnv.jl:97 -> T[obs_dim * n] */
+int32_t rlhip_env_obs(int32_t kind, int32_t is_f64, const rlhip_env_state* st_host, int64_t n,
+                      void* obs_out, rlhip_stream_t stream);
+
+/* -------------------------------------------------------------------------------- scans -- */
+/* discount_rewards / discount_rewards_reduced / generalized_advantage_estimation
+ *   RLCore/utils/basic.jl:138-235, :237-319, :334-417.
+ * Matrices are column-major n1 x n2 like Julia.  dims = 0: vector (n2 must be 1);
+ * dims = 1 / 2: the Julia `dims` keyword = the axis the scan runs along.  A matrix with dims = 0 is
+ * RLHIP_EINVAL (the reference throws MethodError).  terminal / init may be NULL (`nothing`).
+ * values has one more entry than rewards along the scan axis.
+ * dims = 2 is the coalesced PPO layout (rewards (n_env, T)): one lane per env, T serial.        */
+int32_t rlhip_discount_rewards_f32(float* out, const float* rewards, int64_t n1, int64_t n2,
+                                   float gamma, const uint8_t* terminal, const float* init,
+                                   int32_t dims, rlhip_stream_t stream);
+int32_t rlhip_discount_rewards_f64(double* out, const double* rewards, int64_t n1, int64_t n2,
+                                   double gamma, const uint8_t* terminal, const double* init,
+                                   int32_t dims, rlhip_stream_t stream);
+int32_t rlhip_discount_rewards_reduced_f32(float* out, const float* rewards, int64_t n1, int64_t n2,
+                                           float gamma, const uint8_t* terminal, const float* init,
+                                           int32_t dims, rlhip_stream_t stream);
+int32_t rlhip_discount_rewards_reduced_f64(double* out, const double* rewards, int64_t n1,
+                                           int64_t n2, double gamma, const uint8_t* terminal,
+                                           const double* init, int32_t dims, rlhip_stream_t stream);
+int32_t rlhip_gae_f32(float* advantages, const float* rewards, const float* values, int64_t n1,
+                      int64_t n2, float gamma, float lambda, const uint8_t* terminal, int32_t dims,
+                      rlhip_stream_t stream);
+int32_t rlhip_gae_f64(double* advantages, const double* rewards, const double* values, int64_t n1,
+                      int64_t n2, double gamma, double lambda, const uint8_t* terminal, int32_t dims,
+                      rlhip_stream_t stream);
+/* PPO fusion: advantages AND returns = advantages + values[:, 1:T] in one pass over (n_env, T)
+ * time-major arrays (dims = 2 semantics). returns may be NULL. */
+int32_t rlhip_gae_returns_f32(float* advantages, float* returns, const float* rewards,
+                              const float* values, const uint8_t* terminal, int64_t n_env, int64_t T,
+                              float gamma, float lambda, rlhip_stream_t stream);
+
+/* ---------------------------------------------------------------------------- selection -- */
+/* element (k, i) of a (na x n) value array = values[k * k_stride + i * i_stride]:
+ *   Julia (na, N) column-major: k_stride = 1, i_stride = na;  SoA: k_stride = n, i_stride = 1.  */
+
+/* plan!(::EpsilonGreedyExplorer, values[, mask]) for n envs
+ *   RLCore/policies/explorers/epsilon_greedy_explorer.jl:102-131 (+ findmax / find_all_max
+ *   RLCore/utils/basic.jl:91-120); eps from rlhip_get_eps; GreedyExplorer (:200-205) = eps 0.
+ * mask (nullable) u8, same strides as values.  actions: i32[n], 0-based.
+ * draws: Philox(seed, idx = env_id_base + i, blk 0, t = step, EXPLORE): (w0,w1) -> u, w2 -> random index,
+ * w3 -> tie-break index. */
+int32_t rlhip_eps_greedy_select_f32(const float* values, int64_t na, int64_t n, int64_t k_stride,
+                                    int64_t i_stride, const uint8_t* mask, double eps,
+                                    int32_t is_break_tie, uint64_t seed, uint32_t env_id_base,
+                                    uint32_t step, int32_t* actions, rlhip_stream_t stream);
+/* get_eps  epsilon_greedy_explorer.jl:69-88 (host-side scalar; kind 0 = linear, 1 = exp) */
+double rlhip_get_eps(int32_t kind, double eps_stable, double eps_init, int64_t warmup_steps,
+                     int64_t decay_steps, int64_t step);
+/* sample_categorical (Gumbel-max)  RLCore/utils/networks.jl:425-432, masking :466-468.
+ * logp_out (nullable) f32[n] = logsoftmax(logits)[action]. */
+int32_t rlhip_categorical_sample_f32(const float* logits, int64_t na, int64_t n, int64_t k_stride,
+                                     int64_t i_stride, const uint8_t* mask, uint64_t seed,
+                                     uint32_t env_id_base, uint32_t step, int32_t* actions,
+                                     float* logp_out, rlhip_stream_t stream);
+
+/* ---------------------------------------------------------------------- parameter updates -- */
+/* TargetNetwork sync: dest = rho * dest + (1 - rho) * src   target_network.jl:76-85 (rho = 0: hard copy) */
+int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlhip_stream_t stream);
+/* clip_by_global_norm!(gs, ps, clip_norm)  RLCore/utils/basic.jl:19-29 over one flat gradient.
+ * gn_out: f32[1] device (the returned norm). */
+int32_t rlhip_clip_by_global_norm_f32(float* grad, int64_t n, float clip_norm, float* gn_out,
+                                      rlhip_stream_t stream);
+/* Flux.Optimise.update!(opt_state, model, grad)  flux_approximator.jl:46 with Optimisers.Adam.
+ * beta_pow: f32[2] device = running (beta1^t, beta2^t), initialised to (beta1, beta2); updated here. */
+int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, float* beta_pow,
+                       int64_t n, float lr, float beta1, float beta2, float eps,
+                       rlhip_stream_t stream);
+/* fused: [global norm -> clip] -> Adam in ONE single-workgroup launch (n <= ~1M).  clip_norm <= 0
+ * disables clipping.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow,
+                            int64_t n, float grad_scale, float clip_norm, float lr, float beta1,
+                            float beta2, float eps, float* gn_out, rlhip_stream_t stream);
+/* normlogpdf / diagnormlogpdf  RLCore/utils/distributions.jl:18-21, :31-34 (eps = 1f-8).
+ * diag: arrays (d x n) column-major, out f32[n]. */
+int32_t rlhip_normlogpdf_f32(const float* mu, const float* sigma, const float* x, float* out,
+                             int64_t n, rlhip_stream_t stream);
+int32_t rlhip_diagnormlogpdf_f32(const float* mu, const float* sigma, const float* x, int64_t d,
+                                 int64_t n, float* out, rlhip_stream_t stream);
+/* Flux.Losses.huber_loss(q, target; delta) mean-aggregated -> loss_out f32[1]; dq (nullable) = dL/dq */
+int32_t rlhip_huber_f32(const float* q, const float* target, int64_t n, float delta, float* loss_out,
+                        float* dq, rlhip_stream_t stream);
+/* DQN target G = r + gamma * (1 - terminal) * max_a' Qt(s', a')  (qt_next strides as in selection) */
+int32_t rlhip_td_target_f32(const float* qt_next, int64_t na, int64_t n, int64_t k_stride,
+                            int64_t i_stride, const float* reward, const uint8_t* terminal,
+                            float gamma, float* target, rlhip_stream_t stream);
+
+/* -------------------------------------------------------------------------- replay ring -- */
+/* CircularArraySARTSTraces(; capacity, state = Float32 => (obs_dim, n_env), action = Int32 => (n_env,),
+ * reward = Float32 => (n_env,), terminal = Bool => (n_env,)) resident in HBM
+ *   (un-vendored ReinforcementLearningTrajectories 0.4; call sites RLCore/policies/agent/agent_base.jl:45-59,
+ *    RLCore/test/policies/q_based_policy.jl:41-47).
+ * One frame = one vec-step.  state has capacity+1 frames (next_state[i] = state[i+1]), the other traces
+ * capacity frames.  Head/length counters are HOST fields updated by the push calls (they are pure
+ * functions of the push count, so no device sync is ever needed to know them).
+ * elem_bytes: 4 (Float32 observations) or 1 (UInt8 frames, e.g. 84x84x4 Atari stacks).          */
+typedef struct {
+    int64_t capacity, n_env, obs_dim;
+    int64_t head_sa, len_sa, head_rt, len_rt; /* host-side ring counters */
+    int32_t elem_bytes;
+    void* state;       /* (capacity + 1) * obs_dim * n_env elements */
+    int32_t* action;   /* capacity * n_env */
+    float* reward;     /* capacity * n_env */
+    uint8_t* terminal; /* capacity * n_env */
+} rlhip_ring;
+
+int32_t rlhip_ring_init(rlhip_ring* rb_host, int64_t capacity, int64_t n_env, int64_t obs_dim,
+                        int32_t elem_bytes, void* state, int32_t* action, float* reward,
+                        uint8_t* terminal);
+/* push!(trajectory, (state = s,))   Agent PreEpisodeStage  agent_base.jl:45-47 */
+int32_t rlhip_ring_push_state(rlhip_ring* rb_host, const void* obs, rlhip_stream_t stream);
+/* push!(trajectory, (state = s', action = a, reward = r, terminal = t))   PostActStage  :56-59 */
+int32_t rlhip_ring_push_transition(rlhip_ring* rb_host, const void* next_obs, const int32_t* action,
+                                   const float* reward, const uint8_t* terminal,
+                                   rlhip_stream_t stream);
+/* length(trajectory.container) */
+int64_t rlhip_ring_length(const rlhip_ring* rb_host);
+/* BatchSampler(batch): flat indices j = frame_logical * n_env + env, uniform with replacement.
+ * idx_out: i64[batch] device.  Philox(seed, idx = b, blk 0, t = draw_ctr, SAMPLER): ((w0:w1) * total) >> 64 */
+int32_t rlhip_ring_sample_indices(const rlhip_ring* rb_host, int64_t batch, uint64_t seed,
+                                  uint32_t draw_ctr, int64_t* idx_out, rlhip_stream_t stream);
+/* `for batch in trajectory`: gather (s, a, r, t, s') for flat indices.  Outputs SoA: s, s_next
+ * (obs_dim x batch) elements; a i32[batch]; r f32[batch]; term u8[batch].  LDS-staged index tile. */
+/* Output layout of s / s_next: component-major SoA (obs_dim x batch) in general; FRAME-major
+ * (batch x obs_dim, every frame contiguous) when rlhip_ring_gather_is_frame_major() != 0, i.e. for
+ * n_env == 1 rings whose frame is >= 1024 bytes and a multiple of 16 bytes (image observations). */
+int32_t rlhip_ring_gather_is_frame_major(const rlhip_ring* rb_host);
+int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t batch, void* s,
+                          int32_t* a, float* r, uint8_t* term, void* s_next,
+                          rlhip_stream_t stream);
+
+/* ---------------------------------------------------------------------------------- MLP -- */
+/* Chain(Dense(n_in, h, act), Dense(h, n_out)) with flat parameters in Flux.destructure order:
+ *   W1 (h x n_in col-major) | b1 (h) | W2 (n_out x h col-major) | b2 (n_out).   act: 0 relu, 1 tanh.
+ * FluxApproximator.forward  RLCore/policies/learners/flux_approximator.jl:43.
+ * x: SoA (n_in x batch), out: SoA (n_out x batch). */
+int64_t rlhip_mlp2_nparams(int64_t n_in, int64_t h, int64_t n_out);
+int32_t rlhip_mlp2_forward_f32(const float* params, int64_t n_in, int64_t h, int64_t n_out,
+                               int32_t act, const float* x, int64_t batch, float* out,
+                               rlhip_stream_t stream);
+/* glorot_uniform stand-in (Philox INIT stream; biases zero); net_id separates actor / critic / q */
+int32_t rlhip_mlp2_init_f32(float* params, int64_t n_in, int64_t h, int64_t n_out, uint64_t seed,
+                            uint32_t net_id, rlhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------ PPO path -- */
+/* PPOPolicy hyper-parameters (removed Zoo; blog a_practical_introduction_to_RL.jl/index.html:15257-15278) */
+typedef struct {
+    float gamma, lambda, clip_range, max_grad_norm;
+    float actor_loss_weight, critic_loss_weight, entropy_loss_weight;
+    float lr, beta1, beta2, adam_eps;
+    int32_t n_epochs, n_microbatches;
+    int32_t hidden, act;
+    int32_t continuous;          /* 0 categorical actor; 1 gaussian actor (mu, log sigma) */
+    int32_t normalize_advantage; /* reserved, must be 0 */
+} rlhip_ppo_cfg;
+int32_t rlhip_ppo_default(rlhip_ppo_cfg* cfg_host);
+/* parameter count of ActorCritic(actor = ns->hidden->na_out, critic = ns->hidden->1), flat = [actor | critic] */
+int64_t rlhip_ppo_nparams(int32_t kind, const rlhip_ppo_cfg* cfg_host);
+
+/* PPOTrajectory of one update period, time-major SoA device arrays (caller-owned):
+ *   obs (T+1, ns, n) f32 | action_i (T, n) i32 | action_f (T, na, n) f32 | logp (T, n) f32 |
+ *   value (T+1, n) f32 | reward (T, n) f32 | terminal (T, n) u8 | adv (T, n) f32 | ret (T, n) f32 */
+typedef struct {
+    float* obs;
+    float* logp;
+    float* value;
+    float* reward;
+    float* adv;
+    float* ret;
+    float* action_f;
+    int32_t* action_i;
+    uint8_t* terminal;
+} rlhip_ppo_traj;
+
+/* The blog's `_run(policy, env::MultiThreadEnv, ...)` inner loop (index.md:351-374) for T vec-steps in
+ * ONE launch: per step  state(env) -> actor/critic forward -> sample action (+ log-prob) -> trajectory
+ * write -> act! (+ auto-reset) -> reward / terminal write; finally obs[T], value[T].
+ * vec_step0: global vec-step counter at entry (Philox t of the sampling streams). */
+int32_t rlhip_ppo_rollout_f32(int32_t kind, const void* env_cfg_host, const rlhip_env_state* st_host,
+                              int64_t n, int64_t T, const rlhip_ppo_cfg* cfg_host,
+                              const float* params, uint64_t seed, uint32_t env_id_base,
+                              uint32_t vec_step0, const rlhip_ppo_traj* traj_host,
+                              rlhip_stream_t stream);
+/* plan!(policy, env) of the vector env as ONE launch (the per-step form of the rollout above, same
+ * device code and lane split, hence bit-identical to it): actor/critic forward on obs (SoA ns x n),
+ * action sample (Gumbel-max categorical networks.jl:425-432, or gaussian :64-82), log-prob, value.
+ * action_i (discrete) or action_f (continuous) must be non-NULL; logp / value are nullable. */
+int32_t rlhip_ppo_plan_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, const float* params,
+                           const float* obs, int64_t n, uint64_t seed, uint32_t env_id_base,
+                           uint32_t vec_step, int32_t* action_i, float* action_f, float* logp,
+                           float* value, rlhip_stream_t stream);
+/* generalized_advantage_estimation(reward, values, gamma, lambda; dims = 2, terminal) + returns */
+int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                          const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);
+/* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes */
+int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T);
+/* loss + flat gradient of micro-batch `mb` of epoch `epoch_ctr` (samples = keyed permutation of the
+ * T*n transitions).  grad_out: f32[nparams]; losses_out (nullable): f32[4] = loss, actor, critic, entropy */
+int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                           const rlhip_ppo_traj* traj_host, const float* params, uint64_t seed,
+                           uint32_t epoch_ctr, int32_t mb, void* workspace, float* grad_out,
+                           float* losses_out, rlhip_stream_t stream);
+/* n_epochs x n_microbatches of { grad -> clip_by_global_norm! -> Adam } enqueued back to back
+ * (single-GPU optimise!; multi-GPU hosts call rlhip_ppo_grad_f32, all-reduce, rlhip_clip_adam_f32).
+ * update_ctr = number of previous update calls. */
+int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                             const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
+                             float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,
+                             float* grad_scratch, float* losses_out, rlhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------ DQN path -- */
+/* BasicDQN / DQN learner (removed Zoo; spec docs/src/rlcore.md:28, blog index.html:15121-15147):
+ * q-net and target-net = mlp2 (ns -> h -> na).  One launch samples `batch` transitions from the ring
+ * (BatchSampler draw `draw_ctr`), computes the TD target with the target net, the Huber loss and the
+ * flat gradient.  workspace bytes: rlhip_dqn_workspace_bytes. */
+int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch);
+int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act,
+                           const float* params, const float* target_params, int64_t batch,
+                           float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr,
+                           void* workspace, float* grad_out, float* loss_out,
+                           rlhip_stream_t stream);
+/* plan!(QBasedPolicy, env) for the vector env in one launch: q = forward(learner, state(env)) then
+ * eps-greedy selection (q_based_policy.jl:30-32, abstract_learner.jl:37-39, epsilon_greedy_explorer.jl:108-112).
+ * q_out (nullable): SoA (na x n). */
+int32_t rlhip_dqn_plan_f32(const float* params, int64_t ns, int64_t h, int64_t na, int32_t act,
+                           const float* obs, int64_t n, double eps, uint64_t seed,
+                           uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
+                           rlhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLHIP_H */

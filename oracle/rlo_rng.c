@@ -94,10 +94,11 @@ void rlo_fill_uniform_f32(float* out, int64_t n, uint64_t seed, uint32_t t, uint
 }
 
 void rlo_normal_pair_f32(uint32_t w0, uint32_t w1, float* z0, float* z1) {
-    float u1 = (float)((w0 >> 8) + 1u) * 0x1p-24f; /* (0, 1] */
-    float u2 = (float)(w1 >> 8) * 0x1p-24f;        /* [0, 1) */
-    float r = sqrtf(-2.0f * logf(u1));
-    float a = 6.283185307179586f * u2;
-    *z0 = r * cosf(a);
-    *z1 = r * sinf(a);
+    /* evaluated in Float64 and rounded once, so CPU libm and GPU ocml agree bit for bit */
+    double u1 = (double)((w0 >> 8) + 1u) * 0x1p-24; /* (0, 1] */
+    double u2 = (double)(w1 >> 8) * 0x1p-24;        /* [0, 1) */
+    double r = sqrt(-2.0 * log(u1));
+    double a = 6.283185307179586 * u2;
+    *z0 = (float)(r * cos(a));
+    *z1 = (float)(r * sin(a));
 }

@@ -148,8 +148,10 @@ int rlo_categorical_sample_f32(const float* logits, int64_t na, int64_t n, const
             if (lp[k] > mx) mx = lp[k];
         }
         float se = 0.0f;
-        for (int64_t k = 0; k < na; ++k) se += expf(lp[k] - mx);
-        float lse = logf(se);
+        /* exp / log evaluated in Float64 and rounded once: the (almost always) correctly rounded Float32
+         * value, so that CPU libm and GPU ocml agree bit for bit */
+        for (int64_t k = 0; k < na; ++k) se += (float)exp((double)(lp[k] - mx));
+        float lse = (float)log((double)se);
         for (int64_t k = 0; k < na; ++k) lp[k] = (lp[k] - mx) - lse;
         int64_t best = 0;
         double bg = 0;

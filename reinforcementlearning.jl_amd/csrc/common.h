@@ -1,0 +1,144 @@
+// common.h -- shared host/device helpers of librlhip.so (gfx950 only).
+//
+// Error model of the C ABI: every entry point returns int32 (0 = RLHIP_OK, <0 = error) and stores
+// a message readable through rlhip_last_error() (thread-local).  No exceptions cross the boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/rlhip.h"
+
+namespace rlhip {
+
+void set_error(const char* fmt, ...);
+
+#define RLHIP_CHECK_HIP(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::rlhip::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+                               hipGetErrorString(_e));                                     \
+            return RLHIP_EHIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+#define RLHIP_REQUIRE(cond, msg)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            ::rlhip::set_error("%s:%d: invalid argument: %s (%s)", __FILE__, __LINE__, msg, \
+                               #cond);                                                     \
+            return RLHIP_EINVAL;                                                           \
+        }                                                                                  \
+    } while (0)
+
+#define RLHIP_LAUNCH_CHECK() RLHIP_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(rlhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Grid sizing for streaming kernels: enough workgroups to fill 256 CUs x 8 blocks, grid-stride the
+// rest (cdna_hip_programming.md Guideline 11).
+static inline int grid_for(int64_t n, int block, int max_blocks = 256 * 8) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10, ctr = {idx, blk, t, tag}, key = {seed_lo, seed_hi}.  Same specification as the
+// oracle (oracle/rlo_rng.c) -- shared by specification, not by code; checked by tests/.
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t {
+    TAG_RESET = 0,
+    TAG_EXPLORE = 1,
+    TAG_GUMBEL = 2,
+    TAG_NORMAL = 3,
+    TAG_SAMPLER = 4,
+    TAG_SHUFFLE = 5,
+    TAG_INIT = 6,
+    TAG_SYNTH = 7
+};
+
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint32_t idx, uint32_t blk,
+                                                        uint32_t t, uint32_t tag) {
+    uint32_t c0 = idx, c1 = blk, c2 = t, c3 = tag;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0;
+        c1 = (uint32_t)p1;
+        c2 = n2;
+        c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+__host__ __device__ __forceinline__ float u01_f32(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
+__host__ __device__ __forceinline__ double u01_f64(uint32_t hi, uint32_t lo) {
+    uint64_t x = ((uint64_t)hi << 32) | (uint64_t)lo;
+    return (double)(x >> 11) * 0x1p-53;
+}
+__host__ __device__ __forceinline__ uint32_t randint32(uint32_t w, uint32_t n) {
+    return (uint32_t)(((uint64_t)w * (uint64_t)n) >> 32);
+}
+
+// Keyed bijection on [0, n): 6-round Feistel over the enclosing power of 4 + cycle walking
+// (the `shuffle(rng, 1:n)` stand-in; every index appears exactly once per epoch).
+struct PermKeys {
+    uint32_t k[8];
+    uint32_t h, mask, n;
+};
+
+__host__ __device__ __forceinline__ PermKeys perm_keys(uint64_t seed, uint32_t epoch, uint32_t n) {
+    PermKeys pk;
+    u32x4 a = philox4x32_10(seed, 0, 0, epoch, TAG_SHUFFLE);
+    u32x4 b = philox4x32_10(seed, 0, 1, epoch, TAG_SHUFFLE);
+    pk.k[0] = a.x; pk.k[1] = a.y; pk.k[2] = a.z; pk.k[3] = a.w;
+    pk.k[4] = b.x; pk.k[5] = b.y; pk.k[6] = b.z; pk.k[7] = b.w;
+    uint32_t h = 1;
+    while (h < 16 && (1ull << (2 * h)) < (uint64_t)n) ++h;
+    pk.h = h;
+    pk.mask = (1u << h) - 1u;
+    pk.n = n;
+    return pk;
+}
+
+__host__ __device__ __forceinline__ uint32_t feistel_f(uint32_t r, uint32_t k) {
+    uint32_t f = r * 0x9E3779B1u + k;
+    f ^= f >> 15;
+    f *= 0x85EBCA77u;
+    f ^= f >> 13;
+    f *= 0xC2B2AE3Du;
+    f ^= f >> 16;
+    return f;
+}
+
+__host__ __device__ __forceinline__ uint32_t permute(const PermKeys& pk, uint32_t i) {
+    if (pk.n <= 1) return 0;
+    uint32_t x = i;
+    do {
+        uint32_t L = (x >> pk.h) & pk.mask, R = x & pk.mask;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            uint32_t nl = R;
+            uint32_t nr = L ^ (feistel_f(R, pk.k[r]) & pk.mask);
+            L = nl;
+            R = nr;
+        }
+        x = (L << pk.h) | R;
+    } while (x >= pk.n);
+    return x;
+}
+
+}  // namespace rlhip

@@ -1,0 +1,393 @@
+// dqn.hip -- the DQN hot path on the vector env: plan! (Q forward + eps-greedy) and the learner
+// update (replay sample -> TD target -> Huber loss -> gradient), each as one launch.
+//
+// What it replaces in the reference:
+//   plan!(QBasedPolicy, env)      RLCore/policies/q_based_policy.jl:30-32 ->
+//                                 RLCore/policies/learners/abstract_learner.jl:28-39 (forward = model(state),
+//                                 flux_approximator.jl:43) -> plan!(EpsilonGreedyExplorer, values)
+//                                 RLCore/policies/explorers/epsilon_greedy_explorer.jl:108-112
+//   optimise!(learner, stage, trajectory)   q_based_policy.jl:49 -> `for batch in trajectory`
+//                                 (sampler gather, un-vendored RLTrajectories) -> removed Zoo
+//                                 BasicDQN/DQN learner: y = r + gamma * (1 - t) * max_a' Qt(s', a'),
+//                                 Flux.Losses.huber_loss, Zygote backward (docs/src/rlcore.md:28,
+//                                 blog index.md:320-331, index.html:15121-15147)
+// The parameter step itself (Adam, target sync) is optim.hip.
+//
+// dqn_grad_kernel has the same two-phase structure as ppo_grad_kernel (see ppo.hip): the batch
+// indices are drawn inline from the SAMPLER Philox stream and the transitions are gathered straight
+// from the HBM ring into LDS -- the sampled batch is never materialised in HBM.
+#include "mlp_device.h"
+#include "select_device.h"
+
+extern "C" int64_t rlhip_mlp2_nparams(int64_t n_in, int64_t h, int64_t n_out);
+
+namespace rlhip {
+
+constexpr int DTILE = 64;
+constexpr int DQN_MAX_BLOCKS = 512;
+
+struct DqnArgs {
+    const float* state;
+    const int32_t* action;
+    const float* reward;
+    const uint8_t* terminal;
+    int64_t capacity, n_env, head_sa, head_rt;
+    uint64_t total;
+    const float* params;
+    const float* tparams;
+    float* partials;
+    float* loss_partials;
+    int h, na, act, np, num_tiles;
+    int64_t batch;
+    float gamma, delta, inv_b;
+    uint64_t seed;
+    uint32_t draw_ctr;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
+    __shared__ float l_s[NS][DTILE], l_sn[NS][DTILE];
+    __shared__ float l_r[DTILE];
+    __shared__ int32_t l_a[DTILE];
+    __shared__ uint8_t l_t[DTILE];
+    __shared__ float l_part[4][2 * MAXO][DTILE];
+    __shared__ float l_dL[MAXO][DTILE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = g.h, na = g.na, act = g.act, hq = h >> 2;
+    const float* W1 = g.params;
+    const float* b1 = W1 + h * NS;
+    const float* W2 = b1 + h;
+    const float* b2 = W2 + na * h;
+    const float* tW1 = g.tparams;
+    const float* tb1 = tW1 + h * NS;
+    const float* tW2 = tb1 + h;
+    const float* tb2 = tW2 + na * h;
+
+    const bool owner = tid < h;
+    const int j = owner ? tid : 0;
+    float rw1[NS], rw2[MAXO];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) rw1[k] = W1[j + h * k];
+    const float rb1 = b1[j];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) rw2[o] = (o < na) ? W2[o + na * j] : 0.f;
+    float gw1[NS], gw2[MAXO], gb1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) gw1[k] = 0.f;
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) gw2[o] = 0.f;
+    float gb2[MAXO] = {0.f, 0.f, 0.f, 0.f};
+    float s_loss = 0.f;
+
+    for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
+        if (tid < DTILE) {
+            int64_t b = (int64_t)tile * DTILE + tid;
+            bool valid = b < g.batch;
+            u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
+            uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
+            int64_t fj = (int64_t)__umul64hi(xr, g.total);
+            int64_t li = fj / g.n_env, e = fj - li * g.n_env;
+            int64_t ps = (g.head_sa + li) % (g.capacity + 1);
+            int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
+            int64_t pt = (g.head_rt + li) % g.capacity;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                l_s[k][tid] = g.state[(ps * NS + k) * g.n_env + e];
+                l_sn[k][tid] = g.state[(pn * NS + k) * g.n_env + e];
+            }
+            l_a[tid] = g.action[pt * g.n_env + e];
+            l_r[tid] = g.reward[pt * g.n_env + e];
+            l_t[tid] = g.terminal[pt * g.n_env + e];
+        }
+        __syncthreads();
+        {
+            float x[NS], xn[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                x[k] = l_s[k][lane];
+                xn[k] = l_sn[k][lane];
+            }
+            float acc[MAXO] = {0.f, 0.f, 0.f, 0.f}, acn[MAXO] = {0.f, 0.f, 0.f, 0.f};
+            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
+                float z = b1[jj], zn = tb1[jj];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    z = fmaf(W1[jj + h * k], x[k], z);
+                    zn = fmaf(tW1[jj + h * k], xn[k], zn);
+                }
+                float hv = act_fwd(act, z), hn = act_fwd(act, zn);
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o)
+                    if (o < na) {
+                        acc[o] = fmaf(W2[o + na * jj], hv, acc[o]);
+                        acn[o] = fmaf(tW2[o + na * jj], hn, acn[o]);
+                    }
+            }
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) {
+                l_part[w][o][lane] = acc[o];
+                l_part[w][MAXO + o][lane] = acn[o];
+            }
+        }
+        __syncthreads();
+        if (tid < DTILE) {
+            const int s = tid;
+            bool valid = ((int64_t)tile * DTILE + s) < g.batch;
+            float q[MAXO], qn[MAXO];
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) {
+                q[o] = (((l_part[0][o][s] + l_part[1][o][s]) + l_part[2][o][s]) + l_part[3][o][s]) +
+                       ((o < na) ? b2[o] : 0.f);
+                qn[o] = (((l_part[0][MAXO + o][s] + l_part[1][MAXO + o][s]) + l_part[2][MAXO + o][s]) +
+                         l_part[3][MAXO + o][s]) +
+                        ((o < na) ? tb2[o] : 0.f);
+            }
+            float mx = qn[0];
+            for (int k = 1; k < na; ++k) mx = fmaxf(mx, qn[k]);
+            float cont = l_t[s] ? 0.f : 1.f;
+            float G = l_r[s] + g.gamma * cont * mx;
+            int a = l_a[s];
+            float qa = 0.f;
+            for (int k = 0; k < na; ++k)
+                if (k == a) qa = q[k];
+            float d = qa - G;
+            float e = fabsf(d);
+            float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
+            float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
+            gi *= g.inv_b;
+            if (!valid) {
+                gi = 0.f;
+                l = 0.f;
+            }
+            s_loss += l;
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) {
+                float dl = (o == a) ? gi : 0.f;
+                l_dL[o][s] = dl;
+                gb2[o] += dl;
+            }
+        }
+        __syncthreads();
+        if (owner) {
+#pragma unroll 4
+            for (int s = 0; s < DTILE; ++s) {
+                float x[NS];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) x[k] = l_s[k][s];
+                float z = rb1;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) z = fmaf(rw1[k], x[k], z);
+                float hv = act_fwd(act, z);
+                float dh = 0.f;
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o) {
+                    float d = l_dL[o][s];
+                    gw2[o] = fmaf(d, hv, gw2[o]);
+                    dh = fmaf(d, rw2[o], dh);
+                }
+                float dz = dh * act_bwd(act, z, hv);
+                gb1 += dz;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) gw1[k] = fmaf(dz, x[k], gw1[k]);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = g.partials + (int64_t)blockIdx.x * g.np;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) out[j + h * k] = gw1[k];
+        out[h * NS + j] = gb1;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o < na) out[h * NS + h + o + na * j] = gw2[o];
+    }
+    if (tid < DTILE) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) gb2[o] += __shfl_down(gb2[o], off, 64);
+            s_loss += __shfl_down(s_loss, off, 64);
+        }
+        if (tid == 0) {
+            for (int o = 0; o < na; ++o) out[h * NS + h + na * h + o] = gb2[o];
+            g.loss_partials[blockIdx.x] = s_loss;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials,
+                                                         const float* __restrict__ loss_partials, int nb, int np,
+                                                         float* __restrict__ grad, float* __restrict__ loss,
+                                                         float inv_b) {
+    __shared__ float l_g[4][64];
+    int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int p = blockIdx.x * 64 + lane;
+    int per = (nb + 3) / 4;
+    int b0 = grp * per, b1 = min(nb, b0 + per);
+    float acc = 0.f;
+    if (p < np) {
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + p];
+    }
+    l_g[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && p < np) grad[p] = ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane];
+    if (blockIdx.x == 0 && loss != nullptr && grp == 1) {
+        float a = 0.f;
+        for (int b = lane; b < nb; b += 64) a += loss_partials[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) loss[0] = a * inv_b;
+    }
+}
+
+struct RegQ {
+    const float* q;
+    __device__ __forceinline__ float operator()(int k) const { return q[k]; }
+};
+
+template <int NS, int H, int L>
+__global__ __launch_bounds__(256, 1) void dqn_plan_wide_kernel(const float* __restrict__ params, int na, int act,
+                                                               const float* __restrict__ obs, int64_t n,
+                                                               double eps, uint64_t seed, uint32_t env_id_base,
+                                                               uint32_t step, int32_t* __restrict__ actions,
+                                                               float* __restrict__ q_out) {
+    constexpr int HPL = H / L;
+    int64_t gl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t env = gl / L;
+    int sub = (int)(gl % L);
+    bool active = env < n;
+    if (!active) env = n - 1;
+    NetRegs<NS, HPL> Q;
+    load_net<NS, HPL>(Q, params, H, na, sub, L);
+    float x[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) x[k] = obs[(int64_t)k * n + env];
+    float q[MAXO];
+    net_forward<NS, HPL, L>(Q, x, act, q);
+    int32_t a = eps_greedy_select1(RegQ{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)env, step);
+    if (active && sub == 0) {
+        actions[env] = a;
+        if (q_out)
+            for (int o = 0; o < na; ++o) q_out[(int64_t)o * n + env] = q[o];
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void dqn_plan_scalar_kernel(const float* __restrict__ params, int h, int na,
+                                                              int act, const float* __restrict__ obs, int64_t n,
+                                                              double eps, uint64_t seed, uint32_t env_id_base,
+                                                              uint32_t step, int32_t* __restrict__ actions,
+                                                              float* __restrict__ q_out) {
+    int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n) return;
+    float x[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) x[k] = obs[(int64_t)k * n + env];
+    float q[MAXO];
+    net_forward_scalar<NS>(params, h, na, act, x, q);
+    actions[env] = eps_greedy_select1(RegQ{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)env, step);
+    if (q_out)
+        for (int o = 0; o < na; ++o) q_out[(int64_t)o * n + env] = q[o];
+}
+
+template <int NS>
+static int32_t dqn_plan_impl(const float* params, int h, int na, int act, const float* obs, int64_t n, double eps,
+                             uint64_t seed, uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
+                             hipStream_t s) {
+    bool wide = (h == 256 || h == 128 || h == 64) && n * 16 <= (int64_t)1 << 22;
+#define LAUNCH_QW(H, L)                                                                                       \
+    hipLaunchKernelGGL((dqn_plan_wide_kernel<NS, H, L>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, params, \
+                       na, act, obs, n, eps, seed, env_id_base, step, actions, q_out)
+    if (wide && h == 256) LAUNCH_QW(256, 16);
+    else if (wide && h == 128) LAUNCH_QW(128, 8);
+    else if (wide && h == 64) LAUNCH_QW(64, 4);
+    else
+        hipLaunchKernelGGL((dqn_plan_scalar_kernel<NS>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, params, h,
+                           na, act, obs, n, eps, seed, env_id_base, step, actions, q_out);
+#undef LAUNCH_QW
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+}  // namespace rlhip
+
+using namespace rlhip;
+
+extern "C" {
+
+int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
+    (void)batch;
+    int64_t np = mlp2_nparams(ns, h, na);
+    return (int64_t)DQN_MAX_BLOCKS * (np + 1) * (int64_t)sizeof(float);
+}
+
+int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                           const float* target_params, int64_t batch, float gamma, float huber_delta,
+                           uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,
+                           rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && params && target_params && workspace && grad_out, "NULL argument");
+    RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
+    RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
+    RLHIP_REQUIRE(h >= 4 && h <= 256 && h % 4 == 0, "hidden must be a multiple of 4, <= 256");
+    RLHIP_REQUIRE(na >= 1 && na <= MAXO, "na must be <= 4");
+    RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
+    RLHIP_REQUIRE(batch >= 1, "empty batch");
+    RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
+    int ns = (int)rb->obs_dim;
+    int64_t np = mlp2_nparams(ns, h, na);
+    DqnArgs g;
+    g.state = (const float*)rb->state;
+    g.action = rb->action;
+    g.reward = rb->reward;
+    g.terminal = rb->terminal;
+    g.capacity = rb->capacity;
+    g.n_env = rb->n_env;
+    g.head_sa = rb->head_sa;
+    g.head_rt = rb->head_rt;
+    g.total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
+    g.params = params;
+    g.tparams = target_params;
+    g.h = (int)h;
+    g.na = (int)na;
+    g.act = act;
+    g.np = (int)np;
+    g.num_tiles = (int)((batch + DTILE - 1) / DTILE);
+    g.batch = batch;
+    g.gamma = gamma;
+    g.delta = huber_delta;
+    g.inv_b = 1.0f / (float)batch;
+    g.seed = seed;
+    g.draw_ctr = draw_ctr;
+    int nb = g.num_tiles < DQN_MAX_BLOCKS ? g.num_tiles : DQN_MAX_BLOCKS;
+    g.partials = (float*)workspace;
+    g.loss_partials = g.partials + (int64_t)DQN_MAX_BLOCKS * np;
+    hipStream_t s = as_stream(stream);
+    if (ns == 4) hipLaunchKernelGGL((dqn_grad_kernel<4>), dim3(nb), dim3(256), 0, s, g);
+    else if (ns == 3) hipLaunchKernelGGL((dqn_grad_kernel<3>), dim3(nb), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((dqn_grad_kernel<2>), dim3(nb), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
+                       nb, (int)np, grad_out, loss_out, g.inv_b);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_dqn_plan_f32(const float* params, int64_t ns, int64_t h, int64_t na, int32_t act, const float* obs,
+                           int64_t n, double eps, uint64_t seed, uint32_t env_id_base, uint32_t step,
+                           int32_t* actions, float* q_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(params && obs && actions, "NULL argument");
+    RLHIP_REQUIRE(ns >= 2 && ns <= 4, "obs dim must be 2..4");
+    RLHIP_REQUIRE(na >= 1 && na <= MAXO, "na must be <= 4");
+    RLHIP_REQUIRE(h >= 1, "bad hidden size");
+    RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
+    if (n == 0) return RLHIP_OK;
+    hipStream_t s = as_stream(stream);
+    if (ns == 4) return dqn_plan_impl<4>(params, (int)h, (int)na, act, obs, n, eps, seed, env_id_base, step, actions, q_out, s);
+    if (ns == 3) return dqn_plan_impl<3>(params, (int)h, (int)na, act, obs, n, eps, seed, env_id_base, step, actions, q_out, s);
+    return dqn_plan_impl<2>(params, (int)h, (int)na, act, obs, n, eps, seed, env_id_base, step, actions, q_out, s);
+}
+
+}  // extern "C"

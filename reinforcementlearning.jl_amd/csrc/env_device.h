@@ -1,0 +1,338 @@
+// env_device.h -- per-lane physics of the three classic-control envs (device inline functions).
+//
+// One wavefront lane owns one env instance; state lives in registers between load and store.  Used
+// by the stand-alone env kernels (envs.hip) and by the fused rollout kernel (ppo.hip), so both paths
+// produce bit-identical trajectories.
+//
+// The element type T is Float32 or Float64 like `CartPoleEnv(; T = ...)`.  With T = Float32 the
+// reference silently promotes a few sub-expressions to Float64 (Float64 literals `4 / 3`, `0.1`,
+// `0.001`, `0.2`, `0.6`, `2 * pi`).  Those promotions are reproduced here --
+// the file is compiled with -ffp-contract=off so no a*b+c is fused behind our back.
+//
+// Trigonometry: the reference's sin/cos(::Float32) (Julia Base, double-precision kernel, rounded
+// once) is correctly rounded in all but ~1e-9 of inputs; evaluating in Float64 and rounding to
+// Float32 reproduces that, where the GPU's native sinf/cosf (1-2 ulp) would not.  The open-loop
+// pole amplifies a 1-ulp difference by ~1e6 over an episode (Appendix A.7), so this matters.
+#pragma once
+#include "common.h"
+
+namespace rlhip {
+
+#ifndef RLHIP_PI
+#define RLHIP_PI 3.14159265358979323846
+#endif
+
+template <typename T>
+struct Trig;
+template <>
+struct Trig<float> {
+    static __device__ __forceinline__ float sin_(float x) { return (float)::sin((double)x); }
+    static __device__ __forceinline__ float cos_(float x) { return (float)::cos((double)x); }
+    static __device__ __forceinline__ void sincos_(float x, float* s, float* c) {
+        double ds, dc;
+        ::sincos((double)x, &ds, &dc);
+        *s = (float)ds;
+        *c = (float)dc;
+    }
+};
+template <>
+struct Trig<double> {
+    static __device__ __forceinline__ double sin_(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double cos_(double x) { return ::cos(x); }
+    static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { ::sincos(x, s, c); }
+};
+
+template <typename T>
+__device__ __forceinline__ T clampT(T x, T lo, T hi) {
+    return (x > hi) ? hi : ((x < lo) ? lo : x);  // Base.clamp
+}
+
+// per-lane uniform draws of reset!: rand(rng, T) stand-ins from the RESET stream
+template <typename T>
+struct ResetDraw;
+template <>
+struct ResetDraw<float> {
+    // up to 4 uniforms from one Philox block
+    static __device__ __forceinline__ void draw4(uint64_t seed, uint32_t id, uint32_t ep, float u[4]) {
+        u32x4 w = philox4x32_10(seed, id, 0, ep, TAG_RESET);
+        u[0] = u01_f32(w.x);
+        u[1] = u01_f32(w.y);
+        u[2] = u01_f32(w.z);
+        u[3] = u01_f32(w.w);
+    }
+    static __device__ __forceinline__ void draw2(uint64_t seed, uint32_t id, uint32_t ep, float u[2]) {
+        u32x4 w = philox4x32_10(seed, id, 0, ep, TAG_RESET);
+        u[0] = u01_f32(w.x);
+        u[1] = u01_f32(w.y);
+    }
+};
+template <>
+struct ResetDraw<double> {
+    static __device__ __forceinline__ void draw4(uint64_t seed, uint32_t id, uint32_t ep, double u[4]) {
+        u32x4 a = philox4x32_10(seed, id, 0, ep, TAG_RESET);
+        u32x4 b = philox4x32_10(seed, id, 1, ep, TAG_RESET);
+        u[0] = u01_f64(a.x, a.y);
+        u[1] = u01_f64(a.z, a.w);
+        u[2] = u01_f64(b.x, b.y);
+        u[3] = u01_f64(b.z, b.w);
+    }
+    static __device__ __forceinline__ void draw2(uint64_t seed, uint32_t id, uint32_t ep, double u[2]) {
+        u32x4 a = philox4x32_10(seed, id, 0, ep, TAG_RESET);
+        u[0] = u01_f64(a.x, a.y);
+        u[1] = u01_f64(a.z, a.w);
+    }
+};
+
+// --------------------------------------------------------------------------------- CartPole --
+template <typename T>
+struct CartPoleParams {  // CartPoleEnvParams{T}  RLEnvs/CartPoleEnv.jl:3-15
+    T gravity, masscart, masspole, totalmass, halflength, polemasslength, forcemag, dt,
+        thetathreshold, xthreshold;
+    int32_t max_steps;
+    int32_t continuous;
+    static constexpr int SDIM = 4;
+    static constexpr int ODIM = 4;
+    static constexpr int KIND = RLHIP_ENV_CARTPOLE;
+    typedef rlhip_cartpole_cfg cfg_t;
+
+    // CartPoleEnvParams{T}(; kwargs...)  :22-46 -- derive in Float64, then convert to T
+    static CartPoleParams make(const rlhip_cartpole_cfg& c) {
+        CartPoleParams p;
+        p.gravity = (T)c.gravity;
+        p.masscart = (T)c.masscart;
+        p.masspole = (T)c.masspole;
+        p.totalmass = (T)(c.masscart + c.masspole);
+        p.halflength = (T)c.halflength;
+        p.polemasslength = (T)(c.masspole * c.halflength);
+        p.forcemag = (T)c.forcemag;
+        p.dt = (T)c.dt;
+        p.thetathreshold = (T)(c.thetathreshold_deg * RLHIP_PI / 180);
+        p.xthreshold = (T)c.xthreshold;
+        p.max_steps = (int32_t)c.max_steps;
+        p.continuous = c.continuous;
+        return p;
+    }
+    bool is_continuous() const { return continuous != 0; }
+};
+
+template <typename T>
+struct LaneState {
+    T s[4];
+    int32_t t;
+    uint32_t episode;
+};
+
+// reset!  :98-104   state = T(0.1) * rand(rng, T, 4) .- T(0.05); t = 0
+template <typename T>
+__device__ __forceinline__ void env_reset1(const CartPoleParams<T>&, LaneState<T>& e, uint64_t seed,
+                                           uint32_t id) {
+    T u[4];
+    ResetDraw<T>::draw4(seed, id, e.episode, u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.s[k] = (T)0.1 * u[k] - (T)0.05;
+    e.t = 0;
+    e.episode += 1;
+}
+
+// act! + _step!  :106-140, reward :84.  action: raw pointer element already converted by the caller:
+//   discrete -> a in {0,1} (Julia 1,2);  continuous -> a of type T
+template <typename T>
+__device__ __forceinline__ void env_step1(const CartPoleParams<T>& p, LaneState<T>& e, int32_t ai, T af,
+                                          T& reward, bool& done) {
+    T a = p.continuous ? af : ((ai == 1) ? (T)1 : (T)-1);  // :115  a == 2 ? 1 : -1
+    e.t += 1;                                              // :119
+    T force = a * p.forcemag;                              // :120
+    T x = e.s[0], xdot = e.s[1], theta = e.s[2], thetadot = e.s[3];  // :121 (pre-step values)
+    T sintheta, costheta;
+    Trig<T>::sincos_(theta, &sintheta, &costheta);         // :122-123
+    T tmp = (force + p.polemasslength * (thetadot * thetadot) * sintheta) / p.totalmass;  // :124
+    // :125-129  the literal 4 / 3 is Float64: denominator, thetaacc and xacc are Float64
+    T num = p.gravity * sintheta - costheta * tmp;
+    T frac = p.masspole * (costheta * costheta) / p.totalmass;
+    double den = (double)p.halflength * (4.0 / 3.0 - (double)frac);
+    double thetaacc = (double)num / den;
+    double xacc = (double)tmp -
+                  (double)p.polemasslength * thetaacc * (double)costheta / (double)p.totalmass;  // :130
+    e.s[0] = x + p.dt * xdot;                                 // :131
+    e.s[1] = (T)((double)xdot + (double)p.dt * xacc);         // :132
+    e.s[2] = theta + p.dt * thetadot;                         // :133
+    e.s[3] = (T)((double)thetadot + (double)p.dt * thetaacc); // :134
+    T ax = e.s[0] < (T)0 ? -e.s[0] : e.s[0];
+    T ath = e.s[2] < (T)0 ? -e.s[2] : e.s[2];
+    done = ax > p.xthreshold || ath > p.thetathreshold || e.t > p.max_steps;  // :135-138
+    reward = done ? (T)0 : (T)1;                                             // :84
+}
+
+template <typename T>
+__device__ __forceinline__ void env_obs1(const CartPoleParams<T>&, const LaneState<T>& e, T o[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = e.s[k];  // :86
+}
+
+// --------------------------------------------------------------------------------- Pendulum --
+template <typename T>
+struct PendulumParams {  // PendulumEnvParams{T}  RLEnvs/PendulumEnv.jl:3-11
+    T max_speed, max_torque, g, m, l, dt;
+    int32_t max_steps;
+    int32_t continuous, n_actions;
+    static constexpr int SDIM = 2;
+    static constexpr int ODIM = 3;
+    static constexpr int KIND = RLHIP_ENV_PENDULUM;
+    typedef rlhip_pendulum_cfg cfg_t;
+    static PendulumParams make(const rlhip_pendulum_cfg& c) {
+        PendulumParams p;
+        p.max_speed = (T)c.max_speed;
+        p.max_torque = (T)c.max_torque;
+        p.g = (T)c.g;
+        p.m = (T)c.m;
+        p.l = (T)c.l;
+        p.dt = (T)c.dt;
+        p.max_steps = (int32_t)c.max_steps;
+        p.continuous = c.continuous;
+        p.n_actions = c.n_actions;
+        return p;
+    }
+    bool is_continuous() const { return continuous != 0; }
+};
+
+// Julia mod(x::Float64, y::Float64): floored modulo on top of the exact rem (= fmod)
+__device__ __forceinline__ double jl_mod(double x, double y) {
+    double r = ::fmod(x, y);
+    if (r == 0) return ::copysign(r, y);
+    if ((r > 0) != (y > 0)) return r + y;
+    return r;
+}
+
+// reset!  :84-92
+template <typename T>
+__device__ __forceinline__ void env_reset1(const PendulumParams<T>&, LaneState<T>& e, uint64_t seed,
+                                           uint32_t id) {
+    T u[2];
+    ResetDraw<T>::draw2(seed, id, e.episode, u);
+    e.s[0] = (T)((2.0 * RLHIP_PI) * (double)(u[0] - (T)1));  // :85  2 * pi * (rand(T) - 1), Float64 product
+    e.s[1] = (T)2 * (u[1] - (T)1);                           // :86
+    e.t = 0;
+    e.episode += 1;
+}
+
+// act! + torque + _step!  :94-122
+template <typename T>
+__device__ __forceinline__ void env_step1(const PendulumParams<T>& p, LaneState<T>& e, int32_t ai, T af,
+                                          T& reward, bool& done) {
+    T a;
+    if (p.continuous) {
+        a = af;  // :122
+    } else {
+        // :120-121  (4 / (n - 1)) * (a - (n - 1) / 2 - 1) in Float64 with the 1-based a; env.action::T rounds
+        double a1 = (double)(ai + 1);
+        double nm1 = (double)(p.n_actions - 1);
+        a = (T)((4.0 / nm1) * (a1 - nm1 / 2.0 - 1.0));
+    }
+    e.t += 1;                                     // :101
+    T th = e.s[0], thdot = e.s[1];                // :102
+    a = clampT(a, -p.max_torque, p.max_torque);   // :103
+    // :104  costs = angle_normalize(th)^2 + 0.1 * thdot^2 + 0.001 * a^2 (Float64);
+    //       angle_normalize(x) = mod(x + pi, 2 * pi) - pi  (:71): x + pi is T, 2 * pi is Float64
+    T thpi = th + (T)RLHIP_PI;
+    double an = jl_mod((double)thpi, 2.0 * RLHIP_PI) - RLHIP_PI;
+    double costs = an * an + 0.1 * (double)(thdot * thdot) + 0.001 * (double)(a * a);
+    // :105-110  pure T; sin(th + pi) literally
+    T newthdot = thdot + ((T)-3 * p.g / ((T)2 * p.l) * Trig<T>::sin_(thpi) +
+                          (T)3 * a / (p.m * (p.l * p.l))) *
+                             p.dt;
+    th = th + newthdot * p.dt;                                 // :111
+    newthdot = clampT(newthdot, -p.max_speed, p.max_speed);    // :112
+    e.s[0] = th;
+    e.s[1] = newthdot;
+    done = e.t >= p.max_steps;  // :115
+    reward = (T)(-costs);       // :116
+}
+
+template <typename T>
+__device__ __forceinline__ void env_obs1(const PendulumParams<T>&, const LaneState<T>& e, T o[4]) {
+    Trig<T>::sincos_(e.s[0], &o[0], &o[1]);  // :70  [sin(th), cos(th), thdot]
+    o[2] = e.s[1];
+}
+
+// ------------------------------------------------------------------------------ MountainCar --
+template <typename T>
+struct MountainCarParams {  // MountainCarEnvParams{T}  RLEnvs/MountainCarEnv.jl:3-12
+    T min_pos, max_pos, max_speed, goal_pos, goal_velocity, power, gravity;
+    int32_t max_steps;
+    int32_t continuous;
+    static constexpr int SDIM = 2;
+    static constexpr int ODIM = 2;
+    static constexpr int KIND = RLHIP_ENV_MOUNTAINCAR;
+    typedef rlhip_mountaincar_cfg cfg_t;
+    static MountainCarParams make(const rlhip_mountaincar_cfg& c) {
+        MountainCarParams p;
+        p.min_pos = (T)c.min_pos;
+        p.max_pos = (T)c.max_pos;
+        p.max_speed = (T)c.max_speed;
+        p.goal_pos = (T)c.goal_pos;
+        p.goal_velocity = (T)c.goal_velocity;
+        p.power = (T)c.power;
+        p.gravity = (T)c.gravity;
+        p.max_steps = (int32_t)c.max_steps;
+        p.continuous = c.continuous;
+        return p;
+    }
+    bool is_continuous() const { return continuous != 0; }
+};
+
+// reset!  :99-105   x = 0.2 * rand(T) - 0.6 (Float64 arithmetic), v = 0
+template <typename T>
+__device__ __forceinline__ void env_reset1(const MountainCarParams<T>&, LaneState<T>& e, uint64_t seed,
+                                           uint32_t id) {
+    T u[2];
+    ResetDraw<T>::draw2(seed, id, e.episode, u);
+    e.s[0] = (T)(0.2 * (double)u[0] - 0.6);
+    e.s[1] = (T)0;
+    e.t = 0;
+    e.episode += 1;
+}
+
+// act! + _step!  :107-135, reward :95
+template <typename T>
+__device__ __forceinline__ void env_step1(const MountainCarParams<T>& p, LaneState<T>& e, int32_t ai,
+                                          T af, T& reward, bool& done) {
+    T force = p.continuous ? af : (T)(ai - 1);  // :117  a - 2 with the 1-based a
+    e.t += 1;                                   // :120
+    T x = e.s[0], v = e.s[1];
+    v = v + (force * p.power + Trig<T>::cos_((T)3 * x) * (-p.gravity));  // :122
+    v = clampT(v, -p.max_speed, p.max_speed);                            // :123
+    x = x + v;                                                           // :124
+    x = clampT(x, p.min_pos, p.max_pos);                                 // :125
+    if (x == p.min_pos && v < (T)0) v = (T)0;                            // :126-128
+    done = (x >= p.goal_pos && v >= p.goal_velocity) || e.t >= p.max_steps;  // :129-131
+    e.s[0] = x;
+    e.s[1] = v;
+    reward = done ? (T)0 : (T)-1;  // :95
+}
+
+template <typename T>
+__device__ __forceinline__ void env_obs1(const MountainCarParams<T>&, const LaneState<T>& e, T o[4]) {
+    o[0] = e.s[0];
+    o[1] = e.s[1];
+}
+
+// device-pointer view of rlhip_env_state
+template <typename T>
+struct EnvArrays {
+    T* s[4];
+    int32_t* t;
+    uint8_t* done;
+    T* reward;
+    uint32_t* episode;
+    static EnvArrays from(const rlhip_env_state& st) {
+        EnvArrays a;
+        for (int k = 0; k < 4; ++k) a.s[k] = (T*)st.s[k];
+        a.t = st.t;
+        a.done = st.done;
+        a.reward = (T*)st.reward;
+        a.episode = st.episode;
+        return a;
+    }
+};
+
+}  // namespace rlhip

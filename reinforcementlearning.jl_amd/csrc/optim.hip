@@ -1,0 +1,390 @@
+// optim.hip -- flat-buffer parameter-update and loss primitives.
+//
+// Replaces:
+//   TargetNetwork sync (Polyak / hard copy)   RLCore/policies/learners/target_network.jl:76-85
+//   clip_by_global_norm! / global_norm        RLCore/utils/basic.jl:19-29
+//   Flux.Optimise.update!(opt_state, model, grad) with Optimisers.Adam   flux_approximator.jl:46
+//   normlogpdf / diagnormlogpdf               RLCore/utils/distributions.jl:18-21, :31-34
+//   Flux.Losses.huber_loss, DQN TD target     (removed Zoo learner)
+//
+// All HBM-bound element-wise / reduction kernels: Adam 28 B/param, Polyak 12 B/param, clip 4-12 B/param.
+// The learners' parameter vectors are tiny (3 k .. 1 M floats), so the hot variant is
+// clip_adam_kernel: ONE single-workgroup launch doing [scale] -> global norm -> clip -> Adam with the
+// gradient held in registers between the norm and the update (one read of g instead of three).
+#include "common.h"
+
+namespace rlhip {
+
+constexpr float LOG2PI_F = 1.8378770664093453f;  // log(2f0 * pi) rounded to Float32 (distributions.jl:9)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-wide sum (result valid in every thread); scratch: >= 16 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    int nw = (blockDim.x + 63) >> 6;
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += scratch[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                     int64_t n, float rho) {
+    float om = 1.0f - rho;  // (1 - rho)  target_network.jl:81
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = rho * dst[i] + om * src[i];
+}
+
+// stage 1 of the general (large n) global norm: per-block partial sums of squares (Float64 partials)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n,
+                                                            double* __restrict__ partials) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float x = g[i];
+        acc += (double)x * (double)x;
+    }
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// stage 2: gn = sqrt(sum); scale = clip_norm <= gn ? clip_norm / max(clip_norm, gn) : 1   (:23-26)
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const double* __restrict__ partials, int np,
+                                                            float clip_norm, float* __restrict__ gn_out,
+                                                            float* __restrict__ scale_out) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) acc += partials[i];
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        float gn = (float)sqrt(acc);
+        gn_out[0] = gn;
+        scale_out[0] = (clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_const_kernel(float* __restrict__ g, int64_t n, float s) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= s;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ g, int64_t n,
+                                                       const float* __restrict__ scale) {
+    float s = scale[0];
+    if (s == 1.0f) return;  // not clipped: the reference leaves g untouched
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= s;
+}
+
+// Optimisers.Adam: mt = b1*mt + (1-b1)*dx; vt = b2*vt + (1-b2)*dx^2;
+//                  dx' = mt / (1 - b1^t) / (sqrt(vt / (1 - b2^t)) + eps) * eta;  x -= dx'
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float b1, float b2,
+                                      float eps, float c1, float c2) {
+    float mi = b1 * m + (1.0f - b1) * g;
+    float vi = b2 * v + (1.0f - b2) * (g * g);
+    m = mi;
+    v = vi;
+    float d = mi / c1 / (sqrtf(vi / c2) + eps) * lr;
+    p = p - d;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ beta_pow, int64_t n, float lr,
+                                                   float b1, float b2, float eps) {
+    float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam1(pi, g[i], mi, vi, lr, b1, b2, eps, c1, c2);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void beta_pow_advance_kernel(float* beta_pow, float b1, float b2) {
+    beta_pow[0] *= b1;  // bt = bt .* b
+    beta_pow[1] *= b2;
+}
+
+// Single-workgroup fused [grad_scale] -> global norm -> clip -> Adam.  Each thread keeps up to
+// PER_THREAD gradient values in registers between the norm and the update.
+template <int PER_THREAD>
+__global__ __launch_bounds__(1024) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ beta_pow, int64_t n,
+                                                         float grad_scale, float clip_norm, float lr,
+                                                         float b1, float b2, float eps,
+                                                         float* __restrict__ gn_out) {
+    __shared__ double scratch[16];
+    float gr[PER_THREAD];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        int64_t i = (int64_t)k * blockDim.x + threadIdx.x;
+        float x = (i < n) ? g[i] * grad_scale : 0.0f;
+        gr[k] = x;
+        acc += (double)x * (double)x;
+    }
+    float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    acc = block_sum(acc, scratch);
+    float gn = (float)sqrt(acc);
+    float scale = (clip_norm > 0.0f && clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        int64_t i = (int64_t)k * blockDim.x + threadIdx.x;
+        if (i < n) {
+            float gi = (scale == 1.0f) ? gr[k] : gr[k] * scale;
+            float pi = p[i], mi = m[i], vi = v[i];
+            adam1(pi, gi, mi, vi, lr, b1, b2, eps, c1, c2);
+            p[i] = pi;
+            m[i] = mi;
+            v[i] = vi;
+            g[i] = gi;  // the clipped gradient stays observable, like gs[p] .*= ... in the reference
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (gn_out) gn_out[0] = gn;
+        beta_pow[0] *= b1;  // every thread has read beta_pow before the block_sum barrier
+        beta_pow[1] *= b2;
+    }
+}
+
+__global__ __launch_bounds__(256) void normlogpdf_kernel(const float* __restrict__ mu,
+                                                         const float* __restrict__ sigma,
+                                                         const float* __restrict__ x, float* __restrict__ out,
+                                                         int64_t n) {
+    const float eps = 1.0e-8f;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float se = sigma[i] + eps;
+        float z = (x[i] - mu[i]) / se;                        // :19
+        out[i] = -(z * z + LOG2PI_F) / 2.0f - logf(se);       // :20
+    }
+}
+
+__global__ __launch_bounds__(256) void diagnormlogpdf_kernel(const float* __restrict__ mu,
+                                                             const float* __restrict__ sigma,
+                                                             const float* __restrict__ x, int64_t d,
+                                                             int64_t n, float* __restrict__ out) {
+    const float eps = 1.0e-8f;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float prod = 1.0f, sum = 0.0f;
+    for (int64_t k = 0; k < d; ++k) {
+        float s = sigma[i * d + k] + eps;
+        float vv = s * s;                                      // :32
+        float dx = x[i * d + k] - mu[i * d + k];
+        prod *= vv;
+        sum += (dx * dx) / vv;
+    }
+    out[i] = -0.5f * (logf(prod) + sum + (float)d * LOG2PI_F);  // :33
+}
+
+// huber: per-block partial sums (Float64) + optional dL/dq
+__global__ __launch_bounds__(256) void huber_partial_kernel(const float* __restrict__ q,
+                                                            const float* __restrict__ target, int64_t n,
+                                                            float delta, float* __restrict__ dq,
+                                                            double* __restrict__ partials) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    float inv_n = 1.0f / (float)n;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float d = q[i] - target[i];
+        float e = fabsf(d);
+        float l = (e < delta) ? (e * e) * 0.5f : delta * (e - 0.5f * delta);
+        acc += (double)l;
+        if (dq) {
+            float gi = (e < delta) ? d : (d > 0.0f ? delta : (d < 0.0f ? -delta : 0.0f));
+            dq[i] = gi / (float)n;
+        }
+    }
+    (void)inv_n;
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void mean_finalize_kernel(const double* __restrict__ partials, int np,
+                                                            int64_t n, float* __restrict__ out) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) acc += partials[i];
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) out[0] = (float)(acc / (double)n);
+}
+
+__global__ __launch_bounds__(256) void td_target_kernel(const float* __restrict__ qt, int64_t na, int64_t n,
+                                                        int64_t ks, int64_t is, const float* __restrict__ r,
+                                                        const uint8_t* __restrict__ term, float gamma,
+                                                        float* __restrict__ target) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* qp = qt + i * is;
+    float mx = qp[0];
+    for (int64_t k = 1; k < na; ++k) {
+        float x = qp[k * ks];
+        if (x > mx) mx = x;
+    }
+    float cont = term[i] ? 0.0f : 1.0f;
+    target[i] = r[i] + gamma * cont * mx;
+}
+
+// Small persistent scratch for the multi-launch reductions (per stream use is serialized by the
+// stream itself; one scratch per device is enough because every user enqueues on a single stream
+// per device in this library's usage; callers that need concurrency pass disjoint streams at
+// their own risk -- documented in DESIGN.md).
+struct Scratch {
+    double* partials = nullptr;  // 1024 doubles
+    float* scalars = nullptr;    // 4 floats
+    int device = -1;
+};
+static Scratch g_scratch[16];
+
+static int32_t get_scratch(Scratch** out) {
+    int dev = 0;
+    RLHIP_CHECK_HIP(hipGetDevice(&dev));
+    RLHIP_REQUIRE(dev >= 0 && dev < 16, "device index out of range");
+    Scratch& s = g_scratch[dev];
+    if (s.device != dev) {
+        RLHIP_CHECK_HIP(hipMalloc((void**)&s.partials, 1024 * sizeof(double)));
+        RLHIP_CHECK_HIP(hipMalloc((void**)&s.scalars, 4 * sizeof(float)));
+        s.device = dev;
+    }
+    *out = &s;
+    return RLHIP_OK;
+}
+
+}  // namespace rlhip
+
+using namespace rlhip;
+
+extern "C" {
+
+int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(dst != nullptr && src != nullptr && n >= 0, "bad arguments");
+    RLHIP_REQUIRE(rho >= 0.0f && rho <= 1.0f, "rho must be in [0,1] (AssertionError in the reference, target_network.jl:50)");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, src, n,
+                       rho);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_clip_by_global_norm_f32(float* grad, int64_t n, float clip_norm, float* gn_out,
+                                      rlhip_stream_t stream) {
+    RLHIP_REQUIRE(grad != nullptr && gn_out != nullptr && n >= 0, "bad arguments");
+    Scratch* sc;
+    int32_t rc = get_scratch(&sc);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    int nb = grid_for(n > 0 ? n : 1, 256, 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grad, n, sc->partials);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, s, sc->partials, nb, clip_norm, gn_out,
+                       sc->scalars);
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n > 0 ? n : 1, 256)), dim3(256), 0, s, grad, n,
+                       sc->scalars);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, float* beta_pow, int64_t n,
+                       float lr, float beta1, float beta2, float eps, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(params && grad && m && v && beta_pow && n >= 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (n > 0)
+        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, params, grad, m, v, beta_pow,
+                           n, lr, beta1, beta2, eps);
+    hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow, int64_t n,
+                            float grad_scale, float clip_norm, float lr, float beta1, float beta2,
+                            float eps, float* gn_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(params && grad && m && v && beta_pow && n >= 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    int64_t per = (n + 1023) / 1024;
+    if (per > 64) {
+        // large parameter vectors: grid-wide kernels (scale -> norm -> clip -> Adam)
+        Scratch* sc;
+        int32_t rc = get_scratch(&sc);
+        if (rc) return rc;
+        if (grad_scale != 1.0f)
+            hipLaunchKernelGGL(scale_const_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, grad, n, grad_scale);
+        float* gn = gn_out ? gn_out : sc->scalars + 2;
+        if (clip_norm > 0.0f) {
+            rc = rlhip_clip_by_global_norm_f32(grad, n, clip_norm, gn, stream);
+            if (rc) return rc;
+        }
+        return rlhip_adam_f32(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, stream);
+    }
+#define LAUNCH_CA(PT)                                                                                  \
+    hipLaunchKernelGGL((clip_adam_kernel<PT>), dim3(1), dim3(1024), 0, s, params, grad, m, v, beta_pow, n, \
+                       grad_scale, clip_norm, lr, beta1, beta2, eps, gn_out)
+    if (per <= 4) LAUNCH_CA(4);
+    else if (per <= 16) LAUNCH_CA(16);
+    else LAUNCH_CA(64);
+#undef LAUNCH_CA
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_normlogpdf_f32(const float* mu, const float* sigma, const float* x, float* out, int64_t n,
+                             rlhip_stream_t stream) {
+    RLHIP_REQUIRE(mu && sigma && x && out && n >= 0, "bad arguments");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(normlogpdf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), mu, sigma,
+                       x, out, n);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_diagnormlogpdf_f32(const float* mu, const float* sigma, const float* x, int64_t d, int64_t n,
+                                 float* out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(mu && sigma && x && out && n >= 0 && d >= 1, "bad arguments");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(diagnormlogpdf_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       mu, sigma, x, d, n, out);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_huber_f32(const float* q, const float* target, int64_t n, float delta, float* loss_out,
+                        float* dq, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(q && target && loss_out && n >= 1, "bad arguments");
+    Scratch* sc;
+    int32_t rc = get_scratch(&sc);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    int nb = grid_for(n, 256, 1024);
+    hipLaunchKernelGGL(huber_partial_kernel, dim3(nb), dim3(256), 0, s, q, target, n, delta, dq, sc->partials);
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, s, sc->partials, nb, n, loss_out);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_td_target_f32(const float* qt_next, int64_t na, int64_t n, int64_t k_stride, int64_t i_stride,
+                            const float* reward, const uint8_t* terminal, float gamma, float* target,
+                            rlhip_stream_t stream) {
+    RLHIP_REQUIRE(qt_next && reward && terminal && target && na >= 1 && n >= 0, "bad arguments");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(td_target_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream), qt_next,
+                       na, n, k_stride, i_stride, reward, terminal, gamma, target);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+}  // extern "C"

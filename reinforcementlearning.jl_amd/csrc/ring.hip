@@ -1,0 +1,263 @@
+// ring.hip -- CircularArraySARTSTraces-style replay ring resident in HBM: batched push + gather.
+//
+// Replaces (un-vendored ReinforcementLearningTrajectories 0.4 / CircularArrayBuffers 0.1.12; call sites
+// RLCore/policies/agent/agent_base.jl:45-59, docs/src/How_to_implement_a_new_algorithm.md:70-74,90-112):
+//   push!(trajectory, (state = s,))                         -> rlhip_ring_push_state
+//   push!(trajectory, (state = s', action, reward, terminal)) -> rlhip_ring_push_transition
+//   BatchSampler: inds = rand(rng, 1:length, batchsize)      -> rlhip_ring_sample_indices
+//   traces[inds] (`for batch in trajectory`)                 -> rlhip_ring_gather
+// In the reference the trajectory always lives in host RAM and the gather is a per-sample strided
+// memcpy followed by an H2D copy of the batch; here the ring never leaves HBM.
+//
+// Layout: frame-major SoA.  state[(slot * obs_dim + k) * n_env + e]; action/reward/terminal
+// [slot * n_env + e].  One push = one contiguous frame per trace (coalesced 16 B/lane copies).
+// Gather: the index tile of a workgroup is staged in LDS once (flat index -> physical state slot,
+// next slot, transition slot, env), then
+//   * small observations (CartPole: 4 floats): one lane per (sample, component) pair;
+//   * large contiguous frames (n_env == 1, e.g. 84x84x4 u8 = 28 224 B): one workgroup per sample
+//     streams the two frames with 16 B/lane loads -- the HBM-bandwidth stress of BASELINE config 5.
+// Algorithmic bytes per sample: 2 * (2 * obs_bytes + 9)  (SURVEY.md 8d).
+#include "common.h"
+
+namespace rlhip {
+
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
+                                                     int64_t n16) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void copy1_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                                    int64_t n) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+static int32_t copy_bytes(void* dst, const void* src, int64_t bytes, hipStream_t s) {
+    if (bytes == 0) return RLHIP_OK;
+    if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes) & 15) == 0) {
+        int64_t n16 = bytes / 16;
+        hipLaunchKernelGGL(copy16_kernel, dim3(grid_for(n16, 256)), dim3(256), 0, s, (uint4*)dst,
+                           (const uint4*)src, n16);
+    } else {
+        hipLaunchKernelGGL(copy1_kernel, dim3(grid_for(bytes, 256)), dim3(256), 0, s, (uint8_t*)dst,
+                           (const uint8_t*)src, bytes);
+    }
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+// fused push of the three transition traces (one launch instead of three copies)
+__global__ __launch_bounds__(256) void push_art_kernel(int32_t* __restrict__ a_dst, float* __restrict__ r_dst,
+                                                       uint8_t* __restrict__ t_dst,
+                                                       const int32_t* __restrict__ a, const float* __restrict__ r,
+                                                       const uint8_t* __restrict__ t, int64_t n) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        a_dst[i] = a[i];
+        r_dst[i] = r[i];
+        t_dst[i] = t[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_indices_kernel(int64_t* __restrict__ out, int64_t batch,
+                                                             uint64_t total, uint64_t seed,
+                                                             uint32_t draw_ctr) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    u32x4 w = philox4x32_10(seed, (uint32_t)b, 0, draw_ctr, TAG_SAMPLER);
+    uint64_t x = ((uint64_t)w.x << 32) | (uint64_t)w.y;
+    out[b] = (int64_t)__umul64hi(x, total);
+}
+
+struct RingView {
+    int64_t capacity, n_env, obs_dim, head_sa, head_rt;
+    const void* state;
+    const int32_t* action;
+    const float* reward;
+    const uint8_t* terminal;
+};
+
+constexpr int GATHER_TILE = 256;
+
+// small observations: E = element type (float or uint8_t)
+template <typename E>
+__global__ __launch_bounds__(256) void gather_small_kernel(RingView rb, const int64_t* __restrict__ idx,
+                                                           int64_t batch, E* __restrict__ s,
+                                                           int32_t* __restrict__ a, float* __restrict__ r,
+                                                           uint8_t* __restrict__ term, E* __restrict__ sn) {
+    __shared__ int64_t l_ps[GATHER_TILE], l_pn[GATHER_TILE];
+    int64_t b0 = (int64_t)blockIdx.x * GATHER_TILE;
+    int tile = (int)((batch - b0 < GATHER_TILE) ? (batch - b0) : GATHER_TILE);
+    // stage the index tile: decode each flat index once
+    if ((int)threadIdx.x < tile) {
+        int64_t j = idx[b0 + threadIdx.x];
+        int64_t li = j / rb.n_env, e = j - li * rb.n_env;
+        int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
+        int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
+        int64_t pt = (rb.head_rt + li) % rb.capacity;
+        l_ps[threadIdx.x] = ps * rb.obs_dim * rb.n_env + e;
+        l_pn[threadIdx.x] = pn * rb.obs_dim * rb.n_env + e;
+        int64_t o = pt * rb.n_env + e;
+        a[b0 + threadIdx.x] = rb.action[o];
+        r[b0 + threadIdx.x] = rb.reward[o];
+        term[b0 + threadIdx.x] = rb.terminal[o];
+    }
+    __syncthreads();
+    const E* st = (const E*)rb.state;
+    int64_t work = (int64_t)tile * rb.obs_dim;
+    for (int64_t w = threadIdx.x; w < work; w += blockDim.x) {
+        int64_t k = w / tile;
+        int bl = (int)(w - k * tile);  // consecutive lanes -> consecutive samples: coalesced writes
+        s[k * batch + b0 + bl] = st[l_ps[bl] + k * rb.n_env];
+        sn[k * batch + b0 + bl] = st[l_pn[bl] + k * rb.n_env];
+    }
+}
+
+// large contiguous frames (n_env == 1): one workgroup per sample, 16 B/lane streaming copy.
+// Output layout here is sample-major: s[b * frame_bytes ...] (a frame stays contiguous).
+__global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const int64_t* __restrict__ idx,
+                                                            int64_t batch, int64_t frame_bytes,
+                                                            uint8_t* __restrict__ s, int32_t* __restrict__ a,
+                                                            float* __restrict__ r, uint8_t* __restrict__ term,
+                                                            uint8_t* __restrict__ sn) {
+    __shared__ int64_t l_off[2];
+    int64_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int64_t li = idx[b];
+        int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
+        int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
+        int64_t pt = (rb.head_rt + li) % rb.capacity;
+        l_off[0] = ps * frame_bytes;
+        l_off[1] = pn * frame_bytes;
+        a[b] = rb.action[pt];
+        r[b] = rb.reward[pt];
+        term[b] = rb.terminal[pt];
+    }
+    __syncthreads();
+    const uint4* src0 = (const uint4*)((const uint8_t*)rb.state + l_off[0]);
+    const uint4* src1 = (const uint4*)((const uint8_t*)rb.state + l_off[1]);
+    uint4* d0 = (uint4*)(s + b * frame_bytes);
+    uint4* d1 = (uint4*)(sn + b * frame_bytes);
+    int64_t n16 = frame_bytes / 16;
+    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
+        uint4 x = src0[i];
+        uint4 y = src1[i];
+        d0[i] = x;
+        d1[i] = y;
+    }
+}
+
+static RingView view_of(const rlhip_ring* rb) {
+    return {rb->capacity, rb->n_env, rb->obs_dim, rb->head_sa, rb->head_rt,
+            rb->state,    rb->action, rb->reward, rb->terminal};
+}
+
+static int32_t push_state_frame(rlhip_ring* rb, const void* obs, hipStream_t s) {
+    int64_t frames = rb->capacity + 1;
+    int64_t fbytes = rb->obs_dim * rb->n_env * (int64_t)rb->elem_bytes;
+    int64_t phys;
+    if (rb->len_sa < frames) {
+        phys = (rb->head_sa + rb->len_sa) % frames;
+        rb->len_sa += 1;
+    } else {
+        phys = rb->head_sa;  // overwrite the oldest frame; it becomes the newest
+        rb->head_sa = (rb->head_sa + 1) % frames;
+    }
+    return copy_bytes((uint8_t*)rb->state + phys * fbytes, obs, fbytes, s);
+}
+
+}  // namespace rlhip
+
+using namespace rlhip;
+
+extern "C" {
+
+int32_t rlhip_ring_init(rlhip_ring* rb, int64_t capacity, int64_t n_env, int64_t obs_dim, int32_t elem_bytes,
+                        void* state, int32_t* action, float* reward, uint8_t* terminal) {
+    RLHIP_REQUIRE(rb != nullptr, "ring is NULL");
+    RLHIP_REQUIRE(capacity >= 1 && n_env >= 1 && obs_dim >= 1, "capacity, n_env, obs_dim must be >= 1");
+    RLHIP_REQUIRE(elem_bytes == 4 || elem_bytes == 1, "elem_bytes must be 4 (Float32) or 1 (UInt8)");
+    RLHIP_REQUIRE(state && action && reward && terminal, "trace storage is NULL");
+    rb->capacity = capacity;
+    rb->n_env = n_env;
+    rb->obs_dim = obs_dim;
+    rb->head_sa = rb->len_sa = rb->head_rt = rb->len_rt = 0;
+    rb->elem_bytes = elem_bytes;
+    rb->state = state;
+    rb->action = action;
+    rb->reward = reward;
+    rb->terminal = terminal;
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ring_push_state(rlhip_ring* rb, const void* obs, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb != nullptr && obs != nullptr, "NULL argument");
+    return push_state_frame(rb, obs, as_stream(stream));
+}
+
+int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const int32_t* action,
+                                   const float* reward, const uint8_t* terminal, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && next_obs && action && reward && terminal, "NULL argument");
+    hipStream_t s = as_stream(stream);
+    int64_t frames = rb->capacity, n = rb->n_env, phys;
+    if (rb->len_rt < frames) {
+        phys = (rb->head_rt + rb->len_rt) % frames;
+        rb->len_rt += 1;
+    } else {
+        phys = rb->head_rt;
+        rb->head_rt = (rb->head_rt + 1) % frames;
+    }
+    hipLaunchKernelGGL(push_art_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, rb->action + phys * n,
+                       rb->reward + phys * n, rb->terminal + phys * n, action, reward, terminal, n);
+    RLHIP_LAUNCH_CHECK();
+    return push_state_frame(rb, next_obs, s);
+}
+
+int64_t rlhip_ring_length(const rlhip_ring* rb) { return rb ? rb->len_rt : 0; }
+
+int32_t rlhip_ring_sample_indices(const rlhip_ring* rb, int64_t batch, uint64_t seed, uint32_t draw_ctr,
+                                  int64_t* idx_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && idx_out && batch >= 0, "bad arguments");
+    RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
+    if (batch == 0) return RLHIP_OK;
+    uint64_t total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
+    hipLaunchKernelGGL(sample_indices_kernel, dim3((int)((batch + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), idx_out, batch, total, seed, draw_ctr);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ring_gather_is_frame_major(const rlhip_ring* rb) {
+    if (!rb) return 0;
+    int64_t frame_bytes = rb->obs_dim * (int64_t)rb->elem_bytes;
+    return (rb->n_env == 1 && frame_bytes >= 1024 && (frame_bytes % 16 == 0)) ? 1 : 0;
+}
+
+int32_t rlhip_ring_gather(const rlhip_ring* rb, const int64_t* idx, int64_t batch, void* s, int32_t* a,
+                          float* r, uint8_t* term, void* s_next, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && idx && s && a && r && term && s_next && batch >= 0, "bad arguments");
+    if (batch == 0) return RLHIP_OK;
+    hipStream_t st = as_stream(stream);
+    RingView v = view_of(rb);
+    int64_t frame_bytes = rb->obs_dim * (int64_t)rb->elem_bytes;
+    bool big = rlhip_ring_gather_is_frame_major(rb) != 0;
+    if (big) {
+        RLHIP_REQUIRE(((((uintptr_t)rb->state | (uintptr_t)s | (uintptr_t)s_next) & 15) == 0),
+                      "frame-major gather needs 16-byte aligned buffers");
+        hipLaunchKernelGGL(gather_frames_kernel, dim3((int)batch), dim3(256), 0, st, v, idx, batch, frame_bytes,
+                           (uint8_t*)s, a, r, term, (uint8_t*)s_next);
+    } else {
+        int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
+        if (rb->elem_bytes == 4)
+            hipLaunchKernelGGL((gather_small_kernel<float>), dim3(grid), dim3(256), 0, st, v, idx, batch,
+                               (float*)s, a, r, term, (float*)s_next);
+        else
+            hipLaunchKernelGGL((gather_small_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, v, idx, batch,
+                               (uint8_t*)s, a, r, term, (uint8_t*)s_next);
+    }
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// select_device.h -- per-lane action selection (device inline), shared by the stand-alone selection
+// kernels (select.hip) and the fused plan / rollout kernels (ppo.hip, dqn.hip).
+//
+//   findmax(A)[2]: first maximal index, NaN is maximal (Base.findmax)
+//   findmax_masked: masked-out entries become typemin(T) = -Inf   RLCore/utils/basic.jl:117-118
+//   find_all_max + rand(rng, inds): tie-break variant             RLCore/utils/basic.jl:91-114,
+//                                                                 epsilon_greedy_explorer.jl:102-106,118-123
+//   eps-greedy draw order: u = rand(rng) first; `u >= eps ? greedy : rand(1:n)`   :108-112, :127-131
+//   Gumbel-max categorical                                        RLCore/utils/networks.jl:425-432
+#pragma once
+#include "common.h"
+
+namespace rlhip {
+
+struct StridedValues {
+    const float* p;
+    int64_t ks;
+    __device__ __forceinline__ float operator()(int k) const { return p[(int64_t)k * ks]; }
+};
+struct StridedMask {
+    const uint8_t* p;
+    int64_t ks;
+    __device__ __forceinline__ bool has() const { return p != nullptr; }
+    __device__ __forceinline__ bool operator()(int k) const { return p[(int64_t)k * ks] != 0; }
+};
+struct NoMask {
+    __device__ __forceinline__ bool has() const { return false; }
+    __device__ __forceinline__ bool operator()(int) const { return true; }
+};
+
+template <class V, class M>
+__device__ __forceinline__ int findmax_first(const V& q, const M& mk, int na) {
+    int best = 0;
+    float bv = (mk.has() && !mk(0)) ? -INFINITY : q(0);
+    for (int k = 1; k < na; ++k) {
+        float x = (mk.has() && !mk(k)) ? -INFINITY : q(k);
+        if (bv != bv) break;  // first NaN wins
+        if (x != x || x > bv) {
+            bv = x;
+            best = k;
+        }
+    }
+    return best;
+}
+
+// index (0-based) of the j-th (0-based) legal entry equal to the legal maximum
+template <class V, class M>
+__device__ __forceinline__ int tie_break_pick(const V& q, const M& mk, int na, uint32_t w) {
+    bool have = false;
+    float v = 0.f;
+    for (int k = 0; k < na; ++k) {
+        if (mk.has() && !mk(k)) continue;
+        float x = q(k);
+        if (!have) {
+            v = x;
+            have = true;
+        } else if (v == v && (x != x || x > v)) {
+            v = x;  // maximum propagates NaN
+        }
+    }
+    int c = 0;
+    for (int k = 0; k < na; ++k)
+        if (!(mk.has() && !mk(k)) && q(k) == v) ++c;
+    if (c == 0) return 0;
+    int j = (int)randint32(w, (uint32_t)c);
+    for (int k = 0; k < na; ++k)
+        if (!(mk.has() && !mk(k)) && q(k) == v) {
+            if (j == 0) return k;
+            --j;
+        }
+    return 0;
+}
+
+template <class V, class M>
+__device__ __forceinline__ int32_t eps_greedy_select1(const V& q, const M& mk, int na, double eps,
+                                                      bool is_break_tie, uint64_t seed, uint32_t id,
+                                                      uint32_t step) {
+    u32x4 w = philox4x32_10(seed, id, 0, step, TAG_EXPLORE);
+    double u = u01_f64(w.x, w.y);
+    if (u >= eps) {  // greedy branch
+        return is_break_tie ? tie_break_pick(q, mk, na, w.w) : findmax_first(q, mk, na);
+    }
+    if (mk.has()) {  // rand(rng, findall(mask))
+        int c = 0;
+        for (int k = 0; k < na; ++k) c += mk(k) ? 1 : 0;
+        if (c == 0) return 0;
+        int j = (int)randint32(w.z, (uint32_t)c);
+        for (int k = 0; k < na; ++k)
+            if (mk(k)) {
+                if (j == 0) return k;
+                --j;
+            }
+        return 0;
+    }
+    return (int32_t)randint32(w.z, (uint32_t)na);  // rand(rng, 1:n)
+}
+
+// logsoftmax (NNlib: x - max - log(sum(exp(x - max)))), Float32; Gumbel noise and argmax in Float64
+template <class V, class M>
+__device__ __forceinline__ int32_t categorical_sample1(const V& l, const M& mk, int na, uint64_t seed,
+                                                       uint32_t id, uint32_t step, float* logp_out) {
+    float mx = -INFINITY;
+    for (int k = 0; k < na; ++k) {
+        float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
+        if (x > mx) mx = x;
+    }
+    float se = 0.f;
+    for (int k = 0; k < na; ++k) {
+        float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
+        se += (float)::exp((double)(x - mx));  // Float64 eval, rounded once (libm-independent)
+    }
+    float lse = (float)::log((double)se);
+    int best = 0;
+    double bg = 0.0;
+    float blp = 0.f;
+    u32x4 w = {0, 0, 0, 0};
+    for (int k = 0; k < na; ++k) {
+        if ((k & 1) == 0) w = philox4x32_10(seed, id, (uint32_t)(k >> 1), step, TAG_GUMBEL);
+        double u = (k & 1) ? u01_f64(w.z, w.w) : u01_f64(w.x, w.y);
+        float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
+        float lp = (x - mx) - lse;
+        double g = -::log(-::log(u)) + (double)lp;
+        if (k == 0 || g > bg) {
+            bg = g;
+            best = k;
+            blp = lp;
+        }
+    }
+    *logp_out = blp;
+    return best;
+}
+
+}  // namespace rlhip

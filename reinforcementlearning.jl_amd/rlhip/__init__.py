@@ -1,0 +1,13 @@
+"""rlhip -- host-side mirror of the ReinforcementLearning.jl plugin surface for the MI355X-native
+rollout + learner hot path.  Everything numeric runs in librlhip.so (HIP, gfx950) through the C ABI
+declared in include/rlhip.h; importing this package fails loudly if that library is missing.
+"""
+from . import _lib  # noqa: F401  (raises ImportError when librlhip.so is absent)
+from ._lib import RLHipArgumentError, RLHipError  # noqa: F401
+from .envs import (CartPoleEnv, ContinuousMountainCarEnv, HipVecEnv, MountainCarEnv,  # noqa: F401
+                   PendulumEnv, Space)
+from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
+from .trajectory import (BatchSampler, CircularArraySARTSTraces,  # noqa: F401
+                         InsertSampleRatioController, Trajectory)
+
+ABI_VERSION = _lib.lib.rlhip_abi_version()

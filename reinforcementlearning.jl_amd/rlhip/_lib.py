@@ -1,0 +1,186 @@
+"""ctypes loader for librlhip.so -- the C-ABI boundary (include/rlhip.h).
+
+There is NO fallback: if the HIP library is missing this module raises at import time, and every
+wrapper raises `RLHipError` on a non-zero status.  PyTorch is used by the host layer only for device
+memory (`tensor.data_ptr()`), streams (`torch.cuda.current_stream().cuda_stream`) and
+`torch.distributed`; no torch type ever crosses this boundary.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG, "lib", "librlhip.so")
+
+
+class RLHipError(RuntimeError):
+    pass
+
+
+class RLHipArgumentError(RLHipError, ValueError):
+    """RLHIP_EINVAL -- where the reference would throw AssertionError / ArgumentError / MethodError."""
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"librlhip.so not found at {LIB_PATH}. Build it with "
+        f"`python reinforcementlearning.jl_amd/build.py` (hipcc, gfx950). "
+        "There is no CPU fallback for the rlhip hot path.")
+
+lib = C.CDLL(LIB_PATH)
+
+i32, i64, u32, u64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+f32, f64, vp = C.c_float, C.c_double, C.c_void_p
+
+
+class CartPoleCfg(C.Structure):
+    _fields_ = [(n, f64) for n in ("gravity", "masscart", "masspole", "halflength", "forcemag", "dt",
+                                   "thetathreshold_deg", "xthreshold")] + \
+               [("max_steps", i64), ("continuous", i32)]
+
+
+class PendulumCfg(C.Structure):
+    _fields_ = [(n, f64) for n in ("max_speed", "max_torque", "g", "m", "l", "dt")] + \
+               [("max_steps", i64), ("continuous", i32), ("n_actions", i32)]
+
+
+class MountainCarCfg(C.Structure):
+    _fields_ = [(n, f64) for n in ("min_pos", "max_pos", "max_speed", "goal_pos", "goal_velocity",
+                                   "power", "gravity")] + \
+               [("max_steps", i64), ("continuous", i32)]
+
+
+class EnvState(C.Structure):
+    _fields_ = [("s", vp * 4), ("t", vp), ("done", vp), ("reward", vp), ("episode", vp)]
+
+
+class Ring(C.Structure):
+    _fields_ = [(n, i64) for n in ("capacity", "n_env", "obs_dim", "head_sa", "len_sa", "head_rt",
+                                   "len_rt")] + \
+               [("elem_bytes", i32), ("state", vp), ("action", vp), ("reward", vp), ("terminal", vp)]
+
+
+class PPOCfg(C.Structure):
+    _fields_ = [(n, f32) for n in ("gamma", "lam", "clip_range", "max_grad_norm", "actor_loss_weight",
+                                   "critic_loss_weight", "entropy_loss_weight", "lr", "beta1", "beta2",
+                                   "adam_eps")] + \
+               [(n, i32) for n in ("n_epochs", "n_microbatches", "hidden", "act", "continuous",
+                                   "normalize_advantage")]
+
+
+class PPOTraj(C.Structure):
+    _fields_ = [(n, vp) for n in ("obs", "logp", "value", "reward", "adv", "ret", "action_f",
+                                  "action_i", "terminal")]
+
+
+P = C.POINTER
+
+# name -> (restype, argtypes).  Status-returning functions use restype i32 and are error-checked.
+_PROTOS = {
+    "rlhip_abi_version": (i32, []),
+    "rlhip_last_error": (C.c_char_p, []),
+    "rlhip_device_count": (i32, [P(i32)]),
+    "rlhip_set_device": (i32, [i32]),
+    "rlhip_device_name": (i32, [i32, C.c_char_p, i32]),
+    "rlhip_malloc": (i32, [P(vp), C.c_size_t]),
+    "rlhip_free": (i32, [vp]),
+    "rlhip_memset": (i32, [vp, i32, C.c_size_t, vp]),
+    "rlhip_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),
+    "rlhip_memcpy_d2h": (i32, [vp, vp, C.c_size_t, vp]),
+    "rlhip_memcpy_d2d": (i32, [vp, vp, C.c_size_t, vp]),
+    "rlhip_stream_create": (i32, [P(vp)]),
+    "rlhip_stream_destroy": (i32, [vp]),
+    "rlhip_stream_sync": (i32, [vp]),
+    "rlhip_event_create": (i32, [P(vp)]),
+    "rlhip_event_destroy": (i32, [vp]),
+    "rlhip_event_record": (i32, [vp, vp]),
+    "rlhip_event_elapsed_ms": (i32, [vp, vp, P(f32)]),
+    "rlhip_fill_uniform_f32": (i32, [vp, i64, u64, u32, u32, vp]),
+    "rlhip_permutation": (i32, [vp, u32, u64, u32, vp]),
+    "rlhip_cartpole_default": (i32, [P(CartPoleCfg)]),
+    "rlhip_pendulum_default": (i32, [P(PendulumCfg)]),
+    "rlhip_mountaincar_default": (i32, [P(MountainCarCfg), i32]),
+    "rlhip_env_obs_dim": (i32, [i32]),
+    "rlhip_env_state_dim": (i32, [i32]),
+    "rlhip_env_reset": (i32, [i32, i32, vp, P(EnvState), i64, u64, u32, vp, vp]),
+    "rlhip_env_step": (i32, [i32, i32, vp, P(EnvState), i64, vp, i32, u64, u32, vp, vp, vp]),
+    "rlhip_env_obs": (i32, [i32, i32, P(EnvState), i64, vp, vp]),
+    "rlhip_discount_rewards_f32": (i32, [vp, vp, i64, i64, f32, vp, vp, i32, vp]),
+    "rlhip_discount_rewards_f64": (i32, [vp, vp, i64, i64, f64, vp, vp, i32, vp]),
+    "rlhip_discount_rewards_reduced_f32": (i32, [vp, vp, i64, i64, f32, vp, vp, i32, vp]),
+    "rlhip_discount_rewards_reduced_f64": (i32, [vp, vp, i64, i64, f64, vp, vp, i32, vp]),
+    "rlhip_gae_f32": (i32, [vp, vp, vp, i64, i64, f32, f32, vp, i32, vp]),
+    "rlhip_gae_f64": (i32, [vp, vp, vp, i64, i64, f64, f64, vp, i32, vp]),
+    "rlhip_gae_returns_f32": (i32, [vp, vp, vp, vp, vp, i64, i64, f32, f32, vp]),
+    "rlhip_eps_greedy_select_f32": (i32, [vp, i64, i64, i64, i64, vp, f64, i32, u64, u32, u32, vp, vp]),
+    "rlhip_get_eps": (f64, [i32, f64, f64, i64, i64, i64]),
+    "rlhip_categorical_sample_f32": (i32, [vp, i64, i64, i64, i64, vp, u64, u32, u32, vp, vp, vp]),
+    "rlhip_polyak_f32": (i32, [vp, vp, i64, f32, vp]),
+    "rlhip_clip_by_global_norm_f32": (i32, [vp, i64, f32, vp, vp]),
+    "rlhip_adam_f32": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp]),
+    "rlhip_clip_adam_f32": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp]),
+    "rlhip_normlogpdf_f32": (i32, [vp, vp, vp, vp, i64, vp]),
+    "rlhip_diagnormlogpdf_f32": (i32, [vp, vp, vp, i64, i64, vp, vp]),
+    "rlhip_huber_f32": (i32, [vp, vp, i64, f32, vp, vp, vp]),
+    "rlhip_td_target_f32": (i32, [vp, i64, i64, i64, i64, vp, vp, f32, vp, vp]),
+    "rlhip_ring_init": (i32, [P(Ring), i64, i64, i64, i32, vp, vp, vp, vp]),
+    "rlhip_ring_push_state": (i32, [P(Ring), vp, vp]),
+    "rlhip_ring_push_transition": (i32, [P(Ring), vp, vp, vp, vp, vp]),
+    "rlhip_ring_length": (i64, [P(Ring)]),
+    "rlhip_ring_sample_indices": (i32, [P(Ring), i64, u64, u32, vp, vp]),
+    "rlhip_ring_gather_is_frame_major": (i32, [P(Ring)]),
+    "rlhip_ring_gather": (i32, [P(Ring), vp, i64, vp, vp, vp, vp, vp, vp]),
+    "rlhip_mlp2_nparams": (i64, [i64, i64, i64]),
+    "rlhip_mlp2_forward_f32": (i32, [vp, i64, i64, i64, i32, vp, i64, vp, vp]),
+    "rlhip_mlp2_init_f32": (i32, [vp, i64, i64, i64, u64, u32, vp]),
+    "rlhip_ppo_default": (i32, [P(PPOCfg)]),
+    "rlhip_ppo_nparams": (i64, [i32, P(PPOCfg)]),
+    "rlhip_ppo_plan_f32": (i32, [i32, P(PPOCfg), vp, vp, i64, u64, u32, u32, vp, vp, vp, vp, vp]),
+    "rlhip_ppo_rollout_f32": (i32, [i32, vp, P(EnvState), i64, i64, P(PPOCfg), vp, u64, u32, u32,
+                                    P(PPOTraj), vp]),
+    "rlhip_ppo_gae_f32": (i32, [P(PPOCfg), i64, i64, P(PPOTraj), vp]),
+    "rlhip_ppo_workspace_bytes": (i64, [i32, P(PPOCfg), i64, i64]),
+    "rlhip_ppo_grad_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, i32, vp, vp, vp,
+                                 vp]),
+    "rlhip_ppo_update_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp,
+                                   vp, vp, vp]),
+    "rlhip_dqn_workspace_bytes": (i64, [i64, i64, i64, i64]),
+    "rlhip_dqn_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, i64, f32, f32, u64, u32, vp, vp, vp,
+                                 vp]),
+    "rlhip_dqn_plan_f32": (i32, [vp, i64, i64, i64, i32, vp, i64, f64, u64, u32, u32, vp, vp, vp]),
+}
+
+_STATUS = set()
+for _name, (_res, _args) in _PROTOS.items():
+    _f = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _f.restype = _res
+    _f.argtypes = _args
+    if _res is i32 and _name not in ("rlhip_abi_version", "rlhip_env_obs_dim", "rlhip_env_state_dim",
+                                     "rlhip_ring_gather_is_frame_major"):
+        _STATUS.add(_name)
+
+
+def last_error():
+    return lib.rlhip_last_error().decode("utf-8", "replace")
+
+
+def call(name, *args):
+    """Invoke a status-returning ABI function; raise on error (no silent fallback)."""
+    rc = getattr(lib, name)(*args)
+    if name in _STATUS and rc != 0:
+        msg = f"{name} failed with status {rc}: {last_error()}"
+        if rc == -1:
+            raise RLHipArgumentError(msg)
+        raise RLHipError(msg)
+    return rc
+
+
+def declared_symbols(header_path=None):
+    """Names of all functions declared in include/rlhip.h."""
+    import re
+
+    header_path = header_path or os.path.join(os.path.dirname(_PKG), "include", "rlhip.h")
+    with open(header_path) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rlhip_[a-z0-9_]+)\s*\(", src)))

@@ -1,0 +1,212 @@
+"""QBasedPolicy / DQN learner / explorers / approximators on the vectorised env (host mirror).
+
+Reference surface mirrored here:
+    QBasedPolicy            src/ReinforcementLearningCore/src/policies/q_based_policy.jl:13-49
+    EpsilonGreedyExplorer   .../policies/explorers/epsilon_greedy_explorer.jl:38-131 (GreedyExplorer :200-214)
+    FluxApproximator        .../policies/learners/flux_approximator.jl:11-46
+    TargetNetwork           .../policies/learners/target_network.jl:27-88
+    BasicDQN/DQN learner    removed Zoo; spec docs/src/rlcore.md:28 and the blog config
+                            docs/homepage/blog/a_practical_introduction_to_RL.jl/index.html:15121-15147
+All numerics are HIP kernels behind the C ABI (dqn.hip, select.hip, optim.hip).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call
+from .ops import ptr, stream_ptr
+
+
+# ----------------------------------------------------------------------------- functional layer
+def dqn_workspace(ns, h, na, batch, device="cuda"):
+    nbytes = int(_lib.lib.rlhip_dqn_workspace_bytes(ns, h, na, batch))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def dqn_grad(traces, h, na, act, params, target_params, batch, gamma, delta, seed, draw_ctr, workspace=None,
+             grad=None, loss=None):
+    """One DQN learner step up to the gradient: sample `batch` transitions, TD target, Huber, backward."""
+    dev = params.device
+    workspace = workspace if workspace is not None else dqn_workspace(traces.obs_dim, h, na, batch, dev)
+    grad = grad if grad is not None else torch.empty_like(params)
+    loss = loss if loss is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    call("rlhip_dqn_grad_f32", C.byref(traces.rb), h, na, act, ptr(params), ptr(target_params), batch, gamma,
+         delta, seed, draw_ctr, ptr(workspace), ptr(grad), ptr(loss), stream_ptr())
+    return grad, loss
+
+
+def dqn_plan(params, ns, h, na, act, obs, eps, seed, env_id_base, step, actions=None, q_out=None):
+    """plan!(QBasedPolicy, env): Q forward + eps-greedy for n envs; returns (0-based actions, q (na, n))."""
+    n = obs.shape[1]
+    actions = actions if actions is not None else torch.empty(n, dtype=torch.int32, device=obs.device)
+    q_out = q_out if q_out is not None else torch.empty((na, n), dtype=torch.float32, device=obs.device)
+    call("rlhip_dqn_plan_f32", ptr(params), ns, h, na, act, ptr(obs), n, float(eps), seed, env_id_base, step,
+         ptr(actions), ptr(q_out), stream_ptr())
+    return actions, q_out
+
+
+# ----------------------------------------------------------------------------------- explorers
+class EpsilonGreedyExplorer:
+    """EpsilonGreedyExplorer(; ϵ_stable, kind = :linear, ϵ_init = 1.0, warmup_steps = 0, decay_steps = 0,
+    step = 1, is_break_tie = false, rng) -- epsilon_greedy_explorer.jl:38-67.  One `step` per call, shared
+    by all N lanes of a vector env (the historical `policy(env)` was a single call per vec-step)."""
+
+    def __init__(self, eps_stable, kind="linear", eps_init=1.0, warmup_steps=0, decay_steps=0, step=1,
+                 is_break_tie=False, seed=0):
+        if kind not in ("linear", "exp"):
+            raise ValueError("kind must be 'linear' or 'exp'")
+        self.eps_stable, self.kind, self.eps_init = float(eps_stable), kind, float(eps_init)
+        self.warmup_steps, self.decay_steps, self.step = int(warmup_steps), int(decay_steps), int(step)
+        self.is_break_tie, self.seed = bool(is_break_tie), int(seed)
+
+    def get_eps(self, step=None):
+        """get_ϵ(s[, step])  :69-90"""
+        step = self.step if step is None else step
+        return _lib.lib.rlhip_get_eps(0 if self.kind == "linear" else 1, self.eps_stable, self.eps_init,
+                                      self.warmup_steps, self.decay_steps, step)
+
+    def plan_(self, values, mask=None, env_id_base=0):
+        """plan!(s, values[, mask]) for a (na, N) device tensor of values -> 1-based actions."""
+        from .ops import eps_greedy_select
+
+        eps = self.get_eps()
+        step = self.step
+        self.step += 1  # :104,:110 -- incremented on every call, before the draw
+        a0 = eps_greedy_select(values, eps, self.seed, step, env_id_base, mask, self.is_break_tie)
+        return a0 + 1
+
+
+class GreedyExplorer(EpsilonGreedyExplorer):
+    """GreedyExplorer()  :200-214 -- findmax first-index rule, no randomness."""
+
+    def __init__(self):
+        super().__init__(0.0)
+
+    def get_eps(self, step=None):
+        return 0.0
+
+
+# -------------------------------------------------------------------------------- approximators
+class HipApproximator:
+    """FluxApproximator(model = Chain(Dense(ns, h, act), Dense(h, n_out)), optimiser = Adam(lr)).
+    Flat parameters in Flux.destructure order + Adam state, all in HBM."""
+
+    def __init__(self, n_in, hidden, n_out, act="relu", lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, seed=0,
+                 net_id=0, device="cuda", params=None):
+        self.n_in, self.hidden, self.n_out = n_in, hidden, n_out
+        self.act = {"relu": 0, "tanh": 1}[act] if isinstance(act, str) else int(act)
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        from .ops import mlp2_init
+
+        self.params = mlp2_init(n_in, hidden, n_out, seed, net_id, device) if params is None else \
+            torch.as_tensor(params, dtype=torch.float32, device=device).clone()
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.beta_pow = torch.tensor([beta1, beta2], dtype=torch.float32, device=device)
+        self.gn = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def forward(self, x):
+        """forward(A, x) = A.model(x)  (flux_approximator.jl:43): x (n_in, batch) -> (n_out, batch)."""
+        from .ops import mlp2_forward
+
+        return mlp2_forward(self.params, self.n_in, self.hidden, self.n_out, self.act, x)
+
+    def optimise_(self, grad, clip_norm=0.0, grad_scale=1.0):
+        """optimise!(A, grad) = Flux.Optimise.update!(A.optimiser_state, A.model, grad)  (:46)."""
+        from .ops import clip_adam_
+
+        clip_adam_(self.params, grad, self.m, self.v, self.beta_pow, grad_scale, clip_norm, self.lr, self.beta1,
+                   self.beta2, self.eps, self.gn)
+
+
+class TargetNetwork:
+    """TargetNetwork(network; sync_freq = 1, ρ = 0f0)  target_network.jl:27-60."""
+
+    def __init__(self, network, sync_freq=1, rho=0.0):
+        if not 0 <= rho <= 1:
+            raise AssertionError("ρ must in [0,1]")  # :50
+        self.network, self.sync_freq, self.rho, self.n_optimise = network, int(sync_freq), float(rho), 0
+        self.target = network.params.clone()
+
+    def forward(self, x):
+        return self.network.forward(x)
+
+    def optimise_(self, grad, **kw):
+        """optimise!(tn, grad)  :70-88: update the network, then every sync_freq calls
+        dest = ρ·dest + (1-ρ)·src and reset the counter."""
+        from .ops import polyak_
+
+        self.network.optimise_(grad, **kw)
+        self.n_optimise += 1
+        if self.n_optimise % self.sync_freq == 0:
+            polyak_(self.target, self.network.params, self.rho)
+            self.n_optimise = 0
+
+
+# -------------------------------------------------------------------------------------- learner
+class DQNLearner:
+    """BasicDQN / DQN learner on a device trajectory: every `update_freq` vec-steps (once
+    `min_replay_history` transitions are stored) sample a batch, TD target with the target network,
+    Huber loss, gradient, [all-reduce], Adam, target sync."""
+
+    def __init__(self, approximator, batchsize=32, gamma=0.99, huber_delta=1.0, min_replay_history=100,
+                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None):
+        self.approximator = approximator  # a TargetNetwork
+        net = approximator.network
+        self.batchsize, self.gamma, self.delta = batchsize, gamma, huber_delta
+        self.min_replay_history, self.update_freq, self.max_grad_norm = min_replay_history, update_freq, max_grad_norm
+        self.seed, self.draw_ctr, self.n_updates = seed, 0, 0
+        self.process_group = process_group
+        self.grad = torch.zeros_like(net.params)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=net.params.device)
+        self.workspace = dqn_workspace(net.n_in, net.hidden, net.n_out, batchsize, net.params.device)
+
+    def forward(self, x):
+        return self.approximator.forward(x)
+
+    def optimise_(self, trajectory):
+        traces = trajectory.container
+        if traces.n_transitions() < self.min_replay_history:
+            return False
+        net = self.approximator.network
+        dqn_grad(traces, net.hidden, net.n_out, net.act, net.params, self.approximator.target, self.batchsize,
+                 self.gamma, self.delta, self.seed, self.draw_ctr, self.workspace, self.grad, self.loss)
+        self.draw_ctr += 1
+        scale = 1.0
+        if self.process_group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(self.process_group)
+            if world > 1:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+                scale = 1.0 / world
+        self.approximator.optimise_(self.grad, clip_norm=self.max_grad_norm, grad_scale=scale)
+        self.n_updates += 1
+        return True
+
+
+class QBasedPolicy:
+    """QBasedPolicy(; learner, explorer)  q_based_policy.jl:13-49.  plan! on the vector env is one fused
+    launch (Q forward + eps-greedy)."""
+
+    def __init__(self, learner, explorer):
+        self.learner, self.explorer = learner, explorer
+        self._actions = None
+        self._q = None
+
+    def plan_(self, env):
+        net = self.learner.approximator.network
+        ex = self.explorer
+        if ex.is_break_tie:  # tie-break variant: unfused path (forward, then the selection kernel)
+            return ex.plan_(net.forward(env.state()), env_id_base=env.env_id_base)
+        eps = ex.get_eps()
+        step = ex.step
+        ex.step += 1
+        self._actions, self._q = dqn_plan(net.params, net.n_in, net.hidden, net.n_out, net.act, env.state(), eps,
+                                          ex.seed, env.env_id_base, step, self._actions, self._q)
+        return self._actions + 1
+
+    def optimise_(self, trajectory):
+        """optimise!(policy, stage, trajectory) -> optimise!(learner, stage, trajectory)  (:49)."""
+        return self.learner.optimise_(trajectory)

@@ -1,0 +1,239 @@
+"""HipVecEnv -- the vectorised classic-control environment behind the reference's AbstractEnv surface.
+
+Mirrors, for N instances at once (the role the historical `MultiThreadEnv` played, blog
+docs/homepage/blog/an_introduction_to_reinforcement_learning_jl_design_implementations_thoughts/index.md:347-376):
+
+    CartPoleEnv      src/ReinforcementLearningEnvironments/src/environments/examples/CartPoleEnv.jl
+    PendulumEnv      .../PendulumEnv.jl
+    MountainCarEnv   .../MountainCarEnv.jl
+
+API names follow RLBase/src/interface.jl with Julia's `!` spelled as a trailing underscore:
+`reset_`, `act_`, `state`, `reward`, `is_terminated`, `action_space`, `state_space`, `seed_`, `copy`.
+Julia is 1-based: discrete actions here are 1..na exactly like the reference (`act_` takes 1-based
+actions, the C ABI below is 0-based; the shift happens in this glue, as the Julia glue would do).
+
+All state lives in HBM as SoA arrays (one wavefront lane per env instance); `state(env)` returns a
+device tensor view -- "may be reused and mutated at each step; copy if needed" like the reference
+(RLBase/src/interface.jl:515-517).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call
+from .ops import ptr, stream_ptr
+
+KIND = {"cartpole": 0, "pendulum": 1, "mountaincar": 2}
+
+
+def _make_cfg(kind, continuous, kw):
+    if kind == 0:
+        cfg = _lib.CartPoleCfg()
+        call("rlhip_cartpole_default", C.byref(cfg))
+        cfg.continuous = int(bool(continuous))
+    elif kind == 1:
+        cfg = _lib.PendulumCfg()
+        call("rlhip_pendulum_default", C.byref(cfg))
+        cfg.continuous = int(bool(continuous))
+    else:
+        cfg = _lib.MountainCarCfg()
+        call("rlhip_mountaincar_default", C.byref(cfg), int(bool(continuous)))
+    rename = {"thetathreshold": "thetathreshold_deg"}
+    for k, v in kw.items():
+        k = rename.get(k, k)
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown keyword argument {k}")  # MethodError in the reference
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Space:
+    """Minimal descriptor of action_space / state_space: closed interval box or 1..n."""
+
+    def __init__(self, lo=None, hi=None, n=None):
+        self.lo, self.hi, self.n = lo, hi, n
+
+    def __contains__(self, x):
+        if self.n is not None:
+            x = torch.as_tensor(x)
+            return bool(((x >= 1) & (x <= self.n)).all())
+        x = torch.as_tensor(x, dtype=torch.float64).reshape(len(self.lo), -1)
+        lo = torch.tensor(self.lo, dtype=torch.float64).reshape(-1, 1)
+        hi = torch.tensor(self.hi, dtype=torch.float64).reshape(-1, 1)
+        return bool(((x.cpu() >= lo) & (x.cpu() <= hi)).all())
+
+    def __len__(self):
+        return self.n if self.n is not None else len(self.lo)
+
+    def __repr__(self):
+        return f"Base.OneTo({self.n})" if self.n is not None else f"Box({self.lo}, {self.hi})"
+
+
+class HipVecEnv:
+    """N independent instances of one classic-control env stepped by HIP kernels.
+
+    auto_reset=True is the MultiThreadEnv protocol: after `act_`, `reward(env)` / `is_terminated(env)`
+    describe the step just taken while `state(env)` of a terminated instance is already the first
+    state of its next episode.  auto_reset=False gives the scalar-env semantics (caller resets).
+    """
+
+    def __init__(self, kind, n_envs=1, T=torch.float32, continuous=None, seed=0, env_id_base=0,
+                 auto_reset=True, device="cuda", validate_actions=False, **kwargs):
+        self.kind = KIND[kind] if isinstance(kind, str) else int(kind)
+        self.name = {0: "CartPoleEnv", 1: "PendulumEnv", 2: "MountainCarEnv"}[self.kind]
+        if T not in (torch.float32, torch.float64):
+            raise TypeError("T must be torch.float32 or torch.float64")
+        self.T = T
+        self.is_f64 = int(T == torch.float64)
+        self.n = int(n_envs)
+        if continuous is None:
+            continuous = self.kind == 1  # PendulumEnv defaults to continuous = true
+        self.continuous = bool(continuous)
+        self.cfg = _make_cfg(self.kind, self.continuous, kwargs)
+        self.seed = int(seed)
+        self.env_id_base = int(env_id_base)
+        self.auto_reset = bool(auto_reset)
+        self.validate_actions = validate_actions
+        self.device = torch.device(device)
+        self.sdim = int(_lib.lib.rlhip_env_state_dim(self.kind))
+        self.odim = int(_lib.lib.rlhip_env_obs_dim(self.kind))
+        n = self.n
+        self._s = torch.zeros((self.sdim, n), dtype=T, device=self.device)
+        self._t = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._reward = torch.zeros(n, dtype=T, device=self.device)
+        self._episode = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._obs = torch.zeros((self.odim, n), dtype=T, device=self.device)
+        self._last_obs = torch.zeros((self.odim, n), dtype=T, device=self.device)
+        self._st = _lib.EnvState()
+        for k in range(self.sdim):
+            self._st.s[k] = self._s[k].data_ptr()
+        self._st.t = self._t.data_ptr()
+        self._st.done = self._done.data_ptr()
+        self._st.reward = self._reward.data_ptr()
+        self._st.episode = self._episode.data_ptr()
+        self._obs_valid = False
+        self.reset_(is_force=True)  # the constructors call reset! once (CartPoleEnv.jl:77)
+
+    # ------------------------------------------------------------------ RLBase env API
+    def reset_(self, is_force=True):
+        """reset!(env).  is_force=False resets only the terminated instances (MultiThreadEnv.reset!)."""
+        mask = None if is_force else self._done
+        call("rlhip_env_reset", self.kind, self.is_f64, C.byref(self.cfg), C.byref(self._st), self.n,
+             self.seed, self.env_id_base, ptr(mask), stream_ptr())
+        self._obs_valid = False
+
+    def act_(self, actions):
+        """act!(env, actions): actions is a length-N device tensor (1-based ints, or T for continuous)."""
+        if self.continuous:
+            a = actions.to(self.T) if actions.dtype != self.T else actions
+            if self.validate_actions:
+                lim = self.cfg.max_torque if self.kind == 1 else 1.0
+                if not bool(((a >= -lim) & (a <= lim)).all()):
+                    raise AssertionError("a in action_space(env)")  # @assert in act!
+        else:
+            if self.validate_actions and actions not in self.action_space():
+                raise AssertionError("a in action_space(env)")
+            a = (actions - 1).to(torch.int32)  # 1-based -> 0-based ABI
+        self.act0_(a.contiguous())
+
+    def act0_(self, actions0):
+        """ABI-level act!: 0-based int32 (discrete) or T (continuous) device tensor, no checks."""
+        call("rlhip_env_step", self.kind, self.is_f64, C.byref(self.cfg), C.byref(self._st), self.n,
+             ptr(actions0), int(self.auto_reset), self.seed, self.env_id_base, ptr(self._last_obs),
+             ptr(self._obs), stream_ptr())
+        self._obs_valid = True
+
+    def state(self):
+        """state(env): (obs_dim, N) device tensor (component-major)."""
+        if not self._obs_valid:
+            call("rlhip_env_obs", self.kind, self.is_f64, C.byref(self._st), self.n, ptr(self._obs),
+                 stream_ptr())
+            self._obs_valid = True
+        return self._obs
+
+    def last_state(self):
+        """Observation produced by the last act! BEFORE any auto-reset (the terminal observation)."""
+        return self._last_obs
+
+    def reward(self):
+        return self._reward
+
+    def is_terminated(self):
+        return self._done.view(torch.bool)
+
+    def action_space(self):
+        if self.continuous:
+            lim = self.cfg.max_torque if self.kind == 1 else 1.0
+            return Space([-lim], [lim])
+        return Space(n=self.cfg.n_actions if self.kind == 1 else (2 if self.kind == 0 else 3))
+
+    def state_space(self):
+        inf = math.inf
+        c = self.cfg
+        if self.kind == 0:  # CartPoleEnv.jl:88-93
+            th = c.thetathreshold_deg * math.pi / 180
+            return Space([-2 * c.xthreshold, -inf, -2 * th, -inf], [2 * c.xthreshold, inf, 2 * th, inf])
+        if self.kind == 1:  # PendulumEnv.jl:75-79
+            return Space([-1.0, -1.0, -c.max_speed], [1.0, 1.0, c.max_speed])
+        return Space([c.min_pos, -c.max_speed], [c.max_pos, c.max_speed])  # MountainCarEnv.jl:83-86
+
+    def seed_(self, seed):
+        """Random.seed!(env, seed): re-keys the Philox streams and restarts the episode counters."""
+        self.seed = int(seed)
+        self._episode.zero_()
+
+    def copy(self):
+        """copy(env): deep copy, same seed and counters -> identical future under identical actions."""
+        other = object.__new__(HipVecEnv)
+        other.__dict__.update(self.__dict__)
+        for name in ("_s", "_t", "_done", "_reward", "_episode", "_obs", "_last_obs"):
+            setattr(other, name, getattr(self, name).clone())
+        kw = {f: getattr(self.cfg, f) for f, _ in self.cfg._fields_}
+        other.cfg = type(self.cfg)(**kw)
+        other._st = _lib.EnvState()
+        for k in range(self.sdim):
+            other._st.s[k] = other._s[k].data_ptr()
+        other._st.t = other._t.data_ptr()
+        other._st.done = other._done.data_ptr()
+        other._st.reward = other._reward.data_ptr()
+        other._st.episode = other._episode.data_ptr()
+        return other
+
+    def __len__(self):
+        return self.n
+
+    # ------------------------------------------------------------------ low-level access
+    def raw_state(self):
+        """(state_dim, N) internal state (theta is NOT an observation for Pendulum)."""
+        return self._s
+
+    def set_raw_state(self, s, t=None):
+        self._s.copy_(torch.as_tensor(s, dtype=self.T, device=self.device))
+        if t is not None:
+            self._t.copy_(torch.as_tensor(t, dtype=torch.int32, device=self.device))
+        self._obs_valid = False
+
+
+def CartPoleEnv(n_envs=1, **kw):
+    """CartPoleEnv(; T, continuous, gravity, masscart, masspole, halflength, forcemag, max_steps, dt,
+    thetathreshold, xthreshold)  (CartPoleEnv.jl:57-79) x n_envs."""
+    return HipVecEnv("cartpole", n_envs, **kw)
+
+
+def PendulumEnv(n_envs=1, **kw):
+    """PendulumEnv(; T, max_speed, max_torque, g, m, l, dt, max_steps, continuous, n_actions)
+    (PendulumEnv.jl:24-66) x n_envs."""
+    return HipVecEnv("pendulum", n_envs, **kw)
+
+
+def MountainCarEnv(n_envs=1, **kw):
+    """MountainCarEnv(; T, continuous, min_pos, max_pos, max_speed, goal_pos, max_steps, goal_velocity,
+    power, gravity)  (MountainCarEnv.jl:51-81) x n_envs."""
+    return HipVecEnv("mountaincar", n_envs, **kw)
+
+
+def ContinuousMountainCarEnv(n_envs=1, **kw):
+    return HipVecEnv("mountaincar", n_envs, continuous=True, **kw)

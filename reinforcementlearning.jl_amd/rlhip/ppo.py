@@ -1,0 +1,199 @@
+"""PPOPolicy on the vectorised env -- host mirror of the (removed) Zoo `PPOPolicy` + `PPOTrajectory`.
+
+Reference pointers: hyper-parameters and network shapes
+docs/homepage/blog/a_practical_introduction_to_RL.jl/index.html:15257-15287; the vector-env run loop
+docs/homepage/blog/an_introduction_to_reinforcement_learning_jl_design_implementations_thoughts/index.md:351-374;
+`ActorCritic` RLCore/src/utils/networks.jl:15-20; GAE RLCore/src/utils/basic.jl:334-417;
+clip_by_global_norm! :19-29; `optimise!(::FluxApproximator, grad)` flux_approximator.jl:46.
+
+Everything numeric is a HIP kernel behind the C ABI (ppo.hip / scans.hip / optim.hip); this class owns
+device buffers (torch) and counters, and -- for multi-GPU -- inserts the RCCL all-reduce of the flat
+gradient between the gradient kernel and the clip+Adam kernel.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call
+from .ops import ptr, stream_ptr
+
+
+def make_ppo_cfg(**kw):
+    cfg = _lib.PPOCfg()
+    call("rlhip_ppo_default", C.byref(cfg))
+    rename = {"lambda_": "lam", "λ": "lam", "γ": "gamma", "update_freq": None}
+    for k, v in kw.items():
+        k = rename.get(k, k)
+        if k is None:
+            continue
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown PPOPolicy keyword {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+class PPOTrajectory:
+    """PPOTrajectory(; capacity = T, state = (ns, N), action = (N,), action_log_prob = (N,), reward = (N,),
+    terminal = (N,)) (blog index.html:15280-15286), time-major SoA in HBM, plus value / advantage /
+    return traces that the reference recomputes at update time."""
+
+    def __init__(self, ns, n, T, continuous=False, device="cuda"):
+        dev = torch.device(device)
+        f = torch.float32
+        self.ns, self.n, self.T, self.continuous = ns, n, T, continuous
+        self.obs = torch.zeros((T + 1, ns, n), dtype=f, device=dev)
+        self.logp = torch.zeros((T, n), dtype=f, device=dev)
+        self.value = torch.zeros((T + 1, n), dtype=f, device=dev)
+        self.reward = torch.zeros((T, n), dtype=f, device=dev)
+        self.adv = torch.zeros((T, n), dtype=f, device=dev)
+        self.ret = torch.zeros((T, n), dtype=f, device=dev)
+        self.action_f = torch.zeros((T, 1, n), dtype=f, device=dev)
+        self.action_i = torch.zeros((T, n), dtype=torch.int32, device=dev)
+        self.terminal = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+        self.c = _lib.PPOTraj()
+        for name in ("obs", "logp", "value", "reward", "adv", "ret", "action_f", "action_i", "terminal"):
+            setattr(self.c, name, getattr(self, name).data_ptr())
+
+    @property
+    def action(self):
+        """1-based actions like the reference's trace (discrete), raw actions (continuous)."""
+        return self.action_f[:, 0, :] if self.continuous else self.action_i + 1
+
+
+class PPOPolicy:
+    """PPOPolicy(approximator = ActorCritic(actor = ns->hidden->na, critic = ns->hidden->1, Adam(lr)), ...)."""
+
+    def __init__(self, env, update_freq=32, seed=None, params=None, process_group=None, **kw):
+        self.env = env
+        self.kind = env.kind
+        self.cfg = make_ppo_cfg(continuous=int(env.continuous), **kw)
+        self.T = int(update_freq)
+        self.seed = env.seed if seed is None else int(seed)
+        dev = env.device
+        self.np = int(_lib.lib.rlhip_ppo_nparams(self.kind, C.byref(self.cfg)))
+        if self.np <= 0:
+            raise _lib.RLHipArgumentError(_lib.last_error())
+        ns = env.odim
+        self.na = 1 if env.continuous else len(env.action_space())
+        nout_a = 2 * self.na if env.continuous else self.na
+        self.np_actor = int(_lib.lib.rlhip_mlp2_nparams(ns, self.cfg.hidden, nout_a))
+        if params is None:
+            self.params = torch.empty(self.np, dtype=torch.float32, device=dev)
+            # glorot_uniform(rng) stand-in: actor net_id 0, critic net_id 1 (Philox INIT stream)
+            call("rlhip_mlp2_init_f32", ptr(self.params), ns, self.cfg.hidden, nout_a, self.seed, 0, stream_ptr())
+            call("rlhip_mlp2_init_f32", C.c_void_p(self.params.data_ptr() + 4 * self.np_actor), ns,
+                 self.cfg.hidden, 1, self.seed, 1, stream_ptr())
+        else:
+            self.params = torch.as_tensor(params, dtype=torch.float32, device=dev).clone().contiguous()
+            assert self.params.numel() == self.np
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.beta_pow = torch.tensor([self.cfg.beta1, self.cfg.beta2], dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.params)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.gn = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.trajectory = PPOTrajectory(ns, env.n, self.T, env.continuous, dev)
+        ws = int(_lib.lib.rlhip_ppo_workspace_bytes(self.kind, C.byref(self.cfg), env.n, self.T))
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.vec_step = 0      # global vec-step counter (Philox t of the sampling streams)
+        self.update_ctr = 0    # number of update_ calls so far
+        self.n_pushed = 0      # per-step protocol: vec-steps pushed since the last update
+        self.process_group = process_group
+        self._a_i = torch.zeros(env.n, dtype=torch.int32, device=dev)
+        self._a_f = torch.zeros(env.n, dtype=torch.float32, device=dev)
+        self._logp = torch.zeros(env.n, dtype=torch.float32, device=dev)
+        self._value = torch.zeros(env.n, dtype=torch.float32, device=dev)
+
+    # ----------------------------------------------------------------- per-step protocol (drop-in)
+    def plan_(self, env=None):
+        """plan!(policy, env): returns the action tensor (1-based ints for discrete envs)."""
+        env = env or self.env
+        obs = env.state()
+        call("rlhip_ppo_plan_f32", self.kind, C.byref(self.cfg), ptr(self.params), ptr(obs), env.n, self.seed,
+             env.env_id_base, self.vec_step, ptr(self._a_i), ptr(self._a_f), ptr(self._logp), ptr(self._value),
+             stream_ptr())
+        return self._a_f if env.continuous else self._a_i + 1
+
+    def push_preact_(self, env=None):
+        """PreActStage push: state, action, action_log_prob (+ value) of the step about to be taken."""
+        env = env or self.env
+        t = self.n_pushed
+        tr = self.trajectory
+        tr.obs[t].copy_(env.state())
+        tr.value[t].copy_(self._value)
+        tr.logp[t].copy_(self._logp)
+        if env.continuous:
+            tr.action_f[t, 0].copy_(self._a_f)
+        else:
+            tr.action_i[t].copy_(self._a_i)
+
+    def push_postact_(self, env=None):
+        """PostActStage push: reward, terminal."""
+        env = env or self.env
+        t = self.n_pushed
+        tr = self.trajectory
+        tr.reward[t].copy_(env.reward())
+        tr.terminal[t].copy_(env._done)
+        self.n_pushed += 1
+        self.vec_step += 1
+
+    def finish_rollout_(self, env=None):
+        """Bootstrap state/value after the last pushed step (the reference pushes state T+1 lazily)."""
+        env = env or self.env
+        self.plan_(env)  # fills self._value for the current state; draws are not consumed (same step redrawn)
+        self.trajectory.obs[self.T].copy_(env.state())
+        self.trajectory.value[self.T].copy_(self._value)
+        self.n_pushed = 0
+
+    # ----------------------------------------------------------------- fused protocol
+    def rollout_(self, env=None):
+        """T vec-steps of plan!/push!/act!/push! in ONE kernel launch."""
+        env = env or self.env
+        call("rlhip_ppo_rollout_f32", self.kind, C.byref(env.cfg), C.byref(env._st), env.n, self.T,
+             C.byref(self.cfg), ptr(self.params), self.seed, env.env_id_base, self.vec_step,
+             C.byref(self.trajectory.c), stream_ptr())
+        env._obs_valid = False
+        self.vec_step += self.T
+
+    def gae_(self):
+        call("rlhip_ppo_gae_f32", C.byref(self.cfg), self.trajectory.n, self.T, C.byref(self.trajectory.c),
+             stream_ptr())
+
+    def grad_(self, epoch_ctr, mb):
+        call("rlhip_ppo_grad_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
+             C.byref(self.trajectory.c), ptr(self.params), self.seed, epoch_ctr, mb, ptr(self.workspace),
+             ptr(self.grad), ptr(self.losses), stream_ptr())
+
+    def apply_(self, grad_scale=1.0):
+        call("rlhip_clip_adam_f32", ptr(self.params), ptr(self.grad), ptr(self.m), ptr(self.v), ptr(self.beta_pow),
+             self.np, grad_scale, self.cfg.max_grad_norm, self.cfg.lr, self.cfg.beta1, self.cfg.beta2,
+             self.cfg.adam_eps, ptr(self.gn), stream_ptr())
+
+    def update_(self):
+        """optimise!(policy): GAE, then n_epochs x n_microbatches of grad -> [all-reduce] -> clip -> Adam."""
+        self.gae_()
+        world = 1
+        if self.process_group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(self.process_group)
+        if world == 1:
+            call("rlhip_ppo_update_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
+                 C.byref(self.trajectory.c), ptr(self.params), ptr(self.m), ptr(self.v), ptr(self.beta_pow),
+                 self.seed, self.update_ctr, ptr(self.workspace), ptr(self.grad), ptr(self.losses), stream_ptr())
+        else:
+            import torch.distributed as dist
+
+            for e in range(self.cfg.n_epochs):
+                epoch_ctr = self.update_ctr * self.cfg.n_epochs + e
+                for mb in range(self.cfg.n_microbatches):
+                    self.grad_(epoch_ctr, mb)
+                    # gradient all-reduce BEFORE the global-norm clip, so the clip sees the global
+                    # gradient (mean over shards == single-GPU semantics with a world-times larger batch)
+                    dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+                    self.apply_(grad_scale=1.0 / world)
+        self.update_ctr += 1
+
+    def n_updates_per_call(self):
+        return self.cfg.n_epochs * self.cfg.n_microbatches

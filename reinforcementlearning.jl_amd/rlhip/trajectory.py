@@ -1,0 +1,125 @@
+"""Trajectory / CircularArraySARTSTraces / BatchSampler / InsertSampleRatioController -- host mirror of
+the un-vendored ReinforcementLearningTrajectories 0.4 surface the reference re-exports
+(src/ReinforcementLearningCore/src/ReinforcementLearningCore.jl:10), with the storage in HBM.
+
+Constructor forms follow the in-tree call sites: RLCore/test/policies/q_based_policy.jl:41-47,
+docs/src/How_to_implement_a_new_algorithm.md:90-112.  Push protocol: RLCore/src/policies/agent/agent_base.jl:45-59.
+The ring arithmetic itself is ring.hip behind the C ABI; head/length counters are host integers.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call
+from .ops import ptr, stream_ptr
+
+
+class CircularArraySARTSTraces:
+    """CircularArraySARTSTraces(; capacity, state = T => (obs_dim, n_env), action = Int => (n_env,),
+    reward = Float32 => (n_env,), terminal = Bool => (n_env,)).  One frame = one vec-step."""
+
+    def __init__(self, capacity, n_env=1, obs_dim=1, dtype=torch.float32, device="cuda"):
+        if dtype not in (torch.float32, torch.uint8):
+            raise TypeError("state eltype must be Float32 or UInt8")
+        dev = torch.device(device)
+        self.capacity, self.n_env, self.obs_dim, self.dtype = capacity, n_env, obs_dim, dtype
+        self.state = torch.zeros((capacity + 1, obs_dim, n_env), dtype=dtype, device=dev)
+        self.action = torch.zeros((capacity, n_env), dtype=torch.int32, device=dev)
+        self.reward = torch.zeros((capacity, n_env), dtype=torch.float32, device=dev)
+        self.terminal = torch.zeros((capacity, n_env), dtype=torch.uint8, device=dev)
+        self.rb = _lib.Ring()
+        call("rlhip_ring_init", C.byref(self.rb), capacity, n_env, obs_dim, 4 if dtype == torch.float32 else 1,
+             ptr(self.state), ptr(self.action), ptr(self.reward), ptr(self.terminal))
+        self.frame_major = bool(_lib.lib.rlhip_ring_gather_is_frame_major(C.byref(self.rb)))
+
+    def push_state_(self, obs):
+        """push!(traces, (state = s,))"""
+        call("rlhip_ring_push_state", C.byref(self.rb), ptr(obs), stream_ptr())
+
+    def push_transition_(self, next_obs, action0, reward, terminal):
+        """push!(traces, (state = s', action = a, reward = r, terminal = t)); action0 is 0-based int32."""
+        if terminal.dtype == torch.bool:
+            terminal = terminal.view(torch.uint8)
+        call("rlhip_ring_push_transition", C.byref(self.rb), ptr(next_obs), ptr(action0), ptr(reward),
+             ptr(terminal), stream_ptr())
+
+    def __len__(self):
+        return int(_lib.lib.rlhip_ring_length(C.byref(self.rb)))
+
+    def n_transitions(self):
+        return len(self) * self.n_env
+
+    def sample_indices(self, batch, seed, draw_ctr):
+        idx = torch.empty(batch, dtype=torch.int64, device=self.state.device)
+        call("rlhip_ring_sample_indices", C.byref(self.rb), batch, seed, draw_ctr, ptr(idx), stream_ptr())
+        return idx
+
+    def gather(self, idx):
+        """traces[inds] -> (state, action0, reward, terminal, next_state)."""
+        b = idx.numel()
+        dev = self.state.device
+        shape = (b, self.obs_dim) if self.frame_major else (self.obs_dim, b)
+        s = torch.empty(shape, dtype=self.dtype, device=dev)
+        sn = torch.empty(shape, dtype=self.dtype, device=dev)
+        a = torch.empty(b, dtype=torch.int32, device=dev)
+        r = torch.empty(b, dtype=torch.float32, device=dev)
+        t = torch.empty(b, dtype=torch.uint8, device=dev)
+        call("rlhip_ring_gather", C.byref(self.rb), ptr(idx), b, ptr(s), ptr(a), ptr(r), ptr(t), ptr(sn),
+             stream_ptr())
+        return s, a, r, t, sn
+
+
+class BatchSampler:
+    """BatchSampler(batchsize; rng): uniform indices with replacement (Philox SAMPLER stream)."""
+
+    def __init__(self, batchsize, seed=0):
+        self.batchsize, self.seed, self.draw_ctr = batchsize, seed, 0
+
+    def sample(self, traces):
+        idx = traces.sample_indices(self.batchsize, self.seed, self.draw_ctr)
+        self.draw_ctr += 1
+        s, a, r, t, sn = traces.gather(idx)
+        return dict(state=s, action=a + 1, reward=r, terminal=t.view(torch.bool), next_state=sn, key=idx)
+
+
+class InsertSampleRatioController:
+    """InsertSampleRatioController(ratio, threshold; n_inserted = 0, n_sampled = 0): sampling is allowed
+    once n_inserted >= threshold and while n_sampled <= (n_inserted - threshold) * ratio
+    (docs/src/How_to_implement_a_new_algorithm.md:108)."""
+
+    def __init__(self, ratio=1.0, threshold=1, n_inserted=0, n_sampled=0):
+        self.ratio, self.threshold, self.n_inserted, self.n_sampled = ratio, threshold, n_inserted, n_sampled
+
+    def on_insert_(self, n=1):
+        self.n_inserted += n
+
+    def on_sample_(self):
+        if self.n_inserted >= self.threshold and self.n_sampled <= (self.n_inserted - self.threshold) * self.ratio:
+            self.n_sampled += 1
+            return True
+        return False
+
+
+class Trajectory:
+    """Trajectory(container, sampler, controller): `push_` inserts, iteration yields sampled batches while
+    the controller allows (the `for batch in trajectory` protocol, RLCore/src/policies/learners/td_learner.jl:85-92)."""
+
+    def __init__(self, container, sampler=None, controller=None):
+        self.container = container
+        self.sampler = sampler or BatchSampler(32)
+        self.controller = controller or InsertSampleRatioController()
+
+    def push_state_(self, obs):
+        self.container.push_state_(obs)
+
+    def push_transition_(self, next_obs, action0, reward, terminal):
+        self.container.push_transition_(next_obs, action0, reward, terminal)
+        self.controller.on_insert_(1)
+
+    def __len__(self):
+        return len(self.container)
+
+    def __iter__(self):
+        while len(self.container) > 0 and self.controller.on_sample_():
+            yield self.sampler.sample(self.container)

@@ -1,0 +1,291 @@
+"""GPU parity tests of the learner path (policy forward + sampling, fused rollout, PPO / DQN loss and
+gradient, update loop) through the C ABI, against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import oracle  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rl():
+    import rlhip
+
+    return rlhip
+
+
+def dev(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def make_pair(rl, kind, n, T, seed=3, continuous=None, hidden=256, **kw):
+    """(gpu env, gpu policy, oracle env, oracle cfg) with identical seeds / params."""
+    env = rl.HipVecEnv(kind, n, seed=seed, continuous=continuous)
+    pol = rl.PPOPolicy(env, update_freq=T, hidden=hidden, **kw)
+    oenv = oracle.VecEnv(kind, n, seed=seed, continuous=env.continuous)
+    ocfg = oracle.ppo_default(continuous=int(env.continuous), hidden=hidden,
+                              **{("lam" if k == "lam" else k): v for k, v in kw.items()})
+    return env, pol, oenv, ocfg
+
+
+@pytest.mark.parametrize("kind,continuous,hidden", [("cartpole", False, 256), ("cartpole", False, 128),
+                                                    ("mountaincar", False, 64), ("pendulum", True, 256),
+                                                    ("cartpole", False, 96)])
+def test_policy_init_and_plan_vs_oracle(rl, kind, continuous, hidden):
+    n = 2048
+    env, pol, oenv, ocfg = make_pair(rl, kind, n, 8, continuous=continuous, hidden=hidden)
+    ns, na = env.odim, pol.na
+    nout = 2 * na if continuous else na
+    # identical initial parameters (Philox INIT stream)
+    pa = oracle.mlp2_init(ns, hidden, nout, pol.seed, 0)
+    pc = oracle.mlp2_init(ns, hidden, 1, pol.seed, 1)
+    assert np.array_equal(host(pol.params), np.concatenate([pa, pc]))
+    assert pol.np == oracle.ppo_nparams(env.kind, ocfg)
+    # perturb so that biases are non-zero
+    rng = np.random.default_rng(0)
+    p = (host(pol.params) + rng.standard_normal(pol.np) * 0.05).astype(np.float32)
+    pol.params.copy_(dev(p))
+    a = host(pol.plan_())
+    obs = host(env.state())
+    out = oracle.mlp2_forward(p[: pa.size], ns, hidden, nout, 0, obs)
+    val = oracle.mlp2_forward(p[pa.size:], ns, hidden, 1, 0, obs)[0]
+    np.testing.assert_allclose(host(pol._value), val, rtol=2e-5, atol=2e-6)
+    if not continuous:
+        oa, olp = oracle.categorical_sample(out, seed=pol.seed, step=0)
+        agree = (a - 1 == oa).mean()
+        assert agree > 0.999, f"only {agree:.5f} of the sampled actions agree"
+        same = a - 1 == oa
+        np.testing.assert_allclose(host(pol._logp)[same], olp[same], rtol=2e-5, atol=2e-6)
+    else:
+        # z = mu + sigma * noise; logp = normlogpdf
+        mu, ls = out[0], out[1]
+        lp = np.array([oracle.normlogpdf(float(m), float(np.exp(np.float32(s))), float(z))
+                       for m, s, z in zip(mu[:200], ls[:200], a[:200])], np.float32)
+        np.testing.assert_allclose(host(pol._logp)[:200], lp, rtol=1e-4, atol=1e-5)
+        noise = (a - mu) / np.exp(ls)
+        assert abs(noise.mean()) < 0.1 and abs(noise.std() - 1) < 0.1
+
+
+@pytest.mark.parametrize("kind,continuous,hidden", [("cartpole", False, 256), ("pendulum", True, 256),
+                                                    ("mountaincar", False, 128), ("cartpole", False, 96)])
+def test_rollout_fused_equals_stepwise_bit_exact(rl, kind, continuous, hidden):
+    """One launch for T vec-steps must reproduce the per-step plan!/push!/act!/push! protocol exactly."""
+    n, T = 1000, 12
+    envA, polA, _, _ = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden)
+    envB, polB, _, _ = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden)
+    for it in range(2):  # two consecutive update periods (counters carry over)
+        polA.rollout_()
+        for t in range(T):
+            a = polB.plan_()
+            polB.push_preact_()
+            envB.act_(a)
+            polB.push_postact_()
+        polB.finish_rollout_()
+        ta, tb = polA.trajectory, polB.trajectory
+        for name in ("obs", "logp", "value", "reward", "terminal"):
+            assert torch.equal(getattr(ta, name), getattr(tb, name)), f"{name} differs (period {it})"
+        assert torch.equal(ta.action, tb.action)
+        assert torch.equal(envA.raw_state(), envB.raw_state())
+        assert torch.equal(envA._t, envB._t) and torch.equal(envA._episode, envB._episode)
+        assert polA.vec_step == polB.vec_step == (it + 1) * T
+
+
+@pytest.mark.parametrize("kind,continuous", [("cartpole", False), ("mountaincar", False), ("pendulum", True)])
+def test_rollout_vs_oracle(rl, kind, continuous):
+    """Free-running comparison with the CPU restatement of the whole rollout: integer traces identical,
+    Float32 traces within 1e-5 (the MLP sums are evaluated in a different order on the GPU)."""
+    n, T = 512, 24
+    env, pol, oenv, ocfg = make_pair(rl, kind, n, T, continuous=continuous)
+    p = host(pol.params)
+    pol.rollout_()
+    otr = oracle.PPOTraj(env.kind, n, T, na=1, continuous=continuous)
+    oracle.ppo_rollout(oenv, T, ocfg, p, otr, 0)
+    tr = pol.trajectory
+    if not continuous:
+        same = host(tr.action_i) == otr.action_i
+        assert same.mean() > 0.999
+        if not same.all():
+            pytest.skip("a near-tie flipped one sampled action; trajectories legitimately diverge after it")
+        assert np.array_equal(host(tr.terminal), otr.terminal)
+        assert np.array_equal(host(tr.reward), otr.reward)
+        tol = dict(rtol=1e-5, atol=1e-6)
+    else:
+        tol = dict(rtol=2e-3, atol=2e-3)  # continuous actions differ in the last bits -> mild drift over T steps
+        np.testing.assert_allclose(host(tr.action_f), otr.action_f, **tol)
+        assert np.array_equal(host(tr.terminal), otr.terminal)
+    np.testing.assert_allclose(host(tr.obs), otr.obs, **tol)
+    np.testing.assert_allclose(host(tr.logp), otr.logp, rtol=1e-3, atol=1e-4 if continuous else 1e-5)
+    np.testing.assert_allclose(host(tr.value), otr.value, **tol)
+    # GAE + returns on the GPU trajectory: bit-exact vs the oracle scan on the same inputs
+    pol.gae_()
+    o = oracle.generalized_advantage_estimation(host(tr.reward).T, host(tr.value).T, 0.99, 0.95,
+                                                terminal=host(tr.terminal).T, dims=2, dtype=np.float32)
+    assert np.array_equal(host(tr.adv), o.T)
+    assert np.array_equal(host(tr.ret), (o.T + host(tr.value)[:T]).astype(np.float32))
+
+
+def _oracle_microbatch(pol, tr, epoch_ctr, mb):
+    n, T = tr.n, tr.T
+    total = n * T
+    bm = total // pol.cfg.n_microbatches
+    perm = np.array([oracle.permute(pol.seed, epoch_ctr, total, mb * bm + b) for b in range(bm)])
+    t, i = perm // n, perm % n
+    obs = host(tr.obs)[t, :, i].T.copy()  # (ns, bm)
+    flat = lambda x: host(x).reshape(-1)[perm]  # noqa: E731
+    act = host(tr.action_f)[t, 0, i] if tr.continuous else host(tr.action_i).reshape(-1)[perm]
+    return obs, act, flat(tr.logp), flat(tr.adv), flat(tr.ret), perm
+
+
+@pytest.mark.parametrize("kind,continuous,hidden,act", [("cartpole", False, 256, 0), ("cartpole", False, 64, 1),
+                                                        ("pendulum", True, 256, 0), ("mountaincar", False, 128, 0)])
+def test_ppo_loss_and_gradient_vs_oracle(rl, kind, continuous, hidden, act):
+    n, T = 256, 16  # micro-batch of 1024 samples, 16 tiles
+    env, pol, oenv, ocfg = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden, act=act)
+    rng = np.random.default_rng(1)
+    p = (host(pol.params) + rng.standard_normal(pol.np) * 0.05).astype(np.float32)
+    pol.params.copy_(dev(p))
+    pol.rollout_()
+    pol.gae_()
+    # move the policy away from the behaviour policy so that ratios leave the clip range
+    p2 = (p + rng.standard_normal(pol.np) * 0.02).astype(np.float32)
+    pol.params.copy_(dev(p2))
+    tr = pol.trajectory
+    for epoch_ctr, mb in ((0, 0), (0, 3), (5, 1)):
+        pol.grad_(epoch_ctr, mb)
+        obs, a, lp, adv, ret, perm = _oracle_microbatch(pol, tr, epoch_ctr, mb)
+        g, losses = oracle.ppo_loss_grad(ocfg, env.odim, pol.na, p2, obs, a, lp, adv, ret)
+        gg = host(pol.grad)
+        scale = np.abs(g).max()
+        np.testing.assert_allclose(gg, g, rtol=2e-3, atol=2e-5 * scale)
+        np.testing.assert_allclose(host(pol.losses), losses, rtol=1e-4, atol=1e-6)
+    # a permutation epoch covers every transition exactly once
+    allidx = np.concatenate([_oracle_microbatch(pol, tr, 7, mb)[5] for mb in range(pol.cfg.n_microbatches)])
+    assert np.array_equal(np.sort(allidx), np.arange(n * T))
+
+
+def test_ppo_ragged_microbatch(rl):
+    """n*T not divisible by the tile size / micro-batch count: partial tiles contribute nothing extra."""
+    n, T = 100, 7  # 700 transitions, 3 micro-batches of 233 (1 dropped), 233 = 3 tiles + 41
+    env, pol, oenv, ocfg = make_pair(rl, "cartpole", n, T, n_microbatches=3)
+    ocfg.n_microbatches = 3
+    pol.rollout_()
+    pol.gae_()
+    tr = pol.trajectory
+    pol.grad_(2, 2)
+    obs, a, lp, adv, ret, _ = _oracle_microbatch(pol, tr, 2, 2)
+    g, losses = oracle.ppo_loss_grad(ocfg, 4, 2, host(pol.params), obs, a, lp, adv, ret)
+    np.testing.assert_allclose(host(pol.grad), g, rtol=2e-3, atol=2e-5 * np.abs(g).max())
+    np.testing.assert_allclose(host(pol.losses), losses, rtol=1e-4, atol=1e-6)
+
+
+def test_ppo_update_equals_manual_sequence_and_tracks_oracle(rl):
+    n, T = 256, 16
+    envA, polA, oenv, ocfg = make_pair(rl, "cartpole", n, T)
+    envB, polB, _, _ = make_pair(rl, "cartpole", n, T)
+    polA.rollout_()
+    polB.rollout_()
+    p0 = host(polA.params).copy()
+    polA.update_()  # the single enqueue-everything entry point
+    polB.gae_()
+    for e in range(polB.cfg.n_epochs):  # the multi-GPU style sequence: grad -> (all-reduce) -> clip+Adam
+        for mb in range(polB.cfg.n_microbatches):
+            polB.grad_(e, mb)
+            polB.apply_(1.0)
+    polB.update_ctr += 1
+    assert torch.equal(polA.params, polB.params)
+    assert torch.equal(polA.m, polB.m) and torch.equal(polA.v, polB.v) and torch.equal(polA.beta_pow, polB.beta_pow)
+    # oracle: same trajectory (copied from the GPU), same update loop on the CPU
+    tr = polA.trajectory
+    otr = oracle.PPOTraj(0, n, T)
+    for name in ("obs", "logp", "value", "reward", "action_i", "terminal"):
+        getattr(otr, name)[...] = host(getattr(tr, name))
+    oracle.ppo_gae(ocfg, otr)
+    assert np.array_equal(otr.adv, host(tr.adv))
+    po, mo, vo = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    steps, _ = oracle.ppo_update(0, ocfg, otr, po, mo, vo, 0, polA.seed, 0)
+    assert steps == 16
+    d = np.abs(host(polA.params) - po)
+    moved = np.abs(po - p0)
+    # Adam normalises the step to ~lr per parameter, so parameters whose gradient is a near-cancelling
+    # sum may differ by O(lr); the bulk must agree tightly.
+    assert np.quantile(d, 0.99) < 2e-4, f"99th percentile |dp| = {np.quantile(d, 0.99):.2e}"
+    assert d.max() < 16 * 2 * 1e-3
+    assert moved.max() > 1e-3  # something was learned at all
+
+
+def test_ppo_learns_cartpole(rl):
+    """End-to-end sanity of the whole GPU path: mean episode length rises within a few dozen updates."""
+    n, T = 1024, 32
+    env = rl.HipVecEnv("cartpole", n, seed=1)
+    pol = rl.PPOPolicy(env, update_freq=T, lr=3e-3)
+    first = None
+    for it in range(40):
+        pol.rollout_()
+        pol.update_()
+        ep_len = (n * T) / max(1.0, float(pol.trajectory.terminal.sum()))
+        if it == 0:
+            first = ep_len
+    assert ep_len > 2.0 * first, f"episode length {first:.1f} -> {ep_len:.1f}"
+
+
+# ------------------------------------------------------------------------------------------ DQN
+def _fill_ring(rl, n_env, capacity, seed=0):
+    from rlhip.trajectory import CircularArraySARTSTraces
+
+    rng = np.random.default_rng(seed)
+    tr = CircularArraySARTSTraces(capacity=capacity, n_env=n_env, obs_dim=4)
+    ref = oracle.Ring(capacity, n_env, 4)
+    o = rng.standard_normal((4, n_env)).astype(np.float32)
+    tr.push_state_(dev(o))
+    ref.push_state(o)
+    for _ in range(capacity + 3):
+        o = rng.standard_normal((4, n_env)).astype(np.float32)
+        a = rng.integers(0, 2, n_env).astype(np.int32)
+        r = rng.standard_normal(n_env).astype(np.float32)
+        t = (rng.random(n_env) < 0.1).astype(np.uint8)
+        tr.push_transition_(dev(o), dev(a), dev(r), dev(t))
+        ref.push_transition(o, a, r, t)
+    return tr, ref
+
+
+@pytest.mark.parametrize("h,batch", [(128, 32), (128, 512), (256, 4096), (64, 100)])
+def test_dqn_gradient_vs_oracle(rl, h, batch):
+    from rlhip.dqn import dqn_grad
+
+    tr, ref = _fill_ring(rl, 64, 9)
+    rng = np.random.default_rng(2)
+    ns, na = 4, 2
+    p = (oracle.mlp2_init(ns, h, na, 5, 0) + rng.standard_normal(oracle.mlp2_nparams(ns, h, na)) * 0.1).astype(np.float32)
+    pt = (p + rng.standard_normal(p.size) * 0.05).astype(np.float32)
+    grad, loss = dqn_grad(tr, h, na, 0, dev(p), dev(pt), batch, 0.99, 1.0, seed=11, draw_ctr=4)
+    idx = ref.sample_indices(batch, 11, 4)
+    s, a, r, t, sn = ref.gather(idx)
+    ol, og = oracle.dqn_loss_grad(ns, h, na, 0, p, pt, s, a, r, t, sn, 0.99, 1.0)
+    assert float(loss) == pytest.approx(ol, rel=1e-4)
+    np.testing.assert_allclose(host(grad), og, rtol=2e-3, atol=2e-5 * np.abs(og).max())
+
+
+@pytest.mark.parametrize("h", [128, 100])
+def test_dqn_plan_vs_oracle(rl, h):
+    from rlhip.dqn import dqn_plan
+
+    rng = np.random.default_rng(3)
+    n, ns, na = 4096, 4, 2
+    p = (oracle.mlp2_init(ns, h, na, 5, 0) + rng.standard_normal(oracle.mlp2_nparams(ns, h, na)) * 0.1).astype(np.float32)
+    obs = rng.standard_normal((ns, n)).astype(np.float32)
+    for eps in (0.0, 0.3):
+        a, q = dqn_plan(dev(p), ns, h, na, 0, dev(obs), eps, seed=8, env_id_base=100, step=42)
+        oq = oracle.mlp2_forward(p, ns, h, na, 0, obs)
+        np.testing.assert_allclose(host(q), oq, rtol=2e-5, atol=2e-6)
+        # integer selection is bit-exact given the same Q-values and the same Philox draws
+        oa = oracle.eps_greedy_select(host(q), eps, seed=8, step=42, env_id_base=100)
+        assert np.array_equal(host(a), oa)
