@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s + learner updates/s of the 4096-env CartPole PPO hot path on N x MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one PPO iteration of the hot path on every GPU: fused rollout of T = 32 vec-steps of 4096
+CartPole envs (actor/critic forward, Gumbel-max sampling, env step + auto-reset, trajectory writes),
+GAE + returns, then 4 epochs x 4 micro-batches of { clipped-surrogate loss + gradient ->
+[RCCL all-reduce of the flat gradient when N > 1] -> clip_by_global_norm -> Adam }.  Nothing is
+skipped inside the timed region; inputs (env state, parameters) are resident in HBM when it starts.
+Workload = BASELINE.json configs[3] per GPU (the config the metric is quoted on; configs[1] is its
+DQN sibling and is measured in the `extra` block), synthetic data: random-init weights, Philox-seeded
+env states.  Weak scaling: 4096 envs per GPU, env ids / Philox streams disjoint across ranks.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the HBM-bound env-step kernel at the operating point where HBM matters (2^24 envs),
+                achieved = 49 algorithmic bytes x envs / mean launch time (HIP events on the launch stream)
+  cpu_baseline  the CPU oracle ("port") running the same PPO iteration on a bounded sample, 1 core
+  kernels       mean per-launch time of every kernel class of the timed workload (HIP events)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "reinforcementlearning.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N_ENVS = 4096
+T_ROLLOUT = 32
+HIDDEN = 256
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+CARTPOLE_STEP_BYTES = 49     # 24 B read + 25 B written per env-step
+
+
+def event_time_ms(fn, iters, lib, stream):
+    """mean milliseconds per call of fn(), measured with HIP events on `stream`."""
+    from rlhip._lib import call
+
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    call("rlhip_event_create", C.byref(e0))
+    call("rlhip_event_create", C.byref(e1))
+    call("rlhip_event_record", e0, stream)
+    for _ in range(iters):
+        fn()
+    call("rlhip_event_record", e1, stream)
+    ms = C.c_float(0)
+    call("rlhip_event_elapsed_ms", e0, e1, C.byref(ms))
+    call("rlhip_event_destroy", e0)
+    call("rlhip_event_destroy", e1)
+    return ms.value / iters
+
+
+def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
+    from rlhip._lib import call
+    from rlhip.ops import ptr, stream_ptr
+
+    env = rlhip.HipVecEnv("cartpole", n_envs, seed=1)
+    actions = torch.randint(0, 2, (n_envs,), dtype=torch.int32, device="cuda")
+
+    def step():
+        # pure act!: no observation copies (state(env) IS the state arrays for CartPole)
+        call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, ptr(actions), 1,
+             env.seed, 0, None, None, stream_ptr())
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ms = event_time_ms(step, iters, rlhip._lib.lib, stream_ptr())
+    achieved = CARTPOLE_STEP_BYTES * n_envs / (ms * 1e-3) / 1e9
+    del env, actions
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4>", "n_envs": n_envs,
+            "bytes_per_unit": CARTPOLE_STEP_BYTES, "us_per_launch": round(ms * 1e3, 2),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1)}
+
+
+def kernel_breakdown(torch, rlhip, pol, env):
+    """Mean launch time of each kernel class of the workload (same shapes as the timed region)."""
+    from rlhip.ops import stream_ptr
+
+    s = stream_ptr()
+    lib = rlhip._lib.lib
+    out = {}
+    saved = [t.clone() for t in (pol.params, pol.m, pol.v, pol.beta_pow)]
+    out["rollout_T32_us"] = round(event_time_ms(pol.rollout_, 5, lib, s) * 1e3, 2)
+    out["gae_returns_us"] = round(event_time_ms(pol.gae_, 20, lib, s) * 1e3, 2)
+    out["grad_plus_reduce_us"] = round(event_time_ms(lambda: pol.grad_(0, 0), 20, lib, s) * 1e3, 2)
+    out["clip_adam_us"] = round(event_time_ms(lambda: pol.apply_(1.0), 20, lib, s) * 1e3, 2)
+    for t, sv in zip((pol.params, pol.m, pol.v, pol.beta_pow), saved):
+        t.copy_(sv)
+    # f32 flops of one gradient launch: forward 2*h*((ns+nout_a)+(ns+1)) per sample, x3 with backward
+    bm = (env.n * pol.T) // pol.cfg.n_microbatches
+    flops = 3 * 2 * pol.cfg.hidden * ((env.odim + pol.na) + (env.odim + 1)) * bm
+    out["grad_tflops_f32"] = round(flops / (out["grad_plus_reduce_us"] * 1e-6) / 1e12, 2)
+    return out
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's PPO iteration (same algorithm, same hyper-parameters) on a bounded sample."""
+    import numpy as np
+
+    import oracle
+
+    n, T = 256, T_ROLLOUT
+    env = oracle.VecEnv("cartpole", n, seed=1)
+    cfg = oracle.ppo_default(hidden=HIDDEN)
+    npar = oracle.ppo_nparams(0, cfg)
+    params = np.concatenate([oracle.mlp2_init(4, HIDDEN, 2, 1, 0), oracle.mlp2_init(4, HIDDEN, 1, 1, 1)])
+    assert params.size == npar
+    m, v = np.zeros_like(params), np.zeros_like(params)
+    traj = oracle.PPOTraj(0, n, T)
+    opt_step, iters = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        oracle.ppo_rollout(env, T, cfg, params, traj, iters * T)
+        oracle.ppo_gae(cfg, traj)
+        opt_step, _ = oracle.ppo_update(0, cfg, traj, params, m, v, opt_step, 1, iters)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or iters >= 200:
+            break
+    return {"value": round(n * T * iters / el, 1), "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "updates_per_sec": round(16 * iters / el, 2),
+            "sample": f"{iters} PPO iterations of {n} envs x T={T} (same net / epochs / micro-batches) in {el:.1f} s, "
+                      f"oracle C restatement, gcc -O2, single thread; host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / breakdown legs")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pg = dist.group.WORLD
+
+    import rlhip
+
+    env = rlhip.HipVecEnv("cartpole", N_ENVS, seed=123, env_id_base=rank * N_ENVS)
+    pol = rlhip.PPOPolicy(env, update_freq=T_ROLLOUT, hidden=HIDDEN, seed=123, process_group=pg)
+
+    def step():
+        pol.rollout_()
+        pol.update_()
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    env_steps = world * N_ENVS * T_ROLLOUT * args.steps
+    updates = pol.n_updates_per_call() * args.steps
+    result = {
+        "metric": "env_steps_per_sec",
+        "value": round(env_steps / elapsed, 1),
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "updates_per_sec": round(updates / elapsed, 1),
+        "config": {"workload": "ppo_cartpole_4096env_per_gpu (BASELINE.json configs[3] per GPU)",
+                   "n_envs_per_gpu": N_ENVS, "rollout_T": T_ROLLOUT,
+                   "actor": f"4->{HIDDEN}->2 relu", "critic": f"4->{HIDDEN}->1 relu", "n_params": pol.np,
+                   "n_epochs": pol.cfg.n_epochs, "n_microbatches": pol.cfg.n_microbatches,
+                   "microbatch": (N_ENVS * T_ROLLOUT) // pol.cfg.n_microbatches,
+                   "parallelism": f"env-shards x{world}, flat-gradient all-reduce (RCCL) per micro-batch" if world > 1
+                   else "single GPU"},
+        "final_loss": float(pol.losses[0]),
+        "mean_episode_len_last_rollout": round(
+            (N_ENVS * T_ROLLOUT) / max(1.0, float(pol.trajectory.terminal.sum())), 2),
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["kernels"] = kernel_breakdown(torch, rlhip, pol, env)
+        result["roofline"] = roofline_env_step(torch, rlhip)
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

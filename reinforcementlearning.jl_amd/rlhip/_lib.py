@@ -27,6 +27,11 @@ if not os.path.exists(LIB_PATH):
         f"`python reinforcementlearning.jl_amd/build.py` (hipcc, gfx950). "
         "There is no CPU fallback for the rlhip hot path.")
 
+# PyTorch-ROCm bundles its own libamdhip64; import torch FIRST so that librlhip.so binds to the HIP
+# runtime instance that owns the tensors and streams it will be handed (two runtimes in one process
+# do not share device pointers: launches fail with "no ROCm-capable device is detected").
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 i32, i64, u32, u64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
