@@ -44,7 +44,7 @@ struct DqnArgs {
     uint32_t draw_ctr;
 };
 
-template <int NS>
+template <int NS, int ACT>
 __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
     __shared__ float l_s[NS][DTILE], l_sn[NS][DTILE];
     __shared__ float l_r[DTILE];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = g.h, na = g.na, act = g.act, hq = h >> 2;
+    const int h = g.h, na = g.na, hq = h >> 2;
     const float* W1 = g.params;
     const float* b1 = W1 + h * NS;
     const float* W2 = b1 + h;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                     z = fmaf(W1[jj + h * k], x[k], z);
                     zn = fmaf(tW1[jj + h * k], xn[k], zn);
                 }
-                float hv = act_fwd(act, z), hn = act_fwd(act, zn);
+                float hv = act_fwd_t<ACT>(z), hn = act_fwd_t<ACT>(zn);
 #pragma unroll
                 for (int o = 0; o < MAXO; ++o)
                     if (o < na) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                 float z = rb1;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) z = fmaf(rw1[k], x[k], z);
-                float hv = act_fwd(act, z);
+                float hv = act_fwd_t<ACT>(z);
                 float dh = 0.f;
 #pragma unroll
                 for (int o = 0; o < MAXO; ++o) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                     gw2[o] = fmaf(d, hv, gw2[o]);
                     dh = fmaf(d, rw2[o], dh);
                 }
-                float dz = dh * act_bwd(act, z, hv);
+                float dz = dh * act_bwd_t<ACT>(z, hv);
                 gb1 += dz;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) gw1[k] = fmaf(dz, x[k], gw1[k]);
@@ -249,8 +249,8 @@ struct RegQ {
     __device__ __forceinline__ float operator()(int k) const { return q[k]; }
 };
 
-template <int NS, int H, int L>
-__global__ __launch_bounds__(256, 1) void dqn_plan_wide_kernel(const float* __restrict__ params, int na, int act,
+template <int NS, int H, int L, int ACT>
+__global__ __launch_bounds__(256, 1) void dqn_plan_wide_kernel(const float* __restrict__ params, int na,
                                                                const float* __restrict__ obs, int64_t n,
                                                                double eps, uint64_t seed, uint32_t env_id_base,
                                                                uint32_t step, int32_t* __restrict__ actions,
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void dqn_plan_wide_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < NS; ++k) x[k] = obs[(int64_t)k * n + env];
     float q[MAXO];
-    net_forward<NS, HPL, L>(Q, x, act, q);
+    net_forward<NS, HPL, L, ACT>(Q, x, q);
     int32_t a = eps_greedy_select1(RegQ{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)env, step);
     if (active && sub == 0) {
         actions[env] = a;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256, 1) void dqn_plan_wide_kernel(const float* __re
     }
 }
 
-template <int NS>
+template <int NS, int ACT>
 __global__ __launch_bounds__(256) void dqn_plan_scalar_kernel(const float* __restrict__ params, int h, int na,
-                                                              int act, const float* __restrict__ obs, int64_t n,
+                                                              const float* __restrict__ obs, int64_t n,
                                                               double eps, uint64_t seed, uint32_t env_id_base,
                                                               uint32_t step, int32_t* __restrict__ actions,
                                                               float* __restrict__ q_out) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void dqn_plan_scalar_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < NS; ++k) x[k] = obs[(int64_t)k * n + env];
     float q[MAXO];
-    net_forward_scalar<NS>(params, h, na, act, x, q);
+    net_forward_scalar<NS, ACT>(params, h, na, x, q);
     actions[env] = eps_greedy_select1(RegQ{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)env, step);
     if (q_out)
         for (int o = 0; o < na; ++o) q_out[(int64_t)o * n + env] = q[o];
@@ -299,15 +299,24 @@ static int32_t dqn_plan_impl(const float* params, int h, int na, int act, const 
                              uint64_t seed, uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
                              hipStream_t s) {
     bool wide = (h == 256 || h == 128 || h == 64) && n * 16 <= (int64_t)1 << 22;
-#define LAUNCH_QW(H, L)                                                                                       \
-    hipLaunchKernelGGL((dqn_plan_wide_kernel<NS, H, L>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, params, \
-                       na, act, obs, n, eps, seed, env_id_base, step, actions, q_out)
+#define LAUNCH_QW(H, L)                                                                                            \
+    do {                                                                                                           \
+        if (act == 0)                                                                                              \
+            hipLaunchKernelGGL((dqn_plan_wide_kernel<NS, H, L, 0>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, \
+                               params, na, obs, n, eps, seed, env_id_base, step, actions, q_out);                  \
+        else                                                                                                       \
+            hipLaunchKernelGGL((dqn_plan_wide_kernel<NS, H, L, 1>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, \
+                               params, na, obs, n, eps, seed, env_id_base, step, actions, q_out);                  \
+    } while (0)
     if (wide && h == 256) LAUNCH_QW(256, 16);
     else if (wide && h == 128) LAUNCH_QW(128, 8);
     else if (wide && h == 64) LAUNCH_QW(64, 4);
+    else if (act == 0)
+        hipLaunchKernelGGL((dqn_plan_scalar_kernel<NS, 0>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, params, h,
+                           na, obs, n, eps, seed, env_id_base, step, actions, q_out);
     else
-        hipLaunchKernelGGL((dqn_plan_scalar_kernel<NS>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, params, h,
-                           na, act, obs, n, eps, seed, env_id_base, step, actions, q_out);
+        hipLaunchKernelGGL((dqn_plan_scalar_kernel<NS, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, params, h,
+                           na, obs, n, eps, seed, env_id_base, step, actions, q_out);
 #undef LAUNCH_QW
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
@@ -366,9 +375,11 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t 
     g.partials = (float*)workspace;
     g.loss_partials = g.partials + (int64_t)DQN_MAX_BLOCKS * np;
     hipStream_t s = as_stream(stream);
-    if (ns == 4) hipLaunchKernelGGL((dqn_grad_kernel<4>), dim3(nb), dim3(256), 0, s, g);
-    else if (ns == 3) hipLaunchKernelGGL((dqn_grad_kernel<3>), dim3(nb), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((dqn_grad_kernel<2>), dim3(nb), dim3(256), 0, s, g);
+#define LAUNCH_DG(NS_, ACT_) hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_>), dim3(nb), dim3(256), 0, s, g)
+    if (ns == 4) { if (act == 0) LAUNCH_DG(4, 0); else LAUNCH_DG(4, 1); }
+    else if (ns == 3) { if (act == 0) LAUNCH_DG(3, 0); else LAUNCH_DG(3, 1); }
+    else { if (act == 0) LAUNCH_DG(2, 0); else LAUNCH_DG(2, 1); }
+#undef LAUNCH_DG
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
                        nb, (int)np, grad_out, loss_out, g.inv_b);
     RLHIP_LAUNCH_CHECK();

@@ -36,6 +36,7 @@
 #include "env_device.h"
 #include "mlp_device.h"
 #include "select_device.h"
+#include "ppo_common.h"
 
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow,
                                        int64_t n, float grad_scale, float clip_norm, float lr, float beta1,
@@ -90,28 +91,10 @@ __device__ __forceinline__ void policy_sample(int cont, int na, const float oa[M
     }
 }
 
-struct TrajPtrs {
-    float* obs;
-    float* logp;
-    float* value;
-    float* reward;
-    float* adv;
-    float* ret;
-    float* action_f;
-    int32_t* action_i;
-    uint8_t* terminal;
-    static TrajPtrs from(const rlhip_ppo_traj& t) {
-        return {t.obs, t.logp, t.value, t.reward, t.adv, t.ret, t.action_f, t.action_i, t.terminal};
-    }
-};
 
-struct PolicyDesc {
-    int h, act, cont, na, nout_a;
-    int64_t np_a;
-};
 
 // ---------------------------------------------------------------------------------- rollout ----
-template <class P, int H, int L>
+template <class P, int H, int L, int ACT>
 __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<float> st, int64_t n, int T,
                                                               PolicyDesc pd, const float* __restrict__ params,
                                                               uint64_t seed, uint32_t env_id_base,
@@ -142,8 +125,8 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
         float x[4];
         env_obs1(p, e, x);  // state(env) at PreActStage (post auto-reset)
         float oa[MAXO], oc[MAXO];
-        net_forward<NS, HPL, L>(A, x, pd.act, oa);
-        net_forward<NS, HPL, L>(C, x, pd.act, oc);
+        net_forward<NS, HPL, L, ACT>(A, x, oa);
+        net_forward<NS, HPL, L, ACT>(C, x, oc);
         int32_t ai;
         float af, lp;
         policy_sample(pd.cont, pd.na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
@@ -165,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
     {
         float x[4], oc[MAXO];
         env_obs1(p, e, x);
-        net_forward<NS, HPL, L>(C, x, pd.act, oc);
+        net_forward<NS, HPL, L, ACT>(C, x, oc);
         if (writer) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) tr.obs[((int64_t)T * NS + k) * n + env] = x[k];
@@ -184,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
     }
 }
 
-template <class P>
+template <class P, int ACT>
 __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<float> st, int64_t n, int T,
                                                              PolicyDesc pd, const float* __restrict__ params,
                                                              uint64_t seed, uint32_t env_id_base,
@@ -204,8 +187,8 @@ __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<floa
         float x[4];
         env_obs1(p, e, x);
         float oa[MAXO], oc[MAXO];
-        net_forward_scalar<NS>(params, pd.h, pd.nout_a, pd.act, x, oa);
-        net_forward_scalar<NS>(params + pd.np_a, pd.h, 1, pd.act, x, oc);
+        net_forward_scalar<NS, ACT>(params, pd.h, pd.nout_a, x, oa);
+        net_forward_scalar<NS, ACT>(params + pd.np_a, pd.h, 1, x, oc);
         int32_t ai;
         float af, lp;
         policy_sample(pd.cont, pd.na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
@@ -223,7 +206,7 @@ __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<floa
     {
         float x[4], oc[MAXO];
         env_obs1(p, e, x);
-        net_forward_scalar<NS>(params + pd.np_a, pd.h, 1, pd.act, x, oc);
+        net_forward_scalar<NS, ACT>(params + pd.np_a, pd.h, 1, x, oc);
 #pragma unroll
         for (int k = 0; k < NS; ++k) tr.obs[((int64_t)T * NS + k) * n + env] = x[k];
         tr.value[(int64_t)T * n + env] = oc[0];
@@ -240,23 +223,6 @@ __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<floa
     }
 }
 
-static int64_t env_na(int kind, int cont) { return cont ? 1 : (kind == 0 ? 2 : 3); }
-
-static int32_t make_desc(int32_t kind, const rlhip_ppo_cfg* c, PolicyDesc* pd) {
-    RLHIP_REQUIRE(kind >= 0 && kind <= 2, "kind must be 0, 1 or 2");
-    RLHIP_REQUIRE(c != nullptr, "ppo cfg is NULL");
-    RLHIP_REQUIRE(c->hidden >= 4 && c->hidden % 4 == 0, "hidden must be a positive multiple of 4");
-    RLHIP_REQUIRE(c->act == 0 || c->act == 1, "act must be 0 (relu) or 1 (tanh)");
-    RLHIP_REQUIRE(c->normalize_advantage == 0, "normalize_advantage is not supported yet");
-    int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
-    pd->h = c->hidden;
-    pd->act = c->act;
-    pd->cont = c->continuous ? 1 : 0;
-    pd->na = (int)env_na(kind, pd->cont);
-    pd->nout_a = pd->cont ? 2 * pd->na : pd->na;
-    pd->np_a = mlp2_nparams(ns, c->hidden, pd->nout_a);
-    return RLHIP_OK;
-}
 
 template <class P>
 static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, int64_t T,
@@ -269,341 +235,33 @@ static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state*
     TrajPtrs tr = TrajPtrs::from(*traj);
     // wide variant while the chip is not yet full of one-lane-per-env wavefronts
     bool wide = (pd.h == 256 || pd.h == 128 || pd.h == 64) && n * 16 <= (int64_t)1 << 22;
-#define LAUNCH_WIDE(H, L)                                                                            \
-    hipLaunchKernelGGL((rollout_wide_kernel<P, H, L>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, \
-                       p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1)
+#define LAUNCH_WIDE(H, L)                                                                                  \
+    do {                                                                                                   \
+        if (pd.act == 0)                                                                                   \
+            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
+                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);      \
+        else                                                                                               \
+            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 1>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
+                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);      \
+    } while (0)
     if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);
     else if (wide && pd.h == 128) LAUNCH_WIDE(128, 8);
     else if (wide && pd.h == 64) LAUNCH_WIDE(64, 4);
+    else if (pd.act == 0)
+        hipLaunchKernelGGL((rollout_scalar_kernel<P, 0>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n,
+                           (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);
     else
-        hipLaunchKernelGGL((rollout_scalar_kernel<P>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n,
+        hipLaunchKernelGGL((rollout_scalar_kernel<P, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n,
                            (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);
 #undef LAUNCH_WIDE
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
 
-// ------------------------------------------------------------------------------------- grad ----
-constexpr int TILE = 64;
-constexpr int MAX_GRAD_BLOCKS = 512;
-
-struct GradArgs {
-    const float* obs;
-    const float* logp;
-    const float* adv;
-    const float* ret;
-    const float* action_f;
-    const int32_t* action_i;
-    const float* params;
-    float* partials;       // [nb][np]
-    float* loss_partials;  // [nb][4]
-    int64_t n;
-    uint32_t total, bm, pos0;
-    int num_tiles, np;
-    PolicyDesc pd;
-    float lo, hi, wa, wc, we, inv_b, min_logp;
-    uint64_t seed;
-    uint32_t epoch_ctr;
-};
-
-template <int NS>
-__global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
-    __shared__ float l_x[NS][TILE];
-    __shared__ float l_lp[TILE], l_adv[TILE], l_ret[TILE], l_af[TILE];
-    __shared__ int32_t l_ai[TILE];
-    __shared__ float l_part[4][MAXO + 1][TILE];
-    __shared__ float l_dL[MAXO + 1][TILE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = g.pd.h, nout = g.pd.nout_a, act = g.pd.act;
-    const int hq = h >> 2;
-    const float* __restrict__ pa = g.params;
-    const float* __restrict__ pc = g.params + g.pd.np_a;
-    const float* W1a = pa;
-    const float* b1a = W1a + h * NS;
-    const float* W2a = b1a + h;
-    const float* b2a = W2a + nout * h;
-    const float* W1c = pc;
-    const float* b1c = W1c + h * NS;
-    const float* W2c = b1c + h;
-    const float* b2c = W2c + h;
-
-    // phase-2 ownership: thread j < h owns hidden unit j of actor and critic
-    const bool owner = tid < h;
-    const int j = owner ? tid : 0;
-    float rw1a[NS], rw2a[MAXO], rw1c[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        rw1a[k] = W1a[j + h * k];
-        rw1c[k] = W1c[j + h * k];
-    }
-    const float rb1a = b1a[j], rb1c = b1c[j], rw2c = W2c[j];
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o) rw2a[o] = (o < nout) ? W2a[o + nout * j] : 0.0f;
-    float gw1a[NS], gw1c[NS], gw2a[MAXO];
-    float gb1a = 0.f, gb1c = 0.f, gw2c = 0.f;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) gw1a[k] = gw1c[k] = 0.f;
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o) gw2a[o] = 0.f;
-    // wave-0 per-sample-lane accumulators: output-bias gradients and loss sums
-    float gb2a[MAXO] = {0.f, 0.f, 0.f, 0.f};
-    float gb2c = 0.f, s_actor = 0.f, s_critic = 0.f, s_ent = 0.f;
-
-    PermKeys pk = perm_keys(g.seed, g.epoch_ctr, g.total);
-
-    for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
-        // ---- phase 0: gather this tile's samples (keyed permutation -> (t, env)) into LDS ----
-        if (tid < TILE) {
-            uint32_t q = (uint32_t)tile * TILE + tid;
-            bool valid = q < g.bm;
-            uint32_t f = permute(pk, g.pos0 + (valid ? q : 0u));
-            uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) l_x[k][tid] = g.obs[((int64_t)t * NS + k) * g.n + i];
-            l_lp[tid] = g.logp[f];
-            l_adv[tid] = valid ? g.adv[f] : 0.0f;
-            l_ret[tid] = g.ret[f];
-            if (g.pd.cont) l_af[tid] = g.action_f[f];
-            else l_ai[tid] = g.action_i[f];
-        }
-        __syncthreads();
-        // ---- phase 1a: lane = sample, wave w walks hidden units [w*hq, (w+1)*hq) (scalar weights) ----
-        {
-            float x[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) x[k] = l_x[k][lane];
-            float acc[MAXO] = {0.f, 0.f, 0.f, 0.f};
-            float accv = 0.f;
-            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
-                float za = b1a[jj], zc = b1c[jj];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    za = fmaf(W1a[jj + h * k], x[k], za);
-                    zc = fmaf(W1c[jj + h * k], x[k], zc);
-                }
-                float ha = act_fwd(act, za), hc = act_fwd(act, zc);
-#pragma unroll
-                for (int o = 0; o < MAXO; ++o)
-                    if (o < nout) acc[o] = fmaf(W2a[o + nout * jj], ha, acc[o]);
-                accv = fmaf(W2c[jj], hc, accv);
-            }
-#pragma unroll
-            for (int o = 0; o < MAXO; ++o) l_part[w][o][lane] = acc[o];
-            l_part[w][MAXO][lane] = accv;
-        }
-        __syncthreads();
-        // ---- phase 1b: wave 0 finishes the forward, evaluates the loss and dL/d(outputs) ----
-        if (tid < TILE) {
-            const int s = tid;
-            bool valid = ((uint32_t)tile * TILE + s) < g.bm;
-            float oa[MAXO], dl[MAXO];
-#pragma unroll
-            for (int o = 0; o < MAXO; ++o)
-                oa[o] = (((l_part[0][o][s] + l_part[1][o][s]) + l_part[2][o][s]) + l_part[3][o][s]) +
-                        ((o < nout) ? b2a[o] : 0.0f);
-            float v = (((l_part[0][MAXO][s] + l_part[1][MAXO][s]) + l_part[2][MAXO][s]) + l_part[3][MAXO][s]) +
-                      b2c[0];
-            float lp_old = fmaxf(l_lp[s], g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
-            float A = l_adv[s];
-            float lp_new, ent;
-#pragma unroll
-            for (int o = 0; o < MAXO; ++o) dl[o] = 0.f;
-            if (!g.pd.cont) {
-                const int na = g.pd.na;
-                float mx = oa[0];
-                for (int k = 1; k < na; ++k) mx = fmaxf(mx, oa[k]);
-                float se = 0.f;
-                for (int k = 0; k < na; ++k) se += expf(oa[k] - mx);
-                float lse = logf(se);
-                float logp[MAXO], pr[MAXO];
-                ent = 0.f;
-                for (int k = 0; k < na; ++k) {
-                    logp[k] = (oa[k] - mx) - lse;
-                    pr[k] = expf(logp[k]);
-                    ent -= pr[k] * logp[k];
-                }
-                int a = l_ai[s];
-                lp_new = 0.f;
-                for (int k = 0; k < na; ++k)
-                    if (k == a) lp_new = logp[k];
-                float ratio = expf(lp_new - lp_old);
-                float surr1 = ratio * A;
-                float rc = fminf(fmaxf(ratio, g.lo), g.hi);
-                float surr2 = rc * A;
-                bool inside = ratio >= g.lo && ratio <= g.hi;
-                float dobj = (inside || surr1 < surr2) ? A : 0.f;
-                float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
-                if (valid) s_actor += fminf(surr1, surr2);
-                for (int k = 0; k < na; ++k) {
-                    float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
-                    float dent = -pr[k] * (logp[k] + ent);
-                    dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
-                }
-            } else {
-                const float eps = 1.0e-8f;
-                float mu = oa[0], ls = oa[1];
-                float sg = expf(ls);
-                float z = l_af[s];
-                float se = sg + eps;
-                float zz = (z - mu) / se;
-                lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
-                ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
-                float dmu = (z - mu) / (se * se);
-                float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
-                float ratio = expf(lp_new - lp_old);
-                float surr1 = ratio * A;
-                float rc = fminf(fmaxf(ratio, g.lo), g.hi);
-                float surr2 = rc * A;
-                bool inside = ratio >= g.lo && ratio <= g.hi;
-                float dobj = (inside || surr1 < surr2) ? A : 0.f;
-                float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
-                if (valid) s_actor += fminf(surr1, surr2);
-                dl[0] = dL_dlp * dmu;
-                dl[1] = dL_dlp * dls - g.we * g.inv_b * 0.5f;
-            }
-            float dv = l_ret[s] - v;
-            float dvout = -2.0f * g.wc * g.inv_b * dv;
-            if (valid) {
-                s_critic += dv * dv;
-                s_ent += ent;
-            } else {
-#pragma unroll
-                for (int o = 0; o < MAXO; ++o) dl[o] = 0.f;
-                dvout = 0.f;
-            }
-#pragma unroll
-            for (int o = 0; o < MAXO; ++o) {
-                l_dL[o][s] = dl[o];
-                gb2a[o] += dl[o];
-            }
-            l_dL[MAXO][s] = dvout;
-            gb2c += dvout;
-        }
-        __syncthreads();
-        // ---- phase 2: lane = hidden unit j; walk the tile's samples from LDS (broadcast reads) ----
-        if (owner) {
-#pragma unroll 4
-            for (int s = 0; s < TILE; ++s) {
-                float x[NS];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) x[k] = l_x[k][s];
-                float za = rb1a, zc = rb1c;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    za = fmaf(rw1a[k], x[k], za);
-                    zc = fmaf(rw1c[k], x[k], zc);
-                }
-                float ha = act_fwd(act, za), hc = act_fwd(act, zc);
-                float dh = 0.f;
-#pragma unroll
-                for (int o = 0; o < MAXO; ++o) {
-                    float d = l_dL[o][s];
-                    gw2a[o] = fmaf(d, ha, gw2a[o]);
-                    dh = fmaf(d, rw2a[o], dh);
-                }
-                float dza = dh * act_bwd(act, za, ha);
-                float dv = l_dL[MAXO][s];
-                gw2c = fmaf(dv, hc, gw2c);
-                float dzc = (dv * rw2c) * act_bwd(act, zc, hc);
-                gb1a += dza;
-                gb1c += dzc;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    gw1a[k] = fmaf(dza, x[k], gw1a[k]);
-                    gw1c[k] = fmaf(dzc, x[k], gw1c[k]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- write this workgroup's partial gradient (fixed layout = parameter layout) ----
-    float* out = g.partials + (int64_t)blockIdx.x * g.np;
-    if (owner) {
-        float* oa_ = out;
-        float* oc_ = out + g.pd.np_a;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            oa_[j + h * k] = gw1a[k];
-            oc_[j + h * k] = gw1c[k];
-        }
-        oa_[h * NS + j] = gb1a;
-        oc_[h * NS + j] = gb1c;
-#pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-            if (o < nout) oa_[h * NS + h + o + nout * j] = gw2a[o];
-        oc_[h * NS + h + j] = gw2c;
-    }
-    if (tid < TILE) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-            for (int o = 0; o < MAXO; ++o) gb2a[o] += __shfl_down(gb2a[o], off, 64);
-            gb2c += __shfl_down(gb2c, off, 64);
-            s_actor += __shfl_down(s_actor, off, 64);
-            s_critic += __shfl_down(s_critic, off, 64);
-            s_ent += __shfl_down(s_ent, off, 64);
-        }
-        if (tid == 0) {
-            for (int o = 0; o < nout; ++o) out[h * NS + h + nout * h + o] = gb2a[o];
-            out[g.pd.np_a + h * NS + h + h] = gb2c;
-            float* lo_ = g.loss_partials + (int64_t)blockIdx.x * 4;
-            lo_[0] = s_actor;
-            lo_[1] = s_critic;
-            lo_[2] = s_ent;
-            lo_[3] = 0.f;
-        }
-    }
-}
-
-// grad[p] = sum_b partials[b][p] in a fixed order; block 0 also folds the loss sums.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials,
-                                                              const float* __restrict__ loss_partials,
-                                                              int nb, int np, float* __restrict__ grad,
-                                                              float* __restrict__ losses, float wa, float wc,
-                                                              float we, float inv_b) {
-    __shared__ float l_g[4][64];
-    __shared__ float l_loss[4];
-    int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    int p = blockIdx.x * 64 + lane;
-    int per = (nb + 3) / 4;
-    int b0 = grp * per, b1 = min(nb, b0 + per);
-    float acc = 0.f;
-    if (p < np) {
-#pragma unroll 8
-        for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + p];
-    }
-    l_g[grp][lane] = acc;
-    __syncthreads();
-    if (grp == 0 && p < np) grad[p] = ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane];
-    if (blockIdx.x == 0 && losses != nullptr) {
-        if (grp < 3) {
-            float a = 0.f;
-            for (int b = lane; b < nb; b += 64) a += loss_partials[(int64_t)b * 4 + grp];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
-            if (lane == 0) l_loss[grp] = a;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float actor_loss = -l_loss[0] * inv_b;
-            float critic_loss = l_loss[1] * inv_b;
-            float ent_loss = l_loss[2] * inv_b;
-            losses[0] = wa * actor_loss + wc * critic_loss - we * ent_loss;
-            losses[1] = actor_loss;
-            losses[2] = critic_loss;
-            losses[3] = ent_loss;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------- single-step plan ----
 // plan!(policy, env) for the vector env: forward + sample for n observations (SoA ns x n).  Uses the
 // same device functions (and the same lane split) as the fused rollout, so both paths are bit-identical.
-template <int NS, int H, int L>
+template <int NS, int H, int L, int ACT>
 __global__ __launch_bounds__(256, 1) void plan_wide_kernel(int64_t n, PolicyDesc pd,
                                                            const float* __restrict__ params,
                                                            const float* __restrict__ obs, uint64_t seed,
@@ -624,8 +282,8 @@ __global__ __launch_bounds__(256, 1) void plan_wide_kernel(int64_t n, PolicyDesc
 #pragma unroll
     for (int k = 0; k < NS; ++k) x[k] = obs[(int64_t)k * n + env];
     float oa[MAXO], oc[MAXO];
-    net_forward<NS, HPL, L>(A, x, pd.act, oa);
-    net_forward<NS, HPL, L>(C, x, pd.act, oc);
+    net_forward<NS, HPL, L, ACT>(A, x, oa);
+    net_forward<NS, HPL, L, ACT>(C, x, oc);
     int32_t ai;
     float af, lp;
     policy_sample(pd.cont, pd.na, oa, seed, env_id_base + (uint32_t)env, step, ai, af, lp);
@@ -637,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void plan_wide_kernel(int64_t n, PolicyDesc
     }
 }
 
-template <int NS>
+template <int NS, int ACT>
 __global__ __launch_bounds__(256) void plan_scalar_kernel(int64_t n, PolicyDesc pd,
                                                           const float* __restrict__ params,
                                                           const float* __restrict__ obs, uint64_t seed,
@@ -651,8 +309,8 @@ __global__ __launch_bounds__(256) void plan_scalar_kernel(int64_t n, PolicyDesc 
 #pragma unroll
     for (int k = 0; k < NS; ++k) x[k] = obs[(int64_t)k * n + env];
     float oa[MAXO], oc[MAXO];
-    net_forward_scalar<NS>(params, pd.h, pd.nout_a, pd.act, x, oa);
-    net_forward_scalar<NS>(params + pd.np_a, pd.h, 1, pd.act, x, oc);
+    net_forward_scalar<NS, ACT>(params, pd.h, pd.nout_a, x, oa);
+    net_forward_scalar<NS, ACT>(params + pd.np_a, pd.h, 1, x, oc);
     int32_t ai;
     float af, lp;
     policy_sample(pd.cont, pd.na, oa, seed, env_id_base + (uint32_t)env, step, ai, af, lp);
@@ -667,14 +325,23 @@ static int32_t plan_impl(int64_t n, const PolicyDesc& pd, const float* params, c
                          uint32_t env_id_base, uint32_t step, int32_t* ai, float* af, float* logp, float* value,
                          hipStream_t s) {
     bool wide = (pd.h == 256 || pd.h == 128 || pd.h == 64) && n * 16 <= (int64_t)1 << 22;
-#define LAUNCH_PW(H, L)                                                                                   \
-    hipLaunchKernelGGL((plan_wide_kernel<NS, H, L>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, n, pd, \
-                       params, obs, seed, env_id_base, step, ai, af, logp, value)
+#define LAUNCH_PW(H, L)                                                                                        \
+    do {                                                                                                       \
+        if (pd.act == 0)                                                                                       \
+            hipLaunchKernelGGL((plan_wide_kernel<NS, H, L, 0>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, n, \
+                               pd, params, obs, seed, env_id_base, step, ai, af, logp, value);                \
+        else                                                                                                   \
+            hipLaunchKernelGGL((plan_wide_kernel<NS, H, L, 1>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, s, n, \
+                               pd, params, obs, seed, env_id_base, step, ai, af, logp, value);                \
+    } while (0)
     if (wide && pd.h == 256) LAUNCH_PW(256, 16);
     else if (wide && pd.h == 128) LAUNCH_PW(128, 8);
     else if (wide && pd.h == 64) LAUNCH_PW(64, 4);
+    else if (pd.act == 0)
+        hipLaunchKernelGGL((plan_scalar_kernel<NS, 0>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, n, pd, params,
+                           obs, seed, env_id_base, step, ai, af, logp, value);
     else
-        hipLaunchKernelGGL((plan_scalar_kernel<NS>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, n, pd, params,
+        hipLaunchKernelGGL((plan_scalar_kernel<NS, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, n, pd, params,
                            obs, seed, env_id_base, step, ai, af, logp, value);
 #undef LAUNCH_PW
     RLHIP_LAUNCH_CHECK();
@@ -825,86 +492,5 @@ int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const 
                                  cfg->gamma, cfg->lambda, stream);
 }
 
-int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T) {
-    (void)n;
-    (void)T;
-    int64_t np = rlhip_ppo_nparams(kind, cfg);
-    if (np < 0) return -1;
-    return (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float);
-}
-
-int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
-                           const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr,
-                           int32_t mb, void* workspace, float* grad_out, float* losses_out,
-                           rlhip_stream_t stream) {
-    PolicyDesc pd;
-    int32_t rc = make_desc(kind, cfg, &pd);
-    if (rc) return rc;
-    RLHIP_REQUIRE(traj && params && workspace && grad_out, "NULL argument");
-    RLHIP_REQUIRE(pd.h <= 256, "the fused gradient kernel supports hidden <= 256");
-    RLHIP_REQUIRE(n >= 1 && T >= 1 && n * T <= 0x7FFFFFFFll, "n * T out of range");
-    RLHIP_REQUIRE(cfg->n_microbatches >= 1 && mb >= 0 && mb < cfg->n_microbatches, "bad micro-batch index");
-    int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
-    int64_t np = pd.np_a + mlp2_nparams(ns, pd.h, 1);
-    uint32_t total = (uint32_t)(n * T);
-    uint32_t bm = total / (uint32_t)cfg->n_microbatches;
-    RLHIP_REQUIRE(bm >= 1, "micro-batch is empty");
-    GradArgs g;
-    g.obs = traj->obs;
-    g.logp = traj->logp;
-    g.adv = traj->adv;
-    g.ret = traj->ret;
-    g.action_f = traj->action_f;
-    g.action_i = traj->action_i;
-    g.params = params;
-    g.n = n;
-    g.total = total;
-    g.bm = bm;
-    g.pos0 = (uint32_t)mb * bm;
-    g.num_tiles = (int)((bm + TILE - 1) / TILE);
-    g.np = (int)np;
-    g.pd = pd;
-    g.lo = 1.0f - cfg->clip_range;
-    g.hi = 1.0f + cfg->clip_range;
-    g.wa = cfg->actor_loss_weight;
-    g.wc = cfg->critic_loss_weight;
-    g.we = cfg->entropy_loss_weight;
-    g.inv_b = 1.0f / (float)bm;
-    g.min_logp = (float)log(1e-8);
-    g.seed = seed;
-    g.epoch_ctr = epoch_ctr;
-    int nb = g.num_tiles < MAX_GRAD_BLOCKS ? g.num_tiles : MAX_GRAD_BLOCKS;
-    g.partials = (float*)workspace;
-    g.loss_partials = g.partials + (int64_t)MAX_GRAD_BLOCKS * np;
-    hipStream_t s = as_stream(stream);
-    if (ns == 4) hipLaunchKernelGGL((ppo_grad_kernel<4>), dim3(nb), dim3(256), 0, s, g);
-    else if (ns == 3) hipLaunchKernelGGL((ppo_grad_kernel<3>), dim3(nb), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((ppo_grad_kernel<2>), dim3(nb), dim3(256), 0, s, g);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials,
-                       g.loss_partials, nb, (int)np, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b);
-    RLHIP_LAUNCH_CHECK();
-    return RLHIP_OK;
-}
-
-int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
-                             const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
-                             uint64_t seed, uint32_t update_ctr, void* workspace, float* grad_scratch,
-                             float* losses_out, rlhip_stream_t stream) {
-    RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
-    int64_t np = rlhip_ppo_nparams(kind, cfg);
-    RLHIP_REQUIRE(np > 0, "bad ppo cfg");
-    for (int32_t e = 0; e < cfg->n_epochs; ++e) {
-        uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
-        for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
-            int32_t rc = rlhip_ppo_grad_f32(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace,
-                                            grad_scratch, losses_out, stream);
-            if (rc) return rc;
-            rc = rlhip_clip_adam_f32(params, grad_scratch, m, v, beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr,
-                                     cfg->beta1, cfg->beta2, cfg->adam_eps, nullptr, stream);
-            if (rc) return rc;
-        }
-    }
-    return RLHIP_OK;
-}
 
 }  // extern "C"

@@ -1,0 +1,671 @@
+// ppo_grad.hip -- PPO clipped-surrogate loss + gradient over one micro-batch, and the fused
+// "reduce partial gradients -> clip_by_global_norm! -> Adam" tail of the single-GPU update.
+//
+// Replaces the body of the removed Zoo `PPOPolicy` update (hyper-parameters blog
+// a_practical_introduction_to_RL.jl/index.html:15257-15278): shuffled micro-batch gather, actor/critic
+// forward (Flux Dense chains), softmax / ratio / clamp / min, value and entropy terms, Zygote backward,
+// then clip_by_global_norm! (RLCore/utils/basic.jl:19-29) and Flux.Optimise.update! with Adam
+// (RLCore/policies/learners/flux_approximator.jl:46).
+//
+// ppo_grad_kernel (256 threads = 4 waves, persistent over 64-sample tiles):
+//   prologue  every hidden unit's weights go to LDS as one 32-byte record per net
+//             {W1[j,0..3], b1[j], W2[0..2,j]} -- phase 1 reads them with two broadcast ds_read_b128 per
+//             unit per net (conflict-free: all lanes read one address) instead of 13 dependent scalar
+//             loads (the first version's bottleneck: 47.8 us/launch, profiles/r01_a_*).
+//   phase 0   64 threads fetch the tile's samples f = perm(pos) (keyed bijection, no index array) from
+//             the trajectory into registers ONE TILE AHEAD -- the HBM/L2 latency of the scattered gather
+//             hides under phases 1-2 of the current tile -- and publish them to a double-buffered LDS tile.
+//   phase 1a  lane = sample, wave w walks its quarter of the hidden units; partial output sums -> LDS.
+//   phase 1b  wave 0 finishes logits / value, evaluates the loss terms and dL/d(outputs) per sample.
+//   phase 2   lane = hidden unit j (weights in registers); the 64 samples stream from LDS as two
+//             broadcast b128 reads each; weight gradients accumulate in registers: no atomics, no
+//             cross-lane reductions, fixed summation order.
+//   epilogue  each workgroup writes one partial gradient (parameter layout); summation across
+//             workgroups is done in a fixed order by reduce_apply_kernel / reduce_partials_kernel, so
+//             the result is run-to-run deterministic and replicas on different GPUs stay bit-identical.
+// Roofline: VALU-f32 bound by construction (K = ns <= 4 and N = nout <= 3 are far below an MFMA tile);
+// algorithmic work 6*h*((ns+nout)+(ns+1)) flop per sample.
+#include "ppo_common.h"
+
+#include <stdlib.h>
+
+extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow,
+                                       int64_t n, float grad_scale, float clip_norm, float lr, float beta1,
+                                       float beta2, float eps, float* gn_out, rlhip_stream_t stream);
+extern "C" int64_t rlhip_ppo_nparams(int32_t kind, const rlhip_ppo_cfg* c);
+
+namespace rlhip {
+
+constexpr float LOG2PI_F = 1.8378770664093453f;  // log(2f0 * pi) as Float32 (RLCore/utils/distributions.jl:9)
+constexpr int TILE = 64;
+constexpr int MAX_GRAD_BLOCKS = 512;
+constexpr int GMAXO = 3;  // actor outputs handled by the fused gradient kernel (na <= 3, or (mu, log sigma))
+
+struct GradArgs {
+    const float* obs;
+    const float* logp;
+    const float* adv;
+    const float* ret;
+    const float* action_f;
+    const int32_t* action_i;
+    const float* params;
+    float* partials;       // [nb][np]
+    float* loss_partials;  // [nb][4]
+    int64_t n;
+    uint32_t total, bm, pos0;
+    int num_tiles, np;
+    PolicyDesc pd;
+    float lo, hi, wa, wc, we, inv_b, min_logp;
+    uint64_t seed;
+    uint32_t epoch_ctr;
+    long long* dbg;  // optional per-block phase timestamps (s_memtime), 8 per block; NULL in production
+};
+
+#define DBG_STAMP(k)                                                             \
+    do {                                                                         \
+        if (g.dbg && threadIdx.x == 0) g.dbg[(int64_t)blockIdx.x * 8 + (k)] = clock64(); \
+    } while (0)
+
+struct TileRegs {  // one sample's trajectory entries, held in registers one tile ahead
+    float4 x;
+    float4 misc;  // {logp_old, adv, ret, action (int bits or float)}
+};
+
+template <int NS>
+__device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKeys& pk, int tile, int s) {
+    uint32_t q = (uint32_t)tile * TILE + (uint32_t)s;
+    bool valid = q < g.bm;
+    uint32_t f = permute(pk, g.pos0 + (valid ? q : 0u));
+    uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
+    TileRegs r;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NS; ++k) xv[k] = g.obs[((int64_t)t * NS + k) * g.n + i];
+    r.x = make_float4(xv[0], xv[1], xv[2], xv[3]);
+    float a = g.pd.cont ? g.action_f[f] : __int_as_float(g.action_i[f]);
+    r.misc = make_float4(g.logp[f], valid ? g.adv[f] : 0.0f, g.ret[f], a);
+    return r;
+}
+
+template <int NS, int ACT>
+__global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DBG_STAMP(0);
+    const int h = g.pd.h;
+    // LDS carve (all 16-byte aligned): recA[h] | recC[h] | x[2][TILE] | misc[2][TILE] | part[4][TILE] | dL[TILE]
+    float4* recA = reinterpret_cast<float4*>(smem);          // 2 float4 per unit
+    float4* recC = recA + 2 * h;                             // 2 float4 per unit
+    float4* l_x = recC + 2 * h;                              // [2][TILE]
+    float4* l_misc = l_x + 2 * TILE;                         // [2][TILE]
+    float4* l_part = l_misc + 2 * TILE;                      // [4][TILE]  {a0, a1, a2, v} partial sums
+    float4* l_dL = l_part + 4 * TILE;                        // [TILE]     {dl0, dl1, dl2, dv}
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nout = g.pd.nout_a;
+    const int hq = h >> 2;
+    const float* __restrict__ pa = g.params;
+    const float* __restrict__ pc = g.params + g.pd.np_a;
+    const float* W1a = pa;
+    const float* b1a = W1a + h * NS;
+    const float* W2a = b1a + h;
+    const float* b2a = W2a + nout * h;
+    const float* W1c = pc;
+    const float* b1c = W1c + h * NS;
+    const float* W2c = b1c + h;
+    const float* b2c = W2c + h;
+
+    // ---- prologue: the first tile's scattered gather is issued FIRST so that its latency overlaps the
+    // weight-record loads; weight records -> LDS; this thread's unit (phase 2) -> registers ----
+    PermKeys pk = perm_keys(g.seed, g.epoch_ctr, g.total);
+    int tile = blockIdx.x;
+    TileRegs first;
+    const bool first_loader = tid < TILE && tile < g.num_tiles;
+    if (first_loader) first = fetch_sample<NS>(g, pk, tile, tid);
+    const bool owner = tid < h;
+    float rw1a[4] = {0.f, 0.f, 0.f, 0.f}, rw1c[4] = {0.f, 0.f, 0.f, 0.f}, rw2a[GMAXO] = {0.f, 0.f, 0.f};
+    float rb1a = 0.f, rb1c = 0.f, rw2c = 0.f;
+    for (int j = tid; j < h; j += blockDim.x) {
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f}, a2[GMAXO] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            a1[k] = W1a[j + h * k];
+            c1[k] = W1c[j + h * k];
+        }
+#pragma unroll
+        for (int o = 0; o < GMAXO; ++o)
+            if (o < nout) a2[o] = W2a[o + nout * j];
+        float ba = b1a[j], bc = b1c[j], wc2 = W2c[j];
+        recA[2 * j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        recA[2 * j + 1] = make_float4(ba, a2[0], a2[1], a2[2]);
+        recC[2 * j] = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        recC[2 * j + 1] = make_float4(bc, wc2, 0.f, 0.f);
+        if (j == tid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rw1a[k] = a1[k];
+                rw1c[k] = c1[k];
+            }
+#pragma unroll
+            for (int o = 0; o < GMAXO; ++o) rw2a[o] = a2[o];
+            rb1a = ba;
+            rb1c = bc;
+            rw2c = wc2;
+        }
+    }
+    float gw1a[4] = {0.f, 0.f, 0.f, 0.f}, gw1c[4] = {0.f, 0.f, 0.f, 0.f}, gw2a[GMAXO] = {0.f, 0.f, 0.f};
+    float gb1a = 0.f, gb1c = 0.f, gw2c = 0.f;
+    // wave-0 per-sample-lane accumulators: output-bias gradients and loss sums
+    float gb2a[GMAXO] = {0.f, 0.f, 0.f};
+    float gb2c = 0.f, s_actor = 0.f, s_critic = 0.f, s_ent = 0.f;
+    const float b2a0 = (0 < nout) ? b2a[0] : 0.f, b2a1 = (1 < nout) ? b2a[1] : 0.f, b2a2 = (2 < nout) ? b2a[2] : 0.f;
+    const float b2cv = b2c[0];
+
+    int buf = 0;
+    if (first_loader) {
+        l_x[tid] = first.x;
+        l_misc[tid] = first.misc;
+    }
+    __syncthreads();
+    DBG_STAMP(1);
+
+    for (; tile < g.num_tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const float4* cx = l_x + buf * TILE;
+        const float4* cm = l_misc + buf * TILE;
+        // ---- phase 0 (next tile): wave 1 issues the gather now, publishes it after phase 2 ----
+        TileRegs pre;
+        const bool prefetcher = (w == 1) && (next < g.num_tiles);
+        if (prefetcher) pre = fetch_sample<NS>(g, pk, next, lane);
+        // ---- phase 1a: lane = sample, wave w walks hidden units [w*hq, (w+1)*hq) ----
+        {
+            const float4 xv = cx[lane];
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accv = 0.f;
+#pragma unroll 8
+            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
+                const float4 wa_ = recA[2 * jj], ra_ = recA[2 * jj + 1];
+                const float4 wc_ = recC[2 * jj], rc_ = recC[2 * jj + 1];
+                float za = ra_.x, zc = rc_.x;
+                za = fmaf(wa_.x, xv.x, za);
+                zc = fmaf(wc_.x, xv.x, zc);
+                if (NS > 1) {
+                    za = fmaf(wa_.y, xv.y, za);
+                    zc = fmaf(wc_.y, xv.y, zc);
+                }
+                if (NS > 2) {
+                    za = fmaf(wa_.z, xv.z, za);
+                    zc = fmaf(wc_.z, xv.z, zc);
+                }
+                if (NS > 3) {
+                    za = fmaf(wa_.w, xv.w, za);
+                    zc = fmaf(wc_.w, xv.w, zc);
+                }
+                const float ha = act_fwd_t<ACT>(za), hc = act_fwd_t<ACT>(zc);
+                acc0 = fmaf(ra_.y, ha, acc0);
+                acc1 = fmaf(ra_.z, ha, acc1);
+                acc2 = fmaf(ra_.w, ha, acc2);
+                accv = fmaf(rc_.y, hc, accv);
+            }
+            l_part[w * TILE + lane] = make_float4(acc0, acc1, acc2, accv);
+        }
+        __syncthreads();
+        DBG_STAMP(2);
+        // ---- phase 1b: wave 0 finishes the forward, evaluates the loss and dL/d(outputs) ----
+        if (w == 0) {
+            const int s = lane;
+            const bool valid = ((uint32_t)tile * TILE + (uint32_t)s) < g.bm;
+            const float4 p0 = l_part[s], p1 = l_part[TILE + s], p2 = l_part[2 * TILE + s], p3 = l_part[3 * TILE + s];
+            float oa[GMAXO], dl[GMAXO] = {0.f, 0.f, 0.f};
+            oa[0] = (((p0.x + p1.x) + p2.x) + p3.x) + b2a0;
+            oa[1] = (((p0.y + p1.y) + p2.y) + p3.y) + b2a1;
+            oa[2] = (((p0.z + p1.z) + p2.z) + p3.z) + b2a2;
+            const float v = (((p0.w + p1.w) + p2.w) + p3.w) + b2cv;
+            const float4 mi = cm[s];
+            const float lp_old = fmaxf(mi.x, g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
+            const float A = mi.y;
+            float lp_new, ent;
+            if (!g.pd.cont) {
+                const int na = g.pd.na;
+                float mx = oa[0];
+                for (int k = 1; k < na; ++k) mx = fmaxf(mx, oa[k]);
+                float se = 0.f;
+                for (int k = 0; k < na; ++k) se += expf(oa[k] - mx);
+                const float lse = logf(se);
+                float logp[GMAXO], pr[GMAXO];
+                ent = 0.f;
+                for (int k = 0; k < na; ++k) {
+                    logp[k] = (oa[k] - mx) - lse;
+                    pr[k] = expf(logp[k]);
+                    ent -= pr[k] * logp[k];
+                }
+                const int a = __float_as_int(mi.w);
+                lp_new = 0.f;
+                for (int k = 0; k < na; ++k)
+                    if (k == a) lp_new = logp[k];
+                const float ratio = expf(lp_new - lp_old);
+                const float surr1 = ratio * A;
+                const float rc = fminf(fmaxf(ratio, g.lo), g.hi);
+                const float surr2 = rc * A;
+                const bool inside = ratio >= g.lo && ratio <= g.hi;
+                const float dobj = (inside || surr1 < surr2) ? A : 0.f;
+                const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
+                if (valid) s_actor += fminf(surr1, surr2);
+                for (int k = 0; k < na; ++k) {
+                    const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
+                    const float dent = -pr[k] * (logp[k] + ent);
+                    dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
+                }
+            } else {
+                const float eps = 1.0e-8f;
+                const float mu = oa[0], ls = oa[1];
+                const float sg = expf(ls);
+                const float z = mi.w;
+                const float se = sg + eps;
+                const float zz = (z - mu) / se;
+                lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
+                ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
+                const float dmu = (z - mu) / (se * se);
+                const float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
+                const float ratio = expf(lp_new - lp_old);
+                const float surr1 = ratio * A;
+                const float rc = fminf(fmaxf(ratio, g.lo), g.hi);
+                const float surr2 = rc * A;
+                const bool inside = ratio >= g.lo && ratio <= g.hi;
+                const float dobj = (inside || surr1 < surr2) ? A : 0.f;
+                const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
+                if (valid) s_actor += fminf(surr1, surr2);
+                dl[0] = dL_dlp * dmu;
+                dl[1] = dL_dlp * dls - g.we * g.inv_b * 0.5f;
+            }
+            const float dv = mi.z - v;
+            float dvout = -2.0f * g.wc * g.inv_b * dv;
+            if (valid) {
+                s_critic += dv * dv;
+                s_ent += ent;
+            } else {
+                dl[0] = dl[1] = dl[2] = 0.f;
+                dvout = 0.f;
+            }
+            l_dL[s] = make_float4(dl[0], dl[1], dl[2], dvout);
+            gb2a[0] += dl[0];
+            gb2a[1] += dl[1];
+            gb2a[2] += dl[2];
+            gb2c += dvout;
+        }
+        __syncthreads();
+        DBG_STAMP(3);
+        // ---- phase 2: lane = hidden unit j; the tile's samples stream from LDS (broadcast reads) ----
+        if (owner) {
+#pragma unroll 4
+            for (int s = 0; s < TILE; ++s) {
+                const float4 xv = cx[s];
+                const float4 d = l_dL[s];
+                float za = rb1a, zc = rb1c;
+                za = fmaf(rw1a[0], xv.x, za);
+                zc = fmaf(rw1c[0], xv.x, zc);
+                if (NS > 1) {
+                    za = fmaf(rw1a[1], xv.y, za);
+                    zc = fmaf(rw1c[1], xv.y, zc);
+                }
+                if (NS > 2) {
+                    za = fmaf(rw1a[2], xv.z, za);
+                    zc = fmaf(rw1c[2], xv.z, zc);
+                }
+                if (NS > 3) {
+                    za = fmaf(rw1a[3], xv.w, za);
+                    zc = fmaf(rw1c[3], xv.w, zc);
+                }
+                const float ha = act_fwd_t<ACT>(za), hc = act_fwd_t<ACT>(zc);
+                gw2a[0] = fmaf(d.x, ha, gw2a[0]);
+                gw2a[1] = fmaf(d.y, ha, gw2a[1]);
+                gw2a[2] = fmaf(d.z, ha, gw2a[2]);
+                float dh = d.x * rw2a[0];
+                dh = fmaf(d.y, rw2a[1], dh);
+                dh = fmaf(d.z, rw2a[2], dh);
+                const float dza = dh * act_bwd_t<ACT>(za, ha);
+                gw2c = fmaf(d.w, hc, gw2c);
+                const float dzc = (d.w * rw2c) * act_bwd_t<ACT>(zc, hc);
+                gb1a += dza;
+                gb1c += dzc;
+                gw1a[0] = fmaf(dza, xv.x, gw1a[0]);
+                gw1c[0] = fmaf(dzc, xv.x, gw1c[0]);
+                if (NS > 1) {
+                    gw1a[1] = fmaf(dza, xv.y, gw1a[1]);
+                    gw1c[1] = fmaf(dzc, xv.y, gw1c[1]);
+                }
+                if (NS > 2) {
+                    gw1a[2] = fmaf(dza, xv.z, gw1a[2]);
+                    gw1c[2] = fmaf(dzc, xv.z, gw1c[2]);
+                }
+                if (NS > 3) {
+                    gw1a[3] = fmaf(dza, xv.w, gw1a[3]);
+                    gw1c[3] = fmaf(dzc, xv.w, gw1c[3]);
+                }
+            }
+        }
+        // publish the prefetched next tile into the other buffer (nobody reads it before the barrier)
+        if (prefetcher) {
+            l_x[(buf ^ 1) * TILE + lane] = pre.x;
+            l_misc[(buf ^ 1) * TILE + lane] = pre.misc;
+        }
+        __syncthreads();
+        DBG_STAMP(4);
+        buf ^= 1;
+    }
+
+    // ---- epilogue: this workgroup's partial gradient (fixed layout = parameter layout) ----
+    float* out = g.partials + (int64_t)blockIdx.x * g.np;
+    if (owner) {
+        const int j = tid;
+        float* oa_ = out;
+        float* oc_ = out + g.pd.np_a;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            oa_[j + h * k] = gw1a[k];
+            oc_[j + h * k] = gw1c[k];
+        }
+        oa_[h * NS + j] = gb1a;
+        oc_[h * NS + j] = gb1c;
+#pragma unroll
+        for (int o = 0; o < GMAXO; ++o)
+            if (o < nout) oa_[h * NS + h + o + nout * j] = gw2a[o];
+        oc_[h * NS + h + j] = gw2c;
+    }
+    if (w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int o = 0; o < GMAXO; ++o) gb2a[o] += __shfl_down(gb2a[o], off, 64);
+            gb2c += __shfl_down(gb2c, off, 64);
+            s_actor += __shfl_down(s_actor, off, 64);
+            s_critic += __shfl_down(s_critic, off, 64);
+            s_ent += __shfl_down(s_ent, off, 64);
+        }
+        if (lane == 0) {
+            for (int o = 0; o < nout; ++o) out[h * NS + h + nout * h + o] = gb2a[o];
+            out[g.pd.np_a + h * NS + h + h] = gb2c;
+            float* lo_ = g.loss_partials + (int64_t)blockIdx.x * 4;
+            lo_[0] = s_actor;
+            lo_[1] = s_critic;
+            lo_[2] = s_ent;
+            lo_[3] = 0.f;
+        }
+    }
+    DBG_STAMP(5);
+}
+
+static size_t grad_smem_bytes(int h) { return sizeof(float4) * (size_t)(4 * h + 2 * TILE + 2 * TILE + 4 * TILE + TILE); }
+
+// ------------------------------------------------------------------------- reduce (+ apply) ----
+struct ApplyArgs {
+    float* params;
+    float* m;
+    float* v;
+    float* beta_pow;
+    float clip_norm, lr, b1, b2, eps;
+    unsigned int* counter;  // arrival counter (device), zero between launches
+    double* sumsq;          // [gridDim] per-block partial sums of squares
+};
+
+// grad[p] = sum_b partials[b][p] (fixed order); losses folded by block 0.
+// APPLY: the last-arriving workgroup (agent-scope release/acquire around a device counter) computes the
+// global norm from the per-block partials, clips, and runs Adam on all parameters -- one launch instead
+// of reduce + clip_adam.
+constexpr int RP = 64;  // parameters per reduce workgroup (x 16 partial-groups = 1024 threads)
+template <bool APPLY>
+__global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restrict__ partials,
+                                                            const float* __restrict__ loss_partials, int nb,
+                                                            int np, float* __restrict__ grad,
+                                                            float* __restrict__ losses, float wa, float wc,
+                                                            float we, float inv_b, ApplyArgs ap) {
+    __shared__ float l_g[16][RP];
+    __shared__ float l_loss[4];
+    __shared__ double l_d[16];
+    __shared__ int l_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pl = threadIdx.x % RP, grp = threadIdx.x / RP;  // 16 groups of RP parameters
+    const int p = blockIdx.x * RP + pl;
+    const int per = (nb + 15) / 16;
+    const int b0 = grp * per, b1 = min(nb, b0 + per);
+    float acc = 0.f;
+    if (p < np) {
+        // all loads of a 32-partial batch are issued before the first add (one memory latency per batch)
+        for (int bb = b0; bb < b1; bb += 32) {
+            float t[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) t[q] = (bb + q < b1) ? partials[(int64_t)(bb + q) * np + p] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc += t[q];
+        }
+    }
+    l_g[grp][pl] = acc;
+    __syncthreads();
+    float gsum = 0.f;
+    if (grp == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gsum += l_g[q][pl];
+        if (p < np) grad[p] = gsum;
+        else gsum = 0.f;
+    }
+    if (blockIdx.x == 0 && losses != nullptr) {
+        if (wv >= 1 && wv <= 3) {
+            const int c = wv - 1;
+            float a = 0.f;
+            for (int b = lane; b < nb; b += 64) a += loss_partials[(int64_t)b * 4 + c];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) l_loss[c] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float actor_loss = -l_loss[0] * inv_b;
+            const float critic_loss = l_loss[1] * inv_b;
+            const float ent_loss = l_loss[2] * inv_b;
+            losses[0] = wa * actor_loss + wc * critic_loss - we * ent_loss;
+            losses[1] = actor_loss;
+            losses[2] = critic_loss;
+            losses[3] = ent_loss;
+        }
+    }
+    if (!APPLY) return;
+
+    // per-block partial sum of squares (threads 0..RP-1 of wave 0 hold this block's gradient values)
+    if (wv == 0) {
+        double sq = (grp == 0) ? (double)gsum * (double)gsum : 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (lane == 0) ap.sumsq[blockIdx.x] = sq;
+    }
+    // publish: plain stores -> barrier -> one lane: agent-scope release, drain, counter increment
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int prev = __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        l_last = (prev == gridDim.x - 1) ? 1 : 0;
+        if (l_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!l_last) return;
+    // ---- last workgroup: global norm -> clip -> Adam over all parameters ----
+    double part = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x)
+        part += __hip_atomic_load(ap.sumsq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) l_d[wv] = part;
+    __syncthreads();
+    double tot = 0.0;
+    const int nwv = blockDim.x >> 6;
+    for (int q = 0; q < nwv; ++q) tot += l_d[q];
+    const float gn = (float)sqrt(tot);
+    const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+    const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+    __syncthreads();  // every thread has read beta_pow
+    for (int q = threadIdx.x; q < np; q += blockDim.x) {
+        float gi = __hip_atomic_load(grad + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (scale != 1.0f) gi *= scale;
+        // Optimisers.Adam (same expression order as optim.hip adam1)
+        const float mi = ap.b1 * ap.m[q] + (1.0f - ap.b1) * gi;
+        const float vi = ap.b2 * ap.v[q] + (1.0f - ap.b2) * (gi * gi);
+        ap.m[q] = mi;
+        ap.v[q] = vi;
+        const float d = mi / c1 / (sqrtf(vi / c2) + ap.eps) * ap.lr;
+        ap.params[q] = ap.params[q] - d;
+        grad[q] = gi;
+    }
+    if (threadIdx.x == 0) {
+        ap.beta_pow[0] *= ap.b1;
+        ap.beta_pow[1] *= ap.b2;
+        __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+    }
+}
+
+static int grad_blocks(int num_tiles) {
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("RLHIP_GRAD_BLOCKS");
+        cap = e ? atoi(e) : 512;
+        if (cap < 1 || cap > MAX_GRAD_BLOCKS) cap = MAX_GRAD_BLOCKS;
+    }
+    return num_tiles < cap ? num_tiles : cap;
+}
+
+struct GradLaunch {
+    GradArgs g;
+    int nb, ns;
+    int64_t np;
+    unsigned int* counter;
+    double* sumsq;
+};
+
+static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
+                            const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace,
+                            GradLaunch* out) {
+    PolicyDesc pd;
+    int32_t rc = make_desc(kind, cfg, &pd);
+    if (rc) return rc;
+    RLHIP_REQUIRE(traj && params && workspace, "NULL argument");
+    RLHIP_REQUIRE(pd.h <= 256, "the fused gradient kernel supports hidden <= 256");
+    RLHIP_REQUIRE(pd.nout_a <= GMAXO, "the fused gradient kernel supports at most 3 actor outputs");
+    RLHIP_REQUIRE(n >= 1 && T >= 1 && n * T <= 0x7FFFFFFFll, "n * T out of range");
+    RLHIP_REQUIRE(cfg->n_microbatches >= 1 && mb >= 0 && mb < cfg->n_microbatches, "bad micro-batch index");
+    int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
+    int64_t np = pd.np_a + mlp2_nparams(ns, pd.h, 1);
+    uint32_t total = (uint32_t)(n * T);
+    uint32_t bm = total / (uint32_t)cfg->n_microbatches;
+    RLHIP_REQUIRE(bm >= 1, "micro-batch is empty");
+    GradArgs& g = out->g;
+    g.obs = traj->obs;
+    g.logp = traj->logp;
+    g.adv = traj->adv;
+    g.ret = traj->ret;
+    g.action_f = traj->action_f;
+    g.action_i = traj->action_i;
+    g.params = params;
+    g.n = n;
+    g.total = total;
+    g.bm = bm;
+    g.pos0 = (uint32_t)mb * bm;
+    g.num_tiles = (int)((bm + TILE - 1) / TILE);
+    g.np = (int)np;
+    g.pd = pd;
+    g.lo = 1.0f - cfg->clip_range;
+    g.hi = 1.0f + cfg->clip_range;
+    g.wa = cfg->actor_loss_weight;
+    g.wc = cfg->critic_loss_weight;
+    g.we = cfg->entropy_loss_weight;
+    g.inv_b = 1.0f / (float)bm;
+    g.min_logp = (float)log(1e-8);
+    g.seed = seed;
+    g.epoch_ctr = epoch_ctr;
+    out->nb = grad_blocks(g.num_tiles);
+    out->ns = ns;
+    out->np = np;
+    // workspace carve: partials [MAX][np] | loss_partials [MAX][4] | sumsq (doubles) | counter
+    g.partials = (float*)workspace;
+    g.loss_partials = g.partials + (int64_t)MAX_GRAD_BLOCKS * np;
+    uintptr_t q = (uintptr_t)(g.loss_partials + (int64_t)MAX_GRAD_BLOCKS * 4);
+    q = (q + 15) & ~(uintptr_t)15;
+    out->sumsq = (double*)q;
+    out->counter = (unsigned int*)(out->sumsq + 4096);
+    static int dbg_on = -1;
+    if (dbg_on < 0) dbg_on = getenv("RLHIP_GRAD_DEBUG") ? 1 : 0;
+    g.dbg = dbg_on ? (long long*)(out->counter + 16) : nullptr;
+    return RLHIP_OK;
+}
+
+static void launch_grad(const GradLaunch& L, hipStream_t s) {
+    size_t smem = grad_smem_bytes(L.g.pd.h);
+#define LAUNCH_G(NS_, ACT_) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_>), dim3(L.nb), dim3(256), smem, s, L.g)
+    const int a = L.g.pd.act;
+    if (L.ns == 4) { if (a == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
+    else if (L.ns == 3) { if (a == 0) LAUNCH_G(3, 0); else LAUNCH_G(3, 1); }
+    else { if (a == 0) LAUNCH_G(2, 0); else LAUNCH_G(2, 1); }
+#undef LAUNCH_G
+}
+
+}  // namespace rlhip
+
+using namespace rlhip;
+
+extern "C" {
+
+int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T) {
+    (void)n;
+    (void)T;
+    int64_t np = rlhip_ppo_nparams(kind, cfg);
+    if (np < 0) return -1;
+    return (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float) + 16 + 4096 * (int64_t)sizeof(double) + 64 +
+           (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long);
+}
+
+int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                           const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr,
+                           int32_t mb, void* workspace, float* grad_out, float* losses_out,
+                           rlhip_stream_t stream) {
+    RLHIP_REQUIRE(grad_out != nullptr, "grad_out is NULL");
+    GradLaunch L;
+    int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    launch_grad(L, s);
+    ApplyArgs ap{};
+    hipLaunchKernelGGL((reduce_apply_kernel<false>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
+                       L.g.loss_partials, L.nb, (int)L.np, grad_out, losses_out, L.g.wa, L.g.wc, L.g.we, L.g.inv_b,
+                       ap);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                             const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
+                             uint64_t seed, uint32_t update_ctr, void* workspace, float* grad_scratch,
+                             float* losses_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
+    hipStream_t s = as_stream(stream);
+    bool first = true;
+    for (int32_t e = 0; e < cfg->n_epochs; ++e) {
+        uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
+        for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
+            GradLaunch L;
+            int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L);
+            if (rc) return rc;
+            if (first) {  // arm the arrival counter once per call (re-armed in-kernel afterwards)
+                RLHIP_CHECK_HIP(hipMemsetAsync(L.counter, 0, sizeof(unsigned int), s));
+                first = false;
+            }
+            launch_grad(L, s);
+            ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
+                         L.counter, L.sumsq};
+            hipLaunchKernelGGL((reduce_apply_kernel<true>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s,
+                               L.g.partials, L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa,
+                               L.g.wc, L.g.we, L.g.inv_b, ap);
+        }
+    }
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+}  // extern "C"

@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void discount_kernel(T* __restrict__ out, cons
     if (REDUCED) out[sl] = gain;  // :262
 }
 
-// values: slice stride v_slice_stride (n1 + 1 for dims = 1), same element stride as rewards
-template <typename T, bool WITH_RETURNS>
+// values: slice stride v_slice_stride (n1 + 1 for dims = 1), same element stride as rewards.
+// The time axis is walked in register-staged chunks of CH steps: all loads of a chunk are issued
+// back to back (they do not depend on the recurrence), then the chunk is scanned -- one memory
+// latency per CH steps instead of one per step (the first version: 20 us for T = 32 on 64 waves).
+template <typename T, bool WITH_RETURNS, int CH>
 __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __restrict__ ret,
                                                   const T* __restrict__ r, const T* __restrict__ v,
                                                   const uint8_t* __restrict__ term, int64_t n_slices,
@@ -61,17 +64,34 @@ __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __rest
     T gae = (T)0;                         // :409
     T vnext = vp[len * elem_stride];      // V[T+1]
     const T gl = gamma * lambda;
-#pragma unroll 4
-    for (int64_t i = len - 1; i >= 0; --i) {
-        bool is_continue = tp ? !tp[i * elem_stride] : true;  // :411
-        T vi = vp[i * elem_stride];
-        T boot = strong_zero_mul(gamma * vnext, is_continue);
-        T delta = rp[i * elem_stride] + boot - vi;            // :412
-        T glc = strong_zero_mul(gl, is_continue);
-        gae = delta + glc * gae;                              // :413
-        adv[sl * slice_stride + i * elem_stride] = gae;       // :414
-        if (WITH_RETURNS) ret[sl * slice_stride + i * elem_stride] = gae + vi;
-        vnext = vi;
+    for (int64_t hi = len; hi > 0; hi -= CH) {
+        const int cnt = (int)((hi < CH) ? hi : CH);
+        T r_[CH], v_[CH];
+        uint8_t t_[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int64_t i = hi - 1 - c;
+            if (c < cnt) {
+                r_[c] = rp[i * elem_stride];
+                v_[c] = vp[i * elem_stride];
+                t_[c] = tp ? tp[i * elem_stride] : (uint8_t)0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c < cnt) {
+                const int64_t i = hi - 1 - c;
+                bool is_continue = !t_[c];                              // :411
+                T vi = v_[c];
+                T boot = strong_zero_mul(gamma * vnext, is_continue);
+                T delta = r_[c] + boot - vi;                            // :412
+                T glc = strong_zero_mul(gl, is_continue);
+                gae = delta + glc * gae;                                // :413
+                adv[sl * slice_stride + i * elem_stride] = gae;         // :414
+                if (WITH_RETURNS) ret[sl * slice_stride + i * elem_stride] = gae + vi;
+                vnext = vi;
+            }
+        }
     }
 }
 
@@ -124,10 +144,10 @@ static int32_t gae_impl(T* adv, T* ret, const T* r, const T* v, int64_t n1, int6
     if (g.n_slices == 0) return RLHIP_OK;
     dim3 grid((int)((g.n_slices + 255) / 256));
     if (ret)
-        hipLaunchKernelGGL((gae_kernel<T, true>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,
+        hipLaunchKernelGGL((gae_kernel<T, true, 128 / sizeof(T)>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,
                            g.len, g.elem_stride, g.slice_stride, g.v_slice_stride, gamma, lambda);
     else
-        hipLaunchKernelGGL((gae_kernel<T, false>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,
+        hipLaunchKernelGGL((gae_kernel<T, false, 128 / sizeof(T)>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,
                            g.len, g.elem_stride, g.slice_stride, g.v_slice_stride, gamma, lambda);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
