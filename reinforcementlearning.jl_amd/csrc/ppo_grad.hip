@@ -39,6 +39,7 @@ namespace rlhip {
 constexpr float LOG2PI_F = 1.8378770664093453f;  // log(2f0 * pi) as Float32 (RLCore/utils/distributions.jl:9)
 constexpr int TILE = 64;
 constexpr int MAX_GRAD_BLOCKS = 512;
+constexpr int NW = 8;     // waves per workgroup (per 64-sample tile)
 constexpr int GMAXO = 3;  // actor outputs handled by the fused gradient kernel (na <= 3, or (mu, log sigma))
 
 struct GradArgs {
@@ -49,6 +50,7 @@ struct GradArgs {
     const float* action_f;
     const int32_t* action_i;
     const float* params;
+    const float* packed;   // unit records: actor [h][8] | critic [h][8] | {b2a0, b2a1, b2a2, b2c}
     float* partials;       // [nb][np]
     float* loss_partials;  // [nb][4]
     int64_t n;
@@ -56,15 +58,23 @@ struct GradArgs {
     int num_tiles, np;
     PolicyDesc pd;
     float lo, hi, wa, wc, we, inv_b, min_logp;
-    uint64_t seed;
-    uint32_t epoch_ctr;
+    PermKeys pk;           // epoch permutation keys, evaluated on the host (2 Philox blocks)
     long long* dbg;  // optional per-block phase timestamps (s_memtime), 8 per block; NULL in production
 };
 
+// Phase timestamps are a compile-time option (-DRLHIP_GRAD_TIMING): a global store at kernel entry
+// makes every later uniform global load "possibly clobbered", which turns the s_load_dwordx8 record
+// fetches of phase 1 into per-lane global_load_dwordx4 (measured: 22 -> 29.6 us per launch).
+#ifdef RLHIP_GRAD_TIMING
 #define DBG_STAMP(k)                                                             \
     do {                                                                         \
         if (g.dbg && threadIdx.x == 0) g.dbg[(int64_t)blockIdx.x * 8 + (k)] = clock64(); \
     } while (0)
+#else
+#define DBG_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
 
 struct TileRegs {  // one sample's trajectory entries, held in registers one tile ahead
     float4 x;
@@ -88,79 +98,50 @@ __device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKe
 }
 
 template <int NS, int ACT>
-__global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
+__global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DBG_STAMP(0);
     const int h = g.pd.h;
-    // LDS carve (all 16-byte aligned): recA[h] | recC[h] | x[2][TILE] | misc[2][TILE] | part[4][TILE] | dL[TILE]
-    float4* recA = reinterpret_cast<float4*>(smem);          // 2 float4 per unit
-    float4* recC = recA + 2 * h;                             // 2 float4 per unit
-    float4* l_x = recC + 2 * h;                              // [2][TILE]
+    // LDS carve (all 16-byte aligned): x[2][TILE] | misc[2][TILE] | part[4][TILE] | dL[TILE]
+    float4* l_x = reinterpret_cast<float4*>(smem);           // [2][TILE]
     float4* l_misc = l_x + 2 * TILE;                         // [2][TILE]
-    float4* l_part = l_misc + 2 * TILE;                      // [4][TILE]  {a0, a1, a2, v} partial sums
-    float4* l_dL = l_part + 4 * TILE;                        // [TILE]     {dl0, dl1, dl2, dv}
+    float4* l_part = l_misc + 2 * TILE;                      // [8][TILE]  {a0, a1, a2, v} partial sums
+    float4* l_dL = l_part + NW * TILE;                       // [TILE]     {dl0, dl1, dl2, dv}
+    float* l_comb = reinterpret_cast<float*>(l_dL + TILE);   // [14][256] second-half accumulators
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nout = g.pd.nout_a;
-    const int hq = h >> 2;
-    const float* __restrict__ pa = g.params;
-    const float* __restrict__ pc = g.params + g.pd.np_a;
-    const float* W1a = pa;
-    const float* b1a = W1a + h * NS;
-    const float* W2a = b1a + h;
-    const float* b2a = W2a + nout * h;
-    const float* W1c = pc;
-    const float* b1c = W1c + h * NS;
-    const float* W2c = b1c + h;
-    const float* b2c = W2c + h;
+    const int hq = h / NW;               // hidden units per wave in phase 1a
+    const int uidx = tid & 255;          // phase 2: hidden unit of this thread
+    const int shalf = w >> 2;            // phase 2: which half of the tile's samples (0: 0..31, 1: 32..63)
+    const float* __restrict__ recA = (const float*)__builtin_assume_aligned(g.packed, 32);
+    const float* __restrict__ recC = recA + 8 * h;
+    const float* __restrict__ tailb = recC + 8 * h;
 
-    // ---- prologue: the first tile's scattered gather is issued FIRST so that its latency overlaps the
-    // weight-record loads; weight records -> LDS; this thread's unit (phase 2) -> registers ----
-    PermKeys pk = perm_keys(g.seed, g.epoch_ctr, g.total);
+    // ---- prologue: the first tile's scattered gather is issued first; this thread's unit (phase 2)
+    // comes from its two records ----
+    const PermKeys& pk = g.pk;
     int tile = blockIdx.x;
     TileRegs first;
     const bool first_loader = tid < TILE && tile < g.num_tiles;
     if (first_loader) first = fetch_sample<NS>(g, pk, tile, tid);
-    const bool owner = tid < h;
-    float rw1a[4] = {0.f, 0.f, 0.f, 0.f}, rw1c[4] = {0.f, 0.f, 0.f, 0.f}, rw2a[GMAXO] = {0.f, 0.f, 0.f};
-    float rb1a = 0.f, rb1c = 0.f, rw2c = 0.f;
-    for (int j = tid; j < h; j += blockDim.x) {
-        float a1[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f}, a2[GMAXO] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            a1[k] = W1a[j + h * k];
-            c1[k] = W1c[j + h * k];
-        }
-#pragma unroll
-        for (int o = 0; o < GMAXO; ++o)
-            if (o < nout) a2[o] = W2a[o + nout * j];
-        float ba = b1a[j], bc = b1c[j], wc2 = W2c[j];
-        recA[2 * j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-        recA[2 * j + 1] = make_float4(ba, a2[0], a2[1], a2[2]);
-        recC[2 * j] = make_float4(c1[0], c1[1], c1[2], c1[3]);
-        recC[2 * j + 1] = make_float4(bc, wc2, 0.f, 0.f);
-        if (j == tid) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                rw1a[k] = a1[k];
-                rw1c[k] = c1[k];
-            }
-#pragma unroll
-            for (int o = 0; o < GMAXO; ++o) rw2a[o] = a2[o];
-            rb1a = ba;
-            rb1c = bc;
-            rw2c = wc2;
-        }
-    }
+    const bool owner = uidx < h;
+    const int jown = owner ? uidx : 0;
+    const float4 oa0 = *reinterpret_cast<const float4*>(recA + 8 * jown);
+    const float4 oa1 = *reinterpret_cast<const float4*>(recA + 8 * jown + 4);
+    const float4 oc0 = *reinterpret_cast<const float4*>(recC + 8 * jown);
+    const float4 oc1 = *reinterpret_cast<const float4*>(recC + 8 * jown + 4);
+    const float rw1a[4] = {oa0.x, oa0.y, oa0.z, oa0.w}, rw1c[4] = {oc0.x, oc0.y, oc0.z, oc0.w};
+    const float rw2a[GMAXO] = {oa1.y, oa1.z, oa1.w};
+    const float rb1a = oa1.x, rb1c = oc1.x, rw2c = oc1.y;
     float gw1a[4] = {0.f, 0.f, 0.f, 0.f}, gw1c[4] = {0.f, 0.f, 0.f, 0.f}, gw2a[GMAXO] = {0.f, 0.f, 0.f};
     float gb1a = 0.f, gb1c = 0.f, gw2c = 0.f;
     // wave-0 per-sample-lane accumulators: output-bias gradients and loss sums
     float gb2a[GMAXO] = {0.f, 0.f, 0.f};
     float gb2c = 0.f, s_actor = 0.f, s_critic = 0.f, s_ent = 0.f;
-    const float b2a0 = (0 < nout) ? b2a[0] : 0.f, b2a1 = (1 < nout) ? b2a[1] : 0.f, b2a2 = (2 < nout) ? b2a[2] : 0.f;
-    const float b2cv = b2c[0];
+    const float b2a0 = tailb[0], b2a1 = tailb[1], b2a2 = tailb[2], b2cv = tailb[3];
 
     int buf = 0;
     if (first_loader) {
@@ -184,8 +165,13 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accv = 0.f;
 #pragma unroll 8
             for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
-                const float4 wa_ = recA[2 * jj], ra_ = recA[2 * jj + 1];
-                const float4 wc_ = recC[2 * jj], rc_ = recC[2 * jj + 1];
+                // wave-uniform addresses: these become s_load_dwordx8 (SGPR operands of the FMAs below)
+                const float* pa_ = recA + 8 * jj;
+                const float* pc_ = recC + 8 * jj;
+                const float4 wa_ = make_float4(pa_[0], pa_[1], pa_[2], pa_[3]);
+                const float4 ra_ = make_float4(pa_[4], pa_[5], pa_[6], pa_[7]);
+                const float4 wc_ = make_float4(pc_[0], pc_[1], pc_[2], pc_[3]);
+                const float4 rc_ = make_float4(pc_[4], pc_[5], pc_[6], pc_[7]);
                 float za = ra_.x, zc = rc_.x;
                 za = fmaf(wa_.x, xv.x, za);
                 zc = fmaf(wc_.x, xv.x, zc);
@@ -215,12 +201,20 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
         if (w == 0) {
             const int s = lane;
             const bool valid = ((uint32_t)tile * TILE + (uint32_t)s) < g.bm;
-            const float4 p0 = l_part[s], p1 = l_part[TILE + s], p2 = l_part[2 * TILE + s], p3 = l_part[3 * TILE + s];
+            float4 ps = l_part[s];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) {  // fixed summation order over the NW waves' partial sums
+                const float4 pq = l_part[q * TILE + s];
+                ps.x += pq.x;
+                ps.y += pq.y;
+                ps.z += pq.z;
+                ps.w += pq.w;
+            }
             float oa[GMAXO], dl[GMAXO] = {0.f, 0.f, 0.f};
-            oa[0] = (((p0.x + p1.x) + p2.x) + p3.x) + b2a0;
-            oa[1] = (((p0.y + p1.y) + p2.y) + p3.y) + b2a1;
-            oa[2] = (((p0.z + p1.z) + p2.z) + p3.z) + b2a2;
-            const float v = (((p0.w + p1.w) + p2.w) + p3.w) + b2cv;
+            oa[0] = ps.x + b2a0;
+            oa[1] = ps.y + b2a1;
+            oa[2] = ps.z + b2a2;
+            const float v = ps.w + b2cv;
             const float4 mi = cm[s];
             const float lp_old = fmaxf(mi.x, g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
             const float A = mi.y;
@@ -298,7 +292,7 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
         // ---- phase 2: lane = hidden unit j; the tile's samples stream from LDS (broadcast reads) ----
         if (owner) {
 #pragma unroll 4
-            for (int s = 0; s < TILE; ++s) {
+            for (int s = shalf * (TILE / 2); s < (shalf + 1) * (TILE / 2); ++s) {
                 const float4 xv = cx[s];
                 const float4 d = l_dL[s];
                 float za = rb1a, zc = rb1c;
@@ -355,9 +349,39 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
     }
 
     // ---- epilogue: this workgroup's partial gradient (fixed layout = parameter layout) ----
+    // waves 4..7 (second half of the samples) hand their accumulators to waves 0..3 through LDS
+    if (shalf == 1) {
+        float* c = l_comb + uidx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[(k)*256] = gw1a[k];
+            c[(4 + k) * 256] = gw1c[k];
+        }
+        c[8 * 256] = gb1a;
+        c[9 * 256] = gb1c;
+        c[10 * 256] = gw2a[0];
+        c[11 * 256] = gw2a[1];
+        c[12 * 256] = gw2a[2];
+        c[13 * 256] = gw2c;
+    }
+    __syncthreads();
+    if (shalf == 0) {
+        const float* c = l_comb + uidx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gw1a[k] += c[(k)*256];
+            gw1c[k] += c[(4 + k) * 256];
+        }
+        gb1a += c[8 * 256];
+        gb1c += c[9 * 256];
+        gw2a[0] += c[10 * 256];
+        gw2a[1] += c[11 * 256];
+        gw2a[2] += c[12 * 256];
+        gw2c += c[13 * 256];
+    }
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
-    if (owner) {
-        const int j = tid;
+    if (owner && shalf == 0) {
+        const int j = uidx;
         float* oa_ = out;
         float* oc_ = out + g.pd.np_a;
 #pragma unroll
@@ -395,7 +419,51 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(GradArgs g) {
     DBG_STAMP(5);
 }
 
-static size_t grad_smem_bytes(int h) { return sizeof(float4) * (size_t)(4 * h + 2 * TILE + 2 * TILE + 4 * TILE + TILE); }
+static size_t grad_smem_bytes(int h) {
+    (void)h;
+    return sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE) + sizeof(float) * 14 * 256;
+}
+
+// unit records {W1[j,0..3], b1[j], W2[0..2,j]} per net + the output biases; any thread count
+__device__ __forceinline__ void pack_records(const float* __restrict__ params, float* __restrict__ packed, int h,
+                                             int ns, int nout, int64_t np_a, int tid, int nthreads) {
+    const float* W1a = params;
+    const float* b1a = W1a + h * ns;
+    const float* W2a = b1a + h;
+    const float* b2a = W2a + nout * h;
+    const float* W1c = params + np_a;
+    const float* b1c = W1c + h * ns;
+    const float* W2c = b1c + h;
+    const float* b2c = W2c + h;
+    for (int q = tid; q < 2 * h; q += nthreads) {
+        const int net = q / h, j = q - net * h;
+        float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (net == 0) {
+            for (int k = 0; k < ns; ++k) rec[k] = W1a[j + h * k];
+            rec[4] = b1a[j];
+            for (int o = 0; o < nout; ++o) rec[5 + o] = W2a[o + nout * j];
+        } else {
+            for (int k = 0; k < ns; ++k) rec[k] = W1c[j + h * k];
+            rec[4] = b1c[j];
+            rec[5] = W2c[j];
+        }
+        float4* dst = reinterpret_cast<float4*>(packed + 8 * (int64_t)q);
+        dst[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        dst[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    }
+    if (tid == 0) {
+        float* t = packed + 16 * (int64_t)h;
+        t[0] = (0 < nout) ? b2a[0] : 0.f;
+        t[1] = (1 < nout) ? b2a[1] : 0.f;
+        t[2] = (2 < nout) ? b2a[2] : 0.f;
+        t[3] = b2c[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ packed,
+                                                          int h, int ns, int nout, int64_t np_a) {
+    pack_records(params, packed, h, ns, nout, np_a, threadIdx.x, blockDim.x);
+}
 
 // ------------------------------------------------------------------------- reduce (+ apply) ----
 struct ApplyArgs {
@@ -406,6 +474,9 @@ struct ApplyArgs {
     float clip_norm, lr, b1, b2, eps;
     unsigned int* counter;  // arrival counter (device), zero between launches
     double* sumsq;          // [gridDim] per-block partial sums of squares
+    float* packed;          // unit records to refresh after the step
+    int h, ns, nout;
+    int64_t np_a;
 };
 
 // grad[p] = sum_b partials[b][p] (fixed order); losses folded by block 0.
@@ -515,6 +586,8 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         ap.params[q] = ap.params[q] - d;
         grad[q] = gi;
     }
+    __syncthreads();  // this workgroup's parameter stores are visible to its own later loads
+    pack_records(ap.params, ap.packed, ap.h, ap.ns, ap.nout, ap.np_a, threadIdx.x, blockDim.x);
     if (threadIdx.x == 0) {
         ap.beta_pow[0] *= ap.b1;
         ap.beta_pow[1] *= ap.b2;
@@ -538,6 +611,7 @@ struct GradLaunch {
     int64_t np;
     unsigned int* counter;
     double* sumsq;
+    float* packed;
 };
 
 static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
@@ -547,7 +621,7 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;
     RLHIP_REQUIRE(traj && params && workspace, "NULL argument");
-    RLHIP_REQUIRE(pd.h <= 256, "the fused gradient kernel supports hidden <= 256");
+    RLHIP_REQUIRE(pd.h <= 256 && pd.h % NW == 0, "the fused gradient kernel supports hidden <= 256, multiple of 8");
     RLHIP_REQUIRE(pd.nout_a <= GMAXO, "the fused gradient kernel supports at most 3 actor outputs");
     RLHIP_REQUIRE(n >= 1 && T >= 1 && n * T <= 0x7FFFFFFFll, "n * T out of range");
     RLHIP_REQUIRE(cfg->n_microbatches >= 1 && mb >= 0 && mb < cfg->n_microbatches, "bad micro-batch index");
@@ -578,8 +652,7 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     g.we = cfg->entropy_loss_weight;
     g.inv_b = 1.0f / (float)bm;
     g.min_logp = (float)log(1e-8);
-    g.seed = seed;
-    g.epoch_ctr = epoch_ctr;
+    g.pk = perm_keys(seed, epoch_ctr, total);
     out->nb = grad_blocks(g.num_tiles);
     out->ns = ns;
     out->np = np;
@@ -592,18 +665,28 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     out->counter = (unsigned int*)(out->sumsq + 4096);
     static int dbg_on = -1;
     if (dbg_on < 0) dbg_on = getenv("RLHIP_GRAD_DEBUG") ? 1 : 0;
-    g.dbg = dbg_on ? (long long*)(out->counter + 16) : nullptr;
+    long long* dbgp = (long long*)(out->counter + 16);
+    g.dbg = dbg_on ? dbgp : nullptr;
+    uintptr_t pq = (uintptr_t)(dbgp + (int64_t)MAX_GRAD_BLOCKS * 8);
+    pq = (pq + 63) & ~(uintptr_t)63;
+    out->packed = (float*)pq;
+    g.packed = out->packed;
     return RLHIP_OK;
 }
 
 static void launch_grad(const GradLaunch& L, hipStream_t s) {
     size_t smem = grad_smem_bytes(L.g.pd.h);
-#define LAUNCH_G(NS_, ACT_) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_>), dim3(L.nb), dim3(256), smem, s, L.g)
+#define LAUNCH_G(NS_, ACT_) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_>), dim3(L.nb), dim3(64 * NW), smem, s, L.g)
     const int a = L.g.pd.act;
     if (L.ns == 4) { if (a == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
     else if (L.ns == 3) { if (a == 0) LAUNCH_G(3, 0); else LAUNCH_G(3, 1); }
     else { if (a == 0) LAUNCH_G(2, 0); else LAUNCH_G(2, 1); }
 #undef LAUNCH_G
+}
+
+static void launch_pack(const GradLaunch& L, hipStream_t s) {
+    hipLaunchKernelGGL(pack_params_kernel, dim3(1), dim3(256), 0, s, L.g.params, L.packed, L.g.pd.h, L.ns,
+                       L.g.pd.nout_a, L.g.pd.np_a);
 }
 
 }  // namespace rlhip
@@ -618,7 +701,7 @@ int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
     int64_t np = rlhip_ppo_nparams(kind, cfg);
     if (np < 0) return -1;
     return (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float) + 16 + 4096 * (int64_t)sizeof(double) + 64 +
-           (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long);
+           (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long) + 64 + (16 * 256 + 8) * (int64_t)sizeof(float);
 }
 
 int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
@@ -630,6 +713,7 @@ int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, in
     int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L);
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
+    launch_pack(L, s);
     launch_grad(L, s);
     ApplyArgs ap{};
     hipLaunchKernelGGL((reduce_apply_kernel<false>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
@@ -652,13 +736,15 @@ int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, 
             GradLaunch L;
             int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L);
             if (rc) return rc;
-            if (first) {  // arm the arrival counter once per call (re-armed in-kernel afterwards)
+            if (first) {  // arm the arrival counter and pack the unit records once per call; the Adam tail
+                          // re-arms the counter and refreshes the records after every step
                 RLHIP_CHECK_HIP(hipMemsetAsync(L.counter, 0, sizeof(unsigned int), s));
+                launch_pack(L, s);
                 first = false;
             }
             launch_grad(L, s);
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
-                         L.counter, L.sumsq};
+                         L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
             hipLaunchKernelGGL((reduce_apply_kernel<true>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s,
                                L.g.partials, L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa,
                                L.g.wc, L.g.we, L.g.inv_b, ap);

@@ -14,7 +14,7 @@ torch.cuda.synchronize()
 np_ = pol.np
 off = 512 * (np_ + 4) * 4
 off = (off + 15) & ~15
-off += 4096 * 8 + 16 * 4
+off += 4096 * 8 + 16 * 4  # sumsq + counter pad
 ws = pol.workspace
 dbg = ws[off: off + 512 * 8 * 8].view(torch.int64).cpu().numpy().reshape(512, 8)
 t0 = dbg[:, 0].min()
