@@ -6,6 +6,12 @@ from . import _lib  # noqa: F401  (raises ImportError when librlhip.so is absent
 from ._lib import RLHipArgumentError, RLHipError  # noqa: F401
 from .envs import (CartPoleEnv, ContinuousMountainCarEnv, HipVecEnv, MountainCarEnv,  # noqa: F401
                    PendulumEnv, Space)
+from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DoEveryNSteps, EmptyHook,  # noqa: F401
+                   PPOAgent, RandomPolicy, StepsPerEpisode, StopAfterNEpisodes, StopAfterNSeconds,
+                   StopAfterNSteps, StopIfAll, StopIfAny, TimePerStep, TotalBatchRewardPerEpisode, run,
+                   run_fused_ppo)
+from .dqn import (DQNLearner, EpsilonGreedyExplorer, GreedyExplorer, HipApproximator,  # noqa: F401
+                  QBasedPolicy, TargetNetwork)
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
 from .trajectory import (BatchSampler, CircularArraySARTSTraces,  # noqa: F401
                          InsertSampleRatioController, Trajectory)

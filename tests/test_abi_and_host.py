@@ -1,0 +1,167 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/rlhip.h declares, argument
+validation reports errors the documented way (no compute is launched: there is no GPU here), and the
+host-side logic of the mirror (stop conditions, controllers, explorer schedule) follows the reference."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+import rlhip
+from rlhip import _lib
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 60
+    missing = [s for s in syms if not hasattr(_lib.lib, s)]
+    assert not missing, missing
+    # and every declared function has a ctypes prototype in the Python glue
+    assert not [s for s in syms if s not in _lib._PROTOS]
+
+
+def test_abi_version_and_error_reporting():
+    assert _lib.lib.rlhip_abi_version() == 1
+    # argument validation happens before any HIP call: NULL output pointer -> RLHIP_EINVAL + message
+    with pytest.raises(_lib.RLHipArgumentError) as e:
+        _lib.call("rlhip_fill_uniform_f32", None, 16, 0, 0, 0, None)
+    assert "invalid argument" in str(e.value)
+    rc = _lib.lib.rlhip_env_reset(7, 0, None, None, 1, 0, 0, None, None)
+    assert rc == -1 and b"kind" in _lib.lib.rlhip_last_error()
+
+
+def test_struct_layouts_match_header():
+    """sizeof of the POD structs as the C compiler sees them (guards the ctypes mirrors)."""
+    import subprocess
+    import tempfile
+
+    src = r'''
+    #include <stdio.h>
+    #include "rlhip.h"
+    int main(void) {
+        printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(rlhip_cartpole_cfg), sizeof(rlhip_pendulum_cfg),
+               sizeof(rlhip_mountaincar_cfg), sizeof(rlhip_env_state), sizeof(rlhip_ring), sizeof(rlhip_ppo_cfg),
+               sizeof(rlhip_ppo_traj));
+        return 0;
+    }'''
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "t.c"), "w") as f:
+            f.write(src)
+        subprocess.run(["gcc", "-I", inc, os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    sizes = [int(x) for x in out]
+    mirrors = [_lib.CartPoleCfg, _lib.PendulumCfg, _lib.MountainCarCfg, _lib.EnvState, _lib.Ring, _lib.PPOCfg,
+               _lib.PPOTraj]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_default_configs_match_reference_defaults():
+    c = _lib.CartPoleCfg()
+    _lib.call("rlhip_cartpole_default", C.byref(c))
+    # CartPoleEnv.jl:22-32
+    assert (c.gravity, c.masscart, c.masspole, c.halflength, c.forcemag, c.dt, c.thetathreshold_deg, c.xthreshold,
+            c.max_steps) == (9.8, 1.0, 0.1, 0.5, 10.0, 0.02, 12.0, 2.4, 200)
+    p = _lib.PendulumCfg()
+    _lib.call("rlhip_pendulum_default", C.byref(p))
+    assert (p.max_speed, p.max_torque, p.g, p.m, p.l, p.dt, p.max_steps, p.continuous, p.n_actions) == \
+        (8, 2, 10, 1, 1, 0.05, 200, 1, 3)  # PendulumEnv.jl:41-53
+    m = _lib.MountainCarCfg()
+    _lib.call("rlhip_mountaincar_default", C.byref(m), 0)
+    assert (m.min_pos, m.max_pos, m.max_speed, m.goal_pos, m.power, m.gravity) == (-1.2, 0.6, 0.07, 0.5, 0.001, 0.0025)
+    _lib.call("rlhip_mountaincar_default", C.byref(m), 1)
+    assert (m.goal_pos, m.power) == (0.45, 0.0015)  # MountainCarEnv.jl:74
+    q = _lib.PPOCfg()
+    _lib.call("rlhip_ppo_default", C.byref(q))
+    # blog index.html:15257-15278
+    assert (round(q.gamma, 6), round(q.lam, 6), round(q.clip_range, 6), round(q.max_grad_norm, 6), q.n_epochs,
+            q.n_microbatches, q.hidden) == (0.99, 0.95, 0.1, 0.5, 4, 4, 256)
+    assert _lib.lib.rlhip_ppo_nparams(0, C.byref(q)) == 3331  # 3 331 parameters
+    assert _lib.lib.rlhip_mlp2_nparams(4, 128, 2) == 4 * 128 + 128 + 2 * 128 + 2
+
+
+def test_get_eps_host_function_golden():
+    with open(os.path.join(G, "select.json")) as f:
+        S = json.load(f)
+    p = S["get_eps_params"]
+    for case in S["get_eps"]:
+        e = _lib.lib.rlhip_get_eps(0 if case["kind"] == "linear" else 1, p["eps_stable"], p["eps_init"],
+                                   p["warmup_steps"], p["decay_steps"], case["step"])
+        assert abs(e - case["expect"]) <= case.get("atol", 1e-12), case["src"]
+    ex = rlhip.EpsilonGreedyExplorer(0.1, kind="exp", eps_init=0.9, warmup_steps=100, decay_steps=100)
+    assert ex.get_eps(150) == pytest.approx(0.5852245277701068)
+    # EpsilonGreedyExplorer(eps): linear, eps_init 1.0, warmup = decay = 0 -> always eps_stable (:47-78)
+    assert rlhip.EpsilonGreedyExplorer(0.3).get_eps(1) == 0.3
+
+
+def test_stop_after_n_steps_golden():
+    with open(os.path.join(G, "select.json")) as f:
+        c = json.load(f)["stop_after_n_steps"]
+    s = rlhip.StopAfterNSteps(c["n"])
+    assert sum(bool(s.check_()) for _ in range(c["calls"])) == c["n_true"]  # core/stop_conditions.jl:8
+    a, b = rlhip.StopAfterNSteps(3), rlhip.StopAfterNSteps(5)
+    any_, all_ = rlhip.StopIfAny(a, b), rlhip.StopIfAll(rlhip.StopAfterNSteps(3), rlhip.StopAfterNSteps(5))
+    assert [any_.check_(None, None) for _ in range(4)] == [False, False, True, True]
+    assert [all_.check_(None, None) for _ in range(6)] == [False, False, False, False, True, True]
+
+
+def test_insert_sample_ratio_controller():
+    c = rlhip.InsertSampleRatioController(ratio=0.5, threshold=4)
+    allowed = []
+    for _ in range(10):
+        c.on_insert_(1)
+        allowed.append(c.on_sample_())
+    # nothing before 4 inserts; afterwards n_sampled <= (n_inserted - threshold) * ratio
+    assert allowed[:3] == [False, False, False]
+    assert allowed[3] is True and c.n_sampled <= (c.n_inserted - 4) * 0.5 + 1
+
+
+def test_target_network_counter_logic():
+    # TargetNetwork.optimise! counter semantics (target_network.jl:74-86) without touching the device
+    class FakeNet:
+        def __init__(self):
+            self.params = None
+            self.calls = 0
+
+        def optimise_(self, grad, **kw):
+            self.calls += 1
+
+    tn = rlhip.TargetNetwork.__new__(rlhip.TargetNetwork)
+    tn.network, tn.sync_freq, tn.rho, tn.n_optimise, tn.target = FakeNet(), 3, 0.0, 0, None
+    synced = []
+    import rlhip.ops as ops
+
+    orig = ops.polyak_
+    ops.polyak_ = lambda dst, src, rho: synced.append(tn.network.calls)
+    try:
+        seen = []
+        for _ in range(4):
+            tn.optimise_(None)
+            seen.append(tn.n_optimise)
+    finally:
+        ops.polyak_ = orig
+    assert seen == [1, 2, 0, 1] and synced == [3]  # golden: tests/golden/select.json target_sync
+    with pytest.raises(AssertionError):
+        rlhip.TargetNetwork(FakeNet(), rho=1.5)
+
+
+def test_space_membership():
+    sp = rlhip.Space(n=2)
+    assert [1, 2] in sp and [0] not in sp and [3] not in sp and len(sp) == 2
+    box = rlhip.Space([-2.0], [2.0])
+    assert [0.5] in box and [2.5] not in box
+
+
+def test_no_cpu_fallback_in_product_sources():
+    """The product package never imports the oracle and has no CPU fallback path."""
+    pkg = os.path.dirname(rlhip.__file__)
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle", src, re.M), fn
+    csrc = os.path.join(os.path.dirname(pkg), "csrc")
+    for fn in os.listdir(csrc):
+        assert "rl_oracle" not in open(os.path.join(csrc, fn)).read(), fn
