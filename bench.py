@@ -83,8 +83,72 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
             "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1)}
 
 
+def roofline_extras(torch, rlhip):
+    """HBM-bound side kernels at sizes where HBM matters: GAE scan, u8 frame gather (BASELINE config 5 shape,
+    capacity scaled to 2^16 slots = 1.85 GB), and the DQN learner step of BASELINE config 1."""
+    from rlhip import ops
+    from rlhip.ops import stream_ptr
+    from rlhip.trajectory import CircularArraySARTSTraces
+
+    lib, s = rlhip._lib.lib, stream_ptr()
+    out = {}
+    # GAE + returns, N = 2^20 envs x T = 32: 17 B per (env, t) + 4 B per env
+    n, T = 1 << 20, 32
+    r = torch.rand((T, n), device="cuda") * -16
+    v = torch.randn((T + 1, n), device="cuda")
+    term = torch.rand((T, n), device="cuda") < 1 / 200
+    ops.gae_returns(r, v, term, 0.99, 0.95)
+    ms = event_time_ms(lambda: ops.gae_returns(r, v, term, 0.99, 0.95), 10, lib, s)
+    gb = (17 * n * T + 4 * n) / 1e9
+    out["gae_returns"] = {"bound": "hbm", "n_envs": n, "T": T, "us_per_launch": round(ms * 1e3, 1),
+                          "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+    del r, v, term
+    # u8 frame gather: 84x84x4 frames, batch 4096 -> 2 * (2 * 28224 + 9) B per sample
+    fb, cap, batch = 84 * 84 * 4, 1 << 16, 4096
+    tr = CircularArraySARTSTraces(capacity=cap, n_env=1, obs_dim=fb, dtype=torch.uint8)
+    tr.state.random_(0, 256)
+    tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap  # mark the ring full (synthetic frames, no push loop needed)
+    idx = tr.sample_indices(batch, seed=11, draw_ctr=0)
+    tr.gather(idx)
+    bufs = tr.gather(idx)
+
+    def g():
+        rlhip._lib.call("rlhip_ring_gather", C.byref(tr.rb), ops.ptr(idx), batch, ops.ptr(bufs[0]), ops.ptr(bufs[1]),
+                        ops.ptr(bufs[2]), ops.ptr(bufs[3]), ops.ptr(bufs[4]), s)
+
+    ms = event_time_ms(g, 10, lib, s)
+    gb = 2 * (2 * fb + 9) * batch / 1e9
+    out["frame_gather_u8"] = {"bound": "hbm", "capacity": cap, "frame_bytes": fb, "batch": batch,
+                              "us_per_launch": round(ms * 1e3, 1), "achieved": round(gb / (ms * 1e-3), 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4),
+                              "samples_per_sec": round(batch / (ms * 1e-3), 1)}
+    del tr, bufs, idx
+    torch.cuda.empty_cache()
+    # BASELINE configs[1]: 4096-way CartPole + QBasedPolicy(DQN, 4->128->2), batch 512, 1 update per vec-step
+    n = N_ENVS
+    env = rlhip.CartPoleEnv(n, seed=5)
+    net = rlhip.HipApproximator(4, 128, 2, seed=5)
+    learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=100), batchsize=512, min_replay_history=n, seed=5)
+    policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.01, kind="exp", decay_steps=500, seed=5))
+    agent = rlhip.Agent(policy, rlhip.Trajectory(CircularArraySARTSTraces(capacity=256, n_env=n, obs_dim=4)))
+    rlhip.run(agent, env, rlhip.StopAfterNSteps(20))
+    torch.cuda.synchronize()
+    steps = 300
+    t0 = time.perf_counter()
+    rlhip.run(agent, env, rlhip.StopAfterNSteps(steps))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out["dqn_cartpole_4096env"] = {"env_steps_per_sec": round(n * steps / el, 1), "updates_per_sec": round(steps / el, 1),
+                                   "ms_per_vec_step": round(el / steps * 1e3, 4), "batch": 512,
+                                   "note": "per-step drop-in protocol (plan!/act!/push!/optimise! = 6 launches per vec-step, eager)"}
+    return out
+
+
 def kernel_breakdown(torch, rlhip, pol, env):
-    """Mean launch time of each kernel class of the workload (same shapes as the timed region)."""
+    """Device time of the three enqueue units of one step (HIP events on the launch stream).  Each unit is
+    ONE C-ABI call, so the numbers are not host-paced: rollout (1 launch), GAE (1 launch), update
+    (pack + n_epochs x n_microbatches x {grad kernel, reduce+clip+Adam kernel})."""
     from rlhip.ops import stream_ptr
 
     s = stream_ptr()
@@ -92,15 +156,18 @@ def kernel_breakdown(torch, rlhip, pol, env):
     out = {}
     saved = [t.clone() for t in (pol.params, pol.m, pol.v, pol.beta_pow)]
     out["rollout_T32_us"] = round(event_time_ms(pol.rollout_, 5, lib, s) * 1e3, 2)
-    out["gae_returns_us"] = round(event_time_ms(pol.gae_, 20, lib, s) * 1e3, 2)
-    out["grad_plus_reduce_us"] = round(event_time_ms(lambda: pol.grad_(0, 0), 20, lib, s) * 1e3, 2)
-    out["clip_adam_us"] = round(event_time_ms(lambda: pol.apply_(1.0), 20, lib, s) * 1e3, 2)
+    out["gae_returns_us"] = round(event_time_ms(pol.gae_, 5, lib, s) * 1e3, 2)
+    n_upd = pol.n_updates_per_call()
+    upd_ms = event_time_ms(pol.update_, 5, lib, s)
+    out["update_us"] = round(upd_ms * 1e3, 2)
+    out["per_microbatch_us"] = round(upd_ms * 1e3 / n_upd, 2)
     for t, sv in zip((pol.params, pol.m, pol.v, pol.beta_pow), saved):
         t.copy_(sv)
-    # f32 flops of one gradient launch: forward 2*h*((ns+nout_a)+(ns+1)) per sample, x3 with backward
+    # f32 flops of one micro-batch: forward 2*h*((ns+nout_a)+(ns+1)) per sample, x3 with backward
     bm = (env.n * pol.T) // pol.cfg.n_microbatches
     flops = 3 * 2 * pol.cfg.hidden * ((env.odim + pol.na) + (env.odim + 1)) * bm
-    out["grad_tflops_f32"] = round(flops / (out["grad_plus_reduce_us"] * 1e-6) / 1e12, 2)
+    out["learner_tflops_f32"] = round(flops / (out["per_microbatch_us"] * 1e-6) / 1e12, 2)
+    out["learner_f32_peak_tflops"] = 157.3
     return out
 
 
@@ -220,6 +287,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         result["kernels"] = kernel_breakdown(torch, rlhip, pol, env)
         result["roofline"] = roofline_env_step(torch, rlhip)
+        result["roofline_extra"] = roofline_extras(torch, rlhip)
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result), flush=True)
