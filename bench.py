@@ -125,6 +125,25 @@ def roofline_extras(torch, rlhip):
                               "samples_per_sec": round(batch / (ms * 1e-3), 1)}
     del tr, bufs, idx
     torch.cuda.empty_cache()
+    # bf16 MFMA Dense layer (hidden x hidden), batch = one PPO trajectory (131072 rows), 256 -> 256, fused bias + relu
+    Bm, Km, Nm = N_ENVS * T_ROLLOUT, 256, 256
+    xr = torch.randn((Bm, Km), device="cuda").to(torch.bfloat16)
+    wt = (torch.randn((Nm, Km), device="cuda") / 16).to(torch.bfloat16)
+    bias = torch.randn(Nm, device="cuda")
+    y = torch.empty((Bm, Nm), dtype=torch.bfloat16, device="cuda")
+
+    def mf():
+        rlhip._lib.call("rlhip_dense_bf16_forward", ops.ptr(xr), ops.ptr(wt), ops.ptr(bias), 0, Bm, Km, Nm, ops.ptr(y), 1, s)
+
+    for _ in range(3):
+        mf()
+    ms = event_time_ms(mf, 20, lib, s)
+    tf = 2.0 * Bm * Km * Nm / (ms * 1e-3) / 1e12
+    out["dense_bf16_mfma"] = {"bound": "mfma", "kernel": "dense_mfma_kernel<relu,bf16> (v_mfma_f32_32x32x16_bf16)",
+                              "batch": Bm, "k": Km, "n": Nm, "us_per_launch": round(ms * 1e3, 1),
+                              "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                              "note": "first correct version: fragment loads straight from global/L1, no LDS staging"}
+    del xr, wt, y
     # BASELINE configs[1]: 4096-way CartPole + QBasedPolicy(DQN, 4->128->2), batch 512, 1 update per vec-step
     n = N_ENVS
     env = rlhip.CartPoleEnv(n, seed=5)

@@ -1,0 +1,171 @@
+// dense_mfma.hip -- bf16 MFMA path for the GEMM-shaped layers of the actor / critic / Q MLPs:
+//     Y = act(X * W + b),  X (B x K) activations, W (K x N) = a Flux Dense weight, f32 accumulate.
+//
+// Replaces `FluxApproximator.forward` = `A.model(x)` (RLCore/policies/learners/flux_approximator.jl:43) ->
+// Flux `Dense` (NNlib dense + bias + activation) for hidden x hidden layers, e.g. the blog's DQN net
+// 4 -> 128 -> 128 -> 2 (a_practical_introduction_to_RL.jl/index.html:15126-15128) and BASELINE config 3's
+// "actor/critic MLP in bf16 MFMA".  The ns -> h first layers (K <= 4) and h -> nout heads (N <= 3) stay on
+// the VALU (mlp_device.h): they are far below an MFMA tile.
+//
+// Kernel: v_mfma_f32_32x32x16_bf16 (gfx950), one wave = 32 batch rows x 128 output features (4
+// accumulators of 32x32 f32, 64 acc registers), 4 waves per workgroup = 128 rows.  Operand layout is
+// chosen so that every MFMA fragment is ONE 16-byte global load per lane, no LDS transposition:
+//   A fragment (32 x 16): lane l holds X[row = l & 31][k0 + 8 * (l >> 5) .. +7]   -> X row-major bf16
+//   B fragment (16 x 32): lane l holds W[k0 + 8 * (l >> 5) .. +7][col = l & 31]   -> W stored TRANSPOSED
+//                                                                                    (Wt[n][k], k contiguous)
+//   C/D: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)           (MI355X guide section 3)
+// The 4 waves of a workgroup read identical Wt fragments in lock-step (L1 hits); X is streamed once per
+// 128-column block.  Epilogue fuses bias + activation + the bf16 / f32 store.
+// Roofline: MFMA (dense bf16 peak ~2.5 PFLOP/s); 2*B*K*N flop per launch.  This first version has no LDS
+// staging / software pipelining -- measured numbers in profiles/ and DESIGN.md; it is the parity-checked
+// starting point for the tuned kernel, not the end state.
+#include "common.h"
+
+namespace rlhip {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+constexpr int NT = 4;  // 32-column blocks per wave (128 output features)
+
+template <int ACT, bool OUT_BF16>
+__global__ __launch_bounds__(256) void dense_mfma_kernel(const uint16_t* __restrict__ X,
+                                                         const uint16_t* __restrict__ Wt,
+                                                         const float* __restrict__ bias, int64_t B, int K, int N,
+                                                         void* __restrict__ Yv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int col0 = blockIdx.y * (32 * NT);
+    if (row0 >= B) return;
+    const int r = lane & 31, kb = lane >> 5;
+    const uint16_t* xa = X + (row0 + r) * (int64_t)K + 8 * kb;
+    const uint16_t* wb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wb[t] = Wt + (int64_t)(col0 + 32 * t + r) * K + 8 * kb;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + k0);
+        bf16x8 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const bf16x8*>(wb[t] + k0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[t], acc[t], 0, 0, 0);
+    }
+    // epilogue: bias + activation, store.  Lane holds column (col0 + 32 t + (lane & 31)), 16 rows.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = col0 + 32 * t + r;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t row = row0 + (q & 3) + 8 * (q >> 2) + 4 * kb;
+            float y = acc[t][q] + bv;
+            if (ACT == 0) y = fmaxf(y, 0.0f);
+            else if (ACT == 1) y = tanhf(y);
+            if (OUT_BF16) reinterpret_cast<uint16_t*>(Yv)[row * N + col] = f32_to_bf16_rne(y);
+            else reinterpret_cast<float*>(Yv)[row * N + col] = y;
+        }
+    }
+}
+
+// f32 SoA activations (K x B, batch contiguous) -> bf16 rows (B x Kpad), zero padded to Kpad
+__global__ __launch_bounds__(256) void soa_to_bf16_rows_kernel(const float* __restrict__ x, int64_t B, int K,
+                                                               int Kpad, uint16_t* __restrict__ out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int k = 0; k < Kpad; ++k) out[b * Kpad + k] = (k < K) ? f32_to_bf16_rne(x[(int64_t)k * B + b]) : (uint16_t)0;
+}
+
+// Flux Dense weight (N out x K in, column-major: w[o + N * i]) -> Wt[n][k] bf16 (k contiguous), zero padded
+__global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __restrict__ w, int K, int N, int Kpad,
+                                                               int Npad, uint16_t* __restrict__ wt) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)Npad * Kpad) return;
+    int n = (int)(q / Kpad), k = (int)(q % Kpad);
+    wt[q] = (n < N && k < K) ? f32_to_bf16_rne(w[n + (int64_t)N * k]) : (uint16_t)0;
+}
+
+__global__ __launch_bounds__(256) void bf16_rows_to_f32_soa_kernel(const uint16_t* __restrict__ y, int64_t B, int N,
+                                                                   int ld, float* __restrict__ out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int n = 0; n < N; ++n) out[(int64_t)n * B + b] = bf16_to_f32(y[b * ld + n]);
+}
+
+}  // namespace rlhip
+
+using namespace rlhip;
+
+extern "C" {
+
+int32_t rlhip_dense_bf16_forward(const uint16_t* x_rows, const uint16_t* wt, const float* bias, int32_t act,
+                                 int64_t batch, int32_t k, int32_t n, void* y_rows, int32_t y_is_bf16,
+                                 rlhip_stream_t stream) {
+    RLHIP_REQUIRE(x_rows && wt && y_rows, "NULL array");
+    RLHIP_REQUIRE(batch >= 32 && batch % 128 == 0, "batch must be a multiple of 128 (pad the batch)");
+    RLHIP_REQUIRE(k >= 16 && k % 16 == 0, "K must be a multiple of 16 (zero-pad)");
+    RLHIP_REQUIRE(n >= 128 && n % 128 == 0, "N must be a multiple of 128 (zero-pad)");
+    RLHIP_REQUIRE(act >= 0 && act <= 2, "act: 0 relu, 1 tanh, 2 identity");
+    RLHIP_REQUIRE((((uintptr_t)x_rows | (uintptr_t)wt) & 15) == 0, "operands must be 16-byte aligned");
+    dim3 grid((unsigned)(batch / 128), (unsigned)(n / 128));
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_D(A_, O_) \
+    hipLaunchKernelGGL((dense_mfma_kernel<A_, O_>), grid, dim3(256), 0, s, x_rows, wt, bias, batch, k, n, y_rows)
+    if (y_is_bf16) {
+        if (act == 0) LAUNCH_D(0, true);
+        else if (act == 1) LAUNCH_D(1, true);
+        else LAUNCH_D(2, true);
+    } else {
+        if (act == 0) LAUNCH_D(0, false);
+        else if (act == 1) LAUNCH_D(1, false);
+        else LAUNCH_D(2, false);
+    }
+#undef LAUNCH_D
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_soa_f32_to_bf16_rows(const float* x_soa, int64_t batch, int32_t k, int32_t k_pad, uint16_t* out_rows,
+                                   rlhip_stream_t stream) {
+    RLHIP_REQUIRE(x_soa && out_rows && batch >= 0 && k >= 1 && k_pad >= k, "bad arguments");
+    if (batch == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(soa_to_bf16_rows_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), x_soa, batch, k, k_pad, out_rows);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_bf16_rows_to_soa_f32(const uint16_t* y_rows, int64_t batch, int32_t n, int32_t ld, float* out_soa,
+                                   rlhip_stream_t stream) {
+    RLHIP_REQUIRE(y_rows && out_soa && batch >= 0 && n >= 1 && ld >= n, "bad arguments");
+    if (batch == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(bf16_rows_to_f32_soa_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), y_rows, batch, n, ld, out_soa);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_dense_pack_weight_bf16(const float* w_flux, int32_t k, int32_t n, int32_t k_pad, int32_t n_pad,
+                                     uint16_t* wt, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(w_flux && wt && k >= 1 && n >= 1 && k_pad >= k && n_pad >= n, "bad arguments");
+    int64_t total = (int64_t)n_pad * k_pad;
+    hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w_flux, k, n, k_pad, n_pad, wt);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+}  // extern "C"

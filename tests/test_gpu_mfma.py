@@ -1,0 +1,61 @@
+"""bf16 MFMA Dense layer (hand-written v_mfma_f32_32x32x16_bf16 kernel) vs a plain PyTorch fp32 reference of
+the same op on the same bf16-rounded operands (tolerance = bf16 output rounding / f32 accumulation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("batch,k,n,act", [(128, 16, 128, "identity"), (256, 128, 128, "relu"), (4096, 256, 256, "relu"),
+                                          (1024, 64, 384, "tanh"), (32768, 128, 128, "relu")])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_dense_bf16_mfma_forward(batch, k, n, act, out_dtype):
+    from rlhip import ops
+
+    g = torch.Generator(device="cpu").manual_seed(batch + k + n)
+    # ASYMMETRIC operands (a symmetric B would hide a transposed C write -- MI355X guide section 3)
+    x = (torch.randn((k, batch), generator=g) * 0.5).cuda()                 # SoA f32 activations
+    w_flux = (torch.randn(n * k, generator=g) / np.sqrt(k)).cuda()          # (n x k) column-major flat
+    bias = torch.randn(n, generator=g).cuda()
+    xr = ops.soa_to_bf16_rows(x)
+    wt = ops.dense_pack_weight_bf16(w_flux, k, n)
+    assert xr.shape == (batch, k) and wt.shape == (n, k)
+    # converters are exact bf16 round-to-nearest-even
+    assert torch.equal(xr, x.t().contiguous().to(torch.bfloat16))
+    W = w_flux.reshape(k, n).t().contiguous()                                # W[o, i]
+    assert torch.equal(wt, W.to(torch.bfloat16))
+    y = ops.dense_bf16_forward(xr, wt, bias, act, out_dtype)
+    ref = xr.float() @ wt.float().t() + bias
+    ref = {"relu": torch.relu, "tanh": torch.tanh, "identity": lambda t: t}[act](ref)
+    if out_dtype == torch.bfloat16:
+        torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
+    else:
+        torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    back = ops.bf16_rows_to_soa(y, n) if out_dtype == torch.bfloat16 else None
+    if back is not None:
+        assert torch.equal(back, y.float().t().contiguous())
+
+
+def test_dense_mfma_identity_weight_catches_layout_errors():
+    """A = I check with an asymmetric operand: Y must equal X exactly (bf16 values, f32 accumulate)."""
+    from rlhip import ops
+
+    k = n = 128
+    batch = 256
+    x = torch.arange(batch * k, dtype=torch.float32).reshape(batch, k).remainder(251).sub(125).cuda()  # exact in bf16
+    xr = x.to(torch.bfloat16).contiguous()
+    eye = torch.eye(n, dtype=torch.bfloat16, device="cuda").contiguous()
+    y = ops.dense_bf16_forward(xr, eye, None, "identity", torch.float32)
+    assert torch.equal(y, xr.float())
+
+
+def test_dense_mfma_argument_validation():
+    from rlhip import ops
+    from rlhip._lib import RLHipArgumentError
+
+    x = torch.zeros((100, 16), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((128, 16), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RLHipArgumentError):
+        ops.dense_bf16_forward(x, w)  # batch not a multiple of 128
