@@ -250,9 +250,26 @@ def main():
     env = rlhip.HipVecEnv("cartpole", N_ENVS, seed=123, env_id_base=rank * N_ENVS)
     pol = rlhip.PPOPolicy(env, update_freq=T_ROLLOUT, hidden=HIDDEN, seed=123, process_group=pg)
 
+    # One whole iteration is captured in a HIP graph (counters live in device memory):
+    # replay costs one graph launch instead of ~35 kernel launches (+ 16 all-reduces issued from Python).
+    # RLHIP_BENCH_EAGER=1 keeps the eager enqueue path; a failed capture falls back to it loudly.
+    mode = "eager"
+    if os.environ.get("RLHIP_BENCH_EAGER", "0") != "1":
+        try:
+            pol.capture_graph_(warmup=2)
+            mode = "hip_graph"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] graph capture failed on rank {rank} ({type(e).__name__}: {e}); running eager",
+                  file=sys.stderr, flush=True)
+            pol._graph = None
+            pol.sync_counters_()
+
     def step():
-        pol.rollout_()
-        pol.update_()
+        if mode == "hip_graph":
+            pol.replay_()
+        else:
+            pol.rollout_()
+            pol.update_()
 
     def sync():
         if world > 1:
@@ -299,6 +316,7 @@ def main():
                    "microbatch": (N_ENVS * T_ROLLOUT) // pol.cfg.n_microbatches,
                    "parallelism": f"env-shards x{world}, flat-gradient all-reduce (RCCL) per micro-batch" if world > 1
                    else "single GPU"},
+        "launch_mode": mode,
         "final_loss": float(pol.losses[0]),
         "mean_episode_len_last_rollout": round(
             (N_ENVS * T_ROLLOUT) / max(1.0, float(pol.trajectory.terminal.sum())), 2),

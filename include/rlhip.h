@@ -361,7 +361,8 @@ int32_t rlhip_ppo_plan_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, const fl
 /* generalized_advantage_estimation(reward, values, gamma, lambda; dims = 2, terminal) + returns */
 int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                           const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);
-/* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes */
+/* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes.  The caller must
+ * ZERO-INITIALISE it once after allocation (it holds an arrival counter that the kernels re-arm themselves). */
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T);
 /* loss + flat gradient of micro-batch `mb` of epoch `epoch_ctr` (samples = keyed permutation of the
  * T*n transitions).  grad_out: f32[nparams]; losses_out (nullable): f32[4] = loss, actor, critic, entropy */
@@ -376,6 +377,26 @@ int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_
                              const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
                              float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,
                              float* grad_scratch, float* losses_out, rlhip_stream_t stream);
+
+/* Device-resident counters: the same three calls with the vec-step counter (counters[0]) and the update
+ * counter (counters[1]) read from device memory by the kernels instead of being baked into the launch
+ * arguments, so that one whole iteration (rollout -> GAE -> update [-> all-reduces]) can be captured in a
+ * HIP graph and replayed: the Philox streams still advance.  rlhip_counters_advance is the last node.
+ * `epoch_local` = epoch index inside the current update (0 .. n_epochs-1). */
+int32_t rlhip_ppo_rollout_dc_f32(int32_t kind, const void* env_cfg_host, const rlhip_env_state* st_host,
+                                 int64_t n, int64_t T, const rlhip_ppo_cfg* cfg_host, const float* params,
+                                 uint64_t seed, uint32_t env_id_base, const uint32_t* counters,
+                                 const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);
+int32_t rlhip_ppo_grad_dc_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                              const rlhip_ppo_traj* traj_host, const float* params, uint64_t seed,
+                              uint32_t epoch_local, const uint32_t* counters, int32_t mb, void* workspace,
+                              float* grad_out, float* losses_out, rlhip_stream_t stream);
+int32_t rlhip_ppo_update_dc_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                                const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
+                                float* beta_pow, uint64_t seed, const uint32_t* counters, void* workspace,
+                                float* grad_scratch, float* losses_out, rlhip_stream_t stream);
+int32_t rlhip_counters_advance(uint32_t* counters, uint32_t d_vec_step, uint32_t d_update,
+                               rlhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------ DQN path -- */
 /* BasicDQN / DQN learner (removed Zoo; spec docs/src/rlcore.md:28, blog index.html:15121-15147):

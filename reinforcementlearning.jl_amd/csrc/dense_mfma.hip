@@ -55,7 +55,6 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const uint16_t* __restr
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-#pragma unroll 2
     for (int k0 = 0; k0 < K; k0 += 16) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + k0);
         bf16x8 b[NT];

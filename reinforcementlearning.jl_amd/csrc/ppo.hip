@@ -93,12 +93,19 @@ __device__ __forceinline__ void policy_sample(int cont, int na, const float oa[M
 
 
 
+__global__ void counters_advance_kernel(uint32_t* ctr, uint32_t d0, uint32_t d1) {
+    ctr[0] += d0;  // vec-step counter
+    ctr[1] += d1;  // update counter
+}
+
 // ---------------------------------------------------------------------------------- rollout ----
 template <class P, int H, int L, int ACT>
 __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<float> st, int64_t n, int T,
                                                               PolicyDesc pd, const float* __restrict__ params,
                                                               uint64_t seed, uint32_t env_id_base,
-                                                              uint32_t vec_step0, TrajPtrs tr, int store_state) {
+                                                              uint32_t vec_step0_in, const uint32_t* __restrict__ ctr, TrajPtrs tr,
+                                                              int store_state) {
+    const uint32_t vec_step0 = vec_step0_in + (ctr ? ctr[0] : 0u);  // device-resident counter (graph replay)
     constexpr int NS = P::ODIM;
     constexpr int HPL = H / L;
     int64_t gl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +178,9 @@ template <class P, int ACT>
 __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<float> st, int64_t n, int T,
                                                              PolicyDesc pd, const float* __restrict__ params,
                                                              uint64_t seed, uint32_t env_id_base,
-                                                             uint32_t vec_step0, TrajPtrs tr, int store_state) {
+                                                             uint32_t vec_step0_in, const uint32_t* __restrict__ ctr, TrajPtrs tr,
+                                                              int store_state) {
+    const uint32_t vec_step0 = vec_step0_in + (ctr ? ctr[0] : 0u);  // device-resident counter (graph replay)
     constexpr int NS = P::ODIM;
     int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= n) return;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<floa
 template <class P>
 static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, int64_t T,
                             const PolicyDesc& pd, const float* params, uint64_t seed, uint32_t env_id_base,
-                            uint32_t vec_step0, const rlhip_ppo_traj* traj, hipStream_t s) {
+                            uint32_t vec_step0, const uint32_t* ctr, const rlhip_ppo_traj* traj, hipStream_t s) {
     typename P::cfg_t c2 = *cfg;
     c2.continuous = pd.cont;  // the policy head decides the action type
     P p = P::make(c2);
@@ -239,20 +248,20 @@ static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state*
     do {                                                                                                   \
         if (pd.act == 0)                                                                                   \
             hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
-                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);      \
+                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
         else                                                                                               \
             hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 1>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
-                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);      \
+                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
     } while (0)
     if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);
     else if (wide && pd.h == 128) LAUNCH_WIDE(128, 8);
     else if (wide && pd.h == 64) LAUNCH_WIDE(64, 4);
     else if (pd.act == 0)
         hipLaunchKernelGGL((rollout_scalar_kernel<P, 0>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n,
-                           (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);
+                           (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);
     else
         hipLaunchKernelGGL((rollout_scalar_kernel<P, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n,
-                           (int)T, pd, params, seed, env_id_base, vec_step0, tr, 1);
+                           (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);
 #undef LAUNCH_WIDE
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
@@ -465,10 +474,10 @@ int32_t rlhip_ppo_plan_f32(int32_t kind, const rlhip_ppo_cfg* cfg, const float* 
     return plan_impl<2>(n, pd, params, obs, seed, env_id_base, vec_step, action_i, action_f, logp, value, s);
 }
 
-int32_t rlhip_ppo_rollout_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n,
-                              int64_t T, const rlhip_ppo_cfg* cfg, const float* params, uint64_t seed,
-                              uint32_t env_id_base, uint32_t vec_step0, const rlhip_ppo_traj* traj,
-                              rlhip_stream_t stream) {
+static int32_t rollout_entry(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, int64_t T,
+                             const rlhip_ppo_cfg* cfg, const float* params, uint64_t seed, uint32_t env_id_base,
+                             uint32_t vec_step0, const uint32_t* ctr, const rlhip_ppo_traj* traj,
+                             rlhip_stream_t stream) {
     PolicyDesc pd;
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;
@@ -478,10 +487,32 @@ int32_t rlhip_ppo_rollout_f32(int32_t kind, const void* env_cfg, const rlhip_env
     RLHIP_REQUIRE(pd.cont ? (traj->action_f != nullptr) : (traj->action_i != nullptr), "action trace is NULL");
     hipStream_t s = as_stream(stream);
     if (kind == 0)
-        return rollout_impl<CartPoleParams<float>>((const rlhip_cartpole_cfg*)env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, traj, s);
+        return rollout_impl<CartPoleParams<float>>((const rlhip_cartpole_cfg*)env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, ctr, traj, s);
     if (kind == 1)
-        return rollout_impl<PendulumParams<float>>((const rlhip_pendulum_cfg*)env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, traj, s);
-    return rollout_impl<MountainCarParams<float>>((const rlhip_mountaincar_cfg*)env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, traj, s);
+        return rollout_impl<PendulumParams<float>>((const rlhip_pendulum_cfg*)env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, ctr, traj, s);
+    return rollout_impl<MountainCarParams<float>>((const rlhip_mountaincar_cfg*)env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, ctr, traj, s);
+}
+
+int32_t rlhip_ppo_rollout_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n,
+                              int64_t T, const rlhip_ppo_cfg* cfg, const float* params, uint64_t seed,
+                              uint32_t env_id_base, uint32_t vec_step0, const rlhip_ppo_traj* traj,
+                              rlhip_stream_t stream) {
+    return rollout_entry(kind, env_cfg, st, n, T, cfg, params, seed, env_id_base, vec_step0, nullptr, traj, stream);
+}
+
+int32_t rlhip_ppo_rollout_dc_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n,
+                                 int64_t T, const rlhip_ppo_cfg* cfg, const float* params, uint64_t seed,
+                                 uint32_t env_id_base, const uint32_t* counters, const rlhip_ppo_traj* traj,
+                                 rlhip_stream_t stream) {
+    RLHIP_REQUIRE(counters != nullptr, "counters is NULL");
+    return rollout_entry(kind, env_cfg, st, n, T, cfg, params, seed, env_id_base, 0, counters, traj, stream);
+}
+
+int32_t rlhip_counters_advance(uint32_t* counters, uint32_t d_vec_step, uint32_t d_update, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(counters != nullptr, "counters is NULL");
+    hipLaunchKernelGGL(counters_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), counters, d_vec_step, d_update);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
 }
 
 int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,

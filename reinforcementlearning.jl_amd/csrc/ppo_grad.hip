@@ -58,7 +58,10 @@ struct GradArgs {
     int num_tiles, np;
     PolicyDesc pd;
     float lo, hi, wa, wc, we, inv_b, min_logp;
-    PermKeys pk;           // epoch permutation keys, evaluated on the host (2 Philox blocks)
+    PermKeys pk;           // epoch permutation keys, evaluated on the host (2 Philox blocks) ...
+    const uint32_t* ctr;   // ... or, when non-NULL, in the kernel from the device update counter ctr[1]:
+    uint64_t seed;         //     epoch = epoch_local + ctr[1] * n_epochs  (HIP-graph replayable)
+    uint32_t epoch_local, n_epochs;
     long long* dbg;  // optional per-block phase timestamps (s_memtime), 8 per block; NULL in production
 };
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
 
     // ---- prologue: the first tile's scattered gather is issued first; this thread's unit (phase 2)
     // comes from its two records ----
-    const PermKeys& pk = g.pk;
+    const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
     int tile = blockIdx.x;
     TileRegs first;
     const bool first_loader = tid < TILE && tile < g.num_tiles;
@@ -616,7 +619,7 @@ struct GradLaunch {
 
 static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                             const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace,
-                            GradLaunch* out) {
+                            GradLaunch* out, const uint32_t* ctr = nullptr) {
     PolicyDesc pd;
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;
@@ -653,6 +656,10 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     g.inv_b = 1.0f / (float)bm;
     g.min_logp = (float)log(1e-8);
     g.pk = perm_keys(seed, epoch_ctr, total);
+    g.ctr = ctr;
+    g.seed = seed;
+    g.epoch_local = epoch_ctr;  // with ctr: the epoch index inside this update call
+    g.n_epochs = (uint32_t)cfg->n_epochs;
     out->nb = grad_blocks(g.num_tiles);
     out->ns = ns;
     out->np = np;
@@ -704,13 +711,12 @@ int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
            (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long) + 64 + (16 * 256 + 8) * (int64_t)sizeof(float);
 }
 
-int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
-                           const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr,
-                           int32_t mb, void* workspace, float* grad_out, float* losses_out,
-                           rlhip_stream_t stream) {
+static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
+                          const float* params, uint64_t seed, uint32_t epoch_ctr, const uint32_t* ctr, int32_t mb,
+                          void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream) {
     RLHIP_REQUIRE(grad_out != nullptr, "grad_out is NULL");
     GradLaunch L;
-    int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L);
+    int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, ctr);
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
     launch_pack(L, s);
@@ -723,22 +729,39 @@ int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, in
     return RLHIP_OK;
 }
 
-int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
-                             const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
-                             uint64_t seed, uint32_t update_ctr, void* workspace, float* grad_scratch,
-                             float* losses_out, rlhip_stream_t stream) {
+int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                           const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr,
+                           int32_t mb, void* workspace, float* grad_out, float* losses_out,
+                           rlhip_stream_t stream) {
+    return grad_entry(kind, cfg, n, T, traj, params, seed, epoch_ctr, nullptr, mb, workspace, grad_out, losses_out,
+                      stream);
+}
+
+int32_t rlhip_ppo_grad_dc_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                              const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_local,
+                              const uint32_t* counters, int32_t mb, void* workspace, float* grad_out,
+                              float* losses_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(counters != nullptr, "counters is NULL");
+    return grad_entry(kind, cfg, n, T, traj, params, seed, epoch_local, counters, mb, workspace, grad_out, losses_out,
+                      stream);
+}
+
+static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                            const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
+                            uint64_t seed, uint32_t update_ctr, const uint32_t* ctr, void* workspace,
+                            float* grad_scratch, float* losses_out, rlhip_stream_t stream) {
     RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
     hipStream_t s = as_stream(stream);
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
-        uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
+        uint32_t epoch_ctr = ctr ? (uint32_t)e : update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
             GradLaunch L;
-            int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L);
+            int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, ctr);
             if (rc) return rc;
-            if (first) {  // arm the arrival counter and pack the unit records once per call; the Adam tail
-                          // re-arms the counter and refreshes the records after every step
-                RLHIP_CHECK_HIP(hipMemsetAsync(L.counter, 0, sizeof(unsigned int), s));
+            if (first) {  // pack the unit records once per call; the Adam tail refreshes them after every step.
+                          // The arrival counter needs no per-call memset: the workspace is zero-initialised
+                          // by its owner (ABI contract) and the last-arriving workgroup re-arms it in-kernel.
                 launch_pack(L, s);
                 first = false;
             }
@@ -752,6 +775,23 @@ int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, 
     }
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
+}
+
+int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                             const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
+                             uint64_t seed, uint32_t update_ctr, void* workspace, float* grad_scratch,
+                             float* losses_out, rlhip_stream_t stream) {
+    return update_entry(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, nullptr, workspace,
+                        grad_scratch, losses_out, stream);
+}
+
+int32_t rlhip_ppo_update_dc_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                                const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
+                                uint64_t seed, const uint32_t* counters, void* workspace, float* grad_scratch,
+                                float* losses_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(counters != nullptr, "counters is NULL");
+    return update_entry(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, 0, counters, workspace, grad_scratch,
+                        losses_out, stream);
 }
 
 }  // extern "C"

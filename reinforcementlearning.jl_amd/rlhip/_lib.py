@@ -153,6 +153,13 @@ _PROTOS = {
                                  vp]),
     "rlhip_ppo_update_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp,
                                    vp, vp, vp]),
+    "rlhip_ppo_rollout_dc_f32": (i32, [i32, vp, P(EnvState), i64, i64, P(PPOCfg), vp, u64, u32, vp, P(PPOTraj),
+                                       vp]),
+    "rlhip_ppo_grad_dc_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, vp, i32, vp, vp, vp,
+                                    vp]),
+    "rlhip_ppo_update_dc_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, vp, vp, vp, vp,
+                                      vp]),
+    "rlhip_counters_advance": (i32, [vp, u32, u32, vp]),
     "rlhip_dqn_workspace_bytes": (i64, [i64, i64, i64, i64]),
     "rlhip_dqn_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, i64, f32, f32, u64, u32, vp, vp, vp,
                                  vp]),

@@ -95,11 +95,14 @@ class PPOPolicy:
         self.gn = torch.zeros(1, dtype=torch.float32, device=dev)
         self.trajectory = PPOTrajectory(ns, env.n, self.T, env.continuous, dev)
         ws = int(_lib.lib.rlhip_ppo_workspace_bytes(self.kind, C.byref(self.cfg), env.n, self.T))
-        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.workspace = torch.zeros(ws, dtype=torch.uint8, device=dev)  # zero-initialised: ABI contract
         self.vec_step = 0      # global vec-step counter (Philox t of the sampling streams)
         self.update_ctr = 0    # number of update_ calls so far
         self.n_pushed = 0      # per-step protocol: vec-steps pushed since the last update
         self.process_group = process_group
+        # device-resident mirror of (vec_step, update_ctr) for HIP-graph replay of whole iterations
+        self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._graph = None
         self._a_i = torch.zeros(env.n, dtype=torch.int32, device=dev)
         self._a_f = torch.zeros(env.n, dtype=torch.float32, device=dev)
         self._logp = torch.zeros(env.n, dtype=torch.float32, device=dev)
@@ -178,7 +181,7 @@ class PPOPolicy:
             import torch.distributed as dist
 
             world = dist.get_world_size(self.process_group)
-        if world == 1:
+        if world == 1 and not getattr(self, "_force_dist", False):
             call("rlhip_ppo_update_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
                  C.byref(self.trajectory.c), ptr(self.params), ptr(self.m), ptr(self.v), ptr(self.beta_pow),
                  self.seed, self.update_ctr, ptr(self.workspace), ptr(self.grad), ptr(self.losses), stream_ptr())
@@ -193,6 +196,74 @@ class PPOPolicy:
                     # gradient (mean over shards == single-GPU semantics with a world-times larger batch)
                     dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                     self.apply_(grad_scale=1.0 / world)
+        self.update_ctr += 1
+
+    # ----------------------------------------------------------------- HIP-graph protocol
+    def sync_counters_(self):
+        """Copy the host counters to their device mirror (call before switching to the graph path)."""
+        self.counters.copy_(torch.tensor([self.vec_step, self.update_ctr], dtype=torch.int32))
+
+    def _world(self):
+        if self.process_group is None:
+            return 1
+        import torch.distributed as dist
+
+        return dist.get_world_size(self.process_group)
+
+    def iteration_dc_(self, env=None):
+        """One whole iteration -- rollout, GAE, n_epochs x n_microbatches updates (with the gradient
+        all-reduce when a process group is set), counter advance -- enqueued with every counter read from
+        device memory: identical results to rollout_() + update_(), but capturable in a HIP graph."""
+        env = env or self.env
+        tr = self.trajectory
+        call("rlhip_ppo_rollout_dc_f32", self.kind, C.byref(env.cfg), C.byref(env._st), env.n, self.T,
+             C.byref(self.cfg), ptr(self.params), self.seed, env.env_id_base, ptr(self.counters), C.byref(tr.c),
+             stream_ptr())
+        env._obs_valid = False
+        self.gae_()
+        world = self._world()
+        if world == 1 and not getattr(self, "_force_dist", False):
+            call("rlhip_ppo_update_dc_f32", self.kind, C.byref(self.cfg), tr.n, self.T, C.byref(tr.c),
+                 ptr(self.params), ptr(self.m), ptr(self.v), ptr(self.beta_pow), self.seed, ptr(self.counters),
+                 ptr(self.workspace), ptr(self.grad), ptr(self.losses), stream_ptr())
+        else:
+            import torch.distributed as dist
+
+            for e in range(self.cfg.n_epochs):
+                for mb in range(self.cfg.n_microbatches):
+                    call("rlhip_ppo_grad_dc_f32", self.kind, C.byref(self.cfg), tr.n, self.T, C.byref(tr.c),
+                         ptr(self.params), self.seed, e, ptr(self.counters), mb, ptr(self.workspace),
+                         ptr(self.grad), ptr(self.losses), stream_ptr())
+                    dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+                    self.apply_(grad_scale=1.0 / world)
+        call("rlhip_counters_advance", ptr(self.counters), self.T, 1, stream_ptr())
+        self.vec_step += self.T
+        self.update_ctr += 1
+
+    def capture_graph_(self, env=None, warmup=2):
+        """Capture iteration_dc_ into a HIP graph (torch.cuda.CUDAGraph owns the capture stream); `replay_`
+        then costs one graph launch per iteration instead of ~35 kernel launches (+ 16 all-reduces)."""
+        env = env or self.env
+        self.sync_counters_()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # warm-up outside capture (lazy allocations, NCCL channel setup)
+                self.iteration_dc_(env)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.iteration_dc_(env)
+        self._graph = g
+        # the capture itself executed nothing, but iteration_dc_ advanced the host mirrors once: undo
+        self.vec_step -= self.T
+        self.update_ctr -= 1
+        return g
+
+    def replay_(self):
+        self._graph.replay()
+        self.vec_step += self.T
         self.update_ctr += 1
 
     def n_updates_per_call(self):

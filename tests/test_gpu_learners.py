@@ -289,3 +289,65 @@ def test_dqn_plan_vs_oracle(rl, h):
         # integer selection is bit-exact given the same Q-values and the same Philox draws
         oa = oracle.eps_greedy_select(host(q), eps, seed=8, step=42, env_id_base=100)
         assert np.array_equal(host(a), oa)
+
+
+def test_device_counter_path_and_graph_replay_equal_eager(rl):
+    """rollout_() + update_() (host counters) == iteration_dc_() (device counters) == HIP-graph replay."""
+    n, T = 512, 8
+    pols = []
+    for _ in range(3):
+        env = rl.CartPoleEnv(n, seed=9)
+        pols.append(rl.PPOPolicy(env, update_freq=T))
+    a, b, c = pols
+    for _ in range(2):  # two eager iterations first so that the counters are non-zero at capture time
+        for p in pols:
+            p.rollout_()
+            p.update_()
+    b.sync_counters_()
+    c.capture_graph_(warmup=0)
+    for it in range(3):
+        a.rollout_()
+        a.update_()
+        b.iteration_dc_()
+        c.replay_()
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, b.params), f"device-counter path differs at iteration {it}"
+        assert torch.equal(a.params, c.params), f"graph replay differs at iteration {it}"
+        assert torch.equal(a.trajectory.action_i, c.trajectory.action_i)
+        assert a.vec_step == b.vec_step == c.vec_step and a.update_ctr == c.update_ctr
+    assert c.counters.tolist() == [c.vec_step, c.update_ctr]
+
+
+def test_single_rank_nccl_group_graph_capture(rl):
+    """The multi-GPU update sequence (grad -> all-reduce -> clip+Adam) with a 1-rank RCCL group, eager and
+    captured in a HIP graph: must equal the fused single-GPU update."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        n, T = 256, 8
+        envs = [rl.CartPoleEnv(n, seed=3) for _ in range(3)]
+        ref = rl.PPOPolicy(envs[0], update_freq=T)
+        eager = rl.PPOPolicy(envs[1], update_freq=T, process_group=dist.group.WORLD)
+        graph = rl.PPOPolicy(envs[2], update_freq=T, process_group=dist.group.WORLD)
+        for p in (eager, graph):
+            p._force_dist = True  # take the distributed branch although world == 1
+        graph.capture_graph_(warmup=1)
+        for p in (ref, eager):
+            for _ in range(2):  # the graph policy did one warm-up iteration before the capture
+                p.rollout_()
+                p.update_()
+        graph.replay_()
+        torch.cuda.synchronize()
+        assert torch.equal(ref.params, eager.params)
+        assert torch.equal(ref.params, graph.params)
+    finally:
+        if created:
+            dist.destroy_process_group()
