@@ -22,6 +22,27 @@ namespace rlhip {
 #define RLHIP_PI 3.14159265358979323846
 #endif
 
+// Float64 sin / cos on [-pi/4, pi/4] without range reduction: the fdlibm kernel polynomials
+// (k_sin.c / k_cos.c coefficient sets, |error| < 2^-58), ~18 Float64 FMAs instead of the ~150
+// instructions of the general ocml sincos.  CartPole's theta lives in +-0.42 rad (2 x the 12 degree
+// threshold), so the env-step kernel always takes this path; it was VALU-bound on the general routine
+// (profiles/r01_final_bench_stats.md: 156-223 us per 2^24-env launch against a 130 us HBM floor).
+__device__ __forceinline__ void sincos_small_f64(double x, double* s, double* c) {
+    const double z = x * x;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    *s = fma(x * z, ps, x);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    *c = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+
 template <typename T>
 struct Trig;
 template <>
@@ -30,7 +51,8 @@ struct Trig<float> {
     static __device__ __forceinline__ float cos_(float x) { return (float)::cos((double)x); }
     static __device__ __forceinline__ void sincos_(float x, float* s, float* c) {
         double ds, dc;
-        ::sincos((double)x, &ds, &dc);
+        if (fabsf(x) <= 0.78539816f) sincos_small_f64((double)x, &ds, &dc);
+        else ::sincos((double)x, &ds, &dc);
         *s = (float)ds;
         *c = (float)dc;
     }
