@@ -122,11 +122,12 @@ static int32_t scan_geom(int64_t n1, int64_t n2, int32_t dims, ScanGeom* g) {
 template <typename T, bool REDUCED>
 static int32_t discount_impl(T* out, const T* r, int64_t n1, int64_t n2, T gamma, const uint8_t* term,
                              const T* init, int32_t dims, hipStream_t s) {
-    RLHIP_REQUIRE(out != nullptr && r != nullptr, "NULL array");
     ScanGeom g;
     int32_t rc = scan_geom(n1, n2, dims, &g);
     if (rc) return rc;
-    if (g.n_slices == 0) return RLHIP_OK;
+    // empty inputs are a no-op (an empty device array has a NULL base pointer): checked before the NULL test
+    if (g.n_slices == 0 || (g.len == 0 && !REDUCED)) return RLHIP_OK;
+    RLHIP_REQUIRE(out != nullptr && r != nullptr, "NULL array");
     hipLaunchKernelGGL((discount_kernel<T, REDUCED>), dim3((int)((g.n_slices + 255) / 256)), dim3(256), 0,
                        s, out, r, term, init, g.n_slices, g.len, g.elem_stride, g.slice_stride, gamma,
                        dims == 0 ? 0 : 1);
@@ -137,11 +138,11 @@ static int32_t discount_impl(T* out, const T* r, int64_t n1, int64_t n2, T gamma
 template <typename T>
 static int32_t gae_impl(T* adv, T* ret, const T* r, const T* v, int64_t n1, int64_t n2, T gamma, T lambda,
                         const uint8_t* term, int32_t dims, hipStream_t s) {
-    RLHIP_REQUIRE(adv != nullptr && r != nullptr && v != nullptr, "NULL array");
     ScanGeom g;
     int32_t rc = scan_geom(n1, n2, dims, &g);
     if (rc) return rc;
-    if (g.n_slices == 0) return RLHIP_OK;
+    if (g.n_slices == 0 || g.len == 0) return RLHIP_OK;  // empty trajectory: nothing to write
+    RLHIP_REQUIRE(adv != nullptr && r != nullptr && v != nullptr, "NULL array");
     dim3 grid((int)((g.n_slices + 255) / 256));
     if (ret)
         hipLaunchKernelGGL((gae_kernel<T, true, 128 / sizeof(T)>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,

@@ -1,0 +1,152 @@
+"""Edge cases through the C ABI: empty and tiny inputs, ragged sizes around the vector widths / chunk sizes,
+maximum-length episodes, capacity-1 rings (the shape the reference's own trajectory tests use,
+RLCore/test/policies/q_based_policy.jl:41-47,62-94)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import oracle  # noqa: E402
+
+
+def dev(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 257])
+@pytest.mark.parametrize("kind,continuous", [("cartpole", False), ("pendulum", True), ("mountaincar", False)])
+def test_env_ragged_sizes(kind, continuous, n):
+    import rlhip
+
+    env = rlhip.HipVecEnv(kind, n, seed=2, continuous=continuous, max_steps=7)
+    ref = oracle.VecEnv(kind, n, seed=2, continuous=continuous, max_steps=7)
+    rng = np.random.default_rng(n)
+    for step in range(30):
+        a = (rng.uniform(-1, 1, n).astype(np.float32) if continuous
+             else rng.integers(0, 2 if kind == "cartpole" else 3, n).astype(np.int32))
+        env.act0_(dev(a))
+        ref.step(a)
+        assert np.array_equal(host(env._done), ref.done) and np.array_equal(host(env._t), ref.t)
+        assert np.array_equal(host(env._episode).view(np.uint32), ref.episode)
+    for k in range(env.sdim):
+        np.testing.assert_allclose(host(env.raw_state()[k]), ref.s[k], rtol=1e-4, atol=1e-5)
+    assert int(ref.episode.min()) >= 1 + 30 // 9  # every instance was auto-reset several times
+
+
+def test_env_zero_instances_is_a_noop():
+    import ctypes as C
+
+    import rlhip
+    from rlhip import _lib
+
+    env = rlhip.HipVecEnv("cartpole", 4, seed=0)
+    before = env.raw_state().clone()
+    a = torch.zeros(4, dtype=torch.int32, device="cuda")
+    _lib.call("rlhip_env_step", 0, 0, C.byref(env.cfg), C.byref(env._st), 0, rlhip.ops.ptr(a), 1, 0, 0, None, None,
+              rlhip.ops.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(before, env.raw_state())
+
+
+def test_cartpole_maximum_length_episode():
+    """max_steps = 200 with strict `>`: an undisturbed-threshold episode lasts exactly 201 steps."""
+    import rlhip
+
+    env = rlhip.HipVecEnv("cartpole", 8, seed=5, xthreshold=1e9, thetathreshold=1e9)
+    a = torch.ones(8, dtype=torch.int64, device="cuda")
+    lengths = torch.zeros(8, dtype=torch.int64, device="cuda")
+    first_done = None
+    for i in range(1, 203):
+        env.act_(a)
+        if bool(env.is_terminated().any()) and first_done is None:
+            first_done = i
+            assert bool(env.is_terminated().all())
+    assert first_done == 201
+    assert host(env._t).tolist() == [1] * 8  # auto-reset happened at step 201, one step into the next episode
+    assert lengths.sum() == 0
+
+
+@pytest.mark.parametrize("T", [1, 2, 31, 32, 33, 64, 100])
+def test_gae_chunk_boundaries_bit_exact(T):
+    from rlhip import ops
+
+    rng = np.random.default_rng(T)
+    n = 130
+    r = rng.standard_normal((T, n)).astype(np.float32)
+    v = rng.standard_normal((T + 1, n)).astype(np.float32)
+    term = rng.random((T, n)) < 0.1
+    adv, ret = ops.gae_returns(dev(r), dev(v), dev(term), 0.99, 0.95)
+    o = oracle.generalized_advantage_estimation(r.T, v.T, 0.99, 0.95, terminal=term.T, dims=2, dtype=np.float32)
+    assert np.array_equal(host(adv), o.T)
+    # Float64 and the uncoalesced orientation (dims = 1) as well
+    r64, v64 = r.astype(np.float64), v.astype(np.float64)
+    g = ops.to_julia(ops.generalized_advantage_estimation(ops.from_julia(r64), ops.from_julia(v64), 0.9, 0.8,
+                                                          terminal=ops.from_julia(term), dims=1))
+    o1 = oracle.generalized_advantage_estimation(r64, v64, 0.9, 0.8, terminal=term, dims=1, dtype=np.float64)
+    assert np.array_equal(host(g), o1)
+
+
+def test_scans_empty_inputs():
+    from rlhip import ops
+
+    r = torch.zeros((0, 5), dtype=torch.float32, device="cuda")  # storage of a (5, 0) matrix: no time steps
+    v = torch.zeros((1, 5), dtype=torch.float32, device="cuda")
+    out = ops.generalized_advantage_estimation(r, v, 0.9, 0.9, dims=2)
+    assert out.numel() == 0
+
+
+def test_capacity_one_ring_multiplexed_next_state():
+    """capacity = 1 traces: after s0 and one transition, the only sample is (s0, a, r, t, s1); after a second
+    transition the slot is overwritten by (s1, a', r', t', s2)."""
+    from rlhip.trajectory import CircularArraySARTSTraces
+
+    tr = CircularArraySARTSTraces(capacity=1, n_env=1, obs_dim=1)
+    s = [dev(np.array([[float(k)]], np.float32)) for k in range(3)]
+    tr.push_state_(s[0])
+    assert len(tr) == 0
+    tr.push_transition_(s[1], dev(np.array([1], np.int32)), dev(np.array([0.5], np.float32)), dev(np.array([0], np.uint8)))
+    assert len(tr) == 1
+    idx = tr.sample_indices(4, seed=0, draw_ctr=0)
+    assert host(idx).tolist() == [0, 0, 0, 0]
+    st, a, r, t, sn = tr.gather(idx)
+    assert host(st).ravel().tolist() == [0.0] * 4 and host(sn).ravel().tolist() == [1.0] * 4
+    assert host(a).tolist() == [1] * 4 and host(r).tolist() == [0.5] * 4
+    tr.push_transition_(s[2], dev(np.array([0], np.int32)), dev(np.array([-1.0], np.float32)), dev(np.array([1], np.uint8)))
+    assert len(tr) == 1
+    st, a, r, t, sn = tr.gather(tr.sample_indices(2, seed=0, draw_ctr=1))
+    assert host(st).ravel().tolist() == [1.0, 1.0] and host(sn).ravel().tolist() == [2.0, 2.0]
+    assert host(a).tolist() == [0, 0] and host(t).tolist() == [1, 1]
+
+
+def test_sampling_from_empty_ring_is_an_error():
+    from rlhip._lib import RLHipArgumentError
+    from rlhip.trajectory import CircularArraySARTSTraces
+
+    tr = CircularArraySARTSTraces(capacity=4, n_env=2, obs_dim=4)
+    with pytest.raises(RLHipArgumentError):
+        tr.sample_indices(8, seed=0, draw_ctr=0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 100])
+def test_tiny_policies_and_updates(n):
+    """PPO on very small shards (fewer samples than one 64-sample tile / one micro-batch tile)."""
+    import rlhip
+
+    env = rlhip.CartPoleEnv(n, seed=1)
+    pol = rlhip.PPOPolicy(env, update_freq=4, hidden=64, n_microbatches=2)
+    p0 = pol.params.clone()
+    pol.rollout_()
+    pol.update_()
+    torch.cuda.synchronize()
+    assert torch.isfinite(pol.params).all() and not torch.equal(p0, pol.params)
+    tr = pol.trajectory
+    otr = oracle.PPOTraj(0, n, 4)
+    ocfg = oracle.ppo_default(hidden=64, n_microbatches=2)
+    oracle.ppo_rollout(oracle.VecEnv("cartpole", n, seed=1), 4, ocfg, host(p0), otr, 0)
+    assert (host(tr.action_i) == otr.action_i).mean() > 0.99
