@@ -109,25 +109,57 @@ def roofline_extras(torch, rlhip):
                           "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
     del r, v, term
-    # u8 frame gather: 84x84x4 frames, batch 4096 -> 2 * (2 * 28224 + 9) B per sample
-    fb, cap, batch = 84 * 84 * 4, 1 << 16, 4096
-    tr = CircularArraySARTSTraces(capacity=cap, n_env=1, obs_dim=fb, dtype=torch.uint8)
+    # BASELINE configs[4]: 2^20-slot ring of 84x84x4 u8 frames (29.6 GB of states), prioritized sampling
+    # (device sum-tree, priorities U(0,1)^0.6) + frame gather, batch 4096 -> 2 * (2 * 28224 + 9) B per sample
+    fb, cap, batch = 84 * 84 * 4, int(os.environ.get("RLHIP_BENCH_RING_SLOTS", 1 << 20)), 4096
+    tr = rlhip.CircularPrioritizedTraces(capacity=cap, n_env=1, obs_dim=fb, dtype=torch.uint8)
     tr.state.random_(0, 256)
     tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap  # mark the ring full (synthetic frames, no push loop needed)
-    idx = tr.sample_indices(batch, seed=11, draw_ctr=0)
+    keys = torch.arange(cap, dtype=torch.int64, device="cuda")
+    tr.set_priority_(keys, ops.fill_uniform(cap, 11, 0, 7) ** 0.6)
+    idx, key, prio = tr.sample_prioritized(batch, 11, 0)
     tr.gather(idx)
     bufs = tr.gather(idx)
+    ctr = [1]
+
+    def smp():
+        rlhip._lib.call("rlhip_ring_sample_prioritized", C.byref(tr.rb), ops.ptr(tr.priorities), batch, 11, ctr[0],
+                        ops.ptr(idx), ops.ptr(key), ops.ptr(prio), s)
+        ctr[0] += 1
 
     def g():
         rlhip._lib.call("rlhip_ring_gather", C.byref(tr.rb), ops.ptr(idx), batch, ops.ptr(bufs[0]), ops.ptr(bufs[1]),
                         ops.ptr(bufs[2]), ops.ptr(bufs[3]), ops.ptr(bufs[4]), s)
 
-    ms = event_time_ms(g, 10, lib, s)
+    def upd():
+        rlhip._lib.call("rlhip_sumtree_update", ops.ptr(tr.priorities), cap, ops.ptr(key), ops.ptr(prio), batch, s)
+
+    def both():
+        smp()
+        g()
+        upd()
+
+    def fresh_gather():  # new indices every launch: no Infinity-Cache hits from a repeated batch
+        smp()
+        g()
+
+    ms_s = event_time_ms(smp, 10, lib, s)
+    ms = event_time_ms(fresh_gather, 10, lib, s) - ms_s
+    ms_rep = event_time_ms(g, 10, lib, s)
+    ms_u = event_time_ms(upd, 10, lib, s)
+    ms_all = event_time_ms(both, 10, lib, s)
     gb = 2 * (2 * fb + 9) * batch / 1e9
     out["frame_gather_u8"] = {"bound": "hbm", "capacity": cap, "frame_bytes": fb, "batch": batch,
+                              "ring_state_gb": round((cap + 1) * fb / 1e9, 2),
                               "us_per_launch": round(ms * 1e3, 1), "achieved": round(gb / (ms * 1e-3), 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4),
-                              "samples_per_sec": round(batch / (ms * 1e-3), 1)}
+                              "samples_per_sec": round(batch / (ms * 1e-3), 1),
+                              "us_per_launch_repeated_batch": round(ms_rep * 1e3, 1),
+                              "prioritized_sample_us": round(ms_s * 1e3, 1),
+                              "priority_update_us": round(ms_u * 1e3, 1),
+                              "sample_gather_update_us": round(ms_all * 1e3, 1),
+                              "prioritized_samples_per_sec": round(batch / (ms_all * 1e-3), 1)}
+    del key, prio, keys
     del tr, bufs, idx
     torch.cuda.empty_cache()
     # bf16 MFMA Dense layer (hidden x hidden), batch = one PPO trajectory (131072 rows), 256 -> 256, fused bias + relu
@@ -166,6 +198,27 @@ def roofline_extras(torch, rlhip):
     out["dqn_cartpole_4096env"] = {"env_steps_per_sec": round(n * steps / el, 1), "updates_per_sec": round(steps / el, 1),
                                    "ms_per_vec_step": round(el / steps * 1e3, 4), "batch": 512,
                                    "note": "per-step drop-in protocol (plan!/act!/push!/optimise! = 6 launches per vec-step, eager)"}
+    del agent, policy, learner, net, env
+    # BASELINE configs[2]: 4096-way PendulumEnv + PPOPolicy (GAE lambda = 0.95), T = 128, clip 0.1, 4 x 4
+    # micro-batches of 131072, actor 3 -> 256 -> (mu, log sigma), critic 3 -> 256 -> 1.  fp32 VALU: a
+    # 2-layer net has no hidden x hidden GEMM (K = 3, N <= 2), see DESIGN.md section 5.
+    penv = rlhip.HipVecEnv("pendulum", n, seed=7)
+    ppol = rlhip.PPOPolicy(penv, update_freq=128, hidden=HIDDEN, seed=7, clip_range=0.1)
+    for _ in range(3):
+        ppol.rollout_()
+        ppol.update_()
+    torch.cuda.synchronize()
+    iters = 20
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ppol.rollout_()
+        ppol.update_()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out["ppo_pendulum_4096env_T128"] = {"env_steps_per_sec": round(n * 128 * iters / el, 1),
+                                        "updates_per_sec": round(ppol.n_updates_per_call() * iters / el, 1),
+                                        "ms_per_iteration": round(el / iters * 1e3, 4), "dtype": "f32",
+                                        "final_loss": float(ppol.losses[0])}
     return out
 
 

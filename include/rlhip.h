@@ -280,6 +280,35 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
 
+/* -------------------------------------------------------------------- priority sum-tree -- */
+/* Prioritized replay: CircularArrayBuffers.SumTree (compat 0.1.12, RLCore/Project.toml:30) behind
+ * ReinforcementLearningTrajectories 0.4 `CircularPrioritizedTraces` + the prioritized BatchSampler method
+ * (`inds, priorities = rand(rng, sumtree, batchsize)`, `trajectory[:priority, keys] = p`) -- un-vendored, parity
+ * unpinned; BASELINE.json configs[4] ("prioritized sampling gather").
+ * tree: float[rlhip_sumtree_nodes(n_leaves)] device, ZERO-INITIALISED by the caller; implicit heap (root 1,
+ * leaf k at P + k, P = next pow2 >= n_leaves).  Internal nodes are recomputed as left + right (drift-free).
+ * Leaves are keyed by PHYSICAL ring position slot * n_env + env. */
+int64_t rlhip_sumtree_nodes(int64_t n_leaves);
+/* t[start+1 : start+count] .= value */
+int32_t rlhip_sumtree_fill_range(float* tree, int64_t n_leaves, int64_t start, int64_t count, float value,
+                                 rlhip_stream_t stream);
+/* for (k, p) in zip(keys, prio): t[k] = p   (sequential semantics: the last duplicate wins).  0-based keys. */
+int32_t rlhip_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf, const float* prio, int64_t n,
+                             rlhip_stream_t stream);
+/* rand(rng, t, batch): v = u01_f32(Philox(seed, idx = b, blk 0, t = draw_ctr, SAMPLER).w2) * t.tree[1], descent
+ * `v <= left ? left : (v -= left; right)` that never enters a zero-sum subtree.  prio_out may be NULL. */
+int32_t rlhip_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch, uint64_t seed,
+                             uint32_t draw_ctr, int64_t* leaf_out, float* prio_out, rlhip_stream_t stream);
+/* after rlhip_ring_push_transition: the n_env leaves of the newest transition frame := priority
+ * (CircularPrioritizedTraces `default_priority`) */
+int32_t rlhip_ring_push_priority(const rlhip_ring* rb_host, float* tree, float priority,
+                                 rlhip_stream_t stream);
+/* prioritized BatchSampler over the ring: idx_out = logical flat indices for rlhip_ring_gather, key_out =
+ * physical leaf keys for rlhip_sumtree_update (may be NULL), prio_out = their priorities (may be NULL). */
+int32_t rlhip_ring_sample_prioritized(const rlhip_ring* rb_host, const float* tree, int64_t batch,
+                                      uint64_t seed, uint32_t draw_ctr, int64_t* idx_out, int64_t* key_out,
+                                      float* prio_out, rlhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------- MLP -- */
 /* Chain(Dense(n_in, h, act), Dense(h, n_out)) with flat parameters in Flux.destructure order:
  *   W1 (h x n_in col-major) | b1 (h) | W2 (n_out x h col-major) | b2 (n_out).   act: 0 relu, 1 tanh.

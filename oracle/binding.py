@@ -90,6 +90,8 @@ def lib():
         _lib.rlo_mlp2_nparams.argtypes = [C.c_int64] * 3
         _lib.rlo_ppo_nparams.restype = C.c_int64
         _lib.rlo_ring_length.restype = C.c_int64
+        _lib.rlo_sumtree_nodes.restype = C.c_int64
+        _lib.rlo_sumtree_nodes.argtypes = [C.c_int64]
         _lib.rlo_dqn_loss_grad_f32.restype = C.c_float
     return _lib
 
@@ -402,6 +404,47 @@ class Ring:
         idx = np.ascontiguousarray(idx, np.int64)
         lib().rlo_ring_gather(C.byref(self.rb), _p(idx), C.c_int64(b), _p(s), _p(a), _p(r), _p(t), _p(sn))
         return s, a, r, t, sn
+
+
+class SumTree:
+    """priority sum-tree (rlo_buffer.c); leaves keyed 0-based"""
+
+    def __init__(self, n_leaves):
+        self.n_leaves = int(n_leaves)
+        self.tree = np.zeros(int(lib().rlo_sumtree_nodes(self.n_leaves)), np.float32)
+        self.P = self.tree.size // 2
+
+    def fill_range(self, start, count, value):
+        lib().rlo_sumtree_fill_range(_p(self.tree), C.c_int64(self.n_leaves), C.c_int64(start), C.c_int64(count),
+                                     C.c_float(value))
+
+    def update(self, keys, prio):
+        k = np.ascontiguousarray(keys, np.int64)
+        p = np.ascontiguousarray(prio, np.float32)
+        lib().rlo_sumtree_update(_p(self.tree), C.c_int64(self.n_leaves), _p(k), _p(p), C.c_int64(k.size))
+
+    def sample(self, batch, seed, draw_ctr):
+        leaf = np.empty(batch, np.int64)
+        prio = np.empty(batch, np.float32)
+        lib().rlo_sumtree_sample(_p(self.tree), C.c_int64(self.n_leaves), C.c_int64(batch), C.c_uint64(seed),
+                                 C.c_uint32(draw_ctr), _p(leaf), _p(prio))
+        return leaf, prio
+
+    def leaves(self):
+        return self.tree[self.P:self.P + self.n_leaves]
+
+
+def ring_push_priority(ring, st, priority):
+    lib().rlo_ring_push_priority(C.byref(ring.rb), _p(st.tree), C.c_float(priority))
+
+
+def ring_sample_prioritized(ring, st, batch, seed, draw_ctr):
+    idx = np.empty(batch, np.int64)
+    key = np.empty(batch, np.int64)
+    prio = np.empty(batch, np.float32)
+    lib().rlo_ring_sample_prioritized(C.byref(ring.rb), _p(st.tree), C.c_int64(batch), C.c_uint64(seed),
+                                      C.c_uint32(draw_ctr), _p(idx), _p(key), _p(prio))
+    return idx, key, prio
 
 
 # ------------------------------------------------------------------------------------------ MLP

@@ -230,6 +230,22 @@ void rlo_ring_sample_indices(const rlo_ring* rb, int64_t batch, uint64_t seed, u
 void rlo_ring_gather(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, float* s,
                      int32_t* a, float* r, uint8_t* term, float* s_next);
 
+/* ---------------------------------------------------- priority sum-tree -- */
+/* CircularArrayBuffers.SumTree (0.1.12) / RLTrajectories 0.4 prioritized BatchSampler, un-vendored: PARITY
+ * UNPINNED.  Implicit heap float tree[2P], P = next pow2 >= n_leaves, leaf k at P + k (the reference's
+ * nparents + k); internal node = left + right recomputed from the children (drift-free variant of the
+ * reference's `tree[parent] += change` walk); descent `v <= left ? left : (v -= left; right)` made robust
+ * against zero-sum subtrees.  Draw: v = u01_f32(Philox(seed, b, 0, draw_ctr, SAMPLER)[2]) * tree[1]. */
+int64_t rlo_sumtree_nodes(int64_t n_leaves);
+void rlo_sumtree_fill_range(float* tree, int64_t n_leaves, int64_t start, int64_t count, float value);
+void rlo_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf, const float* prio, int64_t n);
+void rlo_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch, uint64_t seed, uint32_t draw_ctr,
+                        int64_t* leaf_out, float* prio_out);
+/* leaf of the newest transition frame gets `priority`; prioritized draw mapped to logical flat indices */
+void rlo_ring_push_priority(const rlo_ring* rb, float* tree, float priority);
+void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t batch, uint64_t seed,
+                                 uint32_t draw_ctr, int64_t* flat_idx, int64_t* key_out, float* prio_out);
+
 /* ------------------------------------------------------------------ MLP -- */
 /* Chain(Dense(n_in, h, act), Dense(h, n_out)) flat parameters in Flux.destructure order:
  * W1 (h x n_in, col-major), b1 (h), W2 (n_out x h, col-major), b2 (n_out).  act: 0 relu, 1 tanh */

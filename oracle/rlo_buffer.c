@@ -95,3 +95,84 @@ void rlo_ring_gather(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch,
         term[b] = rb->terminal[pt * n + e];
     }
 }
+
+/* ---------------------------------------------------------------- priority sum-tree --
+ * Published algorithm of CircularArrayBuffers.SumTree (un-vendored, compat "0.1.12", RLCore/Project.toml:30):
+ *   tree = zeros(nparents + capacity), nparents = 2^ceil(log2(capacity)) - 1; leaf i at nparents + i;
+ *   setindex!: write the leaf, add the change to every ancestor;   get(t, v): walk down from the root,
+ *   `v <= tree[left] ? left : (v -= tree[left]; right)`;   rand(rng, t) = get(t, rand(rng, Float32) * tree[1]).
+ * and of the RLTrajectories 0.4 prioritized sampler: `inds, priorities = rand(rng, sumtree, batchsize)`.
+ * Restated with the two documented differences of rl_oracle.h (recomputed parents, robust descent). */
+static int64_t st_pow2(int64_t n) {
+    int64_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+int64_t rlo_sumtree_nodes(int64_t n_leaves) { return n_leaves < 1 ? 0 : 2 * st_pow2(n_leaves); }
+
+static void st_fix_up(float* tree, int64_t node) {
+    for (node >>= 1; node >= 1; node >>= 1) tree[node] = tree[2 * node] + tree[2 * node + 1];
+}
+
+void rlo_sumtree_fill_range(float* tree, int64_t n_leaves, int64_t start, int64_t count, float value) {
+    int64_t P = st_pow2(n_leaves);
+    for (int64_t i = 0; i < count; ++i) tree[P + start + i] = value;
+    if (count <= 0) return;
+    for (int64_t lo = (P + start) >> 1, hi = (P + start + count - 1) >> 1; lo >= 1; lo >>= 1, hi >>= 1)
+        for (int64_t node = lo; node <= hi; ++node) tree[node] = tree[2 * node] + tree[2 * node + 1];
+}
+
+void rlo_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf, const float* prio, int64_t n) {
+    int64_t P = st_pow2(n_leaves);
+    for (int64_t i = 0; i < n; ++i) { /* in order: the last occurrence of a key wins */
+        if (leaf[i] < 0 || leaf[i] >= n_leaves) continue;
+        tree[P + leaf[i]] = prio[i];
+        st_fix_up(tree, P + leaf[i]);
+    }
+}
+
+static int64_t st_descend(const float* tree, int64_t P, float v) {
+    int64_t node = 1;
+    while (node < P) {
+        float l = tree[2 * node], r = tree[2 * node + 1];
+        int right = (v > l && r > 0.0f) || l == 0.0f;
+        if (right) v = v - l;
+        node = 2 * node + right;
+    }
+    return node - P;
+}
+
+void rlo_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch, uint64_t seed, uint32_t draw_ctr,
+                        int64_t* leaf_out, float* prio_out) {
+    int64_t P = st_pow2(n_leaves);
+    for (int64_t b = 0; b < batch; ++b) {
+        uint32_t w[4];
+        rlo_philox4x32_10(seed, (uint32_t)b, 0, draw_ctr, RLO_TAG_SAMPLER, w);
+        float v = rlo_u01_f32(w[2]) * tree[1];
+        int64_t k = st_descend(tree, P, v);
+        if (k >= n_leaves) k = n_leaves - 1;
+        leaf_out[b] = k;
+        if (prio_out) prio_out[b] = tree[P + k];
+    }
+}
+
+void rlo_ring_push_priority(const rlo_ring* rb, float* tree, float priority) {
+    int64_t newest = (rb->head_rt + rb->len_rt - 1) % rb->capacity;
+    rlo_sumtree_fill_range(tree, rb->capacity * rb->n_env, newest * rb->n_env, rb->n_env, priority);
+}
+
+void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t batch, uint64_t seed,
+                                 uint32_t draw_ctr, int64_t* flat_idx, int64_t* key_out, float* prio_out) {
+    int64_t n_leaves = rb->capacity * rb->n_env;
+    int64_t* keys = key_out ? key_out : flat_idx;
+    rlo_sumtree_sample(tree, n_leaves, batch, seed, draw_ctr, keys, prio_out);
+    for (int64_t b = 0; b < batch; ++b) {
+        int64_t pt = keys[b] / rb->n_env, e = keys[b] % rb->n_env;
+        int64_t li = pt - rb->head_rt;
+        if (li < 0) li += rb->capacity;
+        int64_t k = keys[b];
+        flat_idx[b] = li * rb->n_env + e;
+        if (key_out) key_out[b] = k;
+    }
+}

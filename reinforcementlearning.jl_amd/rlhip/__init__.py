@@ -13,7 +13,7 @@ from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DoEveryNSteps, Emp
 from .dqn import (DQNLearner, EpsilonGreedyExplorer, GreedyExplorer, HipApproximator,  # noqa: F401
                   QBasedPolicy, TargetNetwork)
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
-from .trajectory import (BatchSampler, CircularArraySARTSTraces,  # noqa: F401
+from .trajectory import (BatchSampler, CircularArraySARTSTraces, CircularPrioritizedTraces,  # noqa: F401
                          InsertSampleRatioController, Trajectory)
 
 ABI_VERSION = _lib.lib.rlhip_abi_version()

@@ -135,6 +135,12 @@ _PROTOS = {
     "rlhip_ring_sample_indices": (i32, [P(Ring), i64, u64, u32, vp, vp]),
     "rlhip_ring_gather_is_frame_major": (i32, [P(Ring)]),
     "rlhip_ring_gather": (i32, [P(Ring), vp, i64, vp, vp, vp, vp, vp, vp]),
+    "rlhip_sumtree_nodes": (i64, [i64]),
+    "rlhip_sumtree_fill_range": (i32, [vp, i64, i64, i64, f32, vp]),
+    "rlhip_sumtree_update": (i32, [vp, i64, vp, vp, i64, vp]),
+    "rlhip_sumtree_sample": (i32, [vp, i64, i64, u64, u32, vp, vp, vp]),
+    "rlhip_ring_push_priority": (i32, [P(Ring), vp, f32, vp]),
+    "rlhip_ring_sample_prioritized": (i32, [P(Ring), vp, i64, u64, u32, vp, vp, vp, vp]),
     "rlhip_mlp2_nparams": (i64, [i64, i64, i64]),
     "rlhip_mlp2_forward_f32": (i32, [vp, i64, i64, i64, i32, vp, i64, vp, vp]),
     "rlhip_mlp2_init_f32": (i32, [vp, i64, i64, i64, u64, u32, vp]),

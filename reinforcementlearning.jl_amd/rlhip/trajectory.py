@@ -70,17 +70,64 @@ class CircularArraySARTSTraces:
         return s, a, r, t, sn
 
 
+class CircularPrioritizedTraces(CircularArraySARTSTraces):
+    """CircularPrioritizedTraces(CircularArraySARTSTraces(...); default_priority): every pushed transition
+    enters the device sum-tree with `default_priority`; `traces.set_priority_(keys, p)` is
+    `trajectory[:priority, keys] = p` (un-vendored RLTrajectories 0.4; sumtree.hip)."""
+
+    def __init__(self, capacity, n_env=1, obs_dim=1, dtype=torch.float32, default_priority=100.0, device="cuda"):
+        super().__init__(capacity, n_env, obs_dim, dtype, device)
+        self.default_priority = float(default_priority)
+        self.n_leaves = capacity * n_env
+        nodes = int(_lib.lib.rlhip_sumtree_nodes(self.n_leaves))
+        self.priorities = torch.zeros(nodes, dtype=torch.float32, device=self.state.device)  # zero-init contract
+
+    def push_transition_(self, next_obs, action0, reward, terminal):
+        super().push_transition_(next_obs, action0, reward, terminal)
+        call("rlhip_ring_push_priority", C.byref(self.rb), ptr(self.priorities), self.default_priority, stream_ptr())
+
+    def sample_prioritized(self, batch, seed, draw_ctr):
+        """-> (logical flat indices for gather, physical keys, priorities)"""
+        dev = self.state.device
+        idx = torch.empty(batch, dtype=torch.int64, device=dev)
+        key = torch.empty(batch, dtype=torch.int64, device=dev)
+        prio = torch.empty(batch, dtype=torch.float32, device=dev)
+        call("rlhip_ring_sample_prioritized", C.byref(self.rb), ptr(self.priorities), batch, seed, draw_ctr,
+             ptr(idx), ptr(key), ptr(prio), stream_ptr())
+        return idx, key, prio
+
+    def set_priority_(self, keys, prio):
+        """trajectory[:priority, keys] = prio  (sequential semantics: the last duplicate key wins)"""
+        if keys.dtype != torch.int64 or prio.dtype != torch.float32:
+            raise TypeError("keys must be int64 and priorities float32")
+        if keys.numel() != prio.numel():
+            raise ValueError("keys and priorities differ in length")
+        call("rlhip_sumtree_update", ptr(self.priorities), self.n_leaves, ptr(keys), ptr(prio), keys.numel(),
+             stream_ptr())
+
+    def total_priority(self):
+        return float(self.priorities[1])
+
+
 class BatchSampler:
-    """BatchSampler(batchsize; rng): uniform indices with replacement (Philox SAMPLER stream)."""
+    """BatchSampler(batchsize; rng): uniform indices with replacement (Philox SAMPLER stream); over
+    CircularPrioritizedTraces: `inds, priorities = rand(rng, sumtree, batchsize)` and the batch also carries
+    `key` (for the priority write-back) and `priority`."""
 
     def __init__(self, batchsize, seed=0):
         self.batchsize, self.seed, self.draw_ctr = batchsize, seed, 0
 
     def sample(self, traces):
-        idx = traces.sample_indices(self.batchsize, self.seed, self.draw_ctr)
+        extra = {}
+        if isinstance(traces, CircularPrioritizedTraces):
+            idx, key, prio = traces.sample_prioritized(self.batchsize, self.seed, self.draw_ctr)
+            extra = dict(key=key, priority=prio)
+        else:
+            idx = traces.sample_indices(self.batchsize, self.seed, self.draw_ctr)
+            extra = dict(key=idx)
         self.draw_ctr += 1
         s, a, r, t, sn = traces.gather(idx)
-        return dict(state=s, action=a + 1, reward=r, terminal=t.view(torch.bool), next_state=sn, key=idx)
+        return dict(state=s, action=a + 1, reward=r, terminal=t.view(torch.bool), next_state=sn, **extra)
 
 
 class InsertSampleRatioController:
