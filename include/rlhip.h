@@ -280,6 +280,37 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
 
+/* ------------------------------------------------------ 3-layer Q-network on the MFMA -- */
+/* Chain(Dense(ns, 128, act), Dense(128, 128, act), Dense(128, na)) -- the blog's DQN model
+ * (docs/homepage/blog/a_practical_introduction_to_RL.jl/index.html:15126-15128), forward(learner, x) =
+ * model(x) (RLCore/src/policies/learners/flux_approximator.jl:43).  Flat f32 master parameters in
+ * Flux.destructure order W1 (h x ns) | b1 | W2 (h x h) | b2 | W3 (na x h) | b3.  The hidden x hidden layer runs
+ * on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate) from a packed bf16 copy of W2 in both operand
+ * orders: uint16[rlhip_mlp3_packed_elems(h)], 16-byte aligned, refreshed by rlhip_mlp3_pack_bf16 after every
+ * parameter update.  hidden must be 128. */
+int64_t rlhip_mlp3_nparams(int64_t ns, int64_t h, int64_t na);
+int64_t rlhip_mlp3_packed_elems(int64_t h);
+int32_t rlhip_mlp3_init_f32(float* params, int64_t ns, int64_t h, int64_t na, uint64_t seed, uint32_t net_id,
+                            rlhip_stream_t stream);
+int32_t rlhip_mlp3_pack_bf16(const float* params, int64_t ns, int64_t h, int64_t na, uint16_t* packed,
+                             rlhip_stream_t stream);
+/* plan!(QBasedPolicy, env) = forward + EpsilonGreedyExplorer (no tie-break), as rlhip_dqn_plan_f32.
+ * actions may be NULL (pure forward: q_out (na x n)), q_out may be NULL. */
+int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t ns, int64_t h, int64_t na,
+                            int32_t act, const float* obs, int64_t n, double eps, uint64_t seed,
+                            uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
+                            rlhip_stream_t stream);
+int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch);
+/* optimise!(learner, batch) up to the gradient, as rlhip_dqn_grad_f32.  idx: optional explicit flat logical
+ * indices (e.g. from rlhip_ring_sample_prioritized); NULL = the uniform BatchSampler draw of
+ * rlhip_ring_sample_indices(seed, draw_ctr) evaluated inline.  td_out: optional |Q(s,a) - y| per sample
+ * (priority write-back).  loss_out: mean Huber loss. */
+int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act, const float* params,
+                            const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                            int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
+                            uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
+                            rlhip_stream_t stream);
+
 /* -------------------------------------------------------------------- priority sum-tree -- */
 /* Prioritized replay: CircularArrayBuffers.SumTree (compat 0.1.12, RLCore/Project.toml:30) behind
  * ReinforcementLearningTrajectories 0.4 `CircularPrioritizedTraces` + the prioritized BatchSampler method
@@ -299,6 +330,9 @@ int32_t rlhip_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf,
  * `v <= left ? left : (v -= left; right)` that never enters a zero-sum subtree.  prio_out may be NULL. */
 int32_t rlhip_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch, uint64_t seed,
                              uint32_t draw_ctr, int64_t* leaf_out, float* prio_out, rlhip_stream_t stream);
+/* PrioritizedDQN priority write-back value: out = (|td| + eps)^alpha (power in Float64, rounded once) */
+int32_t rlhip_per_priority_f32(const float* td, int64_t n, float eps, float alpha, float* out,
+                               rlhip_stream_t stream);
 /* after rlhip_ring_push_transition: the n_env leaves of the newest transition frame := priority
  * (CircularPrioritizedTraces `default_priority`) */
 int32_t rlhip_ring_push_priority(const rlhip_ring* rb_host, float* tree, float priority,

@@ -434,6 +434,13 @@ class SumTree:
         return self.tree[self.P:self.P + self.n_leaves]
 
 
+def per_priority(td, eps, alpha):
+    td = np.ascontiguousarray(td, np.float32)
+    out = np.empty_like(td)
+    lib().rlo_per_priority_f32(_p(td), C.c_int64(td.size), C.c_float(eps), C.c_float(alpha), _p(out))
+    return out
+
+
 def ring_push_priority(ring, st, priority):
     lib().rlo_ring_push_priority(C.byref(ring.rb), _p(st.tree), C.c_float(priority))
 
@@ -522,6 +529,50 @@ def dqn_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, 
                                        _p(s_next), C.c_int64(s.shape[1]), C.c_float(gamma),
                                        C.c_float(delta), _p(grad))
     return float(loss), grad
+
+
+# ------------------------------------------------------------------------- 3-layer bf16 Q-net
+def bf16_round(x):
+    x = np.ascontiguousarray(x, np.float32)
+    f = lib().rlo_bf16_round_f32
+    f.restype, f.argtypes = C.c_float, [C.c_float]
+    return np.array([f(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def mlp3_nparams(ns, h, na):
+    f = lib().rlo_mlp3_nparams
+    f.restype, f.argtypes = C.c_int64, [C.c_int64] * 3
+    return int(f(ns, h, na))
+
+
+def mlp3_init(ns, h, na, seed, net_id):
+    p = np.empty(mlp3_nparams(ns, h, na), np.float32)
+    lib().rlo_mlp3_init_f32(_p(p), C.c_int64(ns), C.c_int64(h), C.c_int64(na), C.c_uint64(seed), C.c_uint32(net_id))
+    return p
+
+
+def mlp3_forward(p, ns, h, na, act, x):
+    """x: (ns, batch) SoA.  Returns (na, batch)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty((na, x.shape[1]), np.float32)
+    lib().rlo_mlp3_forward_f32(_p(np.ascontiguousarray(p, np.float32)), C.c_int64(ns), C.c_int64(h), C.c_int64(na),
+                               C.c_int(act), _p(x), C.c_int64(x.shape[1]), _p(out))
+    return out
+
+
+def dqn3_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, gamma, delta=1.0):
+    s = np.ascontiguousarray(s, np.float32)
+    s_next = np.ascontiguousarray(s_next, np.float32)
+    params = np.ascontiguousarray(params, np.float32)
+    target_params = np.ascontiguousarray(target_params, np.float32)
+    grad = np.zeros_like(params)
+    q = np.empty((na, s.shape[1]), np.float32)
+    f = lib().rlo_dqn3_loss_grad_f32
+    f.restype = C.c_float
+    loss = f(C.c_int64(ns), C.c_int64(h), C.c_int64(na), C.c_int(act), _p(params), _p(target_params), _p(s),
+             _p(np.ascontiguousarray(a, np.int32)), _p(np.ascontiguousarray(r, np.float32)), _p(_u8(term)),
+             _p(s_next), C.c_int64(s.shape[1]), C.c_float(gamma), C.c_float(delta), _p(grad), _p(q))
+    return float(loss), grad, q
 
 
 class PPOTraj:

@@ -230,6 +230,19 @@ void rlo_ring_sample_indices(const rlo_ring* rb, int64_t batch, uint64_t seed, u
 void rlo_ring_gather(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, float* s,
                      int32_t* a, float* r, uint8_t* term, float* s_next);
 
+/* ------------------------------------------------ 3-layer bf16 Q-network -- */
+/* Chain(Dense(ns, h, act), Dense(h, h, act), Dense(h, na)) (blog DQN net, index.html:15126-15128); the
+ * hidden x hidden layer in bf16 with f32 accumulate (rlo_mlp3.c). */
+float rlo_bf16_round_f32(float f);
+int64_t rlo_mlp3_nparams(int64_t ns, int64_t h, int64_t na);
+void rlo_mlp3_init_f32(float* p, int64_t ns, int64_t h, int64_t na, uint64_t seed, uint32_t net_id);
+void rlo_mlp3_forward_f32(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x,
+                          int64_t batch, float* out);
+float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
+                             const float* target_params, const float* s, const int32_t* a, const float* r,
+                             const uint8_t* term, const float* s_next, int64_t b, float gamma, float huber_delta,
+                             float* grad, float* q_out);
+
 /* ---------------------------------------------------- priority sum-tree -- */
 /* CircularArrayBuffers.SumTree (0.1.12) / RLTrajectories 0.4 prioritized BatchSampler, un-vendored: PARITY
  * UNPINNED.  Implicit heap float tree[2P], P = next pow2 >= n_leaves, leaf k at P + k (the reference's
@@ -241,6 +254,7 @@ void rlo_sumtree_fill_range(float* tree, int64_t n_leaves, int64_t start, int64_
 void rlo_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf, const float* prio, int64_t n);
 void rlo_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch, uint64_t seed, uint32_t draw_ctr,
                         int64_t* leaf_out, float* prio_out);
+void rlo_per_priority_f32(const float* td, int64_t n, float eps, float alpha, float* out);
 /* leaf of the newest transition frame gets `priority`; prioritized draw mapped to logical flat indices */
 void rlo_ring_push_priority(const rlo_ring* rb, float* tree, float priority);
 void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t batch, uint64_t seed,

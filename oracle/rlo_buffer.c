@@ -15,6 +15,7 @@
  * Vector-env extension: one frame = one vec-step of n_env transitions, stored SoA.
  */
 #include "rl_oracle.h"
+#include <math.h>
 #include <string.h>
 
 void rlo_ring_init(rlo_ring* rb, int64_t capacity, int64_t n_env, int64_t obs_dim, float* state,
@@ -174,5 +175,13 @@ void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t 
         int64_t k = keys[b];
         flat_idx[b] = li * rb->n_env + e;
         if (key_out) key_out[b] = k;
+    }
+}
+
+/* PrioritizedDQN write-back value (removed Zoo learner): p = (|td| + eps)^alpha, power in double, rounded once */
+void rlo_per_priority_f32(const float* td, int64_t n, float eps, float alpha, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        float x = fabsf(td[i]) + eps;
+        out[i] = (alpha == 1.0f) ? x : (float)pow((double)x, (double)alpha);
     }
 }

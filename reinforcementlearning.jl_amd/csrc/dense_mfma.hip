@@ -19,20 +19,9 @@
 // Roofline: MFMA (dense bf16 peak ~2.5 PFLOP/s); 2*B*K*N flop per launch.  This first version has no LDS
 // staging / software pipelining -- measured numbers in profiles/ and DESIGN.md; it is the parity-checked
 // starting point for the tuned kernel, not the end state.
-#include "common.h"
+#include "mfma_common.h"
 
 namespace rlhip {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);                                           // round to nearest even
-    return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 constexpr int NT = 4;  // 32-column blocks per wave (128 output features)
 

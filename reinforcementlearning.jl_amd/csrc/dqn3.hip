@@ -1,0 +1,693 @@
+// dqn3.hip -- the DQN hot path for the blog's three-layer Q-network, hidden x hidden layer on the MFMA.
+//
+//   Chain(Dense(ns, 128, act), Dense(128, 128, act), Dense(128, na))
+//   (docs/homepage/blog/a_practical_introduction_to_RL.jl/index.html:15126-15128)
+//
+// What it replaces: the same reference code as dqn.hip -- forward(learner, x) = model(x)
+// (RLCore/src/policies/learners/flux_approximator.jl:43) inside plan!(QBasedPolicy) (q_based_policy.jl:30-32)
+// + EpsilonGreedyExplorer (explorers/epsilon_greedy_explorer.jl:108-112), and optimise!(learner, batch) of the
+// removed Zoo DQN learner (y = r + gamma (1 - t) max_a' Qt(s', a'), Flux.Losses.huber_loss, Zygote backward).
+//
+// Precision contract (BASELINE.json: "MFMA used only for the dense ... MLP GEMMs"; f32 master weights):
+//   layer 1 (K = ns <= 4) and the head (N = na <= 4) stay f32 on the VALU -- far below an MFMA tile;
+//   the 128 x 128 hidden layer runs on v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (RNE), f32 accumulate;
+//   backward: dz2 is rounded to bf16 for dW2 = dz2^T h1 and dh1 = dz2 W2 (both MFMA); every bias / first-layer
+//   / head gradient is f32.  The oracle (oracle/rlo_mlp3.c) applies the same roundings, so the only difference
+//   left is the MFMA's internal summation order (tolerance stated in tests/test_gpu_dqn3.py).
+//
+// One workgroup (4 waves) owns a tile of 128 samples; wave w owns rows 32w..32w+31 of every row-parallel GEMM.
+// All three GEMMs are "A rows x B rows, both reduction-contiguous", so every MFMA fragment is one 16-byte read:
+//   forward   Z2[r][j]  = sum_k H1[r][k]  W2[j][k]    A = H1 tile  (LDS [r][k])   B = W2jk (global, L2-hot)
+//   backward  dH1[r][k] = sum_j dZ2[r][j] W2[j][k]    A = dZ2 tile (LDS [r][j])   B = W2kj (global)
+//   backward  dW2[j][k] = sum_r dZ2[r][j] H1[r][k]    A = H1^T     (LDS [k][r])   B = dZ2^T (LDS [j][r])
+// LDS tiles are bf16 with a 272-byte row pitch (68 dwords: conflict-free ds_read_b128 over 16-lane phases).
+// The transposed copies are produced where the values are produced (VALU), never by an LDS transpose pass.
+// Roofline: MFMA for the three 128^3 GEMMs per tile (3 * 2 * 128^3 = 12.6 MFLOP); at DQN batch sizes (<= 4096
+// samples = 32 workgroups) the launch is latency-bound -- measured numbers in profiles/ and DESIGN.md.
+#include "mfma_common.h"
+#include "mlp_device.h"
+#include "select_device.h"
+
+namespace rlhip {
+
+constexpr int H3 = 128;   // hidden width of the MFMA path
+constexpr int TR = 128;   // samples per tile (4 waves x 32 rows)
+constexpr int LDH = 136;  // LDS row pitch in bf16 elements (272 B)
+constexpr int TILE_ELEMS = TR * LDH;
+constexpr int D3_MAX_BLOCKS = 1024;
+
+__host__ __device__ __forceinline__ int64_t mlp3_nparams(int64_t ns, int64_t h, int64_t na) {
+    return h * ns + h + h * h + h + na * h + na;
+}
+
+struct Mlp3 {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+};
+__host__ __device__ __forceinline__ Mlp3 mlp3_view(const float* p, int ns, int na) {
+    Mlp3 v;
+    v.W1 = p;
+    v.b1 = v.W1 + H3 * ns;
+    v.W2 = v.b1 + H3;
+    v.b2 = v.W2 + H3 * H3;
+    v.W3 = v.b2 + H3;
+    v.b3 = v.W3 + na * H3;
+    return v;
+}
+
+// acc[t] += A(32 x 128) * B(128 x 128)^T ; A element (row, kk) at A[row * lda + kk], B element (col, kk) at
+// B[col * ldb + kk]; the wave's 32 A rows start at A.
+__device__ __forceinline__ void gemm_slab(const uint16_t* A, int lda, const uint16_t* B, int ldb, f32x16 (&acc)[4],
+                                          int lane) {
+    const int r = lane & 31, kb = lane >> 5;
+    const uint16_t* ap = A + r * lda + 8 * kb;
+    const uint16_t* bp = B + r * ldb + 8 * kb;
+#pragma unroll
+    for (int k0 = 0; k0 < H3; k0 += 16) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + (32 * t) * ldb + k0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+}
+
+__device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16_rne(v[2]) | ((uint32_t)f32_to_bf16_rne(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16_rne(v[4]) | ((uint32_t)f32_to_bf16_rne(v[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16_rne(v[6]) | ((uint32_t)f32_to_bf16_rne(v[7]) << 16);
+    return o;
+}
+
+// h1 = act(b1 + W1 x) for the whole tile, written as bf16 in [row][k] layout (dst_rk) and, when dst_kr is
+// non-NULL, also in [k][row] layout.  lx: f32 [NS][TR] in LDS.  Same fmaf chain as mlp2 / the oracle.
+template <int NS, int ACT>
+__device__ __forceinline__ void layer1_to_lds(const Mlp3& m, const float* lx, uint16_t* dst_rk, uint16_t* dst_kr,
+                                              int tid) {
+    {
+        const int g = tid & 15, r0 = tid >> 4;  // this thread: units 8g..8g+7, rows r0 + 16 it
+        float w1[8][NS], bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bb[u] = m.b1[8 * g + u];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) w1[u][i] = m.W1[8 * g + u + H3 * i];
+        }
+#pragma unroll
+        for (int it = 0; it < TR / 16; ++it) {
+            const int row = r0 + 16 * it;
+            float x[NS], hv[8];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = lx[i * TR + row];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float z = bb[u];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) z = fmaf(w1[u][i], x[i], z);
+                hv[u] = act_fwd_t<ACT>(z);
+            }
+            *reinterpret_cast<uint4*>(dst_rk + row * LDH + 8 * g) = pack8_bf16(hv);
+        }
+    }
+    if (dst_kr) {
+        const int rg = tid & 15, k0 = tid >> 4;  // this thread: rows 8rg..8rg+7, units k0 + 16 it
+        float x[8][NS];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[u][i] = lx[i * TR + 8 * rg + u];
+#pragma unroll
+        for (int it = 0; it < H3 / 16; ++it) {
+            const int k = k0 + 16 * it;
+            float w1[NS], hv[8];
+            const float bb = m.b1[k];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) w1[i] = m.W1[k + H3 * i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float z = bb;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], x[u][i], z);
+                hv[u] = act_fwd_t<ACT>(z);
+            }
+            *reinterpret_cast<uint4*>(dst_kr + k * LDH + 8 * rg) = pack8_bf16(hv);
+        }
+    }
+}
+
+// hidden layer 2 (MFMA) + bias + activation for this wave's 32 rows; h2[t][q] in the MFMA D layout
+template <int ACT>
+__device__ __forceinline__ void layer2(const uint16_t* l_h1rk, const uint16_t* w2jk, const float* b2, int w, int lane,
+                                       f32x16 (&h2)[4]) {
+    zero_acc(h2);
+    gemm_slab(l_h1rk + 32 * w * LDH, LDH, w2jk, H3, h2, lane);
+    const int r = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float bv = b2[r + 32 * t];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h2[t][q] = act_fwd_t<ACT>(h2[t][q] + bv);
+    }
+}
+
+// head: q[o] = b3[o] + sum_j W3[o, j] h2[j] for the wave's 32 rows -> l_q[o][row]   (f32 [MAXO][TR])
+__device__ __forceinline__ void head_to_lds(const Mlp3& m, int na, const f32x16 (&h2)[4], int w, int lane, float* l_q) {
+    const int r = lane & 31, kb = lane >> 5;
+    float w3[MAXO][4];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w3[o][t] = (o < na) ? m.W3[o + na * (r + 32 * t)] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float p[MAXO];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            float a = w3[o][0] * h2[0][q];
+#pragma unroll
+            for (int t = 1; t < 4; ++t) a = fmaf(w3[o][t], h2[t][q], a);
+            p[o] = a;
+        }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (o < na) p[o] += __shfl_xor(p[o], off, 64);
+        }
+        if (r == 0) {
+            const int row = 32 * w + mfma_row(q, kb);
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (o < na) l_q[o * TR + row] = p[o] + m.b3[o];
+        }
+    }
+}
+
+struct RegQ3 {
+    const float* q;
+    __device__ __forceinline__ float operator()(int k) const { return q[k]; }
+};
+
+// ------------------------------------------------------------------------------ forward / plan!
+template <int NS, int ACT>
+__global__ __launch_bounds__(256) void mlp3_plan_kernel(const float* __restrict__ params,
+                                                        const uint16_t* __restrict__ packed, int na,
+                                                        const float* __restrict__ obs, int64_t n, double eps,
+                                                        uint64_t seed, uint32_t env_id_base, uint32_t step,
+                                                        int32_t* __restrict__ actions, float* __restrict__ q_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    float* l_x = reinterpret_cast<float*>(smem3);                       // [4][TR]
+    float* l_q = l_x + 4 * TR;                                          // [MAXO][TR]
+    uint16_t* l_A = reinterpret_cast<uint16_t*>(l_q + MAXO * TR);       // [TR][LDH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Mlp3 m = mlp3_view(params, NS, na);
+    const int64_t e0 = (int64_t)blockIdx.x * TR;
+    if (tid < TR) {
+        int64_t e = e0 + tid;
+        if (e >= n) e = n - 1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) l_x[i * TR + tid] = obs[(int64_t)i * n + e];
+    }
+    __syncthreads();
+    layer1_to_lds<NS, ACT>(m, l_x, l_A, nullptr, tid);
+    __syncthreads();
+    f32x16 h2[4];
+    layer2<ACT>(l_A, packed, m.b2, w, lane, h2);
+    head_to_lds(m, na, h2, w, lane, l_q);
+    __syncthreads();
+    if (tid < TR && e0 + tid < n) {
+        const int64_t e = e0 + tid;
+        float q[MAXO];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) q[o] = (o < na) ? l_q[o * TR + tid] : 0.0f;
+        if (q_out)
+            for (int o = 0; o < na; ++o) q_out[(int64_t)o * n + e] = q[o];
+        if (actions) {
+            actions[e] = eps_greedy_select1(RegQ3{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)e, step);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- gradient
+struct Dqn3Args {
+    const float* state;
+    const int32_t* action;
+    const float* reward;
+    const uint8_t* terminal;
+    int64_t capacity, n_env, head_sa, head_rt;
+    uint64_t total;
+    const int64_t* idx;  // optional explicit flat logical indices (prioritized sampler); NULL = inline uniform draw
+    const float* params;
+    const float* tparams;
+    const uint16_t* packed;   // online net: W2jk | W2kj
+    const uint16_t* tpacked;  // target net
+    float* partials;          // [nb][np]
+    float* loss_partials;     // [nb]
+    float* td_out;            // optional |Q(s,a) - y| per sample (priority write-back), may be NULL
+    int na, np;
+    int64_t batch;
+    float gamma, delta, inv_b;
+    uint64_t seed;
+    uint32_t draw_ctr;
+};
+
+// column sums held per lane (col = r + 32 t) for NV quantities -> l_red[w][v][col], then summed over the 4 waves
+// by threads 0..127 in a fixed order.
+template <int NV>
+__device__ __forceinline__ void reduce_cols_to_lds(float (&acc)[NV][4], float* l_red, int w, int lane) {
+    const int r = lane & 31, kb = lane >> 5;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float s = acc[v][t] + __shfl_xor(acc[v][t], 32, 64);
+            if (kb == 0) l_red[(w * NV + v) * H3 + r + 32 * t] = s;
+        }
+}
+template <int NV>
+__device__ __forceinline__ float sum_waves(const float* l_red, int v, int c) {
+    return ((l_red[(0 * NV + v) * H3 + c] + l_red[(1 * NV + v) * H3 + c]) + l_red[(2 * NV + v) * H3 + c]) +
+           l_red[(3 * NV + v) * H3 + c];
+}
+
+template <int NS, int ACT>
+__global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    float* l_x = reinterpret_cast<float*>(smem3);       // [4][TR]
+    float* l_xn = l_x + 4 * TR;                         // [4][TR]
+    float* l_q = l_xn + 4 * TR;                         // [MAXO][TR]
+    float* l_qn = l_q + MAXO * TR;                      // [MAXO][TR]
+    float* l_dq = l_qn + MAXO * TR;                     // [MAXO][TR]
+    float* l_r = l_dq + MAXO * TR;                      // [TR]
+    float* l_small = l_r + TR;                          // [2][8]
+    int32_t* l_a = reinterpret_cast<int32_t*>(l_small + 16);  // [TR]
+    int32_t* l_t = l_a + TR;                                  // [TR]
+    float* l_red = reinterpret_cast<float*>(l_t + TR);        // [4][5][H3]
+    uint16_t* l_A = reinterpret_cast<uint16_t*>(l_red + 4 * 5 * H3);  // H1 [r][k], later dZ2 [r][j]
+    uint16_t* l_B = l_A + TILE_ELEMS;                                 // H1^T [k][r]
+    uint16_t* l_C = l_B + TILE_ELEMS;                                 // dZ2^T [j][r]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int na = g.na;
+    const Mlp3 m = mlp3_view(g.params, NS, na);
+    const Mlp3 mt = mlp3_view(g.tparams, NS, na);
+    const int tile = blockIdx.x;
+    float* out = g.partials + (int64_t)blockIdx.x * g.np;
+    const int oW1 = 0, ob1 = H3 * NS, oW2 = ob1 + H3, ob2 = oW2 + H3 * H3, oW3 = ob2 + H3, ob3 = oW3 + na * H3;
+
+    // ---- sample + gather the tile's transitions straight from the HBM ring ----
+    if (tid < TR) {
+        int64_t b = (int64_t)tile * TR + tid;
+        bool valid = b < g.batch;
+        int64_t fj;
+        if (g.idx) {
+            fj = g.idx[valid ? b : 0];
+        } else {
+            u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
+            uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
+            fj = (int64_t)__umul64hi(xr, g.total);
+        }
+        int64_t li = fj / g.n_env, e = fj - li * g.n_env;
+        int64_t ps = (g.head_sa + li) % (g.capacity + 1);
+        int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
+        int64_t pt = (g.head_rt + li) % g.capacity;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            l_x[k * TR + tid] = g.state[(ps * NS + k) * g.n_env + e];
+            l_xn[k * TR + tid] = g.state[(pn * NS + k) * g.n_env + e];
+        }
+        l_a[tid] = g.action[pt * g.n_env + e];
+        l_r[tid] = g.reward[pt * g.n_env + e];
+        l_t[tid] = g.terminal[pt * g.n_env + e];
+    }
+    __syncthreads();
+
+    // ---- target network on s' ----
+    f32x16 h2[4];
+    layer1_to_lds<NS, ACT>(mt, l_xn, l_A, nullptr, tid);
+    __syncthreads();
+    layer2<ACT>(l_A, g.tpacked, mt.b2, w, lane, h2);
+    head_to_lds(mt, na, h2, w, lane, l_qn);
+    __syncthreads();  // all waves are done reading l_A
+
+    // ---- online network on s (h2 stays in registers for the backward pass) ----
+    layer1_to_lds<NS, ACT>(m, l_x, l_A, l_B, tid);
+    __syncthreads();
+    layer2<ACT>(l_A, g.packed, m.b2, w, lane, h2);
+    head_to_lds(m, na, h2, w, lane, l_q);
+    __syncthreads();
+
+    // ---- TD target, Huber loss, dL/dq per sample ----
+    if (tid < TR) {
+        const int s = tid;
+        const int64_t b = (int64_t)tile * TR + s;
+        const bool valid = b < g.batch;
+        float mx = l_qn[s];
+        for (int k = 1; k < na; ++k) mx = fmaxf(mx, l_qn[k * TR + s]);
+        float cont = l_t[s] ? 0.f : 1.f;
+        float G = l_r[s] + g.gamma * cont * mx;
+        int a = l_a[s];
+        float qa = 0.f;
+        for (int k = 0; k < na; ++k)
+            if (k == a) qa = l_q[k * TR + s];
+        float d = qa - G;
+        float e = fabsf(d);
+        float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
+        float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
+        gi *= g.inv_b;
+        if (!valid) {
+            gi = 0.f;
+            l = 0.f;
+        }
+        if (valid && g.td_out) g.td_out[b] = e;
+        float red[MAXO + 1];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            float dl = (o == a) ? gi : 0.f;
+            l_dq[o * TR + s] = dl;
+            red[o] = dl;
+        }
+        red[MAXO] = l;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int o = 0; o <= MAXO; ++o) red[o] += __shfl_down(red[o], off, 64);
+        if (lane == 0)
+#pragma unroll
+            for (int o = 0; o <= MAXO; ++o) l_small[w * 8 + o] = red[o];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int o = 0; o < na; ++o) out[ob3 + o] = l_small[o] + l_small[8 + o];
+        g.loss_partials[blockIdx.x] = l_small[MAXO] + l_small[8 + MAXO];
+    }
+
+    // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32), db2; dz2 -> bf16 tiles [r][j] and [j][r] ----
+    {
+        float w3[MAXO][4];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w3[o][t] = (o < na) ? m.W3[o + na * (r + 32 * t)] : 0.0f;
+        float acc[MAXO + 1][4];  // [0] = db2, [1 + o] = dW3[o]
+#pragma unroll
+        for (int v = 0; v <= MAXO; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[v][t] = 0.0f;
+        uint16_t pk[4][4];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * w + mfma_row(q, kb);
+            float dqv[MAXO];
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) dqv[o] = (o < na) ? l_dq[o * TR + row] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float hv = h2[t][q];
+                float dh = 0.0f;
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o)
+                    if (o < na) {
+                        acc[1 + o][t] = fmaf(dqv[o], hv, acc[1 + o][t]);
+                        dh = fmaf(dqv[o], w3[o][t], dh);
+                    }
+                const float dz = dh * act_bwd_t<ACT>(hv, hv);  // relu: h2 > 0 <=> z2 > 0
+                acc[0][t] += dz;
+                const uint16_t dzb = f32_to_bf16_rne(dz);
+                l_A[row * LDH + r + 32 * t] = dzb;
+                pk[t][q & 3] = dzb;
+                if ((q & 3) == 3) {
+                    uint2 v2;
+                    v2.x = (uint32_t)pk[t][0] | ((uint32_t)pk[t][1] << 16);
+                    v2.y = (uint32_t)pk[t][2] | ((uint32_t)pk[t][3] << 16);
+                    *reinterpret_cast<uint2*>(l_C + (r + 32 * t) * LDH + 32 * w + 8 * (q >> 2) + 4 * kb) = v2;
+                }
+            }
+        }
+        reduce_cols_to_lds<MAXO + 1>(acc, l_red, w, lane);
+    }
+    __syncthreads();
+    if (tid < H3) {
+        out[ob2 + tid] = sum_waves<MAXO + 1>(l_red, 0, tid);
+        for (int o = 0; o < na; ++o) out[oW3 + o + na * tid] = sum_waves<MAXO + 1>(l_red, 1 + o, tid);
+    }
+    __syncthreads();  // l_red is reused below
+
+    // ---- dH1 = dZ2 * W2 (MFMA), dz1 = dH1 * act'(z1), dW1 / db1 (f32) ----
+    {
+        f32x16 dh1[4];
+        zero_acc(dh1);
+        gemm_slab(l_A + 32 * w * LDH, LDH, g.packed + H3 * H3, H3, dh1, lane);
+        float w1[4][NS], bb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bb[t] = m.b1[r + 32 * t];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) w1[t][i] = m.W1[r + 32 * t + H3 * i];
+        }
+        float acc[NS + 1][4];  // [0] = db1, [1 + i] = dW1[:, i]
+#pragma unroll
+        for (int v = 0; v <= NS; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[v][t] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * w + mfma_row(q, kb);
+            float x[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = l_x[i * TR + row];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float z = bb[t];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) z = fmaf(w1[t][i], x[i], z);
+                const float hv = act_fwd_t<ACT>(z);
+                const float dz = dh1[t][q] * act_bwd_t<ACT>(z, hv);
+                acc[0][t] += dz;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc[1 + i][t] = fmaf(dz, x[i], acc[1 + i][t]);
+            }
+        }
+        reduce_cols_to_lds<NS + 1>(acc, l_red, w, lane);
+    }
+    __syncthreads();
+    if (tid < H3) {
+        out[ob1 + tid] = sum_waves<NS + 1>(l_red, 0, tid);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) out[oW1 + tid + H3 * i] = sum_waves<NS + 1>(l_red, 1 + i, tid);
+    }
+
+    // ---- dW2^T[k][j] = sum_r H1[r][k] dZ2[r][j] (MFMA); stored as Flux W2[j + h k] ----
+    {
+        f32x16 dw[4];
+        zero_acc(dw);
+        gemm_slab(l_B + 32 * w * LDH, LDH, l_C, LDH, dw, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp3_pack_kernel(const float* __restrict__ params, int ns,
+                                                        uint16_t* __restrict__ packed) {
+    const float* W2 = params + H3 * ns + H3;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= H3 * H3) return;
+    int j = q / H3, k = q % H3;
+    packed[q] = f32_to_bf16_rne(W2[j + H3 * k]);            // W2jk[j][k]
+    packed[H3 * H3 + q] = f32_to_bf16_rne(W2[k + H3 * j]);  // W2kj[j'][k'] with (j', k') = (k-index, j-index)
+}
+
+// glorot_uniform stand-in (same convention as mlp2_init_kernel): tensor ids net_id * 4 + {0: W1, 1: W2, 2: W3}
+__global__ __launch_bounds__(256) void mlp3_init_kernel(float* __restrict__ p, int ns, int h, int na, uint64_t seed,
+                                                        uint32_t net_id) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t o1 = (int64_t)h * ns, o2 = o1 + h, o3 = o2 + (int64_t)h * h, o4 = o3 + h, o5 = o4 + (int64_t)na * h;
+    if (q >= o5 + na) return;
+    float val = 0.0f;  // Flux Dense bias default: zeros
+    int64_t off = -1;
+    uint32_t tid = 0;
+    float fan = 1.0f;
+    if (q < o1) { off = q; tid = 0; fan = (float)(ns + h); }
+    else if (q >= o2 && q < o3) { off = q - o2; tid = 1; fan = (float)(h + h); }
+    else if (q >= o4 && q < o5) { off = q - o4; tid = 2; fan = (float)(h + na); }
+    if (off >= 0) {
+        u32x4 w = philox4x32_10(seed, (uint32_t)off, 0, net_id * 4u + tid, TAG_INIT);
+        val = (2.0f * u01_f32(w.x) - 1.0f) * sqrtf(6.0f / fan);
+    }
+    p[q] = val;
+}
+
+__global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ partials,
+                                                        const float* __restrict__ loss_partials, int nb, int np,
+                                                        float* __restrict__ grad, float* __restrict__ loss,
+                                                        float inv_b) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < np) {
+        float a = 0.f;
+        for (int b = 0; b < nb; ++b) a += partials[(int64_t)b * np + p];
+        grad[p] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64 && loss != nullptr) {
+        float a = 0.f;
+        for (int b = threadIdx.x; b < nb; b += 64) a += loss_partials[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (threadIdx.x == 0) loss[0] = a * inv_b;
+    }
+}
+
+constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
+constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3) * sizeof(float) +
+                            3 * TILE_ELEMS * sizeof(uint16_t);
+
+// gfx950 has 160 KB of LDS per workgroup; anything above 64 KB of dynamic LDS must be opted into per kernel
+template <typename K>
+static int32_t allow_lds(K kernel, size_t bytes, bool* done) {
+    if (*done) return RLHIP_OK;
+    RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    *done = true;
+    return RLHIP_OK;
+}
+
+}  // namespace rlhip
+
+using namespace rlhip;
+
+extern "C" {
+
+int64_t rlhip_mlp3_nparams(int64_t ns, int64_t h, int64_t na) { return mlp3_nparams(ns, h, na); }
+
+int64_t rlhip_mlp3_packed_elems(int64_t h) { return 2 * h * h; }
+
+int32_t rlhip_mlp3_init_f32(float* params, int64_t ns, int64_t h, int64_t na, uint64_t seed, uint32_t net_id,
+                            rlhip_stream_t stream) {
+    RLHIP_REQUIRE(params != nullptr && ns >= 1 && h >= 1 && na >= 1, "bad arguments");
+    int64_t np = mlp3_nparams(ns, h, na);
+    hipLaunchKernelGGL(mlp3_init_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, as_stream(stream), params, (int)ns,
+                       (int)h, (int)na, seed, net_id);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_mlp3_pack_bf16(const float* params, int64_t ns, int64_t h, int64_t na, uint16_t* packed,
+                             rlhip_stream_t stream) {
+    RLHIP_REQUIRE(params && packed, "NULL argument");
+    RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
+    RLHIP_REQUIRE(ns >= 2 && ns <= 4 && na >= 1 && na <= MAXO, "obs dim must be 2..4, na <= 4");
+    hipLaunchKernelGGL(mlp3_pack_kernel, dim3(H3 * H3 / 256), dim3(256), 0, as_stream(stream), params, (int)ns, packed);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t ns, int64_t h, int64_t na,
+                            int32_t act, const float* obs, int64_t n, double eps, uint64_t seed,
+                            uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
+                            rlhip_stream_t stream) {
+    RLHIP_REQUIRE(params && packed && obs && (actions || q_out), "NULL argument");
+    RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
+    RLHIP_REQUIRE(ns >= 2 && ns <= 4 && na >= 1 && na <= MAXO, "obs dim must be 2..4, na <= 4");
+    RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
+    RLHIP_REQUIRE((((uintptr_t)packed) & 15) == 0, "packed weights must be 16-byte aligned");
+    if (n == 0) return RLHIP_OK;
+    hipStream_t s = as_stream(stream);
+    dim3 grid((unsigned)((n + TR - 1) / TR));
+#define LAUNCH_P(NS_, ACT_)                                                                                      \
+    do {                                                                                                         \
+        static bool done_ = false;                                                                               \
+        int32_t rc_ = allow_lds(mlp3_plan_kernel<NS_, ACT_>, PLAN_LDS, &done_);                                  \
+        if (rc_) return rc_;                                                                                     \
+        hipLaunchKernelGGL((mlp3_plan_kernel<NS_, ACT_>), grid, dim3(256), PLAN_LDS, s, params, packed, (int)na, \
+                           obs, n, eps, seed, env_id_base, step, actions, q_out);                                \
+    } while (0)
+    if (ns == 4) { if (act == 0) LAUNCH_P(4, 0); else LAUNCH_P(4, 1); }
+    else if (ns == 3) { if (act == 0) LAUNCH_P(3, 0); else LAUNCH_P(3, 1); }
+    else { if (act == 0) LAUNCH_P(2, 0); else LAUNCH_P(2, 1); }
+#undef LAUNCH_P
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
+    int64_t nb = (batch + TR - 1) / TR;
+    if (nb < 1) nb = 1;
+    return nb * (mlp3_nparams(ns, h, na) + 1) * (int64_t)sizeof(float);
+}
+
+int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                            const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                            int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
+                            uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
+                            rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && params && packed && target_params && target_packed && workspace && grad_out, "NULL argument");
+    RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
+    RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
+    RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
+    RLHIP_REQUIRE(na >= 1 && na <= MAXO, "na must be <= 4");
+    RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
+    RLHIP_REQUIRE(batch >= 1, "empty batch");
+    RLHIP_REQUIRE(batch <= (int64_t)D3_MAX_BLOCKS * TR, "batch too large for one launch");
+    RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
+    RLHIP_REQUIRE(((((uintptr_t)packed) | ((uintptr_t)target_packed)) & 15) == 0, "packed weights must be 16-byte aligned");
+    const int ns = (int)rb->obs_dim;
+    const int64_t np = mlp3_nparams(ns, h, na);
+    const int nb = (int)((batch + TR - 1) / TR);
+    Dqn3Args g;
+    g.state = (const float*)rb->state;
+    g.action = rb->action;
+    g.reward = rb->reward;
+    g.terminal = rb->terminal;
+    g.capacity = rb->capacity;
+    g.n_env = rb->n_env;
+    g.head_sa = rb->head_sa;
+    g.head_rt = rb->head_rt;
+    g.total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
+    g.idx = idx;
+    g.params = params;
+    g.tparams = target_params;
+    g.packed = packed;
+    g.tpacked = target_packed;
+    g.partials = (float*)workspace;
+    g.loss_partials = g.partials + (int64_t)nb * np;
+    g.td_out = td_out;
+    g.na = (int)na;
+    g.np = (int)np;
+    g.batch = batch;
+    g.gamma = gamma;
+    g.delta = huber_delta;
+    g.inv_b = 1.0f / (float)batch;
+    g.seed = seed;
+    g.draw_ctr = draw_ctr;
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_G(NS_, ACT_)                                                                             \
+    do {                                                                                                \
+        static bool done_ = false;                                                                      \
+        int32_t rc_ = allow_lds(dqn3_grad_kernel<NS_, ACT_>, GRAD_LDS, &done_);                         \
+        if (rc_) return rc_;                                                                            \
+        hipLaunchKernelGGL((dqn3_grad_kernel<NS_, ACT_>), dim3(nb), dim3(256), GRAD_LDS, s, g);         \
+    } while (0)
+    if (ns == 4) { if (act == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
+    else if (ns == 3) { if (act == 0) LAUNCH_G(3, 0); else LAUNCH_G(3, 1); }
+    else { if (act == 0) LAUNCH_G(2, 0); else LAUNCH_G(2, 1); }
+#undef LAUNCH_G
+    hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials, nb,
+                       (int)np, grad_out, loss_out, g.inv_b);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// mfma_common.h -- bf16 helpers and the gfx950 MFMA fragment types shared by dense_mfma.hip / dqn3.hip.
+//
+// v_mfma_f32_32x32x16_bf16: D(32x32) += A(32x16) * B(16x32), one wave.  Register layout (MI355X guide
+// section 3; verified against a torch reference in tests/test_gpu_mfma.py):
+//   A: lane l holds A[row = l & 31][k = 8 * (l >> 5) .. +7]          (8 bf16 = one 16-byte load)
+//   B: lane l holds B[k = 8 * (l >> 5) .. +7][col = l & 31]
+//   D: lane l holds D[row = (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)][col = l & 31],  q = 0..15
+#pragma once
+#include "common.h"
+
+namespace rlhip {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// row of MFMA accumulator register q for a lane in half kb = lane >> 5
+__device__ __forceinline__ int mfma_row(int q, int kb) { return (q & 3) + 8 * (q >> 2) + 4 * kb; }
+
+}  // namespace rlhip

@@ -140,6 +140,15 @@ __device__ __forceinline__ int64_t sumtree_descend(const float* __restrict__ tre
     return node - P;
 }
 
+// PrioritizedDQN write-back: p = (|td| + eps)^alpha; the power is evaluated in Float64 and rounded once
+__global__ __launch_bounds__(256) void per_priority_kernel(const float* __restrict__ td, int64_t n, float eps,
+                                                           float alpha, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = fabsf(td[i]) + eps;
+    out[i] = (alpha == 1.0f) ? x : (float)pow((double)x, (double)alpha);
+}
+
 struct RingGeom {
     int64_t capacity, n_env, head_rt;
 };
@@ -222,6 +231,17 @@ int32_t rlhip_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch,
     hipLaunchKernelGGL((sumtree_sample_kernel<false>), dim3((int)((batch + 255) / 256)), dim3(256), 0, as_stream(stream),
                        tree, pow2_ge(n_leaves), n_leaves, batch, seed, draw_ctr, rg, (int64_t*)nullptr, leaf_out,
                        prio_out);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_per_priority_f32(const float* td, int64_t n, float eps, float alpha, float* out,
+                               rlhip_stream_t stream) {
+    RLHIP_REQUIRE(n >= 0 && eps >= 0.0f && alpha >= 0.0f, "bad arguments");
+    if (n == 0) return RLHIP_OK;
+    RLHIP_REQUIRE(td && out, "NULL array");
+    hipLaunchKernelGGL(per_priority_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream), td, n, eps,
+                       alpha, out);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

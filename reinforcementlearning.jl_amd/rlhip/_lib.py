@@ -135,10 +135,19 @@ _PROTOS = {
     "rlhip_ring_sample_indices": (i32, [P(Ring), i64, u64, u32, vp, vp]),
     "rlhip_ring_gather_is_frame_major": (i32, [P(Ring)]),
     "rlhip_ring_gather": (i32, [P(Ring), vp, i64, vp, vp, vp, vp, vp, vp]),
+    "rlhip_mlp3_nparams": (i64, [i64, i64, i64]),
+    "rlhip_mlp3_packed_elems": (i64, [i64]),
+    "rlhip_mlp3_init_f32": (i32, [vp, i64, i64, i64, u64, u32, vp]),
+    "rlhip_mlp3_pack_bf16": (i32, [vp, i64, i64, i64, vp, vp]),
+    "rlhip_dqn3_plan_f32": (i32, [vp, vp, i64, i64, i64, i32, vp, i64, f64, u64, u32, u32, vp, vp, vp]),
+    "rlhip_dqn3_workspace_bytes": (i64, [i64, i64, i64, i64]),
+    "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
+                                  vp, vp]),
     "rlhip_sumtree_nodes": (i64, [i64]),
     "rlhip_sumtree_fill_range": (i32, [vp, i64, i64, i64, f32, vp]),
     "rlhip_sumtree_update": (i32, [vp, i64, vp, vp, i64, vp]),
     "rlhip_sumtree_sample": (i32, [vp, i64, i64, u64, u32, vp, vp, vp]),
+    "rlhip_per_priority_f32": (i32, [vp, i64, f32, f32, vp, vp]),
     "rlhip_ring_push_priority": (i32, [P(Ring), vp, f32, vp]),
     "rlhip_ring_sample_prioritized": (i32, [P(Ring), vp, i64, u64, u32, vp, vp, vp, vp]),
     "rlhip_mlp2_nparams": (i64, [i64, i64, i64]),

@@ -46,6 +46,47 @@ def dqn_plan(params, ns, h, na, act, obs, eps, seed, env_id_base, step, actions=
     return actions, q_out
 
 
+def mlp3_init(ns, h, na, seed, net_id=0, device="cuda"):
+    p = torch.empty(int(_lib.lib.rlhip_mlp3_nparams(ns, h, na)), dtype=torch.float32, device=device)
+    call("rlhip_mlp3_init_f32", ptr(p), ns, h, na, seed, net_id, stream_ptr())
+    return p
+
+
+def mlp3_pack(params, ns, h, na, packed=None):
+    """bf16 copies of W2 in both MFMA operand orders (refresh after every parameter update)."""
+    if packed is None:
+        packed = torch.empty(int(_lib.lib.rlhip_mlp3_packed_elems(h)), dtype=torch.int16, device=params.device)
+    call("rlhip_mlp3_pack_bf16", ptr(params), ns, h, na, ptr(packed), stream_ptr())
+    return packed
+
+
+def dqn3_plan(params, packed, ns, h, na, act, obs, eps=0.0, seed=0, env_id_base=0, step=0, actions=None, q_out=None,
+              want_actions=True):
+    n = obs.shape[1]
+    if want_actions and actions is None:
+        actions = torch.empty(n, dtype=torch.int32, device=obs.device)
+    q_out = q_out if q_out is not None else torch.empty((na, n), dtype=torch.float32, device=obs.device)
+    call("rlhip_dqn3_plan_f32", ptr(params), ptr(packed), ns, h, na, act, ptr(obs), n, float(eps), seed, env_id_base,
+         step, ptr(actions) if want_actions else None, ptr(q_out), stream_ptr())
+    return actions, q_out
+
+
+def dqn3_workspace(ns, h, na, batch, device="cuda"):
+    return torch.empty(int(_lib.lib.rlhip_dqn3_workspace_bytes(ns, h, na, batch)), dtype=torch.uint8, device=device)
+
+
+def dqn3_grad(traces, h, na, act, params, packed, target_params, target_packed, batch, gamma, delta, seed, draw_ctr,
+              idx=None, workspace=None, grad=None, loss=None, td=None):
+    dev = params.device
+    workspace = workspace if workspace is not None else dqn3_workspace(traces.obs_dim, h, na, batch, dev)
+    grad = grad if grad is not None else torch.empty_like(params)
+    loss = loss if loss is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    call("rlhip_dqn3_grad_f32", C.byref(traces.rb), h, na, act, ptr(params), ptr(packed), ptr(target_params),
+         ptr(target_packed), batch, None if idx is None else ptr(idx), gamma, delta, seed, draw_ctr, ptr(workspace),
+         ptr(grad), ptr(loss), None if td is None else ptr(td), stream_ptr())
+    return grad, loss
+
+
 # ----------------------------------------------------------------------------------- explorers
 class EpsilonGreedyExplorer:
     """EpsilonGreedyExplorer(; ϵ_stable, kind = :linear, ϵ_init = 1.0, warmup_steps = 0, decay_steps = 0,
@@ -93,14 +134,20 @@ class HipApproximator:
     Flat parameters in Flux.destructure order + Adam state, all in HBM."""
 
     def __init__(self, n_in, hidden, n_out, act="relu", lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, seed=0,
-                 net_id=0, device="cuda", params=None):
-        self.n_in, self.hidden, self.n_out = n_in, hidden, n_out
+                 net_id=0, device="cuda", params=None, layers=2):
+        """layers = 3: Chain(Dense(n_in, h, act), Dense(h, h, act), Dense(h, n_out)) -- the blog's DQN model; the
+        hidden x hidden layer runs in bf16 on the MFMA (dqn3.hip), hidden must be 128."""
+        if layers not in (2, 3):
+            raise ValueError("layers must be 2 or 3")
+        self.n_in, self.hidden, self.n_out, self.layers = n_in, hidden, n_out, layers
         self.act = {"relu": 0, "tanh": 1}[act] if isinstance(act, str) else int(act)
         self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
         from .ops import mlp2_init
 
-        self.params = mlp2_init(n_in, hidden, n_out, seed, net_id, device) if params is None else \
+        init = mlp2_init if layers == 2 else mlp3_init
+        self.params = init(n_in, hidden, n_out, seed, net_id, device) if params is None else \
             torch.as_tensor(params, dtype=torch.float32, device=device).clone()
+        self.packed = mlp3_pack(self.params, n_in, hidden, n_out) if layers == 3 else None
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.beta_pow = torch.tensor([beta1, beta2], dtype=torch.float32, device=device)
@@ -110,6 +157,9 @@ class HipApproximator:
         """forward(A, x) = A.model(x)  (flux_approximator.jl:43): x (n_in, batch) -> (n_out, batch)."""
         from .ops import mlp2_forward
 
+        if self.layers == 3:
+            return dqn3_plan(self.params, self.packed, self.n_in, self.hidden, self.n_out, self.act, x,
+                             want_actions=False)[1]
         return mlp2_forward(self.params, self.n_in, self.hidden, self.n_out, self.act, x)
 
     def optimise_(self, grad, clip_norm=0.0, grad_scale=1.0):
@@ -118,6 +168,8 @@ class HipApproximator:
 
         clip_adam_(self.params, grad, self.m, self.v, self.beta_pow, grad_scale, clip_norm, self.lr, self.beta1,
                    self.beta2, self.eps, self.gn)
+        if self.layers == 3:
+            mlp3_pack(self.params, self.n_in, self.hidden, self.n_out, self.packed)
 
 
 class TargetNetwork:
@@ -128,6 +180,7 @@ class TargetNetwork:
             raise AssertionError("ρ must in [0,1]")  # :50
         self.network, self.sync_freq, self.rho, self.n_optimise = network, int(sync_freq), float(rho), 0
         self.target = network.params.clone()
+        self.target_packed = network.packed.clone() if network.layers == 3 else None
 
     def forward(self, x):
         return self.network.forward(x)
@@ -142,6 +195,9 @@ class TargetNetwork:
         if self.n_optimise % self.sync_freq == 0:
             polyak_(self.target, self.network.params, self.rho)
             self.n_optimise = 0
+            net = self.network
+            if net.layers == 3:
+                mlp3_pack(self.target, net.n_in, net.hidden, net.n_out, self.target_packed)
 
 
 # -------------------------------------------------------------------------------------- learner
@@ -151,7 +207,8 @@ class DQNLearner:
     Huber loss, gradient, [all-reduce], Adam, target sync."""
 
     def __init__(self, approximator, batchsize=32, gamma=0.99, huber_delta=1.0, min_replay_history=100,
-                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None):
+                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None, per_eps=1e-6, per_alpha=0.6):
+        self.per_eps, self.per_alpha = float(per_eps), float(per_alpha)
         self.approximator = approximator  # a TargetNetwork
         net = approximator.network
         self.batchsize, self.gamma, self.delta = batchsize, gamma, huber_delta
@@ -160,7 +217,11 @@ class DQNLearner:
         self.process_group = process_group
         self.grad = torch.zeros_like(net.params)
         self.loss = torch.zeros(1, dtype=torch.float32, device=net.params.device)
-        self.workspace = dqn_workspace(net.n_in, net.hidden, net.n_out, batchsize, net.params.device)
+        ws = dqn_workspace if net.layers == 2 else dqn3_workspace
+        self.workspace = ws(net.n_in, net.hidden, net.n_out, batchsize, net.params.device)
+        dev = net.params.device
+        self.td = torch.zeros(batchsize, dtype=torch.float32, device=dev) if net.layers == 3 else None
+        self._idx = self._key = self._prio = None
 
     def forward(self, x):
         return self.approximator.forward(x)
@@ -170,8 +231,23 @@ class DQNLearner:
         if traces.n_transitions() < self.min_replay_history:
             return False
         net = self.approximator.network
-        dqn_grad(traces, net.hidden, net.n_out, net.act, net.params, self.approximator.target, self.batchsize,
-                 self.gamma, self.delta, self.seed, self.draw_ctr, self.workspace, self.grad, self.loss)
+        prioritized = hasattr(traces, "sample_prioritized")
+        if net.layers == 3:
+            idx = None
+            if prioritized:  # prioritized BatchSampler: keys + priorities from the device sum-tree
+                idx, self._key, self._prio = traces.sample_prioritized(self.batchsize, self.seed, self.draw_ctr)
+            dqn3_grad(traces, net.hidden, net.n_out, net.act, net.params, net.packed, self.approximator.target,
+                      self.approximator.target_packed, self.batchsize, self.gamma, self.delta, self.seed,
+                      self.draw_ctr, idx, self.workspace, self.grad, self.loss, self.td)
+            if prioritized:  # trajectory[:priority, keys] = (|td| + eps)^alpha  (PrioritizedDQN write-back)
+                call("rlhip_per_priority_f32", ptr(self.td), self.batchsize, self.per_eps, self.per_alpha,
+                     ptr(self.td), stream_ptr())
+                traces.set_priority_(self._key, self.td)
+        else:
+            if prioritized:
+                raise NotImplementedError("prioritized replay is wired to the 3-layer (MFMA) Q-network path")
+            dqn_grad(traces, net.hidden, net.n_out, net.act, net.params, self.approximator.target, self.batchsize,
+                     self.gamma, self.delta, self.seed, self.draw_ctr, self.workspace, self.grad, self.loss)
         self.draw_ctr += 1
         scale = 1.0
         if self.process_group is not None:
@@ -203,8 +279,13 @@ class QBasedPolicy:
         eps = ex.get_eps()
         step = ex.step
         ex.step += 1
-        self._actions, self._q = dqn_plan(net.params, net.n_in, net.hidden, net.n_out, net.act, env.state(), eps,
-                                          ex.seed, env.env_id_base, step, self._actions, self._q)
+        if net.layers == 3:
+            self._actions, self._q = dqn3_plan(net.params, net.packed, net.n_in, net.hidden, net.n_out, net.act,
+                                               env.state(), eps, ex.seed, env.env_id_base, step, self._actions,
+                                               self._q)
+        else:
+            self._actions, self._q = dqn_plan(net.params, net.n_in, net.hidden, net.n_out, net.act, env.state(), eps,
+                                              ex.seed, env.env_id_base, step, self._actions, self._q)
         return self._actions + 1
 
     def optimise_(self, trajectory):
