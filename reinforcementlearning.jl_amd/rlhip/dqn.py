@@ -180,7 +180,7 @@ class TargetNetwork:
             raise AssertionError("ρ must in [0,1]")  # :50
         self.network, self.sync_freq, self.rho, self.n_optimise = network, int(sync_freq), float(rho), 0
         self.target = network.params.clone()
-        self.target_packed = network.packed.clone() if network.layers == 3 else None
+        self.target_packed = network.packed.clone() if getattr(network, "layers", 2) == 3 else None
 
     def forward(self, x):
         return self.network.forward(x)
@@ -196,7 +196,7 @@ class TargetNetwork:
             polyak_(self.target, self.network.params, self.rho)
             self.n_optimise = 0
             net = self.network
-            if net.layers == 3:
+            if getattr(net, "layers", 2) == 3:
                 mlp3_pack(self.target, net.n_in, net.hidden, net.n_out, self.target_packed)
 
 
