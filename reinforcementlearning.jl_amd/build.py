@@ -42,7 +42,7 @@ def _stale(target, deps):
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     if _stale(obj, [os.path.join(CSRC, src)] + headers()):
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + os.environ.get("RLHIP_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -36,6 +36,19 @@ constexpr int LDH = 136;  // LDS row pitch in bf16 elements (272 B)
 constexpr int TILE_ELEMS = TR * LDH;
 constexpr int D3_MAX_BLOCKS = 1024;
 
+// Phase timestamps of block 0 (compile with -DRLHIP_D3_TIMING; read with rlhip_debug_d3_stamps) -- dev only.
+#ifdef RLHIP_D3_TIMING
+__device__ long long g_d3_stamps[32];
+#define D3_STAMP(k)                                                              \
+    do {                                                                         \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_d3_stamps[k] = wall_clock64(); \
+    } while (0)
+#else
+#define D3_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
+
 __host__ __device__ __forceinline__ int64_t mlp3_nparams(int64_t ns, int64_t h, int64_t na) {
     return h * ns + h + h * h + h + na * h + na;
 }
@@ -54,22 +67,65 @@ __host__ __device__ __forceinline__ Mlp3 mlp3_view(const float* p, int ns, int n
     return v;
 }
 
-// acc[t] += A(32 x 128) * B(128 x 128)^T ; A element (row, kk) at A[row * lda + kk], B element (col, kk) at
-// B[col * ldb + kk]; the wave's 32 A rows start at A.
+// The small f32 tensors of one net (everything except W2) staged in LDS: W1 | b1 | b2 | W3 | b3, i.e. the two
+// contiguous parameter ranges around W2.  Global-memory round trips (~2 us each on a cold L2) were on the critical
+// path of every phase of the single-tile latency; LDS reads are ~30x closer.
+constexpr int SMALLW = H3 * 4 + H3 + H3 + MAXO * H3 + MAXO + 4;  // floats reserved per net (NS <= 4, na <= MAXO)
+
+__device__ __forceinline__ Mlp3 stage_small_weights(const float* __restrict__ p, int ns, int na, float* l_w, int tid) {
+    const int n1 = H3 * ns + H3;          // W1 | b1
+    const int n2 = H3 + na * H3 + na;     // b2 | W3 | b3
+    const float* p2 = p + n1 + H3 * H3;
+    for (int i = tid; i < n1; i += 256) l_w[i] = p[i];
+    for (int i = tid; i < n2; i += 256) l_w[n1 + i] = p2[i];
+    Mlp3 v;
+    v.W1 = l_w;
+    v.b1 = l_w + H3 * ns;
+    v.W2 = nullptr;
+    v.b2 = l_w + n1;
+    v.W3 = v.b2 + H3;
+    v.b3 = v.W3 + na * H3;
+    return v;
+}
+
+// acc[t] += A(32 x 128) * B(128 x 128)^T ; A element (row, kk) at A[row * lda + kk]; the wave's 32 A rows start
+// at A.  B either row-major with pitch ldb (element (col, kk) at B[col * ldb + kk], LDS tiles) or, BFRAG = true,
+// pre-packed in MFMA fragment order (global weights): fragment f = (k0 / 16) * 4 + t is 64 lanes x 16 bytes, so one
+// wave load is 1 KB contiguous instead of 64 cache lines.
+template <bool BFRAG>
 __device__ __forceinline__ void gemm_slab(const uint16_t* A, int lda, const uint16_t* B, int ldb, f32x16 (&acc)[4],
                                           int lane) {
     const int r = lane & 31, kb = lane >> 5;
     const uint16_t* ap = A + r * lda + 8 * kb;
-    const uint16_t* bp = B + r * ldb + 8 * kb;
+    const uint16_t* bp = BFRAG ? (B + lane * 8) : (B + r * ldb + 8 * kb);
 #pragma unroll
     for (int k0 = 0; k0 < H3; k0 += 16) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + (32 * t) * ldb + k0);
+            const bf16x8 b = BFRAG ? *reinterpret_cast<const bf16x8*>(bp + ((k0 / 16) * 4 + t) * 512)
+                                   : *reinterpret_cast<const bf16x8*>(bp + (32 * t) * ldb + k0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
         }
     }
+}
+
+// sum over the 32 lanes of each half-wave, result in every lane: 4 DPP adds (quad xor 1, quad xor 2, half-row
+// mirror, row mirror) + one ds_swizzle (xor 16).  Fixed order, no LDS addressing -- ~10x cheaper than 5
+// ds_bpermute butterflies (measured: the two Q heads were 30 of 65 us per tile with __shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float reduce16_dpp(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float swap16_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // lane ^ 16
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
@@ -81,10 +137,10 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 
 __device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
     uint4 o;
-    o.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);
-    o.y = (uint32_t)f32_to_bf16_rne(v[2]) | ((uint32_t)f32_to_bf16_rne(v[3]) << 16);
-    o.z = (uint32_t)f32_to_bf16_rne(v[4]) | ((uint32_t)f32_to_bf16_rne(v[5]) << 16);
-    o.w = (uint32_t)f32_to_bf16_rne(v[6]) | ((uint32_t)f32_to_bf16_rne(v[7]) << 16);
+    o.x = pack2_bf16(v[0], v[1]);
+    o.y = pack2_bf16(v[2], v[3]);
+    o.z = pack2_bf16(v[4], v[5]);
+    o.w = pack2_bf16(v[6], v[7]);
     return o;
 }
 
@@ -149,7 +205,7 @@ template <int ACT>
 __device__ __forceinline__ void layer2(const uint16_t* l_h1rk, const uint16_t* w2jk, const float* b2, int w, int lane,
                                        f32x16 (&h2)[4]) {
     zero_acc(h2);
-    gemm_slab(l_h1rk + 32 * w * LDH, LDH, w2jk, H3, h2, lane);
+    gemm_slab<true>(l_h1rk + 32 * w * LDH, LDH, w2jk, H3, h2, lane);
     const int r = lane & 31;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -160,34 +216,46 @@ __device__ __forceinline__ void layer2(const uint16_t* l_h1rk, const uint16_t* w
 }
 
 // head: q[o] = b3[o] + sum_j W3[o, j] h2[j] for the wave's 32 rows -> l_q[o][row]   (f32 [MAXO][TR])
-__device__ __forceinline__ void head_to_lds(const Mlp3& m, int na, const f32x16 (&h2)[4], int w, int lane, float* l_q) {
+template <int NA>
+__device__ __forceinline__ void head_to_lds(const Mlp3& m, const f32x16 (&h2)[4], int w, int lane, float* l_q) {
+    constexpr int na = NA;
     const int r = lane & 31, kb = lane >> 5;
     float w3[MAXO][4];
 #pragma unroll
     for (int o = 0; o < MAXO; ++o)
 #pragma unroll
         for (int t = 0; t < 4; ++t) w3[o][t] = (o < na) ? m.W3[o + na * (r + 32 * t)] : 0.0f;
+    float b3[MAXO];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        float p[MAXO];
+    for (int o = 0; o < MAXO; ++o) b3[o] = (o < na) ? m.b3[o] : 0.0f;
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o) {
-            float a = w3[o][0] * h2[0][q];
+    for (int q0 = 0; q0 < 16; q0 += 4) {
+        float p[4][MAXO];
 #pragma unroll
-            for (int t = 1; t < 4; ++t) a = fmaf(w3[o][t], h2[t][q], a);
-            p[o] = a;
-        }
+        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
+            for (int o = 0; o < MAXO; ++o) {
+                p[qq][o] = 0.0f;
+                if (o < na) {
+                    float a = w3[o][0] * h2[0][q0 + qq];
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) a = fmaf(w3[o][t], h2[t][q0 + qq], a);
+                    p[qq][o] = reduce16_dpp(a);
+                }
+            }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
             for (int o = 0; o < MAXO; ++o)
-                if (o < na) p[o] += __shfl_xor(p[o], off, 64);
-        }
+                if (o < na) p[qq][o] = swap16_add(p[qq][o]);
         if (r == 0) {
-            const int row = 32 * w + mfma_row(q, kb);
 #pragma unroll
-            for (int o = 0; o < MAXO; ++o)
-                if (o < na) l_q[o * TR + row] = p[o] + m.b3[o];
+            for (int qq = 0; qq < 4; ++qq) {
+                const int row = 32 * w + mfma_row(q0 + qq, kb);
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o)
+                    if (o < na) l_q[o * TR + row] = p[qq][o] + b3[o];
+            }
         }
     }
 }
@@ -198,19 +266,21 @@ struct RegQ3 {
 };
 
 // ------------------------------------------------------------------------------ forward / plan!
-template <int NS, int ACT>
+template <int NS, int NA, int ACT>
 __global__ __launch_bounds__(256) void mlp3_plan_kernel(const float* __restrict__ params,
-                                                        const uint16_t* __restrict__ packed, int na,
+                                                        const uint16_t* __restrict__ packed,
                                                         const float* __restrict__ obs, int64_t n, double eps,
                                                         uint64_t seed, uint32_t env_id_base, uint32_t step,
                                                         int32_t* __restrict__ actions, float* __restrict__ q_out) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
+    constexpr int na = NA;
     float* l_x = reinterpret_cast<float*>(smem3);                       // [4][TR]
     float* l_q = l_x + 4 * TR;                                          // [MAXO][TR]
-    uint16_t* l_A = reinterpret_cast<uint16_t*>(l_q + MAXO * TR);       // [TR][LDH]
+    float* l_w = l_q + MAXO * TR;                                       // [SMALLW]
+    uint16_t* l_A = reinterpret_cast<uint16_t*>(l_w + SMALLW);          // [TR][LDH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Mlp3 m = mlp3_view(params, NS, na);
+    const Mlp3 m = stage_small_weights(params, NS, na, l_w, tid);
     const int64_t e0 = (int64_t)blockIdx.x * TR;
     if (tid < TR) {
         int64_t e = e0 + tid;
@@ -223,7 +293,7 @@ __global__ __launch_bounds__(256) void mlp3_plan_kernel(const float* __restrict_
     __syncthreads();
     f32x16 h2[4];
     layer2<ACT>(l_A, packed, m.b2, w, lane, h2);
-    head_to_lds(m, na, h2, w, lane, l_q);
+    head_to_lds<NA>(m, h2, w, lane, l_q);
     __syncthreads();
     if (tid < TR && e0 + tid < n) {
         const int64_t e = e0 + tid;
@@ -280,7 +350,7 @@ __device__ __forceinline__ float sum_waves(const float* l_red, int v, int c) {
            l_red[(3 * NV + v) * H3 + c];
 }
 
-template <int NS, int ACT>
+template <int NS, int NA, int ACT>
 __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     float* l_x = reinterpret_cast<float*>(smem3);       // [4][TR]
@@ -293,20 +363,22 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     int32_t* l_a = reinterpret_cast<int32_t*>(l_small + 16);  // [TR]
     int32_t* l_t = l_a + TR;                                  // [TR]
     float* l_red = reinterpret_cast<float*>(l_t + TR);        // [4][5][H3]
-    uint16_t* l_A = reinterpret_cast<uint16_t*>(l_red + 4 * 5 * H3);  // H1 [r][k], later dZ2 [r][j]
+    float* l_w = l_red + 4 * 5 * H3;                          // [2][SMALLW] online / target small weights
+    uint16_t* l_A = reinterpret_cast<uint16_t*>(l_w + 2 * SMALLW);    // H1 [r][k], later dZ2 [r][j]
     uint16_t* l_B = l_A + TILE_ELEMS;                                 // H1^T [k][r]
     uint16_t* l_C = l_B + TILE_ELEMS;                                 // dZ2^T [j][r]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
-    const int na = g.na;
-    const Mlp3 m = mlp3_view(g.params, NS, na);
-    const Mlp3 mt = mlp3_view(g.tparams, NS, na);
+    constexpr int na = NA;
+    const Mlp3 m = stage_small_weights(g.params, NS, na, l_w, tid);
+    const Mlp3 mt = stage_small_weights(g.tparams, NS, na, l_w + SMALLW, tid);
     const int tile = blockIdx.x;
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
     const int oW1 = 0, ob1 = H3 * NS, oW2 = ob1 + H3, ob2 = oW2 + H3 * H3, oW3 = ob2 + H3, ob3 = oW3 + na * H3;
 
+    D3_STAMP(0);
     // ---- sample + gather the tile's transitions straight from the HBM ring ----
     if (tid < TR) {
         int64_t b = (int64_t)tile * TR + tid;
@@ -334,19 +406,26 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     }
     __syncthreads();
 
+    D3_STAMP(1);
     // ---- target network on s' ----
     f32x16 h2[4];
     layer1_to_lds<NS, ACT>(mt, l_xn, l_A, nullptr, tid);
     __syncthreads();
+    D3_STAMP(2);
     layer2<ACT>(l_A, g.tpacked, mt.b2, w, lane, h2);
-    head_to_lds(mt, na, h2, w, lane, l_qn);
+    D3_STAMP(3);
+    head_to_lds<NA>(mt, h2, w, lane, l_qn);
+    D3_STAMP(4);
     __syncthreads();  // all waves are done reading l_A
 
     // ---- online network on s (h2 stays in registers for the backward pass) ----
     layer1_to_lds<NS, ACT>(m, l_x, l_A, l_B, tid);
     __syncthreads();
+    D3_STAMP(5);
     layer2<ACT>(l_A, g.packed, m.b2, w, lane, h2);
-    head_to_lds(m, na, h2, w, lane, l_q);
+    D3_STAMP(6);
+    head_to_lds<NA>(m, h2, w, lane, l_q);
+    D3_STAMP(7);
     __syncthreads();
 
     // ---- TD target, Huber loss, dL/dq per sample ----
@@ -394,6 +473,7 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
         g.loss_partials[blockIdx.x] = l_small[MAXO] + l_small[8 + MAXO];
     }
 
+    D3_STAMP(8);
     // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32), db2; dz2 -> bf16 tiles [r][j] and [j][r] ----
     {
         float w3[MAXO][4];
@@ -431,7 +511,7 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
                 if ((q & 3) == 3) {
                     uint2 v2;
                     v2.x = (uint32_t)pk[t][0] | ((uint32_t)pk[t][1] << 16);
-                    v2.y = (uint32_t)pk[t][2] | ((uint32_t)pk[t][3] << 16);
+                    v2.y = (uint32_t)pk[t][2] | ((uint32_t)pk[t][3] << 16);  // (already bf16 bits)
                     *reinterpret_cast<uint2*>(l_C + (r + 32 * t) * LDH + 32 * w + 8 * (q >> 2) + 4 * kb) = v2;
                 }
             }
@@ -445,11 +525,13 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     }
     __syncthreads();  // l_red is reused below
 
+    D3_STAMP(9);
     // ---- dH1 = dZ2 * W2 (MFMA), dz1 = dH1 * act'(z1), dW1 / db1 (f32) ----
     {
         f32x16 dh1[4];
         zero_acc(dh1);
-        gemm_slab(l_A + 32 * w * LDH, LDH, g.packed + H3 * H3, H3, dh1, lane);
+        gemm_slab<true>(l_A + 32 * w * LDH, LDH, g.packed + H3 * H3, H3, dh1, lane);
+    D3_STAMP(12);
         float w1[4][NS], bb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -489,26 +571,34 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
         for (int i = 0; i < NS; ++i) out[oW1 + tid + H3 * i] = sum_waves<NS + 1>(l_red, 1 + i, tid);
     }
 
+    D3_STAMP(10);
     // ---- dW2^T[k][j] = sum_r H1[r][k] dZ2[r][j] (MFMA); stored as Flux W2[j + h k] ----
     {
         f32x16 dw[4];
         zero_acc(dw);
-        gemm_slab(l_B + 32 * w * LDH, LDH, l_C, LDH, dw, lane);
+        gemm_slab<false>(l_B + 32 * w * LDH, LDH, l_C, LDH, dw, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
     }
+    D3_STAMP(11);
 }
 
+// bf16 copies of W2 in MFMA B-fragment order, one per operand orientation (16-byte units, see gemm_slab):
+//   packed[0 .. H*H)      "W2jk": fragment (ks, t), lane l holds W2[j = 32 t + (l & 31)][k = 16 ks + 8 (l >> 5) + u]
+//   packed[H*H .. 2 H*H)  "W2kj": fragment (ks, t), lane l holds W2[j = 16 ks + 8 (l >> 5) + u][k = 32 t + (l & 31)]
+// with W2[j][k] = Flux W2[j + H k].
 __global__ __launch_bounds__(256) void mlp3_pack_kernel(const float* __restrict__ params, int ns,
                                                         uint16_t* __restrict__ packed) {
     const float* W2 = params + H3 * ns + H3;
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= H3 * H3) return;
-    int j = q / H3, k = q % H3;
-    packed[q] = f32_to_bf16_rne(W2[j + H3 * k]);            // W2jk[j][k]
-    packed[H3 * H3 + q] = f32_to_bf16_rne(W2[k + H3 * j]);  // W2kj[j'][k'] with (j', k') = (k-index, j-index)
+    int u = q & 7, l = (q >> 3) & 63, f = q >> 9;
+    int t = f & 3, ks = f >> 2;
+    int col = 32 * t + (l & 31), kk = 16 * ks + 8 * (l >> 5) + u;
+    packed[q] = f32_to_bf16_rne(W2[col + H3 * kk]);            // B(col = j, kk = k) = W2[j][k]
+    packed[H3 * H3 + q] = f32_to_bf16_rne(W2[kk + H3 * col]);  // B(col = k, kk = j) = W2[j][k]
 }
 
 // glorot_uniform stand-in (same convention as mlp2_init_kernel): tensor ids net_id * 4 + {0: W1, 1: W2, 2: W3}
@@ -531,27 +621,36 @@ __global__ __launch_bounds__(256) void mlp3_init_kernel(float* __restrict__ p, i
     p[q] = val;
 }
 
+// partial gradients [nb][np] -> grad[np]: 64 parameters per workgroup, the block range split over the 4 waves,
+// fixed summation order (ascending blocks within a wave, then waves 0..3)
 __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ partials,
                                                         const float* __restrict__ loss_partials, int nb, int np,
                                                         float* __restrict__ grad, float* __restrict__ loss,
                                                         float inv_b) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float l_g[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const int per = (nb + 3) / 4;
+    const int b0 = grp * per, b1 = min(nb, b0 + per);
+    float acc = 0.f;
     if (p < np) {
-        float a = 0.f;
-        for (int b = 0; b < nb; ++b) a += partials[(int64_t)b * np + p];
-        grad[p] = a;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + p];
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64 && loss != nullptr) {
+    l_g[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && p < np) grad[p] = ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane];
+    if (blockIdx.x == 0 && loss != nullptr && grp == 1) {
         float a = 0.f;
-        for (int b = threadIdx.x; b < nb; b += 64) a += loss_partials[b];
+        for (int b = lane; b < nb; b += 64) a += loss_partials[b];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
-        if (threadIdx.x == 0) loss[0] = a * inv_b;
+        if (lane == 0) loss[0] = a * inv_b;
     }
 }
 
-constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
-constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3) * sizeof(float) +
+constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
+constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
                             3 * TILE_ELEMS * sizeof(uint16_t);
 
 // gfx950 has 160 KB of LDS per workgroup; anything above 64 KB of dynamic LDS must be opted into per kernel
@@ -571,6 +670,13 @@ using namespace rlhip;
 extern "C" {
 
 int64_t rlhip_mlp3_nparams(int64_t ns, int64_t h, int64_t na) { return mlp3_nparams(ns, h, na); }
+
+#ifdef RLHIP_D3_TIMING
+int32_t rlhip_debug_d3_stamps(long long* out32) {
+    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_d3_stamps), sizeof(long long) * 32));
+    return RLHIP_OK;
+}
+#endif
 
 int64_t rlhip_mlp3_packed_elems(int64_t h) { return 2 * h * h; }
 
@@ -600,23 +706,25 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
                             rlhip_stream_t stream) {
     RLHIP_REQUIRE(params && packed && obs && (actions || q_out), "NULL argument");
     RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
-    RLHIP_REQUIRE(ns >= 2 && ns <= 4 && na >= 1 && na <= MAXO, "obs dim must be 2..4, na <= 4");
+    RLHIP_REQUIRE((ns == 4 && na == 2) || (ns == 2 && na == 3) || (ns == 3 && na == 3),
+                  "(obs dim, actions) must be (4, 2) CartPole, (2, 3) MountainCar or (3, 3) Pendulum");
     RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
     RLHIP_REQUIRE((((uintptr_t)packed) & 15) == 0, "packed weights must be 16-byte aligned");
     if (n == 0) return RLHIP_OK;
     hipStream_t s = as_stream(stream);
     dim3 grid((unsigned)((n + TR - 1) / TR));
-#define LAUNCH_P(NS_, ACT_)                                                                                      \
-    do {                                                                                                         \
-        static bool done_ = false;                                                                               \
-        int32_t rc_ = allow_lds(mlp3_plan_kernel<NS_, ACT_>, PLAN_LDS, &done_);                                  \
-        if (rc_) return rc_;                                                                                     \
-        hipLaunchKernelGGL((mlp3_plan_kernel<NS_, ACT_>), grid, dim3(256), PLAN_LDS, s, params, packed, (int)na, \
-                           obs, n, eps, seed, env_id_base, step, actions, q_out);                                \
+#define LAUNCH_P(NS_, NA_, ACT_)                                                                               \
+    do {                                                                                                       \
+        static bool done_ = false;                                                                             \
+        int32_t rc_ = allow_lds(mlp3_plan_kernel<NS_, NA_, ACT_>, PLAN_LDS, &done_);                           \
+        if (rc_) return rc_;                                                                                   \
+        hipLaunchKernelGGL((mlp3_plan_kernel<NS_, NA_, ACT_>), grid, dim3(256), PLAN_LDS, s, params, packed,   \
+                           obs, n, eps, seed, env_id_base, step, actions, q_out);                              \
     } while (0)
-    if (ns == 4) { if (act == 0) LAUNCH_P(4, 0); else LAUNCH_P(4, 1); }
-    else if (ns == 3) { if (act == 0) LAUNCH_P(3, 0); else LAUNCH_P(3, 1); }
-    else { if (act == 0) LAUNCH_P(2, 0); else LAUNCH_P(2, 1); }
+    // (obs dim, actions) of the three classic-control envs: CartPole (4, 2), MountainCar (2, 3), Pendulum (3, 3)
+    if (ns == 4 && na == 2) { if (act == 0) LAUNCH_P(4, 2, 0); else LAUNCH_P(4, 2, 1); }
+    else if (ns == 2 && na == 3) { if (act == 0) LAUNCH_P(2, 3, 0); else LAUNCH_P(2, 3, 1); }
+    else { if (act == 0) LAUNCH_P(3, 3, 0); else LAUNCH_P(3, 3, 1); }
 #undef LAUNCH_P
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
@@ -637,7 +745,8 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
     RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
-    RLHIP_REQUIRE(na >= 1 && na <= MAXO, "na must be <= 4");
+    RLHIP_REQUIRE((rb->obs_dim == 4 && na == 2) || (rb->obs_dim == 2 && na == 3) || (rb->obs_dim == 3 && na == 3),
+                  "(obs dim, actions) must be (4, 2) CartPole, (2, 3) MountainCar or (3, 3) Pendulum");
     RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
     RLHIP_REQUIRE(batch >= 1, "empty batch");
     RLHIP_REQUIRE(batch <= (int64_t)D3_MAX_BLOCKS * TR, "batch too large for one launch");
@@ -673,18 +782,18 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t
     g.seed = seed;
     g.draw_ctr = draw_ctr;
     hipStream_t s = as_stream(stream);
-#define LAUNCH_G(NS_, ACT_)                                                                             \
+#define LAUNCH_G(NS_, NA_, ACT_)                                                                        \
     do {                                                                                                \
         static bool done_ = false;                                                                      \
-        int32_t rc_ = allow_lds(dqn3_grad_kernel<NS_, ACT_>, GRAD_LDS, &done_);                         \
+        int32_t rc_ = allow_lds(dqn3_grad_kernel<NS_, NA_, ACT_>, GRAD_LDS, &done_);                    \
         if (rc_) return rc_;                                                                            \
-        hipLaunchKernelGGL((dqn3_grad_kernel<NS_, ACT_>), dim3(nb), dim3(256), GRAD_LDS, s, g);         \
+        hipLaunchKernelGGL((dqn3_grad_kernel<NS_, NA_, ACT_>), dim3(nb), dim3(256), GRAD_LDS, s, g);    \
     } while (0)
-    if (ns == 4) { if (act == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
-    else if (ns == 3) { if (act == 0) LAUNCH_G(3, 0); else LAUNCH_G(3, 1); }
-    else { if (act == 0) LAUNCH_G(2, 0); else LAUNCH_G(2, 1); }
+    if (ns == 4 && na == 2) { if (act == 0) LAUNCH_G(4, 2, 0); else LAUNCH_G(4, 2, 1); }
+    else if (ns == 2 && na == 3) { if (act == 0) LAUNCH_G(2, 3, 0); else LAUNCH_G(2, 3, 1); }
+    else { if (act == 0) LAUNCH_G(3, 3, 0); else LAUNCH_G(3, 3, 1); }
 #undef LAUNCH_G
-    hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials, nb,
+    hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials, nb,
                        (int)np, grad_out, loss_out, g.inv_b);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;

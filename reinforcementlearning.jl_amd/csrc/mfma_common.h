@@ -13,12 +13,15 @@ namespace rlhip {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);                                           // round to nearest even
-    return (uint16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// f32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) { return (uint16_t)(pack2_bf16(f, 0.0f) & 0xFFFFu); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 // row of MFMA accumulator register q for a lane in half kb = lane >> 5

@@ -42,19 +42,24 @@ def _net(ns, na, seed, bias=True):
 def test_init_and_pack_bit_exact():
     from rlhip import dqn
 
-    for ns, na in ((4, 2), (2, 3), (3, 4)):
+    for ns, na in ((4, 2), (2, 3), (3, 3)):
         p = dqn.mlp3_init(ns, H, na, 9, 1)
         ref = oracle.mlp3_init(ns, H, na, 9, 1)
         assert np.array_equal(p.cpu().numpy(), ref)
         packed = dqn.mlp3_pack(p, ns, H, na).cpu().numpy().view(np.uint16)
         W2 = ref[H * ns + H:H * ns + H + H * H]  # Flux column-major: W2[j + H k]
-        bf = (oracle.bf16_round(W2).view(np.uint32) >> 16).astype(np.uint16)
-        assert np.array_equal(packed[H * H:], bf)                       # W2kj = raw order
-        assert np.array_equal(packed[:H * H].reshape(H, H), bf.reshape(H, H).T)  # W2jk[j][k]
+        bf = (oracle.bf16_round(W2).view(np.uint32) >> 16).astype(np.uint16).reshape(H, H).T  # bf[j][k]
+        # MFMA B-fragment order: fragment (ks, t), lane l, element u (dqn3.hip mlp3_pack_kernel)
+        q = np.arange(H * H)
+        u, l, f = q & 7, (q >> 3) & 63, q >> 9
+        t, ks = f & 3, f >> 2
+        col, kk = 32 * t + (l & 31), 16 * ks + 8 * (l >> 5) + u
+        assert np.array_equal(packed[:H * H], bf[col, kk])   # "W2jk": B(col = j, kk = k)
+        assert np.array_equal(packed[H * H:], bf[kk, col])   # "W2kj": B(col = k, kk = j)
 
 
 @pytest.mark.parametrize("act", [0, 1])
-@pytest.mark.parametrize("ns,na,n", [(4, 2, 4096), (4, 2, 1), (2, 3, 130), (3, 4, 257)])
+@pytest.mark.parametrize("ns,na,n", [(4, 2, 4096), (4, 2, 1), (2, 3, 130), (3, 3, 257)])
 def test_forward_and_plan(ns, na, n, act):
     from rlhip import dqn
 
