@@ -199,6 +199,45 @@ def roofline_extras(torch, rlhip):
                                    "ms_per_vec_step": round(el / steps * 1e3, 4), "batch": 512,
                                    "note": "per-step drop-in protocol (plan!/act!/push!/optimise! = 6 launches per vec-step, eager)"}
     del agent, policy, learner, net, env
+    # same config with the blog's 3-layer Q-network 4 -> 128 -> 128 -> 2, hidden layer on the bf16 MFMA (dqn3.hip)
+    env = rlhip.CartPoleEnv(n, seed=5)
+    net = rlhip.HipApproximator(4, 128, 2, seed=5, layers=3)
+    learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=100), batchsize=512, min_replay_history=n, seed=5)
+    policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.01, kind="exp", decay_steps=500, seed=5))
+    agent = rlhip.Agent(policy, rlhip.Trajectory(CircularArraySARTSTraces(capacity=256, n_env=n, obs_dim=4)))
+    rlhip.run(agent, env, rlhip.StopAfterNSteps(20))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rlhip.run(agent, env, rlhip.StopAfterNSteps(steps))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out["dqn3_mfma_cartpole_4096env"] = {"env_steps_per_sec": round(n * steps / el, 1),
+                                         "updates_per_sec": round(steps / el, 1),
+                                         "ms_per_vec_step": round(el / steps * 1e3, 4), "batch": 512,
+                                         "net": "4->128->128->2 relu, hidden layer bf16 MFMA, f32 master weights"}
+    # the MFMA learner kernel alone at a PPO-sized batch (131072 samples): 4 hidden GEMMs per sample
+    # (target fwd, online fwd, dH1, dW2) = 4 * 2 * 128 * 128 flop
+    from rlhip import dqn as _dqn
+
+    bm = 131072
+    ws = _dqn.dqn3_workspace(4, 128, 2, bm)
+    tr2 = agent.trajectory.container
+    gbuf, lbuf = torch.empty_like(net.params), torch.empty(1, device="cuda")
+    tn = learner.approximator
+
+    def gk():
+        _dqn.dqn3_grad(tr2, 128, 2, 0, net.params, net.packed, tn.target, tn.target_packed, bm, 0.99, 1.0, 1, 0,
+                       workspace=ws, grad=gbuf, loss=lbuf)
+
+    gk()
+    ms = event_time_ms(gk, 10, lib, s)
+    tf = 4 * 2 * 128 * 128 * bm / (ms * 1e-3) / 1e12
+    out["dqn3_grad_mfma"] = {"bound": "mfma", "kernel": "dqn3_grad_kernel<4,2,relu> + d3_reduce_kernel", "batch": bm,
+                             "us_per_launch": round(ms * 1e3, 1), "achieved": round(tf, 1), "peak": 2500.0,
+                             "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                             "note": "MFMA flops only; first layer, heads, loss and all bias/W1/W3 gradients run on the "
+                                     "VALU in the same kernel"}
+    del agent, policy, learner, net, env, ws, gbuf
     # BASELINE configs[2]: 4096-way PendulumEnv + PPOPolicy (GAE lambda = 0.95), T = 128, clip 0.1, 4 x 4
     # micro-batches of 131072, actor 3 -> 256 -> (mu, log sigma), critic 3 -> 256 -> 1.  fp32 VALU: a
     # 2-layer net has no hidden x hidden GEMM (K = 3, N <= 2), see DESIGN.md section 5.
