@@ -515,6 +515,9 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
                     *reinterpret_cast<uint2*>(l_C + (r + 32 * t) * LDH + 32 * w + 8 * (q >> 2) + 4 * kb) = v2;
                 }
             }
+            // keep the fully unrolled rows in program order: without this the scheduler hoists every LDS read
+            // of the 16 rows to the top, runs out of VGPRs and spills into AGPRs next to the live accumulators
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         reduce_cols_to_lds<MAXO + 1>(acc, l_red, w, lane);
     }
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) acc[1 + i][t] = fmaf(dz, x[i], acc[1 + i][t]);
             }
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         reduce_cols_to_lds<NS + 1>(acc, l_red, w, lane);
     }

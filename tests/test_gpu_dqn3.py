@@ -82,13 +82,13 @@ def test_forward_and_plan(ns, na, n, act):
         assert np.array_equal(a.cpu().numpy(), sel)
 
 
-def _fill_ring(traces, oring, ns, n_env, steps, rng):
+def _fill_ring(traces, oring, ns, n_env, steps, rng, na=2):
     obs = rng.standard_normal((ns, n_env)).astype(np.float32)
     traces.push_state_(torch.as_tensor(obs, device="cuda"))
     oring.push_state(obs)
     for _ in range(steps):
         nobs = rng.standard_normal((ns, n_env)).astype(np.float32)
-        a = rng.integers(0, 2, n_env).astype(np.int32)
+        a = rng.integers(0, na, n_env).astype(np.int32)
         r = (rng.standard_normal(n_env) * 2).astype(np.float32)
         term = (rng.random(n_env) < 0.2).astype(np.uint8)
         traces.push_transition_(torch.as_tensor(nobs, device="cuda"), torch.as_tensor(a, device="cuda"),
@@ -106,16 +106,18 @@ def _check_grad(g, ref, ns, na):
 
 
 @pytest.mark.parametrize("act", [0, 1])
-@pytest.mark.parametrize("batch", [32, 128, 512, 1000, 4096])
-def test_dqn3_grad_vs_oracle(batch, act):
+@pytest.mark.parametrize("batch,ns,na", [(32, 4, 2), (128, 4, 2), (512, 4, 2), (1000, 4, 2), (4096, 4, 2),
+                                         (300, 2, 3), (300, 3, 3)])
+def test_dqn3_grad_vs_oracle(batch, ns, na, act):
+    """every kernel instantiation (CartPole / MountainCar / Pendulum shapes x relu / tanh) against the oracle"""
     import rlhip
     from rlhip import dqn
 
-    ns, na, n_env, cap = 4, 2, 64, 40
+    n_env, cap = 64, 40
     rng = np.random.default_rng(batch + act)
     traces = rlhip.CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=ns)
     oring = oracle.Ring(cap, n_env, ns)
-    _fill_ring(traces, oring, ns, n_env, 57, rng)  # wraps
+    _fill_ring(traces, oring, ns, n_env, 57, rng, na)  # wraps
     p, tp = _net(ns, na, 11), _net(ns, na, 12)
     pd, tpd = torch.as_tensor(p, device="cuda"), torch.as_tensor(tp, device="cuda")
     packed, tpacked = dqn.mlp3_pack(pd, ns, H, na), dqn.mlp3_pack(tpd, ns, H, na)
