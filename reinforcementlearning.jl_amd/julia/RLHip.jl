@@ -113,6 +113,34 @@ end
 # rlhip_ppo_rollout_f32 / rlhip_ppo_gae_f32 / rlhip_ppo_update_f32 take the POD structs rlhip_ppo_cfg and
 # rlhip_ppo_traj (device pointers of the PPOTrajectory traces); see INTEGRATION.md for the full stubs.
 
+# ---- prioritized replay: CircularPrioritizedTraces + prioritized BatchSampler (RLTrajectories 0.4) -------
+# `ring` is the POD rlhip_ring mirror (Ref{Ring}); `tree` a zero-initialised DevBuf{Float32}(rlhip_sumtree_nodes(n)).
+sumtree_nodes(n_leaves) = ccall((:rlhip_sumtree_nodes, LIB), Int64, (Int64,), n_leaves)
+push_priority!(ring, tree::DevBuf{Float32}, p::Float32) = chk(ccall((:rlhip_ring_push_priority, LIB), Int32,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Ptr{Cvoid}), ring, tree.ptr, p, C_NULL))
+sample_prioritized!(idx::DevBuf{Int64}, key::DevBuf{Int64}, prio::DevBuf{Float32}, ring, tree, batch, seed, ctr) =
+    chk(ccall((:rlhip_ring_sample_prioritized, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              ring, tree.ptr, batch, seed, ctr, idx.ptr, key.ptr, prio.ptr, C_NULL))
+# trajectory[:priority, keys] = p      (keys are the 0-based physical leaf keys returned by the sampler)
+set_priority!(tree::DevBuf{Float32}, n_leaves, key::DevBuf{Int64}, p::DevBuf{Float32}, n) =
+    chk(ccall((:rlhip_sumtree_update, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+              tree.ptr, n_leaves, key.ptr, p.ptr, n, C_NULL))
+
+# ---- the blog's 3-layer Q-network on the MFMA (Chain(Dense(ns,128,relu), Dense(128,128,relu), Dense(128,na))) ---
+# forward(learner, x) / plan!(QBasedPolicy, env): params = Flux.destructure(model)[1] on the device, `packed` =
+# DevBuf{UInt16}(rlhip_mlp3_packed_elems(128)) refreshed by rlhip_mlp3_pack_bf16 after every optimise!.
+mlp3_pack!(packed::DevBuf{UInt16}, params::DevBuf{Float32}, ns, na) = chk(ccall((:rlhip_mlp3_pack_bf16, LIB), Int32,
+    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}), params.ptr, ns, 128, na, packed.ptr, C_NULL))
+dqn3_plan!(actions::DevBuf{Int32}, q, params, packed, ns, na, act, obs, n, ϵ, seed, env_id_base, step) =
+    chk(ccall((:rlhip_dqn3_plan_f32, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Int32, Ptr{Cvoid}, Int64, Float64, UInt64, UInt32, UInt32,
+               Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              params.ptr, packed.ptr, ns, 128, na, act, obs.ptr, n, ϵ, seed, env_id_base, step, actions.ptr, q.ptr, C_NULL))
+# optimise!(learner, batch) up to the gradient: rlhip_dqn3_grad_f32(ring, 128, na, act, params, packed, target,
+# target_packed, batch, idx_or_NULL, γ, δ, seed, draw_ctr, workspace, grad, loss, td_or_NULL, stream); then
+# rlhip_clip_adam_f32 + rlhip_mlp3_pack_bf16 (+ rlhip_polyak_f32 and a re-pack of the target every sync_freq).
+
 # ---- the vector-env run loop (one method added; RLCore/src/core/run.jl is untouched) -------------------
 function _run(policy::AbstractPolicy, env::HipVecEnv, stop_condition, hook, reset_condition)
     push!(hook, PreExperimentStage(), policy, env)
