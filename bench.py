@@ -176,10 +176,25 @@ def roofline_extras(torch, rlhip):
         mf()
     ms = event_time_ms(mf, 20, lib, s)
     tf = 2.0 * Bm * Km * Nm / (ms * 1e-3) / 1e12
-    out["dense_bf16_mfma"] = {"bound": "mfma", "kernel": "dense_mfma_kernel<relu,bf16> (v_mfma_f32_32x32x16_bf16)",
+    out["dense_bf16_mfma_simple"] = {"kernel": "dense_mfma_kernel<relu,bf16> (fragments straight from global)",
+                                     "us_per_launch": round(ms * 1e3, 1), "achieved": round(tf, 1), "unit": "TFLOP/s"}
+    wf = ops.dense_frag_weight_bf16(wt)
+
+    def mt():
+        rlhip._lib.call("rlhip_dense_bf16_forward_tiled", ops.ptr(xr), ops.ptr(wf), ops.ptr(bias), 0, Bm, Km, Nm,
+                        ops.ptr(y), 1, s)
+
+    for _ in range(3):
+        mt()
+    ms = event_time_ms(mt, 20, lib, s)
+    tf = 2.0 * Bm * Km * Nm / (ms * 1e-3) / 1e12
+    hbm = 2.0 * Bm * (Km + Nm) / (ms * 1e-3) / 1e9
+    out["dense_bf16_mfma"] = {"bound": "mfma", "kernel": "dense_tiled_kernel<8,relu,bf16> (v_mfma_f32_32x32x16_bf16)",
                               "batch": Bm, "k": Km, "n": Nm, "us_per_launch": round(ms * 1e3, 1),
                               "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                              "note": "first correct version: fragment loads straight from global/L1, no LDS staging"}
+                              "hbm_gbs": round(hbm, 1),
+                              "note": "this shape is HBM-bound (128 flop/B): 2 (K + N) B per row, ceiling ~1 PFLOP/s at 8 TB/s"}
+    del wf
     del xr, wt, y
     # BASELINE configs[1]: 4096-way CartPole + QBasedPolicy(DQN, 4->128->2), batch 512, 1 update per vec-step
     n = N_ENVS

@@ -373,6 +373,14 @@ int32_t rlhip_bf16_rows_to_soa_f32(const uint16_t* y_rows, int64_t batch, int32_
                                    float* out_soa, rlhip_stream_t stream);
 int32_t rlhip_dense_pack_weight_bf16(const float* w_flux, int32_t k, int32_t n, int32_t k_pad,
                                      int32_t n_pad, uint16_t* wt, rlhip_stream_t stream);
+/* Tiled variant (X tile staged through LDS, coalesced bf16 output): weights in MFMA fragment order, produced
+ * from the row-major Wt of rlhip_dense_pack_weight_bf16 by rlhip_dense_frag_weight_bf16 (same element count).
+ * batch % 128 == 0, 16 <= k <= 512 with k % 16 == 0, n % 128 == 0. */
+int32_t rlhip_dense_frag_weight_bf16(const uint16_t* wt, int32_t k, int32_t n, uint16_t* w_frag,
+                                     rlhip_stream_t stream);
+int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w_frag, const float* bias,
+                                       int32_t act, int64_t batch, int32_t k, int32_t n, void* y_rows,
+                                       int32_t y_is_bf16, rlhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------ PPO path -- */
 /* PPOPolicy hyper-parameters (removed Zoo; blog a_practical_introduction_to_RL.jl/index.html:15257-15278) */

@@ -69,6 +69,116 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const uint16_t* __restr
     }
 }
 
+// ---- tiled kernel: X tile staged through LDS, weights in MFMA fragment order, coalesced bf16 output ----------
+// One workgroup = 128 batch rows x NB = 32 * NTT output columns (NB = N when N <= 256, so X is read from HBM
+// exactly once).  Phase 1: the 128 x K bf16 tile (contiguous in memory: rows are contiguous) is copied to LDS
+// with 16 B/lane coalesced loads, row pitch K + 8 elements (odd multiple of 16 B -> conflict-free fragment
+// reads).  Phase 2: each wave multiplies its 32 rows by the whole column block; B fragments come from the
+// fragment-ordered weight copy (one wave load = 1 KB contiguous, shared by every workgroup -> L1/L2 hits).
+// Phase 3: bias + activation; bf16 results go back through the same LDS region and leave as 16 B/lane row-major
+// stores (f32 results are stored straight from the accumulator layout: 128 B contiguous per row).
+// At the actor/critic shapes (K, N <= 512) the layer is HBM-bound: 2 (K + N) bytes per row against 2 K N flop.
+template <int NTT, int ACT, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void dense_tiled_kernel(const uint16_t* __restrict__ X,
+                                                             const uint16_t* __restrict__ Wfrag,
+                                                             const float* __restrict__ bias, int64_t B, int K, int N,
+                                                             void* __restrict__ Yv) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    uint16_t* tile = reinterpret_cast<uint16_t*>(dsm);
+    constexpr int NB = 32 * NTT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int col0 = blockIdx.y * NB;
+    const int pitch = K + 8;
+    // phase 1: global -> LDS (16-byte chunks, fully coalesced)
+    {
+        const int k8 = K >> 3;
+        const uint4* src = reinterpret_cast<const uint4*>(X + row0 * K);
+        const int chunks = 128 * k8;
+        for (int c = tid; c < chunks; c += 256) {
+            const int row = c / k8, kc = c - row * k8;
+            *reinterpret_cast<uint4*>(tile + row * pitch + 8 * kc) = src[c];
+        }
+    }
+    __syncthreads();
+    // phase 2: MFMA
+    f32x16 acc[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+    {
+        const uint16_t* ap = tile + (32 * w + r) * pitch + 8 * kb;
+        const int nt_all = N >> 5;
+        const uint16_t* bp = Wfrag + ((int64_t)(col0 >> 5) * 64 + lane) * 8;
+        const int ksteps = K >> 4;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+            const uint16_t* bk = bp + (int64_t)ks * nt_all * 512;
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bk + t * 512);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // phase 3: epilogue
+    if (OUT_BF16) {
+        __syncthreads();  // every wave is done reading the X tile
+        const int opitch = NB + 8;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+            const int col = 32 * t + r;
+            const float bv = bias ? bias[col0 + col] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float y = acc[t][q] + bv;
+                if (ACT == 0) y = fmaxf(y, 0.0f);
+                else if (ACT == 1) y = tanhf(y);
+                tile[(32 * w + mfma_row(q, kb)) * opitch + col] = f32_to_bf16_rne(y);
+            }
+        }
+        __syncthreads();
+        constexpr int c8 = NB >> 3;
+        uint16_t* Y = reinterpret_cast<uint16_t*>(Yv);
+        for (int c = tid; c < 128 * c8; c += 256) {
+            const int row = c / c8, cc = c - row * c8;
+            *reinterpret_cast<uint4*>(Y + (row0 + row) * N + col0 + 8 * cc) =
+                *reinterpret_cast<const uint4*>(tile + row * opitch + 8 * cc);
+        }
+    } else {
+        float* Y = reinterpret_cast<float*>(Yv);
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+            const int col = col0 + 32 * t + r;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float y = acc[t][q] + bv;
+                if (ACT == 0) y = fmaxf(y, 0.0f);
+                else if (ACT == 1) y = tanhf(y);
+                Y[(row0 + 32 * w + mfma_row(q, kb)) * N + col] = y;
+            }
+        }
+    }
+}
+
+// Wt[n][k] (row-major bf16, k contiguous) -> MFMA B-fragment order: fragment (ks, tg) = 64 lanes x 8 elements,
+// lane l holds Wt[n = 32 tg + (l & 31)][k = 16 ks + 8 (l >> 5) + u]
+__global__ __launch_bounds__(256) void frag_weight_kernel(const uint16_t* __restrict__ wt, int K, int N,
+                                                          uint16_t* __restrict__ wf) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)K * N) return;
+    int u = (int)(q & 7), l = (int)((q >> 3) & 63);
+    int64_t f = q >> 9;
+    int nt_all = N >> 5;
+    int tg = (int)(f % nt_all), ks = (int)(f / nt_all);
+    int n = 32 * tg + (l & 31), k = 16 * ks + 8 * (l >> 5) + u;
+    wf[q] = wt[(int64_t)n * K + k];
+}
+
 // f32 SoA activations (K x B, batch contiguous) -> bf16 rows (B x Kpad), zero padded to Kpad
 __global__ __launch_bounds__(256) void soa_to_bf16_rows_kernel(const float* __restrict__ x, int64_t B, int K,
                                                                int Kpad, uint16_t* __restrict__ out) {
@@ -122,6 +232,57 @@ int32_t rlhip_dense_bf16_forward(const uint16_t* x_rows, const uint16_t* wt, con
         else LAUNCH_D(2, false);
     }
 #undef LAUNCH_D
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_dense_frag_weight_bf16(const uint16_t* wt, int32_t k, int32_t n, uint16_t* w_frag,
+                                     rlhip_stream_t stream) {
+    RLHIP_REQUIRE(wt && w_frag, "NULL array");
+    RLHIP_REQUIRE(k >= 16 && k % 16 == 0 && n >= 32 && n % 32 == 0, "K must be a multiple of 16, N of 32 (zero-pad)");
+    int64_t total = (int64_t)k * n;
+    hipLaunchKernelGGL(frag_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), wt, k,
+                       n, w_frag);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w_frag, const float* bias, int32_t act,
+                                       int64_t batch, int32_t k, int32_t n, void* y_rows, int32_t y_is_bf16,
+                                       rlhip_stream_t stream) {
+    RLHIP_REQUIRE(x_rows && w_frag && y_rows, "NULL array");
+    RLHIP_REQUIRE(batch >= 128 && batch % 128 == 0, "batch must be a multiple of 128 (pad the batch)");
+    RLHIP_REQUIRE(k >= 16 && k % 16 == 0 && k <= 512, "K must be a multiple of 16, <= 512 (zero-pad)");
+    RLHIP_REQUIRE(n >= 128 && n % 128 == 0, "N must be a multiple of 128 (zero-pad)");
+    RLHIP_REQUIRE(act >= 0 && act <= 2, "act: 0 relu, 1 tanh, 2 identity");
+    RLHIP_REQUIRE((((uintptr_t)x_rows | (uintptr_t)w_frag | (uintptr_t)y_rows) & 15) == 0,
+                  "operands must be 16-byte aligned");
+    const bool wide = (n % 256 == 0);  // 256-column blocks: X is read once when N = 256
+    const int nb = wide ? 256 : 128;
+    size_t lds = (size_t)128 * (size_t)((k > nb ? k : nb) + 8) * sizeof(uint16_t);
+    dim3 grid((unsigned)(batch / 128), (unsigned)(n / nb));
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_T(NTT_, A_, O_)                                                                                   \
+    do {                                                                                                         \
+        static size_t allowed_ = 0;                                                                              \
+        if (lds > allowed_) {                                                                                    \
+            RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tiled_kernel<NTT_, A_, O_>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+            allowed_ = lds;                                                                                      \
+        }                                                                                                        \
+        hipLaunchKernelGGL((dense_tiled_kernel<NTT_, A_, O_>), grid, dim3(256), lds, s, x_rows, w_frag, bias,    \
+                           batch, k, n, y_rows);                                                                 \
+    } while (0)
+#define LAUNCH_TA(NTT_, O_)              \
+    do {                                 \
+        if (act == 0) LAUNCH_T(NTT_, 0, O_); \
+        else if (act == 1) LAUNCH_T(NTT_, 1, O_); \
+        else LAUNCH_T(NTT_, 2, O_);      \
+    } while (0)
+    if (wide) { if (y_is_bf16) LAUNCH_TA(8, true); else LAUNCH_TA(8, false); }
+    else { if (y_is_bf16) LAUNCH_TA(4, true); else LAUNCH_TA(4, false); }
+#undef LAUNCH_TA
+#undef LAUNCH_T
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

@@ -261,6 +261,24 @@ def dense_bf16_forward(x_rows, wt, bias=None, act="relu", out_dtype=torch.bfloat
     return y
 
 
+def dense_frag_weight_bf16(wt):
+    """row-major bf16 Wt (n, k) -> MFMA B-fragment order (same element count) for dense_bf16_forward_tiled."""
+    n, k = wt.shape
+    wf = torch.empty(n * k, dtype=torch.bfloat16, device=wt.device)
+    call("rlhip_dense_frag_weight_bf16", ptr(wt), k, n, ptr(wf), stream_ptr())
+    return wf
+
+
+def dense_bf16_forward_tiled(x_rows, w_frag, n, bias=None, act="relu", out_dtype=torch.bfloat16):
+    """Y = act(X W + b), LDS-staged tiled MFMA kernel.  x_rows (batch, k) bf16, w_frag from dense_frag_weight_bf16."""
+    batch, k = x_rows.shape
+    y = torch.empty((batch, n), dtype=out_dtype, device=x_rows.device)
+    a = {"relu": 0, "tanh": 1, "identity": 2}[act] if isinstance(act, str) else int(act)
+    call("rlhip_dense_bf16_forward_tiled", ptr(x_rows), ptr(w_frag), ptr(bias), a, batch, k, n, ptr(y),
+         int(out_dtype == torch.bfloat16), stream_ptr())
+    return y
+
+
 def bf16_rows_to_soa(y_rows, n):
     batch, ld = y_rows.shape
     out = torch.empty((n, batch), dtype=torch.float32, device=y_rows.device)

@@ -59,3 +59,44 @@ def test_dense_mfma_argument_validation():
     w = torch.zeros((128, 16), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RLHipArgumentError):
         ops.dense_bf16_forward(x, w)  # batch not a multiple of 128
+
+
+@pytest.mark.parametrize("batch,k,n,act", [(128, 16, 128, "identity"), (256, 128, 128, "relu"), (4096, 256, 256, "relu"),
+                                          (1024, 64, 384, "tanh"), (2048, 512, 512, "relu"), (32768, 128, 256, "relu")])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_dense_bf16_mfma_tiled_forward(batch, k, n, act, out_dtype):
+    """the LDS-staged tiled kernel (fragment-ordered weights) against the same torch reference, and bit-for-bit
+    against the simple kernel for the f32 output (same bf16 operands, same k order inside the MFMA chain)."""
+    from rlhip import ops
+
+    g = torch.Generator(device="cpu").manual_seed(batch + k + n + 1)
+    xr = (torch.randn((batch, k), generator=g) * 0.5).cuda().to(torch.bfloat16)
+    wt = (torch.randn((n, k), generator=g) / np.sqrt(k)).cuda().to(torch.bfloat16)
+    bias = torch.randn(n, generator=g).cuda()
+    wf = ops.dense_frag_weight_bf16(wt)
+    # fragment order: fragment (ks, tg), lane l, element u  <-  Wt[32 tg + (l & 31)][16 ks + 8 (l >> 5) + u]
+    q = torch.arange(n * k, device="cuda")
+    u, l, f = q & 7, (q >> 3) & 63, q >> 9
+    tg, ks = f % (n // 32), f // (n // 32)
+    assert torch.equal(wf, wt[32 * tg + (l & 31), 16 * ks + 8 * (l >> 5) + u])
+    y = ops.dense_bf16_forward_tiled(xr, wf, n, bias, act, out_dtype)
+    ref = xr.float() @ wt.float().t() + bias
+    ref = {"relu": torch.relu, "tanh": torch.tanh, "identity": lambda t: t}[act](ref)
+    if out_dtype == torch.bfloat16:
+        torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
+    else:
+        torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+        assert torch.equal(y, ops.dense_bf16_forward(xr, wt, bias, act, out_dtype))
+
+
+def test_dense_tiled_identity_weight():
+    from rlhip import ops
+
+    k = n = 256
+    batch = 384
+    x = torch.arange(batch * k, dtype=torch.float32).reshape(batch, k).remainder(251).sub(125).cuda()
+    xr = x.to(torch.bfloat16).contiguous()
+    wf = ops.dense_frag_weight_bf16(torch.eye(n, dtype=torch.bfloat16, device="cuda").contiguous())
+    for dt in (torch.float32, torch.bfloat16):
+        y = ops.dense_bf16_forward_tiled(xr, wf, n, None, "identity", dt)
+        assert torch.equal(y.float(), xr.float())
