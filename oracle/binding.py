@@ -11,7 +11,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librl_oracle.so")
+_SO_OMP = os.path.join(_HERE, "_build", "librl_oracle_omp.so")
 _lib = None
+_lib_serial = None
+_lib_omp = None
 
 KIND = {"cartpole": 0, "pendulum": 1, "mountaincar": 2}
 TAG = dict(RESET=0, EXPLORE=1, GUMBEL=2, NORMAL=3, SAMPLER=4, SHUFFLE=5, INIT=6, SYNTH=7)
@@ -19,8 +22,8 @@ TAG = dict(RESET=0, EXPLORE=1, GUMBEL=2, NORMAL=3, SAMPLER=4, SHUFFLE=5, INIT=6,
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
-    if (not force and os.path.exists(_SO)
-            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+    if (not force and os.path.exists(_SO) and os.path.exists(_SO_OMP)
+            and all(min(os.path.getmtime(_SO), os.path.getmtime(_SO_OMP)) >= os.path.getmtime(s) for s in srcs)):
         return _SO
     subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
     return _SO
@@ -67,11 +70,34 @@ class RingC(C.Structure):
                [(n, C.c_void_p) for n in ("state", "action", "reward", "terminal")]
 
 
+def use_all_cores(enable=True):
+    """Switch every binding call to the -fopenmp build of the same sources (bench.py's all-cores cpu_baseline)
+    or back to the sequential parity oracle.  Returns the number of threads the selected build uses."""
+    global _lib, _lib_serial, _lib_omp
+    lib()
+    if _lib_serial is None:
+        _lib_serial = _lib
+    if enable:
+        if _lib_omp is None:
+            _lib_omp = _load(_SO_OMP)
+        _lib = _lib_omp
+        gomp = C.CDLL("libgomp.so.1")
+        return int(gomp.omp_get_max_threads())
+    _lib = _lib_serial
+    return 1
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_SO)
+        _lib = _load(_SO)
+    return _lib
+
+
+def _load(path):
+    if True:
+        _lib = C.CDLL(path)
         _lib.rlo_u01_f32.restype = C.c_float
         _lib.rlo_u01_f64.restype = C.c_double
         _lib.rlo_randint.restype = C.c_uint32

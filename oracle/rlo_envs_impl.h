@@ -269,6 +269,7 @@ static int NAME(env_step)(int kind, const void* cfg, rlo_env_state* st, int64_t 
     if (kind == 0) NAME(cartpole_make)((const rlo_cartpole_cfg*)cfg, &cp);
     else if (kind == 1) NAME(pendulum_make)((const rlo_pendulum_cfg*)cfg, &pp);
     else NAME(mountaincar_make)((const rlo_mountaincar_cfg*)cfg, &mp);
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         if (kind == 0) NAME(cartpole_step1)(&cp, st, i, actions);
         else if (kind == 1) NAME(pendulum_step1)(&pp, st, i, actions);

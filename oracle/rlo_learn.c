@@ -15,6 +15,9 @@
  * Appendix B -- PARITY UNPINNED; gradients are checked against torch autograd in tests/.
  */
 #include "rl_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -152,37 +155,15 @@ int64_t rlo_ppo_nparams(int kind, const rlo_ppo_cfg* c) {
 
 static inline float log2pi_f32(void) { return logf(6.2831855f); }
 
-void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const float* params,
-                           const float* obs, const int32_t* act_i, const float* act_f,
-                           const float* logp_old, const float* adv_in, const float* ret, int64_t bm,
-                           float* grad, float* losses_out) {
-    int64_t h = c->hidden;
-    int64_t nout_a = ppo_actor_nout(c, na);
-    int64_t np_a = rlo_mlp2_nparams(ns, h, nout_a);
-    int64_t np_c = rlo_mlp2_nparams(ns, h, 1);
-    const float* pa = params;
-    const float* pc = params + np_a;
-    double* ga = (double*)calloc((size_t)(np_a + np_c), sizeof(double));
-    float* hid = (float*)malloc(sizeof(float) * (size_t)h * 2);
-    float* zb = hid + h;
-    float* adv = (float*)malloc(sizeof(float) * (size_t)bm);
-    memcpy(adv, adv_in, sizeof(float) * (size_t)bm);
-    if (c->normalize_advantage) { /* (A - mean) / clamp(std, 1e-8, 1000) with the corrected std */
-        double mu = 0, s2 = 0;
-        for (int64_t i = 0; i < bm; ++i) mu += adv[i];
-        mu /= (double)bm;
-        for (int64_t i = 0; i < bm; ++i) s2 += (adv[i] - mu) * (adv[i] - mu);
-        double sd = sqrt(s2 / (double)(bm > 1 ? bm - 1 : 1));
-        if (sd < 1e-8) sd = 1e-8;
-        if (sd > 1000.0) sd = 1000.0;
-        for (int64_t i = 0; i < bm; ++i) adv[i] = (float)((adv[i] - mu) / sd);
-    }
-    const float lo = 1.0f - c->clip_range, hi = 1.0f + c->clip_range;
-    const float inv_b = 1.0f / (float)bm;
-    const float min_logp = (float)log(1e-8); /* clamp!(log_p, log(1e-8), Inf) */
-    double actor_acc = 0, critic_acc = 0, ent_acc = 0;
+/* one sample of the PPO loss: forward, loss terms, backward into the Float64 accumulators ga */
+static void ppo_sample(const rlo_ppo_cfg* c, int64_t ns, int64_t na, int64_t h, int64_t nout_a, int64_t np_a,
+                       const float* pa, const float* pc, const float* obs, const int32_t* act_i, const float* act_f,
+                       const float* logp_old, const float* adv, const float* ret, int64_t bm, int64_t i, float lo,
+                       float hi, float inv_b, float min_logp, double* ga, float* hid, float* zb, double* actor_acc_p,
+                       double* critic_acc_p, double* ent_acc_p) {
     float out[64], dout[64];
-    for (int64_t i = 0; i < bm; ++i) {
+    double actor_acc = 0, critic_acc = 0, ent_acc = 0;
+    {
         /* ---- actor ---- */
         mlp2_forward1(pa, ns, h, nout_a, c->act, obs + i, bm, out, 1, hid, zb);
         float lp_old = logp_old[i] < min_logp ? min_logp : logp_old[i];
@@ -259,6 +240,78 @@ void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const f
         float dvout = -2.0f * c->critic_loss_weight * inv_b * dv;
         mlp2_backward1(pc, ns, h, 1, c->act, obs + i, bm, &dvout, 1, ga + np_a, hid, zb);
     }
+    *actor_acc_p += actor_acc;
+    *critic_acc_p += critic_acc;
+    *ent_acc_p += ent_acc;
+}
+
+void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const float* params,
+                           const float* obs, const int32_t* act_i, const float* act_f,
+                           const float* logp_old, const float* adv_in, const float* ret, int64_t bm,
+                           float* grad, float* losses_out) {
+    int64_t h = c->hidden;
+    int64_t nout_a = ppo_actor_nout(c, na);
+    int64_t np_a = rlo_mlp2_nparams(ns, h, nout_a);
+    int64_t np_c = rlo_mlp2_nparams(ns, h, 1);
+    const float* pa = params;
+    const float* pc = params + np_a;
+    double* ga = (double*)calloc((size_t)(np_a + np_c), sizeof(double));
+    float* hid = (float*)malloc(sizeof(float) * (size_t)h * 2);
+    float* zb = hid + h;
+    float* adv = (float*)malloc(sizeof(float) * (size_t)bm);
+    memcpy(adv, adv_in, sizeof(float) * (size_t)bm);
+    if (c->normalize_advantage) { /* (A - mean) / clamp(std, 1e-8, 1000) with the corrected std */
+        double mu = 0, s2 = 0;
+        for (int64_t i = 0; i < bm; ++i) mu += adv[i];
+        mu /= (double)bm;
+        for (int64_t i = 0; i < bm; ++i) s2 += (adv[i] - mu) * (adv[i] - mu);
+        double sd = sqrt(s2 / (double)(bm > 1 ? bm - 1 : 1));
+        if (sd < 1e-8) sd = 1e-8;
+        if (sd > 1000.0) sd = 1000.0;
+        for (int64_t i = 0; i < bm; ++i) adv[i] = (float)((adv[i] - mu) / sd);
+    }
+    const float lo = 1.0f - c->clip_range, hi = 1.0f + c->clip_range;
+    const float inv_b = 1.0f / (float)bm;
+    const float min_logp = (float)log(1e-8); /* clamp!(log_p, log(1e-8), Inf) */
+    /* samples are independent: with OpenMP (the all-cores CPU baseline build, -fopenmp) each thread owns a
+     * contiguous chunk, its own Float64 gradient accumulator and scratch; accumulators are combined in thread
+     * order.  Without OpenMP this is the single sequential pass it always was. */
+    double actor_acc = 0, critic_acc = 0, ent_acc = 0;
+#ifdef _OPENMP
+    int64_t npar = np_a + np_c;
+    int nthr = omp_get_max_threads();
+    if (nthr > 1 && bm >= 4 * (int64_t)nthr) {
+        double* gt = (double*)calloc((size_t)npar * (size_t)nthr, sizeof(double));
+        double* accs = (double*)calloc((size_t)nthr * 3, sizeof(double));
+#pragma omp parallel num_threads(nthr)
+        {
+            int tid = omp_get_thread_num();
+            int64_t i0 = bm * tid / nthr, i1 = bm * (tid + 1) / nthr;
+            float* hid_t = (float*)malloc(sizeof(float) * (size_t)h * 2);
+            double aa = 0, ca = 0, ea = 0;
+            for (int64_t i = i0; i < i1; ++i)
+                ppo_sample(c, ns, na, h, nout_a, np_a, pa, pc, obs, act_i, act_f, logp_old, adv, ret, bm, i, lo, hi,
+                           inv_b, min_logp, gt + (size_t)npar * tid, hid_t, hid_t + h, &aa, &ca, &ea);
+            accs[3 * tid] = aa;
+            accs[3 * tid + 1] = ca;
+            accs[3 * tid + 2] = ea;
+            free(hid_t);
+        }
+        for (int t = 0; t < nthr; ++t) {
+            for (int64_t q = 0; q < npar; ++q) ga[q] += gt[(size_t)npar * t + q];
+            actor_acc += accs[3 * t];
+            critic_acc += accs[3 * t + 1];
+            ent_acc += accs[3 * t + 2];
+        }
+        free(gt);
+        free(accs);
+    } else
+#endif
+    {
+        for (int64_t i = 0; i < bm; ++i)
+            ppo_sample(c, ns, na, h, nout_a, np_a, pa, pc, obs, act_i, act_f, logp_old, adv, ret, bm, i, lo, hi, inv_b,
+                       min_logp, ga, hid, zb, &actor_acc, &critic_acc, &ent_acc);
+    }
     for (int64_t q = 0; q < np_a + np_c; ++q) grad[q] = (float)ga[q];
     float actor_loss = (float)(-actor_acc / (double)bm);
     float critic_loss = (float)(critic_acc / (double)bm);
@@ -326,14 +379,18 @@ int rlo_ppo_rollout_f32(int kind, const void* env_cfg, rlo_env_state* st, int64_
     int64_t np_a = rlo_mlp2_nparams(ns, h, nout_a);
     const float* pa = params;
     const float* pc = params + np_a;
-    float out[64];
     for (int64_t t = 0; t <= T; ++t) {
         float* obs_t = tr->obs + t * ns * n;
         rlo_env_obs(kind, 0, st, n, obs_t); /* state(env) at PreActStage (post auto-reset) */
+        /* env instances are independent: the loops over i run on all cores in the -fopenmp baseline build
+         * (bit-identical results: nothing is reduced across instances) */
+#pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < n; ++i)
             mlp2_forward1(pc, ns, h, 1, c->act, obs_t + i, n, tr->value + t * n + i, 1, 0, 0);
         if (t == T) break;
+#pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < n; ++i) {
+            float out[64];
             mlp2_forward1(pa, ns, h, nout_a, c->act, obs_t + i, n, out, 1, 0, 0);
             if (!c->continuous) {
                 rlo_categorical_sample_f32(out, na, 1, 0, seed, env_id_base + (uint32_t)i,
@@ -392,6 +449,7 @@ int rlo_ppo_update_f32(int kind, const rlo_ppo_cfg* c, int64_t n, int64_t T, rlo
     for (int32_t e = 0; e < c->n_epochs; ++e) {
         uint32_t epoch_ctr = update_ctr * (uint32_t)c->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < c->n_microbatches; ++mb) {
+#pragma omp parallel for schedule(static)
             for (int64_t b = 0; b < bm; ++b) {
                 uint32_t f = rlo_permute(seed, epoch_ctr, (uint32_t)total, (uint32_t)(mb * bm + b));
                 int64_t t = f / n, i = f % n;
