@@ -212,7 +212,16 @@ def roofline_extras(torch, rlhip):
     el = time.perf_counter() - t0
     out["dqn_cartpole_4096env"] = {"env_steps_per_sec": round(n * steps / el, 1), "updates_per_sec": round(steps / el, 1),
                                    "ms_per_vec_step": round(el / steps * 1e3, 4), "batch": 512,
-                                   "note": "per-step drop-in protocol (plan!/act!/push!/optimise! = 6 launches per vec-step, eager)"}
+                                   "note": "per-step drop-in protocol (plan!/act!/push!/optimise! = one ccall each, eager)"}
+    steps_f = 2000
+    t0 = time.perf_counter()
+    rlhip.run_fused_dqn(agent, env, rlhip.StopAfterNSteps(steps_f))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out["dqn_cartpole_4096env"]["fused_vec_step"] = {
+        "env_steps_per_sec": round(n * steps_f / el, 1), "updates_per_sec": round(steps_f / el, 1),
+        "ms_per_vec_step": round(el / steps_f * 1e3, 4),
+        "note": "rlhip_dqn_vec_step_f32: the same kernels enqueued by ONE C-ABI call per vec-step (bit-identical results)"}
     del agent, policy, learner, net, env
     # same config with the blog's 3-layer Q-network 4 -> 128 -> 128 -> 2, hidden layer on the bf16 MFMA (dqn3.hip)
     env = rlhip.CartPoleEnv(n, seed=5)
@@ -230,6 +239,13 @@ def roofline_extras(torch, rlhip):
                                          "updates_per_sec": round(steps / el, 1),
                                          "ms_per_vec_step": round(el / steps * 1e3, 4), "batch": 512,
                                          "net": "4->128->128->2 relu, hidden layer bf16 MFMA, f32 master weights"}
+    t0 = time.perf_counter()
+    rlhip.run_fused_dqn(agent, env, rlhip.StopAfterNSteps(steps_f))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out["dqn3_mfma_cartpole_4096env"]["fused_vec_step"] = {
+        "env_steps_per_sec": round(n * steps_f / el, 1), "updates_per_sec": round(steps_f / el, 1),
+        "ms_per_vec_step": round(el / steps_f * 1e3, 4)}
     # the MFMA learner kernel alone at a PPO-sized batch (131072 samples): 4 hidden GEMMs per sample
     # (target fwd, online fwd, dH1, dW2) = 4 * 2 * 128 * 128 flop
     from rlhip import dqn as _dqn
@@ -342,7 +358,8 @@ def cpu_baseline(budget_s=8.0):
     return {"value": round(N_ENVS * T_ROLLOUT * it / el, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
             "updates_per_sec": round(16 * it / el, 2),
             "sample": f"{it} full PPO iterations of {N_ENVS} envs x T={T_ROLLOUT} (same net / epochs / micro-batches) in "
-                      f"{el:.1f} s, oracle C restatement, gcc -O2 -fopenmp, {threads} threads on {os.cpu_count()} host cores",
+                      f"{el:.1f} s, oracle C restatement, gcc -O2 -fopenmp, {threads} threads = the CPUs this container may "
+                      f"use (cgroup quota) of the host's {os.cpu_count()}",
             "single_thread": single}
 
 

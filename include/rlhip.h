@@ -280,6 +280,48 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
 
+/* ------------------------------------------------- one DQN vec-step as a single call -- */
+/* One trip round the body of `_run` (RLCore/src/core/run.jl:52-70) for Agent{QBasedPolicy{DQN}} on the vector
+ * env: plan! (q_based_policy.jl:30-32) -> act! -> push!(agent, PostActStage) (agent_base.jl:56-59) ->
+ * optimise! (q_based_policy.jl:49; flux_approximator.jl:46; target_network.jl:70-88).  Enqueues exactly the
+ * kernels of the per-step entry points, in the same order, so results are bit-identical to them.
+ * The counters (explorer_step, draw_ctr, do_update, do_sync) are the host's: pure functions of the step count. */
+typedef struct {
+    int32_t kind;              /* 0 CartPole, 1 Pendulum (discrete), 2 MountainCar; Float32 state */
+    const void* env_cfg;       /* rlhip_*_cfg (host) */
+    const rlhip_env_state* st; /* device state arrays */
+    int64_t n;                 /* env instances */
+    uint64_t env_seed;
+    uint32_t env_id_base;
+    float* obs;                /* (obs_dim, n): current observation in, next observation out */
+    float* last_obs;           /* (obs_dim, n) pre-reset observation of the step, may be NULL */
+    rlhip_ring* ring;          /* host struct; its counters advance */
+    int32_t layers;            /* 2: ns -> h -> na (dqn.hip); 3: ns -> 128 -> 128 -> na (dqn3.hip, MFMA) */
+    int64_t h, na;
+    int32_t act;               /* 0 relu, 1 tanh */
+    float* params;
+    uint16_t* packed;          /* layers == 3 */
+    float* target;
+    uint16_t* target_packed;   /* layers == 3 */
+    float *m, *v, *beta_pow;   /* Adam state */
+    float lr, beta1, beta2, adam_eps, max_grad_norm, grad_scale;
+    double eps;                /* get_eps(explorer, explorer_step) */
+    uint64_t explorer_seed;
+    uint32_t explorer_step;
+    int64_t batch;
+    float gamma, huber_delta;
+    uint64_t sampler_seed;
+    uint32_t draw_ctr;
+    int32_t do_update;         /* run optimise! this step */
+    int32_t do_sync;           /* target sync after this update */
+    float rho;
+    void* workspace;
+    float *grad, *loss, *gn;   /* loss / gn: f32[1] device */
+    int32_t* actions;          /* i32[n] out (0-based) */
+    float* q;                  /* (na, n) out, may be NULL */
+} rlhip_dqn_step_args;
+int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* args, rlhip_stream_t stream);
+
 /* ------------------------------------------------------ 3-layer Q-network on the MFMA -- */
 /* Chain(Dense(ns, 128, act), Dense(128, 128, act), Dense(128, na)) -- the blog's DQN model
  * (docs/homepage/blog/a_practical_introduction_to_RL.jl/index.html:15126-15128), forward(learner, x) =

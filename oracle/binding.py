@@ -70,7 +70,26 @@ class RingC(C.Structure):
                [(n, C.c_void_p) for n in ("state", "action", "reward", "terminal")]
 
 
-def use_all_cores(enable=True):
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container with
+    `cpu.max = 1600000 100000` on a 256-thread host gets 16 CPUs' worth of time: more threads only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def use_all_cores(enable=True, threads=None):
     """Switch every binding call to the -fopenmp build of the same sources (bench.py's all-cores cpu_baseline)
     or back to the sequential parity oracle.  Returns the number of threads the selected build uses."""
     global _lib, _lib_serial, _lib_omp
@@ -82,6 +101,7 @@ def use_all_cores(enable=True):
             _lib_omp = _load(_SO_OMP)
         _lib = _lib_omp
         gomp = C.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(int(threads or usable_cpus()))
         return int(gomp.omp_get_max_threads())
     _lib = _lib_serial
     return 1

@@ -1,0 +1,85 @@
+// dqn_step.hip -- one whole vec-step of the DQN agent loop as ONE C-ABI call (host-side composition of the
+// kernels in dqn.hip / dqn3.hip / envs.hip / ring.hip / optim.hip; no new device code).
+//
+// What it replaces: one trip round the body of `_run` (RLCore/src/core/run.jl:52-70) for
+// `Agent{QBasedPolicy{DQNLearner}}` on the vector env --
+//     action = plan!(policy, env)                      q_based_policy.jl:30-32 -> explorer :108-112
+//     act!(env, action)                                CartPoleEnv.jl:112-140 (+ auto-reset, MultiThreadEnv protocol)
+//     push!(agent, PostActStage(), env, action)        agent_base.jl:56-59
+//     optimise!(agent, PostActStage())                 q_based_policy.jl:49 -> learner -> flux_approximator.jl:46,
+//                                                      target_network.jl:70-88
+// The per-step drop-in protocol costs one ccall (and, from Python, ~8 us of interpreter time) per arrow; at 4096
+// envs every kernel is a few microseconds, so the loop was host-paced (72 us per vec-step).  This entry point
+// enqueues the same kernels in the same order with the same arguments -- results are bit-identical to the
+// per-step protocol (tests/test_gpu_run.py) -- from one call.
+#include "common.h"
+
+extern "C" {
+int32_t rlhip_dqn_plan_f32(const float*, int64_t, int64_t, int64_t, int32_t, const float*, int64_t, double, uint64_t,
+                           uint32_t, uint32_t, int32_t*, float*, rlhip_stream_t);
+int32_t rlhip_dqn3_plan_f32(const float*, const uint16_t*, int64_t, int64_t, int64_t, int32_t, const float*, int64_t,
+                            double, uint64_t, uint32_t, uint32_t, int32_t*, float*, rlhip_stream_t);
+int32_t rlhip_dqn_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const float*, const float*, int64_t, float,
+                           float, uint64_t, uint32_t, void*, float*, float*, rlhip_stream_t);
+int32_t rlhip_dqn3_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const float*, const uint16_t*, const float*,
+                            const uint16_t*, int64_t, const int64_t*, float, float, uint64_t, uint32_t, void*, float*,
+                            float*, float*, rlhip_stream_t);
+int32_t rlhip_mlp3_pack_bf16(const float*, int64_t, int64_t, int64_t, uint16_t*, rlhip_stream_t);
+int64_t rlhip_mlp2_nparams(int64_t, int64_t, int64_t);
+int64_t rlhip_mlp3_nparams(int64_t, int64_t, int64_t);
+int32_t rlhip_env_obs_dim(int32_t kind);
+}
+
+extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(a != nullptr, "args is NULL");
+    RLHIP_REQUIRE(a->env_cfg && a->st && a->obs && a->ring && a->params && a->actions, "NULL argument");
+    RLHIP_REQUIRE(a->layers == 2 || a->layers == 3, "layers must be 2 or 3");
+    RLHIP_REQUIRE(a->layers == 2 || (a->packed && a->target_packed), "3-layer network needs the packed weights");
+    RLHIP_REQUIRE(!a->do_update || (a->target && a->m && a->v && a->beta_pow && a->workspace && a->grad),
+                  "learner buffers missing");
+    const int64_t ns = rlhip_env_obs_dim(a->kind);
+    RLHIP_REQUIRE(ns == a->ring->obs_dim && a->n == a->ring->n_env, "ring geometry does not match the env");
+    int32_t rc;
+    // plan!(policy, env): Q forward + eps-greedy on the current observation
+    if (a->layers == 2)
+        rc = rlhip_dqn_plan_f32(a->params, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
+                                a->env_id_base, a->explorer_step, a->actions, a->q, stream);
+    else
+        rc = rlhip_dqn3_plan_f32(a->params, a->packed, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
+                                 a->env_id_base, a->explorer_step, a->actions, a->q, stream);
+    if (rc) return rc;
+    // act!(env, action) with auto-reset; the post-step observation lands in a->obs
+    rc = rlhip_env_step(a->kind, 0, a->env_cfg, a->st, a->n, a->actions, 1, a->env_seed, a->env_id_base, a->last_obs,
+                        a->obs, stream);
+    if (rc) return rc;
+    // push!(trajectory, (state = s', action, reward, terminal))
+    rc = rlhip_ring_push_transition(a->ring, a->obs, a->actions, (const float*)a->st->reward, a->st->done, stream);
+    if (rc) return rc;
+    if (!a->do_update) return RLHIP_OK;
+    // optimise!(learner, trajectory): sample + TD target + Huber + gradient, then clip + Adam
+    int64_t np;
+    if (a->layers == 2) {
+        np = rlhip_mlp2_nparams(ns, a->h, a->na);
+        rc = rlhip_dqn_grad_f32(a->ring, a->h, a->na, a->act, a->params, a->target, a->batch, a->gamma, a->huber_delta,
+                                a->sampler_seed, a->draw_ctr, a->workspace, a->grad, a->loss, stream);
+    } else {
+        np = rlhip_mlp3_nparams(ns, a->h, a->na);
+        rc = rlhip_dqn3_grad_f32(a->ring, a->h, a->na, a->act, a->params, a->packed, a->target, a->target_packed,
+                                 a->batch, nullptr, a->gamma, a->huber_delta, a->sampler_seed, a->draw_ctr,
+                                 a->workspace, a->grad, a->loss, nullptr, stream);
+    }
+    if (rc) return rc;
+    rc = rlhip_clip_adam_f32(a->params, a->grad, a->m, a->v, a->beta_pow, np, a->grad_scale, a->max_grad_norm, a->lr,
+                             a->beta1, a->beta2, a->adam_eps, a->gn, stream);
+    if (rc) return rc;
+    if (a->layers == 3) {
+        rc = rlhip_mlp3_pack_bf16(a->params, ns, a->h, a->na, a->packed, stream);
+        if (rc) return rc;
+    }
+    if (a->do_sync) {  // TargetNetwork: dest = rho * dest + (1 - rho) * src
+        rc = rlhip_polyak_f32(a->target, a->params, np, a->rho, stream);
+        if (rc) return rc;
+        if (a->layers == 3) rc = rlhip_mlp3_pack_bf16(a->target, ns, a->h, a->na, a->target_packed, stream);
+    }
+    return rc;
+}

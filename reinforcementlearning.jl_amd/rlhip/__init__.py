@@ -9,7 +9,7 @@ from .envs import (CartPoleEnv, ContinuousMountainCarEnv, HipVecEnv, MountainCar
 from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DoEveryNSteps, EmptyHook,  # noqa: F401
                    PPOAgent, RandomPolicy, StepsPerEpisode, StopAfterNEpisodes, StopAfterNSeconds,
                    StopAfterNSteps, StopIfAll, StopIfAny, TimePerStep, TotalBatchRewardPerEpisode, run,
-                   run_fused_ppo)
+                   run_fused_dqn, run_fused_ppo)
 from .dqn import (DQNLearner, EpsilonGreedyExplorer, GreedyExplorer, HipApproximator,  # noqa: F401
                   QBasedPolicy, TargetNetwork)
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401

@@ -59,6 +59,18 @@ class EnvState(C.Structure):
     _fields_ = [("s", vp * 4), ("t", vp), ("done", vp), ("reward", vp), ("episode", vp)]
 
 
+class DqnStepArgs(C.Structure):
+    """rlhip_dqn_step_args (include/rlhip.h)"""
+    _fields_ = [("kind", i32), ("env_cfg", vp), ("st", vp), ("n", i64), ("env_seed", u64), ("env_id_base", u32),
+                ("obs", vp), ("last_obs", vp), ("ring", vp), ("layers", i32), ("h", i64), ("na", i64), ("act", i32),
+                ("params", vp), ("packed", vp), ("target", vp), ("target_packed", vp), ("m", vp), ("v", vp),
+                ("beta_pow", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("adam_eps", f32),
+                ("max_grad_norm", f32), ("grad_scale", f32), ("eps", f64), ("explorer_seed", u64),
+                ("explorer_step", u32), ("batch", i64), ("gamma", f32), ("huber_delta", f32), ("sampler_seed", u64),
+                ("draw_ctr", u32), ("do_update", i32), ("do_sync", i32), ("rho", f32), ("workspace", vp), ("grad", vp),
+                ("loss", vp), ("gn", vp), ("actions", vp), ("q", vp)]
+
+
 class Ring(C.Structure):
     _fields_ = [(n, i64) for n in ("capacity", "n_env", "obs_dim", "head_sa", "len_sa", "head_rt",
                                    "len_rt")] + \
@@ -143,6 +155,7 @@ _PROTOS = {
     "rlhip_dqn3_workspace_bytes": (i64, [i64, i64, i64, i64]),
     "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
                                   vp, vp]),
+    "rlhip_dqn_vec_step_f32": (i32, [vp, vp]),
     "rlhip_sumtree_nodes": (i64, [i64]),
     "rlhip_sumtree_fill_range": (i32, [vp, i64, i64, i64, f32, vp]),
     "rlhip_sumtree_update": (i32, [vp, i64, vp, vp, i64, vp]),

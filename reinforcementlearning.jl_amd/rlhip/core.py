@@ -301,6 +301,74 @@ def run(policy, env, stop_condition=None, hook=None):
     return hook
 
 
+def run_fused_dqn(agent, env, stop_condition=None, hook=None):
+    """`run(agent, env, stop, hook)` for Agent{QBasedPolicy{DQNLearner}} on a HipVecEnv with the whole loop body
+    (plan! -> act! -> push! -> optimise!) as ONE C-ABI call per vec-step (rlhip_dqn_vec_step_f32).  Same kernels,
+    same order, same counters as `run`: parameters, trajectory and explorer state end bit-identical
+    (tests/test_gpu_run.py).  Hooks see the PostAct stage of every step."""
+    import ctypes as C
+
+    from . import _lib
+    from ._lib import call
+    from .ops import ptr, stream_ptr
+
+    policy, traj = agent.policy, agent.trajectory
+    learner, ex = policy.learner, policy.explorer
+    tn = learner.approximator
+    net = tn.network
+    traces = traj.container
+    if ex.is_break_tie or env.continuous or env.is_f64 or hasattr(traces, "sample_prioritized") \
+            or learner.process_group is not None:
+        raise NotImplementedError("fused DQN step: plain eps-greedy, Float32 discrete env, uniform replay, 1 GPU")
+    stop_condition = stop_condition or StopAfterNSteps(1)
+    hook = hook or EmptyHook()
+    hook.push_(PRE_EXPERIMENT_STAGE, agent, env)
+    agent.push_(PRE_EXPERIMENT_STAGE, env)
+    dev = env.device
+    if policy._actions is None:
+        policy._actions = torch.empty(env.n, dtype=torch.int32, device=dev)
+        policy._q = torch.empty((net.n_out, env.n), dtype=torch.float32, device=dev)
+    a = _lib.DqnStepArgs()
+    a.kind, a.env_cfg, a.st, a.n = env.kind, C.addressof(env.cfg), C.addressof(env._st), env.n
+    a.env_seed, a.env_id_base = env.seed, env.env_id_base
+    a.obs, a.last_obs = ptr(env.state()), ptr(env._last_obs)
+    a.ring = C.addressof(traces.rb)
+    a.layers, a.h, a.na, a.act = net.layers, net.hidden, net.n_out, net.act
+    a.params, a.target = ptr(net.params), ptr(tn.target)
+    a.packed = ptr(net.packed) if net.layers == 3 else None
+    a.target_packed = ptr(tn.target_packed) if net.layers == 3 else None
+    a.m, a.v, a.beta_pow = ptr(net.m), ptr(net.v), ptr(net.beta_pow)
+    a.lr, a.beta1, a.beta2, a.adam_eps = net.lr, net.beta1, net.beta2, net.eps
+    a.max_grad_norm, a.grad_scale = learner.max_grad_norm, 1.0
+    a.explorer_seed, a.batch, a.gamma, a.huber_delta = ex.seed, learner.batchsize, learner.gamma, learner.delta
+    a.sampler_seed, a.rho = learner.seed, tn.rho
+    a.workspace, a.grad, a.loss, a.gn = ptr(learner.workspace), ptr(learner.grad), ptr(learner.loss), ptr(net.gn)
+    a.actions, a.q = ptr(policy._actions), ptr(policy._q)
+    ctrl = traj.controller
+    s = stream_ptr()
+    while True:
+        a.eps, a.explorer_step = ex.get_eps(), ex.step
+        ex.step += 1
+        # the transition pushed by this call counts towards min_replay_history / the sample-ratio controller
+        ctrl.on_insert_(1)
+        n_after = min(len(traces) + 1, traces.capacity) * traces.n_env
+        a.do_update = int(n_after >= learner.min_replay_history)
+        a.draw_ctr = learner.draw_ctr
+        a.do_sync = int(a.do_update and (tn.n_optimise + 1) % tn.sync_freq == 0)
+        call("rlhip_dqn_vec_step_f32", C.byref(a), s)
+        if a.do_update:
+            learner.draw_ctr += 1
+            learner.n_updates += 1
+            tn.n_optimise = 0 if a.do_sync else tn.n_optimise + 1
+        hook.push_(POST_ACT_STAGE, agent, env)
+        if stop_condition.check_(agent, env):
+            break
+    env._obs_valid = True
+    agent.push_(POST_EXPERIMENT_STAGE, env)
+    hook.push_(POST_EXPERIMENT_STAGE, agent, env)
+    return hook
+
+
 def run_fused_ppo(policy, env, n_updates, hook=None):
     """The same loop with the T-step rollout fused into one launch per update period (hooks see one
     PostActStage per period with the LAST step's reward / terminal flags)."""

@@ -147,3 +147,43 @@ def test_two_ranks_one_gpu_gradient_allreduce(rl):
     pol.update_()
     d = np.abs(pol.params.cpu().numpy() - p0)
     assert np.quantile(d, 0.9) < 5e-3
+
+
+@pytest.mark.parametrize("layers,kind", [(2, "cartpole"), (3, "cartpole"), (2, "mountaincar"), (3, "mountaincar")])
+def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, kind):
+    """rlhip_dqn_vec_step_f32 (one C call per vec-step) against run(): same kernels in the same order, so the
+    parameters, target network, replay ring, env state and every counter must end bit-identical."""
+    import rlhip
+
+    def build():
+        n = 192
+        env = rlhip.HipVecEnv(kind, n, seed=4)
+        na = len(env.action_space())
+        net = rlhip.HipApproximator(env.odim, 128, na, seed=4, layers=layers)
+        tn = rlhip.TargetNetwork(net, sync_freq=7)
+        learner = rlhip.DQNLearner(tn, batchsize=256, min_replay_history=5 * n, seed=4, max_grad_norm=1.0)
+        policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.05, kind="exp", decay_steps=20, seed=4))
+        traces = rlhip.CircularArraySARTSTraces(capacity=16, n_env=n, obs_dim=env.odim)
+        return env, net, tn, learner, policy, traces, rlhip.Agent(policy, rlhip.Trajectory(traces))
+
+    e1, n1, t1, l1, p1, tr1, a1 = build()
+    e2, n2, t2, l2, p2, tr2, a2 = build()
+    steps = 45  # > capacity: the ring wraps; > min_replay_history / n: updates and target syncs happen
+    rlhip.run(a1, e1, rlhip.StopAfterNSteps(steps))
+    rlhip.run_fused_dqn(a2, e2, rlhip.StopAfterNSteps(steps))
+    torch.cuda.synchronize()
+    assert l1.n_updates == l2.n_updates > 30 and l1.draw_ctr == l2.draw_ctr
+    assert p1.explorer.step == p2.explorer.step and t1.n_optimise == t2.n_optimise
+    for a, b in ((n1.params, n2.params), (t1.target, t2.target), (n1.m, n2.m), (n1.v, n2.v), (l1.loss, l2.loss),
+                 (tr1.state, tr2.state), (tr1.action, tr2.action), (tr1.reward, tr2.reward),
+                 (tr1.terminal, tr2.terminal), (e1._s, e2._s), (e1._t, e2._t), (e1.state(), e2.state())):
+        assert torch.equal(a, b)
+    assert (tr1.rb.head_rt, tr1.rb.len_rt, tr1.rb.head_sa, tr1.rb.len_sa) == \
+           (tr2.rb.head_rt, tr2.rb.len_rt, tr2.rb.head_sa, tr2.rb.len_sa)
+    if layers == 3:
+        assert torch.equal(n1.packed, n2.packed) and torch.equal(t1.target_packed, t2.target_packed)
+    # and the two can be interleaved: continue the per-step agent with the fused loop
+    rlhip.run_fused_dqn(a1, e1, rlhip.StopAfterNSteps(5))
+    rlhip.run(a2, e2, rlhip.StopAfterNSteps(5))
+    torch.cuda.synchronize()
+    assert torch.equal(n1.params, n2.params) and torch.equal(tr1.state, tr2.state)
