@@ -162,6 +162,35 @@ def roofline_extras(torch, rlhip):
     del key, prio, keys
     del tr, bufs, idx
     torch.cuda.empty_cache()
+    # same replay as single 84x84 frames (7.4 GB instead of 29.6 GB) with StackFrames applied at sample time:
+    # 5 source frames read once, 2 x 4 frames written per sample
+    f1 = 84 * 84
+    tr1 = CircularArraySARTSTraces(capacity=cap, n_env=1, obs_dim=f1, dtype=torch.uint8)
+    tr1.state.random_(1, 256)
+    tr1.terminal.copy_((torch.rand(cap, 1, device="cuda") < 1 / 800).to(torch.uint8))
+    tr1.rb.len_sa, tr1.rb.len_rt = cap + 1, cap
+    idx1 = tr1.sample_indices(batch, seed=11, draw_ctr=0)
+    outs = tr1.gather_stacked(idx1, 4)
+    cnt = [1]
+
+    def gs():
+        rlhip._lib.call("rlhip_ring_sample_indices", C.byref(tr1.rb), batch, 11, cnt[0], ops.ptr(idx1), s)
+        cnt[0] += 1
+        rlhip._lib.call("rlhip_ring_gather_stacked", C.byref(tr1.rb), ops.ptr(idx1), batch, 4, ops.ptr(outs[0]),
+                        ops.ptr(outs[1]), ops.ptr(outs[2]), ops.ptr(outs[3]), ops.ptr(outs[4]), s)
+
+    def gi():
+        rlhip._lib.call("rlhip_ring_sample_indices", C.byref(tr1.rb), batch, 11, cnt[0], ops.ptr(idx1), s)
+
+    ms = event_time_ms(gs, 10, lib, s) - event_time_ms(gi, 10, lib, s)
+    gb = (5 * f1 + 8 * f1 + 9 + 9) * batch / 1e9
+    out["frame_gather_u8_stack_at_sample"] = {
+        "bound": "hbm", "capacity": cap, "frame_bytes": f1, "n_stack": 4, "batch": batch,
+        "ring_state_gb": round((cap + 1) * f1 / 1e9, 2), "us_per_launch": round(ms * 1e3, 1),
+        "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "samples_per_sec": round(batch / (ms * 1e-3), 1)}
+    del tr1, outs, idx1
+    torch.cuda.empty_cache()
     # bf16 MFMA Dense layer (hidden x hidden), batch = one PPO trajectory (131072 rows), 256 -> 256, fused bias + relu
     Bm, Km, Nm = N_ENVS * T_ROLLOUT, 256, 256
     xr = torch.randn((Bm, Km), device="cuda").to(torch.bfloat16)

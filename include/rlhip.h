@@ -280,6 +280,23 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
 
+/* --------------------------------------- frame stacking at sample time, max-pool push -- */
+/* StackFrames (RLCore/src/utils/stack_frames.jl:11-44) moved from the way in to the way out: the ring stores
+ * single frames (n_env == 1), the gather assembles the n_stack-deep observations
+ *   state stack of transition i = frames i-n+1 .. i,   next stack = i-n+2 .. i+1   (oldest first, newest last),
+ * with all-zero frames before the episode start / before the oldest stored frame (what StackFrames holds after
+ * reset!).  Outputs (batch, n_stack, frame) contiguous; a, r, term as rlhip_ring_gather.  n_stack <= 8. */
+int32_t rlhip_ring_gather_stacked(const rlhip_ring* rb_host, const int64_t* idx, int64_t batch, int32_t n_stack,
+                                  void* s, int32_t* a, float* r, uint8_t* term, void* s_next,
+                                  rlhip_stream_t stream);
+/* AtariEnv.act! 2-frame max-pool `screens[1] .= max.(screens[1], screens[2])`
+ * (RLEnvs/src/environments/3rd_party/atari.jl:104-107) fused into the push of a UInt8 frame. */
+int32_t rlhip_ring_push_state_maxpool(rlhip_ring* rb_host, const void* screen1, const void* screen2,
+                                      rlhip_stream_t stream);
+int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb_host, const void* screen1, const void* screen2,
+                                           const int32_t* action, const float* reward,
+                                           const uint8_t* terminal, rlhip_stream_t stream);
+
 /* ------------------------------------------------- one DQN vec-step as a single call -- */
 /* One trip round the body of `_run` (RLCore/src/core/run.jl:52-70) for Agent{QBasedPolicy{DQN}} on the vector
  * env: plan! (q_based_policy.jl:30-32) -> act! -> push!(agent, PostActStage) (agent_base.jl:56-59) ->

@@ -500,6 +500,18 @@ def ring_sample_prioritized(ring, st, batch, seed, draw_ctr):
     return idx, key, prio
 
 
+def ring_gather_stacked(ring, idx, n_stack):
+    """-> (s (batch, n_stack, obs_dim), a, r, t, s_next) for a single-env ring of single frames"""
+    b, d = len(idx), ring.rb.obs_dim
+    s = np.empty((b, n_stack, d), np.float32)
+    sn = np.empty((b, n_stack, d), np.float32)
+    a, r, t = np.empty(b, np.int32), np.empty(b, np.float32), np.empty(b, np.uint8)
+    idx = np.ascontiguousarray(idx, np.int64)
+    lib().rlo_ring_gather_stacked(C.byref(ring.rb), _p(idx), C.c_int64(b), C.c_int64(n_stack), _p(s), _p(a), _p(r),
+                                  _p(t), _p(sn))
+    return s, a, r, t, sn
+
+
 # ------------------------------------------------------------------------------------------ MLP
 def mlp2_nparams(n_in, h, n_out):
     return int(lib().rlo_mlp2_nparams(n_in, h, n_out))

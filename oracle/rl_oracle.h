@@ -260,6 +260,10 @@ void rlo_ring_push_priority(const rlo_ring* rb, float* tree, float priority);
 void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t batch, uint64_t seed,
                                  uint32_t draw_ctr, int64_t* flat_idx, int64_t* key_out, float* prio_out);
 
+/* stack-at-sample gather for single-env frame rings (StackFrames semantics, rlo_buffer.c) */
+void rlo_ring_gather_stacked(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, int64_t n_stack, float* s,
+                             int32_t* a, float* r, uint8_t* term, float* s_next);
+
 /* ------------------------------------------------------------------ MLP -- */
 /* Chain(Dense(n_in, h, act), Dense(h, n_out)) flat parameters in Flux.destructure order:
  * W1 (h x n_in, col-major), b1 (h), W2 (n_out x h, col-major), b2 (n_out).  act: 0 relu, 1 tanh */

@@ -185,3 +185,41 @@ void rlo_per_priority_f32(const float* td, int64_t n, float eps, float alpha, fl
         out[i] = (alpha == 1.0f) ? x : (float)pow((double)x, (double)alpha);
     }
 }
+
+/* ------------------------------------------------------------- stack-at-sample gather --
+ * StackFrames (RLCore/src/utils/stack_frames.jl:11-44) keeps the latest n frames in a CircularArrayBuffer that
+ * starts zero-filled (:22-26) and is zero-filled again by reset! (:33-36); the newest frame is the last slice
+ * (test RLCore/test/utils/stack_frames.jl:7-9).  With single frames in the ring (n_env == 1) the same stacks are
+ * rebuilt at sample time: going back from the newest frame, a frame is part of the stack until an episode
+ * boundary (terminal flag of the transition being crossed) or the oldest stored frame is passed; the rest is 0.
+ * s, s_next: (batch, n_stack, obs_dim), oldest frame first. */
+void rlo_ring_gather_stacked(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, int64_t n_stack, float* s,
+                             int32_t* a, float* r, uint8_t* term, float* s_next) {
+    int64_t d = rb->obs_dim;
+    for (int64_t b = 0; b < batch; ++b) {
+        int64_t li = flat_idx[b];
+        int64_t pt = (rb->head_rt + li) % rb->capacity;
+        a[b] = rb->action[pt];
+        r[b] = rb->reward[pt];
+        term[b] = rb->terminal[pt];
+        for (int which = 0; which < 2; ++which) { /* 0: state stack ends at frame li, 1: next stack at li + 1 */
+            float* out = which ? s_next : s;
+            int64_t newest = li + which;
+            int ok = 1;
+            for (int64_t k = 0; k < n_stack; ++k) {
+                int64_t f = newest - k;
+                if (k >= 1) { /* stepping back from frame f + 1 to f crosses transition f */
+                    if (f < 0) ok = 0;
+                    else if (rb->terminal[(rb->head_rt + f) % rb->capacity]) ok = 0;
+                }
+                float* dst = out + (b * n_stack + (n_stack - 1 - k)) * d;
+                if (ok) {
+                    const float* src = rb->state + ((rb->head_sa + f) % (rb->capacity + 1)) * d;
+                    memcpy(dst, src, sizeof(float) * (size_t)d);
+                } else {
+                    memset(dst, 0, sizeof(float) * (size_t)d);
+                }
+            }
+        }
+    }
+}

@@ -148,6 +148,85 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
     }
 }
 
+// ---- stack-at-sample gather -----------------------------------------------------------
+// The ring stores SINGLE frames; the n_stack-deep observation the reference builds on the way in with StackFrames
+// (RLCore/src/utils/stack_frames.jl:11-44: a CircularArrayBuffer of the latest n frames, zero-filled by reset!)
+// is assembled on the way out: state stack of transition li = frames li-n+1 .. li, next stack = li-n+2 .. li+1,
+// where a frame older than the episode start (a terminal flag between it and the newest frame) or older than the
+// ring is all zeros -- exactly what StackFrames holds after reset!.  4x less HBM than storing 4-frame stacks
+// (7 GB instead of 28 GB for 2^20 Atari frames); every source frame is read once and written to both stacks.
+constexpr int MAX_STACK = 8;
+
+__global__ __launch_bounds__(256) void gather_stacked_kernel(RingView rb, const int64_t* __restrict__ idx,
+                                                             int64_t batch, int64_t frame_bytes, int n_stack,
+                                                             uint8_t* __restrict__ s, int32_t* __restrict__ a,
+                                                             float* __restrict__ r, uint8_t* __restrict__ term,
+                                                             uint8_t* __restrict__ sn) {
+    __shared__ int64_t l_off[MAX_STACK + 1];
+    __shared__ int l_vs[MAX_STACK + 1], l_vn[MAX_STACK + 1];  // validity as state-stack / next-stack member
+    const int64_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        const int64_t li = idx[b];
+        const int64_t pt = (rb.head_rt + li) % rb.capacity;
+        a[b] = rb.action[pt];
+        r[b] = rb.reward[pt];
+        term[b] = rb.terminal[pt];
+        // frame j (j = 0 .. n_stack) is logical state frame li + 1 - j
+        bool ok_n = true, ok_s = true;
+        for (int j = 0; j <= n_stack; ++j) {
+            const int64_t f = li + 1 - j;
+            if (j >= 1) {  // going one frame further back crosses transition f: stop at an episode boundary
+                const bool exists = f >= 0;
+                const bool boundary = exists && rb.terminal[(rb.head_rt + f) % rb.capacity] != 0;
+                ok_n = ok_n && exists && !boundary;
+                if (j >= 2) ok_s = ok_s && exists && !boundary;
+            }
+            l_vn[j] = (j < n_stack) && ok_n;              // member k = j of the next-state stack
+            l_vs[j] = (j >= 1) && (j == 1 || ok_s);       // member k = j - 1 of the state stack
+            l_off[j] = (f >= 0) ? ((rb.head_sa + f) % (rb.capacity + 1)) * frame_bytes : 0;
+            if (f < 0) {
+                l_vn[j] = 0;
+                l_vs[j] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t n16 = frame_bytes / 16;
+    for (int j = 0; j <= n_stack; ++j) {
+        const bool vn = l_vn[j] != 0, vs = l_vs[j] != 0;
+        const uint4* src = (const uint4*)((const uint8_t*)rb.state + l_off[j]);
+        // stacks are oldest-first (StackFrames: the newest frame is the last slice)
+        uint4* dn = (j < n_stack) ? (uint4*)(sn + (b * n_stack + (n_stack - 1 - j)) * frame_bytes) : nullptr;
+        uint4* ds = (j >= 1) ? (uint4*)(s + (b * n_stack + (n_stack - j)) * frame_bytes) : nullptr;
+        for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if (vn || vs) x = src[i];
+            if (dn) dn[i] = vn ? x : make_uint4(0u, 0u, 0u, 0u);
+            if (ds) ds[i] = vs ? x : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
+// frame = max.(screen1, screen2): the 2-frame max-pool of AtariEnv.act! (RLEnvs/src/environments/3rd_party/
+// atari.jl:104-107), fused into the push so the pooled frame is written once
+__device__ __forceinline__ uint32_t max_u8x4(uint32_t a, uint32_t b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = (a >> (8 * k)) & 0xFFu, y = (b >> (8 * k)) & 0xFFu;
+        o |= (x > y ? x : y) << (8 * k);
+    }
+    return o;
+}
+__global__ __launch_bounds__(256) void maxpool_u8_kernel(uint4* __restrict__ dst, const uint4* __restrict__ s1,
+                                                         const uint4* __restrict__ s2, int64_t n16) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 x = s1[i], y = s2[i];
+        dst[i] = make_uint4(max_u8x4(x.x, y.x), max_u8x4(x.y, y.y), max_u8x4(x.z, y.z), max_u8x4(x.w, y.w));
+    }
+}
+
 static RingView view_of(const rlhip_ring* rb) {
     return {rb->capacity, rb->n_env, rb->obs_dim, rb->head_sa, rb->head_rt,
             rb->state,    rb->action, rb->reward, rb->terminal};
@@ -258,6 +337,67 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb, const int64_t* idx, int64_t batc
     }
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
+}
+
+int32_t rlhip_ring_gather_stacked(const rlhip_ring* rb, const int64_t* idx, int64_t batch, int32_t n_stack, void* s,
+                                  int32_t* a, float* r, uint8_t* term, void* s_next, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && idx && s && a && r && term && s_next && batch >= 0, "bad arguments");
+    RLHIP_REQUIRE(n_stack >= 1 && n_stack <= MAX_STACK, "n_stack must be in 1..8");
+    RLHIP_REQUIRE(rb->n_env == 1, "stack-at-sample gather is defined for single-env frame rings");
+    const int64_t frame_bytes = rb->obs_dim * (int64_t)rb->elem_bytes;
+    RLHIP_REQUIRE(frame_bytes % 16 == 0, "frame size must be a multiple of 16 bytes");
+    RLHIP_REQUIRE(((((uintptr_t)rb->state | (uintptr_t)s | (uintptr_t)s_next) & 15) == 0), "buffers must be 16-byte aligned");
+    if (batch == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(gather_stacked_kernel, dim3((int)batch), dim3(256), 0, as_stream(stream), view_of(rb), idx, batch,
+                       frame_bytes, n_stack, (uint8_t*)s, a, r, term, (uint8_t*)s_next);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+static int32_t maxpool_into_next_state_slot(rlhip_ring* rb, const void* s1, const void* s2, hipStream_t st) {
+    RLHIP_REQUIRE(rb->elem_bytes == 1, "the max-pool push is defined for UInt8 frames");
+    const int64_t frames = rb->capacity + 1;
+    const int64_t fbytes = rb->obs_dim * rb->n_env;
+    RLHIP_REQUIRE(fbytes % 16 == 0 && ((((uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)rb->state) & 15) == 0),
+                  "frames must be 16-byte aligned multiples of 16 bytes");
+    int64_t phys;
+    if (rb->len_sa < frames) {
+        phys = (rb->head_sa + rb->len_sa) % frames;
+        rb->len_sa += 1;
+    } else {
+        phys = rb->head_sa;
+        rb->head_sa = (rb->head_sa + 1) % frames;
+    }
+    const int64_t n16 = fbytes / 16;
+    hipLaunchKernelGGL(maxpool_u8_kernel, dim3(grid_for(n16, 256)), dim3(256), 0, st,
+                       (uint4*)((uint8_t*)rb->state + phys * fbytes), (const uint4*)s1, (const uint4*)s2, n16);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ring_push_state_maxpool(rlhip_ring* rb, const void* screen1, const void* screen2, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && screen1 && screen2, "NULL argument");
+    return maxpool_into_next_state_slot(rb, screen1, screen2, as_stream(stream));
+}
+
+int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb, const void* screen1, const void* screen2,
+                                           const int32_t* action, const float* reward, const uint8_t* terminal,
+                                           rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && screen1 && screen2 && action && reward && terminal, "NULL argument");
+    RLHIP_REQUIRE(rb->elem_bytes == 1, "the max-pool push is defined for UInt8 frames");
+    hipStream_t s = as_stream(stream);
+    int64_t frames = rb->capacity, n = rb->n_env, phys;
+    if (rb->len_rt < frames) {
+        phys = (rb->head_rt + rb->len_rt) % frames;
+        rb->len_rt += 1;
+    } else {
+        phys = rb->head_rt;
+        rb->head_rt = (rb->head_rt + 1) % frames;
+    }
+    hipLaunchKernelGGL(push_art_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, rb->action + phys * n,
+                       rb->reward + phys * n, rb->terminal + phys * n, action, reward, terminal, n);
+    RLHIP_LAUNCH_CHECK();
+    return maxpool_into_next_state_slot(rb, screen1, screen2, s);
 }
 
 }  // extern "C"

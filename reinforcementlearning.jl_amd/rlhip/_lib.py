@@ -156,6 +156,9 @@ _PROTOS = {
     "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
                                   vp, vp]),
     "rlhip_dqn_vec_step_f32": (i32, [vp, vp]),
+    "rlhip_ring_gather_stacked": (i32, [P(Ring), vp, i64, i32, vp, vp, vp, vp, vp, vp]),
+    "rlhip_ring_push_state_maxpool": (i32, [P(Ring), vp, vp, vp]),
+    "rlhip_ring_push_transition_maxpool": (i32, [P(Ring), vp, vp, vp, vp, vp, vp]),
     "rlhip_sumtree_nodes": (i64, [i64]),
     "rlhip_sumtree_fill_range": (i32, [vp, i64, i64, i64, f32, vp]),
     "rlhip_sumtree_update": (i32, [vp, i64, vp, vp, i64, vp]),

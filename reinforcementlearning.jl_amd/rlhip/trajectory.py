@@ -70,6 +70,37 @@ class CircularArraySARTSTraces:
         return s, a, r, t, sn
 
 
+def _gather_stacked(self, idx, n_stack):
+    """traces[inds] with StackFrames applied at sample time (single-env rings of single frames):
+    -> (state (b, n_stack, obs_dim), action0, reward, terminal, next_state), stacks oldest-first."""
+    b, dev = idx.numel(), self.state.device
+    s = torch.empty((b, n_stack, self.obs_dim), dtype=self.dtype, device=dev)
+    sn = torch.empty((b, n_stack, self.obs_dim), dtype=self.dtype, device=dev)
+    a = torch.empty(b, dtype=torch.int32, device=dev)
+    r = torch.empty(b, dtype=torch.float32, device=dev)
+    t = torch.empty(b, dtype=torch.uint8, device=dev)
+    call("rlhip_ring_gather_stacked", C.byref(self.rb), ptr(idx), b, n_stack, ptr(s), ptr(a), ptr(r), ptr(t), ptr(sn),
+         stream_ptr())
+    return s, a, r, t, sn
+
+
+def _push_state_maxpool_(self, screen1, screen2):
+    """push!(traces, (state = max.(screen1, screen2),)) -- AtariEnv's 2-frame max-pool fused into the push"""
+    call("rlhip_ring_push_state_maxpool", C.byref(self.rb), ptr(screen1), ptr(screen2), stream_ptr())
+
+
+def _push_transition_maxpool_(self, screen1, screen2, action0, reward, terminal):
+    if terminal.dtype == torch.bool:
+        terminal = terminal.view(torch.uint8)
+    call("rlhip_ring_push_transition_maxpool", C.byref(self.rb), ptr(screen1), ptr(screen2), ptr(action0),
+         ptr(reward), ptr(terminal), stream_ptr())
+
+
+CircularArraySARTSTraces.gather_stacked = _gather_stacked
+CircularArraySARTSTraces.push_state_maxpool_ = _push_state_maxpool_
+CircularArraySARTSTraces.push_transition_maxpool_ = _push_transition_maxpool_
+
+
 class CircularPrioritizedTraces(CircularArraySARTSTraces):
     """CircularPrioritizedTraces(CircularArraySARTSTraces(...); default_priority): every pushed transition
     enters the device sum-tree with `default_priority`; `traces.set_priority_(keys, p)` is
