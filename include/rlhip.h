@@ -205,6 +205,21 @@ int32_t rlhip_categorical_sample_f32(const float* logits, int64_t na, int64_t n,
                                      uint32_t env_id_base, uint32_t step, int32_t* actions,
                                      float* logp_out, rlhip_stream_t stream);
 
+/* The remaining explorers as batched kernels (BatchExplorer semantics: the inner explorer applied to each column,
+ * RLCore/src/policies/explorers/batch_explorer.jl:14-21).  values / mask addressing as rlhip_eps_greedy_select.
+ *   kind 0  WeightedExplorer{is_normalized}   weighted_explorer.jl:19-33  (mask: weight 0)
+ *   kind 1  WeightedSoftmaxExplorer           weighted_softmax_explorer.jl:21-27  (mask: typemin)
+ *   kind 2  GumbelSoftmaxExplorer             gumbel_softmax_explorer.jl:11-24  (Float32 Gumbel noise)
+ * Draws: Philox(seed, idx = env_id_base + i, t = step, EXPLORE / GUMBEL); na <= 64. */
+int32_t rlhip_explorer_select_f32(int32_t kind, const float* values, int64_t na, int64_t n, int64_t k_stride,
+                                  int64_t i_stride, const uint8_t* mask, int32_t is_normalized, uint64_t seed,
+                                  uint32_t env_id_base, uint32_t step, int32_t* actions, rlhip_stream_t stream);
+/* UCBExplorer  UCB_explorer.jl:24-30: argmax of values + c sqrt(log(step + 1) / counts) with a uniform pick among
+ * ties; action_counts: f64 (na, n) device, counts[k * n + i], initialised to eps (1e-10), incremented here. */
+int32_t rlhip_ucb_select_f32(const float* values, int64_t na, int64_t n, int64_t k_stride, int64_t i_stride,
+                             double c, double* action_counts, int64_t step, uint64_t seed, uint32_t env_id_base,
+                             int32_t* actions, rlhip_stream_t stream);
+
 /* ---------------------------------------------------------------------- parameter updates -- */
 /* TargetNetwork sync: dest = rho * dest + (1 - rho) * src   target_network.jl:76-85 (rho = 0: hard copy) */
 int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlhip_stream_t stream);

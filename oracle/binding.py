@@ -339,6 +339,29 @@ def eps_greedy_select(values, eps, seed, step, env_id_base=0, mask=None, is_brea
     return out
 
 
+def explorer_select(kind, values, seed, step, env_id_base=0, mask=None, is_normalized=False):
+    """kind: 0 / "weighted", 1 / "weighted_softmax", 2 / "gumbel_softmax".  values (na, n).  0-based actions."""
+    kind = {"weighted": 0, "weighted_softmax": 1, "gumbel_softmax": 2}.get(kind, kind)
+    v = np.asfortranarray(np.asarray(values, dtype=np.float32))
+    na, n = v.shape
+    m = None if mask is None else np.asfortranarray(np.asarray(mask, dtype=np.uint8))
+    out = np.empty(n, np.int32)
+    lib().rlo_explorer_select_f32(C.c_int(kind), _p(v), C.c_int64(na), C.c_int64(n), _p(m), C.c_int(int(is_normalized)),
+                                  C.c_uint64(seed), C.c_uint32(env_id_base), C.c_uint32(step), _p(out))
+    return out
+
+
+def ucb_select(values, c, counts, step, seed, env_id_base=0):
+    """values (na, n); counts (na, n) float64 C-contiguous, updated in place.  0-based actions."""
+    v = np.asfortranarray(np.asarray(values, dtype=np.float32))
+    na, n = v.shape
+    assert counts.dtype == np.float64 and counts.shape == (na, n) and counts.flags.c_contiguous
+    out = np.empty(n, np.int32)
+    lib().rlo_ucb_select_f32(_p(v), C.c_int64(na), C.c_int64(n), C.c_double(c), _p(counts), C.c_int64(step),
+                             C.c_uint64(seed), C.c_uint32(env_id_base), _p(out))
+    return out
+
+
 def eps_greedy_prob(values, eps, mask=None, is_break_tie=False):
     v = np.ascontiguousarray(values, dtype=np.float64)
     out = np.empty(len(v), np.float64)

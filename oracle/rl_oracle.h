@@ -199,6 +199,13 @@ float rlo_huber_f32(const float* q, const float* target, int64_t n, float delta,
 void rlo_td_target_f32(const float* qt_next, int64_t na, int64_t n, const float* r,
                        const uint8_t* terminal, float gamma, float* target);
 
+/* remaining explorers (rlo_select.c): kind 0 weighted, 1 weighted-softmax, 2 gumbel-softmax; UCB */
+int rlo_explorer_select_f32(int kind, const float* values, int64_t na, int64_t n, const uint8_t* mask,
+                            int is_normalized, uint64_t seed, uint32_t env_id_base, uint32_t step,
+                            int32_t* actions);
+int rlo_ucb_select_f32(const float* values, int64_t na, int64_t n, double c, double* counts, int64_t step,
+                       uint64_t seed, uint32_t env_id_base, int32_t* actions);
+
 /* ---------------------------------------------------------- replay ring -- */
 /* CircularArraySARTSTraces over a vector env: each slot holds one vec-step (n_env transitions).
  * state is a multiplexed trace of capacity+1 frames (next_state[i] = state[i+1]);

@@ -171,3 +171,111 @@ int rlo_categorical_sample_f32(const float* logits, int64_t na, int64_t n, const
     free(lp);
     return 0;
 }
+
+/* ----------------------------------------------------------------- the remaining explorers --
+ * One column of `values` per env instance (BatchExplorer, RLCore/src/policies/explorers/batch_explorer.jl:14-21).
+ *   kind 0  WeightedExplorer{is_normalized}   weighted_explorer.jl:19-33: sample(rng, Weights(values[, 1]));
+ *           masked: values[.!mask] .= 0.  StatsBase.sample(rng, wv) (un-vendored; published algorithm):
+ *               t = rand(rng) * sum(wv); i = 1; cw = wv[1]; while cw < t && i < n: i += 1; cw += wv[i]
+ *   kind 1  WeightedSoftmaxExplorer           weighted_softmax_explorer.jl:21-27: Weights(softmax(values), 1);
+ *           masked: values[.!mask] .= typemin(T)
+ *   kind 2  GumbelSoftmaxExplorer             gumbel_softmax_explorer.jl:11-24:
+ *           argmax(logsoftmax(v) .- log.(-log.(rand(rng, T, n))))  in T = Float32
+ * values (na x n) column-major: values[k + na * i].  exp / log in Float64, rounded once. */
+int rlo_explorer_select_f32(int kind, const float* values, int64_t na, int64_t n, const uint8_t* mask,
+                            int is_normalized, uint64_t seed, uint32_t env_id_base, uint32_t step,
+                            int32_t* actions) {
+    float* w = (float*)malloc(sizeof(float) * (size_t)na);
+    if (!w) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* v = values + i * na;
+        const uint8_t* mk = mask ? mask + i * na : 0;
+        uint32_t id = env_id_base + (uint32_t)i;
+        if (kind == 0 || kind == 1) {
+            float sum = 1.0f;
+            if (kind == 0) {
+                float acc = 0.0f;
+                for (int64_t k = 0; k < na; ++k) {
+                    w[k] = (mk && !mk[k]) ? 0.0f : v[k];
+                    acc += w[k];
+                }
+                if (!is_normalized) sum = acc;
+            } else {
+                float mx = -INFINITY;
+                for (int64_t k = 0; k < na; ++k) {
+                    w[k] = (mk && !mk[k]) ? -INFINITY : v[k];
+                    if (w[k] > mx) mx = w[k];
+                }
+                float se = 0.0f;
+                for (int64_t k = 0; k < na; ++k) {
+                    w[k] = (float)exp((double)(w[k] - mx));
+                    se += w[k];
+                }
+                for (int64_t k = 0; k < na; ++k) w[k] = w[k] / se;
+            }
+            uint32_t r[4];
+            rlo_philox4x32_10(seed, id, 0, step, RLO_TAG_EXPLORE, r);
+            double t = rlo_u01_f64(r[0], r[1]) * (double)sum;
+            int64_t a = 0;
+            float cw = w[0];
+            while ((double)cw < t && a < na - 1) {
+                ++a;
+                cw += w[a];
+            }
+            actions[i] = (int32_t)a;
+        } else {
+            float mx = -INFINITY;
+            for (int64_t k = 0; k < na; ++k) {
+                w[k] = (mk && !mk[k]) ? -INFINITY : v[k];
+                if (w[k] > mx) mx = w[k];
+            }
+            float se = 0.0f;
+            for (int64_t k = 0; k < na; ++k) se += (float)exp((double)(w[k] - mx));
+            float lse = (float)log((double)se);
+            int64_t best = 0;
+            float bg = 0.0f;
+            uint32_t r[4] = {0, 0, 0, 0};
+            for (int64_t k = 0; k < na; ++k) {
+                if ((k & 3) == 0) rlo_philox4x32_10(seed, id, 0x8000u + (uint32_t)(k >> 2), step, RLO_TAG_GUMBEL, r);
+                float u = rlo_u01_f32(r[k & 3]);
+                float logit = (w[k] - mx) - lse;
+                float inner = (float)log((double)u);
+                float gum = (float)log((double)(-inner));
+                float g = logit - gum;
+                if (k == 0 || g > bg || (isnan(g) && !isnan(bg))) {
+                    bg = g;
+                    best = k;
+                }
+            }
+            actions[i] = (int32_t)best;
+        }
+    }
+    free(w);
+    return 0;
+}
+
+/* UCBExplorer  UCB_explorer.jl:24-30.  counts (na x n): counts[k * n + i] (one counter set per env instance),
+ * initialised by the caller to eps = 1e-10 (:21-22); tie-break rand(rng, inds) = randint(word 0, #ties). */
+int rlo_ucb_select_f32(const float* values, int64_t na, int64_t n, double c, double* counts, int64_t step,
+                       uint64_t seed, uint32_t env_id_base, int32_t* actions) {
+    double* x = (double*)malloc(sizeof(double) * (size_t)na);
+    int64_t* inds = (int64_t*)malloc(sizeof(int64_t) * (size_t)na);
+    if (!x || !inds) return -1;
+    double lg = log((double)(step + 1));
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t k = 0; k < na; ++k) x[k] = (double)values[k + na * i] + c * sqrt(lg / counts[k * n + i]);
+        double vmax;
+        int64_t cnt = rlo_find_all_max_f64(x, na, 0, &vmax, inds);
+        int64_t a = 0;
+        if (cnt > 0) {
+            uint32_t r[4];
+            rlo_philox4x32_10(seed, env_id_base + (uint32_t)i, 0, (uint32_t)step, RLO_TAG_EXPLORE, r);
+            a = inds[rlo_randint(r[0], (uint32_t)cnt)];
+        }
+        counts[a * n + i] += 1.0;
+        actions[i] = (int32_t)a;
+    }
+    free(x);
+    free(inds);
+    return 0;
+}

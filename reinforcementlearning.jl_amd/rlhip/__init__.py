@@ -12,6 +12,8 @@ from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DoEveryNSteps, Emp
                    run_fused_dqn, run_fused_ppo)
 from .dqn import (DQNLearner, EpsilonGreedyExplorer, GreedyExplorer, HipApproximator,  # noqa: F401
                   QBasedPolicy, TargetNetwork)
+from .explorers import (BatchExplorer, GumbelSoftmaxExplorer, UCBExplorer, WeightedExplorer,  # noqa: F401
+                        WeightedSoftmaxExplorer)
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
 from .trajectory import (BatchSampler, CircularArraySARTSTraces, CircularPrioritizedTraces,  # noqa: F401
                          InsertSampleRatioController, Trajectory)
