@@ -295,6 +295,22 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
 
+/* ------------------------------------------------------- device-side episode hooks -- */
+/* TotalRewardPerEpisode / BatchStepsPerEpisode / StepsPerEpisode (RLCore/src/core/hooks.jl:64-101, 146-196,
+ * 202-231) without a per-step host read: one launch per vec-step (PostActStage) updates the per-instance
+ * (steps, return) accumulators and appends one record per finished episode to a device log.
+ * log_count keeps counting past log_capacity (records beyond it are dropped; the host can detect that). */
+typedef struct {
+    uint32_t vec_step; /* the vec-step in which the episode ended */
+    uint32_t env;      /* instance index */
+    int32_t steps;     /* episode length */
+    int32_t pad;
+    double total_reward;
+} rlhip_episode_record;
+int32_t rlhip_hook_episode_stats(const float* reward, const uint8_t* done, int64_t n, uint32_t vec_step,
+                                 int32_t* steps_acc, double* return_acc, rlhip_episode_record* log,
+                                 uint32_t log_capacity, uint32_t* log_count, rlhip_stream_t stream);
+
 /* --------------------------------------- frame stacking at sample time, max-pool push -- */
 /* StackFrames (RLCore/src/utils/stack_frames.jl:11-44) moved from the way in to the way out: the ring stores
  * single frames (n_env == 1), the gather assembles the n_stack-deep observations

@@ -6,7 +6,7 @@ from . import _lib  # noqa: F401  (raises ImportError when librlhip.so is absent
 from ._lib import RLHipArgumentError, RLHipError  # noqa: F401
 from .envs import (CartPoleEnv, ContinuousMountainCarEnv, HipVecEnv, MountainCarEnv,  # noqa: F401
                    PendulumEnv, Space)
-from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DoEveryNSteps, EmptyHook,  # noqa: F401
+from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DeviceEpisodeStats, DoEveryNSteps, EmptyHook,  # noqa: F401
                    PPOAgent, RandomPolicy, StepsPerEpisode, StopAfterNEpisodes, StopAfterNSeconds,
                    StopAfterNSteps, StopIfAll, StopIfAny, TimePerStep, TotalBatchRewardPerEpisode, run,
                    run_fused_dqn, run_fused_ppo)

@@ -156,6 +156,7 @@ _PROTOS = {
     "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
                                   vp, vp]),
     "rlhip_dqn_vec_step_f32": (i32, [vp, vp]),
+    "rlhip_hook_episode_stats": (i32, [vp, vp, i64, u32, vp, vp, vp, u32, vp, vp]),
     "rlhip_explorer_select_f32": (i32, [i32, vp, i64, i64, i64, i64, vp, i32, u64, u32, u32, vp, vp]),
     "rlhip_ucb_select_f32": (i32, [vp, i64, i64, i64, i64, f64, vp, i64, u64, u32, vp, vp]),
     "rlhip_ring_gather_stacked": (i32, [P(Ring), vp, i64, i32, vp, vp, vp, vp, vp, vp]),

@@ -142,6 +142,61 @@ class TotalBatchRewardPerEpisode(EmptyHook):
             self.reward[t] = 0
 
 
+class DeviceEpisodeStats(EmptyHook):
+    """TotalRewardPerEpisode + BatchStepsPerEpisode (hooks.jl:146-231) with the accumulators and the finished-episode
+    log on the device (hooks.hip): `push_` is one kernel launch and never synchronises; `.steps[i]` / `.rewards[i]`
+    (lists per env instance, as the reference hooks expose them) are materialised from the device log on access."""
+
+    def __init__(self, batchsize, log_capacity=1 << 20, device="cuda"):
+        import numpy as np
+
+        self.n, self.cap, self.vec_step = int(batchsize), int(log_capacity), 0
+        self._steps_acc = torch.zeros(self.n, dtype=torch.int32, device=device)
+        self._ret_acc = torch.zeros(self.n, dtype=torch.float64, device=device)
+        self._log = torch.zeros((self.cap, 3), dtype=torch.int64, device=device)  # 24-byte records
+        self._count = torch.zeros(1, dtype=torch.int32, device=device)
+        self._np = np
+
+    def push_(self, stage, policy, env):
+        if stage != POST_ACT_STAGE:
+            return
+        from ._lib import call
+        from .ops import ptr, stream_ptr
+
+        r = env.reward()
+        if r.dtype != torch.float32:
+            r = r.to(torch.float32)
+        call("rlhip_hook_episode_stats", ptr(r), ptr(env._done), self.n, self.vec_step, ptr(self._steps_acc),
+             ptr(self._ret_acc), ptr(self._log), self.cap, ptr(self._count), stream_ptr())
+        self.vec_step += 1
+
+    def records(self):
+        """finished episodes as a structured numpy array sorted by (vec_step, env)"""
+        np = self._np
+        count = int(self._count.item())
+        if count > self.cap:
+            raise OverflowError(f"episode log overflow: {count} episodes finished, capacity {self.cap}")
+        dt = np.dtype([("vec_step", np.uint32), ("env", np.uint32), ("steps", np.int32), ("pad", np.int32),
+                       ("total_reward", np.float64)])
+        rec = self._log[:count].cpu().numpy().view(dt).reshape(-1)
+        return np.sort(rec, order=["vec_step", "env"])
+
+    @property
+    def steps(self):
+        out = [[] for _ in range(self.n)]
+        for e, s in zip(self.records()["env"].tolist(), self.records()["steps"].tolist()):
+            out[e].append(s)
+        return out
+
+    @property
+    def rewards(self):
+        rec = self.records()
+        out = [[] for _ in range(self.n)]
+        for e, v in zip(rec["env"].tolist(), rec["total_reward"].tolist()):
+            out[e].append(v)
+        return out
+
+
 class StepsPerEpisode(EmptyHook):
     """StepsPerEpisode  hooks.jl:64-101, for a single-instance env (n_envs = 1)."""
 

@@ -187,3 +187,25 @@ def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, ki
     rlhip.run(a2, e2, rlhip.StopAfterNSteps(5))
     torch.cuda.synchronize()
     assert torch.equal(n1.params, n2.params) and torch.equal(tr1.state, tr2.state)
+
+
+def test_device_episode_stats_hook_matches_host_hooks():
+    """DeviceEpisodeStats (hooks.hip: no per-step sync) against the host-side BatchStepsPerEpisode /
+    TotalBatchRewardPerEpisode hooks on the same run."""
+    import rlhip
+
+    n = 300
+    env = rlhip.CartPoleEnv(n, seed=8)
+    pol = rlhip.RandomPolicy(env.action_space(), seed=8)
+    dev_hook = rlhip.DeviceEpisodeStats(n)
+    h_steps, h_rew = rlhip.BatchStepsPerEpisode(n), rlhip.TotalBatchRewardPerEpisode(n)
+    rlhip.run(pol, env, rlhip.StopAfterNSteps(120), rlhip.ComposedHook(dev_hook, h_steps, h_rew))
+    assert sum(len(s) for s in h_steps.steps) > n  # random CartPole episodes last ~20 steps
+    assert dev_hook.steps == h_steps.steps
+    assert dev_hook.rewards == h_rew.rewards
+    rec = dev_hook.records()
+    assert (rec["steps"] > 0).all() and (np.diff(rec["vec_step"].astype(np.int64)) >= 0).all()
+    small = rlhip.DeviceEpisodeStats(n, log_capacity=4)
+    rlhip.run(pol, env, rlhip.StopAfterNSteps(60), small)
+    with pytest.raises(OverflowError):
+        small.records()
