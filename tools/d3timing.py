@@ -1,6 +1,6 @@
 """phase timestamps of one dqn3_grad tile (build with RLHIP_EXTRA_FLAGS=-DRLHIP_D3_TIMING)"""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "reinforcementlearning.jl_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reinforcementlearning.jl_amd"))
 import torch, rlhip
 from rlhip import dqn
 ns, na, H = 4, 2, 128

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/reinforcementlearning.jl_amd"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reinforcementlearning.jl_amd")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch, oracle, rlhip
 from rlhip import dqn
 import test_gpu_dqn3 as T

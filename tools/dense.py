@@ -1,7 +1,7 @@
 """timing of the dense MFMA kernels (dev tool)"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "reinforcementlearning.jl_amd"))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reinforcementlearning.jl_amd"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rlhip
 from rlhip import ops
 from rlhip.ops import stream_ptr

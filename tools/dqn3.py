@@ -1,10 +1,10 @@
 """timing of the 3-layer MFMA DQN kernels (dev tool)"""
 import ctypes as C, sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "reinforcementlearning.jl_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reinforcementlearning.jl_amd"))
 import torch, rlhip
 from rlhip import dqn
 from rlhip.ops import stream_ptr
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import event_time_ms
 
 ns, na, H = 4, 2, 128

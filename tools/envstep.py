@@ -1,6 +1,6 @@
 """CartPole env-step kernel at 2^24 envs, 20 launches (for rocprofv3 PMC traffic passes)."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "reinforcementlearning.jl_amd"))
 import torch, rlhip
 from rlhip._lib import call

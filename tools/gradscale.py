@@ -1,6 +1,6 @@
 """grad kernel time vs problem size (HIP events)."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "reinforcementlearning.jl_amd")); sys.path.insert(0, ROOT)
 import torch, rlhip
 from bench import event_time_ms

@@ -1,7 +1,7 @@
 """Phase timeline of ppo_grad_kernel (debug stamps; run with RLHIP_GRAD_DEBUG=1 on the GPU box)."""
 import os, sys
 os.environ["RLHIP_GRAD_DEBUG"] = "1"
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "reinforcementlearning.jl_amd"))
 import ctypes as C
 import numpy as np, torch, rlhip

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <script.py> <counters...>   -- rocprofv3 PMC pass (kernel-trace only) -> per-kernel mean counters
+# usage: tools/pmc.sh <tag> <script.py> <counters...>   -- rocprofv3 PMC pass (kernel-trace only) -> per-kernel mean counters
 tag=$1; script=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/$script > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [bench args...]  -- rocprofv3 kernel-trace stats of bench.py into gpurun_out/prof_<tag>
+# usage: tools/prof.sh <tag> [bench args...]  -- rocprofv3 kernel-trace stats of bench.py into gpurun_out/prof_<tag>
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o bench -- python $GRAFT_REPO_ROOT/bench.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof_cmd.sh <tag> <python script> [args...] -- rocprofv3 kernel-trace stats of any script
+# usage: tools/prof_cmd.sh <tag> <python script> [args...] -- rocprofv3 kernel-trace stats of any script
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o run -- python $GRAFT_REPO_ROOT/"$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1

@@ -1,6 +1,6 @@
 """Unfused sequence grad -> reduce(no apply) -> clip_adam, for kernel-level comparison under rocprofv3."""
 import os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "reinforcementlearning.jl_amd"))
 import torch, rlhip
 env = rlhip.HipVecEnv("cartpole", 4096, seed=1)
