@@ -487,7 +487,23 @@ struct ApplyArgs {
 // global norm from the per-block partials, clips, and runs Adam on all parameters -- one launch instead
 // of reduce + clip_adam.
 constexpr int RP = 64;  // parameters per reduce workgroup (x 16 partial-groups = 1024 threads)
-template <bool APPLY>
+constexpr int APPLY_NONE = 0, APPLY_LAST = 1, APPLY_GRID = 2;
+constexpr int GRID_APPLY_MAX_BLOCKS = 128;  // all workgroups must be co-resident for the spin barrier (256 CUs x 2)
+
+// position of flat parameter q in the unit-record copy (see pack_records)
+__device__ __forceinline__ int64_t record_slot(int64_t q, int h, int ns, int nout, int64_t np_a) {
+    const int net = q >= np_a ? 1 : 0;
+    const int64_t r = q - (net ? np_a : 0);
+    const int no = net ? 1 : nout;
+    const int64_t base = 8 * (int64_t)net * h;
+    if (r < (int64_t)h * ns) return base + 8 * (r % h) + (r / h);               // W1[j + h k] -> rec[j][k]
+    if (r < (int64_t)h * ns + h) return base + 8 * (r - (int64_t)h * ns) + 4;   // b1[j]       -> rec[j][4]
+    const int64_t w = r - ((int64_t)h * ns + h);
+    if (w < (int64_t)no * h) return base + 8 * (w / no) + 5 + (w % no);         // W2[o + no j] -> rec[j][5 + o]
+    return 16 * (int64_t)h + (net ? 3 : (w - (int64_t)no * h));                 // output biases -> tail
+}
+
+template <int APPLY>
 __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restrict__ partials,
                                                             const float* __restrict__ loss_partials, int nb,
                                                             int np, float* __restrict__ grad,
@@ -542,7 +558,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             losses[3] = ent_loss;
         }
     }
-    if (!APPLY) return;
+    if (APPLY == APPLY_NONE) return;
 
     // per-block partial sum of squares (threads 0..RP-1 of wave 0 hold this block's gradient values)
     if (wv == 0) {
@@ -550,6 +566,59 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
         if (lane == 0) ap.sumsq[blockIdx.x] = sq;
+    }
+    if (APPLY == APPLY_GRID) {
+        // ---- every workgroup applies Adam to ITS OWN 64 parameters after a grid-wide barrier on the norm ----
+        // All workgroups are co-resident (host guarantees gridDim <= GRID_APPLY_MAX_BLOCKS), so a spin barrier on an
+        // agent-scope counter is safe.  Only wave 0 (which holds the 64 reduced gradient values in registers)
+        // continues; the other 15 waves are done.  The serial tail of the last-arriver variant (one workgroup running
+        // Adam over all np parameters + re-packing every record) becomes 53 parallel 64-lane updates.
+        if (wv != 0) return;
+        const bool own = p < np;
+        // operands of this lane's parameter do not depend on the barrier: issue the loads first
+        const float m0 = own ? ap.m[p] : 0.0f, v0 = own ? ap.v[p] : 0.0f, p0 = own ? ap.params[p] : 0.0f;
+        const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(ap.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double part = 0.0;  // same summation order in every workgroup -> the same norm, bit for bit
+        for (int b = lane; b < (int)gridDim.x; b += 64)
+            part += __hip_atomic_load(ap.sumsq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        const float gn = (float)sqrt(part);
+        const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+        if (own) {
+            float g1 = gsum;
+            if (scale != 1.0f) g1 *= scale;
+            const float mi = ap.b1 * m0 + (1.0f - ap.b1) * g1;  // Optimisers.Adam, expression order of optim.hip adam1
+            const float vi = ap.b2 * v0 + (1.0f - ap.b2) * (g1 * g1);
+            const float d = mi / c1 / (sqrtf(vi / c2) + ap.eps) * ap.lr;
+            const float pn = p0 - d;
+            ap.m[p] = mi;
+            ap.v[p] = vi;
+            ap.params[p] = pn;
+            grad[p] = g1;
+            ap.packed[record_slot(p, ap.h, ap.ns, ap.nout, ap.np_a)] = pn;
+        }
+        // departure: the last workgroup out re-arms both counters and advances the running beta powers (every
+        // workgroup has read beta_pow above, before its departure increment)
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1) {
+                ap.beta_pow[0] *= ap.b1;
+                ap.beta_pow[1] *= ap.b2;
+                __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
     }
     // publish: plain stores -> barrier -> one lane: agent-scope release, drain, counter increment
     __syncthreads();
@@ -577,17 +646,35 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
     const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
     const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
     __syncthreads();  // every thread has read beta_pow
-    for (int q = threadIdx.x; q < np; q += blockDim.x) {
-        float gi = __hip_atomic_load(grad + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (scale != 1.0f) gi *= scale;
-        // Optimisers.Adam (same expression order as optim.hip adam1)
-        const float mi = ap.b1 * ap.m[q] + (1.0f - ap.b1) * gi;
-        const float vi = ap.b2 * ap.v[q] + (1.0f - ap.b2) * (gi * gi);
-        ap.m[q] = mi;
-        ap.v[q] = vi;
-        const float d = mi / c1 / (sqrtf(vi / c2) + ap.eps) * ap.lr;
-        ap.params[q] = ap.params[q] - d;
-        grad[q] = gi;
+    // four parameters per thread per trip, all 16 loads issued before the first dependent instruction: with
+    // np = 3331 the whole Adam step is one memory round trip instead of four
+    constexpr int U = 4;
+    for (int q0 = threadIdx.x; q0 < np; q0 += (int)blockDim.x * U) {
+        float gi[U], mm[U], vv[U], pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * (int)blockDim.x;
+            const bool in = q < np;
+            gi[u] = in ? __hip_atomic_load(grad + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            mm[u] = in ? ap.m[q] : 0.0f;
+            vv[u] = in ? ap.v[q] : 0.0f;
+            pp[u] = in ? ap.params[q] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * (int)blockDim.x;
+            if (q >= np) continue;
+            float g1 = gi[u];
+            if (scale != 1.0f) g1 *= scale;
+            // Optimisers.Adam (same expression order as optim.hip adam1)
+            const float mi = ap.b1 * mm[u] + (1.0f - ap.b1) * g1;
+            const float vi = ap.b2 * vv[u] + (1.0f - ap.b2) * (g1 * g1);
+            ap.m[q] = mi;
+            ap.v[q] = vi;
+            const float d = mi / c1 / (sqrtf(vi / c2) + ap.eps) * ap.lr;
+            ap.params[q] = pp[u] - d;
+            grad[q] = g1;
+        }
     }
     __syncthreads();  // this workgroup's parameter stores are visible to its own later loads
     pack_records(ap.params, ap.packed, ap.h, ap.ns, ap.nout, ap.np_a, threadIdx.x, blockDim.x);
@@ -722,7 +809,7 @@ static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int
     launch_pack(L, s);
     launch_grad(L, s);
     ApplyArgs ap{};
-    hipLaunchKernelGGL((reduce_apply_kernel<false>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
+    hipLaunchKernelGGL((reduce_apply_kernel<APPLY_NONE>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
                        L.g.loss_partials, L.nb, (int)L.np, grad_out, losses_out, L.g.wa, L.g.wc, L.g.we, L.g.inv_b,
                        ap);
     RLHIP_LAUNCH_CHECK();
@@ -768,9 +855,15 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             launch_grad(L, s);
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                          L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
-            hipLaunchKernelGGL((reduce_apply_kernel<true>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s,
-                               L.g.partials, L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa,
-                               L.g.wc, L.g.we, L.g.inv_b, ap);
+            const int rblocks = (int)((L.np + RP - 1) / RP);
+            if (rblocks <= GRID_APPLY_MAX_BLOCKS && !getenv("RLHIP_APPLY_LAST_ARRIVER"))
+                hipLaunchKernelGGL((reduce_apply_kernel<APPLY_GRID>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
+                                   L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
+                                   L.g.inv_b, ap);
+            else
+                hipLaunchKernelGGL((reduce_apply_kernel<APPLY_LAST>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
+                                   L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
+                                   L.g.inv_b, ap);
         }
     }
     RLHIP_LAUNCH_CHECK();
