@@ -56,7 +56,7 @@ class PPOCfg(C.Structure):
                                          "actor_loss_weight", "critic_loss_weight",
                                          "entropy_loss_weight", "lr", "beta1", "beta2", "adam_eps")] + \
                [(n, C.c_int32) for n in ("n_epochs", "n_microbatches", "hidden", "act", "continuous",
-                                         "normalize_advantage")]
+                                         "normalize_advantage", "layers")]
 
 
 class PPOTrajC(C.Structure):

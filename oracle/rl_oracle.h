@@ -245,6 +245,13 @@ int64_t rlo_mlp3_nparams(int64_t ns, int64_t h, int64_t na);
 void rlo_mlp3_init_f32(float* p, int64_t ns, int64_t h, int64_t na, uint64_t seed, uint32_t net_id);
 void rlo_mlp3_forward_f32(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x,
                           int64_t batch, float* out);
+/* single-sample forward / backward of the 3-layer bf16 network (shared with the PPO oracle, rlo_learn.c).
+ * caches: 4 h floats z1 | h1 | z2 | h2; scratch: dz2b (h floats), dh1 (h doubles); ga: Float64 accumulators */
+void rlo_mlp3_forward1(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x, int64_t xstride,
+                       float* out, int64_t ostride, float* z1, float* h1, float* z2, float* h2);
+void rlo_mlp3_backward1(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x, int64_t xstride,
+                        const float* dout, double* ga, const float* z1, const float* h1, const float* z2,
+                        const float* h2, float* dz2b, double* dh1);
 float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
                              const float* target_params, const float* s, const int32_t* a, const float* r,
                              const uint8_t* term, const float* s_next, int64_t b, float gamma, float huber_delta,
@@ -296,6 +303,7 @@ typedef struct {
     int32_t hidden, act;   /* hidden width of actor and critic, activation */
     int32_t continuous;    /* 0: categorical actor (na logits); 1: gaussian actor (mu, log sigma), 1-D */
     int32_t normalize_advantage;
+    int32_t layers; /* 2 (default, 0 also means 2): ns -> h -> nout; 3: ns -> 128 -> 128 -> nout, bf16 hidden layer */
 } rlo_ppo_cfg;
 void rlo_ppo_default(rlo_ppo_cfg* c);
 

@@ -143,14 +143,40 @@ void rlo_ppo_default(rlo_ppo_cfg* c) {
     c->act = 0;
     c->continuous = 0;
     c->normalize_advantage = 0;
+    c->layers = 2;
 }
 
 static int64_t ppo_actor_nout(const rlo_ppo_cfg* c, int64_t na) { return c->continuous ? 2 * na : na; }
 
+/* actor / critic network of the PPO policy: cfg.layers = 2 (ns -> h -> nout, f32) or 3 (ns -> 128 -> 128 -> nout with
+ * the bf16 hidden layer of rlo_mlp3.c).  Scratch per sample: NET_SCRATCH(h) floats + h doubles. */
+#define NET_SCRATCH(h) (5 * (h))
+static int net_layers(const rlo_ppo_cfg* c) { return c->layers == 3 ? 3 : 2; }
+static int64_t net_nparams(const rlo_ppo_cfg* c, int64_t ns, int64_t nout) {
+    return net_layers(c) == 3 ? rlo_mlp3_nparams(ns, c->hidden, nout) : rlo_mlp2_nparams(ns, c->hidden, nout);
+}
+static void net_forward1(const rlo_ppo_cfg* c, const float* p, int64_t ns, int64_t nout, const float* x,
+                         int64_t xstride, float* out, float* scr) {
+    int64_t h = c->hidden;
+    if (net_layers(c) == 3)
+        rlo_mlp3_forward1(p, ns, h, nout, c->act, x, xstride, out, 1, scr, scr + h, scr + 2 * h, scr + 3 * h);
+    else
+        mlp2_forward1(p, ns, h, nout, c->act, x, xstride, out, 1, scr, scr + h);
+}
+static void net_backward1(const rlo_ppo_cfg* c, const float* p, int64_t ns, int64_t nout, const float* x,
+                          int64_t xstride, const float* dout, double* ga, float* scr, double* dscr) {
+    int64_t h = c->hidden;
+    if (net_layers(c) == 3)
+        rlo_mlp3_backward1(p, ns, h, nout, c->act, x, xstride, dout, ga, scr, scr + h, scr + 2 * h, scr + 3 * h,
+                           scr + 4 * h, dscr);
+    else
+        mlp2_backward1(p, ns, h, nout, c->act, x, xstride, dout, 1, ga, scr, scr + h);
+}
+
 int64_t rlo_ppo_nparams(int kind, const rlo_ppo_cfg* c) {
     int64_t ns = rlo_env_obs_dim(kind);
     int64_t na = (kind == 0) ? 2 : (kind == 1 ? (c->continuous ? 1 : 3) : (c->continuous ? 1 : 3));
-    return rlo_mlp2_nparams(ns, c->hidden, ppo_actor_nout(c, na)) + rlo_mlp2_nparams(ns, c->hidden, 1);
+    return net_nparams(c, ns, ppo_actor_nout(c, na)) + net_nparams(c, ns, 1);
 }
 
 static inline float log2pi_f32(void) { return logf(6.2831855f); }
@@ -163,9 +189,10 @@ static void ppo_sample(const rlo_ppo_cfg* c, int64_t ns, int64_t na, int64_t h, 
                        double* critic_acc_p, double* ent_acc_p) {
     float out[64], dout[64];
     double actor_acc = 0, critic_acc = 0, ent_acc = 0;
+    (void)h;
     {
         /* ---- actor ---- */
-        mlp2_forward1(pa, ns, h, nout_a, c->act, obs + i, bm, out, 1, hid, zb);
+        net_forward1(c, pa, ns, nout_a, obs + i, bm, out, hid);
         float lp_old = logp_old[i] < min_logp ? min_logp : logp_old[i];
         float lp_new, ent;
         if (!c->continuous) {
@@ -231,14 +258,14 @@ static void ppo_sample(const rlo_ppo_cfg* c, int64_t ns, int64_t na, int64_t h, 
             }
         }
         ent_acc += (double)ent;
-        mlp2_backward1(pa, ns, h, nout_a, c->act, obs + i, bm, dout, 1, ga, hid, zb);
+        net_backward1(c, pa, ns, nout_a, obs + i, bm, dout, ga, hid, (double*)zb);
         /* ---- critic ---- */
         float v;
-        mlp2_forward1(pc, ns, h, 1, c->act, obs + i, bm, &v, 1, hid, zb);
+        net_forward1(c, pc, ns, 1, obs + i, bm, &v, hid);
         float dv = ret[i] - v;
         critic_acc += (double)(dv * dv);
         float dvout = -2.0f * c->critic_loss_weight * inv_b * dv;
-        mlp2_backward1(pc, ns, h, 1, c->act, obs + i, bm, &dvout, 1, ga + np_a, hid, zb);
+        net_backward1(c, pc, ns, 1, obs + i, bm, &dvout, ga + np_a, hid, (double*)zb);
     }
     *actor_acc_p += actor_acc;
     *critic_acc_p += critic_acc;
@@ -251,13 +278,14 @@ void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const f
                            float* grad, float* losses_out) {
     int64_t h = c->hidden;
     int64_t nout_a = ppo_actor_nout(c, na);
-    int64_t np_a = rlo_mlp2_nparams(ns, h, nout_a);
-    int64_t np_c = rlo_mlp2_nparams(ns, h, 1);
+    int64_t np_a = net_nparams(c, ns, nout_a);
+    int64_t np_c = net_nparams(c, ns, 1);
     const float* pa = params;
     const float* pc = params + np_a;
     double* ga = (double*)calloc((size_t)(np_a + np_c), sizeof(double));
-    float* hid = (float*)malloc(sizeof(float) * (size_t)h * 2);
-    float* zb = hid + h;
+    /* per-sample scratch: NET_SCRATCH(h) floats of caches, then h doubles (3-layer backward) */
+    float* hid = (float*)malloc(sizeof(float) * (size_t)NET_SCRATCH(h) + sizeof(double) * (size_t)h);
+    float* zb = hid + NET_SCRATCH(h);
     float* adv = (float*)malloc(sizeof(float) * (size_t)bm);
     memcpy(adv, adv_in, sizeof(float) * (size_t)bm);
     if (c->normalize_advantage) { /* (A - mean) / clamp(std, 1e-8, 1000) with the corrected std */
@@ -287,11 +315,11 @@ void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const f
         {
             int tid = omp_get_thread_num();
             int64_t i0 = bm * tid / nthr, i1 = bm * (tid + 1) / nthr;
-            float* hid_t = (float*)malloc(sizeof(float) * (size_t)h * 2);
+            float* hid_t = (float*)malloc(sizeof(float) * (size_t)NET_SCRATCH(h) + sizeof(double) * (size_t)h);
             double aa = 0, ca = 0, ea = 0;
             for (int64_t i = i0; i < i1; ++i)
                 ppo_sample(c, ns, na, h, nout_a, np_a, pa, pc, obs, act_i, act_f, logp_old, adv, ret, bm, i, lo, hi,
-                           inv_b, min_logp, gt + (size_t)npar * tid, hid_t, hid_t + h, &aa, &ca, &ea);
+                           inv_b, min_logp, gt + (size_t)npar * tid, hid_t, hid_t + NET_SCRATCH(h), &aa, &ca, &ea);
             accs[3 * tid] = aa;
             accs[3 * tid + 1] = ca;
             accs[3 * tid + 2] = ea;
@@ -374,9 +402,8 @@ int rlo_ppo_rollout_f32(int kind, const void* env_cfg, rlo_env_state* st, int64_
                         uint32_t env_id_base, uint32_t vec_step0, rlo_ppo_traj* tr) {
     int64_t ns = rlo_env_obs_dim(kind);
     int64_t na = env_na(kind, c);
-    int64_t h = c->hidden;
     int64_t nout_a = ppo_actor_nout(c, na);
-    int64_t np_a = rlo_mlp2_nparams(ns, h, nout_a);
+    int64_t np_a = net_nparams(c, ns, nout_a);
     const float* pa = params;
     const float* pc = params + np_a;
     for (int64_t t = 0; t <= T; ++t) {
@@ -385,13 +412,16 @@ int rlo_ppo_rollout_f32(int kind, const void* env_cfg, rlo_env_state* st, int64_
         /* env instances are independent: the loops over i run on all cores in the -fopenmp baseline build
          * (bit-identical results: nothing is reduced across instances) */
 #pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < n; ++i)
-            mlp2_forward1(pc, ns, h, 1, c->act, obs_t + i, n, tr->value + t * n + i, 1, 0, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            float scr[NET_SCRATCH(256)];
+            net_forward1(c, pc, ns, 1, obs_t + i, n, tr->value + t * n + i, scr);
+        }
         if (t == T) break;
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < n; ++i) {
             float out[64];
-            mlp2_forward1(pa, ns, h, nout_a, c->act, obs_t + i, n, out, 1, 0, 0);
+            float scr[NET_SCRATCH(256)];
+            net_forward1(c, pa, ns, nout_a, obs_t + i, n, out, scr);
             if (!c->continuous) {
                 rlo_categorical_sample_f32(out, na, 1, 0, seed, env_id_base + (uint32_t)i,
                                            vec_step0 + (uint32_t)t, tr->action_i + t * n + i,

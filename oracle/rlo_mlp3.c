@@ -72,7 +72,7 @@ static mlp3_view view3(const float* p, int64_t ns, int64_t h, int64_t na) {
 }
 
 /* caches (each h floats, may be NULL together): z1, h1 (f32), z2, h2 */
-static void mlp3_forward1(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x,
+void rlo_mlp3_forward1(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x,
                           int64_t xstride, float* out, int64_t ostride, float* z1, float* h1, float* z2, float* h2) {
     mlp3_view v = view3(p, ns, h, na);
     for (int64_t j = 0; j < h; ++j) {
@@ -98,11 +98,11 @@ void rlo_mlp3_forward_f32(const float* p, int64_t ns, int64_t h, int64_t na, int
                           int64_t batch, float* out) {
     float* buf = (float*)malloc(sizeof(float) * (size_t)h * 4);
     for (int64_t i = 0; i < batch; ++i)
-        mlp3_forward1(p, ns, h, na, act, x + i, batch, out + i, batch, buf, buf + h, buf + 2 * h, buf + 3 * h);
+        rlo_mlp3_forward1(p, ns, h, na, act, x + i, batch, out + i, batch, buf, buf + h, buf + 2 * h, buf + 3 * h);
     free(buf);
 }
 
-static void mlp3_backward1(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x,
+void rlo_mlp3_backward1(const float* p, int64_t ns, int64_t h, int64_t na, int act, const float* x,
                            int64_t xstride, const float* dout, double* ga, const float* z1, const float* h1,
                            const float* z2, const float* h2, float* dz2b, double* dh1) {
     mlp3_view v = view3(p, ns, h, na);
@@ -151,13 +151,13 @@ float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const f
     float q[64], qn[64], dout[64];
     double acc = 0;
     for (int64_t i = 0; i < b; ++i) {
-        mlp3_forward1(target_params, ns, h, na, act, s_next + i, b, qn, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
+        rlo_mlp3_forward1(target_params, ns, h, na, act, s_next + i, b, qn, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
         float mx = qn[0];
         for (int64_t k = 1; k < na; ++k)
             if (qn[k] > mx) mx = qn[k];
         float cont = term[i] ? 0.0f : 1.0f;
         float G = r[i] + gamma * cont * mx;
-        mlp3_forward1(params, ns, h, na, act, s + i, b, q, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
+        rlo_mlp3_forward1(params, ns, h, na, act, s + i, b, q, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
         if (q_out)
             for (int64_t k = 0; k < na; ++k) q_out[k * b + i] = q[k];
         float d = q[a[i]] - G;
@@ -167,7 +167,7 @@ float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const f
         float gi = (e < huber_delta) ? d : (d > 0.0f ? huber_delta : (d < 0.0f ? -huber_delta : 0.0f));
         for (int64_t k = 0; k < na; ++k) dout[k] = 0.0f;
         dout[a[i]] = gi / (float)b;
-        mlp3_backward1(params, ns, h, na, act, s + i, b, dout, ga, buf, buf + h, buf + 2 * h, buf + 3 * h, buf + 4 * h,
+        rlo_mlp3_backward1(params, ns, h, na, act, s + i, b, dout, ga, buf, buf + h, buf + 2 * h, buf + 3 * h, buf + 4 * h,
                        dh1);
     }
     for (int64_t qq = 0; qq < np; ++qq) grad[qq] = (float)ga[qq];

@@ -82,7 +82,7 @@ class PPOCfg(C.Structure):
                                    "critic_loss_weight", "entropy_loss_weight", "lr", "beta1", "beta2",
                                    "adam_eps")] + \
                [(n, i32) for n in ("n_epochs", "n_microbatches", "hidden", "act", "continuous",
-                                   "normalize_advantage")]
+                                   "normalize_advantage", "layers")]
 
 
 class PPOTraj(C.Structure):

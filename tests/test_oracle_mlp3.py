@@ -78,3 +78,47 @@ def test_dqn3_loss_and_gradient_match_autograd(act):
     scale = np.abs(g).max()
     assert np.abs(grad - g).max() < 1e-2 * scale
     np.testing.assert_allclose(q, qt.detach().numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("continuous,kind", [(False, "cartpole"), (True, "pendulum")])
+def test_ppo_loss_gradient_with_three_layer_nets_matches_autograd(continuous, kind):
+    """oracle PPO loss / gradient with cfg.layers = 3 (actor and critic ns -> 128 -> 128 -> nout, bf16 hidden layer)
+    against torch autograd with straight-through bf16 roundings (tolerance: the oracle also rounds dz2 to bf16)."""
+    ns = 4 if kind == "cartpole" else 3
+    na, h, b = (2, 128, 200) if not continuous else (1, 128, 200)
+    nout_a = 2 * na if continuous else na
+    cfg = oracle.ppo_default(hidden=h, continuous=int(continuous), layers=3)
+    rng = np.random.default_rng(7)
+    pa, pc = oracle.mlp3_init(ns, h, nout_a, 1, 0), oracle.mlp3_init(ns, h, 1, 1, 1)
+    params = np.concatenate([pa, pc])
+    assert params.size == oracle.ppo_nparams(oracle.KIND[kind], cfg)
+    obs = rng.standard_normal((ns, b)).astype(np.float32)
+    adv = rng.standard_normal(b).astype(np.float32)
+    ret = rng.standard_normal(b).astype(np.float32)
+    logp_old = (-0.7 + 0.1 * rng.standard_normal(b)).astype(np.float32)
+    act_i = rng.integers(0, max(na, 2), b).astype(np.int32)
+    act_f = rng.standard_normal((na, b)).astype(np.float32)
+    grad, losses = oracle.ppo_loss_grad(cfg, ns, na, params, obs, act_f if continuous else act_i, logp_old, adv, ret)
+    pt = torch.from_numpy(params).float().requires_grad_(True)
+    x = torch.from_numpy(obs)
+    out = _torch_q(pt[:pa.size], ns, h, nout_a, 0, x)
+    v = _torch_q(pt[pa.size:], ns, h, 1, 0, x)[0]
+    A, lo = torch.from_numpy(adv), torch.clamp(torch.from_numpy(logp_old), min=float(np.log(1e-8)))
+    if continuous:
+        mu, ls = out[:na], out[na:]
+        se = torch.exp(ls) + 1e-8
+        z = torch.from_numpy(act_f)
+        lp = (-(((z - mu) / se) ** 2 + np.log(2 * np.pi)) / 2 - torch.log(se)).sum(0)
+        ent = ((na * (np.log(2 * np.pi) + 1) + ls.sum(0)) / 2).mean()
+    else:
+        logp = torch.log_softmax(out, 0)
+        lp = logp.gather(0, torch.from_numpy(act_i.astype(np.int64))[None])[0]
+        ent = -(logp.exp() * logp).sum(0).mean()
+    ratio = torch.exp(lp - lo)
+    actor = -torch.min(ratio * A, torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range) * A).mean()
+    critic = ((torch.from_numpy(ret) - v) ** 2).mean()
+    loss = cfg.actor_loss_weight * actor + cfg.critic_loss_weight * critic - cfg.entropy_loss_weight * ent
+    loss.backward()
+    assert abs(losses[0] - float(loss.detach())) < 2e-4 * max(1.0, abs(float(loss.detach())))
+    g = pt.grad.numpy()
+    assert np.abs(grad - g).max() < 1e-2 * np.abs(g).max()
