@@ -37,6 +37,7 @@
 #include "mlp_device.h"
 #include "select_device.h"
 #include "ppo_common.h"
+#include "ppo_sample_device.h"
 
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow,
                                        int64_t n, float grad_scale, float clip_norm, float lr, float beta1,
@@ -46,52 +47,6 @@ extern "C" int32_t rlhip_gae_returns_f32(float* advantages, float* returns, cons
                                          int64_t T, float gamma, float lambda, rlhip_stream_t stream);
 
 namespace rlhip {
-
-constexpr float LOG2PI_F = 1.8378770664093453f;  // log(2f0 * pi) as Float32 (RLCore/utils/distributions.jl:9)
-
-struct RegLogits {
-    const float* l;
-    __device__ __forceinline__ float operator()(int k) const { return l[k]; }
-};
-
-// normlogpdf(mu, sigma, x; eps = 1f-8)   RLCore/utils/distributions.jl:18-21
-__device__ __forceinline__ float normlogpdf1(float mu, float sigma, float x) {
-    float se = sigma + 1.0e-8f;
-    float z = (x - mu) / se;
-    return -(z * z + LOG2PI_F) / 2.0f - logf(se);
-}
-
-// Box-Muller standard normal from the NORMAL stream, evaluated in Float64 and rounded once (so that
-// CPU libm and GPU ocml agree); the `randn(rng, Float32, ...)` stand-in of networks.jl:70.
-__device__ __forceinline__ float normal_draw(uint64_t seed, uint32_t id, uint32_t step, int k) {
-    u32x4 w = philox4x32_10(seed, id, (uint32_t)(k >> 1), step, TAG_NORMAL);
-    double u1 = (double)((w.x >> 8) + 1u) * 0x1p-24;
-    double u2 = (double)(w.y >> 8) * 0x1p-24;
-    double r = ::sqrt(-2.0 * ::log(u1));
-    double a = 6.283185307179586 * u2;
-    return (float)((k & 1) ? r * ::sin(a) : r * ::cos(a));
-}
-
-// Sample an action from the actor head output `oa`.
-//   discrete:   oa = logits (na);  Gumbel-max, logp = logsoftmax(logits)[a]
-//   continuous: oa = (mu, log sigma) for a 1-D action;  z = mu + exp(log sigma) * noise,
-//               logp = normlogpdf(mu, sigma, z)   (GaussianNetwork, networks.jl:64-82, squash = identity)
-__device__ __forceinline__ void policy_sample(int cont, int na, const float oa[MAXO], uint64_t seed,
-                                              uint32_t id, uint32_t step, int32_t& ai, float& af,
-                                              float& logp) {
-    if (!cont) {
-        ai = categorical_sample1(RegLogits{oa}, NoMask{}, na, seed, id, step, &logp);
-        af = 0.0f;
-    } else {
-        float mu = oa[0], sg = expf(oa[1]);
-        float z = mu + sg * normal_draw(seed, id, step, 0);
-        logp = normlogpdf1(mu, sg, z);
-        af = z;
-        ai = 0;
-    }
-}
-
-
 
 __global__ void counters_advance_kernel(uint32_t* ctr, uint32_t d0, uint32_t d1) {
     ctr[0] += d0;  // vec-step counter
@@ -424,10 +379,12 @@ int32_t rlhip_ppo_default(rlhip_ppo_cfg* c) {
     c->act = 0;
     c->continuous = 0;
     c->normalize_advantage = 0;
+    c->layers = 2;
     return RLHIP_OK;
 }
 
 int64_t rlhip_ppo_nparams(int32_t kind, const rlhip_ppo_cfg* c) {
+    if (is_layers3(c)) return ppo3_nparams(kind, c);
     PolicyDesc pd;
     if (make_desc(kind, c, &pd)) return -1;
     int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
@@ -462,6 +419,8 @@ int32_t rlhip_ppo_plan_f32(int32_t kind, const rlhip_ppo_cfg* cfg, const float* 
                            int64_t n, uint64_t seed, uint32_t env_id_base, uint32_t vec_step,
                            int32_t* action_i, float* action_f, float* logp, float* value,
                            rlhip_stream_t stream) {
+    RLHIP_REQUIRE(!is_layers3(cfg), "layers = 3: use the fused rollout (rlhip_ppo_rollout_f32), the per-step plan! is "
+                                    "not built for the MFMA actor / critic");
     PolicyDesc pd;
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;
@@ -478,6 +437,10 @@ static int32_t rollout_entry(int32_t kind, const void* env_cfg, const rlhip_env_
                              const rlhip_ppo_cfg* cfg, const float* params, uint64_t seed, uint32_t env_id_base,
                              uint32_t vec_step0, const uint32_t* ctr, const rlhip_ppo_traj* traj,
                              rlhip_stream_t stream) {
+    if (is_layers3(cfg)) {
+        RLHIP_REQUIRE(ctr == nullptr, "layers = 3: the device-counter (graph replay) variant is not built");
+        return ppo3_rollout(kind, env_cfg, st, n, T, cfg, params, seed, env_id_base, vec_step0, traj, stream);
+    }
     PolicyDesc pd;
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;

@@ -25,6 +25,20 @@ struct PolicyDesc {
     int64_t np_a;
 };
 
+// cfg.layers == 3: actor / critic ns -> 128 -> 128 -> nout with the MFMA hidden layer (ppo3.hip)
+static inline bool is_layers3(const rlhip_ppo_cfg* c) { return c != nullptr && c->layers == 3; }
+int64_t ppo3_nparams(int32_t kind, const rlhip_ppo_cfg* c);
+int64_t ppo3_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* c, int64_t n, int64_t T);
+int32_t ppo3_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, int64_t T,
+                     const rlhip_ppo_cfg* cfg, const float* params, uint64_t seed, uint32_t env_id_base,
+                     uint32_t vec_step0, const rlhip_ppo_traj* traj, rlhip_stream_t stream);
+int32_t ppo3_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
+                  const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace, float* grad_out,
+                  float* losses_out, bool do_pack, rlhip_stream_t stream);
+int32_t ppo3_update(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
+                    float* params, float* m, float* v, float* beta_pow, uint64_t seed, uint32_t update_ctr,
+                    void* workspace, float* grad_scratch, float* losses_out, rlhip_stream_t stream);
+
 static inline int64_t env_na(int kind, int cont) { return cont ? 1 : (kind == 0 ? 2 : 3); }
 
 static inline int32_t make_desc(int32_t kind, const rlhip_ppo_cfg* c, PolicyDesc* pd) {
@@ -33,6 +47,7 @@ static inline int32_t make_desc(int32_t kind, const rlhip_ppo_cfg* c, PolicyDesc
     RLHIP_REQUIRE(c->hidden >= 4 && c->hidden % 4 == 0, "hidden must be a positive multiple of 4");
     RLHIP_REQUIRE(c->act == 0 || c->act == 1, "act must be 0 (relu) or 1 (tanh)");
     RLHIP_REQUIRE(c->normalize_advantage == 0, "normalize_advantage is not supported yet");
+    RLHIP_REQUIRE(c->layers == 0 || c->layers == 2 || c->layers == 3, "layers must be 2 or 3");
     int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
     pd->h = c->hidden;
     pd->act = c->act;

@@ -790,8 +790,7 @@ using namespace rlhip;
 extern "C" {
 
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T) {
-    (void)n;
-    (void)T;
+    if (is_layers3(cfg)) return ppo3_workspace_bytes(kind, cfg, n, T);
     int64_t np = rlhip_ppo_nparams(kind, cfg);
     if (np < 0) return -1;
     return (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float) + 16 + 4096 * (int64_t)sizeof(double) + 64 +
@@ -802,6 +801,10 @@ static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int
                           const float* params, uint64_t seed, uint32_t epoch_ctr, const uint32_t* ctr, int32_t mb,
                           void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream) {
     RLHIP_REQUIRE(grad_out != nullptr, "grad_out is NULL");
+    if (is_layers3(cfg)) {
+        RLHIP_REQUIRE(ctr == nullptr, "layers = 3: the device-counter (graph replay) variant is not built");
+        return ppo3_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_out, losses_out, true, stream);
+    }
     GradLaunch L;
     int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, ctr);
     if (rc) return rc;
@@ -838,6 +841,11 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
                             uint64_t seed, uint32_t update_ctr, const uint32_t* ctr, void* workspace,
                             float* grad_scratch, float* losses_out, rlhip_stream_t stream) {
     RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
+    if (is_layers3(cfg)) {
+        RLHIP_REQUIRE(ctr == nullptr, "layers = 3: the device-counter (graph replay) variant is not built");
+        return ppo3_update(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace, grad_scratch,
+                           losses_out, stream);
+    }
     hipStream_t s = as_stream(stream);
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {

@@ -77,12 +77,16 @@ class PPOPolicy:
         ns = env.odim
         self.na = 1 if env.continuous else len(env.action_space())
         nout_a = 2 * self.na if env.continuous else self.na
-        self.np_actor = int(_lib.lib.rlhip_mlp2_nparams(ns, self.cfg.hidden, nout_a))
+        # cfg.layers = 3: actor / critic ns -> 128 -> 128 -> nout with the hidden layer on the bf16 MFMA (ppo3.hip)
+        self.layers = 3 if self.cfg.layers == 3 else 2
+        nparams_fn, init_fn = ("rlhip_mlp2_nparams", "rlhip_mlp2_init_f32") if self.layers == 2 else \
+            ("rlhip_mlp3_nparams", "rlhip_mlp3_init_f32")
+        self.np_actor = int(getattr(_lib.lib, nparams_fn)(ns, self.cfg.hidden, nout_a))
         if params is None:
             self.params = torch.empty(self.np, dtype=torch.float32, device=dev)
             # glorot_uniform(rng) stand-in: actor net_id 0, critic net_id 1 (Philox INIT stream)
-            call("rlhip_mlp2_init_f32", ptr(self.params), ns, self.cfg.hidden, nout_a, self.seed, 0, stream_ptr())
-            call("rlhip_mlp2_init_f32", C.c_void_p(self.params.data_ptr() + 4 * self.np_actor), ns,
+            call(init_fn, ptr(self.params), ns, self.cfg.hidden, nout_a, self.seed, 0, stream_ptr())
+            call(init_fn, C.c_void_p(self.params.data_ptr() + 4 * self.np_actor), ns,
                  self.cfg.hidden, 1, self.seed, 1, stream_ptr())
         else:
             self.params = torch.as_tensor(params, dtype=torch.float32, device=dev).clone().contiguous()
