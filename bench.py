@@ -318,6 +318,32 @@ def roofline_extras(torch, rlhip):
                                         "updates_per_sec": round(ppol.n_updates_per_call() * iters / el, 1),
                                         "ms_per_iteration": round(el / iters * 1e3, 4), "dtype": "f32",
                                         "final_loss": float(ppol.losses[0])}
+    del ppol, penv
+    # the same config with THREE-layer actor / critic 3 -> 128 -> 128 -> {(mu, log sigma), 1}: the hidden x hidden layers
+    # run on the bf16 MFMA (ppo3.hip, cfg.layers = 3) -- "actor/critic MLP in bf16 MFMA", f32 master weights
+    penv = rlhip.HipVecEnv("pendulum", n, seed=7)
+    ppol = rlhip.PPOPolicy(penv, update_freq=128, hidden=128, seed=7, clip_range=0.1, layers=3)
+    for _ in range(3):
+        ppol.rollout_()
+        ppol.update_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ppol.rollout_()
+        ppol.update_()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms_r = event_time_ms(ppol.rollout_, 3, lib, s)
+    ms_u = event_time_ms(ppol.update_, 3, lib, s)
+    bm3 = n * 128 // ppol.cfg.n_microbatches
+    mf = 3 * 2 * 128 * 128 * 2 * bm3  # forward + dH1 + dW2 GEMMs of both nets per micro-batch
+    out["ppo3_mfma_pendulum_4096env_T128"] = {
+        "env_steps_per_sec": round(n * 128 * iters / el, 1),
+        "updates_per_sec": round(ppol.n_updates_per_call() * iters / el, 1),
+        "ms_per_iteration": round(el / iters * 1e3, 4), "dtype": "bf16 MFMA hidden layers, f32 master weights / accumulate",
+        "n_params": ppol.np, "rollout_us": round(ms_r * 1e3, 1), "update_us": round(ms_u * 1e3, 1),
+        "learner_mfma_tflops": round(mf / (ms_u * 1e-3 / ppol.n_updates_per_call()) / 1e12, 1),
+        "final_loss": float(ppol.losses[0])}
     return out
 
 

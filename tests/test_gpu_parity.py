@@ -440,7 +440,7 @@ def test_fused_clip_adam_equals_unfused(rl):
     from rlhip import ops
 
     rng = np.random.default_rng(2)
-    for n in (3331, 4097, 8195, 17410, 30001, 65536, 70000):  # scalar, vectorised (2, 4, 8, 16 x 4096) and grid-wide paths
+    for n in (3331, 4097, 8195, 17410, 30001, 34435, 49152, 65536, 70000):  # scalar, vectorised (2, 4, 8, 16 x 4096) and grid-wide paths
         p0 = rng.standard_normal(n).astype(np.float32)
         g0 = rng.standard_normal(n).astype(np.float32)
         pa, pb = dev(p0.copy()), dev(p0.copy())
