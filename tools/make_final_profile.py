@@ -1,0 +1,39 @@
+"""profiles/r01_final_bench_stats.md from a rocprofv3 --kernel-trace --stats run of the default bench command
+(tools/prof.sh final ...): usage  python tools/make_final_profile.py gpurun_out/prof_final gpurun_out/prof_final.log"""
+import csv, json, os, sys
+
+d, log = sys.argv[1], sys.argv[2]
+line = [l for l in open(log) if l.startswith('{"metric"')][-1]
+bench = json.loads(line)
+stats = list(csv.DictReader(open(os.path.join(d, "bench_kernel_stats.csv"))))
+trace = list(csv.DictReader(open(os.path.join(d, "bench_kernel_trace.csv"))))
+out = []
+out.append("# Round 1 — final state: rocprofv3 `--kernel-trace --stats` of the DEFAULT bench command\n")
+out.append("Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- "
+           "python bench.py` (`tools/prof.sh final`; default flags `--gpus 1 --steps 200 --warmup 20`, all legs: timed PPO "
+           "workload, kernel breakdown, env-step roofline at 2^24 envs, roofline extras incl. the DQN / MFMA / replay "
+           "configs, CPU baseline).\n")
+out.append("Bench line printed by the same (profiled) run:\n\n```json\n" + json.dumps(bench, indent=1) + "\n```\n")
+out.append("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|")
+for r in stats:
+    name = r["Name"].split("(")[0].replace("void ", "")
+    if "rlhip" not in name:
+        continue
+    out.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.2f} | "
+               f"{float(r['Percentage']):.2f} |")
+# agreement check for the roofline kernel: the 2^24-env launches only (grid 16384 x 256 threads = 4194304 work-items)
+big = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in trace
+       if "env_step_kernel" in r["Kernel_Name"] and "CartPole" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= (1 << 22)]
+rf = bench.get("roofline", {})
+if big:
+    avg = sum(big) / len(big) / 1e3
+    tail = big[3:] if len(big) > 3 else big
+    out.append("")
+    out.append(f"**Agreement check (roofline kernel).** The stats row of `env_step_kernel<CartPole, float, 4>` mixes launch "
+               f"sizes (the roofline leg runs 2^24 envs, the DQN legs 4096).  From `bench_kernel_trace.csv`, the {len(big)} "
+               f"launches with 2^24 envs (grid 16384 x 256) take **{avg:.1f} us** on average (min {min(big)/1e3:.1f}, max "
+               f"{max(big)/1e3:.1f}; the {len(tail)} timed ones after the 3 warm-up launches: "
+               f"{sum(tail)/len(tail)/1e3:.1f} us) against **{rf.get('us_per_launch')} us** measured with HIP events inside "
+               f"`bench.py` in the same run -> roofline.achieved = {rf.get('achieved')} GB/s, frac = {rf.get('frac')}.")
+open("profiles/r01_final_bench_stats.md", "w").write("\n".join(out) + "\n")
+print("\n".join(out[-3:])[:1500])
