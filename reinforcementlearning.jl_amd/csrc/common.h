@@ -60,6 +60,15 @@ enum : uint32_t {
     TAG_SYNTH = 7
 };
 
+// 16-byte non-temporal accesses for pure streaming kernels (every byte touched once, working set >> caches)
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ nt_u32x4 nt_load16(const void* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+}
+__device__ __forceinline__ void nt_store16(void* p, nt_u32x4 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_u32x4*>(p));
+}
+
 struct u32x4 {
     uint32_t x, y, z, w;
 };

@@ -140,11 +140,11 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
     uint4* d0 = (uint4*)(s + b * frame_bytes);
     uint4* d1 = (uint4*)(sn + b * frame_bytes);
     int64_t n16 = frame_bytes / 16;
-    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
-        uint4 x = src0[i];
-        uint4 y = src1[i];
-        d0[i] = x;
-        d1[i] = y;
+    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {  // streamed once: non-temporal both ways
+        nt_u32x4 x = nt_load16(src0 + i);
+        nt_u32x4 y = nt_load16(src1 + i);
+        nt_store16(d0 + i, x);
+        nt_store16(d1 + i, y);
     }
 }
 
@@ -199,10 +199,11 @@ __global__ __launch_bounds__(256) void gather_stacked_kernel(RingView rb, const 
         uint4* dn = (j < n_stack) ? (uint4*)(sn + (b * n_stack + (n_stack - 1 - j)) * frame_bytes) : nullptr;
         uint4* ds = (j >= 1) ? (uint4*)(s + (b * n_stack + (n_stack - j)) * frame_bytes) : nullptr;
         for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
-            uint4 x = make_uint4(0u, 0u, 0u, 0u);
-            if (vn || vs) x = src[i];
-            if (dn) dn[i] = vn ? x : make_uint4(0u, 0u, 0u, 0u);
-            if (ds) ds[i] = vs ? x : make_uint4(0u, 0u, 0u, 0u);
+            nt_u32x4 x = {0u, 0u, 0u, 0u};
+            const nt_u32x4 zero = {0u, 0u, 0u, 0u};
+            if (vn || vs) x = nt_load16(src + i);
+            if (dn) nt_store16(dn + i, vn ? x : zero);
+            if (ds) nt_store16(ds + i, vs ? x : zero);
         }
     }
 }
