@@ -76,13 +76,13 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     achieved = CARTPOLE_STEP_BYTES * n_envs / (ms * 1e-3) / 1e9
     del env, actions
     torch.cuda.empty_cache()
-    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4>", "n_envs": n_envs,
+    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal>", "n_envs": n_envs,
             "bytes_per_unit": CARTPOLE_STEP_BYTES, "us_per_launch": round(ms * 1e3, 2),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             # HBM bytes per launch from the PMC counters (separate rocprofv3 passes: FETCH_SIZE x2 gfx950
             # correction + WRITE_SIZE), measured for exactly this kernel / size: profiles/r01_pmc_env_step.md
-            "traffic": 875.8e6 if n_envs == (1 << 24) else None,
+            "traffic": 870.8e6 if n_envs == (1 << 24) else None,
             "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs,
             "traffic_source": "profiles/r01_pmc_env_step.md",
             "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1)}
