@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void discount_kernel(T* __restrict__ out, cons
 // The time axis is walked in register-staged chunks of CH steps: all loads of a chunk are issued
 // back to back (they do not depend on the recurrence), then the chunk is scanned -- one memory
 // latency per CH steps instead of one per step (the first version: 20 us for T = 32 on 64 waves).
-template <typename T, bool WITH_RETURNS, int CH>
+// NT: non-temporal loads / stores, chosen by the host when the scan streams far more than the L2 holds (every element
+// is touched once); the PPO hot path (0.5 MB trajectory, consumed by the gradient kernel next) keeps ordinary accesses.
+template <typename T, bool WITH_RETURNS, int CH, bool NT>
 __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __restrict__ ret,
                                                   const T* __restrict__ r, const T* __restrict__ v,
                                                   const uint8_t* __restrict__ term, int64_t n_slices,
@@ -72,9 +74,15 @@ __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __rest
         for (int c = 0; c < CH; ++c) {
             const int64_t i = hi - 1 - c;
             if (c < cnt) {
-                r_[c] = rp[i * elem_stride];
-                v_[c] = vp[i * elem_stride];
-                t_[c] = tp ? tp[i * elem_stride] : (uint8_t)0;
+                if (NT) {
+                    r_[c] = __builtin_nontemporal_load(rp + i * elem_stride);
+                    v_[c] = __builtin_nontemporal_load(vp + i * elem_stride);
+                    t_[c] = tp ? __builtin_nontemporal_load(tp + i * elem_stride) : (uint8_t)0;
+                } else {
+                    r_[c] = rp[i * elem_stride];
+                    v_[c] = vp[i * elem_stride];
+                    t_[c] = tp ? tp[i * elem_stride] : (uint8_t)0;
+                }
             }
         }
 #pragma unroll
@@ -87,8 +95,13 @@ __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __rest
                 T delta = r_[c] + boot - vi;                            // :412
                 T glc = strong_zero_mul(gl, is_continue);
                 gae = delta + glc * gae;                                // :413
-                adv[sl * slice_stride + i * elem_stride] = gae;         // :414
-                if (WITH_RETURNS) ret[sl * slice_stride + i * elem_stride] = gae + vi;
+                if (NT) {
+                    __builtin_nontemporal_store(gae, adv + sl * slice_stride + i * elem_stride);  // :414
+                    if (WITH_RETURNS) __builtin_nontemporal_store(gae + vi, ret + sl * slice_stride + i * elem_stride);
+                } else {
+                    adv[sl * slice_stride + i * elem_stride] = gae;     // :414
+                    if (WITH_RETURNS) ret[sl * slice_stride + i * elem_stride] = gae + vi;
+                }
                 vnext = vi;
             }
         }
@@ -144,12 +157,18 @@ static int32_t gae_impl(T* adv, T* ret, const T* r, const T* v, int64_t n1, int6
     if (g.n_slices == 0 || g.len == 0) return RLHIP_OK;  // empty trajectory: nothing to write
     RLHIP_REQUIRE(adv != nullptr && r != nullptr && v != nullptr, "NULL array");
     dim3 grid((int)((g.n_slices + 255) / 256));
-    if (ret)
-        hipLaunchKernelGGL((gae_kernel<T, true, 128 / sizeof(T)>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,
-                           g.len, g.elem_stride, g.slice_stride, g.v_slice_stride, gamma, lambda);
-    else
-        hipLaunchKernelGGL((gae_kernel<T, false, 128 / sizeof(T)>), grid, dim3(256), 0, s, adv, ret, r, v, term, g.n_slices,
-                           g.len, g.elem_stride, g.slice_stride, g.v_slice_stride, gamma, lambda);
+    const bool streaming = g.n_slices * g.len >= ((int64_t)1 << 22);
+#define LAUNCH_GAE(WR_, NT_)                                                                                          \
+    hipLaunchKernelGGL((gae_kernel<T, WR_, 128 / sizeof(T), NT_>), grid, dim3(256), 0, s, adv, ret, r, v, term,       \
+                       g.n_slices, g.len, g.elem_stride, g.slice_stride, g.v_slice_stride, gamma, lambda)
+    if (ret) {
+        if (streaming) LAUNCH_GAE(true, true);
+        else LAUNCH_GAE(true, false);
+    } else {
+        if (streaming) LAUNCH_GAE(false, true);
+        else LAUNCH_GAE(false, false);
+    }
+#undef LAUNCH_GAE
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
