@@ -573,6 +573,12 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int
                            float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr,
                            void* workspace, float* grad_out, float* loss_out,
                            rlhip_stream_t stream);
+/* The same learner step on explicit flat logical indices (e.g. from rlhip_ring_sample_prioritized, the prioritized
+ * BatchSampler of RLTrajectories 0.4) with |Q(s,a) - y| per sample returned for the priority write-back. */
+int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act,
+                               const float* params, const float* target_params, int64_t batch,
+                               const int64_t* idx, float gamma, float huber_delta, void* workspace,
+                               float* grad_out, float* loss_out, float* td_out, rlhip_stream_t stream);
 /* plan!(QBasedPolicy, env) for the vector env in one launch: q = forward(learner, state(env)) then
  * eps-greedy selection (q_based_policy.jl:30-32, abstract_learner.jl:37-39, epsilon_greedy_explorer.jl:108-112).
  * q_out (nullable): SoA (na x n). */

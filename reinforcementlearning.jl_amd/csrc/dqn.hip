@@ -42,6 +42,8 @@ struct DqnArgs {
     float gamma, delta, inv_b;
     uint64_t seed;
     uint32_t draw_ctr;
+    const int64_t* idx;  // optional explicit flat logical indices (prioritized sampler); NULL = inline uniform draw
+    float* td_out;       // optional |Q(s,a) - y| per sample (priority write-back)
 };
 
 template <int NS, int ACT>
@@ -85,9 +87,14 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
         if (tid < DTILE) {
             int64_t b = (int64_t)tile * DTILE + tid;
             bool valid = b < g.batch;
-            u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
-            uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
-            int64_t fj = (int64_t)__umul64hi(xr, g.total);
+            int64_t fj;
+            if (g.idx) {
+                fj = g.idx[valid ? b : 0];
+            } else {
+                u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
+                uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
+                fj = (int64_t)__umul64hi(xr, g.total);
+            }
             int64_t li = fj / g.n_env, e = fj - li * g.n_env;
             int64_t ps = (g.head_sa + li) % (g.capacity + 1);
             int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
@@ -160,6 +167,8 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             if (!valid) {
                 gi = 0.f;
                 l = 0.f;
+            } else if (g.td_out) {
+                g.td_out[(int64_t)tile * DTILE + s] = e;
             }
             s_loss += l;
 #pragma unroll
@@ -334,10 +343,10 @@ int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t bat
     return (int64_t)DQN_MAX_BLOCKS * (np + 1) * (int64_t)sizeof(float);
 }
 
-int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
-                           const float* target_params, int64_t batch, float gamma, float huber_delta,
-                           uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,
-                           rlhip_stream_t stream) {
+static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                             const float* target_params, int64_t batch, const int64_t* idx, float gamma,
+                             float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
+                             float* loss_out, float* td_out, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb && params && target_params && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
@@ -371,6 +380,8 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t 
     g.inv_b = 1.0f / (float)batch;
     g.seed = seed;
     g.draw_ctr = draw_ctr;
+    g.idx = idx;
+    g.td_out = td_out;
     int nb = g.num_tiles < DQN_MAX_BLOCKS ? g.num_tiles : DQN_MAX_BLOCKS;
     g.partials = (float*)workspace;
     g.loss_partials = g.partials + (int64_t)DQN_MAX_BLOCKS * np;
@@ -384,6 +395,23 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t 
                        nb, (int)np, grad_out, loss_out, g.inv_b);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
+}
+
+int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                           const float* target_params, int64_t batch, float gamma, float huber_delta,
+                           uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,
+                           rlhip_stream_t stream) {
+    return dqn_grad_impl(rb, h, na, act, params, target_params, batch, nullptr, gamma, huber_delta, seed, draw_ctr,
+                         workspace, grad_out, loss_out, nullptr, stream);
+}
+
+int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                               const float* target_params, int64_t batch, const int64_t* idx, float gamma,
+                               float huber_delta, void* workspace, float* grad_out, float* loss_out, float* td_out,
+                               rlhip_stream_t stream) {
+    RLHIP_REQUIRE(idx != nullptr, "idx is NULL");
+    return dqn_grad_impl(rb, h, na, act, params, target_params, batch, idx, gamma, huber_delta, 0, 0, workspace,
+                         grad_out, loss_out, td_out, stream);
 }
 
 int32_t rlhip_dqn_plan_f32(const float* params, int64_t ns, int64_t h, int64_t na, int32_t act, const float* obs,

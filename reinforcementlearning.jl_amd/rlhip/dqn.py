@@ -220,7 +220,7 @@ class DQNLearner:
         ws = dqn_workspace if net.layers == 2 else dqn3_workspace
         self.workspace = ws(net.n_in, net.hidden, net.n_out, batchsize, net.params.device)
         dev = net.params.device
-        self.td = torch.zeros(batchsize, dtype=torch.float32, device=dev) if net.layers == 3 else None
+        self.td = torch.zeros(batchsize, dtype=torch.float32, device=dev)
         self._idx = self._key = self._prio = None
 
     def forward(self, x):
@@ -243,9 +243,15 @@ class DQNLearner:
                 call("rlhip_per_priority_f32", ptr(self.td), self.batchsize, self.per_eps, self.per_alpha,
                      ptr(self.td), stream_ptr())
                 traces.set_priority_(self._key, self.td)
+        elif prioritized:
+            idx, self._key, self._prio = traces.sample_prioritized(self.batchsize, self.seed, self.draw_ctr)
+            call("rlhip_dqn_grad_idx_f32", C.byref(traces.rb), net.hidden, net.n_out, net.act, ptr(net.params),
+                 ptr(self.approximator.target), self.batchsize, ptr(idx), self.gamma, self.delta, ptr(self.workspace),
+                 ptr(self.grad), ptr(self.loss), ptr(self.td), stream_ptr())
+            call("rlhip_per_priority_f32", ptr(self.td), self.batchsize, self.per_eps, self.per_alpha, ptr(self.td),
+                 stream_ptr())
+            traces.set_priority_(self._key, self.td)
         else:
-            if prioritized:
-                raise NotImplementedError("prioritized replay is wired to the 3-layer (MFMA) Q-network path")
             dqn_grad(traces, net.hidden, net.n_out, net.act, net.params, self.approximator.target, self.batchsize,
                      self.gamma, self.delta, self.seed, self.draw_ctr, self.workspace, self.grad, self.loss)
         self.draw_ctr += 1

@@ -351,3 +351,47 @@ def test_single_rank_nccl_group_graph_capture(rl):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_dqn_grad_on_explicit_indices_and_prioritized_learner():
+    """rlhip_dqn_grad_idx_f32: the 2-layer DQN gradient on explicit (prioritized) indices equals the inline-draw
+    variant on the same indices, returns the TD errors, and the prioritized learner writes priorities back."""
+    import ctypes as C
+
+    import rlhip
+    from rlhip import dqn, ops
+    from rlhip._lib import call
+    from rlhip.ops import ptr, stream_ptr
+
+    n, ns, h, na, batch = 128, 4, 64, 2, 300
+    tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
+    tr.state.normal_()
+    tr.action.random_(0, na)
+    tr.reward.normal_()
+    tr.terminal.copy_((torch.rand(32, n, device="cuda") < 0.1).to(torch.uint8))
+    tr.rb.len_sa, tr.rb.len_rt = 33, 32
+    p, tp = ops.mlp2_init(ns, h, na, 1, 0), ops.mlp2_init(ns, h, na, 2, 0)
+    g0, l0 = dqn.dqn_grad(tr, h, na, 0, p, tp, batch, 0.99, 1.0, 9, 4)
+    idx = tr.sample_indices(batch, 9, 4)
+    ws = dqn.dqn_workspace(ns, h, na, batch)
+    g1, l1, td = torch.empty_like(p), torch.empty(1, device="cuda"), torch.zeros(batch, device="cuda")
+    call("rlhip_dqn_grad_idx_f32", C.byref(tr.rb), h, na, 0, ptr(p), ptr(tp), batch, ptr(idx), 0.99, 1.0, ptr(ws),
+         ptr(g1), ptr(l1), ptr(td), stream_ptr())
+    assert torch.equal(g0, g1) and torch.equal(l0, l1)
+    s, a, r, t, sn = tr.gather(idx)
+    q = ops.mlp2_forward(p, ns, h, na, 0, s)
+    qn = ops.mlp2_forward(tp, ns, h, na, 0, sn)
+    y = r + 0.99 * (1 - t.float()) * qn.max(0).values
+    ref = (q.gather(0, a.long()[None])[0] - y).abs()
+    torch.testing.assert_close(td, ref, rtol=1e-5, atol=1e-6)
+    # the learner with prioritized traces
+    env = rlhip.CartPoleEnv(n, seed=2)
+    net = rlhip.HipApproximator(4, 64, 2, seed=2)
+    learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=4), batchsize=64, min_replay_history=n, seed=2)
+    policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.1, seed=2))
+    traces = rlhip.CircularPrioritizedTraces(capacity=16, n_env=n, obs_dim=4, default_priority=5.0)
+    rlhip.run(rlhip.Agent(policy, rlhip.Trajectory(traces)), env, rlhip.StopAfterNSteps(20))
+    torch.cuda.synchronize()
+    assert learner.n_updates >= 15 and torch.isfinite(net.params).all()
+    leaves = traces.priorities[traces.priorities.numel() // 2:][:traces.n_leaves]
+    assert (leaves != 5.0).any() and (leaves >= 0).all()
