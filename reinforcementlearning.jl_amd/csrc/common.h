@@ -60,6 +60,30 @@ enum : uint32_t {
     TAG_SYNTH = 7
 };
 
+// Cross-lane sums without the LDS crossbar where the hardware allows it: DPP adds inside a 16-lane row (quad xor 1,
+// quad xor 2, half-row mirror, row mirror), ds_swizzle for lane ^ 16, one ds_bpermute for lane ^ 32.  Every lane ends
+// with the total; fixed order.  (A __shfl_xor butterfly is one ds_bpermute round trip per step: measured 5x slower.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int L>
+__device__ __forceinline__ float group_sum_dpp(float v) {  // sum over aligned groups of L = 4, 8 or 16 lanes
+    v = dpp_add<0xB1>(v);                  // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                  // quad_perm [2,3,0,1]
+    if (L >= 8) v = dpp_add<0x141>(v);     // row_half_mirror
+    if (L >= 16) v = dpp_add<0x140>(v);    // row_mirror
+    return v;
+}
+__device__ __forceinline__ float reduce16_dpp(float v) { return group_sum_dpp<16>(v); }
+__device__ __forceinline__ float swap16_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // lane ^ 16
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {  // all 64 lanes
+    v = swap16_add(reduce16_dpp(v));
+    return v + __shfl_xor(v, 32, 64);
+}
+
 // 16-byte non-temporal accesses for pure streaming kernels (every byte touched once, working set >> caches)
 typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ nt_u32x4 nt_load16(const void* p) {

@@ -81,24 +81,7 @@ __device__ __forceinline__ void gemm_slab(const uint16_t* A, int lda, const uint
     }
 }
 
-// sum over the 32 lanes of each half-wave, result in every lane: 4 DPP adds (quad xor 1, quad xor 2, half-row
-// mirror, row mirror) + one ds_swizzle (xor 16).  Fixed order, no LDS addressing -- ~10x cheaper than 5
-// ds_bpermute butterflies (measured: the two Q heads were 30 of 65 us per tile with __shfl_xor).
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float reduce16_dpp(float v) {
-    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);  // row_half_mirror
-    v = dpp_add<0x140>(v);  // row_mirror
-    return v;
-}
-__device__ __forceinline__ float swap16_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // lane ^ 16
-}
-
+// (dpp_add / reduce16_dpp / swap16_add: common.h)
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)

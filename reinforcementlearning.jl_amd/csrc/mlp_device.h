@@ -82,11 +82,10 @@ __device__ __forceinline__ void net_forward(const NetRegs<NS, HPL>& r, const flo
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) acc[o] = fmaf(r.w2[m][o], hv, acc[o]);
     }
+    // the L = 4 / 8 / 16 lanes of a group sit inside one DPP row: row-local adds, no LDS crossbar
+    static_assert(L == 4 || L == 8 || L == 16, "lane groups must fit a DPP row");
 #pragma unroll
-    for (int off = L / 2; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int o = 0; o < MAXO; ++o) acc[o] += __shfl_xor(acc[o], off, 64);
-    }
+    for (int o = 0; o < MAXO; ++o) acc[o] = group_sum_dpp<L>(acc[o]);
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) out[o] = acc[o] + r.b2[o];
 }

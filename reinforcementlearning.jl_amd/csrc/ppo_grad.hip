@@ -401,14 +401,11 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
     }
     if (w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-            for (int o = 0; o < GMAXO; ++o) gb2a[o] += __shfl_down(gb2a[o], off, 64);
-            gb2c += __shfl_down(gb2c, off, 64);
-            s_actor += __shfl_down(s_actor, off, 64);
-            s_critic += __shfl_down(s_critic, off, 64);
-            s_ent += __shfl_down(s_ent, off, 64);
-        }
+        for (int o = 0; o < GMAXO; ++o) gb2a[o] = wave_sum_f32(gb2a[o]);
+        gb2c = wave_sum_f32(gb2c);
+        s_actor = wave_sum_f32(s_actor);
+        s_critic = wave_sum_f32(s_critic);
+        s_ent = wave_sum_f32(s_ent);
         if (lane == 0) {
             for (int o = 0; o < nout; ++o) out[h * NS + h + nout * h + o] = gb2a[o];
             out[g.pd.np_a + h * NS + h + h] = gb2c;
