@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
             tr.value[(int64_t)T * n + env] = oc[0];
         }
     }
+    // generalized_advantage_estimation + returns for this env, from the values / rewards this lane just wrote
+    // (fuses rlhip_ppo_gae_f32 into the rollout launch; identical arithmetic, see gae_device.h)
+    if (writer && T > 0 && tr.adv && tr.ret)
+        gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, pd.gamma, pd.lambda);
     if (writer && store_state) {
 #pragma unroll
         for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
@@ -175,6 +179,8 @@ __global__ __launch_bounds__(256) void rollout_scalar_kernel(P p, EnvArrays<floa
         for (int k = 0; k < NS; ++k) tr.obs[((int64_t)T * NS + k) * n + env] = x[k];
         tr.value[(int64_t)T * n + env] = oc[0];
     }
+    if (T > 0 && tr.adv && tr.ret)
+        gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, pd.gamma, pd.lambda);
     if (store_state) {
 #pragma unroll
         for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];

@@ -55,7 +55,7 @@ template <class P, int NOUT_A, int ACT>
 __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float> st, int64_t n, int T, int cont, int na,
                                                            const float* __restrict__ params, int64_t np_a,
                                                            uint64_t seed, uint32_t env_id_base, uint32_t vec_step0,
-                                                           TrajPtrs tr) {
+                                                           TrajPtrs tr, float gamma, float lambda) {
     constexpr int NS = P::ODIM;
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     float* l_x = reinterpret_cast<float*>(smem3);                   // [4][TR]
@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float>
         }
         __syncthreads();  // l_x / l_q / l_v are rewritten by the next step
     }
+    if (active && T > 0 && tr.adv && tr.ret)  // GAE + returns fused into the rollout launch (gae_device.h)
+        gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, gamma, lambda);
     if (active) {
 #pragma unroll
         for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
@@ -434,7 +436,7 @@ static int32_t rollout3_impl(const typename P::cfg_t* cfg, const rlhip_env_state
         int32_t rc_ = allow_lds3(ppo3_rollout_kernel<P, 2, ACT_>, ROLL3_LDS, &done_);                             \
         if (rc_) return rc_;                                                                                      \
         hipLaunchKernelGGL((ppo3_rollout_kernel<P, 2, ACT_>), grid, dim3(256), ROLL3_LDS, s, p, a, n, (int)T, pd.cont, \
-                           pd.na, params, pd.np_a, seed, env_id_base, vec_step0, tr);                            \
+                           pd.na, params, pd.np_a, seed, env_id_base, vec_step0, tr, pd.gamma, pd.lambda);      \
     } while (0)
     if (pd.act == 0) LAUNCH_R3(0);
     else LAUNCH_R3(1);

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "mlp_device.h"
+#include "gae_device.h"
 
 namespace rlhip {
 
@@ -23,6 +24,7 @@ struct TrajPtrs {
 struct PolicyDesc {
     int h, act, cont, na, nout_a;
     int64_t np_a;
+    float gamma, lambda;  // for the GAE scan fused into the tail of the rollout kernels
 };
 
 // cfg.layers == 3: actor / critic ns -> 128 -> 128 -> nout with the MFMA hidden layer (ppo3.hip)
@@ -55,6 +57,8 @@ static inline int32_t make_desc(int32_t kind, const rlhip_ppo_cfg* c, PolicyDesc
     pd->na = (int)env_na(kind, pd->cont);
     pd->nout_a = pd->cont ? 2 * pd->na : pd->na;
     pd->np_a = mlp2_nparams(ns, c->hidden, pd->nout_a);
+    pd->gamma = c->gamma;
+    pd->lambda = c->lambda;
     return RLHIP_OK;
 }
 

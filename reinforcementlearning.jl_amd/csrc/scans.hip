@@ -13,14 +13,9 @@
 // every t: fully coalesced, 13 B (17 B with fused returns) of algorithmic traffic per (env, t).
 // The loads do not depend on the recurrence, so the unrolled loop keeps several time steps of loads
 // in flight per lane; the dependent chain is 3-4 VALU ops per step.
-#include "common.h"
+#include "gae_device.h"
 
 namespace rlhip {
-
-template <typename T>
-__device__ __forceinline__ T strong_zero_mul(T x, bool keep) {
-    return keep ? x : (T)copysign((T)0, x);  // Julia: x * false == copysign(0, x), also for NaN / Inf
-}
 
 // out may be null (reduced form).  One lane per slice.
 template <typename T, bool REDUCED>

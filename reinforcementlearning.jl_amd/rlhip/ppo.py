@@ -152,6 +152,7 @@ class PPOPolicy:
         self.trajectory.obs[self.T].copy_(env.state())
         self.trajectory.value[self.T].copy_(self._value)
         self.n_pushed = 0
+        self._adv_ready = False  # per-step protocol: adv / ret are computed by gae_() in update_()
 
     # ----------------------------------------------------------------- fused protocol
     def rollout_(self, env=None):
@@ -162,6 +163,7 @@ class PPOPolicy:
              C.byref(self.trajectory.c), stream_ptr())
         env._obs_valid = False
         self.vec_step += self.T
+        self._adv_ready = True  # the rollout kernels finish with the GAE + returns scan of every env (gae_device.h)
 
     def gae_(self):
         call("rlhip_ppo_gae_f32", C.byref(self.cfg), self.trajectory.n, self.T, C.byref(self.trajectory.c),
@@ -178,8 +180,11 @@ class PPOPolicy:
              self.cfg.adam_eps, ptr(self.gn), stream_ptr())
 
     def update_(self):
-        """optimise!(policy): GAE, then n_epochs x n_microbatches of grad -> [all-reduce] -> clip -> Adam."""
-        self.gae_()
+        """optimise!(policy): GAE (unless the fused rollout already wrote adv / ret), then n_epochs x n_microbatches of
+        grad -> [all-reduce] -> clip -> Adam."""
+        if not getattr(self, "_adv_ready", False):
+            self.gae_()
+        self._adv_ready = False
         world = 1
         if self.process_group is not None:
             import torch.distributed as dist

@@ -395,3 +395,21 @@ def test_dqn_grad_on_explicit_indices_and_prioritized_learner():
     assert learner.n_updates >= 15 and torch.isfinite(net.params).all()
     leaves = traces.priorities[traces.priorities.numel() // 2:][:traces.n_leaves]
     assert (leaves != 5.0).any() and (leaves >= 0).all()
+
+
+@pytest.mark.parametrize("kind,layers,hidden", [("cartpole", 2, 256), ("pendulum", 2, 64), ("mountaincar", 2, 100),
+                                                ("cartpole", 3, 128), ("pendulum", 3, 128)])
+def test_rollout_writes_gae_and_returns_bit_identical_to_the_scan(kind, layers, hidden):
+    """the rollout kernels end with the GAE + returns scan of every env (gae_device.h): adv / ret after rollout_()
+    equal what rlhip_ppo_gae_f32 computes from the same trajectory, bit for bit (wide, scalar and MFMA rollouts)"""
+    import rlhip
+
+    env = rlhip.HipVecEnv(kind, 333, seed=3)
+    pol = rlhip.PPOPolicy(env, update_freq=37, hidden=hidden, seed=3, layers=layers)
+    pol.rollout_()
+    adv, ret = pol.trajectory.adv.clone(), pol.trajectory.ret.clone()
+    assert adv.abs().sum() > 0
+    pol.trajectory.adv.zero_()
+    pol.trajectory.ret.zero_()
+    pol.gae_()
+    assert torch.equal(adv, pol.trajectory.adv) and torch.equal(ret, pol.trajectory.ret)
