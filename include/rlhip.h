@@ -328,6 +328,16 @@ int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb_host, const void* scre
                                            const int32_t* action, const float* reward,
                                            const uint8_t* terminal, rlhip_stream_t stream);
 
+/* plan! + act! + push! of one DQN vec-step in ONE launch for the 2-layer Q-network (dqn_act.hip): bit-identical
+ * to rlhip_dqn_plan_f32 -> rlhip_env_step (auto-reset) -> rlhip_ring_push_transition, whose ring counters it
+ * advances the same way.  rlhip_dqn_act_supported: hidden in {64, 128, 256}, n <= 2^18, Float32 discrete env. */
+int32_t rlhip_dqn_act_supported(int32_t kind, int64_t n, int64_t h);
+int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n,
+                          const float* params, int64_t h, int64_t na, int32_t act, double eps,
+                          uint64_t explorer_seed, uint32_t explorer_step, uint64_t env_seed, uint32_t env_id_base,
+                          rlhip_ring* rb_host, int32_t* actions, float* q_out, float* obs_out, float* last_obs,
+                          rlhip_stream_t stream);
+
 /* ------------------------------------------------- one DQN vec-step as a single call -- */
 /* One trip round the body of `_run` (RLCore/src/core/run.jl:52-70) for Agent{QBasedPolicy{DQN}} on the vector
  * env: plan! (q_based_policy.jl:30-32) -> act! -> push!(agent, PostActStage) (agent_base.jl:56-59) ->

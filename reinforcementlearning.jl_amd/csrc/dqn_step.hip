@@ -14,6 +14,8 @@
 // per-step protocol (tests/test_gpu_run.py) -- from one call.
 #include "common.h"
 
+#include <stdlib.h>
+
 extern "C" {
 int32_t rlhip_dqn_plan_f32(const float*, int64_t, int64_t, int64_t, int32_t, const float*, int64_t, double, uint64_t,
                            uint32_t, uint32_t, int32_t*, float*, rlhip_stream_t);
@@ -28,6 +30,11 @@ int32_t rlhip_mlp3_pack_bf16(const float*, int64_t, int64_t, int64_t, uint16_t*,
 int64_t rlhip_mlp2_nparams(int64_t, int64_t, int64_t);
 int64_t rlhip_mlp3_nparams(int64_t, int64_t, int64_t);
 int32_t rlhip_env_obs_dim(int32_t kind);
+int32_t rlhip_dqn_act_supported(int32_t kind, int64_t n, int64_t h);
+int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, const float* params,
+                          int64_t h, int64_t na, int32_t act, double eps, uint64_t explorer_seed, uint32_t explorer_step,
+                          uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb, int32_t* actions, float* q_out,
+                          float* obs_out, float* last_obs, rlhip_stream_t stream);
 }
 
 extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t stream) {
@@ -40,21 +47,29 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
     const int64_t ns = rlhip_env_obs_dim(a->kind);
     RLHIP_REQUIRE(ns == a->ring->obs_dim && a->n == a->ring->n_env, "ring geometry does not match the env");
     int32_t rc;
+    if (a->layers == 2 && rlhip_dqn_act_supported(a->kind, a->n, a->h) && !getenv("RLHIP_DQN_UNFUSED_ACT")) {
+        // plan! + act! + push! in one launch (dqn_act.hip): same device functions, same slots, bit-identical
+        rc = rlhip_dqn_act_f32(a->kind, a->env_cfg, a->st, a->n, a->params, a->h, a->na, a->act, a->eps,
+                               a->explorer_seed, a->explorer_step, a->env_seed, a->env_id_base, a->ring, a->actions,
+                               a->q, a->obs, a->last_obs, stream);
+        if (rc) return rc;
+    } else {
     // plan!(policy, env): Q forward + eps-greedy on the current observation
-    if (a->layers == 2)
-        rc = rlhip_dqn_plan_f32(a->params, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
-                                a->env_id_base, a->explorer_step, a->actions, a->q, stream);
-    else
-        rc = rlhip_dqn3_plan_f32(a->params, a->packed, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
-                                 a->env_id_base, a->explorer_step, a->actions, a->q, stream);
-    if (rc) return rc;
-    // act!(env, action) with auto-reset; the post-step observation lands in a->obs
-    rc = rlhip_env_step(a->kind, 0, a->env_cfg, a->st, a->n, a->actions, 1, a->env_seed, a->env_id_base, a->last_obs,
-                        a->obs, stream);
-    if (rc) return rc;
-    // push!(trajectory, (state = s', action, reward, terminal))
-    rc = rlhip_ring_push_transition(a->ring, a->obs, a->actions, (const float*)a->st->reward, a->st->done, stream);
-    if (rc) return rc;
+        if (a->layers == 2)
+            rc = rlhip_dqn_plan_f32(a->params, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
+                                    a->env_id_base, a->explorer_step, a->actions, a->q, stream);
+        else
+            rc = rlhip_dqn3_plan_f32(a->params, a->packed, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
+                                     a->env_id_base, a->explorer_step, a->actions, a->q, stream);
+        if (rc) return rc;
+        // act!(env, action) with auto-reset; the post-step observation lands in a->obs
+        rc = rlhip_env_step(a->kind, 0, a->env_cfg, a->st, a->n, a->actions, 1, a->env_seed, a->env_id_base, a->last_obs,
+                            a->obs, stream);
+        if (rc) return rc;
+        // push!(trajectory, (state = s', action, reward, terminal))
+        rc = rlhip_ring_push_transition(a->ring, a->obs, a->actions, (const float*)a->st->reward, a->st->done, stream);
+        if (rc) return rc;
+    }
     if (!a->do_update) return RLHIP_OK;
     // optimise!(learner, trajectory): sample + TD target + Huber + gradient, then clip + Adam
     int64_t np;

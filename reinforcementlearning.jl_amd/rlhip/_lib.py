@@ -156,6 +156,9 @@ _PROTOS = {
     "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
                                   vp, vp]),
     "rlhip_dqn_vec_step_f32": (i32, [vp, vp]),
+    "rlhip_dqn_act_supported": (i32, [i32, i64, i64]),
+    "rlhip_dqn_act_f32": (i32, [i32, vp, vp, i64, vp, i64, i64, i32, f64, u64, u32, u64, u32, P(Ring), vp, vp, vp, vp,
+                                vp]),
     "rlhip_hook_episode_stats": (i32, [vp, vp, i64, u32, vp, vp, vp, u32, vp, vp]),
     "rlhip_explorer_select_f32": (i32, [i32, vp, i64, i64, i64, i64, vp, i32, u64, u32, u32, vp, vp]),
     "rlhip_ucb_select_f32": (i32, [vp, i64, i64, i64, i64, f64, vp, i64, u64, u32, vp, vp]),
@@ -209,7 +212,7 @@ for _name, (_res, _args) in _PROTOS.items():
     _f.restype = _res
     _f.argtypes = _args
     if _res is i32 and _name not in ("rlhip_abi_version", "rlhip_env_obs_dim", "rlhip_env_state_dim",
-                                     "rlhip_ring_gather_is_frame_major"):
+                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported"):
         _STATUS.add(_name)
 
 
