@@ -350,7 +350,8 @@ def roofline_extras(torch, rlhip):
 def kernel_breakdown(torch, rlhip, pol, env):
     """Device time of the three enqueue units of one step (HIP events on the launch stream).  Each unit is
     ONE C-ABI call, so the numbers are not host-paced: rollout (1 launch), GAE (1 launch), update
-    (pack + n_epochs x n_microbatches x {grad kernel, reduce+clip+Adam kernel})."""
+    (pack + n_epochs x n_microbatches x {grad kernel, reduce+clip+Adam kernel}).  The rollout launch includes the
+    fused GAE + returns scan; gae_returns_us is the stand-alone scan (used by the per-step protocol)."""
     from rlhip.ops import stream_ptr
 
     s = stream_ptr()
@@ -360,7 +361,11 @@ def kernel_breakdown(torch, rlhip, pol, env):
     out["rollout_T32_us"] = round(event_time_ms(pol.rollout_, 5, lib, s) * 1e3, 2)
     out["gae_returns_us"] = round(event_time_ms(pol.gae_, 5, lib, s) * 1e3, 2)
     n_upd = pol.n_updates_per_call()
-    upd_ms = event_time_ms(pol.update_, 5, lib, s)
+    def upd_only():  # the rollout leaves adv / ret ready (fused GAE scan): time the optimiser steps alone
+        pol._adv_ready = True
+        pol.update_()
+
+    upd_ms = event_time_ms(upd_only, 5, lib, s)
     out["update_us"] = round(upd_ms * 1e3, 2)
     out["per_microbatch_us"] = round(upd_ms * 1e3 / n_upd, 2)
     for t, sv in zip((pol.params, pol.m, pol.v, pol.beta_pow), saved):
