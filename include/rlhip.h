@@ -544,6 +544,17 @@ int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t 
                            const rlhip_ppo_traj* traj_host, const float* params, uint64_t seed,
                            uint32_t epoch_ctr, int32_t mb, void* workspace, float* grad_out,
                            float* losses_out, rlhip_stream_t stream);
+/* Multi-GPU optimiser step: after the host's all-reduce of grad_out, rlhip_ppo_apply_f32 does [grad_scale] ->
+ * clip_by_global_norm! -> Adam AND refreshes the learner's internal weight records in one launch, so that the next
+ * micro-batch can call rlhip_ppo_grad_fresh_f32 (= rlhip_ppo_grad_f32 without its re-pack launch).  The first
+ * gradient of an update call must use rlhip_ppo_grad_f32 (the parameters may have been changed by anyone). */
+int32_t rlhip_ppo_grad_fresh_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                                 const rlhip_ppo_traj* traj_host, const float* params, uint64_t seed,
+                                 uint32_t epoch_ctr, int32_t mb, void* workspace, float* grad_out,
+                                 float* losses_out, rlhip_stream_t stream);
+int32_t rlhip_ppo_apply_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T, float* params,
+                            float* grad, float* m, float* v, float* beta_pow, float grad_scale, void* workspace,
+                            float* gn_out, rlhip_stream_t stream);
 /* n_epochs x n_microbatches of { grad -> clip_by_global_norm! -> Adam } enqueued back to back
  * (single-GPU optimise!; multi-GPU hosts call rlhip_ppo_grad_f32, all-reduce, rlhip_clip_adam_f32).
  * update_ctr = number of previous update calls. */

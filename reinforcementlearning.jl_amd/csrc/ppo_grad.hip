@@ -692,6 +692,20 @@ static int grad_blocks(int num_tiles) {
     return num_tiles < cap ? num_tiles : cap;
 }
 
+// location of the unit-record copy inside the workspace (the carve of prepare_grad)
+static float* workspace_packed(void* workspace, int64_t np) {
+    float* partials = (float*)workspace;
+    float* loss_partials = partials + (int64_t)MAX_GRAD_BLOCKS * np;
+    uintptr_t q = (uintptr_t)(loss_partials + (int64_t)MAX_GRAD_BLOCKS * 4);
+    q = (q + 15) & ~(uintptr_t)15;
+    double* sumsq = (double*)q;
+    unsigned int* counter = (unsigned int*)(sumsq + 4096);
+    long long* dbgp = (long long*)(counter + 16);
+    uintptr_t pq = (uintptr_t)(dbgp + (int64_t)MAX_GRAD_BLOCKS * 8);
+    pq = (pq + 63) & ~(uintptr_t)63;
+    return (float*)pq;
+}
+
 struct GradLaunch {
     GradArgs g;
     int nb, ns;
@@ -765,6 +779,53 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     return RLHIP_OK;
 }
 
+// Multi-GPU optimiser step after the gradient all-reduce: [grad_scale] -> global norm -> clip -> Adam -> unit-record
+// refresh in ONE single-workgroup launch (np <= 16 k), so that the next rlhip_ppo_grad call needs no pack launch.
+__global__ __launch_bounds__(1024) void apply_pack_kernel(float* __restrict__ grad, float grad_scale, int np,
+                                                          float* __restrict__ gn_out, ApplyArgs ap) {
+    __shared__ double l_d[16];
+    constexpr int U = 16;
+    float gr[U];
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = threadIdx.x + u * 1024;
+        gr[u] = q < np ? grad[q] * grad_scale : 0.0f;
+        acc += (double)gr[u] * (double)gr[u];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) l_d[wv] = acc;
+    const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+    __syncthreads();
+    double tot = 0.0;
+    for (int q = 0; q < 16; ++q) tot += l_d[q];
+    const float gn = (float)sqrt(tot);
+    const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = threadIdx.x + u * 1024;
+        if (q >= np) continue;
+        float g1 = gr[u];
+        if (scale != 1.0f) g1 *= scale;
+        const float mi = ap.b1 * ap.m[q] + (1.0f - ap.b1) * g1;  // Optimisers.Adam, expression order of optim.hip adam1
+        const float vi = ap.b2 * ap.v[q] + (1.0f - ap.b2) * (g1 * g1);
+        ap.m[q] = mi;
+        ap.v[q] = vi;
+        const float d = mi / c1 / (sqrtf(vi / c2) + ap.eps) * ap.lr;
+        ap.params[q] = ap.params[q] - d;
+        grad[q] = g1;
+    }
+    __syncthreads();
+    pack_records(ap.params, ap.packed, ap.h, ap.ns, ap.nout, ap.np_a, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) {
+        if (gn_out) gn_out[0] = gn;
+        ap.beta_pow[0] *= ap.b1;
+        ap.beta_pow[1] *= ap.b2;
+    }
+}
+
 static void launch_grad(const GradLaunch& L, hipStream_t s) {
     size_t smem = grad_smem_bytes(L.g.pd.h);
 #define LAUNCH_G(NS_, ACT_) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_>), dim3(L.nb), dim3(64 * NW), smem, s, L.g)
@@ -796,7 +857,8 @@ int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
 
 static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                           const float* params, uint64_t seed, uint32_t epoch_ctr, const uint32_t* ctr, int32_t mb,
-                          void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream) {
+                          void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream,
+                          bool do_pack = true) {
     RLHIP_REQUIRE(grad_out != nullptr, "grad_out is NULL");
     if (is_layers3(cfg)) {
         RLHIP_REQUIRE(ctr == nullptr, "layers = 3: the device-counter (graph replay) variant is not built");
@@ -806,7 +868,7 @@ static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int
     int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, ctr);
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
-    launch_pack(L, s);
+    if (do_pack) launch_pack(L, s);
     launch_grad(L, s);
     ApplyArgs ap{};
     hipLaunchKernelGGL((reduce_apply_kernel<APPLY_NONE>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
@@ -822,6 +884,37 @@ int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, in
                            rlhip_stream_t stream) {
     return grad_entry(kind, cfg, n, T, traj, params, seed, epoch_ctr, nullptr, mb, workspace, grad_out, losses_out,
                       stream);
+}
+
+int32_t rlhip_ppo_grad_fresh_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                                 const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr,
+                                 int32_t mb, void* workspace, float* grad_out, float* losses_out,
+                                 rlhip_stream_t stream) {
+    return grad_entry(kind, cfg, n, T, traj, params, seed, epoch_ctr, nullptr, mb, workspace, grad_out, losses_out, stream,
+                      /*do_pack=*/false);
+}
+
+int32_t rlhip_ppo_apply_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, float* params, float* grad,
+                            float* m, float* v, float* beta_pow, float grad_scale, void* workspace, float* gn_out,
+                            rlhip_stream_t stream) {
+    RLHIP_REQUIRE(cfg && params && grad && m && v && beta_pow && workspace, "NULL argument");
+    const int64_t np = rlhip_ppo_nparams(kind, cfg);
+    RLHIP_REQUIRE(np > 0, "bad configuration");
+    if (is_layers3(cfg) || np > 16 * 1024)  // generic path: fused clip + Adam; the next grad call re-packs
+        return rlhip_clip_adam_f32(params, grad, m, v, beta_pow, np, grad_scale, cfg->max_grad_norm, cfg->lr, cfg->beta1,
+                                   cfg->beta2, cfg->adam_eps, gn_out, stream);
+    (void)n;
+    (void)T;
+    PolicyDesc pd;
+    int32_t rc = make_desc(kind, cfg, &pd);
+    if (rc) return rc;
+    const int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
+    ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
+                 nullptr, nullptr, workspace_packed(workspace, np), pd.h, ns, pd.nout_a, pd.np_a};
+    hipLaunchKernelGGL(apply_pack_kernel, dim3(1), dim3(1024), 0, as_stream(stream), grad, grad_scale, (int)np, gn_out,
+                       ap);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
 }
 
 int32_t rlhip_ppo_grad_dc_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,

@@ -190,6 +190,9 @@ _PROTOS = {
     "rlhip_ppo_workspace_bytes": (i64, [i32, P(PPOCfg), i64, i64]),
     "rlhip_ppo_grad_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, i32, vp, vp, vp,
                                  vp]),
+    "rlhip_ppo_grad_fresh_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, i32, vp, vp, vp,
+                                 vp]),
+    "rlhip_ppo_apply_f32": (i32, [i32, P(PPOCfg), i64, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp]),
     "rlhip_ppo_update_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp,
                                    vp, vp, vp]),
     "rlhip_ppo_rollout_dc_f32": (i32, [i32, vp, P(EnvState), i64, i64, P(PPOCfg), vp, u64, u32, vp, P(PPOTraj),

@@ -169,15 +169,18 @@ class PPOPolicy:
         call("rlhip_ppo_gae_f32", C.byref(self.cfg), self.trajectory.n, self.T, C.byref(self.trajectory.c),
              stream_ptr())
 
-    def grad_(self, epoch_ctr, mb):
-        call("rlhip_ppo_grad_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
+    def grad_(self, epoch_ctr, mb, records_fresh=False):
+        """records_fresh: the previous optimiser step was apply_() (which refreshes the learner's weight records), so
+        the gradient launch can skip its re-pack."""
+        call("rlhip_ppo_grad_fresh_f32" if records_fresh else "rlhip_ppo_grad_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
              C.byref(self.trajectory.c), ptr(self.params), self.seed, epoch_ctr, mb, ptr(self.workspace),
              ptr(self.grad), ptr(self.losses), stream_ptr())
 
     def apply_(self, grad_scale=1.0):
-        call("rlhip_clip_adam_f32", ptr(self.params), ptr(self.grad), ptr(self.m), ptr(self.v), ptr(self.beta_pow),
-             self.np, grad_scale, self.cfg.max_grad_norm, self.cfg.lr, self.cfg.beta1, self.cfg.beta2,
-             self.cfg.adam_eps, ptr(self.gn), stream_ptr())
+        """[grad_scale] -> clip_by_global_norm! -> Adam -> weight-record refresh, one launch"""
+        call("rlhip_ppo_apply_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T, ptr(self.params),
+             ptr(self.grad), ptr(self.m), ptr(self.v), ptr(self.beta_pow), grad_scale, ptr(self.workspace),
+             ptr(self.gn), stream_ptr())
 
     def update_(self):
         """optimise!(policy): GAE (unless the fused rollout already wrote adv / ret), then n_epochs x n_microbatches of
@@ -200,7 +203,7 @@ class PPOPolicy:
             for e in range(self.cfg.n_epochs):
                 epoch_ctr = self.update_ctr * self.cfg.n_epochs + e
                 for mb in range(self.cfg.n_microbatches):
-                    self.grad_(epoch_ctr, mb)
+                    self.grad_(epoch_ctr, mb, records_fresh=(e > 0 or mb > 0))
                     # gradient all-reduce BEFORE the global-norm clip, so the clip sees the global
                     # gradient (mean over shards == single-GPU semantics with a world-times larger batch)
                     dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
