@@ -523,6 +523,9 @@ def main():
                    "parallelism": f"env-shards x{world}, flat-gradient all-reduce (RCCL) per micro-batch" if world > 1
                    else "single GPU"},
         "launch_mode": mode,
+        "gradient_allreduce": ("none (single GPU)" if world == 1 else
+                               ("p2p one-shot over IPC-mapped peer buffers (p2p.hip), validated against RCCL at start-up"
+                                if getattr(pol, "_p2p", None) is not None else "RCCL all-reduce (torch.distributed)")),
         "final_loss": float(pol.losses[0]),
         "mean_episode_len_last_rollout": round(
             (N_ENVS * T_ROLLOUT) / max(1.0, float(pol.trajectory.terminal.sum())), 2),
@@ -532,6 +535,8 @@ def main():
         result["roofline"] = roofline_env_step(torch, rlhip)
         result["roofline_extra"] = roofline_extras(torch, rlhip)
         result["cpu_baseline"] = cpu_baseline()
+    if getattr(pol, "_p2p", None) is not None:
+        result["p2p_timeouts"] = bool(pol._p2p.failed())  # must be false: a timed-out exchange leaves the step unreduced
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

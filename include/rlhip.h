@@ -338,6 +338,24 @@ int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_sta
                           rlhip_ring* rb_host, int32_t* actions, float* q_out, float* obs_out, float* last_obs,
                           rlhip_stream_t stream);
 
+/* ------------------------------------- one-shot peer-to-peer all-reduce (multi-GPU learner) -- */
+/* The exchange step of the sharded learner: SUM of the small flat gradient over the ranks, inside ONE
+ * kernel on the caller's stream.  Each rank owns a comm buffer (uncached device memory, rlhip_p2p_comm_bytes(cap)
+ * bytes, zero-initialised) which every peer maps through HIP IPC; rlhip_p2p_allreduce_f32 publishes the local vector,
+ * waits for every rank's sequence flag and sums the buffers in rank order (bit-identical results on all ranks).
+ * seq = 1, 2, 3, ... must advance by one per call on every rank.  A wait that exceeds timeout_polls sets
+ * status_dev[0] = 1 and leaves `data` untouched.  The host mirror (rlhip.dist.P2PAllReduce) validates the path against
+ * the library all-reduce before using it and falls back to RCCL otherwise. */
+int32_t rlhip_p2p_alloc(int64_t bytes, void** out);
+int32_t rlhip_p2p_free(void* p);
+int32_t rlhip_p2p_export(void* p, uint8_t handle_out[64]);
+int32_t rlhip_p2p_import(const uint8_t handle[64], void** out);
+int32_t rlhip_p2p_close(void* p);
+int64_t rlhip_p2p_comm_bytes(int64_t cap);
+int32_t rlhip_p2p_allreduce_f32(float* data, int64_t n, int64_t cap, int32_t rank, int32_t world,
+                                void* const* comm_bufs_host, uint32_t seq, int64_t timeout_polls,
+                                int32_t* status_dev, rlhip_stream_t stream);
+
 /* ------------------------------------------------- one DQN vec-step as a single call -- */
 /* One trip round the body of `_run` (RLCore/src/core/run.jl:52-70) for Agent{QBasedPolicy{DQN}} on the vector
  * env: plan! (q_based_policy.jl:30-32) -> act! -> push!(agent, PostActStage) (agent_base.jl:56-59) ->

@@ -156,6 +156,13 @@ _PROTOS = {
     "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
                                   vp, vp]),
     "rlhip_dqn_vec_step_f32": (i32, [vp, vp]),
+    "rlhip_p2p_alloc": (i32, [i64, P(vp)]),
+    "rlhip_p2p_free": (i32, [vp]),
+    "rlhip_p2p_export": (i32, [vp, vp]),
+    "rlhip_p2p_import": (i32, [vp, P(vp)]),
+    "rlhip_p2p_close": (i32, [vp]),
+    "rlhip_p2p_comm_bytes": (i64, [i64]),
+    "rlhip_p2p_allreduce_f32": (i32, [vp, i64, i64, i32, i32, vp, u32, i64, vp, vp]),
     "rlhip_dqn_act_supported": (i32, [i32, i64, i64]),
     "rlhip_dqn_act_f32": (i32, [i32, vp, vp, i64, vp, i64, i64, i32, f64, u64, u32, u64, u32, P(Ring), vp, vp, vp, vp,
                                 vp]),

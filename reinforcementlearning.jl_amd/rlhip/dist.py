@@ -72,3 +72,105 @@ def params_checksum_equal(params, group=None):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     return bool((lo == hi).all())
+
+
+class P2PAllReduce:
+    """One-shot peer-to-peer sum all-reduce of a small flat f32 vector inside one kernel on the compute stream
+    (p2p.hip): every rank publishes its vector in an IPC-mapped uncached buffer and sums the world's buffers in rank
+    order.  `create()` returns None -- and the caller keeps using the library all-reduce -- unless every rank maps
+    every peer AND a self-test against torch.distributed's all-reduce passes on all ranks."""
+
+    TIMEOUT_POLLS = 1 << 24       # steady state: tens of seconds of polling before a rank gives up (status flag)
+    SELFTEST_TIMEOUT_POLLS = 1 << 20  # self-test: a path that does not work must fail within a few seconds
+
+    def __init__(self):
+        self.ok = False
+
+    @staticmethod
+    def _agree(flag, group, device):
+        import torch.distributed as dist
+
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+
+    @classmethod
+    def create(cls, group, cap, device):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from ._lib import call, lib
+
+        self = cls()
+        self.group, self.cap, self.device = group, int(cap), device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.seq = 0
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self._own, self._imported = C.c_void_p(), []
+        handle = None
+        try:
+            call("rlhip_p2p_alloc", int(lib.rlhip_p2p_comm_bytes(self.cap)), C.byref(self._own))
+            h = (C.c_uint8 * 64)()
+            call("rlhip_p2p_export", self._own, h)
+            handle = bytes(h)
+        except Exception:  # noqa: BLE001 -- any failure means "use the library collective"
+            handle = None
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, handle, group=group)
+        good = all(g is not None for g in gathered)
+        self.peers = (C.c_void_p * self.world)()
+        if good:
+            try:
+                for p in range(self.world):
+                    if p == self.rank:
+                        self.peers[p] = self._own
+                    else:
+                        q = C.c_void_p()
+                        call("rlhip_p2p_import", (C.c_uint8 * 64).from_buffer_copy(gathered[p]), C.byref(q))
+                        self._imported.append(q)
+                        self.peers[p] = q
+            except Exception:  # noqa: BLE001
+                good = False
+        if not cls._agree(good, group, device):
+            return None
+        # self-test against the library all-reduce: same sums (up to summation order), bit-identical across ranks
+        passed = True
+        try:
+            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+            for _ in range(3):
+                x = torch.randn(min(self.cap, 4099), generator=g).to(device)
+                ref = x.clone()
+                dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=group)
+                y = x.clone()
+                self.all_reduce_(y, timeout_polls=cls.SELFTEST_TIMEOUT_POLLS)
+                torch.cuda.synchronize()
+                if int(self.status.item()) != 0 or not torch.allclose(y, ref, rtol=1e-5, atol=1e-5):
+                    passed = False
+                    break
+                lo, hi = y.clone(), y.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+                if not torch.equal(lo, hi):
+                    passed = False
+                    break
+        except Exception:  # noqa: BLE001
+            passed = False
+        if not cls._agree(passed, group, device):
+            return None
+        self.ok = True
+        return self
+
+    def all_reduce_(self, t, timeout_polls=None):
+        """in-place SUM over the ranks; t: contiguous f32 device tensor with numel <= cap"""
+        from ._lib import call
+        from .ops import ptr, stream_ptr
+
+        self.seq += 1
+        call("rlhip_p2p_allreduce_f32", ptr(t), t.numel(), self.cap, self.rank, self.world, self.peers, self.seq,
+             timeout_polls or self.TIMEOUT_POLLS, ptr(self.status), stream_ptr())
+        return t
+
+    def failed(self):
+        """True if any all-reduce since the last check timed out (synchronises)."""
+        return int(self.status.item()) != 0

@@ -11,6 +11,7 @@ device buffers (torch) and counters, and -- for multi-GPU -- inserts the RCCL al
 gradient between the gradient kernel and the clip+Adam kernel.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -200,15 +201,33 @@ class PPOPolicy:
         else:
             import torch.distributed as dist
 
+            p2p = self._p2p_allreduce(world)
             for e in range(self.cfg.n_epochs):
                 epoch_ctr = self.update_ctr * self.cfg.n_epochs + e
                 for mb in range(self.cfg.n_microbatches):
                     self.grad_(epoch_ctr, mb, records_fresh=(e > 0 or mb > 0))
                     # gradient all-reduce BEFORE the global-norm clip, so the clip sees the global
                     # gradient (mean over shards == single-GPU semantics with a world-times larger batch)
-                    dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+                    if p2p is not None:
+                        p2p.all_reduce_(self.grad)  # one kernel on this stream (p2p.hip), sums in rank order
+                    else:
+                        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                     self.apply_(grad_scale=1.0 / world)
         self.update_ctr += 1
+
+    def _p2p_allreduce(self, world):
+        """The validated one-shot peer-to-peer all-reduce for this policy's gradient, or None (library all-reduce):
+        created on first use; RLHIP_NO_P2P=1 disables it; any failure to map the peers or to pass the self-test
+        against torch.distributed's all-reduce on ANY rank makes every rank fall back."""
+        if world <= 1 or self.process_group is None:
+            return None
+        if not hasattr(self, "_p2p"):
+            self._p2p = None
+            if os.environ.get("RLHIP_NO_P2P", "0") != "1":
+                from .dist import P2PAllReduce
+
+                self._p2p = P2PAllReduce.create(self.process_group, self.np, self.params.device)
+        return self._p2p
 
     # ----------------------------------------------------------------- HIP-graph protocol
     def sync_counters_(self):

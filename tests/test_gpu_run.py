@@ -209,3 +209,55 @@ def test_device_episode_stats_hook_matches_host_hooks():
     rlhip.run(pol, env, rlhip.StopAfterNSteps(60), small)
     with pytest.raises(OverflowError):
         small.records()
+
+
+def _p2p_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "reinforcementlearning.jl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    import rlhip  # noqa: F401
+    from rlhip.dist import P2PAllReduce
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    p2p = P2PAllReduce.create(dist.group.WORLD, 3331, torch.device("cuda"))
+    ok = p2p is not None
+    outs = []
+    if ok:
+        g = torch.Generator(device="cpu").manual_seed(100 + rank)
+        for it in range(40):  # many back-to-back calls: exercises the double buffering
+            x = torch.randn(3331, generator=g).cuda()
+            outs.append((x.cpu().numpy(), p2p.all_reduce_(x.clone()).cpu().numpy()))
+        ok = not p2p.failed()
+    q.put((rank, ok, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_p2p_allreduce_two_ranks_one_gpu():
+    """one-shot IPC all-reduce (p2p.hip) between two processes sharing the GPU: passes its own self-test against
+    torch.distributed, then 40 back-to-back sums equal x0 + x1 exactly (rank-order summation) on both ranks"""
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, ok0, o0), (_, ok1, o1) = res
+    assert ok0 and ok1, "the P2P path did not validate on this box (the product then uses the library all-reduce)"
+    for (x0, y0), (x1, y1) in zip(o0, o1):
+        assert np.array_equal(y0, y1) and np.array_equal(y0, x0 + x1)
