@@ -351,6 +351,8 @@ int32_t rlhip_p2p_free(void* p);
 int32_t rlhip_p2p_export(void* p, uint8_t handle_out[64]);
 int32_t rlhip_p2p_import(const uint8_t handle[64], void** out);
 int32_t rlhip_p2p_close(void* p);
+int32_t rlhip_p2p_can_access(int32_t peer_device);                                  /* hipDeviceCanAccessPeer */
+int32_t rlhip_p2p_probe(const void* p, int64_t byte_offset, uint32_t* value_out);   /* 4-byte D2H copy from a peer */
 int64_t rlhip_p2p_comm_bytes(int64_t cap);
 int32_t rlhip_p2p_allreduce_f32(float* data, int64_t n, int64_t cap, int32_t rank, int32_t world,
                                 void* const* comm_bufs_host, uint32_t seq, int64_t timeout_polls,

@@ -112,6 +112,24 @@ int32_t rlhip_p2p_close(void* p) {
     return RLHIP_OK;
 }
 
+/* 1 if the current device can address memory of `peer_device` (hipDeviceCanAccessPeer), also 1 for itself */
+int32_t rlhip_p2p_can_access(int32_t peer_device) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev == peer_device) return 1;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, peer_device) != hipSuccess) return 0;
+    return can ? 1 : 0;
+}
+
+/* host-driven probe of a mapped peer buffer: a 4-byte device-to-host copy from `p + byte_offset` (a broken mapping
+ * shows up as an error code here instead of a memory fault inside a kernel) */
+int32_t rlhip_p2p_probe(const void* p, int64_t byte_offset, uint32_t* value_out) {
+    RLHIP_REQUIRE(p && value_out && byte_offset >= 0, "bad arguments");
+    RLHIP_CHECK_HIP(hipMemcpy(value_out, (const char*)p + byte_offset, 4, hipMemcpyDeviceToHost));
+    return RLHIP_OK;
+}
+
 /* comm buffer layout: float slots[2][cap] | uint32 flags[2] (+ padding); bytes = rlhip_p2p_comm_bytes(cap) */
 int64_t rlhip_p2p_comm_bytes(int64_t cap) { return 2 * cap * (int64_t)sizeof(float) + 256; }
 

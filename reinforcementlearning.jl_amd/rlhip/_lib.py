@@ -161,6 +161,8 @@ _PROTOS = {
     "rlhip_p2p_export": (i32, [vp, vp]),
     "rlhip_p2p_import": (i32, [vp, P(vp)]),
     "rlhip_p2p_close": (i32, [vp]),
+    "rlhip_p2p_can_access": (i32, [i32]),
+    "rlhip_p2p_probe": (i32, [vp, i64, vp]),
     "rlhip_p2p_comm_bytes": (i64, [i64]),
     "rlhip_p2p_allreduce_f32": (i32, [vp, i64, i64, i32, i32, vp, u32, i64, vp, vp]),
     "rlhip_dqn_act_supported": (i32, [i32, i64, i64]),
@@ -222,7 +224,7 @@ for _name, (_res, _args) in _PROTOS.items():
     _f.restype = _res
     _f.argtypes = _args
     if _res is i32 and _name not in ("rlhip_abi_version", "rlhip_env_obs_dim", "rlhip_env_state_dim",
-                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported"):
+                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported", "rlhip_p2p_can_access"):
         _STATUS.add(_name)
 
 

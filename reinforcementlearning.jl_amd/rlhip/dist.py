@@ -117,19 +117,29 @@ class P2PAllReduce:
         except Exception:  # noqa: BLE001 -- any failure means "use the library collective"
             handle = None
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, handle, group=group)
-        good = all(g is not None for g in gathered)
+        my_dev = torch.cuda.current_device()
+        dist.all_gather_object(gathered, (handle, my_dev), group=group)
+        good = all(g is not None and g[0] is not None for g in gathered)
         self.peers = (C.c_void_p * self.world)()
         if good:
             try:
+                # no kernel touches a peer buffer before (1) the runtime says the devices can address each other and
+                # (2) a host-driven 4-byte copy from the mapped flags succeeded and read the zero they were set to
+                good = all(int(lib.rlhip_p2p_can_access(int(g[1]))) == 1 for g in gathered)
+                flags_off = 2 * self.cap * 4
                 for p in range(self.world):
+                    if not good:
+                        break
                     if p == self.rank:
                         self.peers[p] = self._own
                     else:
                         q = C.c_void_p()
-                        call("rlhip_p2p_import", (C.c_uint8 * 64).from_buffer_copy(gathered[p]), C.byref(q))
+                        call("rlhip_p2p_import", (C.c_uint8 * 64).from_buffer_copy(gathered[p][0]), C.byref(q))
                         self._imported.append(q)
                         self.peers[p] = q
+                        val = C.c_uint32(0xFFFFFFFF)
+                        call("rlhip_p2p_probe", q, flags_off, C.byref(val))
+                        good = good and val.value == 0
             except Exception:  # noqa: BLE001
                 good = False
         if not cls._agree(good, group, device):
