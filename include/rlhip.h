@@ -575,6 +575,16 @@ int32_t rlhip_ppo_grad_fresh_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, in
 int32_t rlhip_ppo_apply_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T, float* params,
                             float* grad, float* m, float* v, float* beta_pow, float grad_scale, void* workspace,
                             float* gn_out, rlhip_stream_t stream);
+/* optimise!(policy) of a policy sharded over `world` GPUs in ONE call: per optimiser step { rlhip_ppo_grad[_fresh]_f32
+ * -> rlhip_p2p_allreduce_f32 -> rlhip_ppo_apply_f32(grad_scale = 1 / world) }, 4 launches on one stream, no host work
+ * in between.  comm_bufs_host / comm_cap / status_dev / timeout_polls as rlhip_p2p_allreduce_f32; seq0 = the last
+ * sequence number used (the call consumes seq0 + 1 .. seq0 + n_epochs * n_microbatches). */
+int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                                 const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
+                                 float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,
+                                 float* grad_scratch, float* losses_out, int32_t rank, int32_t world,
+                                 void* const* comm_bufs_host, int64_t comm_cap, uint32_t seq0,
+                                 int64_t timeout_polls, int32_t* status_dev, rlhip_stream_t stream);
 /* n_epochs x n_microbatches of { grad -> clip_by_global_norm! -> Adam } enqueued back to back
  * (single-GPU optimise!; multi-GPU hosts call rlhip_ppo_grad_f32, all-reduce, rlhip_clip_adam_f32).
  * update_ctr = number of previous update calls. */

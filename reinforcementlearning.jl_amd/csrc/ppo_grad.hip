@@ -917,6 +917,44 @@ int32_t rlhip_ppo_apply_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     return RLHIP_OK;
 }
 
+extern "C" int32_t rlhip_p2p_allreduce_f32(float* data, int64_t n, int64_t cap, int32_t rank, int32_t world,
+                                           void* const* comm_bufs_host, uint32_t seq, int64_t timeout_polls,
+                                           int32_t* status_dev, rlhip_stream_t stream);
+
+/* optimise!(policy) of a SHARDED policy in one call: n_epochs x n_microbatches of { gradient of this rank's shard ->
+ * one-shot peer-to-peer SUM over the ranks (p2p.hip) -> clip (1 / world scale) + Adam + record refresh }, 4 launches per
+ * optimiser step on one stream, no host work in between.  seq0 = the last sequence number this rank used (the call
+ * consumes seq0 + 1 .. seq0 + n_epochs * n_microbatches). */
+int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                                 const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
+                                 uint64_t seed, uint32_t update_ctr, void* workspace, float* grad_scratch,
+                                 float* losses_out, int32_t rank, int32_t world, void* const* comm_bufs_host,
+                                 int64_t comm_cap, uint32_t seq0, int64_t timeout_polls, int32_t* status_dev,
+                                 rlhip_stream_t stream) {
+    RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch && comm_bufs_host && status_dev, "NULL argument");
+    RLHIP_REQUIRE(world >= 1, "bad world size");
+    const int64_t np = rlhip_ppo_nparams(kind, cfg);
+    RLHIP_REQUIRE(np > 0 && np <= comm_cap, "the gradient does not fit the comm buffer");
+    uint32_t seq = seq0;
+    bool first = true;
+    for (int32_t e = 0; e < cfg->n_epochs; ++e) {
+        const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
+        for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
+            int32_t rc = grad_entry(kind, cfg, n, T, traj, params, seed, epoch_ctr, nullptr, mb, workspace, grad_scratch,
+                                    losses_out, stream, /*do_pack=*/first);
+            if (rc) return rc;
+            first = false;
+            rc = rlhip_p2p_allreduce_f32(grad_scratch, np, comm_cap, rank, world, comm_bufs_host, ++seq, timeout_polls,
+                                         status_dev, stream);
+            if (rc) return rc;
+            rc = rlhip_ppo_apply_f32(kind, cfg, n, T, params, grad_scratch, m, v, beta_pow, 1.0f / (float)world, workspace,
+                                     nullptr, stream);
+            if (rc) return rc;
+        }
+    }
+    return RLHIP_OK;
+}
+
 int32_t rlhip_ppo_grad_dc_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
                               const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_local,
                               const uint32_t* counters, int32_t mb, void* workspace, float* grad_out,

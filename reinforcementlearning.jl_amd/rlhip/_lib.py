@@ -201,6 +201,8 @@ _PROTOS = {
                                  vp]),
     "rlhip_ppo_grad_fresh_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, i32, vp, vp, vp,
                                  vp]),
+    "rlhip_ppo_update_p2p_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp, vp, vp, i32,
+                                       i32, vp, i64, u32, i64, vp, vp]),
     "rlhip_ppo_apply_f32": (i32, [i32, P(PPOCfg), i64, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp]),
     "rlhip_ppo_update_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp,
                                    vp, vp, vp]),

@@ -202,6 +202,16 @@ class PPOPolicy:
             import torch.distributed as dist
 
             p2p = self._p2p_allreduce(world)
+            if p2p is not None and self.layers == 2 and os.environ.get("RLHIP_P2P_HOST_LOOP", "0") != "1":
+                # the whole sharded update as one C call: grad -> p2p exchange -> apply per optimiser step
+                n_steps = self.cfg.n_epochs * self.cfg.n_microbatches
+                call("rlhip_ppo_update_p2p_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
+                     C.byref(self.trajectory.c), ptr(self.params), ptr(self.m), ptr(self.v), ptr(self.beta_pow),
+                     self.seed, self.update_ctr, ptr(self.workspace), ptr(self.grad), ptr(self.losses), p2p.rank,
+                     p2p.world, p2p.peers, p2p.cap, p2p.seq, p2p.TIMEOUT_POLLS, ptr(p2p.status), stream_ptr())
+                p2p.seq += n_steps
+                self.update_ctr += 1
+                return
             for e in range(self.cfg.n_epochs):
                 epoch_ctr = self.update_ctr * self.cfg.n_epochs + e
                 for mb in range(self.cfg.n_microbatches):
