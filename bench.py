@@ -358,6 +358,7 @@ def kernel_breakdown(torch, rlhip, pol, env):
     lib = rlhip._lib.lib
     out = {}
     saved = [t.clone() for t in (pol.params, pol.m, pol.v, pol.beta_pow)]
+    pol.gae_()  # first launch of the stand-alone scan in this process (the timed workload uses the fused one)
     out["rollout_T32_us"] = round(event_time_ms(pol.rollout_, 5, lib, s) * 1e3, 2)
     out["gae_returns_us"] = round(event_time_ms(pol.gae_, 5, lib, s) * 1e3, 2)
     n_upd = pol.n_updates_per_call()
