@@ -484,8 +484,19 @@ struct ApplyArgs {
 // global norm from the per-block partials, clips, and runs Adam on all parameters -- one launch instead
 // of reduce + clip_adam.
 constexpr int RP = 64;  // parameters per reduce workgroup (x 16 partial-groups = 1024 threads)
-constexpr int APPLY_NONE = 0, APPLY_LAST = 1, APPLY_GRID = 2;
+constexpr int APPLY_NONE = 0, APPLY_LAST = 1, APPLY_GRID = 2, APPLY_XCHG = 3;
 constexpr int GRID_APPLY_MAX_BLOCKS = 128;  // all workgroups must be co-resident for the spin barrier (256 CUs x 2)
+
+// peer exchange of the sharded learner fused into the reduce + apply kernel (APPLY_XCHG; protocol: p2p.hip)
+struct XchgArgs {
+    float* slot[16];          // comm buffer of every rank (two slots of `cap` floats, then two u32 flags)
+    unsigned int* flags[16];
+    int rank, world, cap;
+    unsigned int seq;
+    long long timeout_polls;
+    int* status;
+    float inv_world;
+};
 
 // position of flat parameter q in the unit-record copy (see pack_records)
 __device__ __forceinline__ int64_t record_slot(int64_t q, int h, int ns, int nout, int64_t np_a) {
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
                                                             const float* __restrict__ loss_partials, int nb,
                                                             int np, float* __restrict__ grad,
                                                             float* __restrict__ losses, float wa, float wc,
-                                                            float we, float inv_b, ApplyArgs ap) {
+                                                            float we, float inv_b, ApplyArgs ap, XchgArgs xa) {
     __shared__ float l_g[16][RP];
     __shared__ float l_loss[4];
     __shared__ double l_d[16];
@@ -556,6 +567,95 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         }
     }
     if (APPLY == APPLY_NONE) return;
+
+    if (APPLY == APPLY_XCHG) {
+        // ---- sharded learner: exchange this workgroup's 64 gradient values with the peers, then clip + Adam ----
+        // publish -> local grid barrier -> rank flag (system-scope release) -> poll the peers' flags -> sum the world's
+        // slices in rank order (x 1 / world) -> sum of squares -> second grid barrier -> norm -> Adam on the own slice.
+        // Counters: ap.counter[0] arrive (publish), [2] arrive (norm), [1] depart.  Same protocol as p2p.hip.
+        if (wv != 0) return;
+        const bool own = p < np;
+        const int par = (int)(xa.seq & 1u);
+        const float m0 = own ? ap.m[p] : 0.0f, v0 = own ? ap.v[p] : 0.0f, p0 = own ? ap.params[p] : 0.0f;
+        const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+        if (own) __builtin_nontemporal_store(gsum, xa.slot[xa.rank] + (int64_t)par * xa.cap + p);
+        __threadfence_system();
+        int fail = 0;
+        if (lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) {  // the rank's flag goes up when all of its workgroups have published
+                while (__hip_atomic_load(ap.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+                    __builtin_amdgcn_s_sleep(1);
+                __threadfence_system();
+                __hip_atomic_store(xa.flags[xa.rank] + par, xa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            for (int q = 0; q < xa.world && !fail; ++q) {
+                long long polls = 0;
+                while (__hip_atomic_load(xa.flags[q] + par, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != xa.seq) {
+                    if (++polls > xa.timeout_polls) {
+                        fail = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (fail) xa.status[0] = 1;
+        }
+        fail = __shfl(fail, 0, 64);
+        __threadfence_system();
+        float gx = 0.0f;
+        if (own && !fail) {
+            for (int q = 0; q < xa.world; ++q) gx += __builtin_nontemporal_load(xa.slot[q] + (int64_t)par * xa.cap + p);
+            gx *= xa.inv_world;
+        }
+        double sq = (double)gx * (double)gx;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (lane == 0) {
+            ap.sumsq[blockIdx.x] = sq;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ap.counter + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(ap.counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double part = 0.0;
+        for (int b = lane; b < (int)gridDim.x; b += 64)
+            part += __hip_atomic_load(ap.sumsq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        const float gn = (float)sqrt(part);
+        const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+        if (own && !fail) {
+            float g1 = gx;
+            if (scale != 1.0f) g1 *= scale;
+            const float mi = ap.b1 * m0 + (1.0f - ap.b1) * g1;  // Optimisers.Adam, expression order of optim.hip adam1
+            const float vi = ap.b2 * v0 + (1.0f - ap.b2) * (g1 * g1);
+            const float d = mi / c1 / (sqrtf(vi / c2) + ap.eps) * ap.lr;
+            const float pn = p0 - d;
+            ap.m[p] = mi;
+            ap.v[p] = vi;
+            ap.params[p] = pn;
+            grad[p] = g1;
+            ap.packed[record_slot(p, ap.h, ap.ns, ap.nout, ap.np_a)] = pn;
+        }
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1) {
+                if (!fail) {
+                    ap.beta_pow[0] *= ap.b1;
+                    ap.beta_pow[1] *= ap.b2;
+                }
+                __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ap.counter + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
 
     // per-block partial sum of squares (threads 0..RP-1 of wave 0 hold this block's gradient values)
     if (wv == 0) {
@@ -873,7 +973,7 @@ static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int
     ApplyArgs ap{};
     hipLaunchKernelGGL((reduce_apply_kernel<APPLY_NONE>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
                        L.g.loss_partials, L.nb, (int)L.np, grad_out, losses_out, L.g.wa, L.g.wc, L.g.we, L.g.inv_b,
-                       ap);
+                       ap, XchgArgs{});
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -937,9 +1037,42 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
     RLHIP_REQUIRE(np > 0 && np <= comm_cap, "the gradient does not fit the comm buffer");
     uint32_t seq = seq0;
     bool first = true;
+    const int rblocks = (int)((np + RP - 1) / RP);
+    const bool fused = !is_layers3(cfg) && rblocks <= GRID_APPLY_MAX_BLOCKS && world <= 16 && comm_cap <= (1 << 24) &&
+                       !getenv("RLHIP_P2P_UNFUSED");
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
+            if (fused) {
+                // grad kernel, then ONE kernel: partial sums -> peer exchange -> clip -> Adam -> record patch
+                GradLaunch L;
+                int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, nullptr);
+                if (rc) return rc;
+                hipStream_t s = as_stream(stream);
+                if (first) launch_pack(L, s);
+                first = false;
+                launch_grad(L, s);
+                ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
+                             L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
+                XchgArgs xa{};
+                for (int q = 0; q < world; ++q) {
+                    RLHIP_REQUIRE(comm_bufs_host[q] != nullptr, "peer buffer is NULL");
+                    xa.slot[q] = (float*)comm_bufs_host[q];
+                    xa.flags[q] = (unsigned int*)((float*)comm_bufs_host[q] + 2 * comm_cap);
+                }
+                xa.rank = rank;
+                xa.world = world;
+                xa.cap = (int)comm_cap;
+                xa.seq = ++seq;
+                xa.timeout_polls = timeout_polls;
+                xa.status = status_dev;
+                xa.inv_world = 1.0f / (float)world;
+                hipLaunchKernelGGL((reduce_apply_kernel<APPLY_XCHG>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
+                                   L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
+                                   L.g.inv_b, ap, xa);
+                RLHIP_LAUNCH_CHECK();
+                continue;
+            }
             int32_t rc = grad_entry(kind, cfg, n, T, traj, params, seed, epoch_ctr, nullptr, mb, workspace, grad_scratch,
                                     losses_out, stream, /*do_pack=*/first);
             if (rc) return rc;
@@ -995,11 +1128,11 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             if (rblocks <= GRID_APPLY_MAX_BLOCKS && !getenv("RLHIP_APPLY_LAST_ARRIVER"))
                 hipLaunchKernelGGL((reduce_apply_kernel<APPLY_GRID>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
                                    L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
-                                   L.g.inv_b, ap);
+                                   L.g.inv_b, ap, XchgArgs{});
             else
                 hipLaunchKernelGGL((reduce_apply_kernel<APPLY_LAST>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
                                    L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
-                                   L.g.inv_b, ap);
+                                   L.g.inv_b, ap, XchgArgs{});
         }
     }
     RLHIP_LAUNCH_CHECK();

@@ -91,7 +91,8 @@ def _free_port():
     return p
 
 
-def _gpu_worker(rank, world, port, q):
+def _gpu_worker(rank, world, port, q, extra_env=None):
+    os.environ.update(extra_env or {})
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import sys
@@ -116,18 +117,24 @@ def _gpu_worker(rank, world, port, q):
     pol.update_()
     torch.cuda.synchronize()
     same = rdist.params_checksum_equal(pol.params.cpu(), dist.group.WORLD)
-    q.put((rank, pol.params.cpu().numpy(), pol.trajectory.obs.cpu().numpy(), same))
+    q.put((rank, pol.params.cpu().numpy(), pol.trajectory.obs.cpu().numpy(), same and (
+        (getattr(pol, "_p2p", None) is not None) == (os.environ.get("RLHIP_NO_P2P", "0") != "1"))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_gradient_allreduce(rl):
+@pytest.mark.parametrize("mode", ["p2p_fused", "p2p_unfused", "p2p_host_loop", "library_allreduce"])
+def test_two_ranks_one_gpu_gradient_allreduce(rl, mode):
+    """every variant of the exchange step: the fused reduce + peer exchange + clip + Adam kernel, the separate p2p
+    kernel (one C call / host loop), and the torch.distributed all-reduce fallback"""
     import torch.multiprocessing as mp
 
+    extra = {"p2p_fused": {}, "p2p_unfused": {"RLHIP_P2P_UNFUSED": "1"}, "p2p_host_loop": {"RLHIP_P2P_HOST_LOOP": "1"},
+             "library_allreduce": {"RLHIP_NO_P2P": "1"}}[mode]
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, extra)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
