@@ -543,6 +543,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        if getattr(pol, "_p2p", None) is not None:
+            pol._p2p.close()
         dist.destroy_process_group()
 
 

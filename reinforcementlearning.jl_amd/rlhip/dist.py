@@ -181,6 +181,31 @@ class P2PAllReduce:
              timeout_polls or self.TIMEOUT_POLLS, ptr(self.status), stream_ptr())
         return t
 
+    def close(self):
+        """unmap the peers, then (after every rank has unmapped) free the own buffer; collective"""
+        import torch.distributed as dist
+
+        from ._lib import call
+
+        torch.cuda.synchronize()
+        for q in self._imported:
+            try:
+                call("rlhip_p2p_close", q)
+            except Exception:  # noqa: BLE001
+                pass
+        self._imported = []
+        try:
+            dist.barrier(group=self.group)
+        except Exception:  # noqa: BLE001
+            pass
+        if self._own:
+            try:
+                call("rlhip_p2p_free", self._own)
+            except Exception:  # noqa: BLE001
+                pass
+            self._own = None
+        self.ok = False
+
     def failed(self):
         """True if any all-reduce since the last check timed out (synchronises)."""
         return int(self.status.item()) != 0
