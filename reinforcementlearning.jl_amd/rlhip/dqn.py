@@ -261,7 +261,17 @@ class DQNLearner:
 
             world = dist.get_world_size(self.process_group)
             if world > 1:
-                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+                if not hasattr(self, "_p2p"):  # validated one-shot peer exchange (p2p.hip) or None -> library
+                    import os
+
+                    from .dist import P2PAllReduce
+
+                    self._p2p = None if os.environ.get("RLHIP_NO_P2P", "0") == "1" else \
+                        P2PAllReduce.create(self.process_group, self.grad.numel(), self.grad.device)
+                if self._p2p is not None:
+                    self._p2p.all_reduce_(self.grad)
+                else:
+                    dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                 scale = 1.0 / world
         self.approximator.optimise_(self.grad, clip_norm=self.max_grad_norm, grad_scale=scale)
         self.n_updates += 1
