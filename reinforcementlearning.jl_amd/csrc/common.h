@@ -3,6 +3,7 @@
 // Error model of the C ABI: every entry point returns int32 (0 = RLHIP_OK, <0 = error) and stores
 // a message readable through rlhip_last_error() (thread-local).  No exceptions cross the boundary.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -59,6 +60,13 @@ enum : uint32_t {
     TAG_INIT = 6,
     TAG_SYNTH = 7
 };
+
+// development switches are read from the environment once per process
+#define RLHIP_ENV_FLAG(name)                          \
+    ([]() -> bool {                                   \
+        static const bool v_ = getenv(name) != nullptr; \
+        return v_;                                    \
+    }())
 
 // Cross-lane sums without the LDS crossbar where the hardware allows it: DPP adds inside a 16-lane row (quad xor 1,
 // quad xor 2, half-row mirror, row mirror), ds_swizzle for lane ^ 16, one ds_bpermute for lane ^ 32.  Every lane ends

@@ -47,7 +47,7 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
     const int64_t ns = rlhip_env_obs_dim(a->kind);
     RLHIP_REQUIRE(ns == a->ring->obs_dim && a->n == a->ring->n_env, "ring geometry does not match the env");
     int32_t rc;
-    if (a->layers == 2 && rlhip_dqn_act_supported(a->kind, a->n, a->h) && !getenv("RLHIP_DQN_UNFUSED_ACT")) {
+    if (a->layers == 2 && rlhip_dqn_act_supported(a->kind, a->n, a->h) && !RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_ACT")) {
         // plan! + act! + push! in one launch (dqn_act.hip): same device functions, same slots, bit-identical
         rc = rlhip_dqn_act_f32(a->kind, a->env_cfg, a->st, a->n, a->params, a->h, a->na, a->act, a->eps,
                                a->explorer_seed, a->explorer_step, a->env_seed, a->env_id_base, a->ring, a->actions,

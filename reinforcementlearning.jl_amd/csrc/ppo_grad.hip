@@ -1039,7 +1039,7 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
     bool first = true;
     const int rblocks = (int)((np + RP - 1) / RP);
     const bool fused = !is_layers3(cfg) && rblocks <= GRID_APPLY_MAX_BLOCKS && world <= 16 && comm_cap <= (1 << 24) &&
-                       !getenv("RLHIP_P2P_UNFUSED");
+                       !RLHIP_ENV_FLAG("RLHIP_P2P_UNFUSED");
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
@@ -1125,7 +1125,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                          L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
             const int rblocks = (int)((L.np + RP - 1) / RP);
-            if (rblocks <= GRID_APPLY_MAX_BLOCKS && !getenv("RLHIP_APPLY_LAST_ARRIVER"))
+            if (rblocks <= GRID_APPLY_MAX_BLOCKS && !RLHIP_ENV_FLAG("RLHIP_APPLY_LAST_ARRIVER"))
                 hipLaunchKernelGGL((reduce_apply_kernel<APPLY_GRID>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
                                    L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
                                    L.g.inv_b, ap, XchgArgs{});
