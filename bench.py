@@ -8,7 +8,7 @@
 One "step" = one PPO iteration of the hot path on every GPU: fused rollout of T = 32 vec-steps of 4096
 CartPole envs (actor/critic forward, Gumbel-max sampling, env step + auto-reset, trajectory writes),
 GAE + returns, then 4 epochs x 4 micro-batches of { clipped-surrogate loss + gradient ->
-[RCCL all-reduce of the flat gradient when N > 1] -> clip_by_global_norm -> Adam }.  Nothing is
+[all-reduce of the flat gradient when N > 1: one-shot peer-to-peer exchange fused into the reduce kernel, RCCL as fallback] -> clip_by_global_norm -> Adam }.  Nothing is
 skipped inside the timed region; inputs (env state, parameters) are resident in HBM when it starts.
 Workload = BASELINE.json configs[3] per GPU (the config the metric is quoted on; configs[1] is its
 DQN sibling and is measured in the `extra` block), synthetic data: random-init weights, Philox-seeded
@@ -521,7 +521,7 @@ def main():
                    "actor": f"4->{HIDDEN}->2 relu", "critic": f"4->{HIDDEN}->1 relu", "n_params": pol.np,
                    "n_epochs": pol.cfg.n_epochs, "n_microbatches": pol.cfg.n_microbatches,
                    "microbatch": (N_ENVS * T_ROLLOUT) // pol.cfg.n_microbatches,
-                   "parallelism": f"env-shards x{world}, flat-gradient all-reduce (RCCL) per micro-batch" if world > 1
+                   "parallelism": f"env-shards x{world}, flat-gradient all-reduce per optimiser step (see gradient_allreduce)" if world > 1
                    else "single GPU"},
         "launch_mode": mode,
         "gradient_allreduce": ("none (single GPU)" if world == 1 else
