@@ -250,7 +250,7 @@ def roofline_extras(torch, rlhip):
     out["dqn_cartpole_4096env"]["fused_vec_step"] = {
         "env_steps_per_sec": round(n * steps_f / el, 1), "updates_per_sec": round(steps_f / el, 1),
         "ms_per_vec_step": round(el / steps_f * 1e3, 4),
-        "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then grad, reduce, clip+Adam -- bit-identical to the per-step protocol"}
+        "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then grad, then reduce + clip + Adam (3 launches per vec-step) -- bit-identical to the per-step protocol"}
     del agent, policy, learner, net, env
     # same config with the blog's 3-layer Q-network 4 -> 128 -> 128 -> 2, hidden layer on the bf16 MFMA (dqn3.hip)
     env = rlhip.CartPoleEnv(n, seed=5)

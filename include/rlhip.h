@@ -617,13 +617,21 @@ int32_t rlhip_counters_advance(uint32_t* counters, uint32_t d_vec_step, uint32_t
 /* BasicDQN / DQN learner (removed Zoo; spec docs/src/rlcore.md:28, blog index.html:15121-15147):
  * q-net and target-net = mlp2 (ns -> h -> na).  One launch samples `batch` transitions from the ring
  * (BatchSampler draw `draw_ctr`), computes the TD target with the target net, the Huber loss and the
- * flat gradient.  workspace bytes: rlhip_dqn_workspace_bytes. */
+ * flat gradient.  workspace bytes: rlhip_dqn_workspace_bytes (allocate it zeroed: see rlhip_dqn_update_f32). */
 int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch);
 int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act,
                            const float* params, const float* target_params, int64_t batch,
                            float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr,
                            void* workspace, float* grad_out, float* loss_out,
                            rlhip_stream_t stream);
+/* optimise!(learner, batch) complete -- gradient, then reduce + clip-by-global-norm + Adam -- in two launches;
+ * bit-identical to rlhip_dqn_grad_f32 followed by rlhip_clip_adam_f32 (which is what runs for > 4096 parameters).
+ * The last 64 bytes of `workspace` are its arrival counters: zero before the first call, re-armed by every call. */
+int32_t rlhip_dqn_update_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act, float* params,
+                             const float* target_params, int64_t batch, float gamma, float huber_delta,
+                             uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,
+                             float* m, float* v, float* beta_pow, float grad_scale, float max_grad_norm, float lr,
+                             float beta1, float beta2, float adam_eps, float* gn_out, rlhip_stream_t stream);
 /* The same learner step on explicit flat logical indices (e.g. from rlhip_ring_sample_prioritized, the prioritized
  * BatchSampler of RLTrajectories 0.4) with |Q(s,a) - y| per sample returned for the priority write-back. */
 int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act,

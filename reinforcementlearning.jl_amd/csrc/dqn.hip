@@ -17,6 +17,7 @@
 // indices are drawn inline from the SAMPLER Philox stream and the transitions are gathered straight
 // from the HBM ring into LDS -- the sampled batch is never materialised in HBM.
 #include "mlp_device.h"
+#include "optim_device.h"
 #include "select_device.h"
 
 extern "C" int64_t rlhip_mlp2_nparams(int64_t n_in, int64_t h, int64_t n_out);
@@ -253,6 +254,103 @@ __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict
     }
 }
 
+// optimise! tail in ONE launch: the partial reduction of dqn_reduce_kernel, then -- in the workgroup that arrives
+// last -- the body of clip_adam_kernel<4> (optim.hip): same element-to-thread mapping (thread t owns t + 1024 k),
+// same Float64 block sum, same Adam expression order, so parameters / moments / gradient are bit-identical to
+// "rlhip_dqn_grad_f32 then rlhip_clip_adam_f32".  Host: np <= 4096 only (the <4> regime of rlhip_clip_adam_f32).
+struct DqnApply {
+    float* p;
+    float* m;
+    float* v;
+    float* beta_pow;
+    float* gn_out;
+    unsigned int* counter;  // arrival counter in the workspace tail: zero before the first launch, re-armed here
+    float grad_scale, clip_norm, lr, b1, b2, eps;
+};
+
+__global__ __launch_bounds__(1024) void dqn_reduce_apply_kernel(const float* __restrict__ partials,
+                                                                const float* __restrict__ loss_partials, int nb,
+                                                                int np, float* __restrict__ grad,
+                                                                float* __restrict__ loss, float inv_b, DqnApply ap) {
+    __shared__ float l_g[4][64];
+    __shared__ double scratch[16];
+    __shared__ int l_last;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    if (grp < 4) {  // identical to dqn_reduce_kernel: four groups of partial blocks, then ((g0 + g1) + g2) + g3
+        const int p = blockIdx.x * 64 + lane;
+        const int per = (nb + 3) / 4;
+        const int b0 = grp * per, b1 = min(nb, b0 + per);
+        float acc = 0.f;
+        if (p < np) {
+#pragma unroll 8
+            for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + p];
+        }
+        l_g[grp][lane] = acc;
+    }
+    __syncthreads();
+    if (grp == 0) {
+        const int p = blockIdx.x * 64 + lane;
+        if (p < np) grad[p] = ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane];
+    }
+    if (blockIdx.x == 0 && loss != nullptr && grp == 1) {
+        float a = 0.f;
+        for (int b = lane; b < nb; b += 64) a += loss_partials[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) loss[0] = a * inv_b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int prev = __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        l_last = (prev == gridDim.x - 1) ? 1 : 0;
+        if (l_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        }
+    }
+    __syncthreads();
+    if (!l_last) return;
+    // ---- clip_adam_kernel<4> ----
+    constexpr int PER_THREAD = 4;
+    float gr[PER_THREAD], pr[PER_THREAD], mr[PER_THREAD], vr[PER_THREAD];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = k * 1024 + (int)threadIdx.x;
+        const bool in = i < np;
+        const float x = in ? __hip_atomic_load(grad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * ap.grad_scale : 0.0f;
+        gr[k] = x;
+        pr[k] = in ? ap.p[i] : 0.0f;  // operands of the Adam phase: in flight during the block sum
+        mr[k] = in ? ap.m[i] : 0.0f;
+        vr[k] = in ? ap.v[i] : 0.0f;
+        acc += (double)x * (double)x;
+    }
+    const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+    acc = block_sum(acc, scratch);
+    const float gn = (float)sqrt(acc);
+    const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = k * 1024 + (int)threadIdx.x;
+        if (i < np) {
+            const float gi = (scale == 1.0f) ? gr[k] : gr[k] * scale;
+            float pi = pr[k], mi = mr[k], vi = vr[k];
+            adam1(pi, gi, mi, vi, ap.lr, ap.b1, ap.b2, ap.eps, c1, c2);
+            ap.p[i] = pi;
+            ap.m[i] = mi;
+            ap.v[i] = vi;
+            grad[i] = gi;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (ap.gn_out) ap.gn_out[0] = gn;
+        ap.beta_pow[0] *= ap.b1;  // every thread has read beta_pow before the block_sum barrier
+        ap.beta_pow[1] *= ap.b2;
+    }
+}
+
 struct RegQ {
     const float* q;
     __device__ __forceinline__ float operator()(int k) const { return q[k]; }
@@ -340,13 +438,14 @@ extern "C" {
 int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
     (void)batch;
     int64_t np = mlp2_nparams(ns, h, na);
-    return (int64_t)DQN_MAX_BLOCKS * (np + 1) * (int64_t)sizeof(float);
+    // partials | loss partials | 64 B of counters for rlhip_dqn_update_f32 (zero before the first use)
+    return (int64_t)DQN_MAX_BLOCKS * (np + 1) * (int64_t)sizeof(float) + 64;
 }
 
 static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
                              const float* target_params, int64_t batch, const int64_t* idx, float gamma,
                              float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
-                             float* loss_out, float* td_out, rlhip_stream_t stream) {
+                             float* loss_out, float* td_out, rlhip_stream_t stream, DqnApply* apply = nullptr) {
     RLHIP_REQUIRE(rb && params && target_params && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
@@ -391,8 +490,14 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
     else if (ns == 3) { if (act == 0) LAUNCH_DG(3, 0); else LAUNCH_DG(3, 1); }
     else { if (act == 0) LAUNCH_DG(2, 0); else LAUNCH_DG(2, 1); }
 #undef LAUNCH_DG
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
-                       nb, (int)np, grad_out, loss_out, g.inv_b);
+    if (apply) {
+        apply->counter = (unsigned int*)(g.loss_partials + DQN_MAX_BLOCKS);
+        hipLaunchKernelGGL(dqn_reduce_apply_kernel, dim3((int)((np + 63) / 64)), dim3(1024), 0, s, g.partials,
+                           g.loss_partials, nb, (int)np, grad_out, loss_out, g.inv_b, *apply);
+    } else {
+        hipLaunchKernelGGL(dqn_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
+                           nb, (int)np, grad_out, loss_out, g.inv_b);
+    }
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -403,6 +508,30 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t 
                            rlhip_stream_t stream) {
     return dqn_grad_impl(rb, h, na, act, params, target_params, batch, nullptr, gamma, huber_delta, seed, draw_ctr,
                          workspace, grad_out, loss_out, nullptr, stream);
+}
+
+int32_t rlhip_clip_adam_f32(float*, float*, float*, float*, float*, int64_t, float, float, float, float, float, float,
+                            float*, rlhip_stream_t);
+
+/* optimise!(learner, batch) in two launches: gradient partials, then reduce + clip + Adam (bit-identical to
+ * rlhip_dqn_grad_f32 followed by rlhip_clip_adam_f32, which is what runs when the network has > 4096 parameters) */
+int32_t rlhip_dqn_update_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, float* params,
+                             const float* target_params, int64_t batch, float gamma, float huber_delta, uint64_t seed,
+                             uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* m, float* v,
+                             float* beta_pow, float grad_scale, float max_grad_norm, float lr, float beta1, float beta2,
+                             float adam_eps, float* gn_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && m && v && beta_pow, "NULL argument");
+    const int64_t np = mlp2_nparams(rb->obs_dim, h, na);
+    if (np > 4096) {
+        int32_t rc = dqn_grad_impl(rb, h, na, act, params, target_params, batch, nullptr, gamma, huber_delta, seed,
+                                   draw_ctr, workspace, grad_out, loss_out, nullptr, stream);
+        if (rc) return rc;
+        return rlhip_clip_adam_f32(params, grad_out, m, v, beta_pow, np, grad_scale, max_grad_norm, lr, beta1, beta2,
+                                   adam_eps, gn_out, stream);
+    }
+    DqnApply ap{params, m, v, beta_pow, gn_out, nullptr, grad_scale, max_grad_norm, lr, beta1, beta2, adam_eps};
+    return dqn_grad_impl(rb, h, na, act, params, target_params, batch, nullptr, gamma, huber_delta, seed, draw_ctr,
+                         workspace, grad_out, loss_out, nullptr, stream, &ap);
 }
 
 int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,

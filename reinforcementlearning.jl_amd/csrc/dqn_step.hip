@@ -21,6 +21,9 @@ int32_t rlhip_dqn_plan_f32(const float*, int64_t, int64_t, int64_t, int32_t, con
                            uint32_t, uint32_t, int32_t*, float*, rlhip_stream_t);
 int32_t rlhip_dqn3_plan_f32(const float*, const uint16_t*, int64_t, int64_t, int64_t, int32_t, const float*, int64_t,
                             double, uint64_t, uint32_t, uint32_t, int32_t*, float*, rlhip_stream_t);
+int32_t rlhip_dqn_update_f32(const rlhip_ring*, int64_t, int64_t, int32_t, float*, const float*, int64_t, float, float,
+                             uint64_t, uint32_t, void*, float*, float*, float*, float*, float*, float, float, float, float,
+                             float, float, float*, rlhip_stream_t);
 int32_t rlhip_dqn_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const float*, const float*, int64_t, float,
                            float, uint64_t, uint32_t, void*, float*, float*, rlhip_stream_t);
 int32_t rlhip_dqn3_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const float*, const uint16_t*, const float*,
@@ -73,20 +76,29 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
     if (!a->do_update) return RLHIP_OK;
     // optimise!(learner, trajectory): sample + TD target + Huber + gradient, then clip + Adam
     int64_t np;
-    if (a->layers == 2) {
+    if (a->layers == 2 && !RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_APPLY")) {
+        // gradient partials, then reduce + clip + Adam in one launch (bit-identical to the two calls below)
         np = rlhip_mlp2_nparams(ns, a->h, a->na);
-        rc = rlhip_dqn_grad_f32(a->ring, a->h, a->na, a->act, a->params, a->target, a->batch, a->gamma, a->huber_delta,
-                                a->sampler_seed, a->draw_ctr, a->workspace, a->grad, a->loss, stream);
+        rc = rlhip_dqn_update_f32(a->ring, a->h, a->na, a->act, a->params, a->target, a->batch, a->gamma, a->huber_delta,
+                                  a->sampler_seed, a->draw_ctr, a->workspace, a->grad, a->loss, a->m, a->v, a->beta_pow,
+                                  a->grad_scale, a->max_grad_norm, a->lr, a->beta1, a->beta2, a->adam_eps, a->gn, stream);
+        if (rc) return rc;
     } else {
-        np = rlhip_mlp3_nparams(ns, a->h, a->na);
-        rc = rlhip_dqn3_grad_f32(a->ring, a->h, a->na, a->act, a->params, a->packed, a->target, a->target_packed,
-                                 a->batch, nullptr, a->gamma, a->huber_delta, a->sampler_seed, a->draw_ctr,
-                                 a->workspace, a->grad, a->loss, nullptr, stream);
+        if (a->layers == 2) {
+            np = rlhip_mlp2_nparams(ns, a->h, a->na);
+            rc = rlhip_dqn_grad_f32(a->ring, a->h, a->na, a->act, a->params, a->target, a->batch, a->gamma,
+                                    a->huber_delta, a->sampler_seed, a->draw_ctr, a->workspace, a->grad, a->loss, stream);
+        } else {
+            np = rlhip_mlp3_nparams(ns, a->h, a->na);
+            rc = rlhip_dqn3_grad_f32(a->ring, a->h, a->na, a->act, a->params, a->packed, a->target, a->target_packed,
+                                     a->batch, nullptr, a->gamma, a->huber_delta, a->sampler_seed, a->draw_ctr,
+                                     a->workspace, a->grad, a->loss, nullptr, stream);
+        }
+        if (rc) return rc;
+        rc = rlhip_clip_adam_f32(a->params, a->grad, a->m, a->v, a->beta_pow, np, a->grad_scale, a->max_grad_norm, a->lr,
+                                 a->beta1, a->beta2, a->adam_eps, a->gn, stream);
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    rc = rlhip_clip_adam_f32(a->params, a->grad, a->m, a->v, a->beta_pow, np, a->grad_scale, a->max_grad_norm, a->lr,
-                             a->beta1, a->beta2, a->adam_eps, a->gn, stream);
-    if (rc) return rc;
     if (a->layers == 3) {
         rc = rlhip_mlp3_pack_bf16(a->params, ns, a->h, a->na, a->packed, stream);
         if (rc) return rc;

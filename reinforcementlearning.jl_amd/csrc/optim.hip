@@ -11,30 +11,11 @@
 // The learners' parameter vectors are tiny (3 k .. 1 M floats), so the hot variant is
 // clip_adam_kernel: ONE single-workgroup launch doing [scale] -> global norm -> clip -> Adam with the
 // gradient held in registers between the norm and the update (one read of g instead of three).
-#include "common.h"
+#include "optim_device.h"
 
 namespace rlhip {
 
 constexpr float LOG2PI_F = 1.8378770664093453f;  // log(2f0 * pi) rounded to Float32 (distributions.jl:9)
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-// block-wide sum (result valid in every thread); scratch: >= 16 doubles of LDS
-__device__ __forceinline__ double block_sum(double v, double* scratch) {
-    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    v = wave_sum(v);
-    if (lane == 0) scratch[wid] = v;
-    __syncthreads();
-    int nw = (blockDim.x + 63) >> 6;
-    double t = 0.0;
-    for (int w = 0; w < nw; ++w) t += scratch[w];
-    __syncthreads();
-    return t;
-}
 
 __global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                      int64_t n, float rho) {
@@ -84,18 +65,6 @@ __global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ g, in
     if (s == 1.0f) return;  // not clipped: the reference leaves g untouched
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= s;
-}
-
-// Optimisers.Adam: mt = b1*mt + (1-b1)*dx; vt = b2*vt + (1-b2)*dx^2;
-//                  dx' = mt / (1 - b1^t) / (sqrt(vt / (1 - b2^t)) + eps) * eta;  x -= dx'
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float b1, float b2,
-                                      float eps, float c1, float c2) {
-    float mi = b1 * m + (1.0f - b1) * g;
-    float vi = b2 * v + (1.0f - b2) * (g * g);
-    m = mi;
-    v = vi;
-    float d = mi / c1 / (sqrtf(vi / c2) + eps) * lr;
-    p = p - d;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,

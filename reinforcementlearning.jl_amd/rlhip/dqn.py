@@ -21,7 +21,16 @@ from .ops import ptr, stream_ptr
 # ----------------------------------------------------------------------------- functional layer
 def dqn_workspace(ns, h, na, batch, device="cuda"):
     nbytes = int(_lib.lib.rlhip_dqn_workspace_bytes(ns, h, na, batch))
-    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return torch.zeros(nbytes, dtype=torch.uint8, device=device)  # zeroed: the tail holds rlhip_dqn_update_f32's counters
+
+
+def dqn_update(traces, h, na, act, params, target_params, batch, gamma, delta, seed, draw_ctr, workspace, grad, loss, m, v,
+               beta_pow, grad_scale, max_grad_norm, lr, beta1, beta2, eps, gn=None):
+    """optimise!(learner, batch) in two launches: gradient partials, then reduce + clip + Adam (in place)."""
+    call("rlhip_dqn_update_f32", C.byref(traces.rb), h, na, act, ptr(params), ptr(target_params), batch, gamma, delta,
+         seed, draw_ctr, ptr(workspace), ptr(grad), ptr(loss), ptr(m), ptr(v), ptr(beta_pow), grad_scale, max_grad_norm,
+         lr, beta1, beta2, eps, ptr(gn) if gn is not None else None, stream_ptr())
+    return grad, loss
 
 
 def dqn_grad(traces, h, na, act, params, target_params, batch, gamma, delta, seed, draw_ctr, workspace=None,

@@ -413,3 +413,36 @@ def test_rollout_writes_gae_and_returns_bit_identical_to_the_scan(kind, layers, 
     pol.trajectory.ret.zero_()
     pol.gae_()
     assert torch.equal(adv, pol.trajectory.adv) and torch.equal(ret, pol.trajectory.ret)
+
+
+@pytest.mark.parametrize("ns,h,na,clip", [(4, 64, 2, 0.5), (4, 64, 2, 0.0), (2, 100, 3, 1e6), (3, 256, 3, 0.05),
+                                           (4, 252, 4, 0.5), (4, 256, 4, 0.5)])
+def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip):
+    """rlhip_dqn_update_f32 (gradient, then reduce + clip + Adam in the last-arriving workgroup) == rlhip_dqn_grad_f32
+    followed by rlhip_clip_adam_f32, bit for bit, over repeated calls (the arrival counter re-arms itself)"""
+    import rlhip
+    from rlhip import dqn, ops
+
+    n, batch = 64, 700
+    tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
+    tr.state.normal_()
+    tr.action.random_(0, na)
+    tr.reward.normal_()
+    tr.terminal.copy_((torch.rand(32, n, device="cuda") < 0.1).to(torch.uint8))
+    tr.rb.len_sa, tr.rb.len_rt = 33, 32
+    tp = ops.mlp2_init(ns, h, na, 2, 0)
+    st = []
+    for _ in range(2):
+        p = ops.mlp2_init(ns, h, na, 1, 0)
+        st.append(dict(p=p, m=torch.zeros_like(p), v=torch.zeros_like(p), g=torch.empty_like(p),
+                       bp=torch.tensor([0.9, 0.999], device="cuda"), loss=torch.empty(1, device="cuda"),
+                       gn=torch.zeros(1, device="cuda"), ws=dqn.dqn_workspace(ns, h, na, batch)))
+    a, b = st
+    for it in range(5):
+        dqn.dqn_grad(tr, h, na, it % 2, a["p"], tp, batch, 0.99, 1.0, 7, it, a["ws"], a["g"], a["loss"])
+        ops.clip_adam_(a["p"], a["g"], a["m"], a["v"], a["bp"], 0.5, clip, 1e-2, 0.9, 0.999, 1e-8, a["gn"])
+        dqn.dqn_update(tr, h, na, it % 2, b["p"], tp, batch, 0.99, 1.0, 7, it, b["ws"], b["g"], b["loss"], b["m"], b["v"],
+                       b["bp"], 0.5, clip, 1e-2, 0.9, 0.999, 1e-8, b["gn"])
+        for k in ("p", "m", "v", "g", "bp", "loss", "gn"):
+            assert torch.equal(a[k], b[k]), (it, k)
+    assert not torch.equal(a["p"], ops.mlp2_init(ns, h, na, 1, 0))
