@@ -81,6 +81,7 @@ int32_t rlhip_permutation(uint32_t* out, uint32_t n, uint64_t seed, uint32_t epo
 #define RLHIP_ENV_CARTPOLE 0    /* RLEnvs/CartPoleEnv.jl */
 #define RLHIP_ENV_PENDULUM 1    /* RLEnvs/PendulumEnv.jl */
 #define RLHIP_ENV_MOUNTAINCAR 2 /* RLEnvs/MountainCarEnv.jl */
+#define RLHIP_ENV_ACROBOT 3     /* RLEnvs/src/environments/3rd_party/AcrobotEnv.jl (stand-alone env kernels only) */
 
 /* CartPoleEnv(; kwargs...)  RLEnvs/CartPoleEnv.jl:22-32,74-79 -- Float64 as typed by the caller */
 typedef struct {
@@ -104,13 +105,27 @@ typedef struct {
     int32_t continuous;
 } rlhip_mountaincar_cfg;
 
+/* AcrobotEnv(; kwargs...)  3rd_party/AcrobotEnv.jl:22-40.  PARITY UNPINNED: the reference integrates one act! with
+ * OrdinaryDiffEq.solve(ode, RK4()) (:128-129), an un-vendored adaptive driver whose step-size controller decides the
+ * arithmetic; this library takes ONE classic RK4 step of length dt over the reference's dsdt (:147-199) in Float64
+ * (the "python gym" scheme the file cites), wraps / bounds (:135-138) and stores the state as T.  Discrete actions
+ * 0..2 (torque -1, 0, +1); max_torque_noise > 0 draws one uniform per act! from the Philox stream ENVNOISE.
+ * reward(env) is -1 after reset! (:99). */
+typedef struct {
+    double link_length_a, link_length_b, link_mass_a, link_mass_b, link_com_pos_a, link_com_pos_b, link_moi,
+        max_torque_noise, max_vel_a, max_vel_b, g, dt;
+    int64_t max_steps;
+    int32_t nips; /* book_or_nips: 0 "book" (default), 1 "nips" */
+} rlhip_acrobot_cfg;
+
 int32_t rlhip_cartpole_default(rlhip_cartpole_cfg* cfg_host);
+int32_t rlhip_acrobot_default(rlhip_acrobot_cfg* cfg_host);
 int32_t rlhip_pendulum_default(rlhip_pendulum_cfg* cfg_host);
 int32_t rlhip_mountaincar_default(rlhip_mountaincar_cfg* cfg_host, int32_t continuous);
 
 /* SoA state of n env instances (device arrays, caller-owned).
  *   s[k]    T[n]   state component k (cartpole: x, xdot, theta, thetadot; pendulum: theta, thetadot;
- *                  mountaincar: x, v)
+ *                  mountaincar: x, v; acrobot: theta1, theta2, dtheta1, dtheta2)
  *   t       i32[n] step counter of the running episode
  *   done    u8[n]  is_terminated(env) after the LAST act!
  *   reward  T[n]   reward(env) after the last act!
@@ -123,8 +138,8 @@ typedef struct {
     uint32_t* episode;
 } rlhip_env_state;
 
-int32_t rlhip_env_obs_dim(int32_t kind);   /* cartpole 4, pendulum 3 (sin, cos, thetadot), mountaincar 2 */
-int32_t rlhip_env_state_dim(int32_t kind); /* cartpole 4, pendulum 2, mountaincar 2 */
+int32_t rlhip_env_obs_dim(int32_t kind);   /* cartpole 4, pendulum 3 (sin, cos, thetadot), mountaincar 2, acrobot 6 */
+int32_t rlhip_env_state_dim(int32_t kind); /* cartpole 4, pendulum 2, mountaincar 2, acrobot 4 */
 
 /* reset!(env)   CartPoleEnv.jl:98-104, PendulumEnv.jl:84-92, MountainCarEnv.jl:99-105.
  * mask == NULL: reset every env (reset!(env; is_force = true) of the vector env); otherwise only

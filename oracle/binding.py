@@ -16,8 +16,8 @@ _lib = None
 _lib_serial = None
 _lib_omp = None
 
-KIND = {"cartpole": 0, "pendulum": 1, "mountaincar": 2}
-TAG = dict(RESET=0, EXPLORE=1, GUMBEL=2, NORMAL=3, SAMPLER=4, SHUFFLE=5, INIT=6, SYNTH=7)
+KIND = {"cartpole": 0, "pendulum": 1, "mountaincar": 2, "acrobot": 3}
+TAG = dict(RESET=0, EXPLORE=1, GUMBEL=2, NORMAL=3, SAMPLER=4, SHUFFLE=5, INIT=6, SYNTH=7, ENVNOISE=8)
 
 
 def build(force=False):
@@ -44,6 +44,13 @@ class MountainCarCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("min_pos", "max_pos", "max_speed", "goal_pos",
                                           "goal_velocity", "power", "gravity")] + \
                [("max_steps", C.c_int64), ("continuous", C.c_int32)]
+
+
+class AcrobotCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("link_length_a", "link_length_b", "link_mass_a", "link_mass_b",
+                                          "link_com_pos_a", "link_com_pos_b", "link_moi", "max_torque_noise",
+                                          "max_vel_a", "max_vel_b", "g", "dt")] + \
+               [("max_steps", C.c_int64), ("nips", C.c_int32)]
 
 
 class EnvStateC(C.Structure):
@@ -193,9 +200,12 @@ def default_cfg(kind, continuous=None, **kw):
         lib().rlo_pendulum_default(C.byref(c))
         if continuous is not None:
             c.continuous = int(continuous)
-    else:
+    elif k == 2:
         c = MountainCarCfg()
         lib().rlo_mountaincar_default(C.byref(c), C.c_int(int(bool(continuous))))
+    else:
+        c = AcrobotCfg()
+        lib().rlo_acrobot_default(C.byref(c))
     for key, val in kw.items():
         if not hasattr(c, key):
             raise TypeError(f"unknown env kwarg {key}")
@@ -245,7 +255,7 @@ class VecEnv:
             self.t[:] = t
 
     def step(self, actions):
-        continuous = bool(self.cfg.continuous)
+        continuous = bool(getattr(self.cfg, "continuous", 0))
         a = np.ascontiguousarray(actions, dtype=self.dtype if continuous else np.int32)
         lib().rlo_env_step(self.kind, self.is_f64, C.byref(self.cfg), C.byref(self._st),
                            C.c_int64(self.n), _p(a), C.c_int(int(self.auto_reset)),

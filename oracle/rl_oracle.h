@@ -61,7 +61,8 @@ enum {
     RLO_TAG_SAMPLER = 4, /* replay batch indices          */
     RLO_TAG_SHUFFLE = 5, /* epoch permutation keys        */
     RLO_TAG_INIT = 6,    /* weight init                   */
-    RLO_TAG_SYNTH = 7    /* synthetic bench / test data   */
+    RLO_TAG_SYNTH = 7,   /* synthetic bench / test data   */
+    RLO_TAG_ENVNOISE = 8 /* per-step env noise (Acrobot torque noise) */
 };
 void rlo_philox4x32_10(uint64_t seed, uint32_t idx, uint32_t blk, uint32_t t, uint32_t tag,
                        uint32_t out[4]);
@@ -103,6 +104,18 @@ typedef struct {
 } rlo_mountaincar_cfg;
 void rlo_mountaincar_default(rlo_mountaincar_cfg* c, int continuous);
 
+/* AcrobotEnv(; kwargs...)  RLEnvs/src/environments/3rd_party/AcrobotEnv.jl:22-40.  PARITY UNPINNED for this env: the
+ * reference integrates one act! with OrdinaryDiffEq.solve(ode, RK4()) (:128-129), an un-vendored ADAPTIVE driver; this
+ * restatement takes ONE classic RK4 step of length dt over the reference's own dsdt (:147-199) in Float64 (what the
+ * "python gym" implementation the file cites does), then wraps / bounds (:135-138) and stores the state as T. */
+typedef struct {
+    double link_length_a, link_length_b, link_mass_a, link_mass_b, link_com_pos_a, link_com_pos_b, link_moi,
+        max_torque_noise, max_vel_a, max_vel_b, g, dt;
+    int64_t max_steps;
+    int32_t nips; /* book_or_nips: 0 "book" (default), 1 "nips" */
+} rlo_acrobot_cfg;
+void rlo_acrobot_default(rlo_acrobot_cfg* c);
+
 /* SoA vector-env state, one entry per env instance.
  * s: state arrays, s[k][i] = component k of env i (cartpole k<4; pendulum, mountaincar k<2)
  * t: step counter; done: terminal flag of the LAST act!; reward: reward(env) after the last act!
@@ -115,7 +128,7 @@ typedef struct {
     uint32_t* episode;
 } rlo_env_state;
 
-/* kind: 0 cartpole, 1 pendulum, 2 mountaincar; is_f64: element type T of the env.
+/* kind: 0 cartpole, 1 pendulum, 2 mountaincar, 3 acrobot; is_f64: element type T of the env.
  * reset(mask == NULL): reset all; else reset where mask[i] != 0.
  * step: act!(env, a) for every env (auto_reset != 0: a terminated env is reset right after
  *       reward/done were recorded -- the MultiThreadEnv protocol); last_obs (optional, may be NULL)
@@ -126,7 +139,7 @@ int rlo_env_reset(int kind, int is_f64, const void* cfg, rlo_env_state* st, int6
 int rlo_env_step(int kind, int is_f64, const void* cfg, rlo_env_state* st, int64_t n,
                  const void* actions, int auto_reset, uint64_t seed, uint32_t env_id_base,
                  void* last_obs);
-/* state(env): obs (obs_dim x n, SoA: obs[k*n + i]); cartpole 4, pendulum 3, mountaincar 2 */
+/* state(env): obs (obs_dim x n, SoA: obs[k*n + i]); cartpole 4, pendulum 3, mountaincar 2, acrobot 6 */
 int rlo_env_obs(int kind, int is_f64, const rlo_env_state* st, int64_t n, void* obs);
 int rlo_env_obs_dim(int kind);
 int rlo_env_state_dim(int kind);

@@ -81,12 +81,30 @@ void rlo_mountaincar_default(rlo_mountaincar_cfg* c, int continuous) {
     c->continuous = continuous;
 }
 
-int rlo_env_obs_dim(int kind) { return kind == 0 ? 4 : (kind == 1 ? 3 : 2); }
-int rlo_env_state_dim(int kind) { return kind == 0 ? 4 : 2; }
+void rlo_acrobot_default(rlo_acrobot_cfg* c) {
+    /* RLEnvs/src/environments/3rd_party/AcrobotEnv.jl:22-40 */
+    c->link_length_a = 1.0;
+    c->link_length_b = 1.0;
+    c->link_mass_a = 1.0;
+    c->link_mass_b = 1.0;
+    c->link_com_pos_a = 0.5;
+    c->link_com_pos_b = 0.5;
+    c->link_moi = 1.0;
+    c->max_torque_noise = 0.0;
+    c->max_vel_a = 4 * M_PI;
+    c->max_vel_b = 9 * M_PI;
+    c->g = 9.8;
+    c->dt = 0.2;
+    c->max_steps = 200;
+    c->nips = 0;
+}
+
+int rlo_env_obs_dim(int kind) { return kind == 0 ? 4 : (kind == 1 ? 3 : (kind == 2 ? 2 : 6)); }
+int rlo_env_state_dim(int kind) { return (kind == 0 || kind == 3) ? 4 : 2; }
 
 int rlo_env_reset(int kind, int is_f64, const void* cfg, rlo_env_state* st, int64_t n,
                   uint64_t seed, uint32_t env_id_base, const uint8_t* mask) {
-    if (kind < 0 || kind > 2) return -1;
+    if (kind < 0 || kind > 3) return -1;
     return is_f64 ? env_reset_f64(kind, cfg, st, n, seed, env_id_base, mask)
                   : env_reset_f32(kind, cfg, st, n, seed, env_id_base, mask);
 }
@@ -94,13 +112,13 @@ int rlo_env_reset(int kind, int is_f64, const void* cfg, rlo_env_state* st, int6
 int rlo_env_step(int kind, int is_f64, const void* cfg, rlo_env_state* st, int64_t n,
                  const void* actions, int auto_reset, uint64_t seed, uint32_t env_id_base,
                  void* last_obs) {
-    if (kind < 0 || kind > 2) return -1;
+    if (kind < 0 || kind > 3) return -1;
     return is_f64 ? env_step_f64(kind, cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs)
                   : env_step_f32(kind, cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs);
 }
 
 int rlo_env_obs(int kind, int is_f64, const rlo_env_state* st, int64_t n, void* obs) {
-    if (kind < 0 || kind > 2) return -1;
+    if (kind < 0 || kind > 3) return -1;
     for (int64_t i = 0; i < n; ++i) {
         if (is_f64) write_obs1_f64(kind, st, n, i, (double*)obs);
         else write_obs1_f32(kind, st, n, i, (float*)obs);

@@ -1,4 +1,4 @@
-/* rlo_envs_impl.h -- type-generic body of the three classic-control envs.  Included twice by
+/* rlo_envs_impl.h -- type-generic body of the classic-control envs (+ Acrobot).  Included twice by
  * rlo_envs.c with T = float (SFX f32) and T = double (SFX f64).  TEST INFRASTRUCTURE ONLY.
  *
  * Julia promotion rules that matter: Float32 op Float64 -> Float64;
@@ -231,6 +231,113 @@ static void NAME(mountaincar_step1)(const NAME(mountaincar_params) * p, rlo_env_
     ((T*)st->reward)[i] = done ? (T)0 : (T)-1; /* :95 */
 }
 
+/* ---- AcrobotEnv (3rd_party/AcrobotEnv.jl) -- parity unpinned, see rl_oracle.h ------------------------------- */
+typedef struct {
+    double m1, m2, l1, lc1, lc2, I1, I2, g, dt;
+    T max_vel_a, max_vel_b, noise;
+    int64_t max_steps;
+    int nips;
+} NAME(acrobot_params);
+
+static void NAME(acrobot_make)(const rlo_acrobot_cfg* c, NAME(acrobot_params) * p) {
+    /* AcrobotEnvParams{T}: every field is stored as T (:42-56); dsdt reads them back (:149-156) */
+    p->m1 = (double)(T)c->link_mass_a;
+    p->m2 = (double)(T)c->link_mass_b;
+    p->l1 = (double)(T)c->link_length_a;
+    p->lc1 = (double)(T)c->link_com_pos_a;
+    p->lc2 = (double)(T)c->link_com_pos_b;
+    p->I1 = (double)(T)c->link_moi;
+    p->I2 = (double)(T)c->link_moi;
+    p->g = (double)(T)c->g;
+    p->dt = (double)(T)c->dt;
+    p->max_vel_a = (T)c->max_vel_a;
+    p->max_vel_b = (T)c->max_vel_b;
+    p->noise = (T)c->max_torque_noise;
+    p->max_steps = c->max_steps;
+    p->nips = c->nips;
+}
+
+/* reset!  :94-101: state = T(0.1) * rand(rng, T, 4) .- T(0.05); t = 0; done = false; reward = -1 */
+static void NAME(acrobot_reset1)(rlo_env_state* st, int64_t i, uint64_t seed, uint32_t env_id) {
+    NAME(cartpole_reset1)(st, i, seed, env_id); /* the same four draws and the same expression */
+}
+
+/* dsdt  :147-199 (du[5] = 0: the torque a is constant over the step) */
+static void NAME(acrobot_dsdt)(const NAME(acrobot_params) * p, const double s[4], double a, double du[4]) {
+    const double m1 = p->m1, m2 = p->m2, l1 = p->l1, lc1 = p->lc1, lc2 = p->lc2, I1 = p->I1, I2 = p->I2, g = p->g;
+    const double theta1 = s[0], theta2 = s[1], dtheta1 = s[2], dtheta2 = s[3];
+    const double c2 = cos(theta2), s2 = sin(theta2);
+    double d1 = ((m1 * (lc1 * lc1) + m2 * ((l1 * l1 + lc2 * lc2) + ((2 * l1) * lc2) * c2)) + I1) + I2; /* :171 */
+    double d2 = m2 * (lc2 * lc2 + (l1 * lc2) * c2) + I2;                                              /* :172 */
+    double phi2 = ((m2 * lc2) * g) * cos((theta1 + theta2) - M_PI / 2.0);                             /* :173 */
+    double phi1 = (((((-m2) * l1) * lc2) * (dtheta2 * dtheta2)) * s2 -
+                   (((((2 * m2) * l1) * lc2) * dtheta2) * dtheta1) * s2) +
+                  ((m1 * lc1 + m2 * l1) * g) * cos(theta1 - M_PI / 2);                                /* :174-179 */
+    phi1 = phi1 + phi2;
+    double ddtheta1 = 0.0, ddtheta2;
+    if (p->nips) {
+        ddtheta2 = ((a + (d2 / d1) * phi1) - phi2) / ((m2 * (lc2 * lc2) + I2) - (d2 * d2) / d1); /* :183 */
+    } else {
+        ddtheta2 = (((a + (d2 / d1) * phi1) - (((m2 * l1) * lc2) * (dtheta1 * dtheta1)) * s2) - phi2) /
+                   ((m2 * (lc2 * lc2) + I2) - (d2 * d2) / d1);                                    /* :187-190 */
+        ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;                                                  /* :191 */
+    }
+    du[0] = dtheta1;
+    du[1] = dtheta2;
+    du[2] = ddtheta1;
+    du[3] = ddtheta2;
+}
+
+static double NAME(acrobot_wrap)(double x, double m, double M) { /* :204-222 */
+    double diff = M - m;
+    while (x > M) x = x - diff;
+    while (x < m) x = x + diff;
+    return x;
+}
+
+/* act!  :104-145 */
+static void NAME(acrobot_step1)(const NAME(acrobot_params) * p, rlo_env_state* st, int64_t i, const void* actions,
+                                uint64_t seed, uint32_t env_id) {
+    st->t[i] += 1;                                             /* :106 */
+    T torque = (T)(((const int32_t*)actions)[i] - 1);          /* :107 avail_torque = [-1, 0, 1] */
+    if (p->noise > (T)0) {                                     /* :110-113 */
+        uint32_t w[4];
+        rlo_philox4x32_10(seed, env_id, (uint32_t)st->t[i], st->episode[i], RLO_TAG_ENVNOISE, w);
+#if IS_F64
+        T u = rlo_u01_f64(w[0], w[1]);
+#else
+        T u = rlo_u01_f32(w[0]);
+#endif
+        torque = (torque + (T)(2.0 * (double)p->noise) * u) - p->noise;
+    }
+    double y[4], k1[4], k2[4], k3[4], k4[4], yt[4];
+    for (int k = 0; k < 4; ++k) y[k] = (double)((const T*)st->s[k])[i];
+    const double a = (double)torque, h = p->dt, h2 = h / 2.0;
+    NAME(acrobot_dsdt)(p, y, a, k1);
+    for (int k = 0; k < 4; ++k) yt[k] = y[k] + h2 * k1[k];
+    NAME(acrobot_dsdt)(p, yt, a, k2);
+    for (int k = 0; k < 4; ++k) yt[k] = y[k] + h2 * k2[k];
+    NAME(acrobot_dsdt)(p, yt, a, k3);
+    for (int k = 0; k < 4; ++k) yt[k] = y[k] + h * k3[k];
+    NAME(acrobot_dsdt)(p, yt, a, k4);
+    double ns[4];
+    for (int k = 0; k < 4; ++k) ns[k] = y[k] + (h / 6.0) * (((k1[k] + 2 * k2[k]) + 2 * k3[k]) + k4[k]);
+    ns[0] = NAME(acrobot_wrap)(ns[0], -M_PI, M_PI);            /* :135-136 */
+    ns[1] = NAME(acrobot_wrap)(ns[1], -M_PI, M_PI);
+    double va = (double)p->max_vel_a, vb = (double)p->max_vel_b;
+    ns[2] = fmin(fmax(ns[2], -va), va);                        /* :137-138 bound */
+    ns[3] = fmin(fmax(ns[3], -vb), vb);
+    T sT[4];
+    for (int k = 0; k < 4; ++k) {
+        sT[k] = (T)ns[k];
+        ((T*)st->s[k])[i] = sT[k];
+    }
+    int succeeded = (-cos((double)sT[0]) - cos((double)sT[1] + (double)sT[0])) > 1.0; /* :141 */
+    int done = succeeded || (int64_t)st->t[i] > p->max_steps;                          /* :142 */
+    st->done[i] = (uint8_t)done;
+    ((T*)st->reward)[i] = succeeded ? (T)0 : (T)-1;                                    /* :143 */
+}
+
 /* ---- drivers ------------------------------------------------------------------------------- */
 static void NAME(write_obs1)(int kind, const rlo_env_state* st, int64_t n, int64_t i, T* obs) {
     if (kind == 0) {
@@ -240,8 +347,16 @@ static void NAME(write_obs1)(int kind, const rlo_env_state* st, int64_t n, int64
         obs[0 * n + i] = SIN(th); /* PendulumEnv.jl:70 */
         obs[1 * n + i] = COS(th);
         obs[2 * n + i] = ((const T*)st->s[1])[i];
-    } else {
+    } else if (kind == 2) {
         for (int k = 0; k < 2; ++k) obs[k * n + i] = ((const T*)st->s[k])[i]; /* MountainCarEnv.jl:97 */
+    } else {
+        T a = ((const T*)st->s[0])[i], b = ((const T*)st->s[1])[i];
+        obs[0 * n + i] = COS(a); /* acrobot_observation  AcrobotEnv.jl:73 */
+        obs[1 * n + i] = SIN(a);
+        obs[2 * n + i] = COS(b);
+        obs[3 * n + i] = SIN(b);
+        obs[4 * n + i] = ((const T*)st->s[2])[i];
+        obs[5 * n + i] = ((const T*)st->s[3])[i];
     }
 }
 
@@ -253,9 +368,10 @@ static int NAME(env_reset)(int kind, const void* cfg, rlo_env_state* st, int64_t
         uint32_t id = env_id_base + (uint32_t)i;
         if (kind == 0) NAME(cartpole_reset1)(st, i, seed, id);
         else if (kind == 1) NAME(pendulum_reset1)(st, i, seed, id);
-        else NAME(mountaincar_reset1)(st, i, seed, id);
+        else if (kind == 2) NAME(mountaincar_reset1)(st, i, seed, id);
+        else NAME(acrobot_reset1)(st, i, seed, id);
         st->done[i] = 0;
-        ((T*)st->reward)[i] = (T)0;
+        ((T*)st->reward)[i] = kind == 3 ? (T)-1 : (T)0; /* AcrobotEnv.jl:99 reward = -1 */
     }
     return 0;
 }
@@ -266,14 +382,17 @@ static int NAME(env_step)(int kind, const void* cfg, rlo_env_state* st, int64_t 
     NAME(cartpole_params) cp;
     NAME(pendulum_params) pp;
     NAME(mountaincar_params) mp;
-    if (kind == 0) NAME(cartpole_make)((const rlo_cartpole_cfg*)cfg, &cp);
+    NAME(acrobot_params) ap;
+    if (kind == 3) NAME(acrobot_make)((const rlo_acrobot_cfg*)cfg, &ap);
+    else if (kind == 0) NAME(cartpole_make)((const rlo_cartpole_cfg*)cfg, &cp);
     else if (kind == 1) NAME(pendulum_make)((const rlo_pendulum_cfg*)cfg, &pp);
     else NAME(mountaincar_make)((const rlo_mountaincar_cfg*)cfg, &mp);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         if (kind == 0) NAME(cartpole_step1)(&cp, st, i, actions);
         else if (kind == 1) NAME(pendulum_step1)(&pp, st, i, actions);
-        else NAME(mountaincar_step1)(&mp, st, i, actions);
+        else if (kind == 2) NAME(mountaincar_step1)(&mp, st, i, actions);
+        else NAME(acrobot_step1)(&ap, st, i, actions, seed, env_id_base + (uint32_t)i);
         if (last_obs) NAME(write_obs1)(kind, st, n, i, (T*)last_obs);
         if (auto_reset && st->done[i]) {
             /* MultiThreadEnv protocol: reward/terminal of the finished step stay visible, the
@@ -281,7 +400,8 @@ static int NAME(env_step)(int kind, const void* cfg, rlo_env_state* st, int64_t 
             uint32_t id = env_id_base + (uint32_t)i;
             if (kind == 0) NAME(cartpole_reset1)(st, i, seed, id);
             else if (kind == 1) NAME(pendulum_reset1)(st, i, seed, id);
-            else NAME(mountaincar_reset1)(st, i, seed, id);
+            else if (kind == 2) NAME(mountaincar_reset1)(st, i, seed, id);
+            else NAME(acrobot_reset1)(st, i, seed, id);
         }
     }
     return 0;

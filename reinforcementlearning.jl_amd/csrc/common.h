@@ -58,7 +58,8 @@ enum : uint32_t {
     TAG_SAMPLER = 4,
     TAG_SHUFFLE = 5,
     TAG_INIT = 6,
-    TAG_SYNTH = 7
+    TAG_SYNTH = 7,
+    TAG_ENVNOISE = 8
 };
 
 // development switches are read from the environment once per process

@@ -1,4 +1,4 @@
-// env_device.h -- per-lane physics of the three classic-control envs (device inline functions).
+// env_device.h -- per-lane physics of the classic-control envs + Acrobot (device inline functions).
 //
 // One wavefront lane owns one env instance; state lives in registers between load and store.  Used
 // by the stand-alone env kernels (envs.hip) and by the fused rollout kernel (ppo.hip), so both paths
@@ -337,6 +337,154 @@ __device__ __forceinline__ void env_obs1(const MountainCarParams<T>&, const Lane
     o[0] = e.s[0];
     o[1] = e.s[1];
 }
+
+// ---------------------------------------------------------------------------------- Acrobot --
+// RLEnvs/src/environments/3rd_party/AcrobotEnv.jl.  PARITY UNPINNED for this env (include/rlhip.h): the reference
+// integrates act! with the un-vendored, adaptive OrdinaryDiffEq.solve(ode, RK4()) (:128-129); here one classic RK4
+// step of length dt over the reference's own dsdt (:147-199), in Float64, the state stored as T.  A heavier per-lane
+// integrator than the other three: 16 Float64 trig evaluations per env-step.
+template <typename T>
+struct AcrobotParams {
+    double m1, m2, l1, lc1, lc2, I1, I2, g, dt;
+    T max_vel_a, max_vel_b, noise;
+    int32_t max_steps;
+    int32_t nips;
+    int32_t continuous;  // always 0 (Base.OneTo(3)); present for the generic kernels
+    static constexpr int SDIM = 4;
+    static constexpr int ODIM = 6;
+    static constexpr int KIND = RLHIP_ENV_ACROBOT;
+    typedef rlhip_acrobot_cfg cfg_t;
+    static AcrobotParams make(const rlhip_acrobot_cfg& c) {
+        AcrobotParams p;  // AcrobotEnvParams{T} stores every field as T (:42-56); dsdt reads them back (:149-156)
+        p.m1 = (double)(T)c.link_mass_a;
+        p.m2 = (double)(T)c.link_mass_b;
+        p.l1 = (double)(T)c.link_length_a;
+        p.lc1 = (double)(T)c.link_com_pos_a;
+        p.lc2 = (double)(T)c.link_com_pos_b;
+        p.I1 = (double)(T)c.link_moi;
+        p.I2 = (double)(T)c.link_moi;
+        p.g = (double)(T)c.g;
+        p.dt = (double)(T)c.dt;
+        p.max_vel_a = (T)c.max_vel_a;
+        p.max_vel_b = (T)c.max_vel_b;
+        p.noise = (T)c.max_torque_noise;
+        p.max_steps = (int32_t)c.max_steps;
+        p.nips = c.nips;
+        p.continuous = 0;
+        return p;
+    }
+    bool is_continuous() const { return false; }
+};
+
+// reset!  :94-101  state = T(0.1) * rand(rng, T, 4) .- T(0.05)  (reward = -1: EnvTraits below)
+template <typename T>
+__device__ __forceinline__ void env_reset1(const AcrobotParams<T>&, LaneState<T>& e, uint64_t seed, uint32_t id) {
+    T u[4];
+    ResetDraw<T>::draw4(seed, id, e.episode, u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.s[k] = (T)0.1 * u[k] - (T)0.05;
+    e.t = 0;
+    e.episode += 1;
+}
+
+// uniform of the torque noise of the coming act! (:110-113): Philox(seed, env, t + 1, episode, ENVNOISE)
+template <typename T>
+__device__ __forceinline__ T acrobot_noise_u(const LaneState<T>& e, uint64_t seed, uint32_t id) {
+    u32x4 w = philox4x32_10(seed, id, (uint32_t)(e.t + 1), e.episode, TAG_ENVNOISE);
+    if constexpr (sizeof(T) == 8) return (T)u01_f64(w.x, w.y);
+    else return (T)u01_f32(w.x);
+}
+
+// dsdt  :147-199
+template <typename T>
+__device__ __forceinline__ void acrobot_dsdt(const AcrobotParams<T>& p, const double s[4], double a, double du[4]) {
+    const double m1 = p.m1, m2 = p.m2, l1 = p.l1, lc1 = p.lc1, lc2 = p.lc2, I1 = p.I1, I2 = p.I2, g = p.g;
+    const double theta1 = s[0], theta2 = s[1], dtheta1 = s[2], dtheta2 = s[3];
+    double s2, c2;
+    ::sincos(theta2, &s2, &c2);
+    const double d1 = ((m1 * (lc1 * lc1) + m2 * ((l1 * l1 + lc2 * lc2) + ((2 * l1) * lc2) * c2)) + I1) + I2;  // :171
+    const double d2 = m2 * (lc2 * lc2 + (l1 * lc2) * c2) + I2;                                               // :172
+    const double phi2 = ((m2 * lc2) * g) * ::cos((theta1 + theta2) - RLHIP_PI / 2.0);                        // :173
+    double phi1 = (((((-m2) * l1) * lc2) * (dtheta2 * dtheta2)) * s2 -
+                   (((((2 * m2) * l1) * lc2) * dtheta2) * dtheta1) * s2) +
+                  ((m1 * lc1 + m2 * l1) * g) * ::cos(theta1 - RLHIP_PI / 2);                                 // :174-179
+    phi1 = phi1 + phi2;
+    double ddtheta1 = 0.0, ddtheta2;
+    if (p.nips) {
+        ddtheta2 = ((a + (d2 / d1) * phi1) - phi2) / ((m2 * (lc2 * lc2) + I2) - (d2 * d2) / d1);  // :183
+    } else {
+        ddtheta2 = (((a + (d2 / d1) * phi1) - (((m2 * l1) * lc2) * (dtheta1 * dtheta1)) * s2) - phi2) /
+                   ((m2 * (lc2 * lc2) + I2) - (d2 * d2) / d1);  // :187-190
+        ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;                // :191
+    }
+    du[0] = dtheta1;
+    du[1] = dtheta2;
+    du[2] = ddtheta1;
+    du[3] = ddtheta2;
+}
+
+__device__ __forceinline__ double acrobot_wrap(double x, double m, double M) {  // :204-222
+    const double diff = M - m;
+    while (x > M) x = x - diff;
+    while (x < m) x = x + diff;
+    return x;
+}
+
+// act!  :104-145.  ai: 0-based action (torque ai - 1); af: the noise uniform (only read when p.noise > 0)
+template <typename T>
+__device__ __forceinline__ void env_step1(const AcrobotParams<T>& p, LaneState<T>& e, int32_t ai, T af, T& reward,
+                                          bool& done) {
+    e.t += 1;               // :106
+    T torque = (T)(ai - 1);  // :107
+    if (p.noise > (T)0) torque = (torque + (T)(2.0 * (double)p.noise) * af) - p.noise;  // :110-113
+    double y[4], k1[4], k2[4], k3[4], k4[4], yt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (double)e.s[k];
+    const double a = (double)torque, h = p.dt, h2 = h / 2.0;
+    acrobot_dsdt(p, y, a, k1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yt[k] = y[k] + h2 * k1[k];
+    acrobot_dsdt(p, yt, a, k2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yt[k] = y[k] + h2 * k2[k];
+    acrobot_dsdt(p, yt, a, k3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yt[k] = y[k] + h * k3[k];
+    acrobot_dsdt(p, yt, a, k4);
+    double ns[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ns[k] = y[k] + (h / 6.0) * (((k1[k] + 2 * k2[k]) + 2 * k3[k]) + k4[k]);
+    ns[0] = acrobot_wrap(ns[0], -RLHIP_PI, RLHIP_PI);  // :135-136
+    ns[1] = acrobot_wrap(ns[1], -RLHIP_PI, RLHIP_PI);
+    const double va = (double)p.max_vel_a, vb = (double)p.max_vel_b;
+    ns[2] = ::fmin(::fmax(ns[2], -va), va);  // :137-138
+    ns[3] = ::fmin(::fmax(ns[3], -vb), vb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.s[k] = (T)ns[k];
+    const bool succeeded = (-::cos((double)e.s[0]) - ::cos((double)e.s[1] + (double)e.s[0])) > 1.0;  // :141
+    done = succeeded || e.t > p.max_steps;                                                         // :142
+    reward = succeeded ? (T)0 : (T)-1;                                                             // :143
+}
+
+template <typename T>
+__device__ __forceinline__ void env_obs1(const AcrobotParams<T>&, const LaneState<T>& e, T o[6]) {
+    Trig<T>::sincos_(e.s[0], &o[1], &o[0]);  // :73  [cos(s1), sin(s1), cos(s2), sin(s2), s3, s4]
+    Trig<T>::sincos_(e.s[1], &o[3], &o[2]);
+    o[4] = e.s[2];
+    o[5] = e.s[3];
+}
+
+// per-env traits the generic kernels need: reward(env) right after reset!, and whether act! draws from the RNG
+template <class P>
+struct EnvTraits {
+    static constexpr bool STEP_NOISE = false;
+    static constexpr int RESET_REWARD = 0;
+};
+template <typename T>
+struct EnvTraits<AcrobotParams<T>> {
+    static constexpr bool STEP_NOISE = true;
+    static constexpr int RESET_REWARD = -1;  // AcrobotEnv.jl:99
+};
 
 // device-pointer view of rlhip_env_state
 template <typename T>

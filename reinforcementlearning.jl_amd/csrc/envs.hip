@@ -93,13 +93,19 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
         for (int k = 0; k < P::SDIM; ++k) e.s[k] = s[k].v[j];
         e.t = tv.v[j];
         e.episode = 0;
+        if constexpr (EnvTraits<P>::STEP_NOISE) {
+            if (p.noise > (T)0) {  // act! draws from the env's rng: uniform keyed by (env, t, episode)
+                e.episode = st.episode[base + j];
+                af.v[j] = acrobot_noise_u(e, seed, env_id_base + (uint32_t)(base + j));
+            }
+        }
         T r;
         bool d;
         env_step1(p, e, ai.v[j], af.v[j], r, d);
         rew.v[j] = r;
         dn.v[j] = (uint8_t)d;
         if (last_obs) {
-            T o[4];
+            T o[6];
             env_obs1(p, e, o);
 #pragma unroll
             for (int k = 0; k < P::ODIM; ++k) lo[k].v[j] = o[k];
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
             st.episode[base + j] = e.episode;
         }
         if (obs_out) {
-            T o[4];
+            T o[6];
             env_obs1(p, e, o);
 #pragma unroll
             for (int k = 0; k < P::ODIM; ++k) oo[k].v[j] = o[k];
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(P p, EnvArrays<T> st, in
     st.t[i] = 0;
     st.episode[i] = e.episode;
     st.done[i] = 0;          // reset!: done = false
-    st.reward[i] = (T)0;
+    st.reward[i] = (T)EnvTraits<P>::RESET_REWARD;
 }
 
 template <class P, typename T>
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void env_obs_kernel(P p, EnvArrays<T> st, int6
     LaneState<T> e;
 #pragma unroll
     for (int k = 0; k < P::SDIM; ++k) e.s[k] = st.s[k][i];
-    T o[4];
+    T o[6];
     env_obs1(p, e, o);
 #pragma unroll
     for (int k = 0; k < P::ODIM; ++k) obs[(int64_t)k * n + i] = o[k];
@@ -225,10 +231,10 @@ static int32_t obs_impl(const rlhip_env_state* st, int64_t n, void* obs, hipStre
 }
 
 static int32_t check_state(int32_t kind, const rlhip_env_state* st, int64_t n) {
-    RLHIP_REQUIRE(kind >= 0 && kind <= 2, "kind must be 0 (cartpole), 1 (pendulum) or 2 (mountaincar)");
+    RLHIP_REQUIRE(kind >= 0 && kind <= 3, "kind must be 0 (cartpole), 1 (pendulum), 2 (mountaincar) or 3 (acrobot)");
     RLHIP_REQUIRE(st != nullptr, "env state is NULL");
     RLHIP_REQUIRE(n >= 0 && n <= 0xFFFFFFFFll, "n out of range");
-    int sd = kind == 0 ? 4 : 2;
+    int sd = (kind == 0 || kind == 3) ? 4 : 2;
     for (int k = 0; k < sd; ++k) RLHIP_REQUIRE(st->s[k] != nullptr, "state array is NULL");
     RLHIP_REQUIRE(st->t && st->done && st->reward && st->episode, "state array is NULL");
     return RLHIP_OK;
@@ -286,8 +292,28 @@ int32_t rlhip_mountaincar_default(rlhip_mountaincar_cfg* c, int32_t continuous) 
     return RLHIP_OK;
 }
 
-int32_t rlhip_env_obs_dim(int32_t kind) { return kind == 0 ? 4 : (kind == 1 ? 3 : 2); }
-int32_t rlhip_env_state_dim(int32_t kind) { return kind == 0 ? 4 : 2; }
+int32_t rlhip_acrobot_default(rlhip_acrobot_cfg* c) {
+    RLHIP_REQUIRE(c != nullptr, "cfg is NULL");
+    // RLEnvs/src/environments/3rd_party/AcrobotEnv.jl:22-40
+    c->link_length_a = 1.0;
+    c->link_length_b = 1.0;
+    c->link_mass_a = 1.0;
+    c->link_mass_b = 1.0;
+    c->link_com_pos_a = 0.5;
+    c->link_com_pos_b = 0.5;
+    c->link_moi = 1.0;
+    c->max_torque_noise = 0.0;
+    c->max_vel_a = 4 * RLHIP_PI;
+    c->max_vel_b = 9 * RLHIP_PI;
+    c->g = 9.8;
+    c->dt = 0.2;
+    c->max_steps = 200;
+    c->nips = 0;
+    return RLHIP_OK;
+}
+
+int32_t rlhip_env_obs_dim(int32_t kind) { return kind == 0 ? 4 : (kind == 1 ? 3 : (kind == 2 ? 2 : 6)); }
+int32_t rlhip_env_state_dim(int32_t kind) { return (kind == 0 || kind == 3) ? 4 : 2; }
 
 int32_t rlhip_env_reset(int32_t kind, int32_t is_f64, const void* cfg, const rlhip_env_state* st,
                         int64_t n, uint64_t seed, uint32_t env_id_base, const uint8_t* mask,
@@ -303,6 +329,9 @@ int32_t rlhip_env_reset(int32_t kind, int32_t is_f64, const void* cfg, const rlh
     if (kind == 1)
         return is_f64 ? reset_impl<PendulumParams<double>, double>((const rlhip_pendulum_cfg*)cfg, st, n, seed, env_id_base, mask, s)
                       : reset_impl<PendulumParams<float>, float>((const rlhip_pendulum_cfg*)cfg, st, n, seed, env_id_base, mask, s);
+    if (kind == 3)
+        return is_f64 ? reset_impl<AcrobotParams<double>, double>((const rlhip_acrobot_cfg*)cfg, st, n, seed, env_id_base, mask, s)
+                      : reset_impl<AcrobotParams<float>, float>((const rlhip_acrobot_cfg*)cfg, st, n, seed, env_id_base, mask, s);
     return is_f64 ? reset_impl<MountainCarParams<double>, double>((const rlhip_mountaincar_cfg*)cfg, st, n, seed, env_id_base, mask, s)
                   : reset_impl<MountainCarParams<float>, float>((const rlhip_mountaincar_cfg*)cfg, st, n, seed, env_id_base, mask, s);
 }
@@ -322,6 +351,9 @@ int32_t rlhip_env_step(int32_t kind, int32_t is_f64, const void* cfg, const rlhi
     if (kind == 1)
         return is_f64 ? step_impl<PendulumParams<double>, double>((const rlhip_pendulum_cfg*)cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs, obs_out, s)
                       : step_impl<PendulumParams<float>, float>((const rlhip_pendulum_cfg*)cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs, obs_out, s);
+    if (kind == 3)
+        return is_f64 ? step_impl<AcrobotParams<double>, double>((const rlhip_acrobot_cfg*)cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs, obs_out, s)
+                      : step_impl<AcrobotParams<float>, float>((const rlhip_acrobot_cfg*)cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs, obs_out, s);
     return is_f64 ? step_impl<MountainCarParams<double>, double>((const rlhip_mountaincar_cfg*)cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs, obs_out, s)
                   : step_impl<MountainCarParams<float>, float>((const rlhip_mountaincar_cfg*)cfg, st, n, actions, auto_reset, seed, env_id_base, last_obs, obs_out, s);
 }
@@ -337,6 +369,8 @@ int32_t rlhip_env_obs(int32_t kind, int32_t is_f64, const rlhip_env_state* st, i
         return is_f64 ? obs_impl<CartPoleParams<double>, double>(st, n, obs, s) : obs_impl<CartPoleParams<float>, float>(st, n, obs, s);
     if (kind == 1)
         return is_f64 ? obs_impl<PendulumParams<double>, double>(st, n, obs, s) : obs_impl<PendulumParams<float>, float>(st, n, obs, s);
+    if (kind == 3)
+        return is_f64 ? obs_impl<AcrobotParams<double>, double>(st, n, obs, s) : obs_impl<AcrobotParams<float>, float>(st, n, obs, s);
     return is_f64 ? obs_impl<MountainCarParams<double>, double>(st, n, obs, s) : obs_impl<MountainCarParams<float>, float>(st, n, obs, s);
 }
 

@@ -47,14 +47,19 @@ struct CartPoleCfg  # rlhip_cartpole_cfg <- CartPoleEnv(; kwargs...) CartPoleEnv
     gravity::Float64; masscart::Float64; masspole::Float64; halflength::Float64; forcemag::Float64
     dt::Float64; thetathreshold_deg::Float64; xthreshold::Float64; max_steps::Int64; continuous::Int32
 end
+struct AcrobotCfg  # rlhip_acrobot_cfg <- AcrobotEnv(; kwargs...) 3rd_party/AcrobotEnv.jl:22-40 (kind = 3)
+    link_length_a::Float64; link_length_b::Float64; link_mass_a::Float64; link_mass_b::Float64
+    link_com_pos_a::Float64; link_com_pos_b::Float64; link_moi::Float64; max_torque_noise::Float64
+    max_vel_a::Float64; max_vel_b::Float64; g::Float64; dt::Float64; max_steps::Int64; nips::Int32
+end
 struct EnvState  # rlhip_env_state
     s::NTuple{4,Ptr{Cvoid}}; t::Ptr{Cvoid}; done::Ptr{Cvoid}; reward::Ptr{Cvoid}; episode::Ptr{Cvoid}
 end
 
 # ---- HipVecEnv <: AbstractEnv ------------------------------------------------------------------------
-mutable struct HipVecEnv{K,T} <: AbstractEnv     # K in (:cartpole, :pendulum, :mountaincar)
+mutable struct HipVecEnv{K,T} <: AbstractEnv     # K in (:cartpole, :pendulum, :mountaincar, :acrobot)
     kind::Int32
-    cfg::Ref                                       # CartPoleCfg / PendulumCfg / MountainCarCfg
+    cfg::Ref                                       # CartPoleCfg / PendulumCfg / MountainCarCfg / AcrobotCfg
     n::Int
     seed::UInt64
     env_id_base::UInt32

@@ -49,6 +49,13 @@ class PendulumCfg(C.Structure):
                [("max_steps", i64), ("continuous", i32), ("n_actions", i32)]
 
 
+class AcrobotCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("link_length_a", "link_length_b", "link_mass_a", "link_mass_b",
+                                          "link_com_pos_a", "link_com_pos_b", "link_moi", "max_torque_noise",
+                                          "max_vel_a", "max_vel_b", "g", "dt")] + \
+               [("max_steps", C.c_int64), ("nips", C.c_int32)]
+
+
 class MountainCarCfg(C.Structure):
     _fields_ = [(n, f64) for n in ("min_pos", "max_pos", "max_speed", "goal_pos", "goal_velocity",
                                    "power", "gravity")] + \
@@ -117,6 +124,7 @@ _PROTOS = {
     "rlhip_cartpole_default": (i32, [P(CartPoleCfg)]),
     "rlhip_pendulum_default": (i32, [P(PendulumCfg)]),
     "rlhip_mountaincar_default": (i32, [P(MountainCarCfg), i32]),
+    "rlhip_acrobot_default": (i32, [P(AcrobotCfg)]),
     "rlhip_env_obs_dim": (i32, [i32]),
     "rlhip_env_state_dim": (i32, [i32]),
     "rlhip_env_reset": (i32, [i32, i32, vp, P(EnvState), i64, u64, u32, vp, vp]),

@@ -25,7 +25,7 @@ from . import _lib
 from ._lib import call
 from .ops import ptr, stream_ptr
 
-KIND = {"cartpole": 0, "pendulum": 1, "mountaincar": 2}
+KIND = {"cartpole": 0, "pendulum": 1, "mountaincar": 2, "acrobot": 3}
 
 
 def _make_cfg(kind, continuous, kw):
@@ -37,9 +37,17 @@ def _make_cfg(kind, continuous, kw):
         cfg = _lib.PendulumCfg()
         call("rlhip_pendulum_default", C.byref(cfg))
         cfg.continuous = int(bool(continuous))
-    else:
+    elif kind == 2:
         cfg = _lib.MountainCarCfg()
         call("rlhip_mountaincar_default", C.byref(cfg), int(bool(continuous)))
+    else:
+        if continuous:
+            raise TypeError("AcrobotEnv has a discrete action space (Base.OneTo(3))")
+        cfg = _lib.AcrobotCfg()
+        call("rlhip_acrobot_default", C.byref(cfg))
+        if "book_or_nips" in kw:  # AcrobotEnv.jl:38
+            kw = dict(kw)
+            kw["nips"] = {"book": 0, "nips": 1}[kw.pop("book_or_nips")]
     rename = {"thetathreshold": "thetathreshold_deg"}
     for k, v in kw.items():
         k = rename.get(k, k)
@@ -82,7 +90,7 @@ class HipVecEnv:
     def __init__(self, kind, n_envs=1, T=torch.float32, continuous=None, seed=0, env_id_base=0,
                  auto_reset=True, device="cuda", validate_actions=False, **kwargs):
         self.kind = KIND[kind] if isinstance(kind, str) else int(kind)
-        self.name = {0: "CartPoleEnv", 1: "PendulumEnv", 2: "MountainCarEnv"}[self.kind]
+        self.name = {0: "CartPoleEnv", 1: "PendulumEnv", 2: "MountainCarEnv", 3: "AcrobotEnv"}[self.kind]
         if T not in (torch.float32, torch.float64):
             raise TypeError("T must be torch.float32 or torch.float64")
         self.T = T
@@ -178,6 +186,8 @@ class HipVecEnv:
             return Space([-2 * c.xthreshold, -inf, -2 * th, -inf], [2 * c.xthreshold, inf, 2 * th, inf])
         if self.kind == 1:  # PendulumEnv.jl:75-79
             return Space([-1.0, -1.0, -c.max_speed], [1.0, 1.0, c.max_speed])
+        if self.kind == 3:  # AcrobotEnv.jl:77-86
+            return Space([-1.0, -1.0, -1.0, -1.0, -c.max_vel_a, -c.max_vel_b], [1.0, 1.0, 1.0, 1.0, c.max_vel_a, c.max_vel_b])
         return Space([c.min_pos, -c.max_speed], [c.max_pos, c.max_speed])  # MountainCarEnv.jl:83-86
 
     def seed_(self, seed):
@@ -233,6 +243,12 @@ def MountainCarEnv(n_envs=1, **kw):
     """MountainCarEnv(; T, continuous, min_pos, max_pos, max_speed, goal_pos, max_steps, goal_velocity,
     power, gravity)  (MountainCarEnv.jl:51-81) x n_envs."""
     return HipVecEnv("mountaincar", n_envs, **kw)
+
+
+def AcrobotEnv(n_envs=1, **kw):
+    """AcrobotEnv(; T, link_length_a, ..., max_torque_noise, max_vel_a, max_vel_b, g, dt, max_steps, book_or_nips)
+    (3rd_party/AcrobotEnv.jl:22-70) x n_envs.  One classic RK4 step per act! (parity unpinned: include/rlhip.h)."""
+    return HipVecEnv("acrobot", n_envs, **kw)
 
 
 def ContinuousMountainCarEnv(n_envs=1, **kw):

@@ -71,6 +71,7 @@ ENV_CASES = [
     ("pendulum", True, torch.float32), ("pendulum", False, torch.float32), ("pendulum", True, torch.float64),
     ("mountaincar", False, torch.float32), ("mountaincar", True, torch.float32),
     ("mountaincar", False, torch.float64),
+    ("acrobot", False, torch.float32), ("acrobot", False, torch.float64),
 ]
 
 
@@ -143,6 +144,34 @@ def test_env_step_teacher_forced(rl, kind, continuous, T, n):
     # values are bit-identical; every value is within the tolerance asserted above.
     limit = 1e-3 if kind == "cartpole" else 1e-2
     assert n_bit_mismatch / total < limit, f"{n_bit_mismatch}/{total} state values differ in the last bit"
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.float64])
+def test_acrobot_torque_noise_and_wrapper(rl, T):
+    """AcrobotEnv: per-step torque noise from the shared Philox stream, reward = -1 after reset!,
+    the RLBase spaces, the nips variant; teacher-forced against the oracle"""
+    npdt = np.float32 if T == torch.float32 else np.float64
+    n = 1000
+    for kw in (dict(max_torque_noise=0.7), dict(book_or_nips="nips"), dict(max_torque_noise=0.3, dt=0.1, link_moi=0.8)):
+        okw = {("nips" if k == "book_or_nips" else k): (1 if v == "nips" else v) for k, v in kw.items()}
+        env = rl.AcrobotEnv(n, T=T, seed=9, env_id_base=40, max_steps=20, **kw)
+        ref = oracle.VecEnv("acrobot", n, seed=9, env_id_base=40, dtype=npdt, max_steps=20, **okw)
+        assert env.name == "AcrobotEnv" and len(env.action_space()) == 3 and len(env.state_space()) == 6
+        assert (host(env.reward()) == -1).all() and not host(env.is_terminated()).any()
+        assert host(env.state()) in env.state_space()
+        rng = np.random.default_rng(2)
+        for step in range(50):
+            ref.set_state([host(env.raw_state()[k]) for k in range(4)], host(env._t))
+            ref.episode[:] = host(env._episode).view(np.uint32)
+            a = rng.integers(0, 3, n).astype(np.int32)
+            env.act0_(dev(a))
+            ref.step(a)
+            assert np.array_equal(host(env._done), ref.done) and np.array_equal(host(env._t), ref.t)
+            assert np.array_equal(host(env.reward()), ref.reward)
+            for k in range(4):
+                np.testing.assert_allclose(host(env.raw_state()[k]), ref.s[k], rtol=2e-6 if npdt == np.float32 else 1e-12,
+                                           atol=1e-7 if npdt == np.float32 else 1e-14)
+        assert host(env._episode).min() >= 2
 
 
 @pytest.mark.parametrize("kind,continuous", [("cartpole", False), ("pendulum", True), ("mountaincar", False)])
