@@ -14,6 +14,8 @@ from .dqn import (DQNLearner, EpsilonGreedyExplorer, GreedyExplorer, HipApproxim
                   QBasedPolicy, TargetNetwork)
 from .explorers import (BatchExplorer, GumbelSoftmaxExplorer, UCBExplorer, WeightedExplorer,  # noqa: F401
                         WeightedSoftmaxExplorer)
+from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint, state_dict  # noqa: F401
+from .timing import disable_debug_timings, enable_debug_timings, timer  # noqa: F401
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
 from .trajectory import (BatchSampler, CircularArraySARTSTraces, CircularPrioritizedTraces,  # noqa: F401
                          InsertSampleRatioController, Trajectory)

@@ -339,16 +339,25 @@ def run(policy, env, stop_condition=None, hook=None):
     """
     stop_condition = stop_condition or StopAfterNSteps(1)
     hook = hook or EmptyHook()
+    from .timing import timer as tm  # `@timeit_debug timer "<label>"` of run.jl:46-72, no-ops unless enabled
+
     hook.push_(PRE_EXPERIMENT_STAGE, policy, env)
     policy.push_(PRE_EXPERIMENT_STAGE, env)
     while True:
-        action = policy.plan_(env)
-        policy.push_(PRE_ACT_STAGE, env, action)
-        hook.push_(PRE_ACT_STAGE, policy, env)
-        env.act_(action)
-        policy.push_(POST_ACT_STAGE, env, action)
-        policy.optimise_(POST_ACT_STAGE)
-        hook.push_(POST_ACT_STAGE, policy, env)
+        with tm("plan!"):
+            action = policy.plan_(env)
+        with tm("push!(policy) PreActStage"):
+            policy.push_(PRE_ACT_STAGE, env, action)
+        with tm("push!(hook) PreActStage"):
+            hook.push_(PRE_ACT_STAGE, policy, env)
+        with tm("act!"):
+            env.act_(action)
+        with tm("push!(policy) PostActStage"):
+            policy.push_(POST_ACT_STAGE, env, action)
+        with tm("optimise! PostActStage"):
+            policy.optimise_(POST_ACT_STAGE)
+        with tm("push!(hook) PostActStage"):
+            hook.push_(POST_ACT_STAGE, policy, env)
         if stop_condition.check_(policy, env):
             break
     policy.push_(POST_EXPERIMENT_STAGE, env)

@@ -165,3 +165,73 @@ def test_no_cpu_fallback_in_product_sources():
     csrc = os.path.join(os.path.dirname(pkg), "csrc")
     for fn in os.listdir(csrc):
         assert "rl_oracle" not in open(os.path.join(csrc, fn)).read(), fn
+
+
+def test_checkpoint_walker_round_trip(tmp_path):
+    """state_dict / load_state_dict (rlhip/checkpoint.py; the JLD2 hook recipe docs/src/How_to_use_hooks.md:122-167):
+    tensors, scalars, C-struct fields (not pointers), nested objects; in-place restore; strictness"""
+    import numpy as np
+    import torch
+
+    from rlhip import checkpoint as ck
+
+    class Node:
+        __module__ = "rlhip.fake"
+
+        def __init__(self, k):
+            self.w = torch.arange(6, dtype=torch.float32).reshape(2, 3) * k
+            self.counter, self.rate, self.flag, self.name = 3 * k, 0.5 * k, bool(k % 2), f"n{k}"
+            self.cfg = _lib.PendulumCfg()
+            self.cfg.max_speed, self.cfg.n_actions = 8.0 + k, 3 + k
+            self.st = _lib.EnvState()          # pointers only: must not be exported
+            self.foreign = re.compile("x")     # not ours: ignored
+            self.child = None
+
+    a, b = Node(1), Node(2)
+    a.child, a.items = b, [torch.ones(2), {"z": torch.zeros(1, dtype=torch.int32)}]
+    a.again = b                                # second path to the same object: visited once
+    d = ck.state_dict(a)
+    assert set(d) == {"w", "counter", "rate", "flag", "name", "cfg.max_speed", "cfg.max_torque", "cfg.g", "cfg.m",
+                      "cfg.l", "cfg.dt", "cfg.max_steps", "cfg.continuous", "cfg.n_actions", "items/0", "items/1/z"} | \
+        {f"again/{k}" for k in ("w", "counter", "rate", "flag", "name", "cfg.max_speed", "cfg.max_torque", "cfg.g",
+                                "cfg.m", "cfg.l", "cfg.dt", "cfg.max_steps", "cfg.continuous", "cfg.n_actions")}
+    assert isinstance(d["w"], np.ndarray) and d["again/counter"] == 6 and d["cfg.n_actions"] == 4
+    n = ck.save_checkpoint(tmp_path / "c.npz", a)
+    assert n == len(d)
+    a2, b2 = Node(5), Node(7)
+    a2.child, a2.items, a2.again = b2, [torch.zeros(2), {"z": torch.ones(1, dtype=torch.int32)}], b2
+    w_ptr = a2.w.data_ptr()
+    ck.load_checkpoint(tmp_path / "c.npz", a2)
+    assert a2.w.data_ptr() == w_ptr and torch.equal(a2.w, a.w) and torch.equal(b2.w, b.w)
+    assert (a2.counter, a2.rate, a2.flag, a2.name) == (3, 0.5, True, "n1") and type(a2.counter) is int
+    assert (b2.counter, b2.cfg.n_actions, b2.cfg.max_speed) == (6, 5, 10.0)
+    assert torch.equal(a2.items[0], torch.ones(2)) and int(a2.items[1]["z"]) == 0
+    del d["rate"]
+    with pytest.raises(KeyError):
+        ck.load_state_dict(a2, d)
+    ck.load_state_dict(a2, d, strict=False)
+    d["w"] = np.zeros((3, 2), np.float32)
+    with pytest.raises(ValueError):
+        ck.load_state_dict(a2, d, strict=False)
+    assert "rate" not in ck.state_dict(a, skip=("rate",))
+
+
+def test_debug_timer_sections_follow_the_reference_labels():
+    """RLCore.timer + TimerOutputs.enable_debug_timings (RLCore/test/core/base.jl:41-57): disabled sections are a shared
+    no-op; enabled ones count calls under the labels of run.jl:46-72 (host clock here, HIP events on a GPU box)"""
+    import rlhip
+    from rlhip import timing as tmod
+
+    t = tmod.TimerOutput()
+    assert t("plan!") is t("act!")            # disabled: the same null context
+    t.enabled = True                           # host-clock only (no device on this box)
+    for _ in range(3):
+        with t("plan!"):
+            pass
+        with t("act!"):
+            pass
+    d = t.todict()
+    assert list(d) == ["plan!", "act!"] and d["plan!"]["ncalls"] == 3 and d["act!"]["host_ns"] > 0
+    assert "plan!" in str(t) and isinstance(rlhip.timer, tmod.TimerOutput)
+    t.reset_()
+    assert not t.sections

@@ -294,3 +294,97 @@ def test_four_ranks_one_gpu_fused_exchange_keeps_replicas_identical(rl):
     assert all(r[3] for r in res)
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1])
+
+
+@pytest.mark.parametrize("layers,prioritized", [(2, False), (3, False), (2, True)])
+def test_checkpoint_resume_of_a_dqn_agent_is_bit_identical(tmp_path, layers, prioritized):
+    """save_checkpoint / load_checkpoint (rlhip/checkpoint.py; the JLD2 hook recipe docs/src/How_to_use_hooks.md:122-167):
+    agent + env exported mid-run from a DoEveryNSteps hook, restored into FRESH objects, continue -> the same bits
+    as the uninterrupted run (parameters, Adam state, target, ring, priorities, env state, every counter)"""
+    import rlhip
+
+    def build(seed):
+        n = 160
+        env = rlhip.CartPoleEnv(n, seed=seed)
+        net = rlhip.HipApproximator(4, 128, 2, seed=seed, layers=layers)
+        learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=5), batchsize=128, min_replay_history=2 * n,
+                                   seed=seed, max_grad_norm=1.0)
+        policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.05, kind="exp", decay_steps=30, seed=seed))
+        traces = (rlhip.CircularPrioritizedTraces if prioritized else rlhip.CircularArraySARTSTraces)(
+            capacity=16, n_env=n, obs_dim=4)
+        return env, rlhip.Agent(policy, rlhip.Trajectory(traces))
+
+    path = str(tmp_path / "ck.npz")
+    env, agent = build(6)
+    saved = []
+
+    def hook_fn(t, policy, e):   # DoEveryNSteps(f; n): f(t, policy, env)
+        if t == 20:
+            saved.append(rlhip.save_checkpoint(path, {"agent": agent, "env": env}))
+
+    rlhip.run(agent, env, rlhip.StopAfterNSteps(45), rlhip.DoEveryNSteps(hook_fn, n=20))
+    assert saved and saved[0] > 20
+    env2, agent2 = build(99)        # different seed: every bit must come from the checkpoint
+    rlhip.load_checkpoint(path, {"agent": agent2, "env": env2})
+    rlhip.run(agent2, env2, rlhip.StopAfterNSteps(25))
+    torch.cuda.synchronize()
+    a, b = rlhip.state_dict({"agent": agent, "env": env}), rlhip.state_dict({"agent": agent2, "env": env2})
+    assert set(a) == set(b)
+    import numpy as np
+    for k in a:
+        if "workspace" in k or k.endswith("/grad") or "/_q" in k:
+            continue    # scratch
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert agent2.policy.learner.n_updates > 30
+
+
+def test_checkpoint_resume_of_a_ppo_policy_is_bit_identical(tmp_path):
+    import numpy as np
+    import rlhip
+
+    def build(seed):
+        env = rlhip.CartPoleEnv(256, seed=seed)
+        return env, rlhip.PPOPolicy(env, update_freq=16, hidden=64, seed=seed)
+
+    env, pol = build(3)
+    rlhip.run_fused_ppo(pol, env, 3)
+    rlhip.save_checkpoint(str(tmp_path / "p.npz"), {"policy": pol, "env": env})
+    rlhip.run_fused_ppo(pol, env, 3)
+    env2, pol2 = build(77)
+    rlhip.load_checkpoint(str(tmp_path / "p.npz"), {"policy": pol2, "env": env2})
+    rlhip.run_fused_ppo(pol2, env2, 3)
+    torch.cuda.synchronize()
+    for x, y in ((pol.params, pol2.params), (pol.m, pol2.m), (pol.v, pol2.v), (pol.beta_pow, pol2.beta_pow),
+                 (env._s, env2._s), (env._episode, env2._episode), (pol.trajectory.obs, pol2.trajectory.obs)):
+        assert torch.equal(x, y)
+    assert (pol.vec_step, pol.update_ctr) == (pol2.vec_step, pol2.update_ctr)
+    assert not np.array_equal(rlhip.state_dict(pol)["params"], rlhip.state_dict(build(3)[1])["params"])
+
+
+def test_debug_timer_reports_device_time_per_run_loop_section():
+    """RLCore.timer with enable_debug_timings (RLCore/test/core/base.jl:41-57): the sections of run.jl:46-72, each with
+    the device time between two HIP events on the compute stream"""
+    import rlhip
+
+    n = 4096
+    env = rlhip.CartPoleEnv(n, seed=2)
+    net = rlhip.HipApproximator(4, 128, 2, seed=2)
+    learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=10), batchsize=512, min_replay_history=n, seed=2)
+    agent = rlhip.Agent(rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.05, seed=2)),
+                        rlhip.Trajectory(rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=4)))
+    rlhip.timer.reset_()
+    rlhip.enable_debug_timings()
+    try:
+        rlhip.run(agent, env, rlhip.StopAfterNSteps(700))   # > the resolve batch: events are recycled
+    finally:
+        rlhip.disable_debug_timings()
+    d = rlhip.timer.todict()
+    assert list(d)[:4] == ["plan!", "push!(policy) PreActStage", "push!(hook) PreActStage", "act!"]
+    assert all(v["ncalls"] == 700 for v in d.values())
+    for k in ("plan!", "act!", "push!(policy) PostActStage", "optimise! PostActStage"):
+        assert 700 * 1e-3 < d[k]["device_ms"] < 700 * 2.0, (k, d[k])       # 1 us .. 2 ms of device time per call
+    assert d["optimise! PostActStage"]["device_ms"] > d["push!(hook) PostActStage"]["device_ms"]
+    print(rlhip.timer)
+    n_before = len(d)
+    rlhip.run(agent, env, rlhip.StopAfterNSteps(3))          # disabled again: nothing is recorded
+    assert rlhip.timer.todict()["plan!"]["ncalls"] == 700 and len(rlhip.timer.todict()) == n_before
