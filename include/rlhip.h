@@ -258,6 +258,21 @@ int32_t rlhip_normlogpdf_f32(const float* mu, const float* sigma, const float* x
                              int64_t n, rlhip_stream_t stream);
 int32_t rlhip_diagnormlogpdf_f32(const float* mu, const float* sigma, const float* x, int64_t d,
                                  int64_t n, float* out, rlhip_stream_t stream);
+/* Stochastic Gaussian policy heads  RLCore/src/utils/networks.jl: GaussianNetwork :64-116 (logpdfcorrection /
+ * inversesquash :39-42), SoftGaussianNetwork :147-198.  mu, raw_sigma: outputs of the mu / sigma sub-networks,
+ * f32 (d x n) column-major; sigma = clamp(raw_sigma, min_sigma, max_sigma).  K samples per state
+ * (K = 1: the `is_sampling = true` call; K > 1: the `(state, action_samples::Int)` call): z = mu + sigma * noise with
+ * noise from the Philox NORMAL stream (draw k + d*j of (seed, env_id_base + i, step)).
+ *   squash 0 identity / 1 tanh (GaussianNetwork.squash); soft 1 = SoftGaussianNetwork (tanh, its own logp form)
+ *   action_out f32 (d x K x n) = squash(z); logp_out f32 (K x n), nullable (`is_return_log_prob = false`)
+ * rlhip_gaussian_head_logp_f32 is the `(model)(state, action)` call: log-probability of given (squashed) actions. */
+int32_t rlhip_gaussian_head_sample_f32(const float* mu, const float* raw_sigma, int64_t d, int64_t n, int64_t K,
+                                       float min_sigma, float max_sigma, int32_t squash, int32_t soft,
+                                       uint64_t seed, uint32_t env_id_base, uint32_t step, float* action_out,
+                                       float* logp_out, rlhip_stream_t stream);
+int32_t rlhip_gaussian_head_logp_f32(const float* mu, const float* raw_sigma, const float* action, int64_t d,
+                                     int64_t n, int64_t K, float min_sigma, float max_sigma, int32_t squash,
+                                     int32_t soft, float* logp_out, rlhip_stream_t stream);
 /* Flux.Losses.huber_loss(q, target; delta) mean-aggregated -> loss_out f32[1]; dq (nullable) = dL/dq */
 int32_t rlhip_huber_f32(const float* q, const float* target, int64_t n, float delta, float* loss_out,
                         float* dq, rlhip_stream_t stream);

@@ -704,3 +704,33 @@ def ppo_update(kind, cfg, traj, params, m, v, opt_step, seed, update_ctr):
                              C.byref(traj.c), _p(params), _p(m), _p(v), C.byref(st), C.c_uint64(seed),
                              C.c_uint32(update_ctr), _p(losses))
     return st.value, losses
+
+
+# ------------------------------------------------------------------------------- stochastic heads
+def gaussian_head_sample(mu, raw_sigma, K=1, min_sigma=0.0, max_sigma=np.inf, squash=0, soft=0, seed=0, env_id_base=0,
+                         step=0, want_logp=True):
+    """mu, raw_sigma (d, n) Julia-shaped -> actions (d, K, n), logp (K, n)  (rlo_heads.c)"""
+    d, n = mu.shape
+    m = np.ascontiguousarray(mu.T, np.float32)
+    s = np.ascontiguousarray(raw_sigma.T, np.float32)
+    act = np.zeros((n, K, d), np.float32)
+    lp = np.zeros((n, K), np.float32) if want_logp else None
+    rc = lib().rlo_gaussian_head_sample_f32(_p(m), _p(s), C.c_int64(d), C.c_int64(n), C.c_int64(K), C.c_float(min_sigma),
+                                            C.c_float(max_sigma), C.c_int(squash), C.c_int(soft), C.c_uint64(seed),
+                                            C.c_uint32(env_id_base), C.c_uint32(step), _p(act), _p(lp))
+    assert rc == 0
+    return act.transpose(2, 1, 0), (lp.T if want_logp else None)
+
+
+def gaussian_head_logp(mu, raw_sigma, action, min_sigma=0.0, max_sigma=np.inf, squash=0, soft=0):
+    """action (d, K, n) -> logp (K, n)"""
+    d, n = mu.shape
+    K = action.shape[1]
+    m = np.ascontiguousarray(mu.T, np.float32)
+    s = np.ascontiguousarray(raw_sigma.T, np.float32)
+    a = np.ascontiguousarray(action.transpose(2, 1, 0), np.float32)
+    lp = np.zeros((n, K), np.float32)
+    rc = lib().rlo_gaussian_head_logp_f32(_p(m), _p(s), _p(a), C.c_int64(d), C.c_int64(n), C.c_int64(K),
+                                          C.c_float(min_sigma), C.c_float(max_sigma), C.c_int(squash), C.c_int(soft), _p(lp))
+    assert rc == 0
+    return lp.T

@@ -144,6 +144,16 @@ int rlo_env_obs(int kind, int is_f64, const rlo_env_state* st, int64_t n, void* 
 int rlo_env_obs_dim(int kind);
 int rlo_env_state_dim(int kind);
 
+/* ---------------------------------------------------------------- stochastic heads -- */
+/* GaussianNetwork / SoftGaussianNetwork heads  RLCore/src/utils/networks.jl:64-116, 147-198 (rlo_heads.c).
+ * mu, raw_sigma (d x n); K samples per state; action (d x K x n), logp (K x n); squash 0 identity / 1 tanh;
+ * soft 1 = SoftGaussianNetwork (always tanh).  d <= 64. */
+int rlo_gaussian_head_sample_f32(const float* mu, const float* raw_sigma, int64_t d, int64_t n, int64_t K,
+                                 float min_sigma, float max_sigma, int squash, int soft, uint64_t seed,
+                                 uint32_t env_id_base, uint32_t step, float* action_out, float* logp_out);
+int rlo_gaussian_head_logp_f32(const float* mu, const float* raw_sigma, const float* action, int64_t d, int64_t n,
+                               int64_t K, float min_sigma, float max_sigma, int squash, int soft, float* logp_out);
+
 /* ---------------------------------------------------------------- scans -- */
 /* RLCore/utils/basic.jl:138-235 discount_rewards, :237-319 discount_rewards_reduced,
  * :334-417 generalized_advantage_estimation.  Matrices column-major (n1 x n2).
