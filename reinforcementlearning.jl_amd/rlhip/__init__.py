@@ -16,7 +16,7 @@ from .explorers import (BatchExplorer, GumbelSoftmaxExplorer, UCBExplorer, Weigh
                         WeightedSoftmaxExplorer)
 from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint, state_dict  # noqa: F401
 from .timing import disable_debug_timings, enable_debug_timings, timer  # noqa: F401
-from .heads import GaussianNetwork, SoftGaussianNetwork  # noqa: F401
+from .heads import CategoricalNetwork, GaussianNetwork, SoftGaussianNetwork  # noqa: F401
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
 from .trajectory import (BatchSampler, CircularArraySARTSTraces, CircularPrioritizedTraces,  # noqa: F401
                          InsertSampleRatioController, Trajectory)

@@ -86,3 +86,32 @@ class SoftGaussianNetwork(GaussianNetwork):
 
     def __init__(self, pre=None, mu=None, sigma=None, min_sigma=0.0, max_sigma=float("inf"), seed=0, env_id_base=0):
         super().__init__(pre, mu, sigma, min_sigma, max_sigma, "tanh", seed, env_id_base)
+
+
+class CategoricalNetwork:
+    """CategoricalNetwork(model)  RLCore/src/utils/networks.jl:405-432 (+ masked methods :459-472).
+
+    `model` maps a state batch to logits shaped (na, n).  `(net)(state; is_sampling, is_return_log_prob)` returns the
+    logits, or a one-hot `z` (na, n) drawn with the Gumbel-max trick (`sample_categorical` :425-432, one launch:
+    rlhip_categorical_sample_f32 on the GUMBEL Philox stream), or `(z, logits)`; with a Bool `mask` (na, n) the masked
+    logits are `logits + ifelse(mask, 0, typemin)` (:461) and masked actions are never drawn.  `actions` holds the
+    0-based indices of the last draw (what the env kernels take)."""
+
+    def __init__(self, model, seed=0, env_id_base=0):
+        self.model, self.seed, self.env_id_base, self.step = model, int(seed), int(env_id_base), 0
+        self.actions = None
+
+    def __call__(self, state, mask=None, is_sampling=False, is_return_log_prob=False):
+        from .ops import categorical_sample
+
+        logits = self.model(state)
+        if mask is not None:
+            logits = logits + torch.where(mask.bool(), 0.0, float("-inf")).to(logits.dtype)
+        if not is_sampling:
+            return logits
+        lg = logits.contiguous()
+        self.actions, _ = categorical_sample(lg, self.seed, self.step, self.env_id_base, mask=mask, soa=True)
+        self.step += 1
+        z = torch.zeros_like(lg)
+        z.scatter_(0, self.actions.long().unsqueeze(0), 1.0)  # Flux.onehotbatch(z, 1:na)
+        return (z, logits) if is_return_log_prob else z

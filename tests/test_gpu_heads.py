@@ -106,3 +106,28 @@ def test_head_throughput_is_streaming(rl):
     byts = n * (3 * d + 1) * 4
     print(f"gaussian head d={d} n={n}: {us:.1f} us per call (incl. two transposes), {byts / us / 1e3:.1f} GB/s")
     assert byts / us / 1e3 > 100
+
+
+def test_categorical_network_call_forms(rl):
+    """CategoricalNetwork (networks.jl:405-432, masked :459-472): logits, one-hot Gumbel-max sample, (z, logits), mask"""
+    na, n = 5, 2000
+    lg = torch.randn((na, n), device="cuda")
+    net = rl.CategoricalNetwork(lambda s: lg, seed=3, env_id_base=7)
+    state = torch.zeros((4, n), device="cuda")
+    assert torch.equal(net(state), lg)
+    z, logits = net(state, is_sampling=True, is_return_log_prob=True)
+    assert z.shape == (na, n) and torch.equal(logits, lg) and torch.equal(z.sum(0), torch.ones(n, device="cuda"))
+    a_ref, _ = oracle.categorical_sample(lg.cpu().numpy(), seed=3, step=0, env_id_base=7)
+    assert np.array_equal(net.actions.cpu().numpy(), a_ref) and np.array_equal(z.argmax(0).cpu().numpy(), a_ref)
+    # empirical frequencies follow softmax(logits) on a constant-logit batch
+    lg2 = torch.tensor([0.0, 1.0, 2.0, -1.0, 0.5], device="cuda").unsqueeze(1).expand(na, 20000).contiguous()
+    net2 = rl.CategoricalNetwork(lambda s: lg2, seed=4)
+    freq = net2(torch.zeros((1, 20000), device="cuda"), is_sampling=True).mean(1)
+    np.testing.assert_allclose(freq.cpu().numpy(), torch.softmax(lg2[:, 0], 0).cpu().numpy(), atol=0.015)
+    # masked: -Inf logits, never sampled
+    mask = torch.ones((na, n), dtype=torch.bool, device="cuda")
+    mask[1] = False
+    mask[3, ::2] = False
+    zm, lm = net(state, mask, is_sampling=True, is_return_log_prob=True)
+    assert torch.isinf(lm[1]).all() and (zm[1] == 0).all() and (zm[3, ::2] == 0).all()
+    assert torch.equal(net(state, mask)[0], lg[0])
