@@ -165,6 +165,114 @@ __global__ __launch_bounds__(256, 2) void dense_tiled_kernel(const uint16_t* __r
     }
 }
 
+// ---- persistent kernel for the 256-wide hidden layer: weights in REGISTERS, X tiles double-buffered in LDS -----------
+// The tiled kernel above re-reads the B fragments from L2 in every wave of every workgroup: 4 waves x 128 KB per
+// 128-row tile against 64 KB of X -- the L2 -> CU fragment traffic (512 MB per 131072-row launch), not HBM (134 MB), was
+// what bounded it (72 us, 1.9 TB/s).  Here a wave owns 64 output columns for ALL 128 rows of a tile, so its B
+// fragments are 2 x K/16 registers-resident 16-byte vectors (128 VGPRs at K = 256), loaded once per workgroup
+// lifetime; one workgroup per CU walks row tiles blockIdx.x, blockIdx.x + gridDim.x, ...  While the MFMAs of tile i
+// run, the global loads of tile i + 1 are in flight (registers -> the other LDS buffer after the epilogue); the
+// bf16 result tile leaves through the consumed X buffer as 16 B/lane row-major stores.  LDS per workgroup: 2 x 128 x
+// (K + 8) x 2 B = 132 KB of the CU's 160 KB.  A fragments are read 4x (once per wave) from LDS: 256 KB per tile,
+// ~0.9 us at 128 B/clk -- below the tile's HBM time (128 KB at 1/256 of ~5 TB/s = 6.5 us).
+template <int KS, int ACT>
+__global__ __launch_bounds__(256, 1) void dense_persist_kernel(const uint16_t* __restrict__ X,
+                                                               const uint16_t* __restrict__ Wfrag,
+                                                               const float* __restrict__ bias, int64_t ntiles,
+                                                               uint16_t* __restrict__ Y) {
+    constexpr int K = 16 * KS, N = 256, PITCH = K + 8, OPITCH = N + 8;
+    constexpr int BUF = 128 * (PITCH > OPITCH ? PITCH : OPITCH);
+    constexpr int K8 = K / 8;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    uint16_t* const buf0 = reinterpret_cast<uint16_t*>(dsm);
+    uint16_t* const buf1 = buf0 + BUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    // this wave's 64 columns of W: fragments (ks, tg = 2 w + c), one 16-byte load each, kept for the whole launch
+    bf16x8 bw[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            bw[ks][c] = *reinterpret_cast<const bf16x8*>(Wfrag + ((int64_t)(ks * (N / 32) + 2 * w + c) * 64 + lane) * 8);
+    float bv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bv[c] = bias ? bias[64 * w + 32 * c + r] : 0.0f;
+    nt_u32x4 pre[KS];  // 128 x K bf16 = 128 K8 16-byte chunks = KS per thread
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {
+        const nt_u32x4* src = reinterpret_cast<const nt_u32x4*>(X + tile * 128 * K);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) pre[i] = nt_load16(src + tid + 256 * i);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int c = tid + 256 * i, row = c / K8, kc = c - row * K8;
+            *reinterpret_cast<nt_u32x4*>(buf0 + row * PITCH + 8 * kc) = pre[i];
+        }
+    }
+    __syncthreads();
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        uint16_t* const cur = (it & 1) ? buf1 : buf0;
+        uint16_t* const nxt = (it & 1) ? buf0 : buf1;
+        const int64_t next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) {  // in flight during the MFMA phase
+            const nt_u32x4* src = reinterpret_cast<const nt_u32x4*>(X + next * 128 * K);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) pre[i] = nt_load16(src + tid + 256 * i);
+        }
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[rt][c][q] = 0.0f;
+        const uint16_t* ap = cur + r * PITCH + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PITCH + 16 * ks);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks][c], acc[rt][c], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave is done reading the X tile: it becomes the output tile
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float y = acc[rt][c][q] + bv[c];
+                    if (ACT == 0) y = fmaxf(y, 0.0f);
+                    else if (ACT == 1) y = tanhf(y);
+                    cur[(32 * rt + mfma_row(q, kb)) * OPITCH + 64 * w + 32 * c + r] = f32_to_bf16_rne(y);
+                }
+        __syncthreads();
+        {
+            nt_u32x4* dst = reinterpret_cast<nt_u32x4*>(Y + tile * 128 * N);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {  // 128 x 256 bf16 = 4096 chunks
+                const int c = tid + 256 * i, row = c >> 5, cc = c & 31;
+                nt_store16(dst + c, *reinterpret_cast<const nt_u32x4*>(cur + row * OPITCH + 8 * cc));
+            }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const int c = tid + 256 * i, row = c / K8, kc = c - row * K8;
+                *reinterpret_cast<nt_u32x4*>(nxt + row * PITCH + 8 * kc) = pre[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Wt[n][k] (row-major bf16, k contiguous) -> MFMA B-fragment order: fragment (ks, tg) = 64 lanes x 8 elements,
 // lane l holds Wt[n = 32 tg + (l & 31)][k = 16 ks + 8 (l >> 5) + u]
 __global__ __launch_bounds__(256) void frag_weight_kernel(const uint16_t* __restrict__ wt, int K, int N,
@@ -257,11 +365,40 @@ int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w
     RLHIP_REQUIRE(act >= 0 && act <= 2, "act: 0 relu, 1 tanh, 2 identity");
     RLHIP_REQUIRE((((uintptr_t)x_rows | (uintptr_t)w_frag | (uintptr_t)y_rows) & 15) == 0,
                   "operands must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    if (n == 256 && y_is_bf16 && (k == 256 || k == 128) && !RLHIP_ENV_FLAG("RLHIP_DENSE_NO_PERSIST")) {
+        // the 256-wide hidden layer: weights in registers, one workgroup per CU walking the row tiles
+        const int64_t ntiles = batch / 128;
+        const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+        const size_t lds = (size_t)2 * 128 * (size_t)((k > 256 ? k : 256) + 8) * sizeof(uint16_t);
+#define LAUNCH_P(KS_, A_)                                                                                         \
+    do {                                                                                                          \
+        static bool set_ = false;                                                                                 \
+        if (!set_) {                                                                                              \
+            RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_persist_kernel<KS_, A_>),     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+            set_ = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((dense_persist_kernel<KS_, A_>), dim3(grid), dim3(256), lds, s, x_rows, w_frag, bias,  \
+                           ntiles, (uint16_t*)y_rows);                                                            \
+    } while (0)
+#define LAUNCH_PA(KS_)                     \
+    do {                                   \
+        if (act == 0) LAUNCH_P(KS_, 0);    \
+        else if (act == 1) LAUNCH_P(KS_, 1); \
+        else LAUNCH_P(KS_, 2);             \
+    } while (0)
+        if (k == 256) LAUNCH_PA(16);
+        else LAUNCH_PA(8);
+#undef LAUNCH_PA
+#undef LAUNCH_P
+        RLHIP_LAUNCH_CHECK();
+        return RLHIP_OK;
+    }
     const bool wide = (n % 256 == 0);  // 256-column blocks: X is read once when N = 256
     const int nb = wide ? 256 : 128;
     size_t lds = (size_t)128 * (size_t)((k > nb ? k : nb) + 8) * sizeof(uint16_t);
     dim3 grid((unsigned)(batch / 128), (unsigned)(n / nb));
-    hipStream_t s = as_stream(stream);
 #define LAUNCH_T(NTT_, A_, O_)                                                                                   \
     do {                                                                                                         \
         static size_t allowed_ = 0;                                                                              \
