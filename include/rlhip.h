@@ -468,6 +468,7 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, in
  * unpinned; BASELINE.json configs[4] ("prioritized sampling gather").
  * tree: float[rlhip_sumtree_nodes(n_leaves)] device, ZERO-INITIALISED by the caller; implicit heap (root 1,
  * leaf k at P + k, P = next pow2 >= n_leaves).  Internal nodes are recomputed as left + right (drift-free).
+ * tree[0] is not a heap node: rlhip_sumtree_update uses it as its arrival counter and leaves it 0.
  * Leaves are keyed by PHYSICAL ring position slot * n_env + env. */
 int64_t rlhip_sumtree_nodes(int64_t n_leaves);
 /* t[start+1 : start+count] .= value */

@@ -22,8 +22,9 @@
 // Kernels (all HBM/L2-latency bound, tiny next to the frame gather they feed):
 //   sumtree_level_kernel     one grid per level for bulk range fills (>= 2048 nodes on the level)
 //   sumtree_range_kernel     one 1024-thread workgroup finishes the remaining levels of a contiguous range
-//   sumtree_update_kernel    one workgroup: leaf writes with "last occurrence wins" for duplicate keys (the
-//                            sequential reference semantics), then the ancestors level by level
+//   sumtree_update_kernel    leaf writes with "last occurrence wins" for duplicate keys (the sequential reference
+//                            semantics), then the ancestors: sparse levels split over workgroups by subtree, the
+//                            top 13 levels recomputed whole in LDS by the last-arriving workgroup
 //   sumtree_sample_kernel    one lane per draw, log2(P) dependent 8-byte loads
 #include "common.h"
 
@@ -66,25 +67,50 @@ __global__ __launch_bounds__(1024) void sumtree_range_kernel(float* tree, int64_
     }
 }
 
+// Priority write-back `t[keys] .= ps`.  The ancestor chain is latency- AND issue-bound: one dependent global round
+// trip per level, and a level's random 8-byte accesses of all keys through ONE CU's memory pipeline (measured: 67 us
+// for 4096 keys on a 2^20-leaf tree, growing linearly with the key count).  So:
+//  * the tree is cut at the first level with <= TOPN nodes.  Keys below different cut nodes never share a node, so
+//    gridDim.x workgroups each take the cut nodes c with (c mod gridDim.x) == blockIdx.x and run election + the
+//    sparse levels on their own keys with workgroup barriers only (duplicates of a leaf land in one workgroup);
+//    membership is re-evaluated from the key array on every pass (coalesced, L2-resident) instead of building lists;
+//  * the child pairs of the sparse levels are touched once up front so that the dependent loads hit the L2;
+//  * the workgroup that arrives last (counter in the unused heap slot tree[0], re-armed to 0) recomputes the top of
+//    the tree WHOLE in LDS: one load of the 2 TOPN cut-level values, 13 LDS levels, stores on the way.
+// Parents are always left + right of the stored children: bit-identical to the sequential reference.
 __global__ __launch_bounds__(1024) void sumtree_update_kernel(float* tree, int64_t P, int logP, int64_t n_leaves,
                                                               const int64_t* __restrict__ leaf,
                                                               const float* __restrict__ prio, int64_t n) {
+    constexpr int TOPN = 4096;
+    __shared__ float l_a[2 * TOPN], l_b[TOPN];  // ping-pong: 2 TOPN children -> TOPN nodes -> TOPN / 2 -> ...
+    __shared__ int l_last;
     uint32_t* bits = reinterpret_cast<uint32_t*>(tree);
     const int tid = threadIdx.x;
-    auto key = [&](int64_t i) -> int64_t {  // out-of-range keys are ignored (never written)
-        int64_t k = leaf[i];
-        return (k >= 0 && k < n_leaves) ? k : -1;
+    const int ltop = logP > 12 ? logP - 12 : 1;  // first level (counted from the leaves) with <= TOPN nodes
+    const int64_t gmask = (int64_t)gridDim.x - 1;  // gridDim.x is a power of two <= 2 TOPN
+    const int64_t mine = blockIdx.x;
+    auto key = [&](int64_t i) -> int64_t {  // out-of-range keys are ignored (never written); -1 also for other
+        int64_t k = leaf[i];               // workgroups' keys
+        if (k < 0 || k >= n_leaves) return -1;
+        return ((((P + k) >> (ltop - 1)) & gmask) == mine) ? k : -1;
     };
+    // this workgroup's view of the first 2 TOPN keys (-1 = not mine / out of range) is kept in LDS: every pass below
+    // walks the whole key array, and re-deriving membership from global memory costs a round trip per pass
+    int32_t* l_keys = reinterpret_cast<int32_t*>(l_a);  // l_a is not needed before the top-of-tree phase
+    const int64_t KC = n_leaves < (1ll << 31) ? 2 * TOPN : 0;  // (leaf indices fit the int32 cache)
+    for (int64_t i = tid; i < n && i < KC; i += 1024) l_keys[i] = (int32_t)key(i);
+    __syncthreads();
+    auto keyc = [&](int64_t i) -> int64_t { return i < KC ? (int64_t)l_keys[i] : key(i); };
     // duplicate keys: the LAST occurrence wins (sequential `for (k, p) in zip(keys, ps); t[k] = p; end`).
     // The leaf itself carries the election: zero it, atomicMax the 1-based item number into it, then the
     // winner replaces the tag by its priority.
     for (int64_t i = tid; i < n; i += 1024) {
-        int64_t k = key(i);
+        int64_t k = keyc(i);
         if (k >= 0) bits[P + k] = 0u;
     }
     __syncthreads();
     for (int64_t i = tid; i < n; i += 1024) {
-        int64_t k = key(i);
+        int64_t k = keyc(i);
         if (k >= 0) atomicMax(&bits[P + k], (uint32_t)(i + 1));
     }
     // chunks of MAXR * 1024 items: every item of a chunk reads its verdict before any winner of that chunk
@@ -96,7 +122,7 @@ __global__ __launch_bounds__(1024) void sumtree_update_kernel(float* tree, int64
 #pragma unroll
         for (int r = 0; r < MAXR; ++r) {
             int64_t i = base + tid + (int64_t)r * 1024;
-            int64_t k = i < n ? key(i) : -1;
+            int64_t k = i < n ? keyc(i) : -1;
             own[r] = k >= 0 && bits[P + k] == (uint32_t)(i + 1);
         }
         __syncthreads();
@@ -106,26 +132,67 @@ __global__ __launch_bounds__(1024) void sumtree_update_kernel(float* tree, int64
             if (own[r]) tree[P + leaf[i]] = prio[i];
         }
     }
-    __syncthreads();
-    // ancestors, level by level; a level with no more nodes than items is recomputed whole
-    for (int l = 1; l <= logP; ++l) {
-        int64_t level_first = P >> l, level_nodes = P >> l;
-        if (level_nodes <= n) {
-            for (int64_t q = tid; q < level_nodes; q += 1024) {
-                int64_t node = level_first + q;
-                float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
-                tree[node] = c.x + c.y;
+    // sparse levels 1 .. ltop - 1
+    if (ltop > 2) {
+        for (int64_t i = tid; i < n; i += 1024) {
+            int64_t k = keyc(i);
+            if (k < 0) continue;
+            for (int l = 2; l < ltop; ++l) {  // level 1's pairs are the leaves just written
+                float2 c = *reinterpret_cast<const float2*>(tree + 2 * ((P + k) >> l));
+                asm volatile("" ::"v"(c.x), "v"(c.y));
             }
-        } else {
-            for (int64_t i = tid; i < n; i += 1024) {
-                int64_t k = key(i);
-                if (k < 0) continue;
-                int64_t node = (P + k) >> l;
-                float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
-                tree[node] = c.x + c.y;  // duplicates write the same value
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < ltop; ++l) {
+        for (int64_t i = tid; i < n; i += 1024) {
+            int64_t k = keyc(i);
+            if (k < 0) continue;
+            int64_t node = (P + k) >> l;
+            // agent-scope loads: past the L1, which may hold the line from the touch pass above
+            float cx = __hip_atomic_load(tree + 2 * node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float cy = __hip_atomic_load(tree + 2 * node + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tree[node] = cx + cy;  // duplicates write the same value
+        }
+        __syncthreads();
+    }
+    // arrival: the last workgroup finishes the top of the tree
+    if (gridDim.x > 1) {
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned int prev = __hip_atomic_fetch_add(bits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l_last = (prev == gridDim.x - 1) ? 1 : 0;
+            if (l_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tree[0] = 0.0f again
             }
         }
         __syncthreads();
+        if (!l_last) return;
+    }
+    {
+        __syncthreads();  // l_keys (aliasing l_a) is dead from here
+        // children of level ltop: level ltop - 1, nodes [P >> (ltop - 1), 2 * that)
+        const int64_t cfirst = P >> (ltop - 1), cn = P >> (ltop - 1);
+        for (int64_t q = tid; q < cn; q += 1024)
+            l_a[q] = __hip_atomic_load(tree + cfirst + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        int64_t m = cn >> 1;  // nodes on level ltop
+        float* src = l_a;
+        float* dst = l_b;
+        for (int l = ltop; l <= logP; ++l) {
+            for (int64_t q = tid; q < m; q += 1024) {
+                const float v = src[2 * q] + src[2 * q + 1];
+                dst[q] = v;
+                tree[(P >> l) + q] = v;
+            }
+            __syncthreads();
+            float* t = src;
+            src = dst;
+            dst = t;
+            m >>= 1;
+        }
     }
 }
 
@@ -216,8 +283,11 @@ int32_t rlhip_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf,
     RLHIP_REQUIRE(tree && leaf && prio, "NULL array");
     RLHIP_REQUIRE(n < (1ll << 31), "too many keys in one update");
     const int64_t P = pow2_ge(n_leaves);
-    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(1024), 0, as_stream(stream), tree, P, log2_of(P), n_leaves,
-                       leaf, prio, n);
+    const int logP = log2_of(P);
+    // several workgroups only when there are sparse levels to split (P > 8192) and enough keys to pay for it
+    const int groups = (logP <= 13 || n < 1024) ? 1 : (n < 16384 ? 64 : 256);
+    hipLaunchKernelGGL(sumtree_update_kernel, dim3(groups), dim3(1024), 0, as_stream(stream), tree, P, logP, n_leaves, leaf,
+                       prio, n);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
