@@ -47,35 +47,45 @@ struct DqnArgs {
     float* td_out;       // optional |Q(s,a) - y| per sample (priority write-back)
 };
 
+// One workgroup = one 64-sample tile (a 512-sample batch is 8 workgroups, so the kernel is a latency chain, not a
+// throughput problem -- measured 19.5 us per launch for the first version, which walked the hidden units with
+// dependent global loads):
+//   phase 0   64 lanes draw their sample (BatchSampler Philox draw or explicit index), issue the 11 scattered ring
+//             loads and keep them in registers; meanwhile ALL lanes stage both networks' weights into LDS
+//             (component-major: a hidden unit's weights are broadcast reads later) -- one overlapped round trip
+//   phase 1a  lane = sample, wave w walks its quarter of the hidden units for Q(s) and Q_target(s') from LDS
+//   phase 1b  64 lanes: TD target, Huber loss, dL/dq
+//   phase 2   lane = hidden unit (weights in registers), samples stream from LDS as broadcast reads; when 2 h <= 256
+//             the two halves of the tile go to two lane groups and are added in a fixed order at the end
+// Gradient partials per workgroup, summed in a fixed order by dqn_reduce[_apply]_kernel: run-to-run deterministic.
 template <int NS, int ACT>
 __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
-    __shared__ float l_s[NS][DTILE], l_sn[NS][DTILE];
+    // LDS: everything a later phase reads as a unit is ONE 16-byte vector (a broadcast or a conflict-free b128 read):
+    //   l_rec[net][j] = {W1[j, 0..3]}, {b1[j], W2[0..2, j]}, {W2[3, j], -, -, -}   (rows beyond NS / na are zeros)
+    //   l_s4 / l_sn4 [sample] = state / next state, l_dL4[sample] = dL/dq
+    constexpr int HMAX = 256;
+    static_assert(NS <= 4 && MAXO == 4, "record layout");
+    __shared__ float4 l_s4[DTILE], l_sn4[DTILE], l_dL4[DTILE];
     __shared__ float l_r[DTILE];
     __shared__ int32_t l_a[DTILE];
     __shared__ uint8_t l_t[DTILE];
     __shared__ float l_part[4][2 * MAXO][DTILE];
-    __shared__ float l_dL[MAXO][DTILE];
+    __shared__ float4 l_rec[2][HMAX][3];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = g.h, na = g.na, hq = h >> 2;
-    const float* W1 = g.params;
-    const float* b1 = W1 + h * NS;
-    const float* W2 = b1 + h;
-    const float* b2 = W2 + na * h;
-    const float* tW1 = g.tparams;
-    const float* tb1 = tW1 + h * NS;
-    const float* tW2 = tb1 + h;
-    const float* tb2 = tW2 + na * h;
+    const float* b2 = g.params + h * NS + h + na * h;
+    const float* tb2 = g.tparams + h * NS + h + na * h;
 
-    const bool owner = tid < h;
-    const int j = owner ? tid : 0;
-    float rw1[NS], rw2[MAXO];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) rw1[k] = W1[j + h * k];
-    const float rb1 = b1[j];
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o) rw2[o] = (o < na) ? W2[o + na * j] : 0.f;
+    // phase-2 ownership: lane group `half` of hidden unit j
+    const int halves = (2 * h <= 256) ? 2 : 1;
+    const int half = tid / h;
+    const bool owner = half < halves;
+    const int j = owner ? tid - half * h : 0;
+    const int s_lo = (halves == 2) ? half * (DTILE / 2) : 0;
+    const int s_hi = (halves == 2) ? s_lo + DTILE / 2 : DTILE;
+
     float gw1[NS], gw2[MAXO], gb1 = 0.f;
 #pragma unroll
     for (int k = 0; k < NS; ++k) gw1[k] = 0.f;
@@ -83,8 +93,14 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
     for (int o = 0; o < MAXO; ++o) gw2[o] = 0.f;
     float gb2[MAXO] = {0.f, 0.f, 0.f, 0.f};
     float s_loss = 0.f;
+    float rw1[NS], rw2[MAXO], rb1 = 0.f;
+    bool staged = false;
 
     for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
+        // ---- phase 0: gather into registers ----
+        float gs[NS], gsn[NS], gr = 0.f;
+        int32_t ga = 0;
+        uint8_t gt = 0;
         if (tid < DTILE) {
             int64_t b = (int64_t)tile * DTILE + tid;
             bool valid = b < g.batch;
@@ -102,36 +118,80 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             int64_t pt = (g.head_rt + li) % g.capacity;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                l_s[k][tid] = g.state[(ps * NS + k) * g.n_env + e];
-                l_sn[k][tid] = g.state[(pn * NS + k) * g.n_env + e];
+                gs[k] = g.state[(ps * NS + k) * g.n_env + e];
+                gsn[k] = g.state[(pn * NS + k) * g.n_env + e];
             }
-            l_a[tid] = g.action[pt * g.n_env + e];
-            l_r[tid] = g.reward[pt * g.n_env + e];
-            l_t[tid] = g.terminal[pt * g.n_env + e];
+            ga = g.action[pt * g.n_env + e];
+            gr = g.reward[pt * g.n_env + e];
+            gt = g.terminal[pt * g.n_env + e];
         }
-        __syncthreads();
-        {
-            float x[NS], xn[NS];
+        if (!staged) {  // both networks -> LDS, while the gather is in flight
+            for (int q = tid; q < 2 * h; q += 256) {
+                const int net = q >= h ? 1 : 0, u = q - net * h;
+                const float* P = net ? g.tparams : g.params;
+                float w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                x[k] = l_s[k][lane];
-                xn[k] = l_sn[k][lane];
-            }
-            float acc[MAXO] = {0.f, 0.f, 0.f, 0.f}, acn[MAXO] = {0.f, 0.f, 0.f, 0.f};
-            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
-                float z = b1[jj], zn = tb1[jj];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    z = fmaf(W1[jj + h * k], x[k], z);
-                    zn = fmaf(tW1[jj + h * k], xn[k], zn);
-                }
-                float hv = act_fwd_t<ACT>(z), hn = act_fwd_t<ACT>(zn);
+                for (int k = 0; k < NS; ++k) w1[k] = P[u + h * k];
 #pragma unroll
                 for (int o = 0; o < MAXO; ++o)
-                    if (o < na) {
-                        acc[o] = fmaf(W2[o + na * jj], hv, acc[o]);
-                        acn[o] = fmaf(tW2[o + na * jj], hn, acn[o]);
-                    }
+                    if (o < na) w2[o] = P[h * NS + h + o + na * u];
+                l_rec[net][u][0] = make_float4(w1[0], w1[1], w1[2], w1[3]);
+                l_rec[net][u][1] = make_float4(P[h * NS + u], w2[0], w2[1], w2[2]);
+                l_rec[net][u][2] = make_float4(w2[3], 0.f, 0.f, 0.f);
+            }
+        }
+        if (tid < DTILE) {
+            float a4[4] = {0.f, 0.f, 0.f, 0.f}, n4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                a4[k] = gs[k];
+                n4[k] = gsn[k];
+            }
+            l_s4[tid] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            l_sn4[tid] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+            l_a[tid] = ga;
+            l_r[tid] = gr;
+            l_t[tid] = gt;
+        }
+        __syncthreads();
+        if (!staged) {
+            staged = true;
+            const float4 r0 = l_rec[0][j][0], r1 = l_rec[0][j][1], r2 = l_rec[0][j][2];
+            const float t1[4] = {r0.x, r0.y, r0.z, r0.w};
+#pragma unroll
+            for (int k = 0; k < NS; ++k) rw1[k] = t1[k];
+            rb1 = r1.x;
+            rw2[0] = r1.y;
+            rw2[1] = r1.z;
+            rw2[2] = r1.w;
+            rw2[3] = r2.x;
+        }
+        // ---- phase 1a ----
+        {
+            const float4 xs = l_s4[lane], xns = l_sn4[lane];
+            const float x[4] = {xs.x, xs.y, xs.z, xs.w}, xn[4] = {xns.x, xns.y, xns.z, xns.w};
+            float acc[MAXO] = {0.f, 0.f, 0.f, 0.f}, acn[MAXO] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
+                const float4 a0 = l_rec[0][jj][0], a1 = l_rec[0][jj][1], c0 = l_rec[1][jj][0], c1 = l_rec[1][jj][1];
+                const float wa[4] = {a0.x, a0.y, a0.z, a0.w}, wc[4] = {c0.x, c0.y, c0.z, c0.w};
+                float z = a1.x, zn = c1.x;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    z = fmaf(wa[k], x[k], z);
+                    zn = fmaf(wc[k], xn[k], zn);
+                }
+                const float hv = act_fwd_t<ACT>(z), hn = act_fwd_t<ACT>(zn);
+                acc[0] = fmaf(a1.y, hv, acc[0]);  // rows o >= na are staged as zeros
+                acn[0] = fmaf(c1.y, hn, acn[0]);
+                acc[1] = fmaf(a1.z, hv, acc[1]);
+                acn[1] = fmaf(c1.z, hn, acn[1]);
+                acc[2] = fmaf(a1.w, hv, acc[2]);
+                acn[2] = fmaf(c1.w, hn, acn[2]);
+                if (na == 4) {
+                    acc[3] = fmaf(l_rec[0][jj][2].x, hv, acc[3]);
+                    acn[3] = fmaf(l_rec[1][jj][2].x, hn, acn[3]);
+                }
             }
 #pragma unroll
             for (int o = 0; o < MAXO; ++o) {
@@ -140,6 +200,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             }
         }
         __syncthreads();
+        // ---- phase 1b ----
         if (tid < DTILE) {
             const int s = tid;
             bool valid = ((int64_t)tile * DTILE + s) < g.batch;
@@ -172,20 +233,21 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                 g.td_out[(int64_t)tile * DTILE + s] = e;
             }
             s_loss += l;
+            float dl[MAXO];
 #pragma unroll
             for (int o = 0; o < MAXO; ++o) {
-                float dl = (o == a) ? gi : 0.f;
-                l_dL[o][s] = dl;
-                gb2[o] += dl;
+                dl[o] = (o == a) ? gi : 0.f;
+                gb2[o] += dl[o];
             }
+            l_dL4[s] = make_float4(dl[0], dl[1], dl[2], dl[3]);
         }
         __syncthreads();
+        // ---- phase 2 ----
         if (owner) {
 #pragma unroll 4
-            for (int s = 0; s < DTILE; ++s) {
-                float x[NS];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) x[k] = l_s[k][s];
+            for (int s = s_lo; s < s_hi; ++s) {
+                const float4 xs = l_s4[s], d4 = l_dL4[s];
+                const float x[4] = {xs.x, xs.y, xs.z, xs.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
                 float z = rb1;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) z = fmaf(rw1[k], x[k], z);
@@ -193,7 +255,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                 float dh = 0.f;
 #pragma unroll
                 for (int o = 0; o < MAXO; ++o) {
-                    float d = l_dL[o][s];
+                    const float d = dd[o];
                     gw2[o] = fmaf(d, hv, gw2[o]);
                     dh = fmaf(d, rw2[o], dh);
                 }
@@ -205,8 +267,31 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
         }
         __syncthreads();
     }
+    // second lane group -> LDS -> first lane group (fixed order: first + second); l_rec[1] is free now
+    if (halves == 2) {
+        if (owner && half == 1) {
+            float t1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NS; ++k) t1[k] = gw1[k];
+            l_rec[1][j][0] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+            l_rec[1][j][1] = make_float4(gb1, gw2[0], gw2[1], gw2[2]);
+            l_rec[1][j][2] = make_float4(gw2[3], 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (owner && half == 0) {
+            const float4 r0 = l_rec[1][j][0], r1 = l_rec[1][j][1], r2 = l_rec[1][j][2];
+            const float t1[4] = {r0.x, r0.y, r0.z, r0.w};
+#pragma unroll
+            for (int k = 0; k < NS; ++k) gw1[k] += t1[k];
+            gb1 += r1.x;
+            gw2[0] += r1.y;
+            gw2[1] += r1.z;
+            gw2[2] += r1.w;
+            gw2[3] += r2.x;
+        }
+    }
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
-    if (owner) {
+    if (owner && half == 0) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) out[j + h * k] = gw1[k];
         out[h * NS + j] = gb1;
