@@ -144,28 +144,28 @@ class P2PAllReduce:
                 good = False
         if not cls._agree(good, group, device):
             return None
-        # self-test against the library all-reduce: same sums (up to summation order), bit-identical across ranks
+        # self-test against the library all-reduce: same sums (up to summation order), bit-identical across ranks.
+        # Every rank issues the SAME sequence of library collectives whatever happens locally (no early exit, local
+        # failures only clear `passed`): a rank that bailed out alone would leave the others inside a collective.
         passed = True
-        try:
-            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
-            for _ in range(3):
-                x = torch.randn(min(self.cap, 4099), generator=g).to(device)
-                ref = x.clone()
-                dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=group)
-                y = x.clone()
+        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        for _ in range(3):
+            x = torch.randn(min(self.cap, 4099), generator=g).to(device)
+            ref = x.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=group)
+            y = x.clone()
+            try:
                 self.all_reduce_(y, timeout_polls=cls.SELFTEST_TIMEOUT_POLLS)
                 torch.cuda.synchronize()
                 if int(self.status.item()) != 0 or not torch.allclose(y, ref, rtol=1e-5, atol=1e-5):
                     passed = False
-                    break
-                lo, hi = y.clone(), y.clone()
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-                if not torch.equal(lo, hi):
-                    passed = False
-                    break
-        except Exception:  # noqa: BLE001
-            passed = False
+            except Exception:  # noqa: BLE001
+                passed = False
+            lo, hi = y.clone(), y.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            if not torch.equal(lo, hi):
+                passed = False
         if not cls._agree(passed, group, device):
             return None
         self.ok = True
