@@ -424,6 +424,45 @@ def cpu_baseline(budget_s=8.0):
             "single_thread": single}
 
 
+def allreduce_report(torch, pol, world):
+    """SURVEY 8(e) "what to report", N > 1 only, outside the timed region, every rank in lock-step: latency of the
+    gradient exchange at the real gradient size (library all-reduce and, when it is active, the one-shot peer-to-peer
+    kernel), and the library's bus bandwidth over 4 KB .. 256 MB (busbw = 2 (N - 1) / N x bytes / time)."""
+    import torch.distributed as dist
+
+    def timed(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / iters], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {"world": world, "gradient_bytes": int(pol.np) * 4}
+    g = torch.zeros(int(pol.np), dtype=torch.float32, device="cuda")
+    out["library_us_at_gradient_size"] = round(timed(lambda: dist.all_reduce(g), 50), 2)
+    p2p = getattr(pol, "_p2p", None)
+    if p2p is not None:
+        out["p2p_us_at_gradient_size"] = round(timed(lambda: p2p.all_reduce_(g), 50), 2)
+    sweep = []
+    for nbytes in (4 << 10, 64 << 10, 1 << 20, 16 << 20, 256 << 20):
+        x = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+        us = timed(lambda: dist.all_reduce(x), 20 if nbytes <= (1 << 20) else 5)
+        sweep.append({"bytes": nbytes, "us": round(us, 2),
+                      "busbw_gbs": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 2)})
+        del x
+    out["library_sweep"] = sweep
+    out["bounds"] = "ring: one xGMI link (~153 GB/s); direct reduce-scatter + all-gather over 7 links: ~1.07 TB/s egress per GPU"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -536,6 +575,11 @@ def main():
         result["roofline"] = roofline_env_step(torch, rlhip)
         result["roofline_extra"] = roofline_extras(torch, rlhip)
         result["cpu_baseline"] = cpu_baseline()
+    if world > 1 and not args.no_extras:
+        try:  # collective on every rank; a local failure must not cost the bench line
+            result["allreduce"] = allreduce_report(torch, pol, world)
+        except Exception as exc:  # noqa: BLE001
+            result["allreduce"] = {"error": repr(exc)}
     if getattr(pol, "_p2p", None) is not None:
         result["p2p_timeouts"] = bool(pol._p2p.failed())  # must be false: a timed-out exchange leaves the step unreduced
     if rank == 0:

@@ -3,6 +3,8 @@ DQN learner end to end, and the multi-process gradient all-reduce with the real 
 one GPU over `gloo`, because RCCL refuses two ranks on one device)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -388,3 +390,28 @@ def test_debug_timer_reports_device_time_per_run_loop_section():
     n_before = len(d)
     rlhip.run(agent, env, rlhip.StopAfterNSteps(3))          # disabled again: nothing is recorded
     assert rlhip.timer.todict()["plan!"]["ncalls"] == 700 and len(rlhip.timer.todict()) == n_before
+
+
+def test_bench_two_ranks_on_one_device_prints_the_contract_line():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), both ranks on this
+    box's single GPU via the RLHIP_BENCH_SINGLE_DEVICE test hook: the JSON contract line, the exchange mode, the
+    all-reduce report of SURVEY 8(e), no peer-to-peer timeouts"""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RLHIP_BENCH_SINGLE_DEVICE="1", RLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")  # RCCL refuses two ranks on one device
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["metric"] == "env_steps_per_sec" and d["config"]["n_envs_per_gpu"] == 4096
+    ar = d["allreduce"]
+    assert "error" not in ar and ar["world"] == 2 and ar["gradient_bytes"] == 3331 * 4
+    assert ar["library_us_at_gradient_size"] > 0 and len(ar["library_sweep"]) == 5
+    if d["gradient_allreduce"].startswith("p2p"):
+        assert d["p2p_timeouts"] is False and ar["p2p_us_at_gradient_size"] > 0
