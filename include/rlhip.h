@@ -460,6 +460,17 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, in
                             int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
                             uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
                             rlhip_stream_t stream);
+/* optimise!(learner, batch) of the 3-layer learner complete, in two launches: the gradient (as rlhip_dqn3_grad_f32
+ * with the inline uniform draw), then reduce + clip-by-global-norm + Adam + the bf16 re-pack of W2 in one launch;
+ * bit-identical to rlhip_dqn3_grad_f32, rlhip_clip_adam_f32, rlhip_mlp3_pack_bf16 in sequence.  `packed` is updated
+ * in place.  The tail of `workspace` (rlhip_dqn3_workspace_bytes) holds the launch's counters: zero before the
+ * first call, re-armed by every call. */
+int32_t rlhip_dqn3_update_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act, float* params,
+                              uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                              int64_t batch, float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr,
+                              void* workspace, float* grad_out, float* loss_out, float* m, float* v,
+                              float* beta_pow, float grad_scale, float max_grad_norm, float lr, float beta1,
+                              float beta2, float adam_eps, float* gn_out, rlhip_stream_t stream);
 
 /* -------------------------------------------------------------------- priority sum-tree -- */
 /* Prioritized replay: CircularArrayBuffers.SumTree (compat 0.1.12, RLCore/Project.toml:30) behind

@@ -48,6 +48,7 @@ __device__ long long g_d3_stamps[32];
 }  // namespace rlhip
 
 #include "mlp3_device.h"
+#include "optim_device.h"
 
 namespace rlhip {
 
@@ -313,6 +314,113 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
     }
 }
 
+// optimise! tail of the 3-layer learner in ONE launch: d3_reduce_kernel + sumsq_scaled_partial_kernel +
+// clip_adam_grid_kernel (optim.hip, the > 12 k parameter regime of rlhip_clip_adam_f32) + mlp3_pack_kernel.
+// One lane per parameter, ceil(np / 256) workgroups (69 for the 17 410-parameter CartPole net: all co-resident, so
+// a spin barrier on an agent-scope counter is safe).  Every step reproduces the arithmetic of the kernel it
+// replaces -- the block reduction order, the Float64 per-workgroup sums of squares and their fold, the Adam expression
+// -- so the result is bit-identical to the four launches; the bf16 fragment copies of W2 are refreshed in place.
+struct D3Apply {
+    float* p;
+    float* m;
+    float* v;
+    float* beta_pow;
+    float* gn_out;
+    uint16_t* packed;
+    double* sumsq;           // [gridDim.x] in the workspace tail
+    unsigned int* counter;   // [0] arrive, [1] depart: zero before the first launch, re-armed here
+    float grad_scale, clip_norm, lr, b1, b2, eps;
+    int ns;
+};
+
+__global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__ partials,
+                                                       const float* __restrict__ loss_partials, int nb, int np,
+                                                       float* __restrict__ grad, float* __restrict__ loss, float inv_b,
+                                                       D3Apply ap) {
+    __shared__ double scratch[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.x * 256 + tid;
+    const bool own = i < np;
+    // operands that do not depend on the barrier
+    const float p0 = own ? ap.p[i] : 0.f, m0 = own ? ap.m[i] : 0.f, v0 = own ? ap.v[i] : 0.f;
+    const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+    // d3_reduce_kernel: block range split in four, ascending inside a part, then ((a0 + a1) + a2) + a3
+    float g = 0.f;
+    if (own) {
+        const int per = (nb + 3) / 4;
+        float a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b0 = q * per, b1 = min(nb, b0 + per);
+            float acc = 0.f;
+#pragma unroll 8
+            for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + i];
+            a[q] = acc;
+        }
+        g = ((a[0] + a[1]) + a[2]) + a[3];
+    }
+    if (blockIdx.x == 0 && loss != nullptr && wv == 1) {
+        float a = 0.f;
+        for (int b = lane; b < nb; b += 64) a += loss_partials[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) loss[0] = a * inv_b;
+    }
+    // sumsq_scaled_partial_kernel (one element per lane at this size)
+    const float x = own ? g * ap.grad_scale : 0.0f;
+    double acc = own ? (double)x * (double)x : 0.0;
+    acc = block_sum(acc, scratch);
+    if (tid == 0) {
+        __hip_atomic_store(ap.sumsq + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ap.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // clip_adam_grid_kernel
+    double tot = 0.0;
+    for (int q = tid; q < (int)gridDim.x; q += 256)
+        tot += __hip_atomic_load(ap.sumsq + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot = block_sum(tot, scratch);
+    const float gn = (float)sqrt(tot);
+    const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+    if (own) {
+        float gi = g * ap.grad_scale;
+        if (scale != 1.0f) gi *= scale;
+        float pi = p0, mi = m0, vi = v0;
+        adam1(pi, gi, mi, vi, ap.lr, ap.b1, ap.b2, ap.eps, c1, c2);
+        ap.p[i] = pi;
+        ap.m[i] = mi;
+        ap.v[i] = vi;
+        grad[i] = gi;
+        // mlp3_pack_kernel, parameter-centric: W2[j + H3 k] goes to one slot of each fragment orientation
+        const int e = i - (H3 * ap.ns + H3);
+        if (e >= 0 && e < H3 * H3) {
+            const int j = e & (H3 - 1), k = e >> 7;
+            const uint16_t hb = f32_to_bf16_rne(pi);
+            const int q1 = (((k >> 4) * 4 + (j >> 5)) << 9) | (((j & 31) + 32 * ((k >> 3) & 1)) << 3) | (k & 7);
+            const int q2 = (((j >> 4) * 4 + (k >> 5)) << 9) | (((k & 31) + 32 * ((j >> 3) & 1)) << 3) | (j & 7);
+            ap.packed[q1] = hb;
+            ap.packed[H3 * H3 + q2] = hb;
+        }
+    }
+    __syncthreads();  // every lane of this workgroup has read beta_pow
+    if (tid == 0) {
+        if (blockIdx.x == 0 && ap.gn_out) ap.gn_out[0] = gn;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow or the arrival counter any more
+            ap.beta_pow[0] *= ap.b1;
+            ap.beta_pow[1] *= ap.b2;
+            __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
 constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
                             3 * TILE_ELEMS * sizeof(uint16_t);
@@ -397,14 +505,18 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
 int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
     int64_t nb = (batch + TR - 1) / TR;
     if (nb < 1) nb = 1;
-    return nb * (mlp3_nparams(ns, h, na) + 1) * (int64_t)sizeof(float);
+    // partials | loss partials | (8-byte aligned) 256 Float64 sums of squares + 64 B of counters for
+    // rlhip_dqn3_update_f32 (the tail must be zero before the first use)
+    int64_t base = nb * (mlp3_nparams(ns, h, na) + 1) * (int64_t)sizeof(float);
+    base = (base + 7) & ~(int64_t)7;
+    return base + 256 * (int64_t)sizeof(double) + 64;
 }
 
-int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
-                            const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
-                            int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
-                            uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
-                            rlhip_stream_t stream) {
+static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                              const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                              int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
+                              uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
+                              rlhip_stream_t stream, D3Apply* apply) {
     RLHIP_REQUIRE(rb && params && packed && target_params && target_packed && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
@@ -457,10 +569,43 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t
     else if (ns == 2 && na == 3) { if (act == 0) LAUNCH_G(2, 3, 0); else LAUNCH_G(2, 3, 1); }
     else { if (act == 0) LAUNCH_G(3, 3, 0); else LAUNCH_G(3, 3, 1); }
 #undef LAUNCH_G
-    hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials, nb,
-                       (int)np, grad_out, loss_out, g.inv_b);
+    if (apply) {
+        int64_t base = ((int64_t)nb * (np + 1) * (int64_t)sizeof(float) + 7) & ~(int64_t)7;
+        apply->sumsq = (double*)((char*)workspace + base);
+        apply->counter = (unsigned int*)((char*)workspace + base + 256 * sizeof(double));
+        apply->ns = ns;
+        hipLaunchKernelGGL(d3_apply_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials,
+                           nb, (int)np, grad_out, loss_out, g.inv_b, *apply);
+    } else {
+        hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
+                           nb, (int)np, grad_out, loss_out, g.inv_b);
+    }
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
+}
+
+int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                            const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                            int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
+                            uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
+                            rlhip_stream_t stream) {
+    return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta,
+                          seed, draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr);
+}
+
+/* optimise!(learner, batch) of the 3-layer learner in two launches: gradient, then reduce + clip + Adam + bf16
+ * re-pack (bit-identical to rlhip_dqn3_grad_f32, rlhip_clip_adam_f32, rlhip_mlp3_pack_bf16 in sequence) */
+int32_t rlhip_dqn3_update_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, float* params, uint16_t* packed,
+                              const float* target_params, const uint16_t* target_packed, int64_t batch, float gamma,
+                              float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
+                              float* loss_out, float* m, float* v, float* beta_pow, float grad_scale,
+                              float max_grad_norm, float lr, float beta1, float beta2, float adam_eps, float* gn_out,
+                              rlhip_stream_t stream) {
+    RLHIP_REQUIRE(m && v && beta_pow, "NULL argument");
+    D3Apply ap{params, m, v, beta_pow, gn_out, packed, nullptr, nullptr, grad_scale, max_grad_norm, lr, beta1, beta2,
+               adam_eps, 0};
+    return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, nullptr, gamma,
+                          huber_delta, seed, draw_ctr, workspace, grad_out, loss_out, nullptr, stream, &ap);
 }
 
 }  // extern "C"

@@ -29,6 +29,9 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const f
 int32_t rlhip_dqn3_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const float*, const uint16_t*, const float*,
                             const uint16_t*, int64_t, const int64_t*, float, float, uint64_t, uint32_t, void*, float*,
                             float*, float*, rlhip_stream_t);
+int32_t rlhip_dqn3_update_f32(const rlhip_ring*, int64_t, int64_t, int32_t, float*, uint16_t*, const float*, const uint16_t*,
+                              int64_t, float, float, uint64_t, uint32_t, void*, float*, float*, float*, float*, float*,
+                              float, float, float, float, float, float, float*, rlhip_stream_t);
 int32_t rlhip_mlp3_pack_bf16(const float*, int64_t, int64_t, int64_t, uint16_t*, rlhip_stream_t);
 int64_t rlhip_mlp2_nparams(int64_t, int64_t, int64_t);
 int64_t rlhip_mlp3_nparams(int64_t, int64_t, int64_t);
@@ -83,6 +86,14 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
                                   a->sampler_seed, a->draw_ctr, a->workspace, a->grad, a->loss, a->m, a->v, a->beta_pow,
                                   a->grad_scale, a->max_grad_norm, a->lr, a->beta1, a->beta2, a->adam_eps, a->gn, stream);
         if (rc) return rc;
+    } else if (a->layers == 3 && !RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_APPLY")) {
+        // gradient, then reduce + clip + Adam + bf16 re-pack in one launch (bit-identical to the calls below)
+        np = rlhip_mlp3_nparams(ns, a->h, a->na);
+        rc = rlhip_dqn3_update_f32(a->ring, a->h, a->na, a->act, a->params, a->packed, a->target, a->target_packed,
+                                   a->batch, a->gamma, a->huber_delta, a->sampler_seed, a->draw_ctr, a->workspace, a->grad,
+                                   a->loss, a->m, a->v, a->beta_pow, a->grad_scale, a->max_grad_norm, a->lr, a->beta1,
+                                   a->beta2, a->adam_eps, a->gn, stream);
+        if (rc) return rc;
     } else {
         if (a->layers == 2) {
             np = rlhip_mlp2_nparams(ns, a->h, a->na);
@@ -98,10 +109,10 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
         rc = rlhip_clip_adam_f32(a->params, a->grad, a->m, a->v, a->beta_pow, np, a->grad_scale, a->max_grad_norm, a->lr,
                                  a->beta1, a->beta2, a->adam_eps, a->gn, stream);
         if (rc) return rc;
-    }
-    if (a->layers == 3) {
-        rc = rlhip_mlp3_pack_bf16(a->params, ns, a->h, a->na, a->packed, stream);
-        if (rc) return rc;
+        if (a->layers == 3) {
+            rc = rlhip_mlp3_pack_bf16(a->params, ns, a->h, a->na, a->packed, stream);
+            if (rc) return rc;
+        }
     }
     if (a->do_sync) {  // TargetNetwork: dest = rho * dest + (1 - rho) * src
         rc = rlhip_polyak_f32(a->target, a->params, np, a->rho, stream);

@@ -81,7 +81,18 @@ def dqn3_plan(params, packed, ns, h, na, act, obs, eps=0.0, seed=0, env_id_base=
 
 
 def dqn3_workspace(ns, h, na, batch, device="cuda"):
-    return torch.empty(int(_lib.lib.rlhip_dqn3_workspace_bytes(ns, h, na, batch)), dtype=torch.uint8, device=device)
+    # zeroed: the tail holds rlhip_dqn3_update_f32's counters
+    return torch.zeros(int(_lib.lib.rlhip_dqn3_workspace_bytes(ns, h, na, batch)), dtype=torch.uint8, device=device)
+
+
+def dqn3_update(traces, h, na, act, params, packed, target_params, target_packed, batch, gamma, delta, seed, draw_ctr,
+                workspace, grad, loss, m, v, beta_pow, grad_scale, max_grad_norm, lr, beta1, beta2, eps, gn=None):
+    """optimise!(learner, batch) of the 3-layer learner in two launches (params, moments, packed updated in place)."""
+    call("rlhip_dqn3_update_f32", C.byref(traces.rb), h, na, act, ptr(params), ptr(packed), ptr(target_params),
+         ptr(target_packed), batch, gamma, delta, seed, draw_ctr, ptr(workspace), ptr(grad), ptr(loss), ptr(m), ptr(v),
+         ptr(beta_pow), grad_scale, max_grad_norm, lr, beta1, beta2, eps, ptr(gn) if gn is not None else None,
+         stream_ptr())
+    return grad, loss
 
 
 def dqn3_grad(traces, h, na, act, params, packed, target_params, target_packed, batch, gamma, delta, seed, draw_ctr,

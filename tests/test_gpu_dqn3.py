@@ -174,3 +174,40 @@ def test_dqn3_learner_trains_and_prioritized_write_back():
     assert torch.equal(t[1:P], t[2:2 * P:2] + t[3:2 * P:2])
     ref = oracle.per_priority(learner.td.cpu().numpy() * 0 + 0.5, 1e-6, 0.6)
     assert abs(float(ref[0]) - (0.5 + 1e-6) ** 0.6) < 1e-6
+
+
+@pytest.mark.parametrize("kind,batch,clip", [("cartpole", 512, 0.5), ("cartpole", 100, 0.0), ("pendulum", 1000, 1e6),
+                                             ("mountaincar", 4096, 0.05)])
+def test_dqn3_update_is_bit_identical_to_grad_clip_adam_pack(kind, batch, clip):
+    """rlhip_dqn3_update_f32 (gradient, then reduce + clip + Adam + bf16 re-pack in one launch with a grid barrier) ==
+    rlhip_dqn3_grad_f32 + rlhip_clip_adam_f32 + rlhip_mlp3_pack_bf16, bit for bit, over repeated calls"""
+    import rlhip
+    from rlhip import dqn, ops
+
+    ns, na = {"cartpole": (4, 2), "pendulum": (3, 3), "mountaincar": (2, 3)}[kind]
+    n, h = 64, 128
+    tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
+    tr.state.normal_()
+    tr.action.random_(0, na)
+    tr.reward.normal_()
+    tr.terminal.copy_((torch.rand(32, n, device="cuda") < 0.1).to(torch.uint8))
+    tr.rb.len_sa, tr.rb.len_rt = 33, 32
+    tp = dqn.mlp3_init(ns, h, na, 2, 1)
+    tpk = dqn.mlp3_pack(tp, ns, h, na)
+    st = []
+    for _ in range(2):
+        p = dqn.mlp3_init(ns, h, na, 1, 0)
+        st.append(dict(p=p, pk=dqn.mlp3_pack(p, ns, h, na), m=torch.zeros_like(p), v=torch.zeros_like(p),
+                       g=torch.empty_like(p), bp=torch.tensor([0.9, 0.999], device="cuda"),
+                       loss=torch.empty(1, device="cuda"), gn=torch.zeros(1, device="cuda"),
+                       ws=dqn.dqn3_workspace(ns, h, na, batch)))
+    a, b = st
+    for it in range(4):
+        dqn.dqn3_grad(tr, h, na, it % 2, a["p"], a["pk"], tp, tpk, batch, 0.99, 1.0, 7, it, None, a["ws"], a["g"], a["loss"])
+        ops.clip_adam_(a["p"], a["g"], a["m"], a["v"], a["bp"], 0.5, clip, 1e-2, 0.9, 0.999, 1e-8, a["gn"])
+        dqn.mlp3_pack(a["p"], ns, h, na, a["pk"])
+        dqn.dqn3_update(tr, h, na, it % 2, b["p"], b["pk"], tp, tpk, batch, 0.99, 1.0, 7, it, b["ws"], b["g"], b["loss"],
+                        b["m"], b["v"], b["bp"], 0.5, clip, 1e-2, 0.9, 0.999, 1e-8, b["gn"])
+        for k in ("p", "pk", "m", "v", "g", "bp", "loss", "gn"):
+            assert torch.equal(a[k], b[k]), (it, k)
+    assert not torch.equal(a["p"], dqn.mlp3_init(ns, h, na, 1, 0))
