@@ -60,6 +60,24 @@ __global__ __launch_bounds__(256) void push_art_kernel(int32_t* __restrict__ a_d
     }
 }
 
+// push!(trajectory, (state = s', action, reward, terminal)) in ONE launch: the state frame (16-byte chunks) and the three
+// per-env traces
+__global__ __launch_bounds__(256) void push_transition_kernel(uint4* __restrict__ s_dst, const uint4* __restrict__ s_src,
+                                                              int64_t n16, int32_t* __restrict__ a_dst,
+                                                              float* __restrict__ r_dst, uint8_t* __restrict__ t_dst,
+                                                              const int32_t* __restrict__ a, const float* __restrict__ r,
+                                                              const uint8_t* __restrict__ t, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, m = n16 > n ? n16 : n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        if (i < n16) s_dst[i] = s_src[i];
+        if (i < n) {
+            a_dst[i] = a[i];
+            r_dst[i] = r[i];
+            t_dst[i] = t[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_indices_kernel(int64_t* __restrict__ out, int64_t batch,
                                                              uint64_t total, uint64_t seed,
                                                              uint32_t draw_ctr) {
@@ -287,6 +305,20 @@ int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const i
     } else {
         phys = rb->head_rt;
         rb->head_rt = (rb->head_rt + 1) % frames;
+    }
+    // slot of the new state frame (same bookkeeping as push_state_frame)
+    const int64_t sframes = rb->capacity + 1;
+    const int64_t fbytes = rb->obs_dim * rb->n_env * (int64_t)rb->elem_bytes;
+    uint8_t* sdst = (uint8_t*)rb->state + ((rb->len_sa < sframes) ? (rb->head_sa + rb->len_sa) % sframes : rb->head_sa) * fbytes;
+    if ((((uintptr_t)sdst | (uintptr_t)next_obs | (uintptr_t)fbytes) & 15) == 0 && fbytes <= (64ll << 20)) {
+        if (rb->len_sa < sframes) rb->len_sa += 1;
+        else rb->head_sa = (rb->head_sa + 1) % sframes;
+        const int64_t n16 = fbytes / 16;
+        hipLaunchKernelGGL(push_transition_kernel, dim3(grid_for(n16 > n ? n16 : n, 256)), dim3(256), 0, s, (uint4*)sdst,
+                           (const uint4*)next_obs, n16, rb->action + phys * n, rb->reward + phys * n,
+                           rb->terminal + phys * n, action, reward, terminal, n);
+        RLHIP_LAUNCH_CHECK();
+        return RLHIP_OK;
     }
     hipLaunchKernelGGL(push_art_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, rb->action + phys * n,
                        rb->reward + phys * n, rb->terminal + phys * n, action, reward, terminal, n);
