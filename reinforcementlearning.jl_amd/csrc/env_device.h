@@ -64,6 +64,22 @@ struct Trig<double> {
     static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { ::sincos(x, s, c); }
 };
 
+// x / c for a divisor c that is a parameter of the env (known on the host): with rc = RN(1 / c), q0 = RN(x rc),
+// r = x - q0 c (exact: one FMA) and q = RN(q0 + r rc), q is the correctly rounded quotient (Markstein's theorem; it
+// is also the last step of the hardware division sequence) -- 3 instructions instead of the ~10 (Float32) / ~35
+// (Float64) of a general division.  The env-step kernel issues ~1000 VALU instructions per wave against ~130 us of HBM
+// time at 2^24 envs: instruction issue, not bandwidth, was what kept it at 150 us.
+__device__ __forceinline__ float div_const(float x, float c, float rc) {
+    const float q0 = x * rc;
+    const float r = fmaf(-q0, c, x);
+    return fmaf(r, rc, q0);
+}
+__device__ __forceinline__ double div_const(double x, double c, double rc) {
+    const double q0 = x * rc;
+    const double r = fma(-q0, c, x);
+    return fma(r, rc, q0);
+}
+
 template <typename T>
 __device__ __forceinline__ T clampT(T x, T lo, T hi) {
     return (x > hi) ? hi : ((x < lo) ? lo : x);  // Base.clamp
@@ -110,6 +126,8 @@ template <typename T>
 struct CartPoleParams {  // CartPoleEnvParams{T}  RLEnvs/CartPoleEnv.jl:3-15
     T gravity, masscart, masspole, totalmass, halflength, polemasslength, forcemag, dt,
         thetathreshold, xthreshold;
+    T rtotalmass;        // RN(1 / totalmass) in T, for div_const
+    double rtotalmass_d;  // RN(1 / Float64(totalmass))
     int32_t max_steps;
     int32_t continuous;
     static constexpr int SDIM = 4;
@@ -124,6 +142,8 @@ struct CartPoleParams {  // CartPoleEnvParams{T}  RLEnvs/CartPoleEnv.jl:3-15
         p.masscart = (T)c.masscart;
         p.masspole = (T)c.masspole;
         p.totalmass = (T)(c.masscart + c.masspole);
+        p.rtotalmass = (T)1 / p.totalmass;
+        p.rtotalmass_d = 1.0 / (double)p.totalmass;
         p.halflength = (T)c.halflength;
         p.polemasslength = (T)(c.masspole * c.halflength);
         p.forcemag = (T)c.forcemag;
@@ -161,20 +181,28 @@ __device__ __forceinline__ void env_reset1(const CartPoleParams<T>&, LaneState<T
 template <typename T>
 __device__ __forceinline__ void env_step1(const CartPoleParams<T>& p, LaneState<T>& e, int32_t ai, T af,
                                           T& reward, bool& done) {
+#ifdef RLHIP_EXP_NOMATH  // dev experiment only: the kernel's streaming skeleton without the physics
+    e.t += 1;
+    e.s[0] += (T)ai;
+    e.s[1] += af;
+    done = e.t > 1000000;
+    reward = (T)1;
+    return;
+#endif
     T a = p.continuous ? af : ((ai == 1) ? (T)1 : (T)-1);  // :115  a == 2 ? 1 : -1
     e.t += 1;                                              // :119
     T force = a * p.forcemag;                              // :120
     T x = e.s[0], xdot = e.s[1], theta = e.s[2], thetadot = e.s[3];  // :121 (pre-step values)
     T sintheta, costheta;
     Trig<T>::sincos_(theta, &sintheta, &costheta);         // :122-123
-    T tmp = (force + p.polemasslength * (thetadot * thetadot) * sintheta) / p.totalmass;  // :124
+    T tmp = div_const(force + p.polemasslength * (thetadot * thetadot) * sintheta, p.totalmass, p.rtotalmass);  // :124
     // :125-129  the literal 4 / 3 is Float64: denominator, thetaacc and xacc are Float64
     T num = p.gravity * sintheta - costheta * tmp;
-    T frac = p.masspole * (costheta * costheta) / p.totalmass;
+    T frac = div_const(p.masspole * (costheta * costheta), p.totalmass, p.rtotalmass);
     double den = (double)p.halflength * (4.0 / 3.0 - (double)frac);
     double thetaacc = (double)num / den;
-    double xacc = (double)tmp -
-                  (double)p.polemasslength * thetaacc * (double)costheta / (double)p.totalmass;  // :130
+    double xacc = (double)tmp - div_const((double)p.polemasslength * thetaacc * (double)costheta, (double)p.totalmass,
+                                          p.rtotalmass_d);  // :130
     e.s[0] = x + p.dt * xdot;                                 // :131
     e.s[1] = (T)((double)xdot + (double)p.dt * xacc);         // :132
     e.s[2] = theta + p.dt * thetadot;                         // :133

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
     VecN<T, EPL> rew;
     VecN<uint8_t, EPL> dn;
     VecN<T, EPL> lo[P::ODIM], oo[P::ODIM];
+    uint32_t pend = 0;  // envs of this lane that terminated and restart right away
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         LaneState<T> e;
@@ -110,22 +111,55 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
 #pragma unroll
             for (int k = 0; k < P::ODIM; ++k) lo[k].v[j] = o[k];
         }
-        if (d && auto_reset) {
-            // MultiThreadEnv protocol: a terminated env starts a fresh episode right away; the
-            // reward / terminal of the finished step stay visible in the reward / done arrays.
-            e.episode = st.episode[base + j];
-            env_reset1(p, e, seed, env_id_base + (uint32_t)(base + j));
-            st.episode[base + j] = e.episode;
+        if (d && auto_reset) pend |= 1u << j;
+#pragma unroll
+        for (int k = 0; k < P::SDIM; ++k) s[k].v[j] = e.s[k];
+        tv.v[j] = e.t;
+    }
+    // MultiThreadEnv protocol: a terminated env starts a fresh episode right away; the reward / terminal of the
+    // finished step stay visible in the reward / done arrays.  The reset (a Philox block per env) is the most
+    // expensive part of the kernel and a branch per j would be taken by almost every wave (any of its 64 lanes);
+    // instead every lane works off its own pending envs, one per trip: the trip count is the largest number of
+    // terminated envs in one lane (1-2) rather than EPL.
+    if constexpr (EPL == 1) {
+        if (pend) {
+            LaneState<T> e;
+            e.episode = st.episode[base];
+            env_reset1(p, e, seed, env_id_base + (uint32_t)base);
+            st.episode[base] = e.episode;
+#pragma unroll
+            for (int k = 0; k < P::SDIM; ++k) s[k].v[0] = e.s[k];
+            tv.v[0] = e.t;
         }
-        if (obs_out) {
+    } else {
+        while (__builtin_amdgcn_ballot_w64(pend != 0) != 0) {
+            if (pend) {
+                const int j = __builtin_ctz(pend);
+                pend &= pend - 1;
+                LaneState<T> e;
+                e.episode = st.episode[base + j];
+                env_reset1(p, e, seed, env_id_base + (uint32_t)(base + j));
+                st.episode[base + j] = e.episode;
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) {
+#pragma unroll
+                    for (int k = 0; k < P::SDIM; ++k) s[k].v[jj] = (jj == j) ? e.s[k] : s[k].v[jj];
+                    tv.v[jj] = (jj == j) ? e.t : tv.v[jj];
+                }
+            }
+        }
+    }
+    if (obs_out) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            LaneState<T> e;
+#pragma unroll
+            for (int k = 0; k < P::SDIM; ++k) e.s[k] = s[k].v[j];
             T o[6];
             env_obs1(p, e, o);
 #pragma unroll
             for (int k = 0; k < P::ODIM; ++k) oo[k].v[j] = o[k];
         }
-#pragma unroll
-        for (int k = 0; k < P::SDIM; ++k) s[k].v[j] = e.s[k];
-        tv.v[j] = e.t;
     }
 #pragma unroll
     for (int k = 0; k < P::SDIM; ++k) stv<T, EPL, NT>(st.s[k], base, s[k]);
