@@ -27,19 +27,35 @@ namespace rlhip {
 // instructions of the general ocml sincos.  CartPole's theta lives in +-0.42 rad (2 x the 12 degree
 // threshold), so the env-step kernel always takes this path; it was VALU-bound on the general routine
 // (profiles/r01_final_bench_stats.md: 156-223 us per 2^24-env launch against a 130 us HBM floor).
+// The coefficients come from constant memory through scalar loads: as SGPR pairs they are operands of v_fma_f64,
+// whereas 64-bit literals cost two v_mov_b32 per FMA (measured: 24 of the ~160 VALU instructions of a CartPole step).
+__constant__ double SINCOS_SMALL_COEF[12] = {
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,  -1.98412698298579493134e-04,
+    8.33333333332248946124e-03, -1.66666666666666324348e-01, -1.13596475577881948265e-11, 2.08757232129817482790e-09,
+    -2.75573143513906633035e-07, 2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02};
+
+// a * b + c with the addend in an SGPR pair (VOP3 form).  The compiler selects v_fmac_f64 for a Horner step and copies
+// the coefficient into the accumulator first (two v_mov_b32 per step); the three-operand form needs neither.
+__device__ __forceinline__ double fma_sgpr_addend(double a, double b, double c_uniform) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+
 __device__ __forceinline__ void sincos_small_f64(double x, double* s, double* c) {
+    const double* __restrict__ k = SINCOS_SMALL_COEF;
     const double z = x * x;
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double ps = fma(z, k[0], k[1]);
+    ps = fma_sgpr_addend(z, ps, k[2]);
+    ps = fma_sgpr_addend(z, ps, k[3]);
+    ps = fma_sgpr_addend(z, ps, k[4]);
+    ps = fma_sgpr_addend(z, ps, k[5]);
     *s = fma(x * z, ps, x);
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double pc = fma(z, k[6], k[7]);
+    pc = fma_sgpr_addend(z, pc, k[8]);
+    pc = fma_sgpr_addend(z, pc, k[9]);
+    pc = fma_sgpr_addend(z, pc, k[10]);
+    pc = fma_sgpr_addend(z, pc, k[11]);
     *c = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 
