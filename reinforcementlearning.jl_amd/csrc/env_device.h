@@ -197,14 +197,6 @@ __device__ __forceinline__ void env_reset1(const CartPoleParams<T>&, LaneState<T
 template <typename T>
 __device__ __forceinline__ void env_step1(const CartPoleParams<T>& p, LaneState<T>& e, int32_t ai, T af,
                                           T& reward, bool& done) {
-#ifdef RLHIP_EXP_NOMATH  // dev experiment only: the kernel's streaming skeleton without the physics
-    e.t += 1;
-    e.s[0] += (T)ai;
-    e.s[1] += af;
-    done = e.t > 1000000;
-    reward = (T)1;
-    return;
-#endif
     T a = p.continuous ? af : ((ai == 1) ? (T)1 : (T)-1);  // :115  a == 2 ? 1 : -1
     e.t += 1;                                              // :119
     T force = a * p.forcemag;                              // :120

@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
     VecN<uint8_t, EPL> dn;
     VecN<T, EPL> lo[P::ODIM], oo[P::ODIM];
     uint32_t pend = 0;  // envs of this lane that terminated and restart right away
+    uint32_t epv[EPL];  // their episode counters: requested as soon as `done` is known, so that the scattered load
+                        // is in flight under the physics of the following envs instead of stalling the reset
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) epv[j] = 0;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         LaneState<T> e;
@@ -111,7 +115,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
 #pragma unroll
             for (int k = 0; k < P::ODIM; ++k) lo[k].v[j] = o[k];
         }
-        if (d && auto_reset) pend |= 1u << j;
+        if (d && auto_reset) {
+            pend |= 1u << j;
+            if constexpr (EPL > 1) epv[j] = st.episode[base + j];
+        }
 #pragma unroll
         for (int k = 0; k < P::SDIM; ++k) s[k].v[j] = e.s[k];
         tv.v[j] = e.t;
@@ -137,7 +144,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
                 const int j = __builtin_ctz(pend);
                 pend &= pend - 1;
                 LaneState<T> e;
-                e.episode = st.episode[base + j];
+                uint32_t ep = epv[0];
+#pragma unroll
+                for (int jj = 1; jj < EPL; ++jj) ep = (jj == j) ? epv[jj] : ep;
+                e.episode = ep;
                 env_reset1(p, e, seed, env_id_base + (uint32_t)(base + j));
                 st.episode[base + j] = e.episode;
 #pragma unroll
