@@ -74,6 +74,18 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     torch.cuda.synchronize()
     ms = event_time_ms(step, iters, rlhip._lib.lib, stream_ptr())
     achieved = CARTPOLE_STEP_BYTES * n_envs / (ms * 1e-3) / 1e9
+    done_frac = float(env._done.float().mean())
+    del env
+    # the same launch when no episode terminates (thresholds out of reach): the auto-reset of the random policy's
+    # ~4.5 % terminations per step (scattered episode-counter RMW + a Philox block each) is what separates the two
+    env = rlhip.HipVecEnv("cartpole", n_envs, seed=1, xthreshold=1e9, thetathreshold=1e9, max_steps=1 << 30)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ms_nr = event_time_ms(step, 8, rlhip._lib.lib, stream_ptr())
+    no_reset = {"us_per_launch": round(ms_nr * 1e3, 2),
+                "achieved": round(CARTPOLE_STEP_BYTES * n_envs / (ms_nr * 1e-3) / 1e9, 1),
+                "frac": round(CARTPOLE_STEP_BYTES * n_envs / (ms_nr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del env, actions
     torch.cuda.empty_cache()
     return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal>", "n_envs": n_envs,
@@ -85,7 +97,9 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
             "traffic": 870.8e6 if n_envs == (1 << 24) else None,
             "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs,
             "traffic_source": "profiles/r01_pmc_env_step.md",
-            "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1)}
+            "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1),
+            "actions": "uniformly random (the pessimistic case for this kernel)",
+            "terminated_per_step": round(done_frac, 4), "without_terminations": no_reset}
 
 
 def roofline_extras(torch, rlhip):
