@@ -232,7 +232,7 @@ def roofline_extras(torch, rlhip):
     ms = event_time_ms(mt, 20, lib, s)
     tf = 2.0 * Bm * Km * Nm / (ms * 1e-3) / 1e12
     hbm = 2.0 * Bm * (Km + Nm) / (ms * 1e-3) / 1e9
-    out["dense_bf16_mfma"] = {"bound": "mfma", "kernel": "dense_persist_kernel<16,relu> (v_mfma_f32_32x32x16_bf16; weights in registers, X tiles double-buffered in LDS)",
+    out["dense_bf16_mfma"] = {"bound": "mfma", "kernel": "dense_persist_kernel<16,relu,RT=2> (v_mfma_f32_32x32x16_bf16; weights in registers, 64-row X tiles double-buffered in LDS, 2 workgroups per CU)",
                               "batch": Bm, "k": Km, "n": Nm, "us_per_launch": round(ms * 1e3, 1),
                               "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                               "hbm_gbs": round(hbm, 1),
