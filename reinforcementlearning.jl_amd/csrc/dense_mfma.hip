@@ -177,12 +177,13 @@ __global__ __launch_bounds__(256, 2) void dense_tiled_kernel(const uint16_t* __r
 // ~0.9 us at 128 B/clk -- below the tile's HBM time (128 KB at 1/256 of ~5 TB/s = 6.5 us).
 // RT = 2 (64-row tiles, 66 KB of LDS, <= 256 VGPRs) puts two workgroups on a CU: while one waits for its tile or drains
 // its result the other multiplies -- 35.8 -> 25.2 us at batch 131072 (683 TFLOP/s, 5.3 TB/s).
-template <int KS, int ACT, int RT>  // RT row tiles of 32 rows per workgroup tile: 4 (1 workgroup / CU) or 2 (2 / CU)
+// RT row tiles of 32 rows per workgroup tile: 4 (1 workgroup / CU) or 2 (2 / CU); NC column tiles of 32 per wave: N = 128 NC
+template <int KS, int ACT, int RT, int NC>
 __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(const uint16_t* __restrict__ X,
                                                                const uint16_t* __restrict__ Wfrag,
                                                                const float* __restrict__ bias, int64_t ntiles,
                                                                uint16_t* __restrict__ Y) {
-    constexpr int K = 16 * KS, N = 256, PITCH = K + 8, OPITCH = N + 8;
+    constexpr int K = 16 * KS, N = 128 * NC, PITCH = K + 8, OPITCH = N + 8;
     constexpr int ROWS = 32 * RT;
     constexpr int BUF = ROWS * (PITCH > OPITCH ? PITCH : OPITCH);
     constexpr int K8 = K / 8;
@@ -193,15 +194,15 @@ __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(c
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
     // this wave's 64 columns of W: fragments (ks, tg = 2 w + c), one 16-byte load each, kept for the whole launch
-    bf16x8 bw[KS][2];
+    bf16x8 bw[KS][NC];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            bw[ks][c] = *reinterpret_cast<const bf16x8*>(Wfrag + ((int64_t)(ks * (N / 32) + 2 * w + c) * 64 + lane) * 8);
-    float bv[2];
+        for (int c = 0; c < NC; ++c)
+            bw[ks][c] = *reinterpret_cast<const bf16x8*>(Wfrag + ((int64_t)(ks * (N / 32) + NC * w + c) * 64 + lane) * 8);
+    float bv[NC];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bv[c] = bias ? bias[64 * w + 32 * c + r] : 0.0f;
+    for (int c = 0; c < NC; ++c) bv[c] = bias ? bias[32 * NC * w + 32 * c + r] : 0.0f;
     constexpr int NPRE = KS * RT / 4;  // ROWS x K bf16 = ROWS K8 16-byte chunks = NPRE per thread
     nt_u32x4 pre[NPRE];
     int64_t tile = blockIdx.x;
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(c
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) pre[i] = nt_load16(src + tid + 256 * i);
         }
-        f32x16 acc[RT][2];
+        f32x16 acc[RT][NC];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[rt][c][q] = 0.0f;
         const uint16_t* ap = cur + r * PITCH + 8 * kb;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(c
             for (int rt = 0; rt < RT; ++rt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PITCH + 16 * ks);
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NC; ++c)
                     acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks][c], acc[rt][c], 0, 0, 0);
             }
         }
@@ -249,20 +250,20 @@ __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(c
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     float y = acc[rt][c][q] + bv[c];
                     if (ACT == 0) y = fmaxf(y, 0.0f);
                     else if (ACT == 1) y = tanhf(y);
-                    cur[(32 * rt + mfma_row(q, kb)) * OPITCH + 64 * w + 32 * c + r] = f32_to_bf16_rne(y);
+                    cur[(32 * rt + mfma_row(q, kb)) * OPITCH + 32 * NC * w + 32 * c + r] = f32_to_bf16_rne(y);
                 }
         __syncthreads();
         {
             nt_u32x4* dst = reinterpret_cast<nt_u32x4*>(Y + tile * ROWS * N);
 #pragma unroll
-            for (int i = 0; i < 4 * RT; ++i) {  // ROWS x 256 bf16 = 32 ROWS chunks
-                const int c = tid + 256 * i, row = c >> 5, cc = c & 31;
+            for (int i = 0; i < 2 * RT * NC; ++i) {  // ROWS x N bf16 = ROWS N / 8 chunks
+                const int c = tid + 256 * i, row = c / (N / 8), cc = c - row * (N / 8);
                 nt_store16(dst + c, *reinterpret_cast<const nt_u32x4*>(cur + row * OPITCH + 8 * cc));
             }
         }
@@ -370,7 +371,7 @@ int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w
     RLHIP_REQUIRE((((uintptr_t)x_rows | (uintptr_t)w_frag | (uintptr_t)y_rows) & 15) == 0,
                   "operands must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    if (n == 256 && y_is_bf16 && (k == 256 || k == 128) && !RLHIP_ENV_FLAG("RLHIP_DENSE_NO_PERSIST")) {
+    if ((n == 256 || n == 128) && y_is_bf16 && (k == 256 || k == 128) && !RLHIP_ENV_FLAG("RLHIP_DENSE_NO_PERSIST")) {
         // the 256-wide hidden layer: weights in registers, one workgroup per CU walking the row tiles
         // 64-row tiles, two workgroups per CU (they interleave their load / MFMA / store phases) unless asked otherwise
         const bool rows64 = !RLHIP_ENV_FLAG("RLHIP_DENSE_ROWS128") && batch % 64 == 0;
@@ -378,22 +379,27 @@ int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w
         const int64_t ntiles = batch / rows;
         const int64_t cap = rows64 ? 512 : 256;
         const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-        const size_t lds = (size_t)2 * rows * (size_t)((k > 256 ? k : 256) + 8) * sizeof(uint16_t);
-#define LAUNCH_P(KS_, A_, RT_)                                                                                       \
+        const size_t lds = (size_t)2 * rows * (size_t)((k > n ? k : n) + 8) * sizeof(uint16_t);
+#define LAUNCH_P(KS_, A_, RT_, NC_)                                                                                     \
     do {                                                                                                             \
         static bool set_ = false;                                                                                    \
         if (!set_) {                                                                                                 \
-            RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_persist_kernel<KS_, A_, RT_>),   \
+            RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_persist_kernel<KS_, A_, RT_, NC_>),   \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
             set_ = true;                                                                                             \
         }                                                                                                            \
-        hipLaunchKernelGGL((dense_persist_kernel<KS_, A_, RT_>), dim3(grid), dim3(256), lds, s, x_rows, w_frag, bias, \
+        hipLaunchKernelGGL((dense_persist_kernel<KS_, A_, RT_, NC_>), dim3(grid), dim3(256), lds, s, x_rows, w_frag, bias, \
                            ntiles, (uint16_t*)y_rows);                                                               \
     } while (0)
-#define LAUNCH_PR(KS_, A_)                   \
-    do {                                     \
-        if (rows64) LAUNCH_P(KS_, A_, 2);    \
-        else LAUNCH_P(KS_, A_, 4);           \
+#define LAUNCH_PR(KS_, A_)                                \
+    do {                                                  \
+        if (n == 256) {                                   \
+            if (rows64) LAUNCH_P(KS_, A_, 2, 2);          \
+            else LAUNCH_P(KS_, A_, 4, 2);                 \
+        } else {                                          \
+            if (rows64) LAUNCH_P(KS_, A_, 2, 1);          \
+            else LAUNCH_P(KS_, A_, 4, 1);                 \
+        }                                                 \
     } while (0)
 #define LAUNCH_PA(KS_)                        \
     do {                                      \

@@ -102,15 +102,15 @@ def test_dense_tiled_identity_weight():
         assert torch.equal(y.float(), xr.float())
 
 
+@pytest.mark.parametrize("n", [256, 128])
 @pytest.mark.parametrize("batch,k,act", [(128, 256, "relu"), (384, 128, "identity"), (33 * 128, 256, "tanh"),
                                          (1025 * 128, 256, "relu"), (600 * 128, 128, "relu")])
-def test_dense_persistent_kernel_equals_the_tiled_kernel_bitwise(batch, k, act):
-    """N = 256 with bf16 output takes the persistent kernel (weights in registers, double-buffered X tiles, one
+def test_dense_persistent_kernel_equals_the_tiled_kernel_bitwise(batch, k, act, n):
+    """N = 256 / 128 with bf16 output takes the persistent kernel (weights in registers, double-buffered X tiles, one
     workgroup per CU walking tiles b, b + 256, ...): same MFMA chain order as the tiled kernel, so its bf16 result
     equals the tiled kernel's f32 result rounded to bf16, bit for bit -- including uneven tile counts per workgroup"""
     from rlhip import ops
 
-    n = 256
     g = torch.Generator(device="cpu").manual_seed(batch + k)
     xr = (torch.randn((batch, k), generator=g) * 0.5).cuda().to(torch.bfloat16)
     wt = (torch.randn((n, k), generator=g) / np.sqrt(k)).cuda().to(torch.bfloat16)
