@@ -17,8 +17,12 @@ env states.  Weak scaling: 4096 envs per GPU, env ids / Philox streams disjoint 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the HBM-bound env-step kernel at the operating point where HBM matters (2^24 envs),
                 achieved = 49 algorithmic bytes x envs / mean launch time (HIP events on the launch stream)
-  cpu_baseline  the CPU oracle ("port") running the same PPO iteration on a bounded sample, 1 core
+                (uniformly random actions; `without_terminations` = the same launch when no episode ends)
+  cpu_baseline  the CPU oracle ("port") running the same PPO iteration on a bounded sample: OpenMP build on every
+                CPU the container may use (cores stated) and the single-thread figure beside it
   kernels       mean per-launch time of every kernel class of the timed workload (HIP events)
+  roofline_extra  the side kernels / configs of BASELINE.json (see roofline_extras)
+  allreduce     (N > 1 only) latency of the gradient exchange and the library's bus bandwidth sweep
 """
 import argparse
 import ctypes as C
@@ -103,8 +107,9 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
 
 
 def roofline_extras(torch, rlhip):
-    """HBM-bound side kernels at sizes where HBM matters: GAE scan, u8 frame gather (BASELINE config 5 shape,
-    capacity scaled to 2^16 slots = 1.85 GB), and the DQN learner step of BASELINE config 1."""
+    """Side kernels at the sizes BASELINE.json names: GAE scan (2^20 envs x 32), u8 frame gather from the full 2^20-slot
+    29.6 GB ring of config 5 (uniform + prioritized + stack-at-sample), the bf16 Dense layer, the DQN vec-step of config 2
+    (2- and 3-layer networks, per-step protocol and one-call-per-step), Pendulum PPO of config 3 (2-layer fp32, 3-layer MFMA)."""
     from rlhip import ops
     from rlhip.ops import stream_ptr
     from rlhip.trajectory import CircularArraySARTSTraces
