@@ -62,6 +62,13 @@ def event_time_ms(fn, iters, lib, stream):
 
 
 def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
+    """The HBM-bound env-step kernel at 2^24 CartPole envs, uniformly random actions.
+
+    All envs start an episode together, so terminations come in waves for the first few dozen steps (none before
+    step ~8, then a burst, ...).  Two well-defined operating points of the same launch are timed on ONE set of arrays:
+      without_terminations  launches 2..6 after a forced reset: no env can have terminated yet (checked)
+      steady state          after 60 more steps have de-synchronised the episodes: ~4.5 % of the envs terminate and
+                            auto-reset per step (scattered episode-counter RMW + a Philox block each); this is `roofline`"""
     from rlhip._lib import call
     from rlhip.ops import ptr, stream_ptr
 
@@ -73,37 +80,36 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
         call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, ptr(actions), 1,
              env.seed, 0, None, None, stream_ptr())
 
-    for _ in range(3):
+    def per_unit(ms):
+        gbs = CARTPOLE_STEP_BYTES * n_envs / (ms * 1e-3) / 1e9
+        return {"us_per_launch": round(ms * 1e3, 2), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+    for _ in range(3):  # clocks / TLB
+        step()
+    env.reset_()
+    step()
+    torch.cuda.synchronize()
+    no_term = per_unit(event_time_ms(step, 5, rlhip._lib.lib, stream_ptr()))
+    no_term["episodes_finished_during_these_launches"] = int((env._episode != 2).sum())  # constructor + this reset
+    for _ in range(60):
         step()
     torch.cuda.synchronize()
     ms = event_time_ms(step, iters, rlhip._lib.lib, stream_ptr())
-    achieved = CARTPOLE_STEP_BYTES * n_envs / (ms * 1e-3) / 1e9
     done_frac = float(env._done.float().mean())
-    del env
-    # the same launch when no episode terminates (thresholds out of reach): the auto-reset of the random policy's
-    # ~4.5 % terminations per step (scattered episode-counter RMW + a Philox block each) is what separates the two
-    env = rlhip.HipVecEnv("cartpole", n_envs, seed=1, xthreshold=1e9, thetathreshold=1e9, max_steps=1 << 30)
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    ms_nr = event_time_ms(step, 8, rlhip._lib.lib, stream_ptr())
-    no_reset = {"us_per_launch": round(ms_nr * 1e3, 2),
-                "achieved": round(CARTPOLE_STEP_BYTES * n_envs / (ms_nr * 1e-3) / 1e9, 1),
-                "frac": round(CARTPOLE_STEP_BYTES * n_envs / (ms_nr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    main = per_unit(ms)
     del env, actions
     torch.cuda.empty_cache()
     return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal>", "n_envs": n_envs,
-            "bytes_per_unit": CARTPOLE_STEP_BYTES, "us_per_launch": round(ms * 1e3, 2),
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "bytes_per_unit": CARTPOLE_STEP_BYTES, "us_per_launch": main["us_per_launch"],
+            "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
             # HBM bytes per launch from the PMC counters (separate rocprofv3 passes: FETCH_SIZE x2 gfx950
             # correction + WRITE_SIZE), measured for exactly this kernel / size: profiles/r01_pmc_env_step.md
             "traffic": 870.8e6 if n_envs == (1 << 24) else None,
             "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs,
             "traffic_source": "profiles/r01_pmc_env_step.md",
             "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1),
-            "actions": "uniformly random (the pessimistic case for this kernel)",
-            "terminated_per_step": round(done_frac, 4), "without_terminations": no_reset}
+            "actions": "uniformly random, episodes de-synchronised by 60 steps before the timed launches",
+            "terminated_per_step": round(done_frac, 4), "without_terminations": no_term}
 
 
 def roofline_extras(torch, rlhip):

@@ -26,14 +26,21 @@ big = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in trace
        if "env_step_kernel" in r["Kernel_Name"] and "CartPole" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= (1 << 22)]
 rf = bench.get("roofline", {})
 if big:
-    avg = sum(big) / len(big) / 1e3
-    tail = big[3:] if len(big) > 3 else big
+    # the roofline leg: 3 warm-up launches, forced reset, 1 + 5 launches before any env can terminate (the 5 are timed),
+    # 60 launches that de-synchronise the episodes, then the 20 timed steady-state launches
+    nt, desync, timed = big[4:9], big[9:69], big[69:89]
+    us = lambda v: f"{sum(v)/len(v)/1e3:.1f}"
     out.append("")
     out.append(f"**Agreement check (roofline kernel).** The stats row of `env_step_kernel<CartPole, float, 4>` mixes launch "
-               f"sizes (the roofline leg runs 2^24 envs, the DQN legs 4096).  From `bench_kernel_trace.csv`, the {len(big)} "
-               f"launches with 2^24 envs (grid 16384 x 256) take **{avg:.1f} us** on average (min {min(big)/1e3:.1f}, max "
-               f"{max(big)/1e3:.1f}; the {len(tail)} timed ones after the 3 warm-up launches: "
-               f"{sum(tail)/len(tail)/1e3:.1f} us) against **{rf.get('us_per_launch')} us** measured with HIP events inside "
-               f"`bench.py` in the same run -> roofline.achieved = {rf.get('achieved')} GB/s, frac = {rf.get('frac')}.")
+               f"sizes (the roofline leg runs 2^24 envs, the DQN legs 4096).  From `bench_kernel_trace.csv` ({len(big)} "
+               f"launches with 2^24 envs, grid 16384 x 256): the 20 timed steady-state launches take **{us(timed)} us** on "
+               f"average (min {min(timed)/1e3:.1f}, max {max(timed)/1e3:.1f}) against **{rf.get('us_per_launch')} us** "
+               f"measured with HIP events inside `bench.py` in the same run -> roofline.achieved = {rf.get('achieved')} "
+               f"GB/s, frac = {rf.get('frac')}; the 5 launches before any env can terminate: **{us(nt)} us** against "
+               f"{rf.get('without_terminations', {}).get('us_per_launch')} us (`roofline.without_terminations`).")
+    out.append("")
+    out.append("Per-launch durations (us) of the 60 de-synchronising launches in between -- the termination waves of the "
+               "synchronised start are visible (no env can terminate before step ~8, then bursts that flatten out): "
+               + ", ".join(f"{x/1e3:.0f}" for x in desync))
 open("profiles/r01_final_bench_stats.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out[-3:])[:1500])
