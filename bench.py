@@ -68,16 +68,21 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     step ~8, then a burst, ...).  Two well-defined operating points of the same launch are timed on ONE set of arrays:
       without_terminations  launches 2..6 after a forced reset: no env can have terminated yet (checked)
       steady state          after 60 more steps have de-synchronised the episodes: ~4.5 % of the envs terminate and
-                            auto-reset per step (scattered episode-counter RMW + a Philox block each); this is `roofline`"""
+                            auto-reset per step (`terminated_per_step` is measured) (scattered episode-counter RMW + a Philox block each); this is `roofline`"""
     from rlhip._lib import call
     from rlhip.ops import ptr, stream_ptr
 
     env = rlhip.HipVecEnv("cartpole", n_envs, seed=1)
-    actions = torch.randint(0, 2, (n_envs,), dtype=torch.int32, device="cuda")
+    # a different random action for every env at every step (16 pre-drawn vectors, cycled): with ONE fixed vector each
+    # env would push the same way for ever, episodes would last ~9 steps and stay synchronised in waves
+    actions = torch.randint(0, 2, (16, n_envs), dtype=torch.int32, device="cuda")
+    a_ptrs = [ptr(actions[k]) for k in range(16)]
+    counter = [0]
 
     def step():
         # pure act!: no observation copies (state(env) IS the state arrays for CartPole)
-        call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, ptr(actions), 1,
+        counter[0] += 1
+        call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, a_ptrs[counter[0] & 15], 1,
              env.seed, 0, None, None, stream_ptr())
 
     def per_unit(ms):
@@ -108,7 +113,7 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
             "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs,
             "traffic_source": "profiles/r01_pmc_env_step.md",
             "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1),
-            "actions": "uniformly random, episodes de-synchronised by 60 steps before the timed launches",
+            "actions": "uniformly random per env and step (16 pre-drawn vectors), episodes de-synchronised by 60 steps before the timed launches",
             "terminated_per_step": round(done_frac, 4), "without_terminations": no_term}
 
 
