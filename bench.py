@@ -109,7 +109,7 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
             "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
             # HBM bytes per launch from the PMC counters (separate rocprofv3 passes: FETCH_SIZE x2 gfx950
             # correction + WRITE_SIZE), measured for exactly this kernel / size: profiles/r01_pmc_env_step.md
-            "traffic": 870.8e6 if n_envs == (1 << 24) else None,
+            "traffic": 897.6e6 if n_envs == (1 << 24) else None,
             "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs,
             "traffic_source": "profiles/r01_pmc_env_step.md",
             "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1),
