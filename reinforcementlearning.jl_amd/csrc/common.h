@@ -77,11 +77,12 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 template <int L>
-__device__ __forceinline__ float group_sum_dpp(float v) {  // sum over aligned groups of L = 4, 8 or 16 lanes
+__device__ __forceinline__ float group_sum_dpp(float v) {  // sum over aligned groups of L = 4, 8, 16 or 32 lanes
     v = dpp_add<0xB1>(v);                  // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);                  // quad_perm [2,3,0,1]
     if (L >= 8) v = dpp_add<0x141>(v);     // row_half_mirror
     if (L >= 16) v = dpp_add<0x140>(v);    // row_mirror
+    if (L >= 32) v = v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // lane ^ 16
     return v;
 }
 __device__ __forceinline__ float reduce16_dpp(float v) { return group_sum_dpp<16>(v); }

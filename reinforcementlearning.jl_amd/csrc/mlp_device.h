@@ -83,7 +83,7 @@ __device__ __forceinline__ void net_forward(const NetRegs<NS, HPL>& r, const flo
         for (int o = 0; o < MAXO; ++o) acc[o] = fmaf(r.w2[m][o], hv, acc[o]);
     }
     // the L = 4 / 8 / 16 lanes of a group sit inside one DPP row: row-local adds, no LDS crossbar
-    static_assert(L == 4 || L == 8 || L == 16, "lane groups must fit a DPP row");
+    static_assert(L == 4 || L == 8 || L == 16 || L == 32, "lane groups: a DPP row, or two rows joined by a swizzle");
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) acc[o] = group_sum_dpp<L>(acc[o]);
 #pragma unroll

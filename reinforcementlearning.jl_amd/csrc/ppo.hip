@@ -214,7 +214,7 @@ static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state*
             hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 1>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
                                s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
     } while (0)
-    if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);
+    if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);  // 32 lanes per env (8 units each, 2 waves per SIMD) is slower: +70 us
     else if (wide && pd.h == 128) LAUNCH_WIDE(128, 8);
     else if (wide && pd.h == 64) LAUNCH_WIDE(64, 4);
     else if (pd.act == 0)
