@@ -594,7 +594,7 @@ def main():
                    else "single GPU"},
         "launch_mode": mode,
         "gradient_allreduce": ("none (single GPU)" if world == 1 else
-                               ("p2p one-shot over IPC-mapped peer buffers (p2p.hip), validated against RCCL at start-up"
+                               ("p2p one-shot over IPC-mapped peer buffers (p2p.hip), validated against the torch.distributed all-reduce at start-up"
                                 if getattr(pol, "_p2p", None) is not None else "RCCL all-reduce (torch.distributed)")),
         "final_loss": float(pol.losses[0]),
         "mean_episode_len_last_rollout": round(
