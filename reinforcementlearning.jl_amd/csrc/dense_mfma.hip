@@ -177,12 +177,14 @@ __global__ __launch_bounds__(256, 2) void dense_tiled_kernel(const uint16_t* __r
 // ~0.9 us at 128 B/clk -- below the tile's HBM time (128 KB at 1/256 of ~5 TB/s = 6.5 us).
 // RT = 2 (64-row tiles, 66 KB of LDS, <= 256 VGPRs) puts two workgroups on a CU: while one waits for its tile or drains
 // its result the other multiplies -- 35.8 -> 25.2 us at batch 131072 (683 TFLOP/s, 5.3 TB/s).
-// RT row tiles of 32 rows per workgroup tile: 4 (1 workgroup / CU) or 2 (2 / CU); NC column tiles of 32 per wave: N = 128 NC
+// RT row tiles of 32 rows per workgroup tile: 4 (1 workgroup / CU) or 2 (2 / CU); NC column tiles of 32 per wave: the
+// workgroup covers N = 128 NC output columns starting at 128 NC blockIdx.y of the layer's `ntot` (wider layers are split
+// over blockIdx.y and re-read X once per column block; K = 512 keeps 256 VGPRs of fragments, hence one workgroup per CU)
 template <int KS, int ACT, int RT, int NC>
-__global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(const uint16_t* __restrict__ X,
+__global__ __launch_bounds__(256, ((RT == 4 || KS > 16) ? 1 : 2)) void dense_persist_kernel(const uint16_t* __restrict__ X,
                                                                const uint16_t* __restrict__ Wfrag,
                                                                const float* __restrict__ bias, int64_t ntiles,
-                                                               uint16_t* __restrict__ Y) {
+                                                               int ntot, uint16_t* __restrict__ Y) {
     constexpr int K = 16 * KS, N = 128 * NC, PITCH = K + 8, OPITCH = N + 8;
     constexpr int ROWS = 32 * RT;
     constexpr int BUF = ROWS * (PITCH > OPITCH ? PITCH : OPITCH);
@@ -193,16 +195,17 @@ __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(c
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
+    const int col0 = blockIdx.y * N;
     // this wave's 64 columns of W: fragments (ks, tg = 2 w + c), one 16-byte load each, kept for the whole launch
     bf16x8 bw[KS][NC];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            bw[ks][c] = *reinterpret_cast<const bf16x8*>(Wfrag + ((int64_t)(ks * (N / 32) + NC * w + c) * 64 + lane) * 8);
+            bw[ks][c] = *reinterpret_cast<const bf16x8*>(Wfrag + ((int64_t)(ks * (ntot / 32) + (col0 >> 5) + NC * w + c) * 64 + lane) * 8);
     float bv[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) bv[c] = bias ? bias[32 * NC * w + 32 * c + r] : 0.0f;
+    for (int c = 0; c < NC; ++c) bv[c] = bias ? bias[col0 + 32 * NC * w + 32 * c + r] : 0.0f;
     constexpr int NPRE = KS * RT / 4;  // ROWS x K bf16 = ROWS K8 16-byte chunks = NPRE per thread
     nt_u32x4 pre[NPRE];
     int64_t tile = blockIdx.x;
@@ -260,11 +263,11 @@ __global__ __launch_bounds__(256, (RT == 4 ? 1 : 2)) void dense_persist_kernel(c
                 }
         __syncthreads();
         {
-            nt_u32x4* dst = reinterpret_cast<nt_u32x4*>(Y + tile * ROWS * N);
+            uint16_t* dst = Y + tile * ROWS * (int64_t)ntot + col0;
 #pragma unroll
             for (int i = 0; i < 2 * RT * NC; ++i) {  // ROWS x N bf16 = ROWS N / 8 chunks
                 const int c = tid + 256 * i, row = c / (N / 8), cc = c - row * (N / 8);
-                nt_store16(dst + c, *reinterpret_cast<const nt_u32x4*>(cur + row * OPITCH + 8 * cc));
+                nt_store16(dst + (int64_t)row * ntot + 8 * cc, *reinterpret_cast<const nt_u32x4*>(cur + row * OPITCH + 8 * cc));
             }
         }
         if (has_next) {
@@ -371,15 +374,18 @@ int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w
     RLHIP_REQUIRE((((uintptr_t)x_rows | (uintptr_t)w_frag | (uintptr_t)y_rows) & 15) == 0,
                   "operands must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    if ((n == 256 || n == 128) && y_is_bf16 && (k == 256 || k == 128) && !RLHIP_ENV_FLAG("RLHIP_DENSE_NO_PERSIST")) {
+    if ((n % 256 == 0 || n == 128) && n <= 1024 && y_is_bf16 && (k == 512 || k == 256 || k == 128) &&
+        !RLHIP_ENV_FLAG("RLHIP_DENSE_NO_PERSIST")) {
         // the 256-wide hidden layer: weights in registers, one workgroup per CU walking the row tiles
         // 64-row tiles, two workgroups per CU (they interleave their load / MFMA / store phases) unless asked otherwise
-        const bool rows64 = !RLHIP_ENV_FLAG("RLHIP_DENSE_ROWS128") && batch % 64 == 0;
+        const bool rows64 = k == 512 || (!RLHIP_ENV_FLAG("RLHIP_DENSE_ROWS128") && batch % 64 == 0);
         const int rows = rows64 ? 64 : 128;
         const int64_t ntiles = batch / rows;
-        const int64_t cap = rows64 ? 512 : 256;
-        const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-        const size_t lds = (size_t)2 * rows * (size_t)((k > n ? k : n) + 8) * sizeof(uint16_t);
+        const int nw = n == 128 ? 128 : 256;  // columns per workgroup
+        const int ncb = n / nw;               // column blocks (blockIdx.y)
+        const int64_t cap = ((rows64 && k <= 256) ? 512 : 256) / ncb;
+        const dim3 grid((unsigned)(ntiles < cap ? ntiles : (cap < 1 ? 1 : cap)), (unsigned)ncb);
+        const size_t lds = (size_t)2 * rows * (size_t)((k > nw ? k : nw) + 8) * sizeof(uint16_t);
 #define LAUNCH_P(KS_, A_, RT_, NC_)                                                                                     \
     do {                                                                                                             \
         static bool set_ = false;                                                                                    \
@@ -388,12 +394,12 @@ int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
             set_ = true;                                                                                             \
         }                                                                                                            \
-        hipLaunchKernelGGL((dense_persist_kernel<KS_, A_, RT_, NC_>), dim3(grid), dim3(256), lds, s, x_rows, w_frag, bias, \
-                           ntiles, (uint16_t*)y_rows);                                                               \
+        hipLaunchKernelGGL((dense_persist_kernel<KS_, A_, RT_, NC_>), grid, dim3(256), lds, s, x_rows, w_frag, bias,       \
+                           ntiles, n, (uint16_t*)y_rows);                                                               \
     } while (0)
 #define LAUNCH_PR(KS_, A_)                                \
     do {                                                  \
-        if (n == 256) {                                   \
+        if (n != 128) {                                   \
             if (rows64) LAUNCH_P(KS_, A_, 2, 2);          \
             else LAUNCH_P(KS_, A_, 4, 2);                 \
         } else {                                          \
@@ -407,7 +413,17 @@ int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w
         else if (act == 1) LAUNCH_PR(KS_, 1); \
         else LAUNCH_PR(KS_, 2);               \
     } while (0)
-        if (k == 256) LAUNCH_PA(16);
+        if (k == 512) {  // 256 VGPRs of fragments: 64-row tiles only, one workgroup per CU
+            if (n != 128) {
+                if (act == 0) LAUNCH_P(32, 0, 2, 2);
+                else if (act == 1) LAUNCH_P(32, 1, 2, 2);
+                else LAUNCH_P(32, 2, 2, 2);
+            } else {
+                if (act == 0) LAUNCH_P(32, 0, 2, 1);
+                else if (act == 1) LAUNCH_P(32, 1, 2, 1);
+                else LAUNCH_P(32, 2, 2, 1);
+            }
+        } else if (k == 256) LAUNCH_PA(16);
         else LAUNCH_PA(8);
 #undef LAUNCH_PA
 #undef LAUNCH_PR

@@ -121,3 +121,24 @@ def test_dense_persistent_kernel_equals_the_tiled_kernel_bitwise(batch, k, act, 
     assert torch.equal(y16, y32.to(torch.bfloat16))
     y16b = ops.dense_bf16_forward_tiled(xr, wf, n, None, act, torch.bfloat16)      # no bias
     assert torch.equal(y16b, ops.dense_bf16_forward_tiled(xr, wf, n, None, act, torch.float32).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("batch,k,n,act", [(33 * 128, 512, 512, "relu"), (1024, 512, 256, "tanh"), (8192, 256, 512, "relu"),
+                                           (2048, 128, 1024, "identity"), (640, 512, 128, "relu"),
+                                           (300 * 128, 512, 1024, "relu")])
+def test_dense_persistent_kernel_wide_layers_bitwise(batch, k, n, act):
+    """K = 512 (256 VGPRs of register-resident fragments, one workgroup per CU) and N > 256 (column blocks of 256 over
+    blockIdx.y): the bf16 result equals the tiled kernel's f32 result rounded to bf16, bit for bit"""
+    from rlhip import ops
+
+    g = torch.Generator(device="cpu").manual_seed(batch + k + n)
+    xr = (torch.randn((batch, k), generator=g) * 0.5).cuda().to(torch.bfloat16)
+    wt = (torch.randn((n, k), generator=g) / np.sqrt(k)).cuda().to(torch.bfloat16)
+    bias = torch.randn(n, generator=g).cuda()
+    wf = ops.dense_frag_weight_bf16(wt)
+    y16 = ops.dense_bf16_forward_tiled(xr, wf, n, bias, act, torch.bfloat16)
+    y32 = ops.dense_bf16_forward_tiled(xr, wf, n, bias, act, torch.float32)
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    ref = xr.float() @ wt.float().t() + bias
+    ref = {"relu": torch.relu, "tanh": torch.tanh, "identity": lambda t: t}[act](ref)
+    torch.testing.assert_close(y16.float(), ref, rtol=2e-2, atol=2e-2)
