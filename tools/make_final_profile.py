@@ -13,7 +13,9 @@ out.append("Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-for
            "python bench.py` (`tools/prof.sh final`; default flags `--gpus 1 --steps 200 --warmup 20`, all legs: timed PPO "
            "workload, kernel breakdown, env-step roofline at 2^24 envs, roofline extras incl. the DQN / MFMA / replay "
            "configs, CPU baseline).\n")
-out.append("Bench line printed by the same (profiled) run:\n\n```json\n" + json.dumps(bench, indent=1) + "\n```\n")
+out.append("Bench line printed by the same (profiled) run -- the profiler intercepts every launch, so `ms_per_step` / `value` of a "
+           "profiled run can sit above the unprofiled ones (0.61 ms, 2.1e8 env-steps/s for this code: README); the per-kernel "
+           "durations below are what this file is for:\n\n```json\n" + json.dumps(bench, indent=1) + "\n```\n")
 out.append("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|")
 for r in stats:
     name = r["Name"].split("(")[0].replace("void ", "")
