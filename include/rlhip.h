@@ -367,6 +367,12 @@ int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_sta
                           uint64_t explorer_seed, uint32_t explorer_step, uint64_t env_seed, uint32_t env_id_base,
                           rlhip_ring* rb_host, int32_t* actions, float* q_out, float* obs_out, float* last_obs,
                           rlhip_stream_t stream);
+/* act! + push! in one launch for a policy whose plan! ran separately (the MFMA Q-network): actions i32[n] 0-based.
+ * Bit-identical to rlhip_env_step(auto_reset = 1, last_obs, obs_out) followed by rlhip_ring_push_transition; the ring
+ * counters advance as in that call.  Discrete Float32 CartPole / Pendulum / MountainCar. */
+int32_t rlhip_env_act_push_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n,
+                               const int32_t* actions, uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb,
+                               float* obs_out, float* last_obs, rlhip_stream_t stream);
 
 /* ------------------------------------- one-shot peer-to-peer all-reduce (multi-GPU learner) -- */
 /* The exchange step of the sharded learner: SUM of the small flat gradient over the ranks, inside ONE

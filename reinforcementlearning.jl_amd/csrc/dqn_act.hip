@@ -112,6 +112,91 @@ static int32_t act_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st,
     return RLHIP_OK;
 }
 
+// act! + push! in one launch for policies whose plan! is a separate kernel (the MFMA Q-network): one lane per env
+// instance, the same device functions and the same ring slots as env_step_kernel + push_transition_kernel.
+template <class P>
+__global__ __launch_bounds__(256) void env_act_push_kernel(P p, EnvArrays<float> st, int64_t n,
+                                                           const int32_t* __restrict__ actions, uint64_t env_seed,
+                                                           uint32_t env_id_base, ActRing rb, float* __restrict__ obs_out,
+                                                           float* __restrict__ last_obs) {
+    constexpr int NS = P::ODIM;
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n) return;
+    const uint32_t id = env_id_base + (uint32_t)env;
+    LaneState<float> e;
+#pragma unroll
+    for (int k = 0; k < P::SDIM; ++k) e.s[k] = st.s[k][env];
+    e.t = st.t[env];
+    e.episode = 0;
+    const int32_t a = actions[env];
+    float r;
+    bool d;
+    env_step1(p, e, a, 0.0f, r, d);
+    float lo[4] = {0.f, 0.f, 0.f, 0.f};
+    if (last_obs) env_obs1(p, e, lo);
+    if (d) {
+        e.episode = st.episode[env];
+        env_reset1(p, e, env_seed, id);
+        st.episode[env] = e.episode;
+    }
+    float xn[4];
+    env_obs1(p, e, xn);
+#pragma unroll
+    for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
+    st.t[env] = e.t;
+    st.reward[env] = r;
+    st.done[env] = (uint8_t)d;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (obs_out) obs_out[(int64_t)k * n + env] = xn[k];
+        if (last_obs) last_obs[(int64_t)k * n + env] = lo[k];
+        rb.state[(rb.state_slot * NS + k) * n + env] = xn[k];
+    }
+    rb.action[rb.rt_slot * n + env] = a;
+    rb.reward[rb.rt_slot * n + env] = r;
+    rb.terminal[rb.rt_slot * n + env] = (uint8_t)d;
+}
+
+// the slots push!(trajectory, (state = s', action, reward, terminal)) writes (ring.hip); advances the ring counters
+static ActRing claim_slots(rlhip_ring* rb) {
+    ActRing ar;
+    ar.state = (float*)rb->state;
+    ar.action = rb->action;
+    ar.reward = rb->reward;
+    ar.terminal = rb->terminal;
+    const int64_t frames = rb->capacity;
+    if (rb->len_rt < frames) {
+        ar.rt_slot = (rb->head_rt + rb->len_rt) % frames;
+        rb->len_rt += 1;
+    } else {
+        ar.rt_slot = rb->head_rt;
+        rb->head_rt = (rb->head_rt + 1) % frames;
+    }
+    const int64_t sframes = rb->capacity + 1;
+    if (rb->len_sa < sframes) {
+        ar.state_slot = (rb->head_sa + rb->len_sa) % sframes;
+        rb->len_sa += 1;
+    } else {
+        ar.state_slot = rb->head_sa;
+        rb->head_sa = (rb->head_sa + 1) % sframes;
+    }
+    return ar;
+}
+
+template <class P>
+static int32_t act_push_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, const int32_t* actions,
+                             uint64_t env_seed, uint32_t env_id_base, ActRing rb, float* obs_out, float* last_obs,
+                             hipStream_t s) {
+    typename P::cfg_t c2 = *cfg;
+    c2.continuous = 0;
+    P p = P::make(c2);
+    EnvArrays<float> a = EnvArrays<float>::from(*st);
+    hipLaunchKernelGGL((env_act_push_kernel<P>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n, actions, env_seed,
+                       env_id_base, rb, obs_out, last_obs);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
 }  // namespace rlhip
 
 using namespace rlhip;
@@ -131,30 +216,7 @@ extern "C" int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rl
     RLHIP_REQUIRE(rb->elem_bytes == 4 && rb->n_env == n && rb->obs_dim == (kind == 0 ? 4 : (kind == 1 ? 3 : 2)),
                   "ring geometry does not match the env");
     RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
-    // the slots push!(trajectory, (state = s', action, reward, terminal)) writes (ring.hip), counters advanced here
-    ActRing ar;
-    ar.state = (float*)rb->state;
-    ar.action = rb->action;
-    ar.reward = rb->reward;
-    ar.terminal = rb->terminal;
-    {
-        const int64_t frames = rb->capacity;
-        if (rb->len_rt < frames) {
-            ar.rt_slot = (rb->head_rt + rb->len_rt) % frames;
-            rb->len_rt += 1;
-        } else {
-            ar.rt_slot = rb->head_rt;
-            rb->head_rt = (rb->head_rt + 1) % frames;
-        }
-        const int64_t sframes = rb->capacity + 1;
-        if (rb->len_sa < sframes) {
-            ar.state_slot = (rb->head_sa + rb->len_sa) % sframes;
-            rb->len_sa += 1;
-        } else {
-            ar.state_slot = rb->head_sa;
-            rb->head_sa = (rb->head_sa + 1) % sframes;
-        }
-    }
+    ActRing ar = claim_slots(rb);
     hipStream_t s = as_stream(stream);
     if (kind == 0)
         return act_impl<CartPoleParams<float>>((const rlhip_cartpole_cfg*)env_cfg, st, n, params, (int)h, (int)na, act, eps,
@@ -167,4 +229,27 @@ extern "C" int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rl
     return act_impl<MountainCarParams<float>>((const rlhip_mountaincar_cfg*)env_cfg, st, n, params, (int)h, (int)na, act,
                                               eps, explorer_seed, explorer_step, env_seed, env_id_base, ar, actions, q_out,
                                               obs_out, last_obs, s);
+}
+
+/* act!(env, actions) + push!(trajectory, (state = s', action, reward, terminal)) in one launch (discrete Float32 envs;
+ * actions: i32[n] 0-based, already planned).  Same outputs as rlhip_env_step (auto-reset) followed by
+ * rlhip_ring_push_transition. */
+extern "C" int32_t rlhip_env_act_push_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n,
+                                          const int32_t* actions, uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb,
+                                          float* obs_out, float* last_obs, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(env_cfg && st && rb && actions, "NULL argument");
+    RLHIP_REQUIRE(kind >= 0 && kind <= 2 && n >= 1, "kind must be 0 (cartpole), 1 (pendulum) or 2 (mountaincar)");
+    RLHIP_REQUIRE(rb->elem_bytes == 4 && rb->n_env == n && rb->obs_dim == (kind == 0 ? 4 : (kind == 1 ? 3 : 2)),
+                  "ring geometry does not match the env");
+    RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
+    ActRing ar = claim_slots(rb);
+    hipStream_t s = as_stream(stream);
+    if (kind == 0)
+        return act_push_impl<CartPoleParams<float>>((const rlhip_cartpole_cfg*)env_cfg, st, n, actions, env_seed, env_id_base,
+                                                    ar, obs_out, last_obs, s);
+    if (kind == 1)
+        return act_push_impl<PendulumParams<float>>((const rlhip_pendulum_cfg*)env_cfg, st, n, actions, env_seed, env_id_base,
+                                                    ar, obs_out, last_obs, s);
+    return act_push_impl<MountainCarParams<float>>((const rlhip_mountaincar_cfg*)env_cfg, st, n, actions, env_seed,
+                                                   env_id_base, ar, obs_out, last_obs, s);
 }

@@ -32,6 +32,8 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring*, int64_t, int64_t, int32_t, const 
 int32_t rlhip_dqn3_update_f32(const rlhip_ring*, int64_t, int64_t, int32_t, float*, uint16_t*, const float*, const uint16_t*,
                               int64_t, float, float, uint64_t, uint32_t, void*, float*, float*, float*, float*, float*,
                               float, float, float, float, float, float, float*, rlhip_stream_t);
+int32_t rlhip_env_act_push_f32(int32_t, const void*, const rlhip_env_state*, int64_t, const int32_t*, uint64_t, uint32_t,
+                               rlhip_ring*, float*, float*, rlhip_stream_t);
 int32_t rlhip_mlp3_pack_bf16(const float*, int64_t, int64_t, int64_t, uint16_t*, rlhip_stream_t);
 int64_t rlhip_mlp2_nparams(int64_t, int64_t, int64_t);
 int64_t rlhip_mlp3_nparams(int64_t, int64_t, int64_t);
@@ -68,13 +70,19 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
             rc = rlhip_dqn3_plan_f32(a->params, a->packed, ns, a->h, a->na, a->act, a->obs, a->n, a->eps, a->explorer_seed,
                                      a->env_id_base, a->explorer_step, a->actions, a->q, stream);
         if (rc) return rc;
-        // act!(env, action) with auto-reset; the post-step observation lands in a->obs
-        rc = rlhip_env_step(a->kind, 0, a->env_cfg, a->st, a->n, a->actions, 1, a->env_seed, a->env_id_base, a->last_obs,
-                            a->obs, stream);
-        if (rc) return rc;
-        // push!(trajectory, (state = s', action, reward, terminal))
-        rc = rlhip_ring_push_transition(a->ring, a->obs, a->actions, (const float*)a->st->reward, a->st->done, stream);
-        if (rc) return rc;
+        // act!(env, action) with auto-reset + push!(trajectory, (state = s', action, reward, terminal)): one launch
+        // (dqn_act.hip; same device functions and slots as rlhip_env_step + rlhip_ring_push_transition)
+        if (!RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_ACT")) {
+            rc = rlhip_env_act_push_f32(a->kind, a->env_cfg, a->st, a->n, a->actions, a->env_seed, a->env_id_base, a->ring,
+                                        a->obs, a->last_obs, stream);
+            if (rc) return rc;
+        } else {
+            rc = rlhip_env_step(a->kind, 0, a->env_cfg, a->st, a->n, a->actions, 1, a->env_seed, a->env_id_base,
+                                a->last_obs, a->obs, stream);
+            if (rc) return rc;
+            rc = rlhip_ring_push_transition(a->ring, a->obs, a->actions, (const float*)a->st->reward, a->st->done, stream);
+            if (rc) return rc;
+        }
     }
     if (!a->do_update) return RLHIP_OK;
     // optimise!(learner, trajectory): sample + TD target + Huber + gradient, then clip + Adam

@@ -226,6 +226,7 @@ _PROTOS = {
                                  vp]),
     "rlhip_gaussian_head_sample_f32": (i32, [vp, vp, i64, i64, i64, f32, f32, i32, i32, u64, u32, u32, vp, vp, vp]),
     "rlhip_gaussian_head_logp_f32": (i32, [vp, vp, vp, i64, i64, i64, f32, f32, i32, i32, vp, vp]),
+    "rlhip_env_act_push_f32": (i32, [i32, vp, P(EnvState), i64, vp, u64, u32, P(Ring), vp, vp, vp]),
     "rlhip_dqn3_update_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, f32, f32, u64, u32, vp, vp, vp, vp, vp,
                                     vp, f32, f32, f32, f32, f32, f32, vp, vp]),
     "rlhip_dqn_update_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, i64, f32, f32, u64, u32, vp, vp, vp, vp, vp, vp,
