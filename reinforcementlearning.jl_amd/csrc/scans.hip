@@ -103,6 +103,68 @@ __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __rest
     }
 }
 
+// Float32, env-major layout (dims = 2: element (env, t) at env + n t), streaming sizes: FOUR envs per lane, so every
+// access is 16 bytes per lane (1 KB per wave instruction instead of 256 B) and the four recurrences interleave; the
+// arithmetic of each env is the scalar kernel's, operation for operation.
+template <bool WITH_RETURNS, int CH>
+__global__ __launch_bounds__(256) void gae_vec4_kernel(float* __restrict__ adv, float* __restrict__ ret,
+                                                       const float* __restrict__ r, const float* __restrict__ v,
+                                                       const uint8_t* __restrict__ term, int64_t n, int64_t len,
+                                                       float gamma, float lambda) {
+    const int64_t sl = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (sl >= n) return;
+    auto ld4 = [](const float* p) {
+        nt_u32x4 u = nt_load16(p);
+        return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+    };
+    auto st4 = [](float* p, float a, float b, float c, float d) {
+        nt_u32x4 u = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+        nt_store16(p, u);
+    };
+    float gae[4] = {0.f, 0.f, 0.f, 0.f};
+    float vnext[4];
+    {
+        const float4 q = ld4(v + len * n + sl);
+        vnext[0] = q.x, vnext[1] = q.y, vnext[2] = q.z, vnext[3] = q.w;
+    }
+    const float gl = gamma * lambda;
+    for (int64_t hi = len; hi > 0; hi -= CH) {
+        const int cnt = (int)((hi < CH) ? hi : CH);
+        float4 r_[CH], v_[CH];
+        uint32_t t_[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int64_t i = hi - 1 - c;
+            if (c < cnt) {
+                r_[c] = ld4(r + i * n + sl);
+                v_[c] = ld4(v + i * n + sl);
+                t_[c] = term ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(term + i * n + sl)) : 0u;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c < cnt) {
+                const int64_t i = hi - 1 - c;
+                const float rr[4] = {r_[c].x, r_[c].y, r_[c].z, r_[c].w};
+                const float vv[4] = {v_[c].x, v_[c].y, v_[c].z, v_[c].w};
+                float rt[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool is_continue = ((t_[c] >> (8 * e)) & 0xFFu) == 0u;   // :411
+                    const float boot = strong_zero_mul(gamma * vnext[e], is_continue);
+                    const float delta = rr[e] + boot - vv[e];                      // :412
+                    const float glc = strong_zero_mul(gl, is_continue);
+                    gae[e] = delta + glc * gae[e];                                 // :413
+                    rt[e] = gae[e] + vv[e];
+                    vnext[e] = vv[e];
+                }
+                st4(adv + i * n + sl, gae[0], gae[1], gae[2], gae[3]);            // :414
+                if (WITH_RETURNS) st4(ret + i * n + sl, rt[0], rt[1], rt[2], rt[3]);
+            }
+        }
+    }
+}
+
 struct ScanGeom {
     int64_t n_slices, len, elem_stride, slice_stride, v_slice_stride;
 };
@@ -153,6 +215,21 @@ static int32_t gae_impl(T* adv, T* ret, const T* r, const T* v, int64_t n1, int6
     RLHIP_REQUIRE(adv != nullptr && r != nullptr && v != nullptr, "NULL array");
     dim3 grid((int)((g.n_slices + 255) / 256));
     const bool streaming = g.n_slices * g.len >= ((int64_t)1 << 22);
+    if constexpr (sizeof(T) == 4) {
+        const bool env_major = g.slice_stride == 1 && g.v_slice_stride == 1 && g.elem_stride == g.n_slices;
+        const uintptr_t al = (uintptr_t)adv | (uintptr_t)r | (uintptr_t)v | (uintptr_t)(ret ? ret : adv);
+        if (!RLHIP_ENV_FLAG("RLHIP_GAE_SCALAR") && streaming && env_major && g.n_slices % 4 == 0 && (al & 15) == 0 && (!term || ((uintptr_t)term & 3) == 0)) {
+            dim3 g4((int)((g.n_slices / 4 + 255) / 256));
+            if (ret)
+                hipLaunchKernelGGL((gae_vec4_kernel<true, 8>), g4, dim3(256), 0, s, (float*)adv, (float*)ret,
+                                   (const float*)r, (const float*)v, term, g.n_slices, g.len, (float)gamma, (float)lambda);
+            else
+                hipLaunchKernelGGL((gae_vec4_kernel<false, 8>), g4, dim3(256), 0, s, (float*)adv, (float*)nullptr,
+                                   (const float*)r, (const float*)v, term, g.n_slices, g.len, (float)gamma, (float)lambda);
+            RLHIP_LAUNCH_CHECK();
+            return RLHIP_OK;
+        }
+    }
 #define LAUNCH_GAE(WR_, NT_)                                                                                          \
     hipLaunchKernelGGL((gae_kernel<T, WR_, 128 / sizeof(T), NT_>), grid, dim3(256), 0, s, adv, ret, r, v, term,       \
                        g.n_slices, g.len, g.elem_stride, g.slice_stride, g.v_slice_stride, gamma, lambda)

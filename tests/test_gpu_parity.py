@@ -335,6 +335,24 @@ def test_gae_fused_returns_full_size(rl):
     assert np.array_equal(host(ret), (o.T + v[:T]).astype(np.float32))
 
 
+@pytest.mark.parametrize("n,T,with_term", [(65536, 64, True), (131072, 37, True), (65536, 70, False), (65538, 64, True)])
+def test_gae_streaming_four_envs_per_lane_bit_exact(rl, n, T, with_term):
+    """scans beyond the L2 (n T >= 2^22) in the env-major Float32 layout take gae_vec4_kernel (four envs per lane,
+    16-byte accesses, chunks of 8 steps); n not a multiple of 4 stays on the scalar kernel: both bit-exact vs the oracle,
+    advantages and returns, with the chunk remainder (T mod 8 != 0) and without terminal flags"""
+    from rlhip import ops
+
+    rng = np.random.default_rng(n + T)
+    r = rng.uniform(-16, 0, (T, n)).astype(np.float32)
+    v = rng.standard_normal((T + 1, n)).astype(np.float32)
+    term = (rng.random((T, n)) < 1 / 50) if with_term else None
+    adv, ret = ops.gae_returns(dev(r), dev(v), dev(term) if with_term else None, 0.99, 0.95)
+    o = oracle.generalized_advantage_estimation(r.T, v.T, 0.99, 0.95, terminal=term.T if with_term else None, dims=2,
+                                                dtype=np.float32)
+    assert np.array_equal(host(adv), o.T)
+    assert np.array_equal(host(ret), (o.T + v[:T]).astype(np.float32))
+
+
 # ------------------------------------------------------------------------------------ selection
 def test_selection_golden_on_gpu(rl):
     from rlhip import ops
