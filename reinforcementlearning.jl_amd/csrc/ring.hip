@@ -182,46 +182,58 @@ __global__ __launch_bounds__(256) void gather_stacked_kernel(RingView rb, const 
                                                              uint8_t* __restrict__ sn) {
     __shared__ int64_t l_off[MAX_STACK + 1];
     __shared__ int l_vs[MAX_STACK + 1], l_vn[MAX_STACK + 1];  // validity as state-stack / next-stack member
+    __shared__ int l_bound[MAX_STACK + 1];                    // frame j exists and no episode boundary lies before it
     const int64_t b = blockIdx.x;
-    if (threadIdx.x == 0) {
-        const int64_t li = idx[b];
+    const int64_t li = idx[b];
+    // one lane per frame fetches its terminal flag (one round trip for all of them), lane 0 chains the verdicts
+    if (threadIdx.x <= n_stack) {
+        const int j = threadIdx.x;
+        const int64_t f = li + 1 - j;  // frame j (j = 0 .. n_stack) is logical state frame li + 1 - j
+        int ok = 1;
+        if (j >= 1) {  // going one frame further back crosses transition f: stop at an episode boundary
+            const bool exists = f >= 0;
+            const bool boundary = exists && rb.terminal[(rb.head_rt + f) % rb.capacity] != 0;
+            ok = (exists && !boundary) ? 1 : 0;
+        }
+        l_bound[j] = ok;
+        l_off[j] = (f >= 0) ? ((rb.head_sa + f) % (rb.capacity + 1)) * frame_bytes : 0;
+    }
+    if (threadIdx.x == 64) {  // another wave: the transition's scalars
         const int64_t pt = (rb.head_rt + li) % rb.capacity;
         a[b] = rb.action[pt];
         r[b] = rb.reward[pt];
         term[b] = rb.terminal[pt];
-        // frame j (j = 0 .. n_stack) is logical state frame li + 1 - j
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         bool ok_n = true, ok_s = true;
         for (int j = 0; j <= n_stack; ++j) {
             const int64_t f = li + 1 - j;
-            if (j >= 1) {  // going one frame further back crosses transition f: stop at an episode boundary
-                const bool exists = f >= 0;
-                const bool boundary = exists && rb.terminal[(rb.head_rt + f) % rb.capacity] != 0;
-                ok_n = ok_n && exists && !boundary;
-                if (j >= 2) ok_s = ok_s && exists && !boundary;
+            if (j >= 1) {
+                ok_n = ok_n && l_bound[j];
+                if (j >= 2) ok_s = ok_s && l_bound[j];
             }
-            l_vn[j] = (j < n_stack) && ok_n;              // member k = j of the next-state stack
-            l_vs[j] = (j >= 1) && (j == 1 || ok_s);       // member k = j - 1 of the state stack
-            l_off[j] = (f >= 0) ? ((rb.head_sa + f) % (rb.capacity + 1)) * frame_bytes : 0;
-            if (f < 0) {
-                l_vn[j] = 0;
-                l_vs[j] = 0;
-            }
+            l_vn[j] = (j < n_stack) && ok_n && f >= 0;              // member k = j of the next-state stack
+            l_vs[j] = (j >= 1) && (j == 1 || ok_s) && f >= 0;       // member k = j - 1 of the state stack
         }
     }
     __syncthreads();
     const int64_t n16 = frame_bytes / 16;
-    for (int j = 0; j <= n_stack; ++j) {
-        const bool vn = l_vn[j] != 0, vs = l_vs[j] != 0;
-        const uint4* src = (const uint4*)((const uint8_t*)rb.state + l_off[j]);
-        // stacks are oldest-first (StackFrames: the newest frame is the last slice)
-        uint4* dn = (j < n_stack) ? (uint4*)(sn + (b * n_stack + (n_stack - 1 - j)) * frame_bytes) : nullptr;
-        uint4* ds = (j >= 1) ? (uint4*)(s + (b * n_stack + (n_stack - j)) * frame_bytes) : nullptr;
-        for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
-            nt_u32x4 x = {0u, 0u, 0u, 0u};
-            const nt_u32x4 zero = {0u, 0u, 0u, 0u};
-            if (vn || vs) x = nt_load16(src + i);
-            if (dn) nt_store16(dn + i, vn ? x : zero);
-            if (ds) nt_store16(ds + i, vs ? x : zero);
+    // every lane moves chunk i of ALL frames per trip: n_stack + 1 loads in flight instead of one
+    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
+        nt_u32x4 x[MAX_STACK + 1];
+        const nt_u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j <= MAX_STACK; ++j) {
+            x[j] = zero;
+            if (j <= n_stack && (l_vn[j] | l_vs[j])) x[j] = nt_load16((const uint4*)((const uint8_t*)rb.state + l_off[j]) + i);
+        }
+#pragma unroll
+        for (int j = 0; j <= MAX_STACK; ++j) {
+            if (j > n_stack) continue;
+            // stacks are oldest-first (StackFrames: the newest frame is the last slice)
+            if (j < n_stack) nt_store16((uint4*)(sn + (b * n_stack + (n_stack - 1 - j)) * frame_bytes) + i, l_vn[j] ? x[j] : zero);
+            if (j >= 1) nt_store16((uint4*)(s + (b * n_stack + (n_stack - j)) * frame_bytes) + i, l_vs[j] ? x[j] : zero);
         }
     }
 }
