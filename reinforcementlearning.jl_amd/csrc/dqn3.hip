@@ -72,19 +72,28 @@ __global__ __launch_bounds__(256) void mlp3_plan_kernel(const float* __restrict_
     uint16_t* l_A = reinterpret_cast<uint16_t*>(l_w + SMALLW);          // [TR][LDH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const Mlp3 m = stage_small_weights(params, NS, na, l_w, tid);
+    // every global load of the kernel is issued up front: the hidden layer's B fragments (registers), the
+    // observations, the small tensors -- one overlapped round trip instead of three in a row
+    bf16x8 bw[H3 / 16][4];
+    load_w2_fragments(packed, lane, bw);
     const int64_t e0 = (int64_t)blockIdx.x * TR;
+    float xin[NS];
     if (tid < TR) {
         int64_t e = e0 + tid;
         if (e >= n) e = n - 1;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) l_x[i * TR + tid] = obs[(int64_t)i * n + e];
+        for (int i = 0; i < NS; ++i) xin[i] = obs[(int64_t)i * n + e];
+    }
+    const Mlp3 m = stage_small_weights(params, NS, na, l_w, tid);
+    if (tid < TR) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) l_x[i * TR + tid] = xin[i];
     }
     __syncthreads();
     layer1_to_lds<NS, ACT>(m, l_x, l_A, nullptr, tid);
     __syncthreads();
     f32x16 h2[4];
-    layer2<ACT>(l_A, packed, m.b2, w, lane, h2);
+    layer2_regs<ACT>(l_A, bw, m.b2, w, lane, h2);
     head_to_lds<NA>(m, h2, w, lane, l_q);
     __syncthreads();
     if (tid < TR && e0 + tid < n) {

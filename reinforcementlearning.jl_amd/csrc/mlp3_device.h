@@ -169,6 +169,34 @@ __device__ __forceinline__ void layer2(const uint16_t* l_h1rk, const uint16_t* w
     }
 }
 
+// the same layer with the 32 B fragments already in registers (fetched at kernel entry, so that their L2 round trip
+// overlaps the first layer instead of following the barrier after it): identical MFMA order, identical bits
+__device__ __forceinline__ void load_w2_fragments(const uint16_t* __restrict__ w2jk, int lane, bf16x8 (&bw)[H3 / 16][4]) {
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bw[ks][t] = *reinterpret_cast<const bf16x8*>(w2jk + lane * 8 + (ks * 4 + t) * 512);
+}
+template <int ACT>
+__device__ __forceinline__ void layer2_regs(const uint16_t* l_h1rk, const bf16x8 (&bw)[H3 / 16][4], const float* b2, int w,
+                                            int lane, f32x16 (&h2)[4]) {
+    zero_acc(h2);
+    const int r = lane & 31, kb = lane >> 5;
+    const uint16_t* ap = l_h1rk + 32 * w * LDH + r * LDH + 8 * kb;
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks][t], h2[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float bv = b2[r + 32 * t];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h2[t][q] = act_fwd_t<ACT>(h2[t][q] + bv);
+    }
+}
+
 // head: q[o] = b3[o] + sum_j W3[o, j] h2[j] for the wave's 32 rows -> l_q[o][row]   (f32 [MAXO][TR])
 template <int NA>
 __device__ __forceinline__ void head_to_lds(const Mlp3& m, const f32x16 (&h2)[4], int w, int lane, float* l_q) {
