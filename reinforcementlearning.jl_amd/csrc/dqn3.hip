@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     const int ob3 = H3 * NS + H3 + H3 * H3 + H3 + na * H3;
 
     D3_STAMP(0);
+    // the target network's hidden-layer B fragments: requested now, consumed after the gather and layer 1
+    bf16x8 bw[H3 / 16][4];
+    load_w2_fragments(g.tpacked, lane, bw);
     // ---- sample + gather the tile's transitions straight from the HBM ring ----
     if (tid < TR) {
         int64_t b = (int64_t)tile * TR + tid;
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     layer1_to_lds<NS, ACT>(mt, l_xn, l_A, nullptr, tid);
     __syncthreads();
     D3_STAMP(2);
-    layer2<ACT>(l_A, g.tpacked, mt.b2, w, lane, h2);
+    layer2_regs<ACT>(l_A, bw, mt.b2, w, lane, h2);
+    load_w2_fragments(g.packed, lane, bw);  // the online network's, in flight during the head and its layer 1
     D3_STAMP(3);
     head_to_lds<NA>(mt, h2, w, lane, l_qn);
     D3_STAMP(4);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     layer1_to_lds<NS, ACT>(m, l_x, l_A, l_B, tid);
     __syncthreads();
     D3_STAMP(5);
-    layer2<ACT>(l_A, g.packed, m.b2, w, lane, h2);
+    layer2_regs<ACT>(l_A, bw, m.b2, w, lane, h2);
     D3_STAMP(6);
     head_to_lds<NA>(m, h2, w, lane, l_q);
     D3_STAMP(7);
