@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void ppo3_grad_kernel(P3Args g) {
     const int ob3a = H3 * NS + H3 + H3 * H3 + H3 + NOUT_A * H3;
     const int ob3c = H3 * NS + H3 + H3 * H3 + H3 + H3;
 
+    // the actor's hidden-layer B fragments: requested now, consumed after the gather and layer 1
+    bf16x8 bw[H3 / 16][4];
+    load_w2_fragments(g.packed, lane, bw);
     // ---- gather the tile's samples f = perm(pos) from the trajectory ----
     if (tid < TR) {
         const uint32_t q = (uint32_t)tile * TR + (uint32_t)tid;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void ppo3_grad_kernel(P3Args g) {
     f32x16 h2[4];
     layer1_to_lds<NS, ACT>(ma, l_x, l_A, l_B, tid);
     __syncthreads();
-    layer2<ACT>(l_A, g.packed, ma.b2, w, lane, h2);
+    layer2_regs<ACT>(l_A, bw, ma.b2, w, lane, h2);
     head_to_lds<NOUT_A>(ma, h2, w, lane, l_q);
     __syncthreads();
     if (tid < TR) {  // PPO clipped surrogate + entropy: loss terms and dL/d(actor outputs), as ppo_grad.hip phase 1b
