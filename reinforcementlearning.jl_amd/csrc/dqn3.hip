@@ -587,6 +587,8 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
         apply->sumsq = (double*)((char*)workspace + base);
         apply->counter = (unsigned int*)((char*)workspace + base + 256 * sizeof(double));
         apply->ns = ns;
+        // the kernel spins on a grid-wide counter: every workgroup must be resident at once (69 for np = 17 410)
+        RLHIP_REQUIRE((np + 255) / 256 <= 256, "too many parameters for the grid-barrier optimiser tail");
         hipLaunchKernelGGL(d3_apply_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials,
                            nb, (int)np, grad_out, loss_out, g.inv_b, *apply);
     } else {
