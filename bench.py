@@ -280,8 +280,27 @@ def roofline_extras(torch, rlhip):
     out["dqn_cartpole_4096env"]["fused_vec_step"] = {
         "env_steps_per_sec": round(n * steps_f / el, 1), "updates_per_sec": round(steps_f / el, 1),
         "ms_per_vec_step": round(el / steps_f * 1e3, 4),
-        "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then grad, then reduce + clip + Adam (3 launches per vec-step) -- bit-identical to the per-step protocol"}
+        "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then the gradient, then reduce + clip + Adam (3 launches per vec-step) -- bit-identical to the per-step protocol"}
     del agent, policy, learner, net, env
+    # the other batch sizes BASELINE config 2 names (32, 4096), fused loop, 2- and 3-layer network
+    by_batch = {}
+    for layers in (2, 3):
+        for bsz in (32, 4096):
+            env = rlhip.CartPoleEnv(n, seed=5)
+            net = rlhip.HipApproximator(4, 128, 2, seed=5, layers=layers)
+            learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=100), batchsize=bsz, min_replay_history=n, seed=5)
+            policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.01, kind="exp", decay_steps=500, seed=5))
+            agent = rlhip.Agent(policy, rlhip.Trajectory(CircularArraySARTSTraces(capacity=256, n_env=n, obs_dim=4)))
+            rlhip.run_fused_dqn(agent, env, rlhip.StopAfterNSteps(30))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rlhip.run_fused_dqn(agent, env, rlhip.StopAfterNSteps(1000))
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            by_batch[f"layers{layers}_batch{bsz}"] = {"env_steps_per_sec": round(n * 1000 / el, 1),
+                                                      "us_per_vec_step": round(el / 1000 * 1e6, 2)}
+            del agent, policy, learner, net, env
+    out["dqn_cartpole_4096env"]["fused_vec_step_other_batches"] = by_batch
     # same config with the blog's 3-layer Q-network 4 -> 128 -> 128 -> 2, hidden layer on the bf16 MFMA (dqn3.hip)
     env = rlhip.CartPoleEnv(n, seed=5)
     net = rlhip.HipApproximator(4, 128, 2, seed=5, layers=3)
