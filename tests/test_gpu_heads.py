@@ -131,3 +131,38 @@ def test_categorical_network_call_forms(rl):
     zm, lm = net(state, mask, is_sampling=True, is_return_log_prob=True)
     assert torch.isinf(lm[1]).all() and (zm[1] == 0).all() and (zm[3, ::2] == 0).all()
     assert torch.equal(net(state, mask)[0], lg[0])
+
+
+def test_kernels_match_the_frozen_oracle_pins(rl):
+    """tests/golden/oracle_pins/pins.json (frozen oracle outputs for the parts without a reference KAT): the Acrobot env
+    kernel and the Gaussian head kernel reproduce them from the same seeds"""
+    import json
+    import os
+
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_pins", "pins.json")))
+
+    def unhx(xs, dtype):
+        return np.array([float.fromhex(x) for x in xs], np.float64).astype(dtype)
+
+    for case in pins["acrobot"]:
+        dt, T = (np.float64, torch.float64) if case["dtype"] == "f64" else (np.float32, torch.float32)
+        kw = dict(case["kw"])
+        if "nips" in kw:
+            kw = {"book_or_nips": "nips"}
+        env = rl.AcrobotEnv(6, T=T, seed=21, env_id_base=3, **kw)
+        for a, want in zip(case["actions"], case["steps"]):
+            env.act0_(torch.tensor(a, dtype=torch.int32, device="cuda"))
+            for k in range(4):
+                np.testing.assert_allclose(env.raw_state()[k].cpu().numpy(), unhx(want["s"][k], dt),
+                                           rtol=1e-12 if dt == np.float64 else 1e-6, atol=0)
+            assert env.is_terminated().cpu().numpy().astype(int).tolist() == want["done"]
+            assert np.array_equal(env.reward().cpu().numpy(), unhx(want["reward"], dt))
+    h = pins["heads"]
+    d, n = h["shape"]
+    mu, raw = unhx(h["mu"], np.float32).reshape(d, n), unhx(h["raw_sigma"], np.float32).reshape(d, n)
+    for c in h["cases"]:
+        gn = _head(rl, mu, raw, c["soft"], c["squash"], 0.2, 1.5, seed=9, base=1)
+        gn.step = 4
+        a, lp = gn.sample(torch.zeros((1, 1, n), device="cuda"), 2)
+        np.testing.assert_allclose(a.cpu().numpy().ravel(), unhx(c["action"], np.float32), rtol=3e-7, atol=0)
+        np.testing.assert_allclose(lp.cpu().numpy().ravel(), unhx(c["logp"], np.float32), rtol=2e-5, atol=2e-5)
