@@ -146,6 +146,208 @@ __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float>
     }
 }
 
+// ---- the same rollout for SMALL env counts: 32 env instances per workgroup ------------------------------------------------
+// With 128-env tiles 4096 envs are 32 workgroups -- an eighth of the CUs, each walking a long per-step chain (measured
+// 8.5 us per step).  Here the four waves of a workgroup SHARE one 32-row tile and split the 128 hidden units: a wave
+// multiplies the 32 x 128 H1 tile by its own 32-column block of W2 (8 MFMAs per net and step instead of 32), layer 1 is
+// 16 units per thread, and the heads are finished from an f32 H2 tile in LDS by all 256 threads (32 rows x 8 column
+// parts).  H1 / W2 are rounded to bf16 and accumulated in f32 exactly as in the 128-row kernel (same k order), so H2 is
+// bit-identical; the head sums run in a different (fixed) order -- inside the tolerance the oracle comparison states.
+constexpr int R32 = 32;
+constexpr int LDH2 = H3 + 4;  // f32 pitch of the H2 tile
+template <class P, int NOUT_A, int ACT>
+__global__ __launch_bounds__(256) void ppo3_rollout32_kernel(P p, EnvArrays<float> st, int64_t n, int T, int cont, int na,
+                                                             const float* __restrict__ params, int64_t np_a,
+                                                             uint64_t seed, uint32_t env_id_base, uint32_t vec_step0,
+                                                             TrajPtrs tr, float gamma, float lambda) {
+    constexpr int NS = P::ODIM;
+    constexpr int NO = NOUT_A + 1;  // head outputs per env: the actor's, then the value
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    float* l_x = reinterpret_cast<float*>(smem3);                    // [4][R32]
+    float* l_part = l_x + 4 * R32;                                   // [8 parts][4][R32]
+    float* l_h2a = l_part + 8 * 4 * R32;                             // [R32][LDH2] actor H2 (f32)
+    float* l_h2c = l_h2a + R32 * LDH2;                               // critic H2
+    float* l_w = l_h2c + R32 * LDH2;                                 // [2][SMALLW]
+    uint16_t* l_fa = reinterpret_cast<uint16_t*>(l_w + 2 * SMALLW);  // actor W2 fragments [H3 * H3]
+    uint16_t* l_fc = l_fa + H3 * H3;                                 // critic W2 fragments
+    uint16_t* l_Ha = l_fc + H3 * H3;                                 // actor H1 tile [R32][LDH] (bf16)
+    uint16_t* l_Hc = l_Ha + R32 * LDH;                               // critic H1 tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const Mlp3 ma = stage_small_weights(params, NS, NOUT_A, l_w, tid);
+    const Mlp3 mc = stage_small_weights(params + np_a, NS, 1, l_w + SMALLW, tid);
+    stage_w2_fragments(params + H3 * NS + H3, l_fa, tid);
+    stage_w2_fragments(params + np_a + H3 * NS + H3, l_fc, tid);
+
+    const int64_t env = (int64_t)blockIdx.x * R32 + tid;
+    const bool active = tid < R32 && env < n;
+    const int64_t envc = env < n ? env : n - 1;
+    const uint32_t id = env_id_base + (uint32_t)envc;
+    LaneState<float> e;
+    float last_r = 0.0f;
+    bool last_d = false;
+    if (tid < R32) {
+#pragma unroll
+        for (int k = 0; k < P::SDIM; ++k) e.s[k] = st.s[k][envc];
+        e.t = st.t[envc];
+        e.episode = st.episode[envc];
+    }
+    const int row1 = tid & 31, u0 = 16 * (tid >> 5);  // layer 1: this thread's row and its 16 hidden units
+    const int part = tid >> 5;                        // heads: this thread's 16-column part of the H2 row `row1`
+    __syncthreads();
+    for (int t = 0; t <= T; ++t) {
+        if (tid < R32) {
+            float x[4];
+            env_obs1(p, e, x);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                l_x[k * R32 + tid] = x[k];
+                if (active) tr.obs[((int64_t)t * NS + k) * n + env] = x[k];
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 of both nets: h1 = act(b1 + W1 x), the fmaf chain of layer1_to_lds, 16 units per thread ----
+        {
+            float x[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = l_x[i * R32 + row1];
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                if (net == 0 && t == T) continue;  // the last pass only needs V(s_T)
+                const Mlp3& m = net ? mc : ma;
+                uint16_t* dst = (net ? l_Hc : l_Ha) + row1 * LDH + u0;
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8) {
+                    float hv[8];
+#pragma unroll
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const int u = u0 + 8 * h8 + 4 * q4;
+                        const float4 b = *reinterpret_cast<const float4*>(m.b1 + u);
+                        float z[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const float4 wv = *reinterpret_cast<const float4*>(m.W1 + u + H3 * i);
+                            z[0] = fmaf(wv.x, x[i], z[0]);
+                            z[1] = fmaf(wv.y, x[i], z[1]);
+                            z[2] = fmaf(wv.z, x[i], z[2]);
+                            z[3] = fmaf(wv.w, x[i], z[3]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+                    }
+                    *reinterpret_cast<uint4*>(dst + 8 * h8) = pack8_bf16(hv);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- layer 2: this wave's 32 output columns of both nets (MFMA), bias + activation, f32 tile to LDS ----
+        {
+            f32x16 aa, ac;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) aa[q] = 0.0f, ac[q] = 0.0f;
+            const uint16_t* apa = l_Ha + r * LDH + 8 * kb;
+            const uint16_t* apc = l_Hc + r * LDH + 8 * kb;
+#pragma unroll
+            for (int ks = 0; ks < H3 / 16; ++ks) {
+                const int fo = ((ks * 4 + w) * 64 + lane) * 8;
+                if (t < T) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(apa + 16 * ks);
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(l_fa + fo);
+                    aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, aa, 0, 0, 0);
+                }
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(apc + 16 * ks);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(l_fc + fo);
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, ac, 0, 0, 0);
+            }
+            const int col = 32 * w + r;
+            const float ba = ma.b2[col], bc = mc.b2[col];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = mfma_row(q, kb);
+                if (t < T) l_h2a[row * LDH2 + col] = act_fwd_t<ACT>(aa[q] + ba);
+                l_h2c[row * LDH2 + col] = act_fwd_t<ACT>(ac[q] + bc);
+            }
+        }
+        __syncthreads();
+        // ---- heads: thread (row1, part) folds 16 columns of its H2 row for every output ----
+        {
+            float pa[NOUT_A], pc = 0.0f;
+#pragma unroll
+            for (int o = 0; o < NOUT_A; ++o) pa[o] = 0.0f;
+            const float* ha = l_h2a + row1 * LDH2 + 16 * part;
+            const float* hc = l_h2c + row1 * LDH2 + 16 * part;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 vc = *reinterpret_cast<const float4*>(hc + 4 * c4);
+                const float hcv[4] = {vc.x, vc.y, vc.z, vc.w};
+                float hav[4] = {0.f, 0.f, 0.f, 0.f};
+                if (t < T) {
+                    const float4 va = *reinterpret_cast<const float4*>(ha + 4 * c4);
+                    hav[0] = va.x, hav[1] = va.y, hav[2] = va.z, hav[3] = va.w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 16 * part + 4 * c4 + c;
+                    pc = fmaf(mc.W3[j], hcv[c], pc);
+#pragma unroll
+                    for (int o = 0; o < NOUT_A; ++o) pa[o] = fmaf(ma.W3[o + NOUT_A * j], hav[c], pa[o]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT_A; ++o) l_part[(part * 4 + o) * R32 + row1] = pa[o];
+            l_part[(part * 4 + NOUT_A) * R32 + row1] = pc;
+        }
+        __syncthreads();
+        if (tid < R32) {
+            float out[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                float acc = l_part[o * R32 + tid];
+#pragma unroll
+                for (int pp = 1; pp < 8; ++pp) acc += l_part[(pp * 4 + o) * R32 + tid];
+                out[o] = acc + (o < NOUT_A ? ma.b3[o] : mc.b3[0]);
+            }
+            const float v = out[NOUT_A];
+            if (active) tr.value[(int64_t)t * n + env] = v;
+            if (t < T) {
+                float oa[MAXO];
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o) oa[o] = (o < NOUT_A) ? out[o] : 0.0f;
+                int32_t ai;
+                float af, lp;
+                policy_sample(cont, na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
+                env_step1(p, e, ai, af, last_r, last_d);
+                if (last_d) env_reset1(p, e, seed, id);
+                if (active) {
+                    tr.logp[(int64_t)t * n + env] = lp;
+                    if (cont) tr.action_f[(int64_t)t * n + env] = af;
+                    else tr.action_i[(int64_t)t * n + env] = ai;
+                    tr.reward[(int64_t)t * n + env] = last_r;
+                    tr.terminal[(int64_t)t * n + env] = (uint8_t)last_d;
+                }
+            }
+        }
+        // no barrier here: the next pass rewrites l_x (last read before the second barrier of this pass) from the same
+        // 32 lanes in program order; every other buffer is rewritten only after the next pass's barriers
+    }
+    if (active && T > 0 && tr.adv && tr.ret)  // GAE + returns fused into the rollout launch (gae_device.h)
+        gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, gamma, lambda);
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
+        st.t[env] = e.t;
+        st.episode[env] = e.episode;
+        if (T > 0) {
+            st.reward[env] = last_r;
+            st.done[env] = (uint8_t)last_d;
+        }
+    }
+}
+
+constexpr size_t ROLL32_LDS = (4 * R32 + 8 * 4 * R32 + 2 * R32 * LDH2 + 2 * SMALLW) * sizeof(float) +
+                              (2 * H3 * H3 + 2 * R32 * LDH) * sizeof(uint16_t);
+
 constexpr size_t ROLL3_LDS = (4 * TR + 2 * MAXO * TR + 2 * SMALLW) * sizeof(float) +
                              (2 * H3 * H3 + TILE_ELEMS) * sizeof(uint16_t);
 
@@ -432,9 +634,19 @@ static int32_t rollout3_impl(const typename P::cfg_t* cfg, const rlhip_env_state
     P p = P::make(c2);
     EnvArrays<float> a = EnvArrays<float>::from(*st);
     TrajPtrs tr = TrajPtrs::from(*traj);
-    dim3 grid((unsigned)((n + TR - 1) / TR));
+    // up to 2^15 envs the 32-env workgroups fill more of the chip and have the shorter per-step chain
+    const bool small = n <= (1 << 15) && !RLHIP_ENV_FLAG("RLHIP_PPO3_ROLLOUT128");
+    dim3 grid((unsigned)(small ? (n + R32 - 1) / R32 : (n + TR - 1) / TR));
 #define LAUNCH_R3(ACT_)                                                                                           \
     do {                                                                                                          \
+        if (small) {                                                                                              \
+            static bool done32_ = false;                                                                          \
+            int32_t rc_ = allow_lds3(ppo3_rollout32_kernel<P, 2, ACT_>, ROLL32_LDS, &done32_);                    \
+            if (rc_) return rc_;                                                                                  \
+            hipLaunchKernelGGL((ppo3_rollout32_kernel<P, 2, ACT_>), grid, dim3(256), ROLL32_LDS, s, p, a, n, (int)T, \
+                               pd.cont, pd.na, params, pd.np_a, seed, env_id_base, vec_step0, tr, pd.gamma, pd.lambda); \
+            break;                                                                                                \
+        }                                                                                                         \
         static bool done_ = false;                                                                                \
         int32_t rc_ = allow_lds3(ppo3_rollout_kernel<P, 2, ACT_>, ROLL3_LDS, &done_);                             \
         if (rc_) return rc_;                                                                                      \
