@@ -109,6 +109,134 @@ __global__ __launch_bounds__(256) void mlp3_plan_kernel(const float* __restrict_
     }
 }
 
+// The same forward for SMALL batches (n <= 2^15): 32 rows per workgroup, the four waves share the row tile and split the
+// 128 hidden units (8 MFMAs per wave instead of 32; the wave's 8 B fragments come straight from the fragment-ordered
+// global copy into registers at kernel entry), layer 1 is 16 units per thread, the head is folded from an f32 H2 tile in
+// LDS by all 256 threads.  4096 envs are 128 workgroups instead of 32.  H2 is bit-identical to the 128-row kernel (same
+// bf16 roundings, same k order); the head sums run in a different fixed order (inside the stated tolerance).
+constexpr int P32 = 32;
+constexpr int LDH2 = H3 + 4;  // f32 pitch of the H2 tile
+template <int NS, int NA, int ACT>
+__global__ __launch_bounds__(256) void mlp3_plan32_kernel(const float* __restrict__ params,
+                                                          const uint16_t* __restrict__ packed,
+                                                          const float* __restrict__ obs, int64_t n, double eps,
+                                                          uint64_t seed, uint32_t env_id_base, uint32_t step,
+                                                          int32_t* __restrict__ actions, float* __restrict__ q_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    constexpr int na = NA;
+    float* l_x = reinterpret_cast<float*>(smem3);               // [4][P32]
+    float* l_part = l_x + 4 * P32;                              // [8 parts][4][P32]
+    float* l_h2 = l_part + 8 * 4 * P32;                         // [P32][LDH2]
+    float* l_w = l_h2 + P32 * LDH2;                             // [SMALLW]
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + SMALLW);  // [P32][LDH] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    bf16x8 bwf[H3 / 16];  // this wave's column tile t = w of every k-step
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks)
+        bwf[ks] = *reinterpret_cast<const bf16x8*>(packed + ((ks * 4 + w) * 64 + lane) * 8);
+    const int64_t e0 = (int64_t)blockIdx.x * P32;
+    float xin[NS];
+    if (tid < P32) {
+        int64_t e = e0 + tid;
+        if (e >= n) e = n - 1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) xin[i] = obs[(int64_t)i * n + e];
+    }
+    const Mlp3 m = stage_small_weights(params, NS, na, l_w, tid);
+    if (tid < P32) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) l_x[i * P32 + tid] = xin[i];
+    }
+    __syncthreads();
+    const int row1 = tid & 31, u0 = 16 * (tid >> 5), part = tid >> 5;
+    {  // layer 1: the fmaf chain of layer1_to_lds, 16 units per thread
+        float x[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = l_x[i * P32 + row1];
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+            float hv[8];
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const int u = u0 + 8 * h8 + 4 * q4;
+                const float4 b = *reinterpret_cast<const float4*>(m.b1 + u);
+                float z[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const float4 wv = *reinterpret_cast<const float4*>(m.W1 + u + H3 * i);
+                    z[0] = fmaf(wv.x, x[i], z[0]);
+                    z[1] = fmaf(wv.y, x[i], z[1]);
+                    z[2] = fmaf(wv.z, x[i], z[2]);
+                    z[3] = fmaf(wv.w, x[i], z[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+            }
+            *reinterpret_cast<uint4*>(l_H + row1 * LDH + u0 + 8 * h8) = pack8_bf16(hv);
+        }
+    }
+    __syncthreads();
+    {  // layer 2: this wave's 32 output columns
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        const uint16_t* ap = l_H + r * LDH + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < H3 / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwf[ks], acc, 0, 0, 0);
+        }
+        const int col = 32 * w + r;
+        const float bv = m.b2[col];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l_h2[mfma_row(q, kb) * LDH2 + col] = act_fwd_t<ACT>(acc[q] + bv);
+    }
+    __syncthreads();
+    {  // head: thread (row1, part) folds 16 columns of its H2 row for every output
+        float pq[NA];
+#pragma unroll
+        for (int o = 0; o < NA; ++o) pq[o] = 0.0f;
+        const float* hp = l_h2 + row1 * LDH2 + 16 * part;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 v = *reinterpret_cast<const float4*>(hp + 4 * c4);
+            const float hv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 16 * part + 4 * c4 + c;
+#pragma unroll
+                for (int o = 0; o < NA; ++o) pq[o] = fmaf(m.W3[o + NA * j], hv[c], pq[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < NA; ++o) l_part[(part * 4 + o) * P32 + row1] = pq[o];
+    }
+    __syncthreads();
+    if (tid < P32 && e0 + tid < n) {
+        const int64_t e = e0 + tid;
+        float q[MAXO];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            float acc = 0.0f;
+            if (o < na) {
+                acc = l_part[o * P32 + tid];
+#pragma unroll
+                for (int pp = 1; pp < 8; ++pp) acc += l_part[(pp * 4 + o) * P32 + tid];
+                acc += m.b3[o];
+            }
+            q[o] = acc;
+        }
+        if (q_out)
+            for (int o = 0; o < na; ++o) q_out[(int64_t)o * n + e] = q[o];
+        if (actions)
+            actions[e] = eps_greedy_select1(RegQ3{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)e, step);
+    }
+}
+
+constexpr size_t PLAN32_LDS = (4 * P32 + 8 * 4 * P32 + P32 * LDH2 + SMALLW) * sizeof(float) + P32 * LDH * sizeof(uint16_t);
+
 // ---------------------------------------------------------------------------------- gradient
 struct Dqn3Args {
     const float* state;
@@ -498,8 +626,15 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
     if (n == 0) return RLHIP_OK;
     hipStream_t s = as_stream(stream);
     dim3 grid((unsigned)((n + TR - 1) / TR));
+    const bool small = n <= (1 << 15) && !RLHIP_ENV_FLAG("RLHIP_DQN3_PLAN128");
+    const dim3 grid32((unsigned)((n + P32 - 1) / P32));
 #define LAUNCH_P(NS_, NA_, ACT_)                                                                               \
     do {                                                                                                       \
+        if (small) {                                                                                           \
+            hipLaunchKernelGGL((mlp3_plan32_kernel<NS_, NA_, ACT_>), grid32, dim3(256), PLAN32_LDS, s, params,  \
+                               packed, obs, n, eps, seed, env_id_base, step, actions, q_out);                  \
+            break;                                                                                             \
+        }                                                                                                      \
         static bool done_ = false;                                                                             \
         int32_t rc_ = allow_lds(mlp3_plan_kernel<NS_, NA_, ACT_>, PLAN_LDS, &done_);                           \
         if (rc_) return rc_;                                                                                   \
