@@ -391,6 +391,343 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     D3_STAMP(11);
 }
 
+// ---- the learner step for SMALL batches: 32 samples per workgroup ------------------------------------------------------
+// A 512-sample batch is 4 workgroups of the 128-row kernel above -- 1.5 % of the CUs, 22 us of latency.  Here the four
+// waves of a workgroup share one 32-sample tile and split the 128 hidden units / columns everywhere: a wave runs 8 MFMAs
+// per GEMM (target forward, online forward, dH1 = dZ2 W2, dW2^T = H1^T dZ2) instead of 32, column sums of the backward
+// pass never cross a wave (its 32 columns are its own), and the heads are folded from an f32 H2 tile by all 256
+// threads.  Same bf16 roundings and k order as the 128-row kernel inside every GEMM; the sums over samples and over
+// hidden units run in a different fixed order, and there are four times as many partial rows for d3_reduce / d3_apply.
+constexpr int G32 = 32;
+constexpr int D3_SMALL_BATCH = 2048;  // up to here the 32-sample kernel (<= 64 workgroups) replaces the 128-row one
+constexpr int LDT = G32 + 8;  // bf16 pitch of the transposed tiles [k][sample]
+template <int NS, int NA, int ACT>
+__global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    constexpr int na = NA;
+    float* l_x = reinterpret_cast<float*>(smem3);                     // [4][G32]
+    float* l_xn = l_x + 4 * G32;                                      // [4][G32]
+    float* l_dq = l_xn + 4 * G32;                                     // [MAXO][G32]
+    float* l_r = l_dq + MAXO * G32;                                   // [G32]
+    float* l_part = l_r + G32;                                        // [8][4][G32] online head partials
+    float* l_partn = l_part + 8 * 4 * G32;                            // [8][4][G32] target head partials
+    int32_t* l_a = reinterpret_cast<int32_t*>(l_partn + 8 * 4 * G32); // [G32]
+    int32_t* l_t = l_a + G32;                                         // [G32]
+    float* l_h2 = reinterpret_cast<float*>(l_t + G32);                // [G32][LDH2] f32 H2 of the current net
+    float* l_w = l_h2 + G32 * LDH2;                                   // [2][SMALLW]
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + 2 * SMALLW);    // H1 [row][k]
+    uint16_t* l_HT = l_H + G32 * LDH;                                 // online H1^T [k][row]
+    uint16_t* l_Z = l_HT + H3 * LDT;                                  // dZ2 [row][j]
+    uint16_t* l_ZT = l_Z + G32 * LDH;                                 // dZ2^T [j][row]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int col = 32 * w + r;  // the hidden unit / column this lane owns in every D-layout phase
+    const int tile = blockIdx.x;
+    float* out = g.partials + (int64_t)blockIdx.x * g.np;
+    const int oW1 = 0, ob1 = H3 * NS, oW2 = ob1 + H3, ob2 = oW2 + H3 * H3, oW3 = ob2 + H3, ob3 = oW3 + na * H3;
+
+    bf16x8 bwf[H3 / 16];  // B fragments of this wave's column tile: target net first
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks)
+        bwf[ks] = *reinterpret_cast<const bf16x8*>(g.tpacked + ((ks * 4 + w) * 64 + lane) * 8);
+    // ---- sample + gather ----
+    float gs[NS], gsn[NS], gr = 0.f;
+    int32_t ga = 0, gt = 0;
+    if (tid < G32) {
+        int64_t b = (int64_t)tile * G32 + tid;
+        bool valid = b < g.batch;
+        int64_t fj;
+        if (g.idx) {
+            fj = g.idx[valid ? b : 0];
+        } else {
+            u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
+            uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
+            fj = (int64_t)__umul64hi(xr, g.total);
+        }
+        int64_t li = fj / g.n_env, e = fj - li * g.n_env;
+        int64_t ps = (g.head_sa + li) % (g.capacity + 1);
+        int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
+        int64_t pt = (g.head_rt + li) % g.capacity;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            gs[k] = g.state[(ps * NS + k) * g.n_env + e];
+            gsn[k] = g.state[(pn * NS + k) * g.n_env + e];
+        }
+        ga = g.action[pt * g.n_env + e];
+        gr = g.reward[pt * g.n_env + e];
+        gt = g.terminal[pt * g.n_env + e];
+    }
+    const Mlp3 m = stage_small_weights(g.params, NS, na, l_w, tid);
+    const Mlp3 mt = stage_small_weights(g.tparams, NS, na, l_w + SMALLW, tid);
+    if (tid < G32) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            l_x[k * G32 + tid] = gs[k];
+            l_xn[k * G32 + tid] = gsn[k];
+        }
+        l_a[tid] = ga;
+        l_r[tid] = gr;
+        l_t[tid] = gt;
+    }
+    __syncthreads();
+    const int row1 = tid & 31, u0 = 16 * (tid >> 5), part = tid >> 5;
+
+    // layer 1 of one net for (row1, units u0 .. u0 + 15): bf16 into l_H [row][k] and, for the online net, l_HT [k][row]
+    auto layer1 = [&](const Mlp3& mm, const float* lx, bool transposed_too) {
+        float x[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = lx[i * G32 + row1];
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+            float hv[8];
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const int u = u0 + 8 * h8 + 4 * q4;
+                const float4 b = *reinterpret_cast<const float4*>(mm.b1 + u);
+                float z[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const float4 wv = *reinterpret_cast<const float4*>(mm.W1 + u + H3 * i);
+                    z[0] = fmaf(wv.x, x[i], z[0]);
+                    z[1] = fmaf(wv.y, x[i], z[1]);
+                    z[2] = fmaf(wv.z, x[i], z[2]);
+                    z[3] = fmaf(wv.w, x[i], z[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+            }
+            *reinterpret_cast<uint4*>(l_H + row1 * LDH + u0 + 8 * h8) = pack8_bf16(hv);
+            if (transposed_too) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) l_HT[(u0 + 8 * h8 + c) * LDT + row1] = f32_to_bf16_rne(hv[c]);
+            }
+        }
+    };
+    // layer 2 for this wave's 32 columns: activated H2 in the D layout (+ the f32 tile for the head)
+    auto layer2w = [&](const float* b2, f32x16& h2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h2[q] = 0.0f;
+        const uint16_t* ap = l_H + r * LDH + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < H3 / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+            h2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwf[ks], h2, 0, 0, 0);
+        }
+        const float bv = b2[col];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            h2[q] = act_fwd_t<ACT>(h2[q] + bv);
+            l_h2[mfma_row(q, kb) * LDH2 + col] = h2[q];
+        }
+    };
+    // head partials of thread (row1, part) over 16 columns of its H2 row
+    auto head = [&](const Mlp3& mm, float* lp) {
+        float pq[NA];
+#pragma unroll
+        for (int o = 0; o < NA; ++o) pq[o] = 0.0f;
+        const float* hp = l_h2 + row1 * LDH2 + 16 * part;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 v = *reinterpret_cast<const float4*>(hp + 4 * c4);
+            const float hv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 16 * part + 4 * c4 + c;
+#pragma unroll
+                for (int o = 0; o < NA; ++o) pq[o] = fmaf(mm.W3[o + NA * j], hv[c], pq[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < NA; ++o) lp[(part * 4 + o) * G32 + row1] = pq[o];
+    };
+
+    // ---- target network on s' ----
+    f32x16 h2;
+    layer1(mt, l_xn, false);
+    __syncthreads();
+    layer2w(mt.b2, h2);
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks)  // the online network's fragments: in flight during the head and its layer 1
+        bwf[ks] = *reinterpret_cast<const bf16x8*>(g.packed + ((ks * 4 + w) * 64 + lane) * 8);
+    __syncthreads();
+    head(mt, l_partn);
+    // ---- online network on s (its H2 stays in registers for the backward pass) ----
+    layer1(m, l_x, true);  // l_H was last read before the barrier above
+    __syncthreads();       // also: every thread is done reading the target's H2 tile
+    layer2w(m.b2, h2);
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks)  // W2kj fragments (ks over j, this wave's k tile) for dH1
+        bwf[ks] = *reinterpret_cast<const bf16x8*>(g.packed + H3 * H3 + ((ks * 4 + w) * 64 + lane) * 8);
+    __syncthreads();
+    head(m, l_part);
+    __syncthreads();
+    // ---- TD target, Huber loss, dL/dq per sample ----
+    if (tid < G32) {
+        const int s = tid;
+        const int64_t b = (int64_t)tile * G32 + s;
+        const bool valid = b < g.batch;
+        float q[MAXO], qn[MAXO];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            q[o] = 0.f, qn[o] = 0.f;
+            if (o < na) {
+                float a1 = l_part[o * G32 + s], a2 = l_partn[o * G32 + s];
+#pragma unroll
+                for (int pp = 1; pp < 8; ++pp) {
+                    a1 += l_part[(pp * 4 + o) * G32 + s];
+                    a2 += l_partn[(pp * 4 + o) * G32 + s];
+                }
+                q[o] = a1 + m.b3[o];
+                qn[o] = a2 + mt.b3[o];
+            }
+        }
+        float mx = qn[0];
+        for (int k = 1; k < na; ++k) mx = fmaxf(mx, qn[k]);
+        float cont = l_t[s] ? 0.f : 1.f;
+        float G = l_r[s] + g.gamma * cont * mx;
+        int a = l_a[s];
+        float qa = 0.f;
+        for (int k = 0; k < na; ++k)
+            if (k == a) qa = q[k];
+        float d = qa - G;
+        float e = fabsf(d);
+        float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
+        float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
+        gi *= g.inv_b;
+        if (!valid) {
+            gi = 0.f;
+            l = 0.f;
+        }
+        if (valid && g.td_out) g.td_out[b] = e;
+        float red[MAXO + 1];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            float dl = (o == a) ? gi : 0.f;
+            l_dq[o * G32 + s] = dl;
+            red[o] = dl;
+        }
+        red[MAXO] = l;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1)  // lanes 0..31 of wave 0
+#pragma unroll
+            for (int o = 0; o <= MAXO; ++o) red[o] += __shfl_down(red[o], off, 64);
+        if (lane == 0) {
+            for (int o = 0; o < na; ++o) out[ob3 + o] = red[o];
+            g.loss_partials[blockIdx.x] = red[MAXO];
+        }
+    }
+    __syncthreads();
+    // ---- head backward in the D layout (this wave's 32 columns): dW3, db2, dZ2 -> bf16 tiles [row][j] and [j][row] ----
+    {
+        float w3[MAXO], accw[MAXO], accb = 0.0f;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            w3[o] = (o < na) ? m.W3[o + na * col] : 0.0f;
+            accw[o] = 0.0f;
+        }
+        uint16_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = mfma_row(q, kb);
+            const float hv = h2[q];
+            float dh = 0.0f;
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (o < na) {
+                    const float dqv = l_dq[o * G32 + row];
+                    accw[o] = fmaf(dqv, hv, accw[o]);
+                    dh = fmaf(dqv, w3[o], dh);
+                }
+            const float dz = dh * act_bwd_t<ACT>(hv, hv);  // relu: h2 > 0 <=> z2 > 0
+            accb += dz;
+            const uint16_t dzb = f32_to_bf16_rne(dz);
+            l_Z[row * LDH + col] = dzb;
+            pk[q & 3] = dzb;
+            if ((q & 3) == 3) {
+                uint2 v2;
+                v2.x = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
+                v2.y = (uint32_t)pk[2] | ((uint32_t)pk[3] << 16);
+                *reinterpret_cast<uint2*>(l_ZT + col * LDT + 8 * (q >> 2) + 4 * kb) = v2;  // rows 8 (q >> 2) + 4 kb .. + 3
+            }
+        }
+        accb += __shfl_xor(accb, 32, 64);  // the other 16 rows
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) accw[o] += __shfl_xor(accw[o], 32, 64);
+        if (kb == 0) {
+            out[ob2 + col] = accb;
+            for (int o = 0; o < na; ++o) out[oW3 + o + na * col] = accw[o];
+        }
+    }
+    __syncthreads();
+    // ---- dH1 = dZ2 W2 (MFMA, this wave's 32 hidden units k), dz1 = dH1 act'(z1), dW1 / db1 ----
+    {
+        f32x16 dh1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dh1[q] = 0.0f;
+        const uint16_t* ap = l_Z + r * LDH + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < H3 / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+            dh1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwf[ks], dh1, 0, 0, 0);
+        }
+        float w1[NS], acc1[NS], accb = 0.0f;
+        const float bb = m.b1[col];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            w1[i] = m.W1[col + H3 * i];
+            acc1[i] = 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = mfma_row(q, kb);
+            float x[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = l_x[i * G32 + row];
+            float z = bb;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) z = fmaf(w1[i], x[i], z);
+            const float hv = act_fwd_t<ACT>(z);
+            const float dz = dh1[q] * act_bwd_t<ACT>(z, hv);
+            accb += dz;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) acc1[i] = fmaf(dz, x[i], acc1[i]);
+        }
+        accb += __shfl_xor(accb, 32, 64);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) acc1[i] += __shfl_xor(acc1[i], 32, 64);
+        if (kb == 0) {
+            out[ob1 + col] = accb;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) out[oW1 + col + H3 * i] = acc1[i];
+        }
+    }
+    // ---- dW2^T[k][j] = sum_s H1[s][k] dZ2[s][j] (MFMA, K = the 32 samples); stored as Flux W2[j + H3 k] ----
+    {
+        f32x16 dw[4];
+        zero_acc(dw);
+        const uint16_t* ap = l_HT + (32 * w + r) * LDT + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < G32 / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(l_ZT + (32 * t + r) * LDT + 16 * ks + 8 * kb);
+                dw[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, dw[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
+    }
+}
+
+constexpr size_t GRAD32_LDS = (4 * G32 * 2 + MAXO * G32 + G32 + 2 * 8 * 4 * G32 + 2 * G32 + G32 * LDH2 + 2 * SMALLW) *
+                                  sizeof(float) +
+                              (2 * G32 * LDH + 2 * H3 * LDT) * sizeof(uint16_t);
+
 // bf16 copies of W2 in MFMA B-fragment order, one per operand orientation (16-byte units, see gemm_slab):
 //   packed[0 .. H*H)      "W2jk": fragment (ks, t), lane l holds W2[j = 32 t + (l & 31)][k = 16 ks + 8 (l >> 5) + u]
 //   packed[H*H .. 2 H*H)  "W2kj": fragment (ks, t), lane l holds W2[j = 16 ks + 8 (l >> 5) + u][k = 32 t + (l & 31)]
@@ -651,7 +988,7 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
 }
 
 int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
-    int64_t nb = (batch + TR - 1) / TR;
+    int64_t nb = batch <= D3_SMALL_BATCH ? (batch + G32 - 1) / G32 : (batch + TR - 1) / TR;  // rows of partials
     if (nb < 1) nb = 1;
     // partials | loss partials | (8-byte aligned) 256 Float64 sums of squares + 64 B of counters for
     // rlhip_dqn3_update_f32 (the tail must be zero before the first use)
@@ -678,7 +1015,8 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     RLHIP_REQUIRE(((((uintptr_t)packed) | ((uintptr_t)target_packed)) & 15) == 0, "packed weights must be 16-byte aligned");
     const int ns = (int)rb->obs_dim;
     const int64_t np = mlp3_nparams(ns, h, na);
-    const int nb = (int)((batch + TR - 1) / TR);
+    const bool small = batch <= D3_SMALL_BATCH && !RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD128");
+    const int nb = small ? (int)((batch + G32 - 1) / G32) : (int)((batch + TR - 1) / TR);
     Dqn3Args g;
     g.state = (const float*)rb->state;
     g.action = rb->action;
@@ -708,6 +1046,13 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     hipStream_t s = as_stream(stream);
 #define LAUNCH_G(NS_, NA_, ACT_)                                                                        \
     do {                                                                                                \
+        if (small) {                                                                                    \
+            static bool done32_ = false;                                                                \
+            int32_t rc_ = allow_lds(dqn3_grad32_kernel<NS_, NA_, ACT_>, GRAD32_LDS, &done32_);          \
+            if (rc_) return rc_;                                                                        \
+            hipLaunchKernelGGL((dqn3_grad32_kernel<NS_, NA_, ACT_>), dim3(nb), dim3(256), GRAD32_LDS, s, g); \
+            break;                                                                                      \
+        }                                                                                               \
         static bool done_ = false;                                                                      \
         int32_t rc_ = allow_lds(dqn3_grad_kernel<NS_, NA_, ACT_>, GRAD_LDS, &done_);                    \
         if (rc_) return rc_;                                                                            \
