@@ -827,13 +827,32 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
     if (own) {
         const int per = (nb + 3) / 4;
         float a[4];
+        if (nb <= 16) {
+            // all loads issued before the first add: one round trip (x + 0.0f is exact, so the padded slots change no bit)
+            float t[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b0 = q * per, b1 = min(nb, b0 + per);
-            float acc = 0.f;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = q * per + u;
+                    t[q][u] = (u < per && b < nb) ? partials[(int64_t)b * np + i] : 0.0f;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += t[q][u];
+                a[q] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b0 = q * per, b1 = min(nb, b0 + per);
+                float acc = 0.f;
 #pragma unroll 8
-            for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + i];
-            a[q] = acc;
+                for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + i];
+                a[q] = acc;
+            }
         }
         g = ((a[0] + a[1]) + a[2]) + a[3];
     }
