@@ -254,6 +254,7 @@ struct Dqn3Args {
     float* loss_partials;     // [nb]
     float* td_out;            // optional |Q(s,a) - y| per sample (priority write-back), may be NULL
     int na, np;
+    int num_tiles;            // dqn3_grad32_kernel: 32-sample tiles of the batch (a workgroup walks several)
     int64_t batch;
     float gamma, delta, inv_b;
     uint64_t seed;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
 // threads.  Same bf16 roundings and k order as the 128-row kernel inside every GEMM; the sums over samples and over
 // hidden units run in a different fixed order, and there are four times as many partial rows for d3_reduce / d3_apply.
 constexpr int G32 = 32;
-constexpr int D3_SMALL_BATCH = 2048;  // up to here the 32-sample kernel (<= 64 workgroups) replaces the 128-row one
+constexpr int D3_GRAD32_BLOCKS = 512;  // persistent workgroups of the 32-sample kernel = rows of partial gradients
 constexpr int LDT = G32 + 8;  // bf16 pitch of the transposed tiles [k][sample]
 template <int NS, int NA, int ACT>
 __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
@@ -424,13 +425,24 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int col = 32 * w + r;  // the hidden unit / column this lane owns in every D-layout phase
-    const int tile = blockIdx.x;
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
     const int oW1 = 0, ob1 = H3 * NS, oW2 = ob1 + H3, ob2 = oW2 + H3 * H3, oW3 = ob2 + H3, ob3 = oW3 + na * H3;
 
-    bf16x8 bwf[H3 / 16];  // B fragments of this wave's column tile: target net first
+    const Mlp3 m = stage_small_weights(g.params, NS, na, l_w, tid);
+    const Mlp3 mt = stage_small_weights(g.tparams, NS, na, l_w + SMALLW, tid);
+    const int row1 = tid & 31, u0 = 16 * (tid >> 5), part = tid >> 5;
+    // gradient accumulators of this workgroup over ALL its tiles (tile, tile + gridDim.x, ...): every sum below is per
+    // lane already (a lane owns its column in each D-layout phase), so a persistent workgroup costs no extra traffic and
+    // writes ONE partial row however large the batch is
+    float acc_b2 = 0.0f, acc_w3[MAXO] = {0.f, 0.f, 0.f, 0.f}, acc_b1 = 0.0f, acc_w1[NS], acc_b3[MAXO + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < H3 / 16; ++ks)
+    for (int i = 0; i < NS; ++i) acc_w1[i] = 0.0f;
+    f32x16 dw[4];
+    zero_acc(dw);
+    bf16x8 bwf[H3 / 16];  // B fragments of this wave's column tile
+    for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int ks = 0; ks < H3 / 16; ++ks)  // target net first
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.tpacked + ((ks * 4 + w) * 64 + lane) * 8);
     // ---- sample + gather ----
     float gs[NS], gsn[NS], gr = 0.f;
@@ -459,8 +471,6 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
         gr = g.reward[pt * g.n_env + e];
         gt = g.terminal[pt * g.n_env + e];
     }
-    const Mlp3 m = stage_small_weights(g.params, NS, na, l_w, tid);
-    const Mlp3 mt = stage_small_weights(g.tparams, NS, na, l_w + SMALLW, tid);
     if (tid < G32) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -472,7 +482,6 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
         l_t[tid] = gt;
     }
     __syncthreads();
-    const int row1 = tid & 31, u0 = 16 * (tid >> 5), part = tid >> 5;
 
     // layer 1 of one net for (row1, units u0 .. u0 + 15): bf16 into l_H [row][k] and, for the online net, l_HT [k][row]
     auto layer1 = [&](const Mlp3& mm, const float* lx, bool transposed_too) {
@@ -614,8 +623,8 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
 #pragma unroll
             for (int o = 0; o <= MAXO; ++o) red[o] += __shfl_down(red[o], off, 64);
         if (lane == 0) {
-            for (int o = 0; o < na; ++o) out[ob3 + o] = red[o];
-            g.loss_partials[blockIdx.x] = red[MAXO];
+#pragma unroll
+            for (int o = 0; o <= MAXO; ++o) acc_b3[o] += red[o];
         }
     }
     __syncthreads();
@@ -655,10 +664,9 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
         accb += __shfl_xor(accb, 32, 64);  // the other 16 rows
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) accw[o] += __shfl_xor(accw[o], 32, 64);
-        if (kb == 0) {
-            out[ob2 + col] = accb;
-            for (int o = 0; o < na; ++o) out[oW3 + o + na * col] = accw[o];
-        }
+        acc_b2 += accb;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) acc_w3[o] += accw[o];
     }
     __syncthreads();
     // ---- dH1 = dZ2 W2 (MFMA, this wave's 32 hidden units k), dz1 = dH1 act'(z1), dW1 / db1 ----
@@ -697,16 +705,12 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
         accb += __shfl_xor(accb, 32, 64);
 #pragma unroll
         for (int i = 0; i < NS; ++i) acc1[i] += __shfl_xor(acc1[i], 32, 64);
-        if (kb == 0) {
-            out[ob1 + col] = accb;
+        acc_b1 += accb;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) out[oW1 + col + H3 * i] = acc1[i];
-        }
+        for (int i = 0; i < NS; ++i) acc_w1[i] += acc1[i];
     }
     // ---- dW2^T[k][j] = sum_s H1[s][k] dZ2[s][j] (MFMA, K = the 32 samples); stored as Flux W2[j + H3 k] ----
     {
-        f32x16 dw[4];
-        zero_acc(dw);
         const uint16_t* ap = l_HT + (32 * w + r) * LDT + 8 * kb;
 #pragma unroll
         for (int ks = 0; ks < G32 / 16; ++ks) {
@@ -717,11 +721,25 @@ __global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
                 dw[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, dw[t], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
     }
+    __syncthreads();  // the next tile's gather rewrites l_x / l_a / ... that the phases above read
+    }  // tiles
+    // ---- this workgroup's partial row ----
+    if (tid == 0) {
+        for (int o = 0; o < na; ++o) out[ob3 + o] = acc_b3[o];
+        g.loss_partials[blockIdx.x] = acc_b3[MAXO];
+    }
+    if (kb == 0) {
+        out[ob2 + col] = acc_b2;
+        for (int o = 0; o < na; ++o) out[oW3 + o + na * col] = acc_w3[o];
+        out[ob1 + col] = acc_b1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) out[oW1 + col + H3 * i] = acc_w1[i];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
 }
 
 constexpr size_t GRAD32_LDS = (4 * G32 * 2 + MAXO * G32 + G32 + 2 * 8 * 4 * G32 + 2 * G32 + G32 * LDH2 + 2 * SMALLW) *
@@ -1007,7 +1025,10 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
 }
 
 int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
-    int64_t nb = batch <= D3_SMALL_BATCH ? (batch + G32 - 1) / G32 : (batch + TR - 1) / TR;  // rows of partials
+    // rows of partials: the larger of what the 32-sample kernel (persistent, <= D3_GRAD32_BLOCKS) and the 128-row kernel use
+    int64_t nb = (batch + G32 - 1) / G32;
+    if (nb > D3_GRAD32_BLOCKS) nb = D3_GRAD32_BLOCKS;
+    if ((batch + TR - 1) / TR > nb) nb = (batch + TR - 1) / TR;
     if (nb < 1) nb = 1;
     // partials | loss partials | (8-byte aligned) 256 Float64 sums of squares + 64 B of counters for
     // rlhip_dqn3_update_f32 (the tail must be zero before the first use)
@@ -1034,8 +1055,13 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     RLHIP_REQUIRE(((((uintptr_t)packed) | ((uintptr_t)target_packed)) & 15) == 0, "packed weights must be 16-byte aligned");
     const int ns = (int)rb->obs_dim;
     const int64_t np = mlp3_nparams(ns, h, na);
-    const bool small = batch <= D3_SMALL_BATCH && !RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD128");
-    const int nb = small ? (int)((batch + G32 - 1) / G32) : (int)((batch + TR - 1) / TR);
+    // measured (gradient + reduce, us; 32-sample persistent / 128-row): batch 512: 14.2 / 24.0, 4096: 19.0 / 25.3,
+    // 8192: 27.0 / 27.2, 16384: 39.7 / 32.1, 32768: 52.3 / 37.0, 65536: 76.2 / 69.3, 131072: 121.7 / 131.9 -- the
+    // 32-sample kernel (280 VGPRs persistent: one workgroup per CU) wins where latency or the partial-row volume decide
+    const bool small = !RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD128") &&
+                       (batch <= 8192 || batch >= 98304 || RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD32"));
+    const int64_t tiles32 = (batch + G32 - 1) / G32;
+    const int nb = small ? (int)(tiles32 < D3_GRAD32_BLOCKS ? tiles32 : D3_GRAD32_BLOCKS) : (int)((batch + TR - 1) / TR);
     Dqn3Args g;
     g.state = (const float*)rb->state;
     g.action = rb->action;
@@ -1056,6 +1082,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     g.td_out = td_out;
     g.na = (int)na;
     g.np = (int)np;
+    g.num_tiles = (int)tiles32;
     g.batch = batch;
     g.gamma = gamma;
     g.delta = huber_delta;

@@ -18,7 +18,7 @@ p = dqn.mlp3_init(ns, H, na, 1)
 tp = dqn.mlp3_init(ns, H, na, 2)
 pk, tpk = dqn.mlp3_pack(p, ns, H, na), dqn.mlp3_pack(tp, ns, H, na)
 lib, s = rlhip._lib.lib, stream_ptr()
-for batch in (32, 512, 4096, 32768, 131072):
+for batch in (32, 512, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
     ws = dqn.dqn3_workspace(ns, H, na, batch)
     g = torch.empty_like(p); loss = torch.empty(1, device="cuda")
     f = lambda: dqn.dqn3_grad(tr, H, na, 0, p, pk, tp, tpk, batch, 0.99, 1.0, 1, 0, workspace=ws, grad=g, loss=loss)
