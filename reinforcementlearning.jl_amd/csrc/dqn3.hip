@@ -402,8 +402,10 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
 constexpr int G32 = 32;
 constexpr int D3_GRAD32_BLOCKS = 512;  // persistent workgroups of the 32-sample kernel = rows of partial gradients
 constexpr int LDT = G32 + 8;  // bf16 pitch of the transposed tiles [k][sample]
-template <int NS, int NA, int ACT>
-__global__ __launch_bounds__(256) void dqn3_grad32_kernel(Dqn3Args g) {
+// OCC = workgroups per CU asked of the compiler: 1 (280 VGPRs, no spills: the latency-bound small batches) or 2 (256 VGPRs,
+// ~30 spilled: two workgroups interleave their phases, which wins from 65536 samples up)
+template <int NS, int NA, int ACT, int OCC>
+__global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     constexpr int na = NA;
     float* l_x = reinterpret_cast<float*>(smem3);                     // [4][G32]
@@ -1057,9 +1059,10 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     const int64_t np = mlp3_nparams(ns, h, na);
     // measured (gradient + reduce, us; 32-sample persistent / 128-row): batch 512: 14.2 / 24.0, 4096: 19.0 / 25.3,
     // 8192: 27.0 / 27.2, 16384: 39.7 / 32.1, 32768: 52.3 / 37.0, 65536: 76.2 / 69.3, 131072: 121.7 / 131.9 -- the
-    // 32-sample kernel (280 VGPRs persistent: one workgroup per CU) wins where latency or the partial-row volume decide
+    // 32-sample kernel (280 VGPRs persistent: one workgroup per CU) wins where latency or the partial-row volume decide;
+    // with two workgroups per CU (256 VGPRs, some spills) it is 66.2 us at 65536 and 106.4 us at 131072 (161 TFLOP/s)
     const bool small = !RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD128") &&
-                       (batch <= 8192 || batch >= 98304 || RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD32"));
+                       (batch <= 8192 || batch >= 65536 || RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD32"));
     const int64_t tiles32 = (batch + G32 - 1) / G32;
     const int nb = small ? (int)(tiles32 < D3_GRAD32_BLOCKS ? tiles32 : D3_GRAD32_BLOCKS) : (int)((batch + TR - 1) / TR);
     Dqn3Args g;
@@ -1093,10 +1096,17 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
 #define LAUNCH_G(NS_, NA_, ACT_)                                                                        \
     do {                                                                                                \
         if (small) {                                                                                    \
+            if (batch >= 65536) {                                                                       \
+                static bool done32b_ = false;                                                           \
+                int32_t rc_ = allow_lds(dqn3_grad32_kernel<NS_, NA_, ACT_, 2>, GRAD32_LDS, &done32b_);   \
+                if (rc_) return rc_;                                                                    \
+                hipLaunchKernelGGL((dqn3_grad32_kernel<NS_, NA_, ACT_, 2>), dim3(nb), dim3(256), GRAD32_LDS, s, g); \
+                break;                                                                                  \
+            }                                                                                           \
             static bool done32_ = false;                                                                \
-            int32_t rc_ = allow_lds(dqn3_grad32_kernel<NS_, NA_, ACT_>, GRAD32_LDS, &done32_);          \
+            int32_t rc_ = allow_lds(dqn3_grad32_kernel<NS_, NA_, ACT_, 1>, GRAD32_LDS, &done32_);       \
             if (rc_) return rc_;                                                                        \
-            hipLaunchKernelGGL((dqn3_grad32_kernel<NS_, NA_, ACT_>), dim3(nb), dim3(256), GRAD32_LDS, s, g); \
+            hipLaunchKernelGGL((dqn3_grad32_kernel<NS_, NA_, ACT_, 1>), dim3(nb), dim3(256), GRAD32_LDS, s, g); \
             break;                                                                                      \
         }                                                                                               \
         static bool done_ = false;                                                                      \
