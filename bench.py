@@ -341,7 +341,7 @@ def roofline_extras(torch, rlhip):
     gk()
     ms = event_time_ms(gk, 10, lib, s)
     tf = 4 * 2 * 128 * 128 * bm / (ms * 1e-3) / 1e12
-    out["dqn3_grad_mfma"] = {"bound": "mfma", "kernel": "dqn3_grad_kernel<4,2,relu> + d3_reduce_kernel", "batch": bm,
+    out["dqn3_grad_mfma"] = {"bound": "mfma", "kernel": "dqn3_grad32_kernel<4,2,relu,OCC=2> (32-sample tiles, persistent workgroups) + d3_reduce_kernel", "batch": bm,
                              "us_per_launch": round(ms * 1e3, 1), "achieved": round(tf, 1), "peak": 2500.0,
                              "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                              "note": "MFMA flops only; first layer, heads, loss and all bias/W1/W3 gradients run on the "
