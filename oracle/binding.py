@@ -207,6 +207,7 @@ def default_cfg(kind, continuous=None, **kw):
         c = AcrobotCfg()
         lib().rlo_acrobot_default(C.byref(c))
     for key, val in kw.items():
+        key = {"thetathreshold": "thetathreshold_deg"}.get(key, key)  # the reference's keyword (degrees, CartPoleEnv.jl:30)
         if not hasattr(c, key):
             raise TypeError(f"unknown env kwarg {key}")
         setattr(c, key, val)

@@ -35,3 +35,35 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---------------------------------------------------------------------------------- gradient parity bar
+# north_star: "within 1e-5 rel for fp32".  For a gradient vector the meaningful relative measure is against the
+# largest entry of the tensor (entries near zero are sums with cancellation): |g - o| <= tol * max|o|.
+# F32_GRAD_TOL is the bar of every f32 VALU path (fixed summation order on the GPU, double accumulation in the
+# oracle); the bf16 MFMA paths round operands to bf16 exactly like the oracle does and differ only by the MFMA's
+# internal summation order: BF16_GRAD_TOL.  Every check appends what it measured to gpurun_out/grad_err.jsonl
+# (scratch) so that the margins are known numbers, not guesses.
+F32_GRAD_TOL = 1e-5
+BF16_GRAD_TOL = 2e-3
+
+
+def assert_grad_close(g, o, tol, tag=""):
+    import json
+
+    import numpy as np
+
+    g = np.asarray(g, np.float64).reshape(-1)
+    o = np.asarray(o, np.float64).reshape(-1)
+    assert g.shape == o.shape, (g.shape, o.shape)
+    assert np.isfinite(g).all(), f"{tag}: non-finite gradient"
+    scale = max(float(np.abs(o).max()), 1e-30)
+    err = float(np.abs(g - o).max()) / scale
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "grad_err.jsonl"), "a") as f:
+            f.write(json.dumps({"tag": tag, "n": int(g.size), "err_over_max": err, "tol": tol}) + "\n")
+    except OSError:
+        pass
+    assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"

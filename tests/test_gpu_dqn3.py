@@ -13,6 +13,7 @@ import pytest
 import torch
 
 import oracle
+from conftest import BF16_GRAD_TOL, assert_grad_close  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -100,8 +101,7 @@ def _check_grad(g, ref, ns, na):
     o = 0
     for name, n in (("W1", H * ns), ("b1", H), ("W2", H * H), ("b2", H), ("W3", na * H), ("b3", na)):
         a, b = g[o:o + n], ref[o:o + n]
-        scale = max(np.abs(b).max(), 1e-12)
-        assert np.abs(a - b).max() <= 2e-3 * scale, (name, np.abs(a - b).max(), scale)
+        assert_grad_close(a, b, BF16_GRAD_TOL, f"dqn3 {name} ns={ns} na={na}")
         o += n
 
 

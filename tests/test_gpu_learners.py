@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import oracle  # noqa: E402
+from conftest import F32_GRAD_TOL, assert_grad_close  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -110,21 +111,29 @@ def test_rollout_vs_oracle(rl, kind, continuous):
     otr = oracle.PPOTraj(env.kind, n, T, na=1, continuous=continuous)
     oracle.ppo_rollout(oenv, T, ocfg, p, otr, 0)
     tr = pol.trajectory
+    # valid[t, i]: env i has taken the same actions as the oracle's env i in steps 0..t-1, so that its
+    # step-t inputs (observation, value, RNG counters) are the same on both sides.  A near-tie of the
+    # Gumbel-max sampler may flip an action (the logits differ in the last bits: different summation
+    # order); from there on that ONE env legitimately diverges, every other env is still compared.
     if not continuous:
-        same = host(tr.action_i) == otr.action_i
-        assert same.mean() > 0.999
-        if not same.all():
-            pytest.skip("a near-tie flipped one sampled action; trajectories legitimately diverge after it")
-        assert np.array_equal(host(tr.terminal), otr.terminal)
-        assert np.array_equal(host(tr.reward), otr.reward)
+        flipped = host(tr.action_i) != otr.action_i  # (T, n)
+        first_flip = np.where(flipped.any(0), flipped.argmax(0), T)  # per env
+        assert (first_flip < T).sum() <= 2, f"{(first_flip < T).sum()} of {n} envs saw a flipped action"
+        before = np.arange(T)[:, None] < first_flip[None, :]  # steps whose action agreed and all before it did
+        upto = np.arange(T + 1)[:, None] <= first_flip[None, :]  # inputs of those steps (+ the flip step itself)
+        assert np.array_equal(host(tr.terminal)[before], otr.terminal[before])
+        assert np.array_equal(host(tr.reward)[before], otr.reward[before])
         tol = dict(rtol=1e-5, atol=1e-6)
     else:
         tol = dict(rtol=2e-3, atol=2e-3)  # continuous actions differ in the last bits -> mild drift over T steps
         np.testing.assert_allclose(host(tr.action_f), otr.action_f, **tol)
         assert np.array_equal(host(tr.terminal), otr.terminal)
-    np.testing.assert_allclose(host(tr.obs), otr.obs, **tol)
-    np.testing.assert_allclose(host(tr.logp), otr.logp, rtol=1e-3, atol=1e-4 if continuous else 1e-5)
-    np.testing.assert_allclose(host(tr.value), otr.value, **tol)
+        before = np.ones((T, n), bool)
+        upto = np.ones((T + 1, n), bool)
+    om = np.broadcast_to(upto[:, None, :], otr.obs.shape)
+    np.testing.assert_allclose(host(tr.obs)[om], otr.obs[om], **tol)
+    np.testing.assert_allclose(host(tr.logp)[before], otr.logp[before], rtol=1e-3, atol=1e-4 if continuous else 1e-5)
+    np.testing.assert_allclose(host(tr.value)[upto], otr.value[upto], **tol)
     # GAE + returns on the GPU trajectory: bit-exact vs the oracle scan on the same inputs
     pol.gae_()
     o = oracle.generalized_advantage_estimation(host(tr.reward).T, host(tr.value).T, 0.99, 0.95,
@@ -163,9 +172,7 @@ def test_ppo_loss_and_gradient_vs_oracle(rl, kind, continuous, hidden, act):
         pol.grad_(epoch_ctr, mb)
         obs, a, lp, adv, ret, perm = _oracle_microbatch(pol, tr, epoch_ctr, mb)
         g, losses = oracle.ppo_loss_grad(ocfg, env.odim, pol.na, p2, obs, a, lp, adv, ret)
-        gg = host(pol.grad)
-        scale = np.abs(g).max()
-        np.testing.assert_allclose(gg, g, rtol=2e-3, atol=2e-5 * scale)
+        assert_grad_close(host(pol.grad), g, F32_GRAD_TOL, f"ppo_grad {kind} h={hidden} act={act} mb={mb}")
         np.testing.assert_allclose(host(pol.losses), losses, rtol=1e-4, atol=1e-6)
     # a permutation epoch covers every transition exactly once
     allidx = np.concatenate([_oracle_microbatch(pol, tr, 7, mb)[5] for mb in range(pol.cfg.n_microbatches)])
@@ -183,7 +190,7 @@ def test_ppo_ragged_microbatch(rl):
     pol.grad_(2, 2)
     obs, a, lp, adv, ret, _ = _oracle_microbatch(pol, tr, 2, 2)
     g, losses = oracle.ppo_loss_grad(ocfg, 4, 2, host(pol.params), obs, a, lp, adv, ret)
-    np.testing.assert_allclose(host(pol.grad), g, rtol=2e-3, atol=2e-5 * np.abs(g).max())
+    assert_grad_close(host(pol.grad), g, F32_GRAD_TOL, "ppo_grad ragged")
     np.testing.assert_allclose(host(pol.losses), losses, rtol=1e-4, atol=1e-6)
 
 
@@ -271,7 +278,7 @@ def test_dqn_gradient_vs_oracle(rl, h, batch):
     s, a, r, t, sn = ref.gather(idx)
     ol, og = oracle.dqn_loss_grad(ns, h, na, 0, p, pt, s, a, r, t, sn, 0.99, 1.0)
     assert float(loss) == pytest.approx(ol, rel=1e-4)
-    np.testing.assert_allclose(host(grad), og, rtol=2e-3, atol=2e-5 * np.abs(og).max())
+    assert_grad_close(host(grad), og, F32_GRAD_TOL, f"dqn_grad h={h} batch={batch}")
 
 
 @pytest.mark.parametrize("h", [128, 100])

@@ -147,6 +147,60 @@ def test_env_step_teacher_forced(rl, kind, continuous, T, n):
 
 
 @pytest.mark.parametrize("T", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [4096, 1001])
+def test_cartpole_reference_test_config_wide_theta(rl, T, n):
+    """The reference's OWN CartPole test configuration, `CartPoleEnv(; T = Float32, thetathreshold = 90.0)`
+    (RLEnvs/test/environments/examples/cart_pole.jl:7; Float64 is the constructor default, `:57`): with a 90 degree
+    threshold the pole swings through |theta| in (pi/4, pi/2] before the episode ends, so the kernel leaves its
+    small-argument sin/cos polynomial for the general branch (csrc/env_device.h `Trig<float>::sincos_`).
+    Teacher-forced against the oracle: (1) free fall from the reset states until |theta| > pi/2
+    terminates the episodes, (2) states injected over the whole range |theta| in (pi/4, pi) incl. the far side of the
+    threshold -- flags / counters bit-exact, states within 2e-6 rel (Float32) / 1e-12 (Float64)."""
+    npdt = np.float32 if T == torch.float32 else np.float64
+    kw = dict(thetathreshold=90.0)
+    env = rl.HipVecEnv("cartpole", n, T=T, seed=21, env_id_base=9, **kw)
+    ref = oracle.VecEnv("cartpole", n, seed=21, env_id_base=9, dtype=npdt, **kw)
+    assert env.cfg.thetathreshold_deg == 90.0
+    rng = np.random.default_rng(4)
+    rtol = 2e-6 if npdt == np.float32 else 1e-12
+    atol = 1e-7 if npdt == np.float32 else 1e-14
+    seen_wide = 0
+    seen_done_by_theta = 0
+
+    def forced_step(step):
+        nonlocal seen_wide, seen_done_by_theta
+        s_in = [host(env.raw_state()[k]) for k in range(4)]
+        ref.set_state(s_in, host(env._t))
+        ref.episode[:] = host(env._episode).view(np.uint32)
+        seen_wide += int((np.abs(s_in[2]) > math.pi / 4).sum())
+        a = rng.integers(0, 2, n).astype(np.int32)
+        env.act0_(dev(a))
+        ref.step(a)
+        assert np.array_equal(host(env._done), ref.done), f"done flags differ at step {step}"
+        assert np.array_equal(host(env._t), ref.t), f"t differs at step {step}"
+        assert np.array_equal(host(env._episode).view(np.uint32), ref.episode)
+        assert np.array_equal(host(env.reward()), ref.reward)
+        for k in range(4):
+            np.testing.assert_allclose(host(env.raw_state()[k]), ref.s[k], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(host(env.last_state()), ref.last_obs, rtol=rtol, atol=atol)
+        seen_done_by_theta += int((ref.done.astype(bool) & (np.abs(ref.last_obs[2]) > math.pi / 2)).sum())
+
+    # (1) free fall: random pushes, the pole tips over in ~60-100 steps
+    for step in range(140):
+        forced_step(step)
+    assert seen_wide > 10 * n, "the free-running phase never left the small-angle branch"
+    assert seen_done_by_theta > n // 2, "episodes did not end through the 90 degree threshold"
+    # (2) injected states: |theta| uniform in (pi/4, pi), both signs, fast poles and carts
+    seen_wide = 0
+    for step in range(20):
+        th = rng.uniform(math.pi / 4, math.pi, n) * rng.choice([-1.0, 1.0], n)
+        s = np.stack([rng.uniform(-2.3, 2.3, n), rng.uniform(-3, 3, n), th, rng.uniform(-6, 6, n)]).astype(npdt)
+        env.set_raw_state(s, t=rng.integers(0, 150, n))
+        forced_step(1000 + step)
+    assert seen_wide == 20 * n
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.float64])
 def test_acrobot_torque_noise_and_wrapper(rl, T):
     """AcrobotEnv: per-step torque noise from the shared Philox stream, reward = -1 after reset!,
     the RLBase spaces, the nips variant; teacher-forced against the oracle"""

@@ -78,6 +78,50 @@ def test_cartpole_float32_promotion_quirk():
     assert env.s[0][0] == f(s[0] + f(f(0.02) * s[1])) and env.s[2][0] == f(s[2] + f(f(0.02) * s[3]))
 
 
+def _cartpole_step_restated(s, a, dtype):
+    """CartPoleEnv.jl:118-140 over arrays, independent of oracle/rlo_envs_impl.h: numpy scalars carry Julia's
+    promotion rules (T op T -> T; T op Float64 -> Float64 through the `4 / 3` literal)."""
+    f = dtype
+    x, xd, th, thd = (v.astype(f) for v in s)
+    force = np.where(a == 1, f(10.0), f(-10.0)).astype(f)
+    c, si = np.cos(th.astype(np.float64)).astype(f), np.sin(th.astype(np.float64)).astype(f)
+    tmp = ((force + f(0.1 * 0.5) * thd ** 2 * si) / f(1.1)).astype(f)
+    num = (f(9.8) * si - c * tmp).astype(f)
+    frac = (f(0.1) * c ** 2 / f(1.1)).astype(f)
+    thacc = num.astype(np.float64) / (np.float64(f(0.5)) * (4 / 3 - frac.astype(np.float64)))
+    xacc = tmp.astype(np.float64) - np.float64(f(0.05)) * thacc * c.astype(np.float64) / np.float64(f(1.1))
+    dt = f(0.02)
+    return [(x + dt * xd).astype(f), (xd.astype(np.float64) + np.float64(dt) * xacc).astype(f), (th + dt * thd).astype(f),
+            (thd.astype(np.float64) + np.float64(dt) * thacc).astype(f)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cartpole_reference_test_config_wide_theta(dtype):
+    """`CartPoleEnv(; T = Float32, thetathreshold = 90.0)` -- the configuration the reference's own test runs
+    (RLEnvs/test/environments/examples/cart_pole.jl:7): states over |theta| in (pi/4, pi), threshold at pi/2."""
+    n = 4000
+    rng = np.random.default_rng(0)
+    env = oracle.VecEnv("cartpole", n, seed=3, dtype=dtype, auto_reset=False, thetathreshold=90.0)
+    th = rng.uniform(math.pi / 4, math.pi, n) * rng.choice([-1.0, 1.0], n)
+    s = [rng.uniform(-2.3, 2.3, n), rng.uniform(-3, 3, n), th, rng.uniform(-6, 6, n)]
+    s = [v.astype(dtype) for v in s]
+    a = rng.integers(0, 2, n).astype(np.int32)
+    env.set_state(s, np.zeros(n, np.int32))
+    env.step(a)
+    exp = _cartpole_step_restated(s, a, dtype)
+    # positions are one exact T operation each; velocities go through sinf / cosf (<= 1 ulp from numpy's rounding
+    # of the Float64 value)
+    assert np.array_equal(env.s[0], exp[0]) and np.array_equal(env.s[2], exp[2])
+    tol = dict(rtol=2e-6, atol=1e-6) if dtype == np.float32 else dict(rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(env.s[1], exp[1], **tol)
+    np.testing.assert_allclose(env.s[3], exp[3], **tol)
+    thr = dtype(90.0 * math.pi / 180) if dtype == np.float64 else np.float32(90.0 * math.pi / 180)
+    done = (np.abs(exp[0]) > dtype(2.4)) | (np.abs(exp[2]) > thr)
+    assert np.array_equal(env.done.astype(bool), done)
+    assert np.array_equal(env.reward, np.where(done, 0, 1).astype(dtype))
+    assert 0.2 < done.mean() < 0.9  # both sides of the 90 degree threshold are populated
+
+
 def test_pendulum_and_mountaincar_rules():
     p = oracle.VecEnv("pendulum", 1, seed=0, dtype=np.float64, auto_reset=False, continuous=True)
     th, thd, a = 0.5, -0.3, 5.0  # action beyond max_torque is clamped inside _step!
