@@ -496,10 +496,23 @@ def allreduce_report(torch, pol, world):
 
     out = {"world": world, "gradient_bytes": int(pol.np) * 4}
     g = torch.zeros(int(pol.np), dtype=torch.float32, device="cuda")
-    out["library_us_at_gradient_size"] = round(timed(lambda: dist.all_reduce(g), 50), 2)
-    p2p = getattr(pol, "_p2p", None)
-    if p2p is not None:
-        out["p2p_us_at_gradient_size"] = round(timed(lambda: p2p.all_reduce_(g), 50), 2)
+    out["library_us_at_gradient_size"] = round(timed(lambda: dist.all_reduce(g), 50), 2)  # torch.distributed, for reference
+    comm = getattr(pol, "_hipcomm", None)
+    if comm is not None:
+        d = comm.info()
+        out["p2p"] = {"active": bool(d.p2p_active), "why": d.why.decode(), "rccl_behind_abi": bool(d.rccl_active),
+                      "rccl_path": d.rccl_path.decode()}
+        if comm.ok:  # what the product's optimiser step pays: rlhip_allreduce_grads on the compute stream
+            out["abi_us_at_gradient_size"] = round(timed(lambda: comm.all_reduce_(g), 50), 2)
+            out["abi_transport_at_gradient_size"] = "p2p kernel" if d.p2p_active else "ncclAllReduce"
+        if d.p2p_active:
+            out["p2p_us_at_gradient_size"] = out["abi_us_at_gradient_size"]
+        if d.rccl_active:  # vectors beyond the exchange buffer take ncclAllReduce behind the same entry point
+            big = torch.zeros(max(int(d.cap) + 1, 1 << 20), dtype=torch.float32, device="cuda")
+            us = timed(lambda: comm.all_reduce_(big), 20)
+            out["abi_rccl"] = {"bytes": big.numel() * 4, "us": round(us, 2),
+                               "busbw_gbs": round(2.0 * (world - 1) / world * big.numel() * 4 / us / 1e3, 2)}
+            del big
     sweep = []
     for nbytes in (4 << 10, 64 << 10, 1 << 20, 16 << 20, 256 << 20):
         x = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
@@ -613,8 +626,7 @@ def main():
                    else "single GPU"},
         "launch_mode": mode,
         "gradient_allreduce": ("none (single GPU)" if world == 1 else
-                               ("p2p one-shot over IPC-mapped peer buffers (p2p.hip), validated against the torch.distributed all-reduce at start-up"
-                                if getattr(pol, "_p2p", None) is not None else "RCCL all-reduce (torch.distributed)")),
+                               (pol._hipcomm.transport() if getattr(pol, "_hipcomm", None) is not None else "not initialised")),
         "final_loss": float(pol.losses[0]),
         "mean_episode_len_last_rollout": round(
             (N_ENVS * T_ROLLOUT) / max(1.0, float(pol.trajectory.terminal.sum())), 2),
@@ -629,15 +641,16 @@ def main():
             result["allreduce"] = allreduce_report(torch, pol, world)
         except Exception as exc:  # noqa: BLE001
             result["allreduce"] = {"error": repr(exc)}
-    if getattr(pol, "_p2p", None) is not None:
-        result["p2p_timeouts"] = bool(pol._p2p.failed())  # must be false: a timed-out exchange leaves the step unreduced
+    if getattr(pol, "_hipcomm", None) is not None:
+        # must be false: a peer that never arrived poisons the step with NaN (csrc/comm.hip) -- also visible in final_loss
+        result["p2p_timeouts"] = bool(pol._hipcomm.failed())
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
 
-        if getattr(pol, "_p2p", None) is not None:
-            pol._p2p.close()
+        if getattr(pol, "_hipcomm", None) is not None:
+            pol._hipcomm.close()
         dist.destroy_process_group()
 
 

@@ -38,6 +38,8 @@ extern "C" {
 #define RLHIP_EINVAL (-1) /* bad argument (the reference would throw AssertionError / ArgumentError / MethodError) */
 #define RLHIP_EHIP (-2)   /* a HIP runtime call failed */
 #define RLHIP_ENODEV (-3) /* no gfx950 device visible */
+#define RLHIP_ETIMEOUT (-4) /* a peer never arrived at a gradient exchange; the result was overwritten with NaN */
+#define RLHIP_ECOMM (-5)    /* RCCL is missing or one of its calls failed / no transport for this exchange */
 
 #define RLHIP_ABI_VERSION 1
 
@@ -380,8 +382,9 @@ int32_t rlhip_env_act_push_f32(int32_t kind, const void* env_cfg, const rlhip_en
  * bytes, zero-initialised) which every peer maps through HIP IPC; rlhip_p2p_allreduce_f32 publishes the local vector,
  * waits for every rank's sequence flag and sums the buffers in rank order (bit-identical results on all ranks).
  * seq = 1, 2, 3, ... must advance by one per call on every rank.  A wait that exceeds timeout_polls sets
- * status_dev[0] = 1 and leaves `data` untouched.  The host mirror (rlhip.dist.P2PAllReduce) validates the path against
- * the library all-reduce before using it and falls back to RCCL otherwise. */
+ * status_dev[0] = 1 (device or host-pinned memory) and overwrites `data` with NaN: an unreduced gradient must not
+ * reach the optimiser silently.  These are the building blocks; hosts use rlhip_comm_* / rlhip_allreduce_grads below,
+ * which own the buffers, validate the path on every rank and fall back to RCCL otherwise. */
 int32_t rlhip_p2p_alloc(int64_t bytes, void** out);
 int32_t rlhip_p2p_free(void* p);
 int32_t rlhip_p2p_export(void* p, uint8_t handle_out[64]);
@@ -393,6 +396,46 @@ int64_t rlhip_p2p_comm_bytes(int64_t cap);
 int32_t rlhip_p2p_allreduce_f32(float* data, int64_t n, int64_t cap, int32_t rank, int32_t world,
                                 void* const* comm_bufs_host, uint32_t seq, int64_t timeout_polls,
                                 int32_t* status_dev, rlhip_stream_t stream);
+
+/* ------------------------------------ the sharded learner's collective behind the ABI -- */
+/* SURVEY.md 8b/8e.  Replaces nothing in the reference (it has no Distributed / MPI / NCCL code); it is the exchange a
+ * data-parallel `optimise!(::FluxApproximator, grad)` (RLCore/src/policies/learners/flux_approximator.jl:46) needs:
+ * the SUM of the flat gradient over the ranks BEFORE clip_by_global_norm! (RLCore/src/utils/basic.jl:19-29).
+ * The host moves two small blobs between its ranks with whatever byte transport it has (csrc/comm.hip header):
+ *   rank 0: rlhip_comm_unique_id -> broadcast 128 B;  all: rlhip_comm_init;  all: rlhip_comm_export -> all-gather
+ *   (64 B handle, device id);  all: rlhip_p2p_setup;  then rlhip_allreduce_grads per optimiser step.
+ * rlhip_comm_init is a collective when unique_id_host != NULL (ncclCommInitRank on the CURRENT device; RCCL is
+ * dlopen'ed here, not at library load).  unique_id_host = NULL creates a communicator without RCCL (the peer-to-peer
+ * path only; e.g. several ranks sharing one GPU, which RCCL refuses).  cap = floats of the largest vector that takes
+ * the peer-to-peer path.  rlhip_p2p_setup is a collective as well: it maps every peer's buffer, runs an exact
+ * self-test and agrees on the verdict across ranks -- *active_out is the same on every rank; when it is 0
+ * rlhip_comm_info().why says why and rlhip_allreduce_grads uses ncclAllReduce on the caller's stream.
+ * rlhip_allreduce_grads: in-place SUM, enqueued on `stream`, bit-identical on every rank on the peer-to-peer path
+ * (rank-order summation).  A peer that does not arrive within the timeout makes the call's result NaN and
+ * rlhip_comm_check return RLHIP_ETIMEOUT (it reads a host-pinned word: no synchronisation).
+ * rlhip_comm_destroy unmaps the peers and frees the own buffer: call it on every rank after a host-side barrier. */
+typedef void* rlhip_comm_t;
+typedef struct rlhip_comm_desc {
+    int32_t rank, world, device, p2p_active, rccl_active;
+    uint32_t seq;          /* last peer-to-peer sequence number used */
+    int64_t cap, timeout_polls;
+    int32_t* status;       /* host-pinned, device-visible: [0] != 0 after a timeout */
+    void* bufs[16];        /* every rank's exchange buffer as mapped in this process (rlhip_p2p_allreduce_f32 layout) */
+    char why[256];         /* why the peer-to-peer path is not active ("ok" when it is) */
+    char rccl_path[256];   /* the RCCL the process bound to ("" before the first use) */
+} rlhip_comm_desc;
+int32_t rlhip_comm_unique_id(uint8_t id_out_host[128]);
+int32_t rlhip_comm_init(int32_t rank, int32_t world, const uint8_t* unique_id_host, int64_t cap,
+                        rlhip_comm_t* comm_out);
+int32_t rlhip_comm_export(rlhip_comm_t comm, uint8_t handle_out_host[64], int32_t* device_out);
+int32_t rlhip_p2p_setup(rlhip_comm_t comm, const uint8_t* handles_host /* world x 64 B */,
+                        const int32_t* devices_host /* world */, int32_t* active_out);
+int32_t rlhip_allreduce_grads(rlhip_comm_t comm, float* grad, int64_t n, rlhip_stream_t stream);
+int32_t rlhip_comm_check(rlhip_comm_t comm);
+int32_t rlhip_comm_info(rlhip_comm_t comm, rlhip_comm_desc* out_host);
+int32_t rlhip_comm_set_timeout(rlhip_comm_t comm, int64_t timeout_polls);
+int32_t rlhip_comm_advance_seq(rlhip_comm_t comm, uint32_t n_steps);
+int32_t rlhip_comm_destroy(rlhip_comm_t comm);
 
 /* ------------------------------------------------- one DQN vec-step as a single call -- */
 /* One trip round the body of `_run` (RLCore/src/core/run.jl:52-70) for Agent{QBasedPolicy{DQN}} on the vector
@@ -633,6 +676,13 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, in
                                  float* grad_scratch, float* losses_out, int32_t rank, int32_t world,
                                  void* const* comm_bufs_host, int64_t comm_cap, uint32_t seq0,
                                  int64_t timeout_polls, int32_t* status_dev, rlhip_stream_t stream);
+/* The same with a communicator (rlhip_comm_init): the fused peer-to-peer kernels when rlhip_p2p_setup activated them,
+ * otherwise per optimiser step { gradient -> rlhip_allreduce_grads (ncclAllReduce on `stream`) -> rlhip_ppo_apply_f32 }.
+ * world = 1 communicators run rlhip_ppo_update_f32.  Sequence numbers are kept inside the communicator. */
+int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
+                                  const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
+                                  float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,
+                                  float* grad_scratch, float* losses_out, rlhip_comm_t comm, rlhip_stream_t stream);
 /* n_epochs x n_microbatches of { grad -> clip_by_global_norm! -> Adam } enqueued back to back
  * (single-GPU optimise!; multi-GPU hosts call rlhip_ppo_grad_f32, all-reduce, rlhip_clip_adam_f32).
  * update_ctr = number of previous update calls. */

@@ -17,7 +17,7 @@
 //   3. write the sum back to the local vector
 //   A slot is rewritten at seq + 2; by then every peer has finished reading seq (it had to publish seq + 1 first,
 //   and kernels of one rank run in stream order), so two slots suffice.  A poll gives up after `timeout_polls`
-//   iterations and raises status[0] (the host checks it in the self-test and at the end of a run).
+//   iterations, raises status[0] and overwrites the result with NaN (the host polls the status word: comm.hip).
 #include "common.h"
 
 #include <string.h>
@@ -60,8 +60,11 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(float* __restrict__
     }
     __syncthreads();
     if (l_fail) {
-        if (threadIdx.x == 0) status[0] = 1;
-        return;  // leave `data` untouched: the host falls back
+        // a peer never arrived: an unreduced gradient must not reach the optimiser silently -- poison the result (the
+        // next exchange spreads the NaNs to every replica) and raise the status word the host polls (comm.hip)
+        if (threadIdx.x == 0) __hip_atomic_store(status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) data[i] = __builtin_nanf("");
+        return;
     }
     __threadfence_system();  // acquire side for the whole workgroup
     // 3. sum in rank order (identical on every rank)

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
-            if (fail) xa.status[0] = 1;
+            if (fail) __hip_atomic_store(xa.status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         fail = __shfl(fail, 0, 64);
         __threadfence_system();
@@ -609,6 +609,10 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             for (int q = 0; q < xa.world; ++q) gx += __builtin_nontemporal_load(xa.slot[q] + (int64_t)par * xa.cap + p);
             gx *= xa.inv_world;
         }
+        // a peer never arrived: the step must not be taken on an unreduced gradient, and must not be skipped silently
+        // either (the replicas would diverge for good) -- NaN gradient -> NaN parameters on this rank, loud everywhere
+        // after the next exchange; the host sees the status word (rlhip_comm_check)
+        if (fail) gx = __builtin_nanf("");
         double sq = (double)gx * (double)gx;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
         const float gn = (float)sqrt(part);
         const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
-        if (own && !fail) {
+        if (own) {
             float g1 = gx;
             if (scale != 1.0f) g1 *= scale;
             const float mi = ap.b1 * m0 + (1.0f - ap.b1) * g1;  // Optimisers.Adam, expression order of optim.hip adam1
@@ -645,10 +649,8 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == gridDim.x - 1) {
-                if (!fail) {
-                    ap.beta_pow[0] *= ap.b1;
-                    ap.beta_pow[1] *= ap.b2;
-                }
+                ap.beta_pow[0] *= ap.b1;
+                ap.beta_pow[1] *= ap.b2;
                 __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ap.counter + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1081,6 +1083,47 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
                                          status_dev, stream);
             if (rc) return rc;
             rc = rlhip_ppo_apply_f32(kind, cfg, n, T, params, grad_scratch, m, v, beta_pow, 1.0f / (float)world, workspace,
+                                     nullptr, stream);
+            if (rc) return rc;
+        }
+    }
+    return RLHIP_OK;
+}
+
+/* optimise!(policy) of a sharded policy through a communicator (comm.hip): the fused peer-to-peer kernels when every
+ * rank validated that path, otherwise gradient -> rlhip_allreduce_grads (ncclAllReduce on this stream) -> apply */
+int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T,
+                                  const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow,
+                                  uint64_t seed, uint32_t update_ctr, void* workspace, float* grad_scratch,
+                                  float* losses_out, rlhip_comm_t comm, rlhip_stream_t stream) {
+    rlhip_comm_desc d;
+    int32_t rc = rlhip_comm_info(comm, &d);
+    if (rc) return rc;
+    RLHIP_REQUIRE(cfg != nullptr, "cfg is NULL");
+    if (d.world == 1)
+        return rlhip_ppo_update_f32(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace, grad_scratch,
+                                    losses_out, stream);
+    const int64_t np = rlhip_ppo_nparams(kind, cfg);
+    RLHIP_REQUIRE(np > 0, "bad configuration");
+    const uint32_t n_steps = (uint32_t)cfg->n_epochs * (uint32_t)cfg->n_microbatches;
+    if (d.p2p_active && np <= d.cap) {
+        rc = rlhip_ppo_update_p2p_f32(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace,
+                                      grad_scratch, losses_out, d.rank, d.world, d.bufs, d.cap, d.seq, d.timeout_polls,
+                                      d.status, stream);
+        if (rc) return rc;
+        return rlhip_comm_advance_seq(comm, n_steps);
+    }
+    bool first = true;
+    for (int32_t e = 0; e < cfg->n_epochs; ++e) {
+        const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
+        for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
+            rc = grad_entry(kind, cfg, n, T, traj, params, seed, epoch_ctr, nullptr, mb, workspace, grad_scratch, losses_out,
+                            stream, /*do_pack=*/first);
+            if (rc) return rc;
+            first = false;
+            rc = rlhip_allreduce_grads(comm, grad_scratch, np, stream);
+            if (rc) return rc;
+            rc = rlhip_ppo_apply_f32(kind, cfg, n, T, params, grad_scratch, m, v, beta_pow, 1.0f / (float)d.world, workspace,
                                      nullptr, stream);
             if (rc) return rc;
         }

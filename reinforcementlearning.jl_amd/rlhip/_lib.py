@@ -17,6 +17,10 @@ class RLHipError(RuntimeError):
     pass
 
 
+class RLHipTimeoutError(RLHipError, TimeoutError):
+    """RLHIP_ETIMEOUT -- a rank never arrived at a gradient exchange (csrc/comm.hip)."""
+
+
 class RLHipArgumentError(RLHipError, ValueError):
     """RLHIP_EINVAL -- where the reference would throw AssertionError / ArgumentError / MethodError."""
 
@@ -97,6 +101,13 @@ class PPOTraj(C.Structure):
                                   "action_i", "terminal")]
 
 
+class CommDesc(C.Structure):
+    """rlhip_comm_desc (include/rlhip.h)"""
+    _fields_ = [(n, i32) for n in ("rank", "world", "device", "p2p_active", "rccl_active")] + \
+               [("seq", u32), ("cap", i64), ("timeout_polls", i64), ("status", vp), ("bufs", vp * 16),
+                ("why", C.c_char * 256), ("rccl_path", C.c_char * 256)]
+
+
 P = C.POINTER
 
 # name -> (restype, argtypes).  Status-returning functions use restype i32 and are error-checked.
@@ -173,6 +184,18 @@ _PROTOS = {
     "rlhip_p2p_probe": (i32, [vp, i64, vp]),
     "rlhip_p2p_comm_bytes": (i64, [i64]),
     "rlhip_p2p_allreduce_f32": (i32, [vp, i64, i64, i32, i32, vp, u32, i64, vp, vp]),
+    "rlhip_comm_unique_id": (i32, [vp]),
+    "rlhip_comm_init": (i32, [i32, i32, vp, i64, P(vp)]),
+    "rlhip_comm_export": (i32, [vp, vp, P(i32)]),
+    "rlhip_p2p_setup": (i32, [vp, vp, vp, P(i32)]),
+    "rlhip_allreduce_grads": (i32, [vp, vp, i64, vp]),
+    "rlhip_comm_check": (i32, [vp]),
+    "rlhip_comm_info": (i32, [vp, P(CommDesc)]),
+    "rlhip_comm_set_timeout": (i32, [vp, i64]),
+    "rlhip_comm_advance_seq": (i32, [vp, u32]),
+    "rlhip_comm_destroy": (i32, [vp]),
+    "rlhip_ppo_update_comm_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp, vp, vp, vp,
+                                        vp]),
     "rlhip_dqn_act_supported": (i32, [i32, i64, i64]),
     "rlhip_dqn_act_f32": (i32, [i32, vp, vp, i64, vp, i64, i64, i32, f64, u64, u32, u64, u32, P(Ring), vp, vp, vp, vp,
                                 vp]),
@@ -256,6 +279,8 @@ def call(name, *args):
         msg = f"{name} failed with status {rc}: {last_error()}"
         if rc == -1:
             raise RLHipArgumentError(msg)
+        if rc == -4:
+            raise RLHipTimeoutError(msg)
         raise RLHipError(msg)
     return rc
 

@@ -74,138 +74,155 @@ def params_checksum_equal(params, group=None):
     return bool((lo == hi).all())
 
 
-class P2PAllReduce:
-    """One-shot peer-to-peer sum all-reduce of a small flat f32 vector inside one kernel on the compute stream
-    (p2p.hip): every rank publishes its vector in an IPC-mapped uncached buffer and sums the world's buffers in rank
-    order.  `create()` returns None -- and the caller keeps using the library all-reduce -- unless every rank maps
-    every peer AND a self-test against torch.distributed's all-reduce passes on all ranks."""
+class HipComm:
+    """The sharded learner's collective, owned by librlhip.so (csrc/comm.hip, `rlhip_comm_*`): the one-shot
+    peer-to-peer kernel over IPC-mapped buffers once every rank validated it, RCCL's ncclAllReduce on the compute
+    stream otherwise -- both behind `rlhip_allreduce_grads`.  torch.distributed is ONLY the byte transport of the
+    set-up (a 128-byte RCCL id from rank 0, one 64-byte IPC handle + device id per rank) -- what a Julia host would
+    do with any transport it has.
 
-    TIMEOUT_POLLS = 1 << 24       # steady state: tens of seconds of polling before a rank gives up (status flag)
-    SELFTEST_TIMEOUT_POLLS = 1 << 20  # self-test: a path that does not work must fail within a few seconds
+    use_rccl: None = yes when the group's backend is nccl and RLHIP_COMM_NO_RCCL is unset (RCCL refuses two ranks on
+    one device: the one-GPU multi-process tests run the peer-to-peer path alone, over a gloo group).
+    RLHIP_NO_P2P=1 skips the peer-to-peer set-up (RCCL only); RLHIP_REQUIRE_P2P=1 makes a failed validation fatal."""
 
     def __init__(self):
-        self.ok = False
-
-    @staticmethod
-    def _agree(flag, group, device):
-        import torch.distributed as dist
-
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        return bool(int(t.item()))
+        self.h = None
 
     @classmethod
-    def create(cls, group, cap, device):
+    def create(cls, group, cap, device, use_rccl=None):
         import ctypes as C
+        import sys
 
         import torch.distributed as dist
 
-        from ._lib import call, lib
+        from . import _lib
+        from ._lib import call
 
         self = cls()
         self.group, self.cap, self.device = group, int(cap), device
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.seq = 0
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self._own, self._imported = C.c_void_p(), []
-        handle = None
-        try:
-            call("rlhip_p2p_alloc", int(lib.rlhip_p2p_comm_bytes(self.cap)), C.byref(self._own))
-            h = (C.c_uint8 * 64)()
-            call("rlhip_p2p_export", self._own, h)
-            handle = bytes(h)
-        except Exception:  # noqa: BLE001 -- any failure means "use the library collective"
-            handle = None
+        if use_rccl is None:
+            use_rccl = dist.get_backend(group) == "nccl" and os.environ.get("RLHIP_COMM_NO_RCCL", "0") != "1"
+        uid = [None]
+        if use_rccl:
+            if self.rank == 0:
+                b = (C.c_uint8 * 128)()
+                call("rlhip_comm_unique_id", b)
+                uid = [bytes(b)]
+            dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = C.c_void_p()
+        call("rlhip_comm_init", self.rank, self.world, (C.c_uint8 * 128).from_buffer_copy(uid[0]) if uid[0] else None,
+             self.cap, C.byref(h))
+        self.h = h
+        hb, dev_id = (C.c_uint8 * 64)(), _lib.i32(0)
+        call("rlhip_comm_export", h, hb, C.byref(dev_id))
         gathered = [None] * self.world
-        my_dev = torch.cuda.current_device()
-        dist.all_gather_object(gathered, (handle, my_dev), group=group)
-        good = all(g is not None and g[0] is not None for g in gathered)
-        self.peers = (C.c_void_p * self.world)()
-        if good:
-            try:
-                # no kernel touches a peer buffer before (1) the runtime says the devices can address each other and
-                # (2) a host-driven 4-byte copy from the mapped flags succeeded and read the zero they were set to
-                good = all(int(lib.rlhip_p2p_can_access(int(g[1]))) == 1 for g in gathered)
-                flags_off = 2 * self.cap * 4
-                for p in range(self.world):
-                    if not good:
-                        break
-                    if p == self.rank:
-                        self.peers[p] = self._own
-                    else:
-                        q = C.c_void_p()
-                        call("rlhip_p2p_import", (C.c_uint8 * 64).from_buffer_copy(gathered[p][0]), C.byref(q))
-                        self._imported.append(q)
-                        self.peers[p] = q
-                        val = C.c_uint32(0xFFFFFFFF)
-                        call("rlhip_p2p_probe", q, flags_off, C.byref(val))
-                        good = good and val.value == 0
-            except Exception:  # noqa: BLE001
-                good = False
-        if not cls._agree(good, group, device):
-            return None
-        # self-test against the library all-reduce: same sums (up to summation order), bit-identical across ranks.
-        # Every rank issues the SAME sequence of library collectives whatever happens locally (no early exit, local
-        # failures only clear `passed`): a rank that bailed out alone would leave the others inside a collective.
-        passed = True
-        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
-        for _ in range(3):
-            x = torch.randn(min(self.cap, 4099), generator=g).to(device)
-            ref = x.clone()
-            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=group)
-            y = x.clone()
-            try:
-                self.all_reduce_(y, timeout_polls=cls.SELFTEST_TIMEOUT_POLLS)
-                torch.cuda.synchronize()
-                if int(self.status.item()) != 0 or not torch.allclose(y, ref, rtol=1e-5, atol=1e-5):
-                    passed = False
-            except Exception:  # noqa: BLE001
-                passed = False
-            lo, hi = y.clone(), y.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-            if not torch.equal(lo, hi):
-                passed = False
-        if not cls._agree(passed, group, device):
-            return None
-        self.ok = True
+        dist.all_gather_object(gathered, (bytes(hb), int(dev_id.value)), group=group)
+        if os.environ.get("RLHIP_NO_P2P", "0") != "1" and self.world > 1:
+            handles = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(g[0] for g in gathered))
+            devices = (_lib.i32 * self.world)(*[g[1] for g in gathered])
+            active = _lib.i32(0)
+            call("rlhip_p2p_setup", h, handles, devices, C.byref(active))
+        d = self.info()
+        if self.world > 1 and not d.p2p_active:
+            msg = (f"[rlhip] rank {self.rank}: peer-to-peer gradient exchange NOT active: {d.why.decode()} -> "
+                   f"{'RCCL ncclAllReduce' if d.rccl_active else 'torch.distributed all_reduce'} per optimiser step")
+            if os.environ.get("RLHIP_REQUIRE_P2P", "0") == "1":
+                raise RuntimeError(msg)
+            if self.rank == 0:
+                print(msg, file=sys.stderr, flush=True)
         return self
 
-    def all_reduce_(self, t, timeout_polls=None):
-        """in-place SUM over the ranks; t: contiguous f32 device tensor with numel <= cap"""
+    def info(self):
+        import ctypes as C
+
+        from . import _lib
+        from ._lib import call
+
+        d = _lib.CommDesc()
+        call("rlhip_comm_info", self.h, C.byref(d))
+        return d
+
+    @property
+    def p2p_active(self):
+        return bool(self.info().p2p_active)
+
+    @property
+    def rccl_active(self):
+        return bool(self.info().rccl_active)
+
+    @property
+    def ok(self):
+        """a transport behind rlhip_allreduce_grads exists"""
+        d = self.info()
+        return self.world == 1 or bool(d.p2p_active or d.rccl_active)
+
+    def transport(self):
+        d = self.info()
+        if self.world == 1:
+            return "none (single rank)"
+        if d.p2p_active:
+            return "p2p one-shot kernel over IPC-mapped peer buffers (csrc/p2p.hip), validated on every rank at start-up" + \
+                   ("; RCCL communicator behind the same ABI as fallback" if d.rccl_active else "")
+        if d.rccl_active:
+            return f"RCCL ncclAllReduce on the compute stream via rlhip_allreduce_grads (p2p not active: {d.why.decode()})"
+        return f"torch.distributed all_reduce (no transport behind the ABI: {d.why.decode()})"
+
+    def set_timeout(self, polls):
+        from ._lib import call
+
+        call("rlhip_comm_set_timeout", self.h, int(polls))
+
+    def all_reduce_(self, t):
+        """in-place SUM over the ranks on the current stream; t: contiguous f32 device tensor"""
         from ._lib import call
         from .ops import ptr, stream_ptr
 
-        self.seq += 1
-        call("rlhip_p2p_allreduce_f32", ptr(t), t.numel(), self.cap, self.rank, self.world, self.peers, self.seq,
-             timeout_polls or self.TIMEOUT_POLLS, ptr(self.status), stream_ptr())
+        call("rlhip_allreduce_grads", self.h, ptr(t), t.numel(), stream_ptr())
         return t
 
+    def check(self):
+        """raises RLHipTimeoutError if a peer never arrived at an exchange (reads a host-pinned word: no sync)"""
+        from ._lib import call
+
+        call("rlhip_comm_check", self.h)
+
+    def failed(self):
+        """True if any exchange since the start timed out (synchronises first)."""
+        from ._lib import RLHipTimeoutError
+
+        torch.cuda.synchronize()
+        try:
+            self.check()
+        except RLHipTimeoutError:
+            return True
+        return False
+
     def close(self):
-        """unmap the peers, then (after every rank has unmapped) free the own buffer; collective"""
+        """collective: every rank unmaps its peers and frees its own buffer after a barrier"""
         import torch.distributed as dist
 
         from ._lib import call
 
+        if self.h is None:
+            return
         torch.cuda.synchronize()
-        for q in self._imported:
-            try:
-                call("rlhip_p2p_close", q)
-            except Exception:  # noqa: BLE001
-                pass
-        self._imported = []
         try:
             dist.barrier(group=self.group)
         except Exception:  # noqa: BLE001
             pass
-        if self._own:
-            try:
-                call("rlhip_p2p_free", self._own)
-            except Exception:  # noqa: BLE001
-                pass
-            self._own = None
-        self.ok = False
+        call("rlhip_comm_destroy", self.h)
+        self.h = None
 
-    def failed(self):
-        """True if any all-reduce since the last check timed out (synchronises)."""
-        return int(self.status.item()) != 0
+
+class P2PAllReduce:
+    """Round-1 name of the validated peer-to-peer exchange: `create()` returns a HipComm whose peer-to-peer path is
+    active, or None (then the caller uses the library all-reduce)."""
+
+    @classmethod
+    def create(cls, group, cap, device):
+        comm = HipComm.create(group, cap, device)
+        if comm.p2p_active:
+            return comm
+        comm.close()
+        return None

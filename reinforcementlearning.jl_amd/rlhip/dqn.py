@@ -281,15 +281,13 @@ class DQNLearner:
 
             world = dist.get_world_size(self.process_group)
             if world > 1:
-                if not hasattr(self, "_p2p"):  # validated one-shot peer exchange (p2p.hip) or None -> library
-                    import os
+                if not hasattr(self, "_hipcomm"):  # rlhip_comm_* (csrc/comm.hip): p2p kernel or RCCL behind one call
+                    from .dist import HipComm
 
-                    from .dist import P2PAllReduce
-
-                    self._p2p = None if os.environ.get("RLHIP_NO_P2P", "0") == "1" else \
-                        P2PAllReduce.create(self.process_group, self.grad.numel(), self.grad.device)
-                if self._p2p is not None:
-                    self._p2p.all_reduce_(self.grad)
+                    self._hipcomm = HipComm.create(self.process_group, self.grad.numel(), self.grad.device)
+                if self._hipcomm.ok:
+                    self._hipcomm.all_reduce_(self.grad)
+                    self._hipcomm.check()
                 else:
                     dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                 scale = 1.0 / world

@@ -201,15 +201,16 @@ class PPOPolicy:
         else:
             import torch.distributed as dist
 
-            p2p = self._p2p_allreduce(world)
-            if p2p is not None and self.layers == 2 and os.environ.get("RLHIP_P2P_HOST_LOOP", "0") != "1":
-                # the whole sharded update as one C call: grad -> p2p exchange -> apply per optimiser step
-                n_steps = self.cfg.n_epochs * self.cfg.n_microbatches
-                call("rlhip_ppo_update_p2p_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
+            comm = self._comm(world)
+            if comm.ok and os.environ.get("RLHIP_P2P_HOST_LOOP", "0") != "1":
+                # the whole sharded update as ONE C call (csrc/ppo_grad.hip rlhip_ppo_update_comm_f32): per optimiser
+                # step gradient -> exchange -> clip + Adam; the exchange is the fused peer-to-peer kernel when every
+                # rank validated it, ncclAllReduce on this stream otherwise -- no torch.distributed in the data path
+                call("rlhip_ppo_update_comm_f32", self.kind, C.byref(self.cfg), self.trajectory.n, self.T,
                      C.byref(self.trajectory.c), ptr(self.params), ptr(self.m), ptr(self.v), ptr(self.beta_pow),
-                     self.seed, self.update_ctr, ptr(self.workspace), ptr(self.grad), ptr(self.losses), p2p.rank,
-                     p2p.world, p2p.peers, p2p.cap, p2p.seq, p2p.TIMEOUT_POLLS, ptr(p2p.status), stream_ptr())
-                p2p.seq += n_steps
+                     self.seed, self.update_ctr, ptr(self.workspace), ptr(self.grad), ptr(self.losses), comm.h,
+                     stream_ptr())
+                comm.check()  # a peer that never arrived at an earlier exchange: RLHipTimeoutError (host-pinned word, no sync)
                 self.update_ctr += 1
                 return
             for e in range(self.cfg.n_epochs):
@@ -218,26 +219,28 @@ class PPOPolicy:
                     self.grad_(epoch_ctr, mb, records_fresh=(e > 0 or mb > 0))
                     # gradient all-reduce BEFORE the global-norm clip, so the clip sees the global
                     # gradient (mean over shards == single-GPU semantics with a world-times larger batch)
-                    if p2p is not None:
-                        p2p.all_reduce_(self.grad)  # one kernel on this stream (p2p.hip), sums in rank order
-                    else:
+                    if comm.ok:
+                        comm.all_reduce_(self.grad)  # rlhip_allreduce_grads on this stream
+                    else:  # no transport behind the ABI (e.g. a gloo group whose peer-to-peer validation failed)
                         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                     self.apply_(grad_scale=1.0 / world)
+            comm.check()
         self.update_ctr += 1
 
-    def _p2p_allreduce(self, world):
-        """The validated one-shot peer-to-peer all-reduce for this policy's gradient, or None (library all-reduce):
-        created on first use; RLHIP_NO_P2P=1 disables it; any failure to map the peers or to pass the self-test
-        against torch.distributed's all-reduce on ANY rank makes every rank fall back."""
-        if world <= 1 or self.process_group is None:
-            return None
-        if not hasattr(self, "_p2p"):
-            self._p2p = None
-            if os.environ.get("RLHIP_NO_P2P", "0") != "1":
-                from .dist import P2PAllReduce
+    def _comm(self, world):
+        """The communicator of this policy's gradient exchange (rlhip.dist.HipComm over csrc/comm.hip), created on
+        first use -- a collective: every rank reaches its first update_ together."""
+        if not hasattr(self, "_hipcomm"):
+            from .dist import HipComm
 
-                self._p2p = P2PAllReduce.create(self.process_group, self.np, self.params.device)
-        return self._p2p
+            self._hipcomm = HipComm.create(self.process_group, self.np, self.params.device)
+        return self._hipcomm
+
+    @property
+    def _p2p(self):
+        """the communicator if its peer-to-peer path is active, else None (round-1 attribute, bench.py / tests)"""
+        c = getattr(self, "_hipcomm", None)
+        return c if (c is not None and c.p2p_active) else None
 
     # ----------------------------------------------------------------- HIP-graph protocol
     def sync_counters_(self):

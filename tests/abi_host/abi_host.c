@@ -1,0 +1,508 @@
+/*
+ * abi_host.c -- a host with NO PyTorch and NO Python driving librlhip.so through include/rlhip.h only.
+ *
+ * This is the call sequence the Julia glue (reinforcementlearning.jl_amd/julia/RLHip.jl) makes with `ccall`:
+ * device memory from rlhip_malloc, a stream from rlhip_stream_create, host <-> device copies with
+ * rlhip_memcpy_*, and then the hot path of the reference's run loop (RLCore/src/core/run.jl:36-78):
+ *
+ *   part A  Agent{QBasedPolicy{DQN}} on a 192-instance CartPoleEnv: reset! -> push!(state)  (agent_base.jl:45-47)
+ *           -> 45 x { plan! -> act! -> push!(transition) -> optimise! (+ target sync) } as ONE call per vec-step
+ *           (rlhip_dqn_vec_step_f32; ring capacity 16 so the ring wraps; updates start after 5 vec-steps)
+ *   part B  PPOPolicy on a 256-instance CartPoleEnv: fused T = 8 rollout (+ GAE), then optimise! =
+ *           4 epochs x 4 micro-batches of { gradient -> clip_by_global_norm! -> Adam }   (rlhip_ppo_update_f32)
+ *   part C  the same PPO update through a world = 1 communicator (rlhip_comm_init / rlhip_ppo_update_comm_f32 /
+ *           rlhip_allreduce_grads / rlhip_comm_check / rlhip_comm_destroy): the collective entry points of
+ *           SURVEY.md 8b, callable without torch.distributed
+ *
+ * Everything the run produced is written to <out> as tagged Float32 / Int32 / UInt8 arrays; tests/test_gpu_abi_host.py
+ * compares them with the CPU oracle and, bit for bit, with the PyTorch-hosted mirror of the same sequence.
+ * Test infrastructure (it ships no product code); built by __graft_entry__.build() with plain gcc.
+ */
+#define _DEFAULT_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rlhip.h"
+
+#define CK(call)                                                                            \
+    do {                                                                                    \
+        int32_t rc_ = (call);                                                               \
+        if (rc_ != RLHIP_OK) {                                                              \
+            fprintf(stderr, "%s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #call, (int)rc_, rlhip_last_error()); \
+            exit(2);                                                                        \
+        }                                                                                   \
+    } while (0)
+
+static rlhip_stream_t g_stream;
+static FILE* g_out;
+
+static void* dmalloc(size_t bytes) { /* zero-initialised device memory */
+    void* p = NULL;
+    CK(rlhip_malloc(&p, bytes));
+    CK(rlhip_memset(p, 0, bytes, g_stream));
+    return p;
+}
+
+/* record: 16-byte name | u32 element size | u32 pad | u64 count | payload */
+static void dump(const char* name, const void* dev, size_t elem, size_t count) {
+    void* h = malloc(elem * count + 1);
+    CK(rlhip_memcpy_d2h(h, dev, elem * count, g_stream));
+    char tag[16];
+    memset(tag, 0, sizeof(tag));
+    strncpy(tag, name, 15);
+    uint32_t es = (uint32_t)elem, pad = 0;
+    uint64_t cnt = (uint64_t)count;
+    fwrite(tag, 1, 16, g_out);
+    fwrite(&es, 4, 1, g_out);
+    fwrite(&pad, 4, 1, g_out);
+    fwrite(&cnt, 8, 1, g_out);
+    fwrite(h, elem, count, g_out);
+    free(h);
+}
+
+static void dump_host(const char* name, const void* host, size_t elem, size_t count) {
+    char tag[16];
+    memset(tag, 0, sizeof(tag));
+    strncpy(tag, name, 15);
+    uint32_t es = (uint32_t)elem, pad = 0;
+    uint64_t cnt = (uint64_t)count;
+    fwrite(tag, 1, 16, g_out);
+    fwrite(&es, 4, 1, g_out);
+    fwrite(&pad, 4, 1, g_out);
+    fwrite(&cnt, 8, 1, g_out);
+    fwrite(host, elem, count, g_out);
+}
+
+typedef struct {
+    rlhip_env_state st;
+    float *obs, *last_obs;
+    int64_t n;
+} vec_env;
+
+static vec_env make_cartpole(int64_t n, const rlhip_cartpole_cfg* cfg, uint64_t seed, uint32_t id_base) {
+    vec_env e;
+    memset(&e, 0, sizeof(e));
+    e.n = n;
+    for (int k = 0; k < 4; ++k) e.st.s[k] = dmalloc(sizeof(float) * (size_t)n);
+    e.st.t = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)n);
+    e.st.done = (uint8_t*)dmalloc((size_t)n);
+    e.st.reward = dmalloc(sizeof(float) * (size_t)n);
+    e.st.episode = (uint32_t*)dmalloc(sizeof(uint32_t) * (size_t)n);
+    e.obs = (float*)dmalloc(sizeof(float) * 4 * (size_t)n);
+    e.last_obs = (float*)dmalloc(sizeof(float) * 4 * (size_t)n);
+    /* the constructor calls reset! once (CartPoleEnv.jl:77) */
+    CK(rlhip_env_reset(RLHIP_ENV_CARTPOLE, 0, cfg, &e.st, n, seed, id_base, NULL, g_stream));
+    CK(rlhip_env_obs(RLHIP_ENV_CARTPOLE, 0, &e.st, n, e.obs, g_stream));
+    return e;
+}
+
+static void free_env(vec_env* e) {
+    for (int k = 0; k < 4; ++k) CK(rlhip_free(e->st.s[k]));
+    CK(rlhip_free(e->st.t));
+    CK(rlhip_free(e->st.done));
+    CK(rlhip_free(e->st.reward));
+    CK(rlhip_free(e->st.episode));
+    CK(rlhip_free(e->obs));
+    CK(rlhip_free(e->last_obs));
+}
+
+/* ------------------------------------------------------------------------------------------------ part A */
+static void run_dqn(void) {
+    const int64_t n = 192, h = 128, na = 2, ns = 4, capacity = 16, batch = 256;
+    const uint64_t seed = 4;
+    const int steps = 45, sync_freq = 7;
+    const int64_t min_replay_history = 5 * n;
+    rlhip_cartpole_cfg cfg;
+    CK(rlhip_cartpole_default(&cfg));
+    vec_env env = make_cartpole(n, &cfg, seed, 0);
+
+    const int64_t np = rlhip_mlp2_nparams(ns, h, na);
+    float* params = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* target = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* m = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* v = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* grad = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* beta_pow = (float*)dmalloc(8);
+    float* loss = (float*)dmalloc(4);
+    float* gn = (float*)dmalloc(4);
+    int32_t* actions = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)n);
+    float* q = (float*)dmalloc(sizeof(float) * (size_t)(na * n));
+    CK(rlhip_mlp2_init_f32(params, ns, h, na, seed, 0, g_stream));
+    CK(rlhip_memcpy_d2d(target, params, sizeof(float) * (size_t)np, g_stream)); /* TargetNetwork: deepcopy */
+    const float b0[2] = {0.9f, 0.999f}; /* running beta powers of Adam start at beta^1 */
+    CK(rlhip_memcpy_h2d(beta_pow, b0, 8, g_stream));
+    void* workspace = dmalloc((size_t)rlhip_dqn_workspace_bytes(ns, h, na, batch)); /* zeroed: ABI contract */
+
+    rlhip_ring ring;
+    void* r_state = dmalloc(sizeof(float) * (size_t)((capacity + 1) * ns * n));
+    int32_t* r_action = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(capacity * n));
+    float* r_reward = (float*)dmalloc(sizeof(float) * (size_t)(capacity * n));
+    uint8_t* r_term = (uint8_t*)dmalloc((size_t)(capacity * n));
+    CK(rlhip_ring_init(&ring, capacity, n, ns, 4, r_state, r_action, r_reward, r_term));
+    /* push!(agent, PreEpisodeStage(), env): the first state (agent_base.jl:45-47) */
+    CK(rlhip_ring_push_state(&ring, env.obs, g_stream));
+
+    rlhip_dqn_step_args a;
+    memset(&a, 0, sizeof(a));
+    a.kind = RLHIP_ENV_CARTPOLE;
+    a.env_cfg = &cfg;
+    a.st = &env.st;
+    a.n = n;
+    a.env_seed = seed;
+    a.env_id_base = 0;
+    a.obs = env.obs;
+    a.last_obs = env.last_obs;
+    a.ring = &ring;
+    a.layers = 2;
+    a.h = h;
+    a.na = na;
+    a.act = 0;
+    a.params = params;
+    a.target = target;
+    a.m = m;
+    a.v = v;
+    a.beta_pow = beta_pow;
+    a.lr = 1e-3f;
+    a.beta1 = 0.9f;
+    a.beta2 = 0.999f;
+    a.adam_eps = 1e-8f;
+    a.max_grad_norm = 1.0f;
+    a.grad_scale = 1.0f;
+    a.explorer_seed = seed;
+    a.batch = batch;
+    a.gamma = 0.99f;
+    a.huber_delta = 1.0f;
+    a.sampler_seed = seed;
+    a.rho = 0.0f;
+    a.workspace = workspace;
+    a.grad = grad;
+    a.loss = loss;
+    a.gn = gn;
+    a.actions = actions;
+    a.q = q;
+    /* EpsilonGreedyExplorer(0.05; kind = :exp, decay_steps = 20), step starts at 1 (epsilon_greedy_explorer.jl:38-67) */
+    uint32_t explorer_step = 1, draw_ctr = 0;
+    int n_optimise = 0, n_updates = 0;
+    for (int it = 0; it < steps; ++it) {
+        a.eps = rlhip_get_eps(1, 0.05, 1.0, 0, 20, (int64_t)explorer_step);
+        a.explorer_step = explorer_step++;
+        int64_t frames = rlhip_ring_length(&ring) + 1;
+        if (frames > capacity) frames = capacity;
+        a.do_update = frames * n >= min_replay_history;
+        a.draw_ctr = draw_ctr;
+        a.do_sync = a.do_update && ((n_optimise + 1) % sync_freq == 0);
+        CK(rlhip_dqn_vec_step_f32(&a, g_stream));
+        if (a.do_update) {
+            ++draw_ctr;
+            ++n_updates;
+            n_optimise = a.do_sync ? 0 : n_optimise + 1;
+        }
+    }
+    CK(rlhip_stream_sync(g_stream));
+    int32_t counters[8] = {n_updates, (int32_t)draw_ctr, (int32_t)explorer_step, n_optimise, (int32_t)ring.head_sa,
+                           (int32_t)ring.len_sa, (int32_t)ring.head_rt, (int32_t)ring.len_rt};
+    dump_host("dqn.counters", counters, 4, 8);
+    dump("dqn.params", params, 4, (size_t)np);
+    dump("dqn.target", target, 4, (size_t)np);
+    dump("dqn.m", m, 4, (size_t)np);
+    dump("dqn.v", v, 4, (size_t)np);
+    dump("dqn.loss", loss, 4, 1);
+    dump("dqn.ring.state", r_state, 4, (size_t)((capacity + 1) * ns * n));
+    dump("dqn.ring.action", r_action, 4, (size_t)(capacity * n));
+    dump("dqn.ring.reward", r_reward, 4, (size_t)(capacity * n));
+    dump("dqn.ring.term", r_term, 1, (size_t)(capacity * n));
+    for (int k = 0; k < 4; ++k) {
+        char nm[16];
+        snprintf(nm, sizeof(nm), "dqn.env.s%d", k);
+        dump(nm, env.st.s[k], 4, (size_t)n);
+    }
+    dump("dqn.env.t", env.st.t, 4, (size_t)n);
+    dump("dqn.env.obs", env.obs, 4, (size_t)(4 * n));
+    void* frees[] = {params, target, m, v, grad, beta_pow, loss, gn, actions, q, workspace, r_state, r_action, r_reward, r_term};
+    for (size_t i = 0; i < sizeof(frees) / sizeof(frees[0]); ++i) CK(rlhip_free(frees[i]));
+    free_env(&env);
+}
+
+/* ------------------------------------------------------------------------------------------------ part B/C */
+static void run_ppo(int through_comm) {
+    const int64_t n = 256, T = 8, ns = 4;
+    const uint64_t seed = 77;
+    rlhip_cartpole_cfg ecfg;
+    CK(rlhip_cartpole_default(&ecfg));
+    vec_env env = make_cartpole(n, &ecfg, seed, 0);
+    rlhip_ppo_cfg cfg;
+    CK(rlhip_ppo_default(&cfg));
+    const int64_t np = rlhip_ppo_nparams(RLHIP_ENV_CARTPOLE, &cfg);
+    const int64_t np_actor = rlhip_mlp2_nparams(ns, cfg.hidden, 2);
+    float* params = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* m = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* v = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* grad = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* beta_pow = (float*)dmalloc(8);
+    float* losses = (float*)dmalloc(16);
+    CK(rlhip_mlp2_init_f32(params, ns, cfg.hidden, 2, seed, 0, g_stream));            /* actor  (net_id 0) */
+    CK(rlhip_mlp2_init_f32(params + np_actor, ns, cfg.hidden, 1, seed, 1, g_stream)); /* critic (net_id 1) */
+    const float b0[2] = {cfg.beta1, cfg.beta2};
+    CK(rlhip_memcpy_h2d(beta_pow, b0, 8, g_stream));
+    rlhip_ppo_traj tr;
+    tr.obs = (float*)dmalloc(sizeof(float) * (size_t)((T + 1) * ns * n));
+    tr.logp = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.value = (float*)dmalloc(sizeof(float) * (size_t)((T + 1) * n));
+    tr.reward = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.adv = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.ret = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.action_f = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.action_i = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(T * n));
+    tr.terminal = (uint8_t*)dmalloc((size_t)(T * n));
+    void* workspace = dmalloc((size_t)rlhip_ppo_workspace_bytes(RLHIP_ENV_CARTPOLE, &cfg, n, T));
+
+    float* p0 = (float*)malloc(sizeof(float) * (size_t)np);
+    CK(rlhip_memcpy_d2h(p0, params, sizeof(float) * (size_t)np, g_stream));
+    CK(rlhip_ppo_rollout_f32(RLHIP_ENV_CARTPOLE, &ecfg, &env.st, n, T, &cfg, params, seed, 0, 0, &tr, g_stream));
+    if (!through_comm) {
+        CK(rlhip_ppo_update_f32(RLHIP_ENV_CARTPOLE, &cfg, n, T, &tr, params, m, v, beta_pow, seed, 0, workspace, grad,
+                                losses, g_stream));
+    } else {
+        /* world = 1 communicator: no RCCL id needed, rlhip_allreduce_grads is the identity, the update is the same */
+        rlhip_comm_t comm = NULL;
+        CK(rlhip_comm_init(0, 1, NULL, np, &comm));
+        uint8_t handle[64];
+        int32_t device = -1, active = -1;
+        CK(rlhip_comm_export(comm, handle, &device));
+        CK(rlhip_p2p_setup(comm, handle, &device, &active));
+        CK(rlhip_ppo_update_comm_f32(RLHIP_ENV_CARTPOLE, &cfg, n, T, &tr, params, m, v, beta_pow, seed, 0, workspace,
+                                     grad, losses, comm, g_stream));
+        CK(rlhip_allreduce_grads(comm, grad, np, g_stream));
+        CK(rlhip_comm_check(comm));
+        rlhip_comm_desc d;
+        CK(rlhip_comm_info(comm, &d));
+        if (d.world != 1 || d.rank != 0 || d.p2p_active != 0 || device < 0) {
+            fprintf(stderr, "unexpected communicator description\n");
+            exit(3);
+        }
+        CK(rlhip_stream_sync(g_stream));
+        CK(rlhip_comm_destroy(comm));
+    }
+    CK(rlhip_stream_sync(g_stream));
+    const char* pre = through_comm ? "ppoc" : "ppo";
+    char nm[16];
+#define NM(s) (snprintf(nm, sizeof(nm), "%s.%s", pre, s), nm)
+    dump_host(NM("params0"), p0, 4, (size_t)np);
+    dump(NM("params"), params, 4, (size_t)np);
+    dump(NM("m"), m, 4, (size_t)np);
+    dump(NM("v"), v, 4, (size_t)np);
+    dump(NM("losses"), losses, 4, 4);
+    dump(NM("obs"), tr.obs, 4, (size_t)((T + 1) * ns * n));
+    dump(NM("value"), tr.value, 4, (size_t)((T + 1) * n));
+    dump(NM("logp"), tr.logp, 4, (size_t)(T * n));
+    dump(NM("reward"), tr.reward, 4, (size_t)(T * n));
+    dump(NM("adv"), tr.adv, 4, (size_t)(T * n));
+    dump(NM("ret"), tr.ret, 4, (size_t)(T * n));
+    dump(NM("action"), tr.action_i, 4, (size_t)(T * n));
+    dump(NM("terminal"), tr.terminal, 1, (size_t)(T * n));
+#undef NM
+    free(p0);
+    void* frees[] = {params, m, v, grad, beta_pow, losses, tr.obs, tr.logp, tr.value, tr.reward, tr.adv, tr.ret, tr.action_f,
+                     tr.action_i, tr.terminal, workspace};
+    for (size_t i = 0; i < sizeof(frees) / sizeof(frees[0]); ++i) CK(rlhip_free(frees[i]));
+    free_env(&env);
+}
+
+/* ------------------------------------------------------------------------------------------------ part D */
+/* One rank of a sharded PPO learner whose only "network" is a directory: the byte transport of the communicator
+ * set-up is the file system (any transport will do: INTEGRATION.md).  `abi_host comm <rank> <world> <dir> [rccl]`.
+ * Without `rccl` the communicator has no RCCL side (several ranks share the test box's one GPU, which RCCL refuses):
+ * the exchange is the peer-to-peer kernel or nothing.  With `rccl` rank 0 publishes rlhip_comm_unique_id. */
+#include <unistd.h>
+
+static void put_file(const char* dir, const char* stem, int rank, const void* data, size_t bytes) {
+    char tmp[512], fin[512];
+    snprintf(tmp, sizeof(tmp), "%s/.%s.%d.tmp", dir, stem, rank);
+    snprintf(fin, sizeof(fin), "%s/%s.%d", dir, stem, rank);
+    FILE* f = fopen(tmp, "wb");
+    if (!f || fwrite(data, 1, bytes, f) != bytes) {
+        fprintf(stderr, "cannot write %s\n", tmp);
+        exit(4);
+    }
+    fclose(f);
+    if (rename(tmp, fin) != 0) exit(4);
+}
+
+static void get_file(const char* dir, const char* stem, int rank, void* data, size_t bytes) {
+    char fin[512];
+    snprintf(fin, sizeof(fin), "%s/%s.%d", dir, stem, rank);
+    for (int tries = 0; tries < 60000; ++tries) { /* <= 60 s */
+        FILE* f = fopen(fin, "rb");
+        if (f) {
+            size_t got = fread(data, 1, bytes, f);
+            fclose(f);
+            if (got == bytes) return;
+        }
+        usleep(1000);
+    }
+    fprintf(stderr, "timed out waiting for %s\n", fin);
+    exit(5);
+}
+
+static void file_barrier(const char* dir, const char* stem, int rank, int world) {
+    char one = 1, got;
+    put_file(dir, stem, rank, &one, 1);
+    for (int r = 0; r < world; ++r) get_file(dir, stem, r, &got, 1);
+}
+
+static int run_comm_rank(int rank, int world, const char* dir, int use_rccl) {
+    const int64_t n = 256, T = 8, ns = 4;
+    const uint64_t seed = 77;
+    rlhip_cartpole_cfg ecfg;
+    CK(rlhip_cartpole_default(&ecfg));
+    /* shard `rank` owns the global env ids [rank * n, (rank + 1) * n): disjoint Philox streams */
+    vec_env env = make_cartpole(n, &ecfg, seed, (uint32_t)(rank * n));
+    rlhip_ppo_cfg cfg;
+    CK(rlhip_ppo_default(&cfg));
+    const int64_t np = rlhip_ppo_nparams(RLHIP_ENV_CARTPOLE, &cfg);
+    const int64_t np_actor = rlhip_mlp2_nparams(ns, cfg.hidden, 2);
+    /* ---- communicator set-up: 128-byte id from rank 0 (optional), then one 64-byte handle + device id per rank */
+    uint8_t uid[128];
+    if (use_rccl) {
+        if (rank == 0) {
+            CK(rlhip_comm_unique_id(uid));
+            put_file(dir, "uid", 0, uid, 128);
+        }
+        get_file(dir, "uid", 0, uid, 128);
+    }
+    rlhip_comm_t comm = NULL;
+    CK(rlhip_comm_init(rank, world, use_rccl ? uid : NULL, np, &comm));
+    uint8_t mine[68];
+    int32_t device = -1;
+    CK(rlhip_comm_export(comm, mine, &device));
+    memcpy(mine + 64, &device, 4);
+    put_file(dir, "handle", rank, mine, 68);
+    uint8_t* handles = (uint8_t*)malloc(64 * (size_t)world);
+    int32_t* devices = (int32_t*)malloc(4 * (size_t)world);
+    for (int r = 0; r < world; ++r) {
+        uint8_t rec[68];
+        get_file(dir, "handle", r, rec, 68);
+        memcpy(handles + 64 * r, rec, 64);
+        memcpy(devices + r, rec + 64, 4);
+    }
+    int32_t active = 0;
+    CK(rlhip_p2p_setup(comm, handles, devices, &active));
+    rlhip_comm_desc d;
+    CK(rlhip_comm_info(comm, &d));
+    if (!active && !d.rccl_active) {
+        fprintf(stderr, "rank %d: no transport: %s\n", rank, d.why);
+        return 7;
+    }
+    /* ---- 20 exact sums: x_r[i] = (r + 1) * (i % 97) -> sum_r = world (world + 1) / 2 * (i % 97) */
+    const int64_t nv = 3331;
+    float* x = (float*)dmalloc(sizeof(float) * (size_t)nv);
+    float* hx = (float*)malloc(sizeof(float) * (size_t)nv);
+    for (int it = 0; it < 20; ++it) {
+        for (int64_t i = 0; i < nv; ++i) hx[i] = (float)((rank + 1) * ((i + it) % 97));
+        CK(rlhip_memcpy_h2d(x, hx, sizeof(float) * (size_t)nv, g_stream));
+        CK(rlhip_allreduce_grads(comm, x, nv, g_stream));
+        CK(rlhip_memcpy_d2h(hx, x, sizeof(float) * (size_t)nv, g_stream));
+        for (int64_t i = 0; i < nv; ++i)
+            if (hx[i] != (float)(world * (world + 1) / 2 * ((i + it) % 97))) {
+                fprintf(stderr, "rank %d: wrong sum at %lld (round %d): %g\n", rank, (long long)i, it, hx[i]);
+                return 8;
+            }
+    }
+    CK(rlhip_comm_check(comm));
+    /* ---- one sharded PPO iteration: every rank rolls out its own shard, the update exchanges gradients */
+    float* params = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* m = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* v = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* grad = (float*)dmalloc(sizeof(float) * (size_t)np);
+    float* beta_pow = (float*)dmalloc(8);
+    float* losses = (float*)dmalloc(16);
+    CK(rlhip_mlp2_init_f32(params, ns, cfg.hidden, 2, seed, 0, g_stream));
+    CK(rlhip_mlp2_init_f32(params + np_actor, ns, cfg.hidden, 1, seed, 1, g_stream));
+    const float b0[2] = {cfg.beta1, cfg.beta2};
+    CK(rlhip_memcpy_h2d(beta_pow, b0, 8, g_stream));
+    rlhip_ppo_traj tr;
+    tr.obs = (float*)dmalloc(sizeof(float) * (size_t)((T + 1) * ns * n));
+    tr.logp = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.value = (float*)dmalloc(sizeof(float) * (size_t)((T + 1) * n));
+    tr.reward = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.adv = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.ret = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.action_f = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
+    tr.action_i = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(T * n));
+    tr.terminal = (uint8_t*)dmalloc((size_t)(T * n));
+    void* workspace = dmalloc((size_t)rlhip_ppo_workspace_bytes(RLHIP_ENV_CARTPOLE, &cfg, n, T));
+    for (uint32_t it = 0; it < 2; ++it) {
+        CK(rlhip_ppo_rollout_f32(RLHIP_ENV_CARTPOLE, &ecfg, &env.st, n, T, &cfg, params, seed, (uint32_t)(rank * n),
+                                 it * (uint32_t)T, &tr, g_stream));
+        CK(rlhip_ppo_update_comm_f32(RLHIP_ENV_CARTPOLE, &cfg, n, T, &tr, params, m, v, beta_pow, seed, it, workspace, grad,
+                                     losses, comm, g_stream));
+    }
+    CK(rlhip_stream_sync(g_stream));
+    CK(rlhip_comm_check(comm));
+    char path[512];
+    snprintf(path, sizeof(path), "%s/out.%d.bin", dir, rank);
+    g_out = fopen(path, "wb");
+    if (!g_out) return 67;
+    int32_t info[4] = {active, d.rccl_active, (int32_t)d.seq, device};
+    dump_host("comm.info", info, 4, 4);
+    dump("comm.params", params, 4, (size_t)np);
+    dump("comm.obs", tr.obs, 4, (size_t)((T + 1) * ns * n));
+    fclose(g_out);
+    /* every rank must have stopped using its peers' buffers before anyone frees its own */
+    file_barrier(dir, "done", rank, world);
+    CK(rlhip_comm_destroy(comm));
+    printf("rank %d of %d: p2p %s, rccl %s, 20 exact sums + 2 sharded PPO iterations through the C ABI only\n", rank, world,
+           active ? "active" : "off", d.rccl_active ? "yes" : "no");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 5 && strcmp(argv[1], "comm") == 0) {
+        int rank = atoi(argv[2]), world = atoi(argv[3]);
+        CK(rlhip_set_device(getenv("ABI_HOST_DEVICE") ? atoi(getenv("ABI_HOST_DEVICE")) : 0));
+        CK(rlhip_stream_create(&g_stream));
+        int rc = run_comm_rank(rank, world, argv[4], argc >= 6 && strcmp(argv[5], "rccl") == 0);
+        return rc;
+    }
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s <out.bin> | comm <rank> <world> <dir> [rccl]\n", argv[0]);
+        return 64;
+    }
+    if (rlhip_abi_version() != RLHIP_ABI_VERSION) {
+        fprintf(stderr, "ABI version mismatch\n");
+        return 65;
+    }
+    int32_t ndev = 0;
+    CK(rlhip_device_count(&ndev));
+    if (ndev < 1) {
+        fprintf(stderr, "no device\n");
+        return 66;
+    }
+    CK(rlhip_set_device(0));
+    char arch[64];
+    CK(rlhip_device_name(0, arch, sizeof(arch)));
+    CK(rlhip_stream_create(&g_stream));
+    g_out = fopen(argv[1], "wb");
+    if (!g_out) return 67;
+    /* timing through the ABI's own events (what RLHip.jl uses for TimePerStep) */
+    rlhip_event_t e0, e1;
+    CK(rlhip_event_create(&e0));
+    CK(rlhip_event_create(&e1));
+    CK(rlhip_event_record(e0, g_stream));
+    run_dqn();
+    run_ppo(0);
+    run_ppo(1);
+    CK(rlhip_event_record(e1, g_stream));
+    float ms = 0.0f;
+    CK(rlhip_event_elapsed_ms(e0, e1, &ms));
+    fclose(g_out);
+    CK(rlhip_event_destroy(e0));
+    CK(rlhip_event_destroy(e1));
+    CK(rlhip_stream_destroy(g_stream));
+    printf("abi_host ok on %s: DQN 45 vec-steps + 2 PPO updates, %.2f ms between the ABI's events, no PyTorch in this process\n",
+           arch, ms);
+    return 0;
+}

@@ -44,8 +44,11 @@ def pytest_collection_modifyitems(config, items):
 # oracle); the bf16 MFMA paths round operands to bf16 exactly like the oracle does and differ only by the MFMA's
 # internal summation order: BF16_GRAD_TOL.  Every check appends what it measured to gpurun_out/grad_err.jsonl
 # (scratch) so that the margins are known numbers, not guesses.
-F32_GRAD_TOL = 1e-5
-BF16_GRAD_TOL = 2e-3
+# Measured on MI355X (gpurun_out/grad_err.jsonl, round 2): f32 paths <= 9.4e-8, bf16 MFMA paths <= 1.9e-4 (median 1e-7;
+# the tail is a bf16 rounding flip next to a tanh ulp difference between ocml and glibc).  The bars below keep a 10x /
+# 2.5x margin over what was measured -- a regression by an order of magnitude fails.
+F32_GRAD_TOL = 1e-6
+BF16_GRAD_TOL = 5e-4
 
 
 def assert_grad_close(g, o, tol, tag=""):

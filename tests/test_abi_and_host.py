@@ -42,9 +42,9 @@ def test_struct_layouts_match_header():
     #include <stdio.h>
     #include "rlhip.h"
     int main(void) {
-        printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(rlhip_cartpole_cfg), sizeof(rlhip_pendulum_cfg),
+        printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rlhip_cartpole_cfg), sizeof(rlhip_pendulum_cfg),
                sizeof(rlhip_mountaincar_cfg), sizeof(rlhip_env_state), sizeof(rlhip_ring), sizeof(rlhip_ppo_cfg),
-               sizeof(rlhip_ppo_traj));
+               sizeof(rlhip_ppo_traj), sizeof(rlhip_comm_desc), sizeof(rlhip_dqn_step_args));
         return 0;
     }'''
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
@@ -55,8 +55,33 @@ def test_struct_layouts_match_header():
         out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
     sizes = [int(x) for x in out]
     mirrors = [_lib.CartPoleCfg, _lib.PendulumCfg, _lib.MountainCarCfg, _lib.EnvState, _lib.Ring, _lib.PPOCfg,
-               _lib.PPOTraj]
+               _lib.PPOTraj, _lib.CommDesc, _lib.DqnStepArgs]
     assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_communicator_entry_points_validate_before_touching_a_device():
+    """SURVEY 8b export list: rlhip_comm_init / rlhip_allreduce_grads exist and reject bad arguments with RLHIP_EINVAL
+    (no GPU here: nothing may be launched); the plain-C host that drives them without PyTorch compiles against the
+    header with -Wall (tests/abi_host/abi_host.c; it RUNS in tests/test_gpu_abi_host.py)."""
+    import subprocess
+    import tempfile
+
+    h = C.c_void_p()
+    for rank, world in ((2, 2), (-1, 4), (0, 0), (0, 17)):
+        with pytest.raises(_lib.RLHipArgumentError):
+            _lib.call("rlhip_comm_init", rank, world, None, 100, C.byref(h))
+    with pytest.raises(_lib.RLHipArgumentError):
+        _lib.call("rlhip_comm_init", 0, 2, None, 0, C.byref(h))  # cap
+    for fn, args in (("rlhip_allreduce_grads", (None, None, 4, None)), ("rlhip_comm_check", (None,)),
+                     ("rlhip_comm_destroy", (None,)), ("rlhip_comm_unique_id", (None,))):
+        with pytest.raises(_lib.RLHipArgumentError):
+            _lib.call(fn, *args)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                            os.path.join(root, "tests", "abi_host", "abi_host.c"), "-o", os.path.join(d, "a.o")],
+                           capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 def test_default_configs_match_reference_defaults():

@@ -1,0 +1,216 @@
+"""The C ABI driven by a host that has neither PyTorch nor Python in its process: tests/abi_host/abi_host.c (plain C99,
+built with gcc against include/rlhip.h + librlhip.so) allocates with rlhip_malloc, creates its stream with
+rlhip_stream_create, copies with rlhip_memcpy_* and runs env -> ring push -> rlhip_dqn_vec_step_f32 and
+rlhip_ppo_rollout_f32 -> rlhip_ppo_update[_comm]_f32 -- the `ccall` sequence of julia/RLHip.jl.
+
+What it wrote is compared (1) with the CPU oracle (PPO rollout, GAE) and (2) bit for bit with the PyTorch-hosted
+mirror of the same sequence (which the other GPU tests pin against the oracle piece by piece): the allocator, the
+stream and the host language do not matter to the results."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import oracle  # noqa: E402  (the checker)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "tests", "abi_host")
+HOST_BIN = os.path.join(HOST_DIR, "abi_host.bin")
+
+
+def _build_host():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    return ge.build_abi_host()
+
+
+def _read_dump(path):
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    o = 0
+    while o < len(data):
+        name = data[o:o + 16].split(b"\0")[0].decode()
+        es, _, cnt = struct.unpack_from("<IIQ", data, o + 16)
+        o += 32
+        dt = {4: np.uint32, 1: np.uint8}[es]
+        out[name] = np.frombuffer(data, dtype=dt, count=cnt, offset=o).copy()
+        o += es * cnt
+    return out
+
+
+def f32(a):
+    return a.view(np.float32)
+
+
+@pytest.fixture(scope="module")
+def dump(tmp_path_factory):
+    if not os.path.exists(HOST_BIN) or os.path.getmtime(HOST_BIN) < os.path.getmtime(os.path.join(HOST_DIR, "abi_host.c")):
+        _build_host()
+    out = str(tmp_path_factory.mktemp("abi") / "abi_host_out.bin")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([HOST_BIN, out], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, f"abi_host failed ({r.returncode}):\n{r.stdout}\n{r.stderr}"
+    assert "no PyTorch in this process" in r.stdout
+    # the process really had no torch / python mapped: its only non-system dependency is librlhip.so (+ the HIP runtime)
+    ldd = subprocess.run(["ldd", HOST_BIN], capture_output=True, text=True).stdout
+    assert "librlhip.so" in ldd and "torch" not in ldd and "python" not in ldd
+    return _read_dump(out)
+
+
+def test_c_host_dqn_run_is_bit_identical_to_the_torch_hosted_mirror(dump):
+    import rlhip
+
+    n = 192
+    env = rlhip.HipVecEnv("cartpole", n, seed=4)
+    net = rlhip.HipApproximator(4, 128, 2, seed=4, layers=2)
+    tn = rlhip.TargetNetwork(net, sync_freq=7)
+    learner = rlhip.DQNLearner(tn, batchsize=256, min_replay_history=5 * n, seed=4, max_grad_norm=1.0)
+    policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.05, kind="exp", decay_steps=20, seed=4))
+    traces = rlhip.CircularArraySARTSTraces(capacity=16, n_env=n, obs_dim=4)
+    agent = rlhip.Agent(policy, rlhip.Trajectory(traces))
+    rlhip.run_fused_dqn(agent, env, rlhip.StopAfterNSteps(45))
+    torch.cuda.synchronize()
+    c = dump["dqn.counters"].view(np.int32)
+    assert c[0] == learner.n_updates > 30 and c[1] == learner.draw_ctr and c[2] == policy.explorer.step
+    assert c[3] == tn.n_optimise
+    assert tuple(c[4:8]) == (traces.rb.head_sa, traces.rb.len_sa, traces.rb.head_rt, traces.rb.len_rt)
+    for name, t in (("dqn.params", net.params), ("dqn.target", tn.target), ("dqn.m", net.m), ("dqn.v", net.v),
+                    ("dqn.loss", learner.loss), ("dqn.ring.state", traces.state), ("dqn.ring.reward", traces.reward),
+                    ("dqn.env.obs", env.state())):
+        assert np.array_equal(dump[name], t.cpu().numpy().reshape(-1).view(np.uint32)), name
+    assert np.array_equal(dump["dqn.ring.action"].view(np.int32), traces.action.cpu().numpy().reshape(-1))
+    assert np.array_equal(dump["dqn.ring.term"], traces.terminal.cpu().numpy().reshape(-1))
+    for k in range(4):
+        assert np.array_equal(f32(dump[f"dqn.env.s{k}"]), env.raw_state()[k].cpu().numpy())
+    assert np.array_equal(dump["dqn.env.t"].view(np.int32), env._t.cpu().numpy())
+    assert not np.array_equal(dump["dqn.params"], dump["dqn.target"])  # updates happened after the last sync
+
+
+@pytest.mark.parametrize("pre", ["ppo", "ppoc"])
+def test_c_host_ppo_iteration_vs_oracle_and_torch_hosted_mirror(dump, pre):
+    """pre = "ppoc": the same update through a world = 1 communicator (rlhip_comm_* entry points)"""
+    import rlhip
+
+    n, T = 256, 8
+    p0 = f32(dump[f"{pre}.params0"])
+    # (1) the CPU oracle: identical initial parameters (Philox INIT stream), rollout, GAE
+    pa = oracle.mlp2_init(4, 256, 2, 77, 0)
+    pc = oracle.mlp2_init(4, 256, 1, 77, 1)
+    assert np.array_equal(p0, np.concatenate([pa, pc]))
+    oenv = oracle.VecEnv("cartpole", n, seed=77)
+    ocfg = oracle.ppo_default()
+    otr = oracle.PPOTraj(0, n, T)
+    oracle.ppo_rollout(oenv, T, ocfg, p0, otr, 0)
+    act = dump[f"{pre}.action"].view(np.int32).reshape(T, n)
+    flipped = act != otr.action_i
+    first_flip = np.where(flipped.any(0), flipped.argmax(0), T)
+    assert (first_flip < T).sum() <= 1
+    before = np.arange(T)[:, None] < first_flip[None, :]
+    upto = np.arange(T + 1)[:, None] <= first_flip[None, :]
+    obs = f32(dump[f"{pre}.obs"]).reshape(T + 1, 4, n)
+    om = np.broadcast_to(upto[:, None, :], obs.shape)
+    np.testing.assert_allclose(obs[om], otr.obs[om], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f32(dump[f"{pre}.value"]).reshape(T + 1, n)[upto], otr.value[upto], rtol=1e-5, atol=1e-6)
+    term = dump[f"{pre}.terminal"].reshape(T, n)
+    rew = f32(dump[f"{pre}.reward"]).reshape(T, n)
+    assert np.array_equal(term[before], otr.terminal[before]) and np.array_equal(rew[before], otr.reward[before])
+    val = f32(dump[f"{pre}.value"]).reshape(T + 1, n)
+    o = oracle.generalized_advantage_estimation(rew.T, val.T, 0.99, 0.95, terminal=term.T, dims=2, dtype=np.float32)
+    assert np.array_equal(f32(dump[f"{pre}.adv"]).reshape(T, n), o.T)
+    assert np.array_equal(f32(dump[f"{pre}.ret"]).reshape(T, n), (o.T + val[:T]).astype(np.float32))
+    # (2) the PyTorch-hosted mirror: every bit
+    env = rlhip.CartPoleEnv(n, seed=77)
+    pol = rlhip.PPOPolicy(env, update_freq=T, seed=77)
+    pol.rollout_()
+    pol.update_()
+    torch.cuda.synchronize()
+    for name, t in (("params", pol.params), ("m", pol.m), ("v", pol.v), ("losses", pol.losses),
+                    ("obs", pol.trajectory.obs), ("logp", pol.trajectory.logp), ("adv", pol.trajectory.adv)):
+        assert np.array_equal(dump[f"{pre}.{name}"], t.cpu().numpy().reshape(-1).view(np.uint32)), name
+    assert not np.array_equal(dump[f"{pre}.params"], dump[f"{pre}.params0"])
+    assert np.isfinite(f32(dump[f"{pre}.params"])).all()
+
+
+def test_communicator_entry_points_single_process(dump):
+    """rlhip_comm_* through ctypes: world = 1 is the identity; a forced timeout (rank 0 of a 2-rank exchange whose
+    peer never publishes) NaN-poisons the result and rlhip_comm_check / the status word report it"""
+    import ctypes as C
+
+    from rlhip import _lib
+    from rlhip._lib import call
+
+    h = C.c_void_p()
+    call("rlhip_comm_init", 0, 1, None, 1000, C.byref(h))
+    x = torch.arange(1000, dtype=torch.float32, device="cuda")
+    call("rlhip_allreduce_grads", h, C.c_void_p(x.data_ptr()), 1000, None)
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32))
+    call("rlhip_comm_check", h)
+    d = _lib.CommDesc()
+    call("rlhip_comm_info", h, C.byref(d))
+    assert (d.rank, d.world, d.p2p_active, d.rccl_active) == (0, 1, 0, 0) and b"world = 1" in d.why
+    call("rlhip_comm_destroy", h)
+    with pytest.raises(_lib.RLHipArgumentError):
+        call("rlhip_comm_check", None)
+    with pytest.raises(_lib.RLHipArgumentError):
+        call("rlhip_comm_init", 3, 2, None, 10, C.byref(h))
+    # forced timeout on the raw exchange kernel: two comm buffers in this process, "rank 1" never publishes
+    cap = 512
+    bufs = (C.c_void_p * 2)()
+    for r in range(2):
+        q = C.c_void_p()
+        call("rlhip_p2p_alloc", int(_lib.lib.rlhip_p2p_comm_bytes(cap)), C.byref(q))
+        bufs[r] = q
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    g = torch.ones(cap, dtype=torch.float32, device="cuda")
+    call("rlhip_p2p_allreduce_f32", C.c_void_p(g.data_ptr()), cap, cap, 0, 2, bufs, 1, 2000, C.c_void_p(status.data_ptr()),
+         None)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 1 and bool(torch.isnan(g).all()), "a timed-out exchange must poison its result"
+    for r in range(2):
+        call("rlhip_p2p_free", bufs[r])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_learner_driven_by_c_processes_only(tmp_path, world):
+    """`world` plain-C processes (no PyTorch, no torch.distributed, no Python) sharing this box's GPU: the communicator
+    is set up through FILES (rlhip_comm_init / rlhip_comm_export / rlhip_p2p_setup), then 20 exact all-reduces and two
+    sharded PPO iterations (rlhip_ppo_update_comm_f32).  The replicas must end bit-identical.  RCCL refuses several
+    ranks on one device, so here the communicator has no RCCL side; `abi_host comm ... rccl` is the multi-GPU form."""
+    if not os.path.exists(HOST_BIN):
+        _build_host()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    procs = [subprocess.Popen([HOST_BIN, "comm", str(r), str(world), str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed ({p.returncode}):\n{so}\n{se}"
+        assert "p2p active" in so
+    dumps = [_read_dump(str(tmp_path / f"out.{r}.bin")) for r in range(world)]
+    for r in range(world):
+        info = dumps[r]["comm.info"].view(np.int32)
+        assert info[0] == 1 and info[1] == 0
+        assert np.array_equal(dumps[r]["comm.params"], dumps[0]["comm.params"]), f"replica {r} differs from replica 0"
+        assert np.isfinite(f32(dumps[r]["comm.params"])).all()
+    # shards are different env instances (global env ids): different observations
+    assert not np.array_equal(dumps[0]["comm.obs"], dumps[1]["comm.obs"])
+    # and shard 0 of the C ranks saw exactly what a PyTorch-hosted shard 0 sees
+    import rlhip
+
+    e = rlhip.CartPoleEnv(256, seed=77, env_id_base=0)
+    pol = rlhip.PPOPolicy(e, update_freq=8, seed=77)
+    pol.rollout_()
+    obs_first = pol.trajectory.obs.cpu().numpy().copy()
+    assert obs_first.shape == (9, 4, 256)
+    # (the dump holds the second rollout; its first frame is the state after 8 steps of the first one)
+    assert np.array_equal(f32(dumps[0]["comm.obs"]).reshape(9, 4, 256)[0], obs_first[8])
