@@ -678,7 +678,8 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, in
                                  int64_t timeout_polls, int32_t* status_dev, rlhip_stream_t stream);
 /* The same with a communicator (rlhip_comm_init): the fused peer-to-peer kernels when rlhip_p2p_setup activated them,
  * otherwise per optimiser step { gradient -> rlhip_allreduce_grads (ncclAllReduce on `stream`) -> rlhip_ppo_apply_f32 }.
- * world = 1 communicators run rlhip_ppo_update_f32.  Sequence numbers are kept inside the communicator. */
+ * world = 1 communicators without an RCCL side run rlhip_ppo_update_f32 (with one, the general sequence over a
+ * one-rank ncclAllReduce: same bits).  Sequence numbers are kept inside the communicator. */
 int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                                   const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
                                   float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,

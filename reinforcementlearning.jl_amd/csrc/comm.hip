@@ -169,7 +169,7 @@ int32_t rlhip_comm_init(int32_t rank, int32_t world, const uint8_t* unique_id_ho
         }
         c->peers[rank] = c->own;
     }
-    if (unique_id_host != nullptr && world > 1) {
+    if (unique_id_host != nullptr) {  // also for world = 1: a one-rank communicator exercises the whole RCCL side
         if (!rccl_load()) {
             (void)hipHostFree(c->status);
             delete c;
@@ -186,7 +186,10 @@ int32_t rlhip_comm_init(int32_t rank, int32_t world, const uint8_t* unique_id_ho
             return RLHIP_ECOMM;
         }
     }
-    if (world == 1) snprintf(c->why, sizeof(c->why), "world = 1: nothing to exchange");
+    if (world == 1) {
+        snprintf(c->why, sizeof(c->why), "world = 1: nothing to exchange");
+        if (c->nccl && hipMalloc((void**)&c->scratch, 64) != hipSuccess) c->scratch = nullptr;
+    }
     *comm_out = c;
     return RLHIP_OK;
 }
@@ -322,7 +325,7 @@ int32_t rlhip_p2p_setup(rlhip_comm_t comm, const uint8_t* handles_host, const in
 int32_t rlhip_allreduce_grads(rlhip_comm_t comm, float* grad, int64_t n, rlhip_stream_t stream) {
     Comm* c = as_comm(comm);
     RLHIP_REQUIRE(c && (grad || n == 0) && n >= 0, "bad communicator / arguments");
-    if (c->world == 1 || n == 0) return RLHIP_OK;
+    if ((c->world == 1 && !c->nccl) || n == 0) return RLHIP_OK;
     if (c->p2p_active && n <= c->cap)
         return rlhip_p2p_allreduce_f32(grad, n, c->cap, c->rank, c->world, c->peers, ++c->seq, c->timeout_polls,
                                        c->status, stream);

@@ -1100,7 +1100,7 @@ int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
     int32_t rc = rlhip_comm_info(comm, &d);
     if (rc) return rc;
     RLHIP_REQUIRE(cfg != nullptr, "cfg is NULL");
-    if (d.world == 1)
+    if (d.world == 1 && !d.rccl_active)
         return rlhip_ppo_update_f32(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace, grad_scratch,
                                     losses_out, stream);
     const int64_t np = rlhip_ppo_nparams(kind, cfg);

@@ -12,7 +12,8 @@
  *           4 epochs x 4 micro-batches of { gradient -> clip_by_global_norm! -> Adam }   (rlhip_ppo_update_f32)
  *   part C  the same PPO update through a world = 1 communicator (rlhip_comm_init / rlhip_ppo_update_comm_f32 /
  *           rlhip_allreduce_grads / rlhip_comm_check / rlhip_comm_destroy): the collective entry points of
- *           SURVEY.md 8b, callable without torch.distributed
+ *           SURVEY.md 8b, callable without torch.distributed; once more with a one-rank RCCL communicator behind it
+ *           (rlhip_comm_unique_id -> ncclCommInitRank -> ncclAllReduce on the compute stream per optimiser step)
  *
  * Everything the run produced is written to <out> as tagged Float32 / Int32 / UInt8 arrays; tests/test_gpu_abi_host.py
  * compares them with the CPU oracle and, bit for bit, with the PyTorch-hosted mirror of the same sequence.
@@ -266,9 +267,14 @@ static void run_ppo(int through_comm) {
         CK(rlhip_ppo_update_f32(RLHIP_ENV_CARTPOLE, &cfg, n, T, &tr, params, m, v, beta_pow, seed, 0, workspace, grad,
                                 losses, g_stream));
     } else {
-        /* world = 1 communicator: no RCCL id needed, rlhip_allreduce_grads is the identity, the update is the same */
+        /* world = 1 communicator.  through_comm = 1: no RCCL id, rlhip_allreduce_grads is the identity and the update is
+         * rlhip_ppo_update_f32.  through_comm = 2: with rlhip_comm_unique_id -> a ONE-rank RCCL communicator, so that
+         * every optimiser step runs gradient -> ncclAllReduce (on this stream) -> rlhip_ppo_apply_f32: the multi-GPU
+         * fallback sequence, bit-identical on one rank */
         rlhip_comm_t comm = NULL;
-        CK(rlhip_comm_init(0, 1, NULL, np, &comm));
+        uint8_t uid[128];
+        if (through_comm == 2) CK(rlhip_comm_unique_id(uid));
+        CK(rlhip_comm_init(0, 1, through_comm == 2 ? uid : NULL, np, &comm));
         uint8_t handle[64];
         int32_t device = -1, active = -1;
         CK(rlhip_comm_export(comm, handle, &device));
@@ -279,7 +285,7 @@ static void run_ppo(int through_comm) {
         CK(rlhip_comm_check(comm));
         rlhip_comm_desc d;
         CK(rlhip_comm_info(comm, &d));
-        if (d.world != 1 || d.rank != 0 || d.p2p_active != 0 || device < 0) {
+        if (d.world != 1 || d.rank != 0 || d.p2p_active != 0 || device < 0 || d.rccl_active != (through_comm == 2)) {
             fprintf(stderr, "unexpected communicator description\n");
             exit(3);
         }
@@ -287,7 +293,7 @@ static void run_ppo(int through_comm) {
         CK(rlhip_comm_destroy(comm));
     }
     CK(rlhip_stream_sync(g_stream));
-    const char* pre = through_comm ? "ppoc" : "ppo";
+    const char* pre = through_comm == 2 ? "ppor" : (through_comm ? "ppoc" : "ppo");
     char nm[16];
 #define NM(s) (snprintf(nm, sizeof(nm), "%s.%s", pre, s), nm)
     dump_host(NM("params0"), p0, 4, (size_t)np);
@@ -495,6 +501,7 @@ int main(int argc, char** argv) {
     run_dqn();
     run_ppo(0);
     run_ppo(1);
+    run_ppo(2);
     CK(rlhip_event_record(e1, g_stream));
     float ms = 0.0f;
     CK(rlhip_event_elapsed_ms(e0, e1, &ms));
@@ -502,7 +509,7 @@ int main(int argc, char** argv) {
     CK(rlhip_event_destroy(e0));
     CK(rlhip_event_destroy(e1));
     CK(rlhip_stream_destroy(g_stream));
-    printf("abi_host ok on %s: DQN 45 vec-steps + 2 PPO updates, %.2f ms between the ABI's events, no PyTorch in this process\n",
+    printf("abi_host ok on %s: DQN 45 vec-steps + 3 PPO updates, %.2f ms between the ABI's events, no PyTorch in this process\n",
            arch, ms);
     return 0;
 }

@@ -95,9 +95,11 @@ def test_c_host_dqn_run_is_bit_identical_to_the_torch_hosted_mirror(dump):
     assert not np.array_equal(dump["dqn.params"], dump["dqn.target"])  # updates happened after the last sync
 
 
-@pytest.mark.parametrize("pre", ["ppo", "ppoc"])
+@pytest.mark.parametrize("pre", ["ppo", "ppoc", "ppor"])
 def test_c_host_ppo_iteration_vs_oracle_and_torch_hosted_mirror(dump, pre):
-    """pre = "ppoc": the same update through a world = 1 communicator (rlhip_comm_* entry points)"""
+    """pre = "ppoc": the same update through a world = 1 communicator (rlhip_comm_* entry points); "ppor": through a
+    one-rank RCCL communicator created from the C host (dlopen'ed librccl: ncclCommInitRank, ncclAllReduce on the compute
+    stream between the gradient and the apply kernel of every optimiser step)"""
     import rlhip
 
     n, T = 256, 8

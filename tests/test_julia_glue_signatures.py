@@ -1,0 +1,187 @@
+"""Static check of the Julia glue (reinforcementlearning.jl_amd/julia/RLHip.jl) against include/rlhip.h.
+
+There is no `julia` binary in the image, so the glue cannot be executed here.  What CAN be verified mechanically is
+what breaks a `ccall` binding silently: the symbol name, the number of arguments, the C type of every argument and of
+the return value, and the layout (field order and types) of every struct passed by reference.  This test parses both
+files and compares them.  (The same call SEQUENCE is executed from a PyTorch-free C process on the GPU:
+tests/abi_host/abi_host.c, tests/test_gpu_abi_host.py.)"""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rlhip.h")
+GLUE = os.path.join(ROOT, "reinforcementlearning.jl_amd", "julia", "RLHip.jl")
+
+SCALARS = {"int32_t": "Int32", "int64_t": "Int64", "uint32_t": "UInt32", "uint64_t": "UInt64", "float": "Float32",
+           "double": "Float64", "size_t": "Csize_t", "uint8_t": "UInt8", "uint16_t": "UInt16", "char": "UInt8"}
+HANDLES = {"rlhip_stream_t", "rlhip_event_t", "rlhip_comm_t"}  # typedef void*
+
+
+def _header_src():
+    with open(HEADER) as f:
+        src = f.read()
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def c_type_class(decl):
+    """class of one C parameter / field declaration: 'ptr' or the Julia scalar name"""
+    decl = decl.strip()
+    if "*" in decl or "[" in decl:
+        return "ptr"
+    toks = [t for t in re.split(r"\s+", decl) if t not in ("const", "struct")]
+    base = toks[0]
+    if base in HANDLES:
+        return "ptr"
+    return SCALARS[base]
+
+
+def header_prototypes():
+    protos = {}
+    for ret, name, params in re.findall(r"\b(int32_t|int64_t|double|const char\s*\*)\s+(rlhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;",
+                                        _header_src()):
+        params = params.strip()
+        plist = [] if params in ("", "void") else [c_type_class(p) for p in params.split(",")]
+        rt = "Cstring" if "char" in ret else SCALARS[ret]
+        protos[name] = (rt, plist)
+    return protos
+
+
+def split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "{(":
+            depth += 1
+        elif ch in "})":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out if x.strip()]
+
+
+def jl_type_class(t):
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring",):
+        return "ptr"
+    return t
+
+
+def glue_ccalls():
+    with open(GLUE) as f:
+        src = f.read()
+    src = re.sub(r"#[^\n]*", "", src)
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(rlhip_[a-z0-9_]+),\s*LIB\),\s*([A-Za-z0-9_{}]+),\s*\(", src):
+        i = m.end()
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        args = split_top(src[i:j - 1])
+        calls.append((m.group(1), m.group(2), [jl_type_class(a) for a in args], src.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def test_every_ccall_matches_its_prototype():
+    protos = header_prototypes()
+    assert len(protos) >= 120
+    calls = glue_ccalls()
+    assert len(calls) >= 60
+    for name, ret, args, line in calls:
+        assert name in protos, f"RLHip.jl:{line}: {name} is not declared in include/rlhip.h"
+        rt, plist = protos[name]
+        assert (ret if ret != "Cstring" else "Cstring") == rt, f"RLHip.jl:{line}: {name} returns {rt}, glue says {ret}"
+        assert len(args) == len(plist), f"RLHip.jl:{line}: {name} takes {len(plist)} arguments, glue passes {len(args)}"
+        for k, (a, p) in enumerate(zip(args, plist)):
+            assert a == p, f"RLHip.jl:{line}: {name} argument {k + 1}: header {p}, glue {a}"
+
+
+def test_the_integration_table_entry_points_are_bound():
+    """every ABI function INTEGRATION.md names as the replacement of a reference call site has a ccall in the glue"""
+    bound = {c[0] for c in glue_ccalls()}
+    needed = ["rlhip_env_reset", "rlhip_env_step", "rlhip_env_obs", "rlhip_cartpole_default", "rlhip_pendulum_default",
+              "rlhip_mountaincar_default", "rlhip_acrobot_default", "rlhip_ring_init", "rlhip_ring_push_state",
+              "rlhip_ring_push_transition", "rlhip_ring_length", "rlhip_ring_sample_indices", "rlhip_ring_gather",
+              "rlhip_dqn_plan_f32", "rlhip_dqn3_plan_f32", "rlhip_dqn_update_f32", "rlhip_dqn3_update_f32",
+              "rlhip_dqn_vec_step_f32", "rlhip_mlp2_init_f32", "rlhip_mlp3_init_f32", "rlhip_mlp3_pack_bf16",
+              "rlhip_mlp2_forward_f32", "rlhip_clip_adam_f32", "rlhip_polyak_f32", "rlhip_clip_by_global_norm_f32",
+              "rlhip_ppo_default", "rlhip_ppo_nparams", "rlhip_ppo_plan_f32", "rlhip_ppo_rollout_f32", "rlhip_ppo_gae_f32",
+              "rlhip_ppo_update_f32", "rlhip_ppo_update_comm_f32", "rlhip_ppo_workspace_bytes", "rlhip_gae_f32",
+              "rlhip_discount_rewards_f32", "rlhip_hook_episode_stats", "rlhip_comm_unique_id", "rlhip_comm_init",
+              "rlhip_comm_export", "rlhip_p2p_setup", "rlhip_allreduce_grads", "rlhip_comm_check", "rlhip_comm_info",
+              "rlhip_comm_destroy", "rlhip_malloc", "rlhip_free", "rlhip_memset", "rlhip_memcpy_h2d", "rlhip_memcpy_d2h",
+              "rlhip_memcpy_d2d", "rlhip_stream_create", "rlhip_stream_sync", "rlhip_event_create", "rlhip_event_record",
+              "rlhip_event_elapsed_ms", "rlhip_device_count", "rlhip_set_device", "rlhip_abi_version", "rlhip_last_error"]
+    missing = [n for n in needed if n not in bound]
+    assert not missing, missing
+    # and the reference-side types of SURVEY 8b exist
+    with open(GLUE) as f:
+        src = f.read()
+    for t in ("mutable struct HipVecEnv", "mutable struct HipTrajectory", "mutable struct HipApproximator",
+              "mutable struct HipTargetNetwork", "mutable struct HipQBasedPolicy", "mutable struct HipPPOPolicy",
+              "function HipCartPoleEnv", "function HipPendulumEnv", "function HipMountainCarEnv", "function HipAcrobotEnv",
+              "state_space(env::HipVecEnv{:cartpole})", "Base.copy(env::HipVecEnv", "Random.seed!(env::HipVecEnv",
+              "function Base.iterate(t::HipTrajectory", "function _run(policy::AbstractPolicy, env::HipVecEnv"):
+        assert t in src, f"RLHip.jl lacks `{t}`"
+
+
+def c_structs():
+    out = {}
+    src = _header_src()
+    for body, name in re.findall(r"typedef struct(?:\s+\w+)?\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"((?:const\s+)?(?:struct\s+)?\w+)\s*(.*)", decl)
+            base, rest = m.group(1), m.group(2)
+            for item in rest.split(","):
+                item = item.strip()
+                arr = re.search(r"\[(\d+)\]", item)
+                is_ptr = "*" in item or base.replace("const ", "") in HANDLES
+                cls = "ptr" if is_ptr else SCALARS[base.replace("const ", "").replace("struct ", "")]
+                if arr:
+                    fields.extend([cls] * int(arr.group(1)))
+                else:
+                    fields.append(cls)
+        out[name] = fields
+    return out
+
+
+def jl_structs():
+    with open(GLUE) as f:
+        src = re.sub(r"#[^\n]*", "", f.read())
+    out = {}
+    for name, body in re.findall(r"(?:mutable\s+)?struct\s+(\w+)(?:\s*<:\s*\w+)?\s*\n(.*?)\nend", src, flags=re.S):
+        fields = []
+        for part in re.split(r"[;\n]", body):
+            part = part.strip()
+            m = re.match(r"^(\w+)::(.+)$", part)
+            if not m:
+                continue
+            t = m.group(2).strip()
+            nt = re.match(r"NTuple\{(\d+),\s*(.+)\}$", t)
+            if nt:
+                fields.extend([jl_type_class(nt.group(2))] * int(nt.group(1)))
+            else:
+                fields.append(jl_type_class(t))
+        out[name] = fields
+    return out
+
+
+@pytest.mark.parametrize("jl,c", [("CartPoleCfg", "rlhip_cartpole_cfg"), ("PendulumCfg", "rlhip_pendulum_cfg"),
+                                  ("MountainCarCfg", "rlhip_mountaincar_cfg"), ("AcrobotCfg", "rlhip_acrobot_cfg"),
+                                  ("EnvState", "rlhip_env_state"), ("Ring", "rlhip_ring"), ("PPOCfg", "rlhip_ppo_cfg"),
+                                  ("PPOTraj", "rlhip_ppo_traj"), ("DqnStepArgs", "rlhip_dqn_step_args"),
+                                  ("CommDesc", "rlhip_comm_desc")])
+def test_struct_mirrors_have_the_c_layout(jl, c):
+    cs, js = c_structs(), jl_structs()
+    assert c in cs and jl in js
+    assert js[jl] == cs[c], f"{jl} vs {c}:\n julia {js[jl]}\n c     {cs[c]}"
