@@ -789,6 +789,77 @@ function clip_by_global_norm!(g::DevBuf{Float32}, clip_norm::Float32)
 end
 
 # ------------------------------------------------------------------------------------------------------------------
+# SURVEY 8f rows: prioritized replay, frame stacking at sample time, explorers, stochastic heads (device buffers in / out)
+# ------------------------------------------------------------------------------------------------------------------
+# CircularPrioritizedTraces + prioritized BatchSampler (RLTrajectories 0.4): `tree` = zeroed DevBuf{Float32}(sumtree_nodes(n))
+sumtree_nodes(n_leaves) = ccall((:rlhip_sumtree_nodes, LIB), Int64, (Int64,), n_leaves)
+push_priority!(t::HipTrajectory, tree::DevBuf{Float32}, p::Float32) = chk(ccall((:rlhip_ring_push_priority, LIB), Int32,
+    (Ref{Ring}, Ptr{Cvoid}, Float32, Ptr{Cvoid}), t.rb, tree.ptr, p, stream()))
+"`inds, priorities = rand(rng, sumtree, batchsize)`: logical indices for the gather, physical keys for the write-back"
+sample_prioritized!(idx::DevBuf{Int64}, key::DevBuf{Int64}, prio::DevBuf{Float32}, t::HipTrajectory, tree, batch, seed, ctr) =
+    chk(ccall((:rlhip_ring_sample_prioritized, LIB), Int32,
+              (Ref{Ring}, Ptr{Cvoid}, Int64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, tree.ptr, batch, seed, ctr, idx.ptr, key.ptr, prio.ptr, stream()))
+"priority write-back value (|td| + eps)^alpha of PrioritizedDQN"
+per_priority!(out::DevBuf{Float32}, td::DevBuf{Float32}, eps::Float32, alpha::Float32) =
+    chk(ccall((:rlhip_per_priority_f32, LIB), Int32, (Ptr{Cvoid}, Int64, Float32, Float32, Ptr{Cvoid}, Ptr{Cvoid}),
+              td.ptr, td.n, eps, alpha, out.ptr, stream()))
+"trajectory[:priority, keys] = p   (0-based physical leaf keys from the sampler)"
+set_priority!(tree::DevBuf{Float32}, n_leaves, key::DevBuf{Int64}, p::DevBuf{Float32}, n) =
+    chk(ccall((:rlhip_sumtree_update, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+              tree.ptr, n_leaves, key.ptr, p.ptr, n, stream()))
+# StackFrames (RLCore/utils/stack_frames.jl:11-44) applied at sample time + AtariEnv's 2-frame max-pool (atari.jl:104-107)
+gather_stacked!(t::HipTrajectory, idx::DevBuf{Int64}, batch, n_stack, s, a, r, term, s_next) =
+    chk(ccall((:rlhip_ring_gather_stacked, LIB), Int32,
+              (Ref{Ring}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, idx.ptr, batch, n_stack, s.ptr, a.ptr, r.ptr, term.ptr, s_next.ptr, stream()))
+push_maxpool!(t::HipTrajectory, screen1::DevBuf{UInt8}, screen2::DevBuf{UInt8}, a::DevBuf{Int32}, r::DevBuf{Float32},
+              term::DevBuf{UInt8}) =
+    chk(ccall((:rlhip_ring_push_transition_maxpool, LIB), Int32,
+              (Ref{Ring}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, screen1.ptr, screen2.ptr, a.ptr, r.ptr, term.ptr, stream()))
+# plan!(explorer, values[, mask]) on a device (na, n) SoA matrix: EpsilonGreedy (epsilon_greedy_explorer.jl:102-131),
+# Weighted / WeightedSoftmax / GumbelSoftmax (kind 0 / 1 / 2), UCB; BatchExplorer semantics (one column per env)
+plan_eps_greedy!(actions::DevBuf{Int32}, values::DevBuf{Float32}, na, n, ϵ; mask = nothing, is_break_tie = false, seed = 0,
+                 env_id_base = 0, step = 1) =
+    chk(ccall((:rlhip_eps_greedy_select_f32, LIB), Int32,
+              (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, Float64, Int32, UInt64, UInt32, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+              values.ptr, na, n, n, 1, mask === nothing ? C_NULL : mask.ptr, ϵ, is_break_tie, seed, env_id_base, step,
+              actions.ptr, stream()))
+plan_explorer!(kind::Integer, actions::DevBuf{Int32}, values::DevBuf{Float32}, na, n; mask = nothing, is_normalized = false,
+               seed = 0, env_id_base = 0, step = 1) =
+    chk(ccall((:rlhip_explorer_select_f32, LIB), Int32,
+              (Int32, Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, Int32, UInt64, UInt32, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+              kind, values.ptr, na, n, n, 1, mask === nothing ? C_NULL : mask.ptr, is_normalized, seed, env_id_base, step,
+              actions.ptr, stream()))
+plan_ucb!(actions::DevBuf{Int32}, values::DevBuf{Float32}, counts::DevBuf{Float64}, na, n, c, step; seed = 0, env_id_base = 0) =
+    chk(ccall((:rlhip_ucb_select_f32, LIB), Int32,
+              (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Float64, Ptr{Cvoid}, Int64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+              values.ptr, na, n, n, 1, c, counts.ptr, step, seed, env_id_base, actions.ptr, stream()))
+"sample_categorical (Gumbel-max, RLCore/utils/networks.jl:425-432) with optional mask (:466-468)"
+sample_categorical!(actions::DevBuf{Int32}, logp::DevBuf{Float32}, logits::DevBuf{Float32}, na, n; mask = nothing, seed = 0,
+                    env_id_base = 0, step = 0) =
+    chk(ccall((:rlhip_categorical_sample_f32, LIB), Int32,
+              (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, UInt64, UInt32, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              logits.ptr, na, n, n, 1, mask === nothing ? C_NULL : mask.ptr, seed, env_id_base, step, actions.ptr, logp.ptr,
+              stream()))
+"(gn::GaussianNetwork)(rng, s; is_sampling = true, is_return_log_prob = true) on the mu / sigma heads' outputs (d x n),
+K samples per state; squash = tanh, soft = SoftGaussianNetwork  (RLCore/utils/networks.jl:64-116,147-198)"
+gaussian_sample!(action::DevBuf{Float32}, logp::DevBuf{Float32}, mu::DevBuf{Float32}, raw_sigma::DevBuf{Float32}, d, n, K;
+                 min_sigma = 0f0, max_sigma = Inf32, squash = false, soft = false, seed = 0, env_id_base = 0, step = 0) =
+    chk(ccall((:rlhip_gaussian_head_sample_f32, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Float32, Float32, Int32, Int32, UInt64, UInt32, UInt32, Ptr{Cvoid},
+               Ptr{Cvoid}, Ptr{Cvoid}),
+              mu.ptr, raw_sigma.ptr, d, n, K, min_sigma, max_sigma, squash, soft, seed, env_id_base, step, action.ptr, logp.ptr,
+              stream()))
+"(gn::GaussianNetwork)(s, action): log-probability of given (squashed) actions"
+gaussian_logp!(logp::DevBuf{Float32}, mu::DevBuf{Float32}, raw_sigma::DevBuf{Float32}, action::DevBuf{Float32}, d, n, K;
+               min_sigma = 0f0, max_sigma = Inf32, squash = false, soft = false) =
+    chk(ccall((:rlhip_gaussian_head_logp_f32, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Float32, Float32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+              mu.ptr, raw_sigma.ptr, action.ptr, d, n, K, min_sigma, max_sigma, squash, soft, logp.ptr, stream()))
+
+# ------------------------------------------------------------------------------------------------------------------
 # hooks: TotalRewardPerEpisode + BatchStepsPerEpisode (RLCore/core/hooks.jl:146-231) with device accumulators
 # ------------------------------------------------------------------------------------------------------------------
 mutable struct HipEpisodeStats <: AbstractHook
