@@ -72,7 +72,10 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     from rlhip._lib import call
     from rlhip.ops import ptr, stream_ptr
 
-    env = rlhip.HipVecEnv("cartpole", n_envs, seed=1)
+    # the layout a large vector env gets from the host (rlhip/envs.py): arrays staggered inside one allocation, reset
+    # counters packed into the spare bits of the step-counter word (rlhip_env_state packed mode) -- an auto-reset then
+    # moves no byte beyond the 49 algorithmic ones
+    env = rlhip.HipVecEnv("cartpole", n_envs, seed=1, packed_episode=True)
     # a different random action for every env at every step (16 pre-drawn vectors, cycled): with ONE fixed vector each
     # env would push the same way for ever, episodes would last ~9 steps and stay synchronised in waves
     actions = torch.randint(0, 2, (16, n_envs), dtype=torch.int32, device="cuda")
@@ -95,7 +98,7 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     step()
     torch.cuda.synchronize()
     no_term = per_unit(event_time_ms(step, 5, rlhip._lib.lib, stream_ptr()))
-    no_term["episodes_finished_during_these_launches"] = int((env._episode != 2).sum())  # constructor + this reset
+    no_term["episodes_finished_during_these_launches"] = int((env.episode_counter() != 2).sum())  # constructor + this reset
     for _ in range(60):
         step()
     torch.cuda.synchronize()
@@ -104,17 +107,40 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     main = per_unit(ms)
     del env, actions
     torch.cuda.empty_cache()
-    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal>", "n_envs": n_envs,
+    traffic, traffic_note = measured_traffic(n_envs)
+    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal,packed>", "n_envs": n_envs,
             "bytes_per_unit": CARTPOLE_STEP_BYTES, "us_per_launch": main["us_per_launch"],
             "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
             # HBM bytes per launch from the PMC counters (separate rocprofv3 passes: FETCH_SIZE x2 gfx950
-            # correction + WRITE_SIZE), measured for exactly this kernel / size: profiles/r01_pmc_env_step.md
-            "traffic": 897.6e6 if n_envs == (1 << 24) else None,
-            "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs,
-            "traffic_source": "profiles/r01_pmc_env_step.md",
+            # correction + WRITE_SIZE) for exactly this kernel / size; the figure is only reported while the kernel
+            # sources still hash to what was profiled (PMC_TRAFFIC below) -- otherwise null, never a stale literal
+            "traffic": traffic, "algorithmic_bytes": CARTPOLE_STEP_BYTES * n_envs, "traffic_source": traffic_note,
             "env_steps_per_sec": round(n_envs / (ms * 1e-3), 1),
+            "layout": "arrays staggered by 4352 B inside one allocation; episode counters packed into the step-counter word",
             "actions": "uniformly random per env and step (16 pre-drawn vectors), episodes de-synchronised by 60 steps before the timed launches",
             "terminated_per_step": round(done_frac, 4), "without_terminations": no_term}
+
+
+# PMC measurement of the env-step kernel (tools/pmc.sh + tools/envstep.py; profiles/r02_pmc_env_step.md), valid for
+# the kernel sources whose sha256 (first 16 hex digits over csrc/envs.hip + csrc/env_device.h) is `sha`
+PMC_TRAFFIC = {"sha": "79f48aed59ea847b", "n_envs": 1 << 24, "bytes": 822261248.0, "source": "profiles/r02_pmc_env_step.md"}
+
+
+def env_kernel_sha():
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("envs.hip", "env_device.h"):
+        with open(os.path.join(ROOT, "reinforcementlearning.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(n_envs):
+    sha = env_kernel_sha()
+    if PMC_TRAFFIC["bytes"] is not None and PMC_TRAFFIC["sha"] == sha and PMC_TRAFFIC["n_envs"] == n_envs:
+        return PMC_TRAFFIC["bytes"], f"{PMC_TRAFFIC['source']} (kernel sources sha {sha})"
+    return None, f"not measured for the current kernel sources (sha {sha}; last PMC pass: sha {PMC_TRAFFIC['sha'] or 'none'})"
 
 
 def roofline_extras(torch, rlhip):

@@ -131,7 +131,13 @@ int32_t rlhip_mountaincar_default(rlhip_mountaincar_cfg* cfg_host, int32_t conti
  *   t       i32[n] step counter of the running episode
  *   done    u8[n]  is_terminated(env) after the LAST act!
  *   reward  T[n]   reward(env) after the last act!
- *   episode u32[n] number of resets so far (Philox time counter of the next reset)          */
+ *   episode u32[n] number of resets so far (Philox time counter of the next reset)
+ * PACKED MODE (episode == NULL; rlhip_env_reset / rlhip_env_step / rlhip_env_obs only): the reset counter lives in
+ * the bits of t[i] that max_steps leaves free -- t[i] = step | episode << tbits, tbits = the smallest b >= 1 with
+ * 2^b > max_steps + 1 (CartPole default 200: 8 bits of step, 24 bits = 16.7 M episodes; the counter wraps there).
+ * Same states, rewards, flags and reset draws as the separate array; an auto-reset then touches no memory that the
+ * step kernel does not stream anyway (with episode[] every reset is a scattered 4-byte read-modify-write: +9 % HBM
+ * traffic at 2^24 CartPole envs under a random policy).  max_steps < 2^20 - 1.                  */
 typedef struct {
     void* s[4];
     int32_t* t;

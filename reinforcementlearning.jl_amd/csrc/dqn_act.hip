@@ -89,6 +89,7 @@ static int32_t act_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st,
                         int na, int act, double eps, uint64_t explorer_seed, uint32_t step, uint64_t env_seed,
                         uint32_t env_id_base, ActRing rb, int32_t* actions, float* q_out, float* obs_out, float* last_obs,
                         hipStream_t s) {
+    RLHIP_REQUIRE(st && st->episode, "this entry point needs the separate episode[] array (packed step / episode words are an rlhip_env_step / rlhip_env_reset mode)");
     typename P::cfg_t c2 = *cfg;
     c2.continuous = 0;
     P p = P::make(c2);
@@ -187,6 +188,7 @@ template <class P>
 static int32_t act_push_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, const int32_t* actions,
                              uint64_t env_seed, uint32_t env_id_base, ActRing rb, float* obs_out, float* last_obs,
                              hipStream_t s) {
+    RLHIP_REQUIRE(st && st->episode, "this entry point needs the separate episode[] array (packed step / episode words are an rlhip_env_step / rlhip_env_reset mode)");
     typename P::cfg_t c2 = *cfg;
     c2.continuous = 0;
     P p = P::make(c2);

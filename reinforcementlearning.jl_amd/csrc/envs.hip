@@ -60,12 +60,17 @@ __device__ __forceinline__ void stv(T* p, int64_t i, const VecN<T, N>& x) {
     }
 }
 
-template <class P, typename T, int EPL, bool NT>
+// PK (packed episode counters, rlhip_env_state.episode == NULL): the reset counter of an env lives in the bits of its
+// step-counter word that max_steps leaves free -- t[i] = step | episode << tbits -- so an auto-reset touches no array the
+// kernel does not stream anyway.  With a separate episode[] every reset is a scattered 4-byte read-modify-write = one
+// 64-byte sector in and out: at the ~4.8 % of CartPole envs that terminate per step under a random policy more than
+// half of all sectors of episode[] are hit, +9 % HBM traffic over the 49 algorithmic bytes (profiles/r01_pmc_env_step.md).
+template <class P, typename T, int EPL, bool NT, bool PK>
 __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int64_t n,
                                                        const void* __restrict__ actions,
                                                        int auto_reset, uint64_t seed,
                                                        uint32_t env_id_base, T* __restrict__ last_obs,
-                                                       T* __restrict__ obs_out) {
+                                                       T* __restrict__ obs_out, int tbits) {
     int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * EPL;
     if (base >= n) return;
     VecN<T, EPL> s[P::SDIM];
@@ -89,18 +94,20 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
     uint32_t pend = 0;  // envs of this lane that terminated and restart right away
     uint32_t epv[EPL];  // their episode counters: requested as soon as `done` is known, so that the scattered load
                         // is in flight under the physics of the following envs instead of stalling the reset
+                        // (PK: unpacked from the step-counter word, no load at all)
+    const uint32_t tmask = PK ? ((1u << tbits) - 1u) : 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) epv[j] = 0;
+    for (int j = 0; j < EPL; ++j) epv[j] = PK ? ((uint32_t)tv.v[j] >> tbits) : 0u;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         LaneState<T> e;
 #pragma unroll
         for (int k = 0; k < P::SDIM; ++k) e.s[k] = s[k].v[j];
-        e.t = tv.v[j];
-        e.episode = 0;
+        e.t = (int32_t)((uint32_t)tv.v[j] & tmask);
+        e.episode = epv[j];
         if constexpr (EnvTraits<P>::STEP_NOISE) {
             if (p.noise > (T)0) {  // act! draws from the env's rng: uniform keyed by (env, t, episode)
-                e.episode = st.episode[base + j];
+                if constexpr (!PK) e.episode = st.episode[base + j];
                 af.v[j] = acrobot_noise_u(e, seed, env_id_base + (uint32_t)(base + j));
             }
         }
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
         }
         if (d && auto_reset) {
             pend |= 1u << j;
-            if constexpr (EPL > 1) epv[j] = st.episode[base + j];
+            if constexpr (EPL > 1 && !PK) epv[j] = st.episode[base + j];
         }
 #pragma unroll
         for (int k = 0; k < P::SDIM; ++k) s[k].v[j] = e.s[k];
@@ -131,9 +138,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
     if constexpr (EPL == 1) {
         if (pend) {
             LaneState<T> e;
-            e.episode = st.episode[base];
+            if constexpr (PK) e.episode = epv[0];
+            else e.episode = st.episode[base];
             env_reset1(p, e, seed, env_id_base + (uint32_t)base);
-            st.episode[base] = e.episode;
+            if constexpr (PK) epv[0] = e.episode;
+            else st.episode[base] = e.episode;
 #pragma unroll
             for (int k = 0; k < P::SDIM; ++k) s[k].v[0] = e.s[k];
             tv.v[0] = e.t;
@@ -149,12 +158,13 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
                 for (int jj = 1; jj < EPL; ++jj) ep = (jj == j) ? epv[jj] : ep;
                 e.episode = ep;
                 env_reset1(p, e, seed, env_id_base + (uint32_t)(base + j));
-                st.episode[base + j] = e.episode;
+                if constexpr (!PK) st.episode[base + j] = e.episode;
 #pragma unroll
                 for (int jj = 0; jj < EPL; ++jj) {
 #pragma unroll
                     for (int k = 0; k < P::SDIM; ++k) s[k].v[jj] = (jj == j) ? e.s[k] : s[k].v[jj];
                     tv.v[jj] = (jj == j) ? e.t : tv.v[jj];
+                    if constexpr (PK) epv[jj] = (jj == j) ? e.episode : epv[jj];
                 }
             }
         }
@@ -173,6 +183,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
     }
 #pragma unroll
     for (int k = 0; k < P::SDIM; ++k) stv<T, EPL, NT>(st.s[k], base, s[k]);
+    if constexpr (PK) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) tv.v[j] = (int32_t)((uint32_t)tv.v[j] | (epv[j] << tbits));
+    }
     stv<int32_t, EPL, NT>(st.t, base, tv);
     stv<T, EPL, NT>(st.reward, base, rew);
     stv<uint8_t, EPL, NT>(st.done, base, dn);
@@ -189,17 +203,22 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
 template <class P, typename T>
 __global__ __launch_bounds__(256) void env_reset_kernel(P p, EnvArrays<T> st, int64_t n, uint64_t seed,
                                                         uint32_t env_id_base,
-                                                        const uint8_t* __restrict__ mask) {
+                                                        const uint8_t* __restrict__ mask, int tbits) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
     LaneState<T> e;
-    e.episode = st.episode[i];
+    const bool packed = st.episode == nullptr;
+    e.episode = packed ? ((uint32_t)st.t[i] >> tbits) : st.episode[i];
     env_reset1(p, e, seed, env_id_base + (uint32_t)i);
 #pragma unroll
     for (int k = 0; k < P::SDIM; ++k) st.s[k][i] = e.s[k];
-    st.t[i] = 0;
-    st.episode[i] = e.episode;
+    if (packed) {
+        st.t[i] = (int32_t)(e.episode << tbits);
+    } else {
+        st.t[i] = 0;
+        st.episode[i] = e.episode;
+    }
     st.done[i] = 0;          // reset!: done = false
     st.reward[i] = (T)EnvTraits<P>::RESET_REWARD;
 }
@@ -220,6 +239,13 @@ __global__ __launch_bounds__(256) void env_obs_kernel(P p, EnvArrays<T> st, int6
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// bits of the step-counter word that hold the step count in packed mode: t can reach max_steps + 1 (CartPole's strict `>`)
+static int packed_tbits(int64_t max_steps) {
+    int b = 1;
+    while (b < 31 && ((int64_t)1 << b) <= max_steps + 1) ++b;
+    return b;
+}
+
 template <class P, typename T>
 static int32_t step_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n,
                          const void* actions, int32_t auto_reset, uint64_t seed, uint32_t env_id_base,
@@ -234,20 +260,28 @@ static int32_t step_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st
     if (last_obs) vec = vec && aligned16(last_obs);
     if (obs_out) vec = vec && aligned16(obs_out);
     const bool streaming = n >= ((int64_t)1 << 20);  // state arrays beyond the L2: non-temporal accesses
+    const bool packed = st->episode == nullptr;
+    const int tbits = packed_tbits(p.max_steps);
+    RLHIP_REQUIRE(!packed || tbits <= 20, "packed episode counters need max_steps < 2^20 - 1");
+#define STEP_LAUNCH(EPL_, NT_, PK_, GRID_)                                                                               \
+    hipLaunchKernelGGL((env_step_kernel<P, T, EPL_, NT_, PK_>), dim3(GRID_), dim3(256), 0, stream, p, a, n, actions,      \
+                       auto_reset, seed, env_id_base, (T*)last_obs, (T*)obs_out, tbits)
     if (vec) {
         int64_t lanes = n / EPL;
         int grid = (int)((lanes + 255) / 256);
-        if (streaming)
-            hipLaunchKernelGGL((env_step_kernel<P, T, EPL, true>), dim3(grid), dim3(256), 0, stream, p, a, n, actions,
-                               auto_reset, seed, env_id_base, (T*)last_obs, (T*)obs_out);
-        else
-            hipLaunchKernelGGL((env_step_kernel<P, T, EPL, false>), dim3(grid), dim3(256), 0, stream, p, a, n, actions,
-                               auto_reset, seed, env_id_base, (T*)last_obs, (T*)obs_out);
+        if (streaming) {
+            if (packed) STEP_LAUNCH(EPL, true, true, grid);
+            else STEP_LAUNCH(EPL, true, false, grid);
+        } else {
+            if (packed) STEP_LAUNCH(EPL, false, true, grid);
+            else STEP_LAUNCH(EPL, false, false, grid);
+        }
     } else {
         int grid = (int)((n + 255) / 256);
-        hipLaunchKernelGGL((env_step_kernel<P, T, 1, false>), dim3(grid), dim3(256), 0, stream, p, a, n,
-                           actions, auto_reset, seed, env_id_base, (T*)last_obs, (T*)obs_out);
+        if (packed) STEP_LAUNCH(1, false, true, grid);
+        else STEP_LAUNCH(1, false, false, grid);
     }
+#undef STEP_LAUNCH
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -258,8 +292,10 @@ static int32_t reset_impl(const typename P::cfg_t* cfg, const rlhip_env_state* s
                           hipStream_t stream) {
     P p = P::make(*cfg);
     EnvArrays<T> a = EnvArrays<T>::from(*st);
+    const int tbits = packed_tbits(p.max_steps);
+    RLHIP_REQUIRE(st->episode != nullptr || tbits <= 20, "packed episode counters need max_steps < 2^20 - 1");
     hipLaunchKernelGGL((env_reset_kernel<P, T>), dim3((int)((n + 255) / 256)), dim3(256), 0, stream, p,
-                       a, n, seed, env_id_base, mask);
+                       a, n, seed, env_id_base, mask, tbits);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -274,13 +310,13 @@ static int32_t obs_impl(const rlhip_env_state* st, int64_t n, void* obs, hipStre
     return RLHIP_OK;
 }
 
-static int32_t check_state(int32_t kind, const rlhip_env_state* st, int64_t n) {
+static int32_t check_state(int32_t kind, const rlhip_env_state* st, int64_t n, bool allow_packed = false) {
     RLHIP_REQUIRE(kind >= 0 && kind <= 3, "kind must be 0 (cartpole), 1 (pendulum), 2 (mountaincar) or 3 (acrobot)");
     RLHIP_REQUIRE(st != nullptr, "env state is NULL");
     RLHIP_REQUIRE(n >= 0 && n <= 0xFFFFFFFFll, "n out of range");
     int sd = (kind == 0 || kind == 3) ? 4 : 2;
     for (int k = 0; k < sd; ++k) RLHIP_REQUIRE(st->s[k] != nullptr, "state array is NULL");
-    RLHIP_REQUIRE(st->t && st->done && st->reward && st->episode, "state array is NULL");
+    RLHIP_REQUIRE(st->t && st->done && st->reward && (st->episode || allow_packed), "state array is NULL");
     return RLHIP_OK;
 }
 
@@ -362,7 +398,7 @@ int32_t rlhip_env_state_dim(int32_t kind) { return (kind == 0 || kind == 3) ? 4 
 int32_t rlhip_env_reset(int32_t kind, int32_t is_f64, const void* cfg, const rlhip_env_state* st,
                         int64_t n, uint64_t seed, uint32_t env_id_base, const uint8_t* mask,
                         rlhip_stream_t stream) {
-    int32_t rc = check_state(kind, st, n);
+    int32_t rc = check_state(kind, st, n, /*allow_packed=*/true);
     if (rc) return rc;
     RLHIP_REQUIRE(cfg != nullptr, "cfg is NULL");
     if (n == 0) return RLHIP_OK;
@@ -383,7 +419,7 @@ int32_t rlhip_env_reset(int32_t kind, int32_t is_f64, const void* cfg, const rlh
 int32_t rlhip_env_step(int32_t kind, int32_t is_f64, const void* cfg, const rlhip_env_state* st,
                        int64_t n, const void* actions, int32_t auto_reset, uint64_t seed,
                        uint32_t env_id_base, void* last_obs, void* obs_out, rlhip_stream_t stream) {
-    int32_t rc = check_state(kind, st, n);
+    int32_t rc = check_state(kind, st, n, /*allow_packed=*/true);
     if (rc) return rc;
     RLHIP_REQUIRE(cfg != nullptr, "cfg is NULL");
     RLHIP_REQUIRE(actions != nullptr, "actions is NULL");
@@ -404,7 +440,7 @@ int32_t rlhip_env_step(int32_t kind, int32_t is_f64, const void* cfg, const rlhi
 
 int32_t rlhip_env_obs(int32_t kind, int32_t is_f64, const rlhip_env_state* st, int64_t n, void* obs,
                       rlhip_stream_t stream) {
-    int32_t rc = check_state(kind, st, n);
+    int32_t rc = check_state(kind, st, n, /*allow_packed=*/true);
     if (rc) return rc;
     RLHIP_REQUIRE(obs != nullptr, "obs is NULL");
     if (n == 0) return RLHIP_OK;

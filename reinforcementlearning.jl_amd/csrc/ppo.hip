@@ -198,6 +198,7 @@ template <class P>
 static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, int64_t T,
                             const PolicyDesc& pd, const float* params, uint64_t seed, uint32_t env_id_base,
                             uint32_t vec_step0, const uint32_t* ctr, const rlhip_ppo_traj* traj, hipStream_t s) {
+    RLHIP_REQUIRE(st && st->episode, "this entry point needs the separate episode[] array (packed step / episode words are an rlhip_env_step / rlhip_env_reset mode)");
     typename P::cfg_t c2 = *cfg;
     c2.continuous = pd.cont;  // the policy head decides the action type
     P p = P::make(c2);

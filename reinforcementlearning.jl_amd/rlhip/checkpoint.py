@@ -40,7 +40,7 @@ def _walk(obj, prefix, visit, seen, skip):
         items = [(k, obj, k, v) for k, v in sorted(vars(obj).items())]
     for name, owner, key, v in items:
         path = f"{prefix}{name}"
-        if any(s in path for s in skip):
+        if any(s in path for s in skip) or name == "_backing":  # _backing: the allocation the env's arrays are views of
             continue
         if isinstance(v, torch.Tensor):
             visit("tensor", path, owner, key, v)

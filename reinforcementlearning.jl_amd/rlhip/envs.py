@@ -88,7 +88,11 @@ class HipVecEnv:
     """
 
     def __init__(self, kind, n_envs=1, T=torch.float32, continuous=None, seed=0, env_id_base=0,
-                 auto_reset=True, device="cuda", validate_actions=False, **kwargs):
+                 auto_reset=True, device="cuda", validate_actions=False, packed_episode=False, **kwargs):
+        """packed_episode: keep each instance's reset counter in the spare bits of its step-counter word (the packed mode
+        of rlhip_env_state, include/rlhip.h) instead of a separate `episode` array: same trajectories, and an auto-reset
+        touches no memory the step kernel does not stream anyway.  For the stand-alone env (`act_` / `reset_` / `state`);
+        the fused policy kernels (PPOPolicy.rollout_, the fused DQN step) need the separate array."""
         self.kind = KIND[kind] if isinstance(kind, str) else int(kind)
         self.name = {0: "CartPoleEnv", 1: "PendulumEnv", 2: "MountainCarEnv", 3: "AcrobotEnv"}[self.kind]
         if T not in (torch.float32, torch.float64):
@@ -104,26 +108,77 @@ class HipVecEnv:
         self.env_id_base = int(env_id_base)
         self.auto_reset = bool(auto_reset)
         self.validate_actions = validate_actions
+        self.packed_episode = bool(packed_episode)
+        self.tbits = 1
+        while self.tbits < 31 and (1 << self.tbits) <= int(self.cfg.max_steps) + 1:
+            self.tbits += 1
+        if self.packed_episode and self.tbits > 20:
+            raise ValueError("packed_episode needs max_steps < 2^20 - 1")
         self.device = torch.device(device)
         self.sdim = int(_lib.lib.rlhip_env_state_dim(self.kind))
         self.odim = int(_lib.lib.rlhip_env_obs_dim(self.kind))
-        n = self.n
-        self._s = torch.zeros((self.sdim, n), dtype=T, device=self.device)
-        self._t = torch.zeros(n, dtype=torch.int32, device=self.device)
-        self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        self._reward = torch.zeros(n, dtype=T, device=self.device)
-        self._episode = torch.zeros(n, dtype=torch.int32, device=self.device)
-        self._obs = torch.zeros((self.odim, n), dtype=T, device=self.device)
-        self._last_obs = torch.zeros((self.odim, n), dtype=T, device=self.device)
+        self._alloc_state()
+        self._bind_state()
+        self._obs_valid = False
+        self.reset_(is_force=True)  # the constructors call reset! once (CartPoleEnv.jl:77)
+
+    # Streamed arrays of a large vector env are carved from ONE allocation at staggered offsets: with the allocator's
+    # default placement every array starts a multiple of 64 MB from the others (2^24 Float32 envs), so that the 13
+    # streams of a step launch walk the HBM channels in lock-step; 4352 bytes (17 x 256 B) between consecutive arrays
+    # spreads them: 150 -> 144 us per CartPole step at 2^24 envs (tools/envstep_layout.py, profiles/r02_env_step.md).
+    STAGGER_BYTES = 4352
+    STAGGER_MIN_ENVS = 1 << 20
+
+    def _alloc_state(self):
+        n, T, dev = self.n, self.T, self.device
+        es = 8 if self.is_f64 else 4
+        if n < self.STAGGER_MIN_ENVS:
+            self._s = torch.zeros((self.sdim, n), dtype=T, device=dev)
+            self._t = torch.zeros(n, dtype=torch.int32, device=dev)
+            self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self._reward = torch.zeros(n, dtype=T, device=dev)
+            self._episode = None if self.packed_episode else torch.zeros(n, dtype=torch.int32, device=dev)
+        else:
+            def up(b):  # next array start: its bytes + the stagger, rounded to 256 B (16-byte vector accesses stay aligned)
+                return (b + self.STAGGER_BYTES + 255) // 256 * 256
+
+            row = up(es * n)  # uniform spacing of the state components -> one strided (sdim, n) view
+            o_t = self.sdim * row
+            o_r = o_t + up(4 * n)
+            o_d = o_r + up(es * n)
+            o_e = o_d + up(n)
+            total = o_e + (0 if self.packed_episode else up(4 * n))
+            self._backing = torch.zeros(total + 256, dtype=torch.uint8, device=dev)
+            base = (-self._backing.data_ptr()) % 256
+
+            def view(off, dtype, count):
+                nb = count * torch.empty(0, dtype=dtype).element_size()
+                return self._backing[base + off: base + off + nb].view(dtype)
+
+            self._s = torch.as_strided(view(0, T, (self.sdim - 1) * (row // es) + n), (self.sdim, n), (row // es, 1))
+            self._t = view(o_t, torch.int32, n)
+            self._reward = view(o_r, T, n)
+            self._done = view(o_d, torch.uint8, n)
+            self._episode = None if self.packed_episode else view(o_e, torch.int32, n)
+        self._obs = torch.zeros((self.odim, n), dtype=T, device=dev)
+        self._last_obs = torch.zeros((self.odim, n), dtype=T, device=dev)
+
+    def _bind_state(self):
         self._st = _lib.EnvState()
         for k in range(self.sdim):
             self._st.s[k] = self._s[k].data_ptr()
         self._st.t = self._t.data_ptr()
         self._st.done = self._done.data_ptr()
         self._st.reward = self._reward.data_ptr()
-        self._st.episode = self._episode.data_ptr()
-        self._obs_valid = False
-        self.reset_(is_force=True)  # the constructors call reset! once (CartPoleEnv.jl:77)
+        self._st.episode = None if self._episode is None else self._episode.data_ptr()
+
+    def step_counter(self):
+        """t of every instance (i32[n]); unpacked when the episode counters share the word"""
+        return (self._t & ((1 << self.tbits) - 1)) if self.packed_episode else self._t
+
+    def episode_counter(self):
+        """number of resets of every instance so far (i32[n])"""
+        return ((self._t >> self.tbits) & ((1 << (32 - self.tbits)) - 1)) if self.packed_episode else self._episode
 
     # ------------------------------------------------------------------ RLBase env API
     def reset_(self, is_force=True):
@@ -193,23 +248,22 @@ class HipVecEnv:
     def seed_(self, seed):
         """Random.seed!(env, seed): re-keys the Philox streams and restarts the episode counters."""
         self.seed = int(seed)
-        self._episode.zero_()
+        if self.packed_episode:
+            self._t &= (1 << self.tbits) - 1
+        else:
+            self._episode.zero_()
 
     def copy(self):
         """copy(env): deep copy, same seed and counters -> identical future under identical actions."""
         other = object.__new__(HipVecEnv)
         other.__dict__.update(self.__dict__)
         for name in ("_s", "_t", "_done", "_reward", "_episode", "_obs", "_last_obs"):
-            setattr(other, name, getattr(self, name).clone())
+            v = getattr(self, name)
+            setattr(other, name, None if v is None else v.clone())
+        other.__dict__.pop("_backing", None)
         kw = {f: getattr(self.cfg, f) for f, _ in self.cfg._fields_}
         other.cfg = type(self.cfg)(**kw)
-        other._st = _lib.EnvState()
-        for k in range(self.sdim):
-            other._st.s[k] = other._s[k].data_ptr()
-        other._st.t = other._t.data_ptr()
-        other._st.done = other._done.data_ptr()
-        other._st.reward = other._reward.data_ptr()
-        other._st.episode = other._episode.data_ptr()
+        other._bind_state()
         return other
 
     def __len__(self):
@@ -223,7 +277,10 @@ class HipVecEnv:
     def set_raw_state(self, s, t=None):
         self._s.copy_(torch.as_tensor(s, dtype=self.T, device=self.device))
         if t is not None:
-            self._t.copy_(torch.as_tensor(t, dtype=torch.int32, device=self.device))
+            t = torch.as_tensor(t, dtype=torch.int32, device=self.device)
+            if self.packed_episode:
+                t = t | (self._t & ~((1 << self.tbits) - 1))
+            self._t.copy_(t)
         self._obs_valid = False
 
 

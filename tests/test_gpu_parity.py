@@ -200,6 +200,82 @@ def test_cartpole_reference_test_config_wide_theta(rl, T, n):
     assert seen_wide == 20 * n
 
 
+@pytest.mark.parametrize("kind,continuous,T", ENV_CASES)
+@pytest.mark.parametrize("n", [4096, 1001])
+def test_packed_episode_counters_give_the_same_trajectories(rl, kind, continuous, T, n):
+    """rlhip_env_state.episode == NULL: the reset counter shares the step-counter word (include/rlhip.h).  Same
+    actions into an env with the separate array and a packed one: every state, reward, flag bit-identical at every
+    step, and the unpacked (step, episode) pair equal to the two arrays -- over several auto-resets per env."""
+    kw = dict(max_torque_noise=0.4) if kind == "acrobot" else {}
+    a = rl.HipVecEnv(kind, n, T=T, continuous=continuous, seed=13, env_id_base=5, max_steps=37, **kw)
+    b = rl.HipVecEnv(kind, n, T=T, continuous=continuous, seed=13, env_id_base=5, max_steps=37, packed_episode=True, **kw)
+    assert b._episode is None and b.tbits == 6
+    npdt = np.float32 if T == torch.float32 else np.float64
+    rng = np.random.default_rng(3)
+
+    def same():
+        assert torch.equal(a.raw_state(), b.raw_state())
+        assert torch.equal(a._t, b.step_counter()) and torch.equal(a._episode, b.episode_counter())
+        assert torch.equal(a._done, b._done) and torch.equal(a.reward(), b.reward())
+        assert torch.equal(a.state(), b.state())
+
+    same()
+    for step in range(150):
+        act = dev(_rand_actions(kind, continuous, n, rng, npdt))
+        a.act0_(act)
+        b.act0_(act)
+        if step % 10 == 0 or step > 140:
+            same()
+            assert torch.equal(a.last_state(), b.last_state())
+    assert int(a._episode.min()) >= 4
+    # masked and forced reset!, seed!
+    a.reset_(is_force=False)
+    b.reset_(is_force=False)
+    same()
+    a.reset_()
+    b.reset_()
+    same()
+    a.seed_(99)
+    b.seed_(99)
+    a.reset_()
+    b.reset_()
+    same()
+    # the fused policy kernels need the separate array and say so
+    if kind == "cartpole" and T == torch.float32 and not continuous:
+        from rlhip._lib import RLHipArgumentError
+
+        pol = rl.PPOPolicy(b, update_freq=4)
+        with pytest.raises(RLHipArgumentError):
+            pol.rollout_()
+
+
+def test_staggered_layout_of_a_large_env_matches_the_oracle(rl):
+    """n >= 2^20: the state arrays are views of one allocation at staggered offsets (rlhip/envs.py) and the step kernel
+    takes its non-temporal path -- teacher-forced against the oracle, packed and separate episode counters"""
+    n = 1 << 20
+    rng = np.random.default_rng(6)
+    for packed in (False, True):
+        env = rl.HipVecEnv("cartpole", n, seed=2, packed_episode=packed, max_steps=20)
+        assert hasattr(env, "_backing") and not env.raw_state().is_contiguous()
+        assert (env._s[1].data_ptr() - env._s[0].data_ptr()) % (4 * n) != 0
+        ref = oracle.VecEnv("cartpole", n, seed=2, max_steps=20)
+        for step in range(30):
+            ref.set_state([host(env.raw_state()[k]) for k in range(4)], host(env.step_counter()))
+            ref.episode[:] = host(env.episode_counter()).view(np.uint32)
+            a = rng.integers(0, 2, n).astype(np.int32)
+            env.act0_(dev(a))
+            ref.step(a)
+            assert np.array_equal(host(env._done), ref.done) and np.array_equal(host(env.step_counter()), ref.t)
+            assert np.array_equal(host(env.episode_counter()).view(np.uint32), ref.episode)
+            for k in range(4):
+                np.testing.assert_allclose(host(env.raw_state()[k]), ref.s[k], rtol=2e-6, atol=1e-7)
+        assert int(env.episode_counter().max()) >= 2
+        twin = env.copy()
+        assert torch.equal(twin.raw_state(), env.raw_state()) and torch.equal(twin._t, env._t)
+        del env, twin
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("T", [torch.float32, torch.float64])
 def test_acrobot_torque_noise_and_wrapper(rl, T):
     """AcrobotEnv: per-step torque noise from the shared Philox stream, reward = -1 after reset!,

@@ -8,7 +8,7 @@ import torch, rlhip
 from rlhip._lib import call
 from rlhip.ops import ptr, stream_ptr
 n = 1 << 24
-env = rlhip.HipVecEnv("cartpole", n, seed=1)
+env = rlhip.HipVecEnv("cartpole", n, seed=1, packed_episode=os.environ.get("RLHIP_UNPACKED", "0") != "1")
 a = torch.randint(0, 2, (16, n), dtype=torch.int32, device="cuda")
 ptrs = [ptr(a[k]) for k in range(16)]
 for i in range(84):
