@@ -46,6 +46,23 @@ static inline int grid_for(int64_t n, int block, int max_blocks = 256 * 8) {
     return (int)g;
 }
 
+// Kernels that synchronise their whole grid through a spin barrier (reduce_apply_kernel<APPLY_GRID / APPLY_XCHG>,
+// d3_apply_kernel) are only launched when every workgroup can be RESIDENT at once with room to spare: the occupancy API's
+// answer for this kernel on this device, minus one workgroup per CU (on gfx950 / ROCm 7.2 the API can be one block per CU
+// high: MI355X_MICROARCH.md, residency), times the CU count of the device actually present (not an assumed 256), and
+// the grid may use at most HALF of that (other streams, other ranks sharing the device, a profiler's kernels).  Work that
+// other streams have already placed on the CUs drains -- it does not wait for us -- so residency is delayed, never
+// denied; a grid beyond the capacity would deadlock, and the callers then take their barrier-free variant.
+template <class K>
+static inline int grid_barrier_capacity(K kernel, int block_threads, size_t dynamic_lds = 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dynamic_lds) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (per_cu > 1) per_cu -= 1;
+    return (per_cu * cus) / 2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10, ctr = {idx, blk, t, tag}, key = {seed_lo, seed_hi}.  Same specification as the
 // oracle (oracle/rlo_rng.c) -- shared by specification, not by code; checked by tests/.

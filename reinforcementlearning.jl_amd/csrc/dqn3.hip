@@ -1123,10 +1123,29 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
         apply->sumsq = (double*)((char*)workspace + base);
         apply->counter = (unsigned int*)((char*)workspace + base + 256 * sizeof(double));
         apply->ns = ns;
-        // the kernel spins on a grid-wide counter: every workgroup must be resident at once (69 for np = 17 410)
-        RLHIP_REQUIRE((np + 255) / 256 <= 256, "too many parameters for the grid-barrier optimiser tail");
-        hipLaunchKernelGGL(d3_apply_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials,
-                           nb, (int)np, grad_out, loss_out, g.inv_b, *apply);
+        // the kernel spins on a grid-wide counter: every workgroup must be resident at once (69 for np = 17 410) --
+        // checked against the occupancy of this kernel on this device (grid_barrier_capacity, common.h); beyond it the
+        // tail runs as the launches it fuses (bit-identical): reduce, clip + Adam, bf16 re-pack
+        static int cap = -1;
+        if (cap < 0) {
+            cap = grid_barrier_capacity(d3_apply_kernel, 256);
+            const char* e = getenv("RLHIP_GRID_BARRIER_CAP");
+            if (e) cap = atoi(e);
+        }
+        if ((np + 255) / 256 <= cap) {
+            hipLaunchKernelGGL(d3_apply_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials,
+                               nb, (int)np, grad_out, loss_out, g.inv_b, *apply);
+        } else {
+            hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
+                               nb, (int)np, grad_out, loss_out, g.inv_b);
+            RLHIP_LAUNCH_CHECK();
+            int32_t rc2 = rlhip_clip_adam_f32(apply->p, grad_out, apply->m, apply->v, apply->beta_pow, np, apply->grad_scale,
+                                              apply->clip_norm, apply->lr, apply->b1, apply->b2, apply->eps, apply->gn_out,
+                                              stream);
+            if (rc2) return rc2;
+            rc2 = rlhip_mlp3_pack_bf16(apply->p, ns, h, na, apply->packed, stream);
+            if (rc2) return rc2;
+        }
     } else {
         hipLaunchKernelGGL(d3_reduce_kernel, dim3((int)((np + 63) / 64)), dim3(256), 0, s, g.partials, g.loss_partials,
                            nb, (int)np, grad_out, loss_out, g.inv_b);

@@ -485,8 +485,6 @@ struct ApplyArgs {
 // of reduce + clip_adam.
 constexpr int RP = 64;  // parameters per reduce workgroup (x 16 partial-groups = 1024 threads)
 constexpr int APPLY_NONE = 0, APPLY_LAST = 1, APPLY_GRID = 2, APPLY_XCHG = 3;
-constexpr int GRID_APPLY_MAX_BLOCKS = 128;  // all workgroups must be co-resident for the spin barrier (256 CUs x 2)
-
 // peer exchange of the sharded learner fused into the reduce + apply kernel (APPLY_XCHG; protocol: p2p.hip)
 struct XchgArgs {
     float* slot[16];          // comm buffer of every rank (two slots of `cap` floats, then two u32 flags)
@@ -510,6 +508,15 @@ __device__ __forceinline__ int64_t record_slot(int64_t q, int h, int ns, int nou
     if (w < (int64_t)no * h) return base + 8 * (w / no) + 5 + (w % no);         // W2[o + no j] -> rec[j][5 + o]
     return 16 * (int64_t)h + (net ? 3 : (w - (int64_t)no * h));                 // output biases -> tail
 }
+
+template <int APPLY>
+__global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restrict__ partials,
+                                                            const float* __restrict__ loss_partials, int nb,
+                                                            int np, float* __restrict__ grad,
+                                                            float* __restrict__ losses, float wa, float wc,
+                                                            float we, float inv_b, ApplyArgs ap, XchgArgs xa);
+template <int APPLY>
+static auto reduce_apply_kernel_ptr() { return &reduce_apply_kernel<APPLY>; }
 
 template <int APPLY>
 __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restrict__ partials,
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
     }
     if (APPLY == APPLY_GRID) {
         // ---- every workgroup applies Adam to ITS OWN 64 parameters after a grid-wide barrier on the norm ----
-        // All workgroups are co-resident (host guarantees gridDim <= GRID_APPLY_MAX_BLOCKS), so a spin barrier on an
+        // All workgroups are co-resident (the host launches this variant only for gridDim <= grid_apply_max_blocks()), so a spin barrier on an
         // agent-scope counter is safe.  Only wave 0 (which holds the 64 reduced gradient values in registers)
         // continues; the other 15 waves are done.  The serial tail of the last-arriver variant (one workgroup running
         // Adam over all np parameters + re-packing every record) becomes 53 parallel 64-lane updates.
@@ -782,6 +789,19 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         ap.beta_pow[1] *= ap.b2;
         __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
     }
+}
+
+// all workgroups of the grid-barrier variants must be co-resident: the bound comes from the occupancy of the kernel on the
+// device at hand (grid_barrier_capacity, common.h), queried once per process
+template <int APPLY>
+static int grid_apply_max_blocks() {
+    static int cap = -1;
+    if (cap < 0) {
+        cap = grid_barrier_capacity(reduce_apply_kernel_ptr<APPLY>(), 1024);
+        const char* e = getenv("RLHIP_GRID_BARRIER_CAP");  // test hook: force the barrier-free variants (0) or a small device
+        if (e) cap = atoi(e);
+    }
+    return cap;
 }
 
 static int grad_blocks(int num_tiles) {
@@ -1040,8 +1060,8 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
     uint32_t seq = seq0;
     bool first = true;
     const int rblocks = (int)((np + RP - 1) / RP);
-    const bool fused = !is_layers3(cfg) && rblocks <= GRID_APPLY_MAX_BLOCKS && world <= 16 && comm_cap <= (1 << 24) &&
-                       !RLHIP_ENV_FLAG("RLHIP_P2P_UNFUSED");
+    const bool fused = !is_layers3(cfg) && rblocks <= grid_apply_max_blocks<APPLY_XCHG>() && world <= 16 &&
+                       comm_cap <= (1 << 24) && !RLHIP_ENV_FLAG("RLHIP_P2P_UNFUSED");
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
@@ -1168,7 +1188,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                          L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
             const int rblocks = (int)((L.np + RP - 1) / RP);
-            if (rblocks <= GRID_APPLY_MAX_BLOCKS && !RLHIP_ENV_FLAG("RLHIP_APPLY_LAST_ARRIVER"))
+            if (rblocks <= grid_apply_max_blocks<APPLY_GRID>() && !RLHIP_ENV_FLAG("RLHIP_APPLY_LAST_ARRIVER"))
                 hipLaunchKernelGGL((reduce_apply_kernel<APPLY_GRID>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
                                    L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
                                    L.g.inv_b, ap, XchgArgs{});

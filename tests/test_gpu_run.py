@@ -1,6 +1,7 @@
 """GPU tests of the drop-in surface: run(policy, env, stop, hook) on the vector env, Agent + trajectory +
 DQN learner end to end, and the multi-process gradient all-reduce with the real kernels (2 ranks sharing
 one GPU over `gloo`, because RCCL refuses two ranks on one device)."""
+import ctypes as C
 import os
 import socket
 import subprocess
@@ -415,3 +416,67 @@ def test_bench_two_ranks_on_one_device_prints_the_contract_line():
     assert ar["library_us_at_gradient_size"] > 0 and len(ar["library_sweep"]) == 5
     if d["gradient_allreduce"].startswith("p2p"):
         assert d["p2p_timeouts"] is False and ar["p2p_us_at_gradient_size"] > 0
+
+
+def _grid_barrier_probe():
+    """one PPO update (reduce_apply_kernel<APPLY_GRID>) + a few 3-layer DQN updates (d3_apply_kernel): parameter bytes"""
+    import rlhip
+
+    env = rlhip.CartPoleEnv(512, seed=3)
+    pol = rlhip.PPOPolicy(env, update_freq=8, seed=3)
+    pol.rollout_()
+    pol.update_()
+    n = 128
+    e2 = rlhip.CartPoleEnv(n, seed=5)
+    net = rlhip.HipApproximator(4, 128, 2, seed=5, layers=3)
+    tn = rlhip.TargetNetwork(net, sync_freq=3)
+    learner = rlhip.DQNLearner(tn, batchsize=64, min_replay_history=2 * n, seed=5, max_grad_norm=1.0)
+    policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.1, seed=5))
+    agent = rlhip.Agent(policy, rlhip.Trajectory(rlhip.CircularArraySARTSTraces(capacity=8, n_env=n, obs_dim=4)))
+    rlhip.run_fused_dqn(agent, e2, rlhip.StopAfterNSteps(12))
+    torch.cuda.synchronize()
+    return pol.params.cpu().numpy().tobytes() + net.params.cpu().numpy().tobytes(), learner.n_updates
+
+
+def test_grid_barrier_kernels_while_another_stream_saturates_the_device():
+    """the spin-barrier kernels (occupancy-sized grids, csrc/common.h grid_barrier_capacity) must
+    finish -- with the same bits -- while a second stream keeps every CU busy with thousands of streaming workgroups"""
+    import rlhip
+    from rlhip._lib import call
+    from rlhip.ops import ptr
+
+    quiet, nup = _grid_barrier_probe()
+    assert nup >= 8
+    big = rlhip.HipVecEnv("cartpole", 1 << 22, seed=1, packed_episode=True)
+    acts = torch.randint(0, 2, (1 << 22,), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(400):  # ~40 us x 400 of 4096-workgroup launches queued on the side stream
+            call("rlhip_env_step", big.kind, 0, C.byref(big.cfg), C.byref(big._st), big.n, ptr(acts), 1, big.seed, 0, None,
+                 None, C.c_void_p(side.cuda_stream))
+    busy, _ = _grid_barrier_probe()  # enqueued while the side stream is saturating the device
+    torch.cuda.synchronize()
+    assert busy == quiet
+
+
+def test_barrier_free_fallback_of_the_optimiser_tails_is_bit_identical():
+    """RLHIP_GRID_BARRIER_CAP=0 (what a device too small for co-residency gets): the last-arriver reduce_apply variant
+    and the unfused 3-layer tail produce the same parameters as the grid-barrier kernels"""
+    import hashlib
+
+    src = ("import os, sys, hashlib\n"
+           "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+           "import torch\n"
+           "import tests.test_gpu_run as t\n"
+           "b, n = t._grid_barrier_probe()\n"
+           "print('HASH', hashlib.sha256(b).hexdigest(), n)\n") % (
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reinforcementlearning.jl_amd"))
+    env = dict(os.environ, RLHIP_GRID_BARRIER_CAP="0")
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0].split()
+    here, nup = _grid_barrier_probe()
+    assert line[1] == hashlib.sha256(here).hexdigest() and int(line[2]) == nup
