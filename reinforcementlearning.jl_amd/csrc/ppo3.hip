@@ -551,6 +551,11 @@ __global__ __launch_bounds__(256) void ppo3_grad_kernel(P3Args g) {
 constexpr size_t GRAD3_LDS = (4 * TR + 2 * MAXO * TR + 4 * TR + 16 + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
                              3 * TILE_ELEMS * sizeof(uint16_t);
 
+}  // namespace rlhip
+#include "ppo3t_kernel.h"
+namespace rlhip {
+static bool g_ppo3_force128 = false;  // test hook (rlhip_debug_ppo3_force128): the round-1 tile for A / B comparisons
+
 // both nets' W2 -> bf16 MFMA fragments: [actor W2jk | actor W2kj | critic W2jk | critic W2kj]
 __global__ __launch_bounds__(256) void ppo3_pack_kernel(const float* __restrict__ params, int ns, int64_t np_a,
                                                         uint16_t* __restrict__ packed) {
@@ -751,8 +756,32 @@ int32_t ppo3_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, 
     g.pk = perm_keys(seed, epoch_ctr, (uint32_t)total);
     if (do_pack)
         hipLaunchKernelGGL(ppo3_pack_kernel, dim3(2 * H3 * H3 / 256), dim3(256), 0, s, params, ns, g.np_a, packed);
+    // default: the register-chained tile (ppo3t_kernel.h), persistent workgroups, one partial row per workgroup and net;
+    // RLHIP_PPO3_GRAD128=1 keeps the round-1 kernel (one 128-row tile per workgroup) for A/B comparison
+    // (relu only: the tanh instantiations of the chained tile need 64 more live registers for act'(h1), spill ~300
+    //  dwords per lane and -- cartpole / tanh -- came out of the compiler computing a wrong actor loss; they stay on the
+    //  round-1 tile, which tests/test_gpu_ppo3.py pins against the oracle)
+    const bool chained = pd.act == 0 && !(g_ppo3_force128 || RLHIP_ENV_FLAG("RLHIP_PPO3_GRAD128"));
+    const int ntiles = (int)nb;
+    static int t3_wg_cap = -1;
+    if (t3_wg_cap < 0) {
+        const char* e = getenv("RLHIP_PPO3_WGS");
+        t3_wg_cap = e ? atoi(e) : 128;
+        if (t3_wg_cap < 1 || t3_wg_cap > 1024) t3_wg_cap = 128;
+    }
+    const int nwg = ntiles < t3_wg_cap ? ntiles : t3_wg_cap;  // per net
+    const int nrows = chained ? nwg : (int)nb;
+    g.loss_partials = g.partials + (int64_t)nrows * g.np;
 #define LAUNCH_G3(NS_, ACT_, CONT_)                                                                       \
     do {                                                                                                  \
+        if (chained) {                                                                                    \
+            static bool donet_ = false;                                                                   \
+            int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, 0, CONT_>, GRADT_LDS, &donet_);               \
+            if (rc_) return rc_;                                                                          \
+            hipLaunchKernelGGL((ppo3_gradT_kernel<NS_, 0, CONT_>), dim3(2 * nwg), dim3(256), GRADT_LDS, s, g, nwg, \
+                               ntiles);                                                                   \
+            break;                                                                                        \
+        }                                                                                                 \
         static bool done_ = false;                                                                        \
         int32_t rc_ = allow_lds3(ppo3_grad_kernel<NS_, 2, ACT_, CONT_>, GRAD3_LDS, &done_);               \
         if (rc_) return rc_;                                                                              \
@@ -768,11 +797,25 @@ int32_t ppo3_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, 
         else LAUNCH_G3(3, 1, 1);
     }
 #undef LAUNCH_G3
-    hipLaunchKernelGGL(ppo3_reduce_kernel, dim3((g.np + 63) / 64), dim3(256), 0, s, g.partials, g.loss_partials, (int)nb,
+    hipLaunchKernelGGL(ppo3_reduce_kernel, dim3((g.np + 63) / 64), dim3(256), 0, s, g.partials, g.loss_partials, nrows,
                        g.np, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
+
+/* test hook, not part of include/rlhip.h: 1 = the round-1 128-row tile for every PPO layers = 3 gradient */
+extern "C" int32_t rlhip_debug_ppo3_force128(int32_t on) {
+    g_ppo3_force128 = on != 0;
+    return RLHIP_OK;
+}
+
+#ifdef RLHIP_T3_TIMING
+extern "C" int32_t rlhip_debug_t3_stamps(long long* out_host) {
+    RLHIP_CHECK_HIP(hipDeviceSynchronize());
+    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_t3_stamps), 16 * sizeof(long long)));
+    return RLHIP_OK;
+}
+#endif
 
 int32_t ppo3_update(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                     float* params, float* m, float* v, float* beta_pow, uint64_t seed, uint32_t update_ctr,

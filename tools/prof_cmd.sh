@@ -1,13 +1,12 @@
 #!/bin/bash
-# usage: tools/prof_cmd.sh <tag> <python script> [args...] -- rocprofv3 kernel-trace stats of any script
-tag=$1; shift
+# usage: tools/prof_cmd.sh <tag> <script.py> [args...]  -- rocprofv3 kernel-trace stats of a tools/ script -> top kernels
+tag=$1; script=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o run -- python $GRAFT_REPO_ROOT/"$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
-grep -v "^W2026\|^E2026\|amdgpu.ids" $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log | tail -15
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o p -- python $GRAFT_REPO_ROOT/$script "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:12]:
-    print(f"{r['Name'].split('(')[0][-70:]:70s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} min_us={float(r['MinNs'])/1e3:9.2f} max_us={float(r['MaxNs'])/1e3:9.2f}")
+for r in rows[:10]:
+    print(f"{r['Name'].split('(')[0][-80:]:80s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
 PY
