@@ -829,6 +829,10 @@ struct D3Apply {
     unsigned int* counter;   // [0] arrive, [1] depart: zero before the first launch, re-armed here
     float grad_scale, clip_norm, lr, b1, b2, eps;
     int ns;
+    // PPO actor / critic (ppo3.hip): two nets in one flat vector, [actor (np_a) | critic]; np_a = 0: one net (DQN).
+    // packed then holds [actor W2jk | W2kj | critic W2jk | W2kj]; the loss line is the four PPO numbers.
+    int np_a;
+    float wa, wc, we;
 };
 
 __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__ partials,
@@ -865,23 +869,59 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
                 a[q] = acc;
             }
         } else {
+            // 64 loads in flight per trip (32 rows of two of the four groups): with up to 512 partial rows coming from
+            // other XCDs' L2 slices every dependent round trip costs ~2 us, and the adds must stay sequential per group --
+            // the same ascending order as d3_reduce_kernel / ppo3_reduce_kernel (x + 0.0f is exact: padded slots change no bit)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int b0 = q * per, b1 = min(nb, b0 + per);
-                float acc = 0.f;
-#pragma unroll 8
-                for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * np + i];
-                a[q] = acc;
+            for (int qp = 0; qp < 4; qp += 2) {
+                const int b0a = qp * per, b1a = min(nb, b0a + per);
+                const int b0b = (qp + 1) * per, b1b = min(nb, b0b + per);
+                float acca = 0.f, accb = 0.f;
+                for (int off = 0; off < per; off += 32) {
+                    float ta[32], tb[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        ta[u] = (b0a + off + u < b1a) ? partials[(int64_t)(b0a + off + u) * np + i] : 0.0f;
+                        tb[u] = (b0b + off + u < b1b) ? partials[(int64_t)(b0b + off + u) * np + i] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        acca += ta[u];
+                        accb += tb[u];
+                    }
+                }
+                a[qp] = acca;
+                a[qp + 1] = accb;
             }
         }
         g = ((a[0] + a[1]) + a[2]) + a[3];
     }
-    if (blockIdx.x == 0 && loss != nullptr && wv == 1) {
+    if (blockIdx.x == 0 && loss != nullptr && ap.np_a == 0 && wv == 1) {
         float a = 0.f;
         for (int b = lane; b < nb; b += 64) a += loss_partials[b];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
         if (lane == 0) loss[0] = a * inv_b;
+    }
+    if (blockIdx.x == 0 && loss != nullptr && ap.np_a > 0) {  // ppo3_reduce_kernel's loss line (block-uniform branch)
+        __shared__ float l_loss[4];
+        if (wv < 3) {
+            float a = 0.f;
+            for (int b = lane; b < nb; b += 64) a += loss_partials[(int64_t)b * 4 + wv];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) l_loss[wv] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float actor_loss = -l_loss[0] * inv_b;
+            const float critic_loss = l_loss[1] * inv_b;
+            const float ent_loss = l_loss[2] * inv_b;
+            loss[0] = ap.wa * actor_loss + ap.wc * critic_loss - ap.we * ent_loss;
+            loss[1] = actor_loss;
+            loss[2] = critic_loss;
+            loss[3] = ent_loss;
+        }
     }
     // sumsq_scaled_partial_kernel (one element per lane at this size)
     const float x = own ? g * ap.grad_scale : 0.0f;
@@ -914,14 +954,16 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
         ap.v[i] = vi;
         grad[i] = gi;
         // mlp3_pack_kernel, parameter-centric: W2[j + H3 k] goes to one slot of each fragment orientation
-        const int e = i - (H3 * ap.ns + H3);
+        const bool second = ap.np_a > 0 && i >= ap.np_a;  // the critic of a PPO pair
+        const int e = (second ? i - ap.np_a : i) - (H3 * ap.ns + H3);
         if (e >= 0 && e < H3 * H3) {
             const int j = e & (H3 - 1), k = e >> 7;
             const uint16_t hb = f32_to_bf16_rne(pi);
             const int q1 = (((k >> 4) * 4 + (j >> 5)) << 9) | (((j & 31) + 32 * ((k >> 3) & 1)) << 3) | (k & 7);
             const int q2 = (((j >> 4) * 4 + (k >> 5)) << 9) | (((k & 31) + 32 * ((j >> 3) & 1)) << 3) | (j & 7);
-            ap.packed[q1] = hb;
-            ap.packed[H3 * H3 + q2] = hb;
+            uint16_t* pk = ap.packed + (second ? 2 * H3 * H3 : 0);
+            pk[q1] = hb;
+            pk[H3 * H3 + q2] = hb;
         }
     }
     __syncthreads();  // every lane of this workgroup has read beta_pow
@@ -936,6 +978,31 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
             __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+// optimiser tail of the 3-layer PPO learner (ppo3.hip): partial rows -> gradient, PPO loss line, Float64 norm, clip,
+// Adam, bf16 re-pack of both nets' W2 in ONE launch behind a grid barrier -- the arithmetic of ppo3_reduce_kernel,
+// sumsq_scaled_partial_kernel, clip_adam_grid_kernel and ppo3_pack_kernel, which it replaces (their sequence stays the
+// fallback when the grid does not fit the device: grid_barrier_capacity).  tail: 256 doubles + 16 counters, zero before
+// the first call.  Returns 1 when the caller has to run the unfused sequence.
+int32_t ppo3_apply_fused(const float* partials, const float* loss_partials, int nb, int np, int np_a, int ns, float* grad,
+                         float* losses, float inv_b, float wa, float wc, float we, float* params, float* m, float* v,
+                         float* beta_pow, uint16_t* packed, void* tail, float clip_norm, float lr, float b1, float b2,
+                         float eps, hipStream_t s) {
+    static int cap = -1;
+    if (cap < 0) {
+        cap = grid_barrier_capacity(d3_apply_kernel, 256);
+        const char* e = getenv("RLHIP_GRID_BARRIER_CAP");
+        if (e) cap = atoi(e);
+    }
+    const int grid = (np + 255) / 256;
+    if (grid > cap || grid > 256 || RLHIP_ENV_FLAG("RLHIP_PPO3_UNFUSED_TAIL")) return 1;
+    D3Apply ap{params, m, v, beta_pow, nullptr, packed, (double*)tail, (unsigned int*)((double*)tail + 256), 1.0f,
+               clip_norm, lr, b1, b2, eps, ns, np_a, wa, wc, we};
+    hipLaunchKernelGGL(d3_apply_kernel, dim3(grid), dim3(256), 0, s, partials, loss_partials, nb, np, grad, losses, inv_b,
+                       ap);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
 }
 
 constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
@@ -1173,7 +1240,7 @@ int32_t rlhip_dqn3_update_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32
                               rlhip_stream_t stream) {
     RLHIP_REQUIRE(m && v && beta_pow, "NULL argument");
     D3Apply ap{params, m, v, beta_pow, gn_out, packed, nullptr, nullptr, grad_scale, max_grad_norm, lr, beta1, beta2,
-               adam_eps, 0};
+               adam_eps, 0, 0, 0.f, 0.f, 0.f};
     return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, nullptr, gamma,
                           huber_delta, seed, draw_ctr, workspace, grad_out, loss_out, nullptr, stream, &ap);
 }

@@ -31,7 +31,13 @@ extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, flo
 
 namespace rlhip {
 
+int32_t ppo3_apply_fused(const float* partials, const float* loss_partials, int nb, int np, int np_a, int ns, float* grad,
+                         float* losses, float inv_b, float wa, float wc, float we, float* params, float* m, float* v,
+                         float* beta_pow, uint16_t* packed, void* tail, float clip_norm, float lr, float b1, float b2,
+                         float eps, hipStream_t s);  // dqn3.hip
+
 constexpr int P3_MAX_BLOCKS = 2048;
+constexpr int64_t P3_TAIL_BYTES = 256 * 8 + 64 + 64;  // fused optimiser tail: Float64 partial norms + counters (zero-initialised)
 
 __host__ __device__ __forceinline__ int64_t mlp3_np(int64_t ns, int64_t nout) {
     return H3 * ns + H3 + (int64_t)H3 * H3 + H3 + nout * H3 + nout;
@@ -683,7 +689,7 @@ int64_t ppo3_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* c, int64_t n, in
     const int64_t np = ppo3_nparams(kind, c);
     if (np < 0) return -1;
     const int64_t nb = ppo3_nb(c, n, T);
-    return 4 * H3 * H3 * (int64_t)sizeof(uint16_t) + nb * (np + 4) * (int64_t)sizeof(float) + 256;
+    return 4 * H3 * H3 * (int64_t)sizeof(uint16_t) + nb * (np + 4) * (int64_t)sizeof(float) + 256 + P3_TAIL_BYTES;
 }
 
 int32_t ppo3_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, int64_t T,
@@ -708,9 +714,25 @@ int32_t ppo3_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* s
 }
 
 // one micro-batch: pack -> grad -> reduce; grad_out = summed gradient, losses_out (4) optional
+struct P3Tail {  // optimise! state for the fused tail (ppo3_update); *fused_out tells the caller whether it ran
+    float *params, *m, *v, *beta_pow;
+    bool* fused_out;
+};
+
+static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
+                              const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace,
+                              float* grad_out, float* losses_out, bool do_pack, rlhip_stream_t stream, const P3Tail* tail);
+
 int32_t ppo3_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                   const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace, float* grad_out,
                   float* losses_out, bool do_pack, rlhip_stream_t stream) {
+    return ppo3_grad_impl(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_out, losses_out, do_pack, stream,
+                          nullptr);
+}
+
+static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
+                              const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace,
+                              float* grad_out, float* losses_out, bool do_pack, rlhip_stream_t stream, const P3Tail* tail) {
     PolicyDesc pd;
     int32_t rc = check3(kind, cfg, &pd);
     if (rc) return rc;
@@ -797,6 +819,18 @@ int32_t ppo3_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, 
         else LAUNCH_G3(3, 1, 1);
     }
 #undef LAUNCH_G3
+    if (tail) {
+        // reduce + PPO loss line + Float64 norm + clip + Adam + bf16 re-pack of both W2 in one launch (dqn3.hip)
+        char* tp = (char*)workspace + ppo3_workspace_bytes(kind, cfg, n, T) - P3_TAIL_BYTES;
+        tp = (char*)(((uintptr_t)tp + 63) & ~(uintptr_t)63);
+        const int32_t rcf = ppo3_apply_fused(g.partials, g.loss_partials, nrows, g.np, (int)g.np_a, ns, grad_out, losses_out,
+                                             g.inv_b, g.wa, g.wc, g.we, tail->params, tail->m, tail->v, tail->beta_pow,
+                                             packed, tp, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
+                                             s);
+        if (rcf < 0) return rcf;
+        *tail->fused_out = rcf == 0;
+        if (rcf == 0) return RLHIP_OK;
+    }
     hipLaunchKernelGGL(ppo3_reduce_kernel, dim3((g.np + 63) / 64), dim3(256), 0, s, g.partials, g.loss_partials, nrows,
                        g.np, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b);
     RLHIP_LAUNCH_CHECK();
@@ -823,15 +857,21 @@ int32_t ppo3_update(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T
     RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
     const int64_t np = ppo3_nparams(kind, cfg);
     RLHIP_REQUIRE(np > 0, "bad configuration");
+    bool packed_fresh = false;  // the previous optimiser step's fused tail left the bf16 W2 images up to date
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
-            int32_t rc = ppo3_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_scratch,
-                                   losses_out, /*do_pack=*/true, stream);
+            bool fused = false;
+            const P3Tail tail{params, m, v, beta_pow, &fused};
+            int32_t rc = ppo3_grad_impl(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_scratch,
+                                        losses_out, /*do_pack=*/!packed_fresh, stream, &tail);
             if (rc) return rc;
-            rc = rlhip_clip_adam_f32(params, grad_scratch, m, v, beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr,
-                                     cfg->beta1, cfg->beta2, cfg->adam_eps, nullptr, stream);
-            if (rc) return rc;
+            packed_fresh = fused;
+            if (!fused) {
+                rc = rlhip_clip_adam_f32(params, grad_scratch, m, v, beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr,
+                                         cfg->beta1, cfg->beta2, cfg->adam_eps, nullptr, stream);
+                if (rc) return rc;
+            }
         }
     }
     return RLHIP_OK;

@@ -62,15 +62,23 @@ constexpr size_t GRADT_LDS = 4 * T3_FRAG * sizeof(uint16_t) + (H3 * 4 + H3 + H3 
 __device__ __forceinline__ bf16x8 as_frag(const float (&v)[8]) { return __builtin_bit_cast(bf16x8, pack8_bf16(v)); }
 __device__ __forceinline__ int t3_row(int q, int kb) { return (q & 3) + 8 * (q >> 2) + 4 * kb; }
 
-// natural fragment image (lane = column, 8 consecutive k: ppo3_pack_kernel) -> the pi-ordered image in LDS
-__device__ __forceinline__ void stage_pi_image(const uint16_t* __restrict__ nat, uint16_t* l_img, int tid) {
-    for (int q8 = tid; q8 < T3_FRAG / 8; q8 += 256) {
+// natural fragment images (lane = column, 8 consecutive k: ppo3_pack_kernel; W2jk then W2kj, 2 x 32 KB contiguous) -> the
+// pi-ordered images in LDS.  All 32 8-byte loads of a thread are issued before the first LDS store: one L2 round trip
+// for the 64 KB instead of sixteen (the per-launch fixed cost of this kernel was ~20 us, half of a 2-tile launch).
+__device__ __forceinline__ void stage_pi_images(const uint16_t* __restrict__ nat, uint16_t* l_img, int tid) {
+    constexpr int IT = 2 * T3_FRAG / 8 / 256;  // 16 slots of 16 bytes per thread over both images
+    uint2 a0[IT], a1[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int q8 = tid + 256 * it;
         const int l = q8 & 63, f = q8 >> 6;
         const int cc = l & 31, kk = l >> 5;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(nat + ((size_t)(f * 64 + cc) * 8 + 4 * kk));
-        const uint2 a1 = *reinterpret_cast<const uint2*>(nat + ((size_t)(f * 64 + cc + 32) * 8 + 4 * kk));
-        *reinterpret_cast<uint4*>(l_img + 8 * q8) = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        a0[it] = *reinterpret_cast<const uint2*>(nat + ((size_t)(f * 64 + cc) * 8 + 4 * kk));
+        a1[it] = *reinterpret_cast<const uint2*>(nat + ((size_t)(f * 64 + cc + 32) * 8 + 4 * kk));
     }
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+        *reinterpret_cast<uint4*>(l_img + 8 * (size_t)(tid + 256 * it)) = make_uint4(a0[it].x, a0[it].y, a1[it].x, a1[it].y);
 }
 
 template <int NS, int NOUT, int ACT, int CONT, int CRITIC>
@@ -96,8 +104,7 @@ __device__ __forceinline__ void ppo3T_body(const P3Args& g, int wg, int nwg, int
     const uint16_t* __restrict__ pk = g.packed + (CRITIC ? 2 * H3 * H3 : 0);
 
     // ---- stage the weights ----
-    stage_pi_image(pk, l_F, tid);
-    stage_pi_image(pk + H3 * H3, l_G, tid);
+    stage_pi_images(pk, l_F, tid);  // l_G follows l_F, W2kj follows W2jk: one pass over both
     if (tid < H3) {
         const int u = tid;
         l_w1r[u] = make_float4(W1[u], NS > 1 ? W1[u + H3] : 0.f, NS > 2 ? W1[u + 2 * H3] : 0.f, NS > 3 ? W1[u + 3 * H3] : 0.f);

@@ -145,7 +145,7 @@ def test_layers3_rejects_unsupported_configs():
 def test_chained_tile_equals_the_round1_tile(kind, cont, n, T):
     """ppo3_gradT_kernel (register-chained tile, persistent workgroups, csrc/ppo3t_kernel.h) against ppo3_grad_kernel
     (one 128-row tile per workgroup) on the same micro-batches: identical roundings, different summation order ->
-    gradients within 1e-4 of max|g| per tensor (measured <= 1.4e-5: W1, behind two bf16 MFMA layers), loss numbers within 1e-5; both are pinned to the oracle above.
+    gradients within BF16_GRAD_TOL of max|g| per tensor (measured: 1e-7 typical, 1.6e-4 when one of the ~10^6 relu decisions of a 12288-sample micro-batch sits within an ulp of zero and flips), loss numbers within 1e-5; both are pinned to the oracle above.
     Sizes: many tiles per persistent workgroup (pendulum: 12288-sample micro-batches = 96 tiles over <= 128 workgroups
     with RLHIP_PPO3_WGS unset) and a ragged single-tile case."""
     import rlhip
@@ -174,7 +174,7 @@ def test_chained_tile_equals_the_round1_tile(kind, cont, n, T):
         for name, a, b, no in (("actor", g0[:np_a], g1[:np_a], nout), ("critic", g0[np_a:], g1[np_a:], 1)):
             o = 0
             for tname, sz in (("W1", 128 * ns), ("b1", 128), ("W2", 128 * 128), ("b2", 128), ("W3", no * 128), ("b3", no)):
-                assert_grad_close(a[o:o + sz], b[o:o + sz], 1e-4, f"chained vs round-1 tile {kind} {name} {tname}")
+                assert_grad_close(a[o:o + sz], b[o:o + sz], BF16_GRAD_TOL, f"chained vs round-1 tile {kind} {name} {tname}")
                 o += sz
     # and a full update with the chained tile keeps training finite
     pol.update_()

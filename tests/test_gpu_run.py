@@ -434,8 +434,15 @@ def _grid_barrier_probe():
     policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.1, seed=5))
     agent = rlhip.Agent(policy, rlhip.Trajectory(rlhip.CircularArraySARTSTraces(capacity=8, n_env=n, obs_dim=4)))
     rlhip.run_fused_dqn(agent, e2, rlhip.StopAfterNSteps(12))
+    # 3-layer PPO: gradient + fused optimiser tail (d3_apply_kernel with two nets: reduce, loss line, norm, clip, Adam,
+    # bf16 re-pack of both W2) -- or, without the grid barrier, reduce / clip_adam / pack as separate launches
+    e3 = rlhip.HipVecEnv("pendulum", 256, seed=9)
+    p3 = rlhip.PPOPolicy(e3, update_freq=8, hidden=128, seed=9, layers=3)
+    p3.rollout_()
+    p3.update_()
     torch.cuda.synchronize()
-    return pol.params.cpu().numpy().tobytes() + net.params.cpu().numpy().tobytes(), learner.n_updates
+    return (pol.params.cpu().numpy().tobytes() + net.params.cpu().numpy().tobytes() + p3.params.cpu().numpy().tobytes()
+            + p3.losses.cpu().numpy().tobytes()), learner.n_updates
 
 
 def test_grid_barrier_kernels_while_another_stream_saturates_the_device():
