@@ -416,7 +416,7 @@ def run_fused_dqn(agent, env, stop_condition=None, hook=None):
         # the transition pushed by this call counts towards min_replay_history / the sample-ratio controller
         ctrl.on_insert_(1)
         n_after = min(len(traces) + 1, traces.capacity) * traces.n_env
-        a.do_update = int(n_after >= learner.min_replay_history)
+        a.do_update = int(learner.should_update_(traj, n_after))  # warm-up, update_freq, sample / insert controller
         a.draw_ctr = learner.draw_ctr
         a.do_sync = int(a.do_update and (tn.n_optimise + 1) % tn.sync_freq == 0)
         call("rlhip_dqn_vec_step_f32", C.byref(a), s)

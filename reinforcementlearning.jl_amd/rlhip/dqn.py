@@ -223,8 +223,16 @@ class TargetNetwork:
 # -------------------------------------------------------------------------------------- learner
 class DQNLearner:
     """BasicDQN / DQN learner on a device trajectory: every `update_freq` vec-steps (once
-    `min_replay_history` transitions are stored) sample a batch, TD target with the target network,
-    Huber loss, gradient, [all-reduce], Adam, target sync."""
+    `min_replay_history` transitions are stored, and while the trajectory's InsertSampleRatioController
+    allows another batch) sample a batch, TD target with the target network, Huber loss, gradient,
+    [all-reduce], Adam, target sync.  At most ONE batch per optimise! call (the reference's
+    `for batch in trajectory` may yield several to catch up after a warm-up; a vec-step already inserts
+    n_env transitions at once).
+
+    Prioritized replay (CircularPrioritizedTraces): batches are drawn in proportion to the stored priorities
+    and (|td| + per_eps)^per_alpha is written back, WITHOUT importance-sampling weights in the loss
+    (beta = 0 in the PER paper's notation): the update is the proportional-sampling variant, not
+    annealed-IS PrioritizedDQN."""
 
     def __init__(self, approximator, batchsize=32, gamma=0.99, huber_delta=1.0, min_replay_history=100,
                  update_freq=1, max_grad_norm=0.0, seed=0, process_group=None, per_eps=1e-6, per_alpha=0.6):
@@ -233,7 +241,10 @@ class DQNLearner:
         net = approximator.network
         self.batchsize, self.gamma, self.delta = batchsize, gamma, huber_delta
         self.min_replay_history, self.update_freq, self.max_grad_norm = min_replay_history, update_freq, max_grad_norm
+        if int(update_freq) < 1:
+            raise ValueError("update_freq must be >= 1")
         self.seed, self.draw_ctr, self.n_updates = seed, 0, 0
+        self.vec_steps = 0  # optimise! calls so far (one per vec-step): the update_freq gate
         self.process_group = process_group
         self.grad = torch.zeros_like(net.params)
         self.loss = torch.zeros(1, dtype=torch.float32, device=net.params.device)
@@ -246,9 +257,18 @@ class DQNLearner:
     def forward(self, x):
         return self.approximator.forward(x)
 
+    def should_update_(self, trajectory, n_transitions=None):
+        """the gate of optimise!: warm-up, every `update_freq`-th vec-step, the trajectory's sample / insert controller.
+        Advances the vec-step counter (call once per vec-step; run_fused_dqn uses it for its `do_update` flag)."""
+        self.vec_steps += 1
+        n = trajectory.container.n_transitions() if n_transitions is None else n_transitions
+        if n < self.min_replay_history or self.vec_steps % self.update_freq != 0:
+            return False
+        return bool(trajectory.controller.on_sample_())
+
     def optimise_(self, trajectory):
         traces = trajectory.container
-        if traces.n_transitions() < self.min_replay_history:
+        if not self.should_update_(trajectory):
             return False
         net = self.approximator.network
         prioritized = hasattr(traces, "sample_prioritized")

@@ -109,6 +109,8 @@ class CircularPrioritizedTraces(CircularArraySARTSTraces):
     def __init__(self, capacity, n_env=1, obs_dim=1, dtype=torch.float32, default_priority=100.0, device="cuda"):
         super().__init__(capacity, n_env, obs_dim, dtype, device)
         self.default_priority = float(default_priority)
+        if not self.default_priority > 0.0:  # a tree without mass cannot be sampled (the draw would land on an empty slot)
+            raise ValueError("default_priority must be > 0")
         self.n_leaves = capacity * n_env
         nodes = int(_lib.lib.rlhip_sumtree_nodes(self.n_leaves))
         self.priorities = torch.zeros(nodes, dtype=torch.float32, device=self.state.device)  # zero-init contract

@@ -487,3 +487,36 @@ def test_barrier_free_fallback_of_the_optimiser_tails_is_bit_identical():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0].split()
     here, nup = _grid_barrier_probe()
     assert line[1] == hashlib.sha256(here).hexdigest() and int(line[2]) == nup
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_dqn_update_freq_and_sample_ratio_controller_gate_the_updates(fused):
+    """`update_freq` and the trajectory's InsertSampleRatioController were stored but never consulted.
+    update_freq = 4 -> one optimiser step every fourth vec-step after the warm-up; ratio = 0.5 -> every second; both
+    loops (per-step protocol and one-call-per-step) gate identically and end with identical parameters."""
+    import rlhip
+
+    def build(update_freq, ratio):
+        n = 64
+        env = rlhip.CartPoleEnv(n, seed=3)
+        net = rlhip.HipApproximator(4, 128, 2, seed=3)
+        learner = rlhip.DQNLearner(rlhip.TargetNetwork(net, sync_freq=5), batchsize=32, min_replay_history=4 * n, seed=3,
+                                   update_freq=update_freq)
+        policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.1, seed=3))
+        traj = rlhip.Trajectory(rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=4),
+                                controller=rlhip.InsertSampleRatioController(ratio=ratio, threshold=1))
+        return env, learner, net, rlhip.Agent(policy, traj)
+
+    runner = rlhip.run_fused_dqn if fused else rlhip.run
+    counts = {}
+    for uf, ratio in ((1, 1.0), (4, 1.0), (1, 0.5)):
+        env, learner, net, agent = build(uf, ratio)
+        runner(agent, env, rlhip.StopAfterNSteps(44))
+        torch.cuda.synchronize()
+        counts[(uf, ratio)] = learner.n_updates
+        assert learner.vec_steps == 44 and learner.draw_ctr == learner.n_updates
+    assert counts[(1, 1.0)] == 41          # warm-up: 4 vec-steps of 64 transitions, then every step
+    assert counts[(4, 1.0)] == 11          # vec-steps 4, 8, ..., 44
+    assert 19 <= counts[(1, 0.5)] <= 23    # n_sampled <= (n_inserted - 1) / 2
+    with pytest.raises(ValueError):
+        rlhip.DQNLearner(rlhip.TargetNetwork(rlhip.HipApproximator(4, 128, 2)), update_freq=0)
