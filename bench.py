@@ -41,6 +41,7 @@ T_ROLLOUT = 32
 HIDDEN = 256
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 CARTPOLE_STEP_BYTES = 49     # 24 B read + 25 B written per env-step
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def event_time_ms(fn, iters, lib, stream):
@@ -409,16 +410,33 @@ def roofline_extras(torch, rlhip):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ms_r = event_time_ms(ppol.rollout_, 3, lib, s)
-    ms_u = event_time_ms(ppol.update_, 3, lib, s)
+
+    def upd_only():  # the rollout launch leaves adv / ret ready (fused GAE scan): the 16 optimiser steps alone
+        ppol._adv_ready = True
+        ppol.update_()
+
+    ms_u = event_time_ms(upd_only, 3, lib, s)
     bm3 = n * 128 // ppol.cfg.n_microbatches
-    mf = 3 * 2 * 128 * 128 * 2 * bm3  # forward + dH1 + dW2 GEMMs of both nets per micro-batch
+    mf = 3 * 2 * 128 * 128 * 2 * bm3  # forward + dH1 + dW2 GEMMs of both nets per micro-batch (the USEFUL MFMA flops)
+    per_step_us = ms_u * 1e3 / ppol.n_updates_per_call()
     out["ppo3_mfma_pendulum_4096env_T128"] = {
         "env_steps_per_sec": round(n * 128 * iters / el, 1),
         "updates_per_sec": round(ppol.n_updates_per_call() * iters / el, 1),
         "ms_per_iteration": round(el / iters * 1e3, 4), "dtype": "bf16 MFMA hidden layers, f32 master weights / accumulate",
         "n_params": ppol.np, "rollout_us": round(ms_r * 1e3, 1), "update_us": round(ms_u * 1e3, 1),
-        "learner_mfma_tflops": round(mf / (ms_u * 1e-3 / ppol.n_updates_per_call()) / 1e12, 1),
+        "per_microbatch_us": round(per_step_us, 1), "microbatch": bm3,
+        "kernels": "ppo3_gradT_kernel<3,relu,gaussian> (register-chained tile, persistent workgroups, csrc/ppo3t_kernel.h) + "
+                   "d3_apply_kernel (reduce + loss + norm + clip + Adam + bf16 re-pack, one launch)",
+        "learner_mfma_tflops": round(mf / (per_step_us * 1e-6) / 1e12, 1),
         "final_loss": float(ppol.losses[0])}
+    out["ppo3_grad_mfma"] = {"bound": "mfma", "kernel": "ppo3_gradT_kernel<3,relu,gaussian> + d3_apply_kernel", "batch": bm3,
+                             "us_per_launch": round(per_step_us, 1),
+                             "achieved": round(mf / (per_step_us * 1e-6) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(mf / (per_step_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                             "note": "useful GEMM flops (3 GEMMs x 2 nets) of one optimiser step over the WHOLE step incl. the "
+                                     "optimiser tail; the tile issues 144 MFMAs per 96 useful (layer 2 in both operand roles, "
+                                     "one MFMA transposition); layer 1, heads, loss and every elementwise pass run on the VALU "
+                                     "in the same kernel and bound it (profiles/r02_ppo3_gradT.md)"}
     return out
 
 
