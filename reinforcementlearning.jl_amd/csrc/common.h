@@ -82,7 +82,10 @@ enum : uint32_t {
 // development switches are read from the environment once per process
 #define RLHIP_ENV_FLAG(name)                          \
     ([]() -> bool {                                   \
-        static const bool v_ = getenv(name) != nullptr; \
+        static const bool v_ = []() {                 \
+            const char* e_ = getenv(name);            \
+            return e_ != nullptr && e_[0] != '\0' && !(e_[0] == '0' && e_[1] == '\0'); \
+        }();                                          \
         return v_;                                    \
     }())
 

@@ -559,8 +559,10 @@ constexpr size_t GRAD3_LDS = (4 * TR + 2 * MAXO * TR + 4 * TR + 16 + 4 * 5 * H3 
 
 }  // namespace rlhip
 #include "ppo3t_kernel.h"
+#include "ppo3p_kernel.h"
 namespace rlhip {
 static bool g_ppo3_force128 = false;  // test hook (rlhip_debug_ppo3_force128): the round-1 tile for A / B comparisons
+static int g_ppo3_variant = -1;       // test hook (rlhip_debug_ppo3_variant): 0 = chained 4-wave tile, 1 = producer / consumer tile
 
 // both nets' W2 -> bf16 MFMA fragments: [actor W2jk | actor W2kj | critic W2jk | critic W2kj]
 __global__ __launch_bounds__(256) void ppo3_pack_kernel(const float* __restrict__ params, int ns, int64_t np_a,
@@ -791,11 +793,23 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
         t3_wg_cap = e ? atoi(e) : 128;
         if (t3_wg_cap < 1 || t3_wg_cap > 1024) t3_wg_cap = 128;
     }
-    const int nwg = ntiles < t3_wg_cap ? ntiles : t3_wg_cap;  // per net
+    if (g_ppo3_variant < 0) g_ppo3_variant = RLHIP_ENV_FLAG("RLHIP_PPO3_GRADP") ? 1 : 0;
+    const bool pc = chained && g_ppo3_variant == 1;  // producer / consumer tile (ppo3p_kernel.h), rounds of 192 samples
+    const int nrounds = (int)((bm + P3P_ROUND - 1) / P3P_ROUND);
+    const int nunits = pc ? nrounds : ntiles;
+    const int nwg = nunits < t3_wg_cap ? nunits : t3_wg_cap;  // per net
     const int nrows = chained ? nwg : (int)nb;
     g.loss_partials = g.partials + (int64_t)nrows * g.np;
 #define LAUNCH_G3(NS_, ACT_, CONT_)                                                                       \
     do {                                                                                                  \
+        if (pc) {                                                                                         \
+            static bool donep_ = false;                                                                   \
+            int32_t rc_ = allow_lds3(ppo3_gradP_kernel<NS_, CONT_>, GRADP_LDS, &donep_);                  \
+            if (rc_) return rc_;                                                                          \
+            hipLaunchKernelGGL((ppo3_gradP_kernel<NS_, CONT_>), dim3(2 * nwg), dim3(512), GRADP_LDS, s, g, nwg, \
+                               nrounds);                                                                  \
+            break;                                                                                        \
+        }                                                                                                 \
         if (chained) {                                                                                    \
             static bool donet_ = false;                                                                   \
             int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, 0, CONT_>, GRADT_LDS, &donet_);               \
@@ -842,6 +856,20 @@ extern "C" int32_t rlhip_debug_ppo3_force128(int32_t on) {
     g_ppo3_force128 = on != 0;
     return RLHIP_OK;
 }
+
+/* test hook: 0 = the chained 4-wave tile (default), 1 = the producer / consumer tile */
+extern "C" int32_t rlhip_debug_ppo3_variant(int32_t v) {
+    g_ppo3_variant = v;
+    return RLHIP_OK;
+}
+
+#ifdef RLHIP_P3P_TIMING
+extern "C" int32_t rlhip_debug_p3p_stamps(long long* out_host) {
+    RLHIP_CHECK_HIP(hipDeviceSynchronize());
+    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_p3p_stamps), 3 * 16 * sizeof(long long)));
+    return RLHIP_OK;
+}
+#endif
 
 #ifdef RLHIP_T3_TIMING
 extern "C" int32_t rlhip_debug_t3_stamps(long long* out_host) {

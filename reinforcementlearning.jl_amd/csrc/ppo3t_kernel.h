@@ -81,6 +81,95 @@ __device__ __forceinline__ void stage_pi_images(const uint16_t* __restrict__ nat
         *reinterpret_cast<uint4*>(l_img + 8 * (size_t)(tid + 256 * it)) = make_uint4(a0[it].x, a0[it].y, a1[it].x, a1[it].y);
 }
 
+// Per-sample loss terms and dL/d(head outputs) of one net (the per-sample block of ppo3_grad_kernel): PPO clipped surrogate
+// + entropy for the actor (categorical or Gaussian head), squared value error for the critic.  acc0 receives
+// min(surr1, surr2) (actor) or (ret - v)^2 (critic), acc1 the entropy (actor); zero for samples beyond the micro-batch.
+template <int NOUT, int CONT, int CRITIC>
+__device__ __forceinline__ void ppo3_sample_loss(const P3Args& g, const float (&outv)[NOUT], float m_lp, float m_adv,
+                                                 float m_ret, float m_act, bool valid, float (&dl)[NOUT], float& acc0,
+                                                 float& acc1) {
+    acc0 = 0.f;
+    acc1 = 0.f;
+    if (!CRITIC) {
+        const float lp_old = fmaxf(m_lp, g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
+        const float A = m_adv;
+        float ent, surr_min;
+        if (!CONT) {
+            float mx = outv[0];
+#pragma unroll
+            for (int k = 1; k < NOUT; ++k) mx = fmaxf(mx, outv[k]);
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) se += expf(outv[k] - mx);
+            const float lse = logf(se);
+            float logp[NOUT], pr[NOUT];
+            ent = 0.f;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                logp[k] = (outv[k] - mx) - lse;
+                pr[k] = expf(logp[k]);
+                ent -= pr[k] * logp[k];
+            }
+            const int a = __float_as_int(m_act);
+            float lp_new = 0.f;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k)
+                if (k == a) lp_new = logp[k];
+            const float ratio = expf(lp_new - lp_old);
+            const float surr1 = ratio * A;
+            const float surr2 = fminf(fmaxf(ratio, g.lo), g.hi) * A;
+            const bool inside = ratio >= g.lo && ratio <= g.hi;
+            const float dobj = (inside || surr1 < surr2) ? A : 0.f;
+            const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
+            surr_min = fminf(surr1, surr2);
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
+                const float dent = -pr[k] * (logp[k] + ent);
+                dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
+            }
+        } else {
+            const float eps = 1.0e-8f;
+            const float mu = outv[0], ls = outv[NOUT > 1 ? 1 : 0];
+            const float sg = expf(ls);
+            const float z = m_act;
+            const float se = sg + eps;
+            const float zz = (z - mu) / se;
+            const float lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
+            ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
+            const float dmu = (z - mu) / (se * se);
+            const float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
+            const float ratio = expf(lp_new - lp_old);
+            const float surr1 = ratio * A;
+            const float surr2 = fminf(fmaxf(ratio, g.lo), g.hi) * A;
+            const bool inside = ratio >= g.lo && ratio <= g.hi;
+            const float dobj = (inside || surr1 < surr2) ? A : 0.f;
+            const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
+            surr_min = fminf(surr1, surr2);
+            dl[0] = dL_dlp * dmu;
+            if (NOUT > 1) dl[NOUT > 1 ? 1 : 0] = dL_dlp * dls - g.we * g.inv_b * 0.5f;
+        }
+        if (!valid) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dl[o] = 0.f;
+            surr_min = 0.f;
+            ent = 0.f;
+        }
+        acc0 = surr_min;
+        acc1 = ent;
+    } else {
+        const float dv = m_ret - outv[0];
+        float dvout = -2.0f * g.wc * g.inv_b * dv;
+        float sq = dv * dv;
+        if (!valid) {
+            dvout = 0.f;
+            sq = 0.f;
+        }
+        dl[0] = dvout;
+        acc0 = sq;
+    }
+}
+
 template <int NS, int NOUT, int ACT, int CONT, int CRITIC>
 __device__ __forceinline__ void ppo3T_body(const P3Args& g, int wg, int nwg, int ntiles, char* smem) {
     uint16_t* l_F = reinterpret_cast<uint16_t*>(smem);  // W2 fragments   (lane = j, k = u in pi order)
@@ -290,85 +379,13 @@ __device__ __forceinline__ void ppo3T_body(const P3Args& g, int wg, int nwg, int
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) outv[o] = (outv[o] + __shfl_xor(outv[o], 32, 64)) + b3v[o];
         float dl[NOUT];
-        if (!CRITIC) {  // PPO clipped surrogate + entropy (the per-sample block of ppo3_grad_kernel)
-            const float lp_old = fmaxf(m_lp, g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
-            const float A = m_adv;
-            float ent, surr_min;
-            if (!CONT) {
-                float mx = outv[0];
-#pragma unroll
-                for (int k = 1; k < NOUT; ++k) mx = fmaxf(mx, outv[k]);
-                float se = 0.f;
-#pragma unroll
-                for (int k = 0; k < NOUT; ++k) se += expf(outv[k] - mx);
-                const float lse = logf(se);
-                float logp[NOUT], pr[NOUT];
-                ent = 0.f;
-#pragma unroll
-                for (int k = 0; k < NOUT; ++k) {
-                    logp[k] = (outv[k] - mx) - lse;
-                    pr[k] = expf(logp[k]);
-                    ent -= pr[k] * logp[k];
-                }
-                const int a = __float_as_int(m_act);
-                float lp_new = 0.f;
-#pragma unroll
-                for (int k = 0; k < NOUT; ++k)
-                    if (k == a) lp_new = logp[k];
-                const float ratio = expf(lp_new - lp_old);
-                const float surr1 = ratio * A;
-                const float surr2 = fminf(fmaxf(ratio, g.lo), g.hi) * A;
-                const bool inside = ratio >= g.lo && ratio <= g.hi;
-                const float dobj = (inside || surr1 < surr2) ? A : 0.f;
-                const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
-                surr_min = fminf(surr1, surr2);
-#pragma unroll
-                for (int k = 0; k < NOUT; ++k) {
-                    const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
-                    const float dent = -pr[k] * (logp[k] + ent);
-                    dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
-                }
-            } else {
-                const float eps = 1.0e-8f;
-                const float mu = outv[0], ls = outv[NOUT > 1 ? 1 : 0];
-                const float sg = expf(ls);
-                const float z = m_act;
-                const float se = sg + eps;
-                const float zz = (z - mu) / se;
-                const float lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
-                ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
-                const float dmu = (z - mu) / (se * se);
-                const float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
-                const float ratio = expf(lp_new - lp_old);
-                const float surr1 = ratio * A;
-                const float surr2 = fminf(fmaxf(ratio, g.lo), g.hi) * A;
-                const bool inside = ratio >= g.lo && ratio <= g.hi;
-                const float dobj = (inside || surr1 < surr2) ? A : 0.f;
-                const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
-                surr_min = fminf(surr1, surr2);
-                dl[0] = dL_dlp * dmu;
-                if (NOUT > 1) dl[NOUT > 1 ? 1 : 0] = dL_dlp * dls - g.we * g.inv_b * 0.5f;
-            }
-            if (!valid) {
-#pragma unroll
-                for (int o = 0; o < NOUT; ++o) dl[o] = 0.f;
-                surr_min = 0.f;
-                ent = 0.f;
-            }
+        {
+            float l0, l1;
+            ppo3_sample_loss<NOUT, CONT, CRITIC>(g, outv, m_lp, m_adv, m_ret, m_act, valid, dl, l0, l1);
             if (kb == 0) {
-                sA += surr_min;
-                sE += ent;
+                sA += l0;
+                sE += l1;
             }
-        } else {
-            const float dv = m_ret - outv[0];
-            float dvout = -2.0f * g.wc * g.inv_b * dv;
-            float sq = dv * dv;
-            if (!valid) {
-                dvout = 0.f;
-                sq = 0.f;
-            }
-            dl[0] = dvout;
-            if (kb == 0) sA += sq;
         }
         if (kb == 0) {
             dls[c] = make_float4(dl[0], NOUT > 1 ? dl[NOUT > 1 ? 1 : 0] : 0.f, NOUT > 2 ? dl[NOUT > 2 ? 2 : 0] : 0.f, 0.f);
