@@ -68,7 +68,8 @@ __device__ __forceinline__ void load_net(NetRegs<NS, HPL>& r, const float* __res
 
 // out[o] = b2[o] + sum_j W2[o,j] * act(b1[j] + sum_k W1[j,k] x[k]); partial sums per lane (ascending m),
 // then an xor-butterfly over the L lanes of the group (every lane ends with the identical total).
-template <int NS, int HPL, int L, int ACT>
+// NO: outputs actually evaluated (the net has <= NO outputs; the rest of out[] is b2 = 0 either way)
+template <int NS, int HPL, int L, int ACT, int NO = MAXO>
 __device__ __forceinline__ void net_forward(const NetRegs<NS, HPL>& r, const float x[NS], float out[MAXO]) {
     float acc[MAXO];
 #pragma unroll
@@ -80,12 +81,12 @@ __device__ __forceinline__ void net_forward(const NetRegs<NS, HPL>& r, const flo
         for (int k = 0; k < NS; ++k) z = fmaf(r.w1[m][k], x[k], z);
         float hv = act_fwd_t<ACT>(z);
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o) acc[o] = fmaf(r.w2[m][o], hv, acc[o]);
+        for (int o = 0; o < NO; ++o) acc[o] = fmaf(r.w2[m][o], hv, acc[o]);
     }
     // the L = 4 / 8 / 16 lanes of a group sit inside one DPP row: row-local adds, no LDS crossbar
     static_assert(L == 4 || L == 8 || L == 16 || L == 32, "lane groups: a DPP row, or two rows joined by a swizzle");
 #pragma unroll
-    for (int o = 0; o < MAXO; ++o) acc[o] = group_sum_dpp<L>(acc[o]);
+    for (int o = 0; o < NO; ++o) acc[o] = group_sum_dpp<L>(acc[o]);
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) out[o] = acc[o] + r.b2[o];
 }

@@ -54,7 +54,8 @@ __global__ void counters_advance_kernel(uint32_t* ctr, uint32_t d0, uint32_t d1)
 }
 
 // ---------------------------------------------------------------------------------- rollout ----
-template <class P, int H, int L, int ACT>
+// NOA: actor outputs evaluated (2: two actions or (mu, log sigma); MAXO otherwise); the critic has one
+template <class P, int H, int L, int ACT, int NOA>
 __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<float> st, int64_t n, int T,
                                                               PolicyDesc pd, const float* __restrict__ params,
                                                               uint64_t seed, uint32_t env_id_base,
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
         float x[4];
         env_obs1(p, e, x);  // state(env) at PreActStage (post auto-reset)
         float oa[MAXO], oc[MAXO];
-        net_forward<NS, HPL, L, ACT>(A, x, oa);
-        net_forward<NS, HPL, L, ACT>(C, x, oc);
+        net_forward<NS, HPL, L, ACT, NOA>(A, x, oa);
+        net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
         int32_t ai;
         float af, lp;
         policy_sample(pd.cont, pd.na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
     {
         float x[4], oc[MAXO];
         env_obs1(p, e, x);
-        net_forward<NS, HPL, L, ACT>(C, x, oc);
+        net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
         if (writer) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) tr.obs[((int64_t)T * NS + k) * n + env] = x[k];
@@ -208,11 +209,14 @@ static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state*
     bool wide = (pd.h == 256 || pd.h == 128 || pd.h == 64) && n * 16 <= (int64_t)1 << 22;
 #define LAUNCH_WIDE(H, L)                                                                                  \
     do {                                                                                                   \
-        if (pd.act == 0)                                                                                   \
-            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
+        if (pd.act == 0 && pd.nout_a <= 2)                                                                 \
+            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0, 2>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
+                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
+        else if (pd.act == 0)                                                                              \
+            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0, MAXO>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
                                s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
         else                                                                                               \
-            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 1>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
+            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 1, MAXO>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
                                s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
     } while (0)
     if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);  // 32 lanes per env (8 units each, 2 waves per SIMD) is slower: +70 us

@@ -100,7 +100,9 @@ __device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKe
     return r;
 }
 
-template <int NS, int ACT>
+// NO = 2: the actor has at most two outputs (two actions, or (mu, log sigma)) -- the third output's FMAs (zero weights,
+// zero dL/dout: exact no-ops) are not issued; NO = 3: three actions
+template <int NS, int ACT, int NO>
 __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DBG_STAMP(0);
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
                 const float ha = act_fwd_t<ACT>(za), hc = act_fwd_t<ACT>(zc);
                 acc0 = fmaf(ra_.y, ha, acc0);
                 acc1 = fmaf(ra_.z, ha, acc1);
-                acc2 = fmaf(ra_.w, ha, acc2);
+                if (NO > 2) acc2 = fmaf(ra_.w, ha, acc2);
                 accv = fmaf(rc_.y, hc, accv);
             }
             l_part[w * TILE + lane] = make_float4(acc0, acc1, acc2, accv);
@@ -316,13 +318,15 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
                 const float ha = act_fwd_t<ACT>(za), hc = act_fwd_t<ACT>(zc);
                 gw2a[0] = fmaf(d.x, ha, gw2a[0]);
                 gw2a[1] = fmaf(d.y, ha, gw2a[1]);
-                gw2a[2] = fmaf(d.z, ha, gw2a[2]);
+                if (NO > 2) gw2a[2] = fmaf(d.z, ha, gw2a[2]);
                 float dh = d.x * rw2a[0];
                 dh = fmaf(d.y, rw2a[1], dh);
-                dh = fmaf(d.z, rw2a[2], dh);
-                const float dza = dh * act_bwd_t<ACT>(za, ha);
+                if (NO > 2) dh = fmaf(d.z, rw2a[2], dh);
+                // relu: dh * [z > 0] as a select (the product differs only in the sign of a zero)
+                const float dza = ACT == 0 ? (za > 0.0f ? dh : 0.0f) : dh * act_bwd_t<ACT>(za, ha);
                 gw2c = fmaf(d.w, hc, gw2c);
-                const float dzc = (d.w * rw2c) * act_bwd_t<ACT>(zc, hc);
+                const float dhc = d.w * rw2c;
+                const float dzc = ACT == 0 ? (zc > 0.0f ? dhc : 0.0f) : dhc * act_bwd_t<ACT>(zc, hc);
                 gb1a += dza;
                 gb1c += dzc;
                 gw1a[0] = fmaf(dza, xv.x, gw1a[0]);
@@ -950,7 +954,11 @@ __global__ __launch_bounds__(1024) void apply_pack_kernel(float* __restrict__ gr
 
 static void launch_grad(const GradLaunch& L, hipStream_t s) {
     size_t smem = grad_smem_bytes(L.g.pd.h);
-#define LAUNCH_G(NS_, ACT_) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_>), dim3(L.nb), dim3(64 * NW), smem, s, L.g)
+#define LAUNCH_G(NS_, ACT_)                                                                                      \
+    do {                                                                                                        \
+        if (L.g.pd.nout_a > 2) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 3>), dim3(L.nb), dim3(64 * NW), smem, s, L.g); \
+        else hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 2>), dim3(L.nb), dim3(64 * NW), smem, s, L.g);         \
+    } while (0)
     const int a = L.g.pd.act;
     if (L.ns == 4) { if (a == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
     else if (L.ns == 3) { if (a == 0) LAUNCH_G(3, 0); else LAUNCH_G(3, 1); }
