@@ -84,7 +84,24 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
     float last_r = 0.0f;
     bool last_d = false;
 
+    // The random part of the action sampling (Gumbel / normal noise: Philox + Float64 log, sqrt, sin / cos -- 4 of the
+    // 5 logarithms of a categorical step) depends on (env, step) only, not on the actor output: it is evaluated NOISE_CH
+    // steps ahead, one step per lane of the env's L-lane group instead of every step on all L lanes, and handed over
+    // through LDS (the group sits inside one wave: in-order LDS access, no barrier).  Same operations on the same
+    // operands as policy_sample: bit-identical actions and log-probabilities.
+    constexpr int NOISE_CH = 16;
+    __shared__ double l_noise[256 / L][NOISE_CH][MAXO];
+    double(*my_noise)[MAXO] = l_noise[threadIdx.x / L];
+
     for (int t = 0; t < T; ++t) {
+        if ((t & (NOISE_CH - 1)) == 0) {
+            for (int i = sub; i < NOISE_CH && t + i < T; i += L) {
+                double nz[MAXO] = {0.0, 0.0, 0.0, 0.0};
+                policy_noise(pd.cont, pd.na, seed, id, vec_step0 + (uint32_t)(t + i), nz);
+#pragma unroll
+                for (int k = 0; k < MAXO; ++k) my_noise[i][k] = nz[k];
+            }
+        }
         float x[4];
         env_obs1(p, e, x);  // state(env) at PreActStage (post auto-reset)
         float oa[MAXO], oc[MAXO];
@@ -92,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<flo
         net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
         int32_t ai;
         float af, lp;
-        policy_sample(pd.cont, pd.na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
+        policy_select(pd.cont, pd.na, oa, my_noise[t & (NOISE_CH - 1)], ai, af, lp);
         if (writer) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) tr.obs[((int64_t)t * NS + k) * n + env] = x[k];

@@ -57,6 +57,14 @@ __device__ __forceinline__ void stage_w2_fragments(const float* __restrict__ W2,
 }
 
 // ------------------------------------------------------------------------------------ rollout
+// The random part of the action sampling (policy_noise: Philox + Float64 log / sqrt / sin / cos) depends on (env, step) only:
+// the rollout kernels evaluate it NCH steps ahead with ALL 256 threads (the env step itself occupies 128 / 32 of them)
+// into a double-buffered LDS table [chunk parity][step in chunk][env][MAXO]; policy_select reads it back.  Bit-identical
+// to policy_sample (same operations on the same operands).
+constexpr int NCH3 = 2;   // 256 threads / 128 envs
+constexpr size_t ROLL3_NOISE_OFF = (((4 * TR + 2 * MAXO * TR + 2 * SMALLW) * sizeof(float) +
+                                     (2 * H3 * H3 + TILE_ELEMS) * sizeof(uint16_t)) + 15) & ~(size_t)15;
+
 template <class P, int NOUT_A, int ACT>
 __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float> st, int64_t n, int T, int cont, int na,
                                                            const float* __restrict__ params, int64_t np_a,
@@ -91,7 +99,19 @@ __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float>
         e.t = st.t[envc];
         e.episode = st.episode[envc];
     }
+    double* l_noise = reinterpret_cast<double*>(smem3 + ROLL3_NOISE_OFF);  // [2][NCH3][TR][MAXO]
     for (int t = 0; t <= T; ++t) {
+        if ((t & (NCH3 - 1)) == 0) {
+            const int i = tid >> 7, er = tid & (TR - 1);
+            if (t + i < T) {
+                const int64_t en = (int64_t)blockIdx.x * TR + er;
+                double nz[MAXO] = {0.0, 0.0, 0.0, 0.0};
+                policy_noise(cont, na, seed, env_id_base + (uint32_t)(en < n ? en : n - 1), vec_step0 + (uint32_t)(t + i), nz);
+                double* dst = l_noise + ((size_t)((((t / NCH3) & 1) * NCH3 + i) * TR + er)) * MAXO;
+#pragma unroll
+                for (int k = 0; k < MAXO; ++k) dst[k] = nz[k];
+            }
+        }
         if (tid < TR) {
             float x[4];
             env_obs1(p, e, x);
@@ -124,7 +144,8 @@ __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float>
                 for (int o = 0; o < MAXO; ++o) oa[o] = (o < NOUT_A) ? l_q[o * TR + tid] : 0.0f;
                 int32_t ai;
                 float af, lp;
-                policy_sample(cont, na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
+                policy_select(cont, na, oa, l_noise + ((size_t)((((t / NCH3) & 1) * NCH3 + (t & (NCH3 - 1))) * TR + tid)) * MAXO,
+                              ai, af, lp);
                 env_step1(p, e, ai, af, last_r, last_d);
                 if (last_d) env_reset1(p, e, seed, id);
                 if (active) {
@@ -161,6 +182,9 @@ __global__ __launch_bounds__(256) void ppo3_rollout_kernel(P p, EnvArrays<float>
 // bit-identical; the head sums run in a different (fixed) order -- inside the tolerance the oracle comparison states.
 constexpr int R32 = 32;
 constexpr int LDH2 = H3 + 4;  // f32 pitch of the H2 tile
+constexpr int NCH32 = 8;  // 256 threads / 32 envs: noise of 8 steps per evaluation
+constexpr size_t ROLL32_NOISE_OFF = (((4 * R32 + 8 * 4 * R32 + 2 * R32 * LDH2 + 2 * SMALLW) * sizeof(float) +
+                                      (2 * H3 * H3 + 2 * R32 * LDH) * sizeof(uint16_t)) + 15) & ~(size_t)15;
 template <class P, int NOUT_A, int ACT>
 __global__ __launch_bounds__(256) void ppo3_rollout32_kernel(P p, EnvArrays<float> st, int64_t n, int T, int cont, int na,
                                                              const float* __restrict__ params, int64_t np_a,
@@ -201,8 +225,20 @@ __global__ __launch_bounds__(256) void ppo3_rollout32_kernel(P p, EnvArrays<floa
     }
     const int row1 = tid & 31, u0 = 16 * (tid >> 5);  // layer 1: this thread's row and its 16 hidden units
     const int part = tid >> 5;                        // heads: this thread's 16-column part of the H2 row `row1`
+    double* l_noise = reinterpret_cast<double*>(smem3 + ROLL32_NOISE_OFF);  // [2][NCH32][R32][MAXO]
     __syncthreads();
     for (int t = 0; t <= T; ++t) {
+        if ((t & (NCH32 - 1)) == 0) {
+            const int i = tid >> 5, er = tid & (R32 - 1);
+            if (t + i < T) {
+                const int64_t en = (int64_t)blockIdx.x * R32 + er;
+                double nz[MAXO] = {0.0, 0.0, 0.0, 0.0};
+                policy_noise(cont, na, seed, env_id_base + (uint32_t)(en < n ? en : n - 1), vec_step0 + (uint32_t)(t + i), nz);
+                double* dst = l_noise + ((size_t)((((t / NCH32) & 1) * NCH32 + i) * R32 + er)) * MAXO;
+#pragma unroll
+                for (int k = 0; k < MAXO; ++k) dst[k] = nz[k];
+            }
+        }
         if (tid < R32) {
             float x[4];
             env_obs1(p, e, x);
@@ -322,7 +358,8 @@ __global__ __launch_bounds__(256) void ppo3_rollout32_kernel(P p, EnvArrays<floa
                 for (int o = 0; o < MAXO; ++o) oa[o] = (o < NOUT_A) ? out[o] : 0.0f;
                 int32_t ai;
                 float af, lp;
-                policy_sample(cont, na, oa, seed, id, vec_step0 + (uint32_t)t, ai, af, lp);
+                policy_select(cont, na, oa, l_noise + ((size_t)((((t / NCH32) & 1) * NCH32 + (t & (NCH32 - 1))) * R32 + tid)) * MAXO,
+                              ai, af, lp);
                 env_step1(p, e, ai, af, last_r, last_d);
                 if (last_d) env_reset1(p, e, seed, id);
                 if (active) {
@@ -351,11 +388,8 @@ __global__ __launch_bounds__(256) void ppo3_rollout32_kernel(P p, EnvArrays<floa
     }
 }
 
-constexpr size_t ROLL32_LDS = (4 * R32 + 8 * 4 * R32 + 2 * R32 * LDH2 + 2 * SMALLW) * sizeof(float) +
-                              (2 * H3 * H3 + 2 * R32 * LDH) * sizeof(uint16_t);
-
-constexpr size_t ROLL3_LDS = (4 * TR + 2 * MAXO * TR + 2 * SMALLW) * sizeof(float) +
-                             (2 * H3 * H3 + TILE_ELEMS) * sizeof(uint16_t);
+constexpr size_t ROLL32_LDS = ROLL32_NOISE_OFF + 2 * NCH32 * R32 * MAXO * sizeof(double);
+constexpr size_t ROLL3_LDS = ROLL3_NOISE_OFF + 2 * NCH3 * TR * MAXO * sizeof(double);
 
 // ----------------------------------------------------------------------------------- gradient
 struct P3Args {

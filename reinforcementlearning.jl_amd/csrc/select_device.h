@@ -95,31 +95,47 @@ __device__ __forceinline__ int32_t eps_greedy_select1(const V& q, const M& mk, i
     return (int32_t)randint32(w.z, (uint32_t)na);  // rand(rng, 1:n)
 }
 
-// logsoftmax (NNlib: x - max - log(sum(exp(x - max)))), Float32; Gumbel noise and argmax in Float64
-template <class V, class M>
-__device__ __forceinline__ int32_t categorical_sample1(const V& l, const M& mk, int na, uint64_t seed,
-                                                       uint32_t id, uint32_t step, float* logp_out) {
+// Gumbel noise of action k of (id, step): -log(-log(u_k)), Float64; depends on nothing but the counters, so a rollout
+// kernel may evaluate it for many steps ahead, spread over the lanes that cooperate on an env (ppo.hip)
+__device__ __forceinline__ void gumbel_noise(int na, uint64_t seed, uint32_t id, uint32_t step, double* gn) {
+    u32x4 w = {0, 0, 0, 0};
+    for (int k = 0; k < na; ++k) {
+        if ((k & 1) == 0) w = philox4x32_10(seed, id, (uint32_t)(k >> 1), step, TAG_GUMBEL);
+        double u = (k & 1) ? u01_f64(w.z, w.w) : u01_f64(w.x, w.y);
+        gn[k] = -::log(-::log(u));
+    }
+}
+
+// logsoftmax (NNlib: x - max - log(sum(exp(x - max)))), Float32; Gumbel-max over log-probability + noise in Float64.
+// GN: functor k -> the Gumbel noise of action k
+template <class V, class M, class GN>
+__device__ __forceinline__ int32_t categorical_select1(const V& l, const M& mk, int na, const GN& gn, float* logp_out) {
     float mx = -INFINITY;
     for (int k = 0; k < na; ++k) {
         float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
         if (x > mx) mx = x;
     }
     float se = 0.f;
-    for (int k = 0; k < na; ++k) {
-        float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
-        se += (float)::exp((double)(x - mx));  // Float64 eval, rounded once (libm-independent)
+    if (na == 2 && !mk.has()) {
+        // two actions: the term of the maximum is exp(0) = 1 exactly, so ONE exponential gives the same sum bit for bit
+        // (0 + e + 1 and 0 + 1 + e are both RN(1 + e))
+        const float x0 = l(0), x1 = l(1);
+        const float other = (x1 > x0) ? x0 : x1;
+        se = 1.0f + (float)::exp((double)(other - mx));
+    } else {
+        for (int k = 0; k < na; ++k) {
+            float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
+            se += (float)::exp((double)(x - mx));  // Float64 eval, rounded once (libm-independent)
+        }
     }
     float lse = (float)::log((double)se);
     int best = 0;
     double bg = 0.0;
     float blp = 0.f;
-    u32x4 w = {0, 0, 0, 0};
     for (int k = 0; k < na; ++k) {
-        if ((k & 1) == 0) w = philox4x32_10(seed, id, (uint32_t)(k >> 1), step, TAG_GUMBEL);
-        double u = (k & 1) ? u01_f64(w.z, w.w) : u01_f64(w.x, w.y);
         float x = (mk.has() && !mk(k)) ? -INFINITY : l(k);
         float lp = (x - mx) - lse;
-        double g = -::log(-::log(u)) + (double)lp;
+        double g = gn(k) + (double)lp;
         if (k == 0 || g > bg) {
             bg = g;
             best = k;
@@ -128,6 +144,23 @@ __device__ __forceinline__ int32_t categorical_sample1(const V& l, const M& mk, 
     }
     *logp_out = blp;
     return best;
+}
+
+struct GumbelInline {  // the noise evaluated on the spot, one Philox block per two actions
+    uint64_t seed;
+    uint32_t id, step;
+    mutable u32x4 w;
+    __device__ __forceinline__ double operator()(int k) const {
+        if ((k & 1) == 0) w = philox4x32_10(seed, id, (uint32_t)(k >> 1), step, TAG_GUMBEL);
+        const double u = (k & 1) ? u01_f64(w.z, w.w) : u01_f64(w.x, w.y);
+        return -::log(-::log(u));
+    }
+};
+
+template <class V, class M>
+__device__ __forceinline__ int32_t categorical_sample1(const V& l, const M& mk, int na, uint64_t seed,
+                                                       uint32_t id, uint32_t step, float* logp_out) {
+    return categorical_select1(l, mk, na, GumbelInline{seed, id, step, u32x4{0, 0, 0, 0}}, logp_out);
 }
 
 }  // namespace rlhip

@@ -1,21 +1,25 @@
-"""profiles/r01_final_bench_stats.md from a rocprofv3 --kernel-trace --stats run of the default bench command
-(tools/prof.sh final ...): usage  python tools/make_final_profile.py gpurun_out/prof_final gpurun_out/prof_final.log"""
+"""profiles/rNN_final_bench_stats.md (+ rNN_bench_line.json) from a rocprofv3 --kernel-trace --stats run of the default
+bench command (tools/prof.sh final ...):
+    python tools/make_final_profile.py gpurun_out/prof_final gpurun_out/prof_final.log [round = 2] [unprofiled bench json]"""
 import csv, json, os, sys
 
 d, log = sys.argv[1], sys.argv[2]
+rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+unprof = json.loads([l for l in open(sys.argv[4]) if l.startswith('{"metric"')][-1]) if len(sys.argv) > 4 else None
 line = [l for l in open(log) if l.startswith('{"metric"')][-1]
 bench = json.loads(line)
 stats = list(csv.DictReader(open(os.path.join(d, "bench_kernel_stats.csv"))))
 trace = list(csv.DictReader(open(os.path.join(d, "bench_kernel_trace.csv"))))
 out = []
-out.append("# Round 1 — final state: rocprofv3 `--kernel-trace --stats` of the DEFAULT bench command\n")
+out.append(f"# Round {rnd} — final state: rocprofv3 `--kernel-trace --stats` of the DEFAULT bench command\n")
 out.append("Command (MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- "
            "python bench.py` (`tools/prof.sh final`; default flags `--gpus 1 --steps 200 --warmup 20`, all legs: timed PPO "
            "workload, kernel breakdown, env-step roofline at 2^24 envs, roofline extras incl. the DQN / MFMA / replay "
            "configs, CPU baseline).\n")
 out.append("Bench line printed by the same (profiled) run -- the profiler intercepts every launch, so `ms_per_step` / `value` of a "
-           "profiled run can sit above the unprofiled ones (0.61 ms, 2.1e8 env-steps/s for this code: README); the per-kernel "
-           "durations below are what this file is for:\n\n```json\n" + json.dumps(bench, indent=1) + "\n```\n")
+           "profiled run can sit above the unprofiled ones"
+           + (f" ({unprof['ms_per_step']} ms, {unprof['value']:.3e} env-steps/s for this code, `profiles/r{rnd:02d}_bench_line.json`)" if unprof else "")
+           + "; the per-kernel durations below are what this file is for:\n\n```json\n" + json.dumps(bench, indent=1) + "\n```\n")
 out.append("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|")
 for r in stats:
     name = r["Name"].split("(")[0].replace("void ", "")
@@ -33,7 +37,7 @@ if big:
     nt, desync, timed = big[4:9], big[9:69], big[69:89]
     us = lambda v: f"{sum(v)/len(v)/1e3:.1f}"
     out.append("")
-    out.append(f"**Agreement check (roofline kernel).** The stats row of `env_step_kernel<CartPole, float, 4>` mixes launch "
+    out.append(f"**Agreement check (roofline kernel).** The stats rows of `env_step_kernel<CartPole, float, ...>` mix launch "
                f"sizes (the roofline leg runs 2^24 envs, the DQN legs 4096).  From `bench_kernel_trace.csv` ({len(big)} "
                f"launches with 2^24 envs, grid 16384 x 256): the 20 timed steady-state launches take **{us(timed)} us** on "
                f"average (min {min(timed)/1e3:.1f}, max {max(timed)/1e3:.1f}) against **{rf.get('us_per_launch')} us** "
@@ -44,5 +48,7 @@ if big:
     out.append("Per-launch durations (us) of the 60 de-synchronising launches in between -- the termination waves of the "
                "synchronised start are visible (no env can terminate before step ~8, then bursts that flatten out): "
                + ", ".join(f"{x/1e3:.0f}" for x in desync))
-open("profiles/r01_final_bench_stats.md", "w").write("\n".join(out) + "\n")
+open(f"profiles/r{rnd:02d}_final_bench_stats.md", "w").write("\n".join(out) + "\n")
+if unprof:
+    json.dump(unprof, open(f"profiles/r{rnd:02d}_bench_line.json", "w"), indent=1)
 print("\n".join(out[-3:])[:1500])
