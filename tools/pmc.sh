@@ -8,9 +8,9 @@ python3 - "$f" <<'PY'
 import csv,sys,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    k=r['Kernel_Name'].split('(')[0][-48:]
+    k=r['Kernel_Name'].split('(')[0]
     acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,d in acc.items():
     if 'rlhip' not in k: continue
-    print(k, {c: round(sum(v)/len(v),1) for c,v in d.items()}, 'n=',len(next(iter(d.values()))))
+    print(k[-80:], {c: round(sum(v)/len(v),1) for c,v in d.items()}, 'n=',len(next(iter(d.values()))))
 PY
