@@ -65,17 +65,28 @@ struct GradArgs {
     long long* dbg;  // optional per-block phase timestamps (s_memtime), 8 per block; NULL in production
 };
 
-// Phase timestamps are a compile-time option (-DRLHIP_GRAD_TIMING): a global store at kernel entry
-// makes every later uniform global load "possibly clobbered", which turns the s_load_dwordx8 record
-// fetches of phase 1 into per-lane global_load_dwordx4 (measured: 22 -> 29.6 us per launch).
+// Phase timestamps are a compile-time option (-DRLHIP_GRAD_TIMING).  They are kept in (scalar) registers and stored at
+// the very end: a global store at kernel entry makes every later uniform global load "possibly clobbered", which turns
+// the s_load_dwordx8 record fetches of phase 1 into per-lane global_load_dwordx4 (measured: 22 -> 29.6 us per launch,
+// all of it in phase 1a).
 #ifdef RLHIP_GRAD_TIMING
-#define DBG_STAMP(k)                                                             \
-    do {                                                                         \
-        if (g.dbg && threadIdx.x == 0) g.dbg[(int64_t)blockIdx.x * 8 + (k)] = clock64(); \
+#define DBG_DECL long long dbg_t[6] = {0, 0, 0, 0, 0, 0}
+#define DBG_STAMP(k) dbg_t[(k)] = __builtin_amdgcn_s_memtime()
+#define DBG_FLUSH()                                                                          \
+    do {                                                                                     \
+        if (g.dbg && threadIdx.x == 0) {                                                     \
+            _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) g.dbg[(int64_t)blockIdx.x * 8 + k_] = dbg_t[k_]; \
+        }                                                                                    \
     } while (0)
 #else
+#define DBG_DECL \
+    do {         \
+    } while (0)
 #define DBG_STAMP(k) \
     do {             \
+    } while (0)
+#define DBG_FLUSH() \
+    do {            \
     } while (0)
 #endif
 
@@ -100,21 +111,34 @@ __device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKe
     return r;
 }
 
+// LDS of one team of 8 waves: x[2][TILE] | misc[2][TILE] | part[8][TILE] | dL[TILE] (float4) | comb[14][256] + 16 scalars (float)
+__host__ __device__ constexpr size_t grad_team_smem_bytes() {
+    return sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE) + sizeof(float) * (14 * 256 + 16);
+}
+
 // NO = 2: the actor has at most two outputs (two actions, or (mu, log sigma)) -- the third output's FMAs (zero weights,
-// zero dL/dout: exact no-ops) are not issued; NO = 3: three actions
-template <int NS, int ACT, int NO>
-__global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
+// zero dL/dout: exact no-ops) are not issued; NO = 3: three actions.
+// NT: teams of 8 waves per workgroup.  NT = 2: a 1024-thread workgroup walks TWO 64-sample tiles side by side (same code,
+// same barriers, its own LDS carve per team) and folds both into ONE partial row: half the rows to write at the end of
+// the launch (512 rows x 13 KB cost 2.7 us of an 18.8 us launch: the launch cannot retire before they are flushed) and
+// half the rows for the optimiser tail to read back.  The two-workgroups-per-CU occupancy of NT = 1 is kept (16 waves).
+template <int NS, int ACT, int NO, int NT>
+__global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DBG_DECL;
     DBG_STAMP(0);
     const int h = g.pd.h;
-    // LDS carve (all 16-byte aligned): x[2][TILE] | misc[2][TILE] | part[4][TILE] | dL[TILE]
-    float4* l_x = reinterpret_cast<float4*>(smem);           // [2][TILE]
+    const int gtid = threadIdx.x;
+    const int team = NT > 1 ? __builtin_amdgcn_readfirstlane(gtid >> 9) : 0;
+    // LDS carve per team (all 16-byte aligned): x[2][TILE] | misc[2][TILE] | part[8][TILE] | dL[TILE] | comb[14][256]
+    char* tsm = smem + (size_t)team * grad_team_smem_bytes();
+    float4* l_x = reinterpret_cast<float4*>(tsm);            // [2][TILE]
     float4* l_misc = l_x + 2 * TILE;                         // [2][TILE]
     float4* l_part = l_misc + 2 * TILE;                      // [8][TILE]  {a0, a1, a2, v} partial sums
     float4* l_dL = l_part + NW * TILE;                       // [TILE]     {dl0, dl1, dl2, dv}
     float* l_comb = reinterpret_cast<float*>(l_dL + TILE);   // [14][256] second-half accumulators
 
-    const int tid = threadIdx.x;
+    const int tid = gtid & 511;  // thread within the team
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nout = g.pd.nout_a;
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
     // ---- prologue: the first tile's scattered gather is issued first; this thread's unit (phase 2)
     // comes from its two records ----
     const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x * NT + team;
     TileRegs first;
     const bool first_loader = tid < TILE && tile < g.num_tiles;
     if (first_loader) first = fetch_sample<NS>(g, pk, tile, tid);
@@ -152,12 +176,19 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
     if (first_loader) {
         l_x[tid] = first.x;
         l_misc[tid] = first.misc;
+    } else if (NT > 1 && tid < TILE) {  // a team without a tile: finite operands, so that its (all-zero-weight) sums stay exact zeros
+        l_x[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l_misc[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l_x[TILE + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l_misc[TILE + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     DBG_STAMP(1);
 
-    for (; tile < g.num_tiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
+    // both teams run the same number of trips (the barriers are workgroup-wide); a team without a tile left computes on
+    // stale LDS with all-invalid samples: dL = 0, nothing is accumulated
+    for (int base = blockIdx.x * NT; base < g.num_tiles; base += gridDim.x * NT, tile += gridDim.x * NT) {
+        const int next = tile + gridDim.x * NT;
         const float4* cx = l_x + buf * TILE;
         const float4* cm = l_misc + buf * TILE;
         // ---- phase 0 (next tile): wave 1 issues the gather now, publishes it after phase 2 ----
@@ -386,6 +417,71 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
         gw2a[2] += c[12 * 256];
         gw2c += c[13 * 256];
     }
+    float* l_sc = l_comb + 14 * 256;  // [16] scalars of this team's wave 0
+    if (w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
+#pragma unroll
+        for (int o = 0; o < GMAXO; ++o) gb2a[o] = wave_sum_f32(gb2a[o]);
+        gb2c = wave_sum_f32(gb2c);
+        s_actor = wave_sum_f32(s_actor);
+        s_critic = wave_sum_f32(s_critic);
+        s_ent = wave_sum_f32(s_ent);
+    }
+    if (NT > 1) {
+        // team 1 hands its (already half-combined) accumulators to team 0 through its own comb area, fixed order
+        __syncthreads();  // the readers of the comb areas (above) are done
+        if (team == 1) {
+            if (shalf == 0) {
+                float* c = l_comb + uidx;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    c[(k)*256] = gw1a[k];
+                    c[(4 + k) * 256] = gw1c[k];
+                }
+                c[8 * 256] = gb1a;
+                c[9 * 256] = gb1c;
+                c[10 * 256] = gw2a[0];
+                c[11 * 256] = gw2a[1];
+                c[12 * 256] = gw2a[2];
+                c[13 * 256] = gw2c;
+            }
+            if (w == 0 && lane == 0) {
+                l_sc[0] = gb2a[0];
+                l_sc[1] = gb2a[1];
+                l_sc[2] = gb2a[2];
+                l_sc[3] = gb2c;
+                l_sc[4] = s_actor;
+                l_sc[5] = s_critic;
+                l_sc[6] = s_ent;
+            }
+        }
+        __syncthreads();
+        if (team == 1) return;
+        const float* c1 = reinterpret_cast<const float*>(smem + grad_team_smem_bytes() + sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE));
+        if (shalf == 0) {
+            const float* c = c1 + uidx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gw1a[k] += c[(k)*256];
+                gw1c[k] += c[(4 + k) * 256];
+            }
+            gb1a += c[8 * 256];
+            gb1c += c[9 * 256];
+            gw2a[0] += c[10 * 256];
+            gw2a[1] += c[11 * 256];
+            gw2a[2] += c[12 * 256];
+            gw2c += c[13 * 256];
+        }
+        if (w == 0) {
+            const float* sc1 = c1 + 14 * 256;
+            gb2a[0] += sc1[0];
+            gb2a[1] += sc1[1];
+            gb2a[2] += sc1[2];
+            gb2c += sc1[3];
+            s_actor += sc1[4];
+            s_critic += sc1[5];
+            s_ent += sc1[6];
+        }
+    }
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
     if (owner && shalf == 0) {
         const int j = uidx;
@@ -403,29 +499,22 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(GradArgs g) {
             if (o < nout) oa_[h * NS + h + o + nout * j] = gw2a[o];
         oc_[h * NS + h + j] = gw2c;
     }
-    if (w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
-#pragma unroll
-        for (int o = 0; o < GMAXO; ++o) gb2a[o] = wave_sum_f32(gb2a[o]);
-        gb2c = wave_sum_f32(gb2c);
-        s_actor = wave_sum_f32(s_actor);
-        s_critic = wave_sum_f32(s_critic);
-        s_ent = wave_sum_f32(s_ent);
-        if (lane == 0) {
-            for (int o = 0; o < nout; ++o) out[h * NS + h + nout * h + o] = gb2a[o];
-            out[g.pd.np_a + h * NS + h + h] = gb2c;
-            float* lo_ = g.loss_partials + (int64_t)blockIdx.x * 4;
-            lo_[0] = s_actor;
-            lo_[1] = s_critic;
-            lo_[2] = s_ent;
-            lo_[3] = 0.f;
-        }
+    if (w == 0 && lane == 0) {
+        for (int o = 0; o < nout; ++o) out[h * NS + h + nout * h + o] = gb2a[o];
+        out[g.pd.np_a + h * NS + h + h] = gb2c;
+        float* lo_ = g.loss_partials + (int64_t)blockIdx.x * 4;
+        lo_[0] = s_actor;
+        lo_[1] = s_critic;
+        lo_[2] = s_ent;
+        lo_[3] = 0.f;
     }
     DBG_STAMP(5);
+    DBG_FLUSH();
 }
 
 static size_t grad_smem_bytes(int h) {
     (void)h;
-    return sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE) + sizeof(float) * 14 * 256;
+    return grad_team_smem_bytes();
 }
 
 // unit records {W1[j,0..3], b1[j], W2[0..2,j]} per net + the output biases; any thread count
@@ -837,7 +926,7 @@ static float* workspace_packed(void* workspace, int64_t np) {
 
 struct GradLaunch {
     GradArgs g;
-    int nb, ns;
+    int nb, ns, nt;  // partial rows (= workgroups), observation size, teams (tiles side by side) per workgroup
     int64_t np;
     unsigned int* counter;
     double* sumsq;
@@ -887,7 +976,15 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     g.seed = seed;
     g.epoch_local = epoch_ctr;  // with ctr: the epoch index inside this update call
     g.n_epochs = (uint32_t)cfg->n_epochs;
-    out->nb = grad_blocks(g.num_tiles);
+    // two tiles side by side per workgroup (one partial row for both) once there are more tiles than CUs can take one
+    // 8-wave workgroup each: below that, more (smaller) workgroups fill the chip better.  RLHIP_GRAD_TEAMS=1 / 2 forces.
+    static int teams_env = -1;
+    if (teams_env < 0) {
+        const char* e = getenv("RLHIP_GRAD_TEAMS");
+        teams_env = e ? atoi(e) : 0;
+    }
+    out->nt = teams_env == 1 ? 1 : (teams_env == 2 ? 2 : (g.num_tiles > 256 ? 2 : 1));
+    out->nb = grad_blocks((g.num_tiles + out->nt - 1) / out->nt);
     out->ns = ns;
     out->np = np;
     // workspace carve: partials [MAX][np] | loss_partials [MAX][4] | sumsq (doubles) | counter
@@ -957,10 +1054,17 @@ __global__ __launch_bounds__(1024) void apply_pack_kernel(float* __restrict__ gr
 
 static void launch_grad(const GradLaunch& L, hipStream_t s) {
     size_t smem = grad_smem_bytes(L.g.pd.h);
-#define LAUNCH_G(NS_, ACT_)                                                                                      \
-    do {                                                                                                        \
-        if (L.g.pd.nout_a > 2) hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 3>), dim3(L.nb), dim3(64 * NW), smem, s, L.g); \
-        else hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 2>), dim3(L.nb), dim3(64 * NW), smem, s, L.g);         \
+#define LAUNCH_G(NS_, ACT_)                                                                                            \
+    do {                                                                                                              \
+        if (L.nt == 2) {                                                                                              \
+            if (L.g.pd.nout_a > 2)                                                                                    \
+                hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 3, 2>), dim3(L.nb), dim3(64 * NW * 2), 2 * smem, s, L.g); \
+            else                                                                                                      \
+                hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 2, 2>), dim3(L.nb), dim3(64 * NW * 2), 2 * smem, s, L.g); \
+        } else if (L.g.pd.nout_a > 2)                                                                                 \
+            hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 3, 1>), dim3(L.nb), dim3(64 * NW), smem, s, L.g);           \
+        else                                                                                                          \
+            hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 2, 1>), dim3(L.nb), dim3(64 * NW), smem, s, L.g);           \
     } while (0)
     const int a = L.g.pd.act;
     if (L.ns == 4) { if (a == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
