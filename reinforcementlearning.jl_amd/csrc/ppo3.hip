@@ -819,7 +819,8 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
     // (relu only: the tanh instantiations of the chained tile need 64 more live registers for act'(h1), spill ~300
     //  dwords per lane and -- cartpole / tanh -- came out of the compiler computing a wrong actor loss; they stay on the
     //  round-1 tile, which tests/test_gpu_ppo3.py pins against the oracle)
-    const bool chained = pd.act == 0 && !(g_ppo3_force128 || RLHIP_ENV_FLAG("RLHIP_PPO3_GRAD128"));
+    const bool chained = (pd.act == 0 || RLHIP_ENV_FLAG("RLHIP_PPO3_CHAINED_TANH")) &&
+                         !(g_ppo3_force128 || RLHIP_ENV_FLAG("RLHIP_PPO3_GRAD128"));
     const int ntiles = (int)nb;
     static int t3_wg_cap = -1;
     if (t3_wg_cap < 0) {
@@ -846,9 +847,9 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
         }                                                                                                 \
         if (chained) {                                                                                    \
             static bool donet_ = false;                                                                   \
-            int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, 0, CONT_>, GRADT_LDS, &donet_);               \
+            int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, ACT_, CONT_>, GRADT_LDS, &donet_);            \
             if (rc_) return rc_;                                                                          \
-            hipLaunchKernelGGL((ppo3_gradT_kernel<NS_, 0, CONT_>), dim3(2 * nwg), dim3(256), GRADT_LDS, s, g, nwg, \
+            hipLaunchKernelGGL((ppo3_gradT_kernel<NS_, ACT_, CONT_>), dim3(2 * nwg), dim3(256), GRADT_LDS, s, g, nwg, \
                                ntiles);                                                                   \
             break;                                                                                        \
         }                                                                                                 \
