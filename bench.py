@@ -437,6 +437,42 @@ def roofline_extras(torch, rlhip):
                                      "optimiser tail; the tile issues 144 MFMAs per 96 useful (layer 2 in both operand roles, "
                                      "one MFMA transposition); layer 1, heads, loss and every elementwise pass run on the VALU "
                                      "in the same kernel and bound it (profiles/r02_ppo3_gradT.md)"}
+    del ppol, penv
+    # config 3 at the width SURVEY 8(d) names (256): 3 -> 256 -> 256 -> {(mu, log sigma), 1}, csrc/ppo3w.hip -- three
+    # streaming kernels per net (forward + loss + dZ2 / dH1 -> dW1 / dW2) with one operand resident in registers each
+    penv = rlhip.HipVecEnv("pendulum", n, seed=7)
+    ppol = rlhip.PPOPolicy(penv, update_freq=128, hidden=256, seed=7, clip_range=0.1, layers=3)
+    for _ in range(2):
+        ppol.rollout_()
+        ppol.update_()
+    torch.cuda.synchronize()
+    it256 = 5
+    t0 = time.perf_counter()
+    for _ in range(it256):
+        ppol.rollout_()
+        ppol.update_()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms_r = event_time_ms(ppol.rollout_, 3, lib, s)
+
+    def upd_only256():
+        ppol._adv_ready = True
+        ppol.update_()
+
+    ms_u = event_time_ms(upd_only256, 2, lib, s)
+    mf = 3 * 2 * 256 * 256 * 2 * bm3
+    per_step_us = ms_u * 1e3 / ppol.n_updates_per_call()
+    out["ppo3w_mfma_pendulum_4096env_T128_hidden256"] = {
+        "env_steps_per_sec": round(n * 128 * it256 / el, 1),
+        "updates_per_sec": round(ppol.n_updates_per_call() * it256 / el, 1),
+        "ms_per_iteration": round(el / it256 * 1e3, 4), "dtype": "bf16 MFMA hidden layers, f32 master weights / accumulate",
+        "n_params": ppol.np, "rollout_us": round(ms_r * 1e3, 1), "update_us": round(ms_u * 1e3, 1),
+        "per_microbatch_us": round(per_step_us, 1), "microbatch": bm3,
+        "kernels": "per net: ppo3w_fwd_kernel + ppo3w_bwd_kernel + ppo3w_dw2_kernel; ppo3w_reduce_kernel; clip_adam (2 launches); "
+                   "ppo3w_pack_kernel",
+        "learner_mfma_tflops": round(mf / (per_step_us * 1e-6) / 1e12, 1),
+        "frac_of_bf16_peak": round(mf / (per_step_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+        "final_loss": float(ppol.losses[0])}
     return out
 
 

@@ -36,6 +36,20 @@ int32_t ppo3_apply_fused(const float* partials, const float* loss_partials, int 
                          float* beta_pow, uint16_t* packed, void* tail, float clip_norm, float lr, float b1, float b2,
                          float eps, hipStream_t s);  // dqn3.hip
 
+// hidden = 256: ppo3w.hip (three streaming kernels per net instead of one tile kernel; same contract)
+int64_t ppo3w_nparams(int ns, int nout_a);
+int64_t ppo3w_workspace_bytes(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t n, int64_t T);
+int32_t ppo3w_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, int64_t T,
+                      const PolicyDesc& pd, const float* params, uint64_t seed, uint32_t env_id_base, uint32_t vec_step0,
+                      const rlhip_ppo_traj* traj, rlhip_stream_t stream);
+int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
+                   const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb,
+                   void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream);
+int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
+                     const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow, uint64_t seed,
+                     uint32_t update_ctr, void* workspace, float* grad_scratch, float* losses_out, rlhip_stream_t stream);
+constexpr int HWIDE = 256;
+
 constexpr int P3_MAX_BLOCKS = 2048;
 constexpr int64_t P3_TAIL_BYTES = 256 * 8 + 64 + 64;  // fused optimiser tail: Float64 partial norms + counters (zero-initialised)
 
@@ -667,7 +681,7 @@ static int32_t allow_lds3(K kernel, size_t bytes, bool* done) {
 static int32_t check3(int32_t kind, const rlhip_ppo_cfg* c, PolicyDesc* pd) {
     int32_t rc = make_desc(kind, c, pd);
     if (rc) return rc;
-    RLHIP_REQUIRE(c->hidden == H3, "layers = 3 (MFMA actor / critic) is built for hidden = 128");
+    RLHIP_REQUIRE(c->hidden == H3 || c->hidden == HWIDE, "layers = 3 (MFMA actor / critic) is built for hidden = 128 or 256");
     RLHIP_REQUIRE(pd->nout_a == 2, "layers = 3 supports CartPole (discrete, 2 actions) and Pendulum (continuous)");
     return RLHIP_OK;
 }
@@ -713,6 +727,7 @@ int64_t ppo3_nparams(int32_t kind, const rlhip_ppo_cfg* c) {
     PolicyDesc pd;
     if (check3(kind, c, &pd)) return -1;
     const int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
+    if (c->hidden == HWIDE) return ppo3w_nparams(ns, pd.nout_a);
     return mlp3_np(ns, pd.nout_a) + mlp3_np(ns, 1);
 }
 
@@ -724,6 +739,11 @@ static int64_t ppo3_nb(const rlhip_ppo_cfg* c, int64_t n, int64_t T) {
 int64_t ppo3_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* c, int64_t n, int64_t T) {
     const int64_t np = ppo3_nparams(kind, c);
     if (np < 0) return -1;
+    if (c->hidden == HWIDE) {
+        PolicyDesc pd;
+        if (check3(kind, c, &pd)) return -1;
+        return ppo3w_workspace_bytes(kind == 0 ? 4 : (kind == 1 ? 3 : 2), pd.nout_a, c, n, T);
+    }
     const int64_t nb = ppo3_nb(c, n, T);
     return 4 * H3 * H3 * (int64_t)sizeof(uint16_t) + nb * (np + 4) * (int64_t)sizeof(float) + 256 + P3_TAIL_BYTES;
 }
@@ -741,6 +761,8 @@ int32_t ppo3_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* s
     RLHIP_REQUIRE(n >= 1 && n <= 0x7FFFFFFFll && T >= 0 && T <= 0x7FFFFFFFll, "bad n / T");
     RLHIP_REQUIRE(traj->obs && traj->logp && traj->value && traj->reward && traj->terminal, "trajectory array is NULL");
     RLHIP_REQUIRE(pd.cont ? (traj->action_f != nullptr) : (traj->action_i != nullptr), "action trace is NULL");
+    if (cfg->hidden == HWIDE)
+        return ppo3w_rollout(kind, env_cfg, st, n, T, pd, params, seed, env_id_base, vec_step0, traj, stream);
     hipStream_t s = as_stream(stream);
     if (kind == 0)
         return rollout3_impl<CartPoleParams<float>>((const rlhip_cartpole_cfg*)env_cfg, st, n, T, pd, params, seed,
@@ -775,6 +797,8 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
     RLHIP_REQUIRE(kind == 0 || kind == 1, "layers = 3 supports CartPole and Pendulum");
     RLHIP_REQUIRE(traj && params && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(cfg->n_microbatches >= 1 && mb >= 0 && mb < cfg->n_microbatches, "micro-batch index out of range");
+    if (cfg->hidden == HWIDE)  // (no fused tail: *tail->fused_out stays false and the caller runs clip + Adam)
+        return ppo3w_grad(kind, cfg, pd, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_out, losses_out, stream);
     const int ns = kind == 0 ? 4 : 3;
     const int64_t total = n * T;
     RLHIP_REQUIRE(total >= 1 && total <= 0x7FFFFFFFll, "n * T out of range");
@@ -920,6 +944,15 @@ int32_t ppo3_update(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T
     RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
     const int64_t np = ppo3_nparams(kind, cfg);
     RLHIP_REQUIRE(np > 0, "bad configuration");
+    if (cfg->hidden == HWIDE) {
+        PolicyDesc pd;
+        int32_t rc = check3(kind, cfg, &pd);
+        if (rc) return rc;
+        RLHIP_REQUIRE(kind == 0 || kind == 1, "layers = 3 supports CartPole and Pendulum");
+        RLHIP_REQUIRE(traj && workspace && cfg->n_microbatches >= 1, "NULL argument");
+        return ppo3w_update(kind, cfg, pd, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace, grad_scratch,
+                            losses_out, stream);
+    }
     bool packed_fresh = false;  // the previous optimiser step's fused tail left the bf16 W2 images up to date
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;

@@ -1,0 +1,1052 @@
+// ppo3w.hip -- the three-layer PPO actor / critic at hidden width 256 (rlhip_ppo_cfg.layers = 3, hidden = 256):
+//     actor  ns -> 256 -> 256 -> nout_a      critic  ns -> 256 -> 256 -> 1
+// Same reference code, precision contract and oracle as ppo3.hip (bf16 operands / f32 accumulate on
+// v_mfma_f32_32x32x16_bf16 for the hidden x hidden layer and its two backward GEMMs, f32 master weights, everything else
+// f32; oracle/rlo_learn.c with cfg.layers = 3, hidden = 256), selected behind the unchanged rlhip_ppo_* entry points.
+//
+// Why a separate design.  At 128 the learner tile of ppo3.hip keeps both bf16 images of W2 (64 KB) in LDS and the whole
+// forward -> loss -> backward chain of a sample tile inside one workgroup.  At 256 one net's two images are 256 KB: they
+// do not fit the 160 KB of LDS, and the dW2 accumulators alone (256 x 256 f32) are 128 registers per lane of an 8-wave
+// workgroup.  So the width-256 learner is THREE streaming kernels per net, each with exactly one operand resident in
+// registers for the lifetime of a persistent workgroup (the scheme of dense_persist_kernel, dense_mfma.hip), 8 waves per
+// workgroup, wave w owning the 32 output columns [32 w, 32 w + 32) of its GEMM, 64-sample tiles:
+//   ppo3w_fwd_kernel  W2 fragments resident (64 VGPRs).  gather -> layer 1 (VALU) -> H1 tile in LDS -> MFMA -> H2 in
+//                     registers -> head (DPP) -> PPO loss line per sample -> dZ2 in the MFMA D layout; db2 / dW3 / db3
+//                     and the loss sums stay in registers across tiles.  dZ2 leaves as bf16 twice: row-major (A operand
+//                     of dH1 = dZ2 W2, via the consumed H1 tile: 16 B per lane) and in MFMA B-fragment order (B operand of
+//                     dW2 = H1^T dZ2: the D layout holds 4 consecutive samples of one column per register group, which
+//                     IS 8 of the 16 bytes of a fragment slot -- 512 B contiguous per store instruction, no transposition).
+//   ppo3w_bwd_kernel  W2^T fragments resident.  dZ2 rows tile -> LDS -> MFMA -> dH1 in registers; z1 is recomputed from
+//                     the gathered observation (ns <= 4 FMAs per element: cheaper than 2 bytes of HBM), dz1, db1 / dW1
+//                     in registers across tiles.
+//   ppo3w_dw2_kernel  the 256 x 256 f32 accumulator resident: a workgroup owns one half of the k range (128 x 256
+//                     outputs = 64 accumulator registers per lane) for a strided set of sample tiles; A = H1^T recomputed
+//                     into LDS in [k][sample] order, B = the dZ2 fragments straight from global memory (1 KB per wave load,
+//                     every element fetched once per workgroup).
+// Partial gradients are rows (one per persistent workgroup) summed in a fixed order by ppo3w_reduce_kernel: deterministic,
+// no atomics.  HBM traffic per sample and net: 2 x 512 B written + 2 x 512 B read (+ 512 B for the second k half) against
+// 0.39 MFLOP of MFMA work -- the path is MFMA / L2 bound, not HBM bound.
+// ppo3w_rollout_kernel  the rollout of ppo3.hip's 32-env workgroups at width 256: 8 waves, BOTH nets' W2 fragments in
+//                     registers (2 x 64 VGPRs, converted from the f32 master weights at kernel entry) for all T vec-steps,
+//                     f32 H2 tiles in LDS for the heads.
+#include "env_device.h"
+#include "ppo_common.h"
+#include "ppo_sample_device.h"
+#include "mlp3_device.h"
+
+extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow, int64_t n,
+                                       float grad_scale, float clip_norm, float lr, float beta1, float beta2,
+                                       float eps, float* gn_out, rlhip_stream_t stream);
+
+namespace rlhip {
+
+constexpr int HW = 256;        // hidden width
+constexpr int WV = HW / 32;    // 8 waves; wave w owns output columns [32 w, 32 w + 32)
+constexpr int NTW = 64 * WV;   // 512 threads
+constexpr int RW = 64;         // samples per tile (two 32-row MFMA tiles)
+constexpr int PW = HW + 8;     // bf16 pitch of a [sample][feature] tile: 528 B
+constexpr int KSW = HW / 16;   // MFMA k-steps across the hidden width
+constexpr int PT = RW + 8;     // bf16 pitch of a [feature][sample] tile: 144 B
+constexpr int SMALLWW = HW * 4 + HW + HW + MAXO * HW + MAXO + 4;  // floats: W1 | b1 | b2 | W3 | b3 of one net (ns <= 4)
+
+__host__ __device__ __forceinline__ int64_t mlp3w_np(int64_t ns, int64_t nout) {
+    return HW * ns + HW + (int64_t)HW * HW + HW + nout * HW + nout;
+}
+// "small" parameter space of one net = everything except W2, in parameter order: W1 | b1 | b2 | W3 | b3
+__host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { return HW * ns + 2 * HW + nout * HW + nout; }
+
+struct Mlp3W {
+    const float *W1, *b1, *b2, *W3, *b3;
+};
+
+// W1 | b1 and b2 | W3 | b3 (the two parameter ranges around W2) -> LDS.  Caller barriers before use.
+__device__ __forceinline__ Mlp3W stage_small_w(const float* __restrict__ p, int ns, int nout, float* l_w, int tid) {
+    const int n1 = HW * ns + HW;
+    const int n2 = HW + nout * HW + nout;
+    const float* p2 = p + n1 + HW * HW;
+    for (int i = tid; i < n1; i += NTW) l_w[i] = p[i];
+    for (int i = tid; i < n2; i += NTW) l_w[n1 + i] = p2[i];
+    Mlp3W v;
+    v.W1 = l_w;
+    v.b1 = l_w + HW * ns;
+    v.b2 = l_w + n1;
+    v.W3 = v.b2 + HW;
+    v.b3 = v.W3 + nout * HW;
+    return v;
+}
+
+struct P3WArgs {
+    const float* obs;
+    const float* logp;
+    const float* adv;
+    const float* ret;
+    const float* action_f;
+    const int32_t* action_i;
+    const float* params;     // [actor | critic]
+    const uint16_t* packed;  // actor W2jk | actor W2kj | critic W2jk | critic W2kj   (MFMA B-fragment order, HW * HW each)
+    uint16_t* dz_rows;       // [ntiles * RW][HW] bf16
+    uint16_t* dz_frag;       // [ntiles][RW / 16][WV][64 lanes][8] bf16
+    float* partS;            // [rows][npS]: partial gradients of the small tensors, [actor small | critic small]
+    float* partW;            // [rows][2][HW * HW]: partial dW2 (Flux order W2[j + HW k])
+    float* loss_partials;    // [rows][4] {sum min(surr1, surr2), sum (ret - v)^2, sum entropy, -}
+    int64_t n, np_a;
+    uint32_t total, bm, pos0;
+    int ntiles, npS, nS_a, na;
+    float lo, hi, wa, wc, we, inv_b, min_logp;
+    PermKeys pk;
+};
+
+// both nets' W2 -> bf16 MFMA B fragments.  Fragment (ks, t) = 64 lanes x 8 elements, lane l, element u:
+//   W2jk (forward, H2 = H1 W2^T):   B[k = 16 ks + 8 (l >> 5) + u][col j = 32 t + (l & 31)] = W2[j + HW k]
+//   W2kj (backward, dH1 = dZ2 W2):  B[j = 16 ks + 8 (l >> 5) + u][col k = 32 t + (l & 31)] = W2[j + HW k]
+__global__ __launch_bounds__(256) void ppo3w_pack_kernel(const float* __restrict__ params, int ns, int64_t np_a,
+                                                         uint16_t* __restrict__ packed) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 2 * HW * HW) return;
+    const int net = q / (HW * HW);
+    q -= net * HW * HW;
+    const float* W2 = params + (net ? np_a : 0) + HW * ns + HW;
+    uint16_t* pk = packed + (int64_t)net * 2 * HW * HW;
+    const int u = q & 7, l = (q >> 3) & 63, f = q >> 9;
+    const int t = f % WV, ks = f / WV;
+    const int col = 32 * t + (l & 31), kk = 16 * ks + 8 * (l >> 5) + u;
+    pk[q] = f32_to_bf16_rne(W2[col + HW * kk]);
+    pk[HW * HW + q] = f32_to_bf16_rne(W2[kk + HW * col]);
+}
+
+__device__ __forceinline__ void load_frags_w(const uint16_t* __restrict__ wf, int w, int lane, bf16x8 (&bw)[KSW]) {
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) bw[ks] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(ks * WV + w) * 64 + lane) * 8);
+}
+
+// the same fragments converted on the fly from the f32 master weights (rollout: once per launch, no packed image needed):
+// lane l of wave w, k-step ks: W2[j = 32 w + (l & 31)][k = 16 ks + 8 (l >> 5) + u], u = 0..7 (128 B coalesced per load)
+__device__ __forceinline__ void load_frags_f32(const float* __restrict__ W2, int w, int lane, bf16x8 (&bw)[KSW]) {
+    const float* src = W2 + 32 * w + (lane & 31) + HW * 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[HW * (16 * ks + u)];
+        const uint4 pk = pack8_bf16(v);
+        bw[ks] = __builtin_bit_cast(bf16x8, pk);
+    }
+}
+
+// the tile's samples f = perm(pos0 + q): observation components -> l_x [4][RW]; returns f and validity
+__device__ __forceinline__ uint32_t gather_x(const P3WArgs& g, int ns, int tile, int tid, float* l_x, bool* valid_out) {
+    const uint32_t q = (uint32_t)tile * RW + (uint32_t)tid;
+    const bool valid = q < g.bm;
+    const uint32_t f = permute(g.pk, g.pos0 + (valid ? q : 0u));
+    const uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
+    for (int k = 0; k < ns; ++k) l_x[k * RW + tid] = g.obs[((int64_t)t * ns + k) * g.n + i];
+    *valid_out = valid;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------ forward + loss + dZ2
+constexpr size_t FWDW_LDS = (4 * RW + 4 * RW + MAXO * RW + WV * MAXO * RW + SMALLWW) * sizeof(float) +
+                            (size_t)RW * PW * sizeof(uint16_t);
+
+template <int NS, int NOUT, int ACT, int CONT, int NET>
+__global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    float* l_x = reinterpret_cast<float*>(smw);  // [4][RW]
+    float* l_s = l_x + 4 * RW;                   // [4][RW]: old log-prob, advantage, return, action
+    float* l_dq = l_s + 4 * RW;                  // [MAXO][RW] dL/d(head outputs)
+    float* l_part = l_dq + MAXO * RW;            // [WV][MAXO][RW] head partial sums per wave
+    float* l_w = l_part + WV * MAXO * RW;        // [SMALLWW]
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + SMALLWW);  // [RW][PW]: H1, then dZ2 rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int col = 32 * w + r;
+    const float* pnet = g.params + (NET ? g.np_a : 0);
+    const Mlp3W m = stage_small_w(pnet, NS, NOUT, l_w, tid);
+    bf16x8 bw[KSW];
+    load_frags_w(g.packed + (NET ? 2 * HW * HW : 0), w, lane, bw);
+    __syncthreads();
+    const float b2v = m.b2[col];
+    float w3[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) w3[o] = m.W3[o + NOUT * col];
+    float a_db2 = 0.0f, a_dw3[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) a_dw3[o] = 0.0f;
+    float s_red[NOUT + 2];  // wave 0, one sample row per lane: sum dq[o] (= db3), loss terms
+#pragma unroll
+    for (int o = 0; o < NOUT + 2; ++o) s_red[o] = 0.0f;
+    const int row1 = tid & (RW - 1), u0 = 32 * (tid >> 6);  // layer 1: this thread's sample row and its 32 hidden units
+
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        if (tid < RW) {
+            bool valid;
+            const uint32_t f = gather_x(g, NS, tile, tid, l_x, &valid);
+            if (NET == 0) {
+                l_s[tid] = g.logp[f];
+                l_s[RW + tid] = valid ? g.adv[f] : 0.0f;
+                l_s[3 * RW + tid] = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
+            } else {
+                l_s[2 * RW + tid] = g.ret[f];
+            }
+        }
+        __syncthreads();
+        // ---- layer 1: h1 = act(b1 + W1 x) (the fmaf chain of mlp2 / the oracle), bf16 rows ----
+        {
+            float x[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = l_x[i * RW + row1];
+            uint16_t* dst = l_H + row1 * PW + u0;
+#pragma unroll
+            for (int h8 = 0; h8 < 4; ++h8) {
+                float hv[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const int u = u0 + 8 * h8 + 4 * q4;
+                    const float4 b = *reinterpret_cast<const float4*>(m.b1 + u);
+                    float z[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const float4 wv = *reinterpret_cast<const float4*>(m.W1 + u + HW * i);
+                        z[0] = fmaf(wv.x, x[i], z[0]);
+                        z[1] = fmaf(wv.y, x[i], z[1]);
+                        z[2] = fmaf(wv.z, x[i], z[2]);
+                        z[3] = fmaf(wv.w, x[i], z[3]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+                }
+                *reinterpret_cast<uint4*>(dst + 8 * h8) = pack8_bf16(hv);
+            }
+        }
+        __syncthreads();
+        // ---- layer 2 on the MFMA: this wave's 32 columns for the tile's 64 rows; bias + activation ----
+        f32x16 h2[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) h2[rt][q] = 0.0f;
+        {
+            const uint16_t* ap = l_H + r * PW + 8 * kb;
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PW + 16 * ks);
+                    h2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], h2[rt], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) h2[rt][q] = act_fwd_t<ACT>(h2[rt][q] + b2v);
+        // ---- head: this wave's share of sum_j W3[o, j] h2[j] per row (32 columns: DPP row sums + lane ^ 16) ----
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float a = swap16_add(reduce16_dpp(w3[o] * h2[rt][q]));
+                    if (r == 0) l_part[(w * MAXO + o) * RW + 32 * rt + mfma_row(q, kb)] = a;
+                }
+        __syncthreads();
+        // ---- the loss line of each sample and dL/d(head outputs): wave 0, one row per lane ----
+        if (tid < RW) {
+            const int s = tid;
+            const bool valid = ((uint32_t)tile * RW + (uint32_t)s) < g.bm;
+            float oa[MAXO] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float acc = l_part[o * RW + s];
+#pragma unroll
+                for (int ww = 1; ww < WV; ++ww) acc += l_part[(ww * MAXO + o) * RW + s];
+                oa[o] = acc + m.b3[o];
+            }
+            if (NET == 0) {
+                float dl[MAXO] = {0.f, 0.f, 0.f, 0.f};
+                const float lp_old = fmaxf(l_s[s], g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
+                const float A = l_s[RW + s];
+                float ent, surr_min;
+                if (!CONT) {
+                    const int na = g.na;
+                    float mx = oa[0];
+                    for (int k = 1; k < na; ++k) mx = fmaxf(mx, oa[k]);
+                    float se = 0.f;
+                    for (int k = 0; k < na; ++k) se += expf(oa[k] - mx);
+                    const float lse = logf(se);
+                    float logp[MAXO], pr[MAXO];
+                    ent = 0.f;
+                    for (int k = 0; k < na; ++k) {
+                        logp[k] = (oa[k] - mx) - lse;
+                        pr[k] = expf(logp[k]);
+                        ent -= pr[k] * logp[k];
+                    }
+                    const int a = __float_as_int(l_s[3 * RW + s]);
+                    float lp_new = 0.f;
+                    for (int k = 0; k < na; ++k)
+                        if (k == a) lp_new = logp[k];
+                    const float ratio = expf(lp_new - lp_old);
+                    const float surr1 = ratio * A;
+                    const float surr2 = fminf(fmaxf(ratio, g.lo), g.hi) * A;
+                    const bool inside = ratio >= g.lo && ratio <= g.hi;
+                    const float dobj = (inside || surr1 < surr2) ? A : 0.f;
+                    const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
+                    surr_min = fminf(surr1, surr2);
+                    for (int k = 0; k < na; ++k) {
+                        const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
+                        const float dent = -pr[k] * (logp[k] + ent);
+                        dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
+                    }
+                } else {
+                    const float eps = 1.0e-8f;
+                    const float mu = oa[0], ls = oa[1];
+                    const float sg = expf(ls);
+                    const float z = l_s[3 * RW + s];
+                    const float se = sg + eps;
+                    const float zz = (z - mu) / se;
+                    const float lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
+                    ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
+                    const float dmu = (z - mu) / (se * se);
+                    const float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
+                    const float ratio = expf(lp_new - lp_old);
+                    const float surr1 = ratio * A;
+                    const float surr2 = fminf(fmaxf(ratio, g.lo), g.hi) * A;
+                    const bool inside = ratio >= g.lo && ratio <= g.hi;
+                    const float dobj = (inside || surr1 < surr2) ? A : 0.f;
+                    const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
+                    surr_min = fminf(surr1, surr2);
+                    dl[0] = dL_dlp * dmu;
+                    dl[1] = dL_dlp * dls - g.we * g.inv_b * 0.5f;
+                }
+                if (!valid) {
+                    dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
+                    surr_min = 0.f;
+                    ent = 0.f;
+                }
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    l_dq[o * RW + s] = dl[o];
+                    s_red[o] += dl[o];
+                }
+                s_red[NOUT] += surr_min;
+                s_red[NOUT + 1] += ent;
+            } else {
+                const float dv = l_s[2 * RW + s] - oa[0];
+                float dvout = -2.0f * g.wc * g.inv_b * dv;
+                float sq = dv * dv;
+                if (!valid) {
+                    dvout = 0.f;
+                    sq = 0.f;
+                }
+                l_dq[s] = dvout;
+                s_red[0] += dvout;
+                s_red[NOUT] += sq;
+            }
+        }
+        __syncthreads();
+        // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32) -> db2; dz2 -> bf16, rows (LDS) + fragments ----
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * rt + mfma_row(q, kb);
+                float dqv[NOUT];
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) dqv[o] = l_dq[o * RW + row];
+                const float hv = h2[rt][q];
+                float dh = 0.0f;
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    a_dw3[o] = fmaf(dqv[o], hv, a_dw3[o]);
+                    dh = fmaf(dqv[o], w3[o], dh);
+                }
+                const float dz = dh * act_bwd_t<ACT>(hv, hv);  // relu: h2 > 0 <=> z2 > 0
+                a_db2 += dz;
+                h2[rt][q] = dz;  // the register is free: keep dz for the packed stores below
+                l_H[row * PW + col] = f32_to_bf16_rne(dz);
+            }
+            // fragment order: samples 32 rt + 8 gq + 4 kb + {0..3} of column `col` = bytes 8 kb .. 8 kb + 7 of slot
+            // (k-step 2 rt + (gq >> 1), column tile w, lane 32 (gq & 1) + r)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 v2;
+                v2.x = pack2_bf16(h2[rt][4 * gq + 0], h2[rt][4 * gq + 1]);
+                v2.y = pack2_bf16(h2[rt][4 * gq + 2], h2[rt][4 * gq + 3]);
+                const int64_t slot = (((int64_t)tile * (RW / 16) + 2 * rt + (gq >> 1)) * WV + w) * 64 + 32 * (gq & 1) + r;
+                *reinterpret_cast<uint2*>(g.dz_frag + slot * 8 + 4 * kb) = v2;
+            }
+        }
+        __syncthreads();
+        // ---- dZ2 rows -> global, 16 B per lane ----
+        {
+            uint16_t* dst = g.dz_rows + (int64_t)tile * RW * HW;
+#pragma unroll
+            for (int i = 0; i < RW * HW / 8 / NTW; ++i) {
+                const int c = tid + NTW * i, row = c >> 5, cc = c & 31;
+                *reinterpret_cast<uint4*>(dst + row * HW + 8 * cc) = *reinterpret_cast<const uint4*>(l_H + row * PW + 8 * cc);
+            }
+        }
+        // the next pass writes l_x / l_s (last read before the previous barrier) and then waits at its first barrier,
+        // which every thread reaches only after the copy above
+    }
+    // ---- this workgroup's partial row: b2, W3, b3 and the loss sums ----
+    const int sb2 = HW * NS + HW, sW3 = sb2 + HW, sb3 = sW3 + NOUT * HW;
+    float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + (NET ? g.nS_a : 0);
+    a_db2 += __shfl_xor(a_db2, 32, 64);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) a_dw3[o] += __shfl_xor(a_dw3[o], 32, 64);
+    if (kb == 0) {
+        rowS[sb2 + col] = a_db2;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) rowS[sW3 + o + NOUT * col] = a_dw3[o];
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int o = 0; o < NOUT + 2; ++o) s_red[o] = wave_sum_f32(s_red[o]);
+        if (lane == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) rowS[sb3 + o] = s_red[o];
+            float* lp = g.loss_partials + (int64_t)blockIdx.x * 4;
+            if (NET == 0) {
+                lp[0] = s_red[NOUT];
+                lp[2] = s_red[NOUT + 1];
+            } else {
+                lp[1] = s_red[NOUT];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dH1 -> dW1 / db1
+constexpr size_t BWDW_LDS = (4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)RW * PW * sizeof(uint16_t);
+
+template <int NS, int ACT>
+__global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    float* l_x = reinterpret_cast<float*>(smw);  // [4][RW]
+    float* l_w = l_x + 4 * RW;                   // W1 | b1
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [RW][PW] dZ2 rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int k = 32 * w + r;  // this lane's hidden unit of layer 1
+    const float* pnet = g.params + (net ? g.np_a : 0);
+    for (int i = tid; i < HW * NS + HW; i += NTW) l_w[i] = pnet[i];
+    bf16x8 bw[KSW];
+    load_frags_w(g.packed + (net ? 2 * HW * HW : 0) + HW * HW, w, lane, bw);
+    __syncthreads();
+    float w1[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) w1[i] = l_w[k + HW * i];
+    const float b1v = l_w[HW * NS + k];
+    float a_db1 = 0.0f, a_dw1[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) a_dw1[i] = 0.0f;
+
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        if (tid < RW) {
+            bool valid;
+            gather_x(g, NS, tile, tid, l_x, &valid);
+        }
+        {
+            const uint16_t* src = g.dz_rows + (int64_t)tile * RW * HW;
+#pragma unroll
+            for (int i = 0; i < RW * HW / 8 / NTW; ++i) {
+                const int c = tid + NTW * i, row = c >> 5, cc = c & 31;
+                *reinterpret_cast<uint4*>(l_H + row * PW + 8 * cc) = *reinterpret_cast<const uint4*>(src + row * HW + 8 * cc);
+            }
+        }
+        __syncthreads();
+        f32x16 dh[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dh[rt][q] = 0.0f;
+        {
+            const uint16_t* ap = l_H + r * PW + 8 * kb;
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PW + 16 * ks);
+                    dh[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], dh[rt], 0, 0, 0);
+                    if (rt == 1 && (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 8 A fragments in flight
+                }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * rt + mfma_row(q, kb);
+                float x[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) x[i] = l_x[i * RW + row];
+                float z = b1v;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], x[i], z);
+                const float hv = act_fwd_t<ACT>(z);
+                const float dz = dh[rt][q] * act_bwd_t<ACT>(z, hv);
+                a_db1 += dz;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) a_dw1[i] = fmaf(dz, x[i], a_dw1[i]);
+                // keep the unrolled rows in program order (otherwise every LDS read of the 32 rows is hoisted to the top
+                // and the live x values spill)
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();  // l_x / l_H are rewritten by the next pass
+    }
+    const int nS_net = net ? g.nS_a : 0;
+    float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + nS_net;
+    a_db1 += __shfl_xor(a_db1, 32, 64);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) a_dw1[i] += __shfl_xor(a_dw1[i], 32, 64);
+    if (kb == 0) {
+        rowS[HW * NS + k] = a_db1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) rowS[k + HW * i] = a_dw1[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dW2 = H1^T dZ2
+constexpr size_t DW2W_LDS = (4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)(HW / 2) * PT * sizeof(uint16_t);
+
+template <int NS, int ACT>
+__global__ __launch_bounds__(NTW, 4) void ppo3w_dw2_kernel(P3WArgs g, int net, int nsr) {
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    float* l_x = reinterpret_cast<float*>(smw);  // [4][RW]
+    float* l_w = l_x + 4 * RW;                   // W1 | b1
+    uint16_t* l_T = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [HW / 2][PT]: H1^T of this k half
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int kh = blockIdx.x & 1, sr = blockIdx.x >> 1;
+    const float* pnet = g.params + (net ? g.np_a : 0);
+    for (int i = tid; i < HW * NS + HW; i += NTW) l_w[i] = pnet[i];
+    f32x16 acc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[kt][q] = 0.0f;
+
+    for (int tile = sr; tile < g.ntiles; tile += nsr) {
+        if (tid < RW) {
+            bool valid;
+            gather_x(g, NS, tile, tid, l_x, &valid);
+        }
+        bf16x8 b[RW / 16];  // this wave's column tile of dZ2 for the tile's four k-steps: in flight during layer 1
+#pragma unroll
+        for (int ks = 0; ks < RW / 16; ++ks)
+            b[ks] = *reinterpret_cast<const bf16x8*>(g.dz_frag + ((((int64_t)tile * (RW / 16) + ks) * WV + w) * 64 + lane) * 8);
+        __syncthreads();
+        // ---- layer 1 in [k][sample] order for the 128 hidden units of this half: 8 samples of one unit per item ----
+#pragma unroll
+        for (int it = 0; it < (HW / 2) * (RW / 8) / NTW; ++it) {
+            const int item = tid + NTW * it, rg = item & 7, kl = item >> 3;
+            const int k = (HW / 2) * kh + kl;
+            float w1[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) w1[i] = l_w[k + HW * i];
+            const float bb = l_w[HW * NS + k];
+            float hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float z = bb;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], l_x[i * RW + 8 * rg + u], z);
+                hv[u] = act_fwd_t<ACT>(z);
+            }
+            *reinterpret_cast<uint4*>(l_T + kl * PT + 8 * rg) = pack8_bf16(hv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < RW / 16; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(l_T + (32 * kt + r) * PT + 16 * ks + 8 * kb);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc[kt], 0, 0, 0);
+            }
+        __syncthreads();  // l_x / l_T are rewritten by the next pass
+    }
+    // D[row = k (local)][col = j]: dW2[j + HW k]
+    float* out = g.partW + ((int64_t)sr * 2 + net) * HW * HW;
+    const int j = 32 * w + r;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[j + HW * ((HW / 2) * kh + 32 * kt + mfma_row(q, kb))] = acc[kt][q];
+}
+
+// ------------------------------------------------------------------------------------------------ partial rows -> gradient
+__global__ __launch_bounds__(256) void ppo3w_reduce_kernel(const float* __restrict__ partS, const float* __restrict__ partW,
+                                                           const float* __restrict__ loss_partials, int nrowsS, int nrowsW,
+                                                           int npS, int nS_a, int np, int np_a, int ns,
+                                                           float* __restrict__ grad, float* __restrict__ losses, float wa,
+                                                           float wc, float we, float inv_b) {
+    __shared__ float l_g[4][64];
+    __shared__ float l_loss[4];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (p < np) {
+        const int net = p >= np_a ? 1 : 0;
+        const int q = p - net * np_a;
+        const int nA = HW * ns + HW;
+        const float* src;
+        int64_t stride;
+        int nrows;
+        if (q < nA) {
+            src = partS + (net ? nS_a : 0) + q;
+            stride = npS;
+            nrows = nrowsS;
+        } else if (q < nA + HW * HW) {
+            src = partW + (int64_t)net * HW * HW + (q - nA);
+            stride = 2 * HW * HW;
+            nrows = nrowsW;
+        } else {
+            src = partS + (net ? nS_a : 0) + (q - HW * HW);
+            stride = npS;
+            nrows = nrowsS;
+        }
+        const int per = (nrows + 3) / 4;
+        const int b0 = grp * per, b1 = min(nrows, b0 + per);
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) acc += src[(int64_t)b * stride];
+    }
+    l_g[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && p < np) grad[p] = ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane];
+    if (blockIdx.x == 0 && losses != nullptr) {
+        if (grp < 3) {
+            float a = 0.f;
+            for (int b = lane; b < nrowsS; b += 64) a += loss_partials[(int64_t)b * 4 + grp];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) l_loss[grp] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float actor_loss = -l_loss[0] * inv_b;
+            const float critic_loss = l_loss[1] * inv_b;
+            const float ent_loss = l_loss[2] * inv_b;
+            losses[0] = wa * actor_loss + wc * critic_loss - we * ent_loss;
+            losses[1] = actor_loss;
+            losses[2] = critic_loss;
+            losses[3] = ent_loss;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rollout
+// 32 env instances per workgroup for all T vec-steps (ppo3_rollout32_kernel at width 256): 8 waves share the 32-row tile,
+// wave w multiplies it by its 32-column block of W2 -- both nets' blocks live in registers for the whole launch.
+constexpr int R32W = 32;
+constexpr int LDH2W = HW + 4;   // f32 pitch of the H2 tiles
+constexpr int NCHW = 8;         // sampling noise of 8 steps per evaluation (threads 0..255: 8 steps x 32 envs)
+constexpr int NPARTW = NTW / R32W;  // 16 column parts per H2 row in the head phase
+constexpr size_t ROLLW_NOISE_OFF = (((4 * R32W + NPARTW * 4 * R32W + 2 * R32W * LDH2W + 2 * SMALLWW) * sizeof(float) +
+                                     (2 * R32W * PW) * sizeof(uint16_t)) + 15) & ~(size_t)15;
+constexpr size_t ROLLW_LDS = ROLLW_NOISE_OFF + 2 * NCHW * R32W * MAXO * sizeof(double);
+
+template <class P, int NOUT_A, int ACT>
+__global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float> st, int64_t n, int T, int cont, int na,
+                                                            const float* __restrict__ params, int64_t np_a, uint64_t seed,
+                                                            uint32_t env_id_base, uint32_t vec_step0, TrajPtrs tr, float gamma,
+                                                            float lambda) {
+    constexpr int NS = P::ODIM;
+    constexpr int NO = NOUT_A + 1;  // head outputs per env: the actor's, then the value
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    float* l_x = reinterpret_cast<float*>(smw);   // [4][R32W]
+    float* l_part = l_x + 4 * R32W;               // [NPARTW][4][R32W]
+    float* l_h2a = l_part + NPARTW * 4 * R32W;    // [R32W][LDH2W] actor H2 (f32)
+    float* l_h2c = l_h2a + R32W * LDH2W;          // critic H2
+    float* l_w = l_h2c + R32W * LDH2W;            // [2][SMALLWW]
+    uint16_t* l_Ha = reinterpret_cast<uint16_t*>(l_w + 2 * SMALLWW);  // actor H1 tile [R32W][PW] (bf16)
+    uint16_t* l_Hc = l_Ha + R32W * PW;            // critic H1 tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const Mlp3W ma = stage_small_w(params, NS, NOUT_A, l_w, tid);
+    const Mlp3W mc = stage_small_w(params + np_a, NS, 1, l_w + SMALLWW, tid);
+    bf16x8 bwa[KSW], bwc[KSW];
+    load_frags_f32(params + HW * NS + HW, w, lane, bwa);
+    load_frags_f32(params + np_a + HW * NS + HW, w, lane, bwc);
+
+    const int64_t env = (int64_t)blockIdx.x * R32W + tid;
+    const bool active = tid < R32W && env < n;
+    const int64_t envc = env < n ? env : n - 1;
+    const uint32_t id = env_id_base + (uint32_t)envc;
+    LaneState<float> e;
+    float last_r = 0.0f;
+    bool last_d = false;
+    if (tid < R32W) {
+#pragma unroll
+        for (int k = 0; k < P::SDIM; ++k) e.s[k] = st.s[k][envc];
+        e.t = st.t[envc];
+        e.episode = st.episode[envc];
+    }
+    const int row1 = tid & 31, u0 = 16 * (tid >> 5);  // layer 1: this thread's row and its 16 hidden units
+    const int part = tid >> 5;                        // heads: this thread's 16-column part of the H2 row `row1`
+    double* l_noise = reinterpret_cast<double*>(smw + ROLLW_NOISE_OFF);  // [2][NCHW][R32W][MAXO]
+    __syncthreads();
+    const int colw = 32 * w + r;
+    const float b2a = ma.b2[colw], b2c = mc.b2[colw];
+    for (int t = 0; t <= T; ++t) {
+        if ((t & (NCHW - 1)) == 0 && tid < NCHW * R32W) {
+            const int i = tid >> 5, er = tid & (R32W - 1);
+            if (t + i < T) {
+                const int64_t en = (int64_t)blockIdx.x * R32W + er;
+                double nz[MAXO] = {0.0, 0.0, 0.0, 0.0};
+                policy_noise(cont, na, seed, env_id_base + (uint32_t)(en < n ? en : n - 1), vec_step0 + (uint32_t)(t + i), nz);
+                double* dst = l_noise + ((size_t)((((t / NCHW) & 1) * NCHW + i) * R32W + er)) * MAXO;
+#pragma unroll
+                for (int k = 0; k < MAXO; ++k) dst[k] = nz[k];
+            }
+        }
+        if (tid < R32W) {
+            float x[4];
+            env_obs1(p, e, x);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                l_x[k * R32W + tid] = x[k];
+                if (active) tr.obs[((int64_t)t * NS + k) * n + env] = x[k];
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 of both nets, 16 units per thread ----
+        {
+            float x[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = l_x[i * R32W + row1];
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                if (net == 0 && t == T) continue;  // the last pass only needs V(s_T)
+                const Mlp3W& m = net ? mc : ma;
+                uint16_t* dst = (net ? l_Hc : l_Ha) + row1 * PW + u0;
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8) {
+                    float hv[8];
+#pragma unroll
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const int u = u0 + 8 * h8 + 4 * q4;
+                        const float4 b = *reinterpret_cast<const float4*>(m.b1 + u);
+                        float z[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const float4 wv = *reinterpret_cast<const float4*>(m.W1 + u + HW * i);
+                            z[0] = fmaf(wv.x, x[i], z[0]);
+                            z[1] = fmaf(wv.y, x[i], z[1]);
+                            z[2] = fmaf(wv.z, x[i], z[2]);
+                            z[3] = fmaf(wv.w, x[i], z[3]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+                    }
+                    *reinterpret_cast<uint4*>(dst + 8 * h8) = pack8_bf16(hv);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- layer 2: this wave's 32 output columns of both nets (MFMA), bias + activation, f32 tiles to LDS ----
+        {
+            f32x16 aa, ac;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) aa[q] = 0.0f, ac[q] = 0.0f;
+            const uint16_t* apa = l_Ha + r * PW + 8 * kb;
+            const uint16_t* apc = l_Hc + r * PW + 8 * kb;
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                if (t < T) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(apa + 16 * ks);
+                    aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwa[ks], aa, 0, 0, 0);
+                }
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(apc + 16 * ks);
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bwc[ks], ac, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = mfma_row(q, kb);
+                if (t < T) l_h2a[row * LDH2W + colw] = act_fwd_t<ACT>(aa[q] + b2a);
+                l_h2c[row * LDH2W + colw] = act_fwd_t<ACT>(ac[q] + b2c);
+            }
+        }
+        __syncthreads();
+        // ---- heads: thread (row1, part) folds 16 columns of its H2 row for every output ----
+        {
+            float pa[NOUT_A], pc = 0.0f;
+#pragma unroll
+            for (int o = 0; o < NOUT_A; ++o) pa[o] = 0.0f;
+            const float* ha = l_h2a + row1 * LDH2W + 16 * part;
+            const float* hc = l_h2c + row1 * LDH2W + 16 * part;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 vc = *reinterpret_cast<const float4*>(hc + 4 * c4);
+                const float hcv[4] = {vc.x, vc.y, vc.z, vc.w};
+                float hav[4] = {0.f, 0.f, 0.f, 0.f};
+                if (t < T) {
+                    const float4 va = *reinterpret_cast<const float4*>(ha + 4 * c4);
+                    hav[0] = va.x, hav[1] = va.y, hav[2] = va.z, hav[3] = va.w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 16 * part + 4 * c4 + c;
+                    pc = fmaf(mc.W3[j], hcv[c], pc);
+#pragma unroll
+                    for (int o = 0; o < NOUT_A; ++o) pa[o] = fmaf(ma.W3[o + NOUT_A * j], hav[c], pa[o]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT_A; ++o) l_part[(part * 4 + o) * R32W + row1] = pa[o];
+            l_part[(part * 4 + NOUT_A) * R32W + row1] = pc;
+        }
+        __syncthreads();
+        if (tid < R32W) {
+            float out[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                float acc = l_part[o * R32W + tid];
+#pragma unroll
+                for (int pp = 1; pp < NPARTW; ++pp) acc += l_part[(pp * 4 + o) * R32W + tid];
+                out[o] = acc + (o < NOUT_A ? ma.b3[o] : mc.b3[0]);
+            }
+            const float v = out[NOUT_A];
+            if (active) tr.value[(int64_t)t * n + env] = v;
+            if (t < T) {
+                float oa[MAXO];
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o) oa[o] = (o < NOUT_A) ? out[o] : 0.0f;
+                int32_t ai;
+                float af, lp;
+                policy_select(cont, na, oa, l_noise + ((size_t)((((t / NCHW) & 1) * NCHW + (t & (NCHW - 1))) * R32W + tid)) * MAXO,
+                              ai, af, lp);
+                env_step1(p, e, ai, af, last_r, last_d);
+                if (last_d) env_reset1(p, e, seed, id);
+                if (active) {
+                    tr.logp[(int64_t)t * n + env] = lp;
+                    if (cont) tr.action_f[(int64_t)t * n + env] = af;
+                    else tr.action_i[(int64_t)t * n + env] = ai;
+                    tr.reward[(int64_t)t * n + env] = last_r;
+                    tr.terminal[(int64_t)t * n + env] = (uint8_t)last_d;
+                }
+            }
+        }
+        // no barrier here (as ppo3_rollout32_kernel): the next pass rewrites l_x from the same 32 lanes in program order and
+        // every other buffer only after the next pass's barriers
+    }
+    if (active && T > 0 && tr.adv && tr.ret)  // GAE + returns fused into the rollout launch (gae_device.h)
+        gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, gamma, lambda);
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
+        st.t[env] = e.t;
+        st.episode[env] = e.episode;
+        if (T > 0) {
+            st.reward[env] = last_r;
+            st.done[env] = (uint8_t)last_d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+constexpr int P3W_ROWS_S = 512;  // persistent workgroups (= partial rows) of the forward / backward kernels: two per CU
+constexpr int P3W_ROWS_W = 128;  // sample ranges (= partial rows) of the dW2 kernel; its grid is twice that (two k halves)
+constexpr int64_t P3W_MAX_TILES = 1 << 20;
+
+template <typename K>
+static int32_t allow_lds_w(K kernel, size_t bytes, bool* done) {
+    if (*done) return RLHIP_OK;
+    RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bytes));
+    *done = true;
+    return RLHIP_OK;
+}
+
+static int p3w_rows_w() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RLHIP_PPO3W_NSR");
+        v = e ? atoi(e) : P3W_ROWS_W;
+        if (v < 1 || v > 256) v = P3W_ROWS_W;
+    }
+    return v;
+}
+
+struct P3WLayout {
+    int64_t ntiles, off_rows, off_frag, off_partS, off_partW, off_loss, bytes;
+    int npS, nS_a;
+};
+
+static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t n, int64_t T) {
+    P3WLayout L;
+    const int64_t bm = (n * T) / (c->n_microbatches > 0 ? c->n_microbatches : 1);
+    L.ntiles = (bm + RW - 1) / RW;
+    L.nS_a = mlp3w_ns_small(ns, nout_a);
+    L.npS = L.nS_a + mlp3w_ns_small(ns, 1);
+    int64_t o = 4 * (int64_t)HW * HW * sizeof(uint16_t);
+    L.off_rows = o;
+    o += L.ntiles * RW * HW * (int64_t)sizeof(uint16_t);
+    L.off_frag = o;
+    o += L.ntiles * RW * HW * (int64_t)sizeof(uint16_t);
+    L.off_partS = o;
+    o += (int64_t)P3W_ROWS_S * L.npS * (int64_t)sizeof(float);
+    L.off_partW = o;
+    o += (int64_t)256 * 2 * HW * HW * (int64_t)sizeof(float);
+    L.off_loss = o;
+    o += (int64_t)P3W_ROWS_S * 4 * (int64_t)sizeof(float);
+    L.bytes = o + 256;
+    return L;
+}
+
+int64_t ppo3w_nparams(int ns, int nout_a) { return mlp3w_np(ns, nout_a) + mlp3w_np(ns, 1); }
+
+int64_t ppo3w_workspace_bytes(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t n, int64_t T) {
+    return p3w_layout(ns, nout_a, c, n, T).bytes;
+}
+
+static int32_t ppo3w_pack(const float* params, int ns, int64_t np_a, uint16_t* packed, hipStream_t s) {
+    hipLaunchKernelGGL(ppo3w_pack_kernel, dim3(2 * HW * HW / 256), dim3(256), 0, s, params, ns, np_a, packed);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+template <class P>
+static int32_t rollout3w_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, int64_t T,
+                              const PolicyDesc& pd, const float* params, uint64_t seed, uint32_t env_id_base, uint32_t vec_step0, const rlhip_ppo_traj* traj, hipStream_t s) {
+    RLHIP_REQUIRE(st && st->episode, "this entry point needs the separate episode[] array (packed step / episode words are an rlhip_env_step / rlhip_env_reset mode)");
+    typename P::cfg_t c2 = *cfg;
+    c2.continuous = pd.cont;
+    P p = P::make(c2);
+    EnvArrays<float> a = EnvArrays<float>::from(*st);
+    TrajPtrs tr = TrajPtrs::from(*traj);
+    dim3 grid((unsigned)((n + R32W - 1) / R32W));
+#define LAUNCH_RW(ACT_)                                                                                            \
+    do {                                                                                                           \
+        static bool done_ = false;                                                                                 \
+        int32_t rc_ = allow_lds_w(ppo3w_rollout_kernel<P, 2, ACT_>, ROLLW_LDS, &done_);                            \
+        if (rc_) return rc_;                                                                                       \
+        hipLaunchKernelGGL((ppo3w_rollout_kernel<P, 2, ACT_>), grid, dim3(NTW), ROLLW_LDS, s, p, a, n, (int)T, pd.cont, \
+                           pd.na, params, pd.np_a, seed, env_id_base, vec_step0, tr, pd.gamma, pd.lambda);         \
+    } while (0)
+    if (pd.act == 0) LAUNCH_RW(0);
+    else LAUNCH_RW(1);
+#undef LAUNCH_RW
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t ppo3w_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, int64_t T,
+                      const PolicyDesc& pd_in, const float* params, uint64_t seed, uint32_t env_id_base, uint32_t vec_step0,
+                      const rlhip_ppo_traj* traj, rlhip_stream_t stream) {
+    PolicyDesc pd = pd_in;
+    const int ns = kind == 0 ? 4 : 3;
+    pd.np_a = mlp3w_np(ns, pd.nout_a);
+    hipStream_t s = as_stream(stream);
+    if (kind == 0)
+        return rollout3w_impl<CartPoleParams<float>>((const rlhip_cartpole_cfg*)env_cfg, st, n, T, pd, params, seed,
+                                                     env_id_base, vec_step0, traj, s);
+    return rollout3w_impl<PendulumParams<float>>((const rlhip_pendulum_cfg*)env_cfg, st, n, T, pd, params, seed,
+                                                 env_id_base, vec_step0, traj, s);
+}
+
+int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
+                   const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb,
+                   void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream) {
+    const int ns = kind == 0 ? 4 : 3;
+    const int64_t total = n * T;
+    RLHIP_REQUIRE(total >= 1 && total <= 0x7FFFFFFFll, "n * T out of range");
+    const int64_t bm = total / cfg->n_microbatches;
+    RLHIP_REQUIRE(bm >= 1, "empty micro-batch");
+    const P3WLayout L = p3w_layout(ns, pd.nout_a, cfg, n, T);
+    RLHIP_REQUIRE(L.ntiles <= P3W_MAX_TILES, "micro-batch too large for one launch");
+    hipStream_t s = as_stream(stream);
+    char* ws = (char*)workspace;
+    P3WArgs g;
+    g.obs = traj->obs;
+    g.logp = traj->logp;
+    g.adv = traj->adv;
+    g.ret = traj->ret;
+    g.action_f = traj->action_f;
+    g.action_i = traj->action_i;
+    RLHIP_REQUIRE(g.obs && g.logp && g.adv && g.ret && (pd.cont ? (const void*)g.action_f : (const void*)g.action_i),
+                  "trajectory array is NULL");
+    g.params = params;
+    uint16_t* packed = (uint16_t*)ws;
+    g.packed = packed;
+    g.dz_rows = (uint16_t*)(ws + L.off_rows);
+    g.dz_frag = (uint16_t*)(ws + L.off_frag);
+    g.partS = (float*)(ws + L.off_partS);
+    g.partW = (float*)(ws + L.off_partW);
+    g.loss_partials = (float*)(ws + L.off_loss);
+    g.n = n;
+    g.np_a = mlp3w_np(ns, pd.nout_a);
+    const int np = (int)(g.np_a + mlp3w_np(ns, 1));
+    g.total = (uint32_t)total;
+    g.bm = (uint32_t)bm;
+    g.pos0 = (uint32_t)(mb * bm);
+    g.ntiles = (int)L.ntiles;
+    g.npS = L.npS;
+    g.nS_a = L.nS_a;
+    g.na = pd.na;
+    g.lo = 1.0f - cfg->clip_range;
+    g.hi = 1.0f + cfg->clip_range;
+    g.wa = cfg->actor_loss_weight;
+    g.wc = cfg->critic_loss_weight;
+    g.we = cfg->entropy_loss_weight;
+    g.inv_b = 1.0f / (float)bm;
+    g.min_logp = (float)::log(1e-8);
+    g.pk = perm_keys(seed, epoch_ctr, (uint32_t)total);
+    int32_t rc = ppo3w_pack(params, ns, g.np_a, packed, s);
+    if (rc) return rc;
+    const int nrowsS = (int)(L.ntiles < P3W_ROWS_S ? L.ntiles : P3W_ROWS_S);
+    const int nsr = (int)(L.ntiles < p3w_rows_w() ? L.ntiles : p3w_rows_w());
+#define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
+    do {                                                                                                              \
+        static bool d0_ = false, d1_ = false, d2_ = false, d3_ = false;                                               \
+        int32_t rc_;                                                                                                  \
+        if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>, FWDW_LDS, &d0_))) return rc_;                \
+        if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>, FWDW_LDS, &d1_))) return rc_;                \
+        if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                             \
+        if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                             \
+        hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
+        hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                \
+        hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 0, nsr);          \
+        hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
+        hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 1);                \
+        hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 1, nsr);          \
+    } while (0)
+    if (kind == 0) {
+        RLHIP_REQUIRE(!pd.cont, "layers = 3: CartPole uses the categorical head");
+        if (pd.act == 0) LAUNCH_GW(4, 0, 0);
+        else LAUNCH_GW(4, 1, 0);
+    } else {
+        RLHIP_REQUIRE(pd.cont, "layers = 3: Pendulum uses the Gaussian head");
+        if (pd.act == 0) LAUNCH_GW(3, 0, 1);
+        else LAUNCH_GW(3, 1, 1);
+    }
+#undef LAUNCH_GW
+    hipLaunchKernelGGL(ppo3w_reduce_kernel, dim3((np + 63) / 64), dim3(256), 0, s, g.partS, g.partW, g.loss_partials, nrowsS,
+                       nsr, g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
+                     const rlhip_ppo_traj* traj, float* params, float* m, float* v, float* beta_pow, uint64_t seed,
+                     uint32_t update_ctr, void* workspace, float* grad_scratch, float* losses_out, rlhip_stream_t stream) {
+    const int ns = kind == 0 ? 4 : 3;
+    const int64_t np = ppo3w_nparams(ns, pd.nout_a);
+    for (int32_t e = 0; e < cfg->n_epochs; ++e) {
+        const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
+        for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
+            int32_t rc = ppo3w_grad(kind, cfg, pd, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_scratch, losses_out,
+                                    stream);
+            if (rc) return rc;
+            rc = rlhip_clip_adam_f32(params, grad_scratch, m, v, beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr, cfg->beta1,
+                                     cfg->beta2, cfg->adam_eps, nullptr, stream);
+            if (rc) return rc;
+        }
+    }
+    return RLHIP_OK;
+}
+
+}  // namespace rlhip

@@ -135,7 +135,7 @@ def test_layers3_rejects_unsupported_configs():
 
     env = rlhip.HipVecEnv("cartpole", 64, seed=1)
     with pytest.raises(RLHipError):
-        rlhip.PPOPolicy(env, update_freq=4, hidden=256, layers=3)       # hidden must be 128
+        rlhip.PPOPolicy(env, update_freq=4, hidden=64, layers=3)        # hidden must be 128 or 256
     env = rlhip.HipVecEnv("mountaincar", 64, seed=1)
     with pytest.raises(RLHipError):
         rlhip.PPOPolicy(env, update_freq=4, hidden=128, layers=3)       # 3 actions: not instantiated

@@ -1,0 +1,161 @@
+"""GPU parity of the width-256 three-layer PPO actor / critic (csrc/ppo3w.hip: cfg.layers = 3, hidden = 256 -- the
+streaming forward / backward / dW2 kernels and the 8-wave rollout) against the oracle (oracle/rlo_learn.c with
+layers = 3, hidden = 256).  Same contract and bars as tests/test_gpu_ppo3.py (hidden = 128): head outputs
+2e-5 * (1 + |x|), gradients BF16_GRAD_TOL * max|g| per tensor, integer actions bit-exact away from sampling ties."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import BF16_GRAD_TOL, assert_grad_close  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def _setup(kind, n, T, seed=5, **kw):
+    import rlhip
+
+    env = rlhip.HipVecEnv(kind, n, seed=seed)
+    pol = rlhip.PPOPolicy(env, update_freq=T, hidden=H, seed=seed, layers=3, **kw)
+    return env, pol
+
+
+def test_parameter_count_and_workspace():
+    env, pol = _setup("pendulum", 64, 4)
+    ns = 3
+    per = lambda nout: H * ns + H + H * H + H + nout * H + nout  # noqa: E731
+    assert pol.np_actor == per(2) and pol.np == per(2) + per(1)
+    assert pol.np == oracle.ppo_nparams(oracle.KIND["pendulum"], oracle.ppo_default(hidden=H, continuous=1, layers=3))
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+@pytest.mark.parametrize("kind,cont", [("cartpole", False), ("pendulum", True)])
+def test_rollout_matches_oracle(kind, cont, act):
+    n, T = 200, 6  # 7 workgroups of 32 envs, the last one ragged
+    a = {"relu": 0, "tanh": 1}[act]
+    env, pol = _setup(kind, n, T, act=a)
+    params = pol.params.cpu().numpy()
+    oenv = oracle.VecEnv(kind, n, seed=5)
+    ocfg = oracle.ppo_default(hidden=H, continuous=int(cont), layers=3, act=a)
+    otr = oracle.PPOTraj(oracle.KIND[kind], n, T, continuous=cont)
+    oracle.ppo_rollout(oenv, T, ocfg, params, otr, 0)
+    pol.rollout_()
+    tr = pol.trajectory
+    v, ov = tr.value.cpu().numpy(), otr.value
+    vtol = 1e-4 if (cont or act == "tanh") else 2e-5
+    if cont:
+        np.testing.assert_allclose(tr.obs[0].cpu().numpy(), otr.obs[0], rtol=0, atol=2e-7)
+    else:
+        assert np.array_equal(tr.obs[0].cpu().numpy(), otr.obs[0])
+    assert np.all(np.abs(v[0] - ov[0]) <= vtol * (1 + np.abs(ov[0]))), np.abs(v[0] - ov[0]).max()
+    if cont:
+        af, oaf = tr.action_f.cpu().numpy().reshape(T, n), otr.action_f.reshape(T, n)
+        assert np.all(np.abs(af[0] - oaf[0]) <= 1e-4 * (1 + np.abs(oaf[0])))
+        assert np.all(np.abs(tr.logp[0].cpu().numpy() - otr.logp[0]) <= 1e-3)
+    else:
+        ai, oai = tr.action_i.cpu().numpy(), otr.action_i
+        agree = (ai == oai)
+        assert agree[0].mean() >= 0.995
+        same = agree.all(0)
+        assert same.mean() >= 0.95
+        for name in ("reward", "terminal"):
+            assert np.array_equal(getattr(tr, name).cpu().numpy()[:, same], getattr(otr, name)[:, same])
+        assert np.array_equal(tr.obs.cpu().numpy()[:, :, same], otr.obs[:, :, same])
+        assert np.all(np.abs(v[:, same] - ov[:, same]) <= 1e-4 * (1 + np.abs(ov[:, same])))
+    # the GAE scan fused into the rollout launch equals the stand-alone scan on the same arrays
+    adv = tr.adv.cpu().numpy().copy()
+    pol.gae_()
+    assert np.array_equal(tr.adv.cpu().numpy(), adv)
+
+
+def _oracle_grad(pol, env, cont, ocfg, epoch, mb, bm, total, n, T):
+    tr = pol.trajectory
+    ns = env.odim
+    na = 1 if cont else 2
+    f = np.array([oracle.permute(pol.seed, epoch, total, mb * bm + b) for b in range(bm)])
+    t, i = f // n, f % n
+    obs = tr.obs.cpu().numpy()[t, :, i].T.copy()
+    action = tr.action_f.cpu().numpy().reshape(T, n)[t, i][None, :] if cont else tr.action_i.cpu().numpy()[t, i]
+    return oracle.ppo_loss_grad(ocfg, ns, na, pol.params.cpu().numpy(), obs, action, tr.logp.cpu().numpy()[t, i],
+                                tr.adv.cpu().numpy()[t, i], tr.ret.cpu().numpy()[t, i])
+
+
+def _check_grad(pol, g, og, ns, label):
+    np_a = pol.np_actor
+    for name, a, b in (("actor", g[:np_a], og[:np_a]), ("critic", g[np_a:], og[np_a:])):
+        o = 0
+        nout = 2 if name == "actor" else 1
+        for tname, sz in (("W1", H * ns), ("b1", H), ("W2", H * H), ("b2", H), ("W3", nout * H), ("b3", nout)):
+            assert_grad_close(a[o:o + sz], b[o:o + sz], BF16_GRAD_TOL, f"ppo3w {label} {name} {tname} ns={ns}")
+            o += sz
+        assert o == a.size
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+@pytest.mark.parametrize("kind,cont", [("cartpole", False), ("pendulum", True)])
+def test_grad_matches_oracle(kind, cont, act):
+    """one micro-batch gradient on a GPU-generated trajectory: 432 samples = 6 full 64-sample tiles + a ragged one"""
+    n, T = 96, 9
+    a = {"relu": 0, "tanh": 1}[act]
+    env, pol = _setup(kind, n, T, n_microbatches=2, act=a)
+    pol.rollout_()
+    pol.gae_()
+    ocfg = oracle.ppo_default(hidden=H, continuous=int(cont), layers=3, n_microbatches=2, act=a)
+    total, bm = n * T, (n * T) // 2
+    for mb, epoch in ((0, 0), (1, 3)):
+        pol.grad_(epoch, mb)
+        g = pol.grad.cpu().numpy()
+        losses = pol.losses.cpu().numpy()
+        og, ol = _oracle_grad(pol, env, cont, ocfg, epoch, mb, bm, total, n, T)
+        assert np.all(np.abs(losses - ol) <= 2e-4 * (1 + np.abs(ol))), (losses, ol)
+        _check_grad(pol, g, og, env.odim, f"{kind} {act}")
+    pol.grad_(3, 1)  # deterministic: fixed summation order, no atomics
+    assert np.array_equal(pol.grad.cpu().numpy(), g)
+
+
+def test_grad_many_tiles_per_workgroup_matches_oracle():
+    """2048 envs x 40 steps / 2 micro-batches = 40960 samples = 640 tiles: the 512 persistent forward / backward
+    workgroups walk one or two tiles each, the 128 sample ranges of the dW2 kernel five tiles each"""
+    kind, cont, n, T = "pendulum", True, 2048, 40
+    env, pol = _setup(kind, n, T, n_microbatches=2)
+    pol.rollout_()
+    pol.gae_()
+    ocfg = oracle.ppo_default(hidden=H, continuous=1, layers=3, n_microbatches=2)
+    total, bm = n * T, (n * T) // 2
+    pol.grad_(1, 1)
+    g = pol.grad.cpu().numpy()
+    losses = pol.losses.cpu().numpy()
+    og, ol = _oracle_grad(pol, env, cont, ocfg, 1, 1, bm, total, n, T)
+    assert np.all(np.abs(losses - ol) <= 2e-4 * (1 + np.abs(ol))), (losses, ol)
+    _check_grad(pol, g, og, env.odim, "pendulum 640 tiles")
+    for _ in range(3):
+        pol.grad_(1, 1)
+        assert np.array_equal(pol.grad.cpu().numpy(), g)
+
+
+@pytest.mark.parametrize("kind", ["cartpole", "pendulum"])
+def test_update_runs_and_equals_the_microbatch_protocol(kind):
+    """full iterations through the unchanged rlhip_ppo_* entry points: parameters move, stay finite, the fused update
+    equals grad -> clip + Adam micro-batch by micro-batch (the multi-GPU code path with one rank)"""
+    n, T = 512, 16
+    env, pol = _setup(kind, n, T)
+    env2, pol2 = _setup(kind, n, T)
+    p0 = pol.params.clone()
+    pol.rollout_()
+    pol2.rollout_()
+    assert torch.equal(pol.trajectory.reward, pol2.trajectory.reward)
+    pol.update_()
+    pol2.gae_()
+    for e in range(pol2.cfg.n_epochs):
+        for mb in range(pol2.cfg.n_microbatches):
+            pol2.grad_(pol2.update_ctr * pol2.cfg.n_epochs + e, mb)
+            pol2.apply_(1.0)
+    pol2.update_ctr += 1
+    torch.cuda.synchronize()
+    assert torch.isfinite(pol.params).all() and not torch.equal(pol.params, p0)
+    assert torch.equal(pol.params, pol2.params)
+    for _ in range(3):
+        pol.rollout_()
+        pol.update_()
+    assert torch.isfinite(pol.params).all() and torch.isfinite(pol.losses).all()
