@@ -33,6 +33,7 @@
 #include "ppo_common.h"
 #include "ppo_sample_device.h"
 #include "mlp3_device.h"
+#include <type_traits>
 
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow, int64_t n,
                                        float grad_scale, float clip_norm, float lr, float beta1, float beta2,
@@ -54,6 +55,26 @@ __host__ __device__ __forceinline__ int64_t mlp3w_np(int64_t ns, int64_t nout) {
 }
 // "small" parameter space of one net = everything except W2, in parameter order: W1 | b1 | b2 | W3 | b3
 __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { return HW * ns + 2 * HW + nout * HW + nout; }
+
+// per-phase cycle stamps of one steady-state tile (workgroup 0, thread 0, its second tile): -DRLHIP_W3_TIMING
+#ifdef RLHIP_W3_TIMING
+__device__ long long g_w3_stamps[3][16];
+#define W3_STAMP(kern, k)                                                                                  \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tile == (int)(W3_STRIDE)) g_w3_stamps[kern][(k)] = clock64(); \
+    } while (0)
+#define W3_MARK(kern, k, on)                                                                 \
+    do {                                                                                     \
+        if ((on) && blockIdx.x == 0 && threadIdx.x == 0) g_w3_stamps[kern][(k)] = clock64(); \
+    } while (0)
+#else
+#define W3_STAMP(kern, k) \
+    do {                  \
+    } while (0)
+#define W3_MARK(kern, k, on) \
+    do {                     \
+    } while (0)
+#endif
 
 struct Mlp3W {
     const float *W1, *b1, *b2, *W3, *b3;
@@ -133,39 +154,94 @@ __device__ __forceinline__ void load_frags_f32(const float* __restrict__ W2, int
     }
 }
 
-// the tile's samples f = perm(pos0 + q): observation components -> l_x [4][RW]; returns f and validity
-__device__ __forceinline__ uint32_t gather_x(const P3WArgs& g, int ns, int tile, int tid, float* l_x, bool* valid_out) {
-    const uint32_t q = (uint32_t)tile * RW + (uint32_t)tid;
+// One sample of a tile gathered into registers.  stage_issue computes f = perm(pos0 + q) and issues the global loads;
+// stage_write lands them in LDS one tile pass later, so the ~4000-cycle dependent chain (permutation -> index -> load) of
+// tile i + 2 runs under the compute of tile i (measured with the s_memtime stamps of tools/w3timing.py: the exposed
+// gather was 19 % of the forward tile and 56 - 65 % of the backward / dW2 tiles).  MODE 0: observation only; 1: + old
+// log-prob, advantage, action (actor); 2: + return (critic).
+struct Staged {
+    float x[4];
+    float s0, s1, s2;
+};
+template <int NS, int MODE, int CONT>
+__device__ __forceinline__ void stage_issue(const P3WArgs& g, int tile, int lane, Staged& st) {
+    const uint32_t q = (uint32_t)tile * RW + (uint32_t)lane;
     const bool valid = q < g.bm;
     const uint32_t f = permute(g.pk, g.pos0 + (valid ? q : 0u));
     const uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
-    for (int k = 0; k < ns; ++k) l_x[k * RW + tid] = g.obs[((int64_t)t * ns + k) * g.n + i];
-    *valid_out = valid;
-    return f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st.x[k] = g.obs[((int64_t)t * NS + k) * g.n + i];
+    if (MODE == 1) {
+        st.s0 = g.logp[f];
+        st.s1 = g.adv[f];
+        if (!valid) st.s1 = 0.0f;
+        st.s2 = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
+    } else if (MODE == 2) {
+        st.s0 = g.ret[f];
+    }
+}
+template <int NS, int MODE>
+__device__ __forceinline__ void stage_write(const Staged& st, float* l_x, float* l_s, int lane) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) l_x[k * RW + lane] = st.x[k];
+    if (MODE == 1) {
+        l_s[lane] = st.s0;
+        l_s[RW + lane] = st.s1;
+        l_s[3 * RW + lane] = st.s2;
+    } else if (MODE == 2) {
+        l_s[2 * RW + lane] = st.s0;
+    }
+}
+
+// LDS exchange inside ONE wave (its private block): LDS instructions of a wave execute in order, so no workgroup barrier
+// is needed -- only the compiler has to keep the accesses in program order (the block is viewed as f32 and as bf16)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ------------------------------------------------------------------------------------------------ forward + loss + dZ2
-constexpr size_t FWDW_LDS = (4 * RW + 4 * RW + MAXO * RW + WV * MAXO * RW + SMALLWW) * sizeof(float) +
+constexpr int TPW = 36;  // f32 pitch of a wave's private 64 x 32 transposition block (144 B rows)
+constexpr int ZPW = 40;  // bf16 pitch of the same block when it holds the wave's dZ2 columns (80 B rows)
+constexpr size_t FWDW_LDS = (2 * 4 * RW + 2 * 4 * RW + MAXO * RW + WV * MAXO * RW + SMALLWW + WV * RW * TPW) * sizeof(float) +
                             (size_t)RW * PW * sizeof(uint16_t);
 
 template <int NS, int NOUT, int ACT, int CONT, int NET>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
+    constexpr int MODE = NET == 0 ? 1 : 2;
+    W3_MARK(0, 8, NET == 0);
     extern __shared__ __attribute__((aligned(16))) char smw[];
-    float* l_x = reinterpret_cast<float*>(smw);  // [4][RW]
-    float* l_s = l_x + 4 * RW;                   // [4][RW]: old log-prob, advantage, return, action
-    float* l_dq = l_s + 4 * RW;                  // [MAXO][RW] dL/d(head outputs)
+    float* l_x = reinterpret_cast<float*>(smw);  // [2][4][RW]   (double-buffered: the tile after this one lands meanwhile)
+    float* l_s = l_x + 2 * 4 * RW;               // [2][4][RW]: old log-prob, advantage, return, action
+    float* l_dq = l_s + 2 * 4 * RW;              // [MAXO][RW] dL/d(head outputs)
     float* l_part = l_dq + MAXO * RW;            // [WV][MAXO][RW] head partial sums per wave
     float* l_w = l_part + WV * MAXO * RW;        // [SMALLWW]
-    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + SMALLWW);  // [RW][PW]: H1, then dZ2 rows
+    float* l_t = l_w + SMALLWW;                  // [WV][RW][TPW] wave-private transposition blocks
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_t + WV * RW * TPW);  // [RW][PW] H1 rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int col = 32 * w + r;
+    float* l_tw = l_t + w * RW * TPW;
+    uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);
     const float* pnet = g.params + (NET ? g.np_a : 0);
     const Mlp3W m = stage_small_w(pnet, NS, NOUT, l_w, tid);
     bf16x8 bw[KSW];
     load_frags_w(g.packed + (NET ? 2 * HW * HW : 0), w, lane, bw);
+    const int stride = gridDim.x;
+    Staged stg;
+    // two gather waves take turns (wave 7: the tiles of odd passes, wave 6: of even passes), so a tile's loads are in flight
+    // for TWO passes: tile 0 goes straight into buffer 0, tiles 1 and 2 into the registers of waves 7 and 6
+    if (w == WV - 1) {
+        stage_issue<NS, MODE, CONT>(g, blockIdx.x, lane, stg);
+        stage_write<NS, MODE>(stg, l_x, l_s, lane);
+        if ((int)blockIdx.x + stride < g.ntiles) stage_issue<NS, MODE, CONT>(g, blockIdx.x + stride, lane, stg);
+    } else if (w == WV - 2) {
+        if ((int)blockIdx.x + 2 * stride < g.ntiles) stage_issue<NS, MODE, CONT>(g, blockIdx.x + 2 * stride, lane, stg);
+    }
     __syncthreads();
+    W3_MARK(0, 9, NET == 0);
     const float b2v = m.b2[col];
     float w3[NOUT];
 #pragma unroll
@@ -178,24 +254,23 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     for (int o = 0; o < NOUT + 2; ++o) s_red[o] = 0.0f;
     const int row1 = tid & (RW - 1), u0 = 32 * (tid >> 6);  // layer 1: this thread's sample row and its 32 hidden units
 
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        if (tid < RW) {
-            bool valid;
-            const uint32_t f = gather_x(g, NS, tile, tid, l_x, &valid);
-            if (NET == 0) {
-                l_s[tid] = g.logp[f];
-                l_s[RW + tid] = valid ? g.adv[f] : 0.0f;
-                l_s[3 * RW + tid] = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
-            } else {
-                l_s[2 * RW + tid] = g.ret[f];
-            }
+#define W3_STRIDE (NET == 0 ? gridDim.x : 0x7fffffff)
+    int it = 0;
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += stride, ++it) {
+        W3_STAMP(0, 0);
+        const int p = it & 1;
+        const float* lx = l_x + p * 4 * RW;
+        const float* ls = l_s + p * 4 * RW;
+        if (w == WV - 1 - p && tile + stride < g.ntiles) {  // pass `it`: wave 7 - (it & 1) lands tile + 1 and requests tile + 3
+            stage_write<NS, MODE>(stg, l_x + (p ^ 1) * 4 * RW, l_s + (p ^ 1) * 4 * RW, lane);
+            if (tile + 3 * stride < g.ntiles) stage_issue<NS, MODE, CONT>(g, tile + 3 * stride, lane, stg);
         }
-        __syncthreads();
+        W3_STAMP(0, 1);
         // ---- layer 1: h1 = act(b1 + W1 x) (the fmaf chain of mlp2 / the oracle), bf16 rows ----
         {
             float x[NS];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) x[i] = l_x[i * RW + row1];
+            for (int i = 0; i < NS; ++i) x[i] = lx[i * RW + row1];
             uint16_t* dst = l_H + row1 * PW + u0;
 #pragma unroll
             for (int h8 = 0; h8 < 4; ++h8) {
@@ -219,7 +294,8 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 *reinterpret_cast<uint4*>(dst + 8 * h8) = pack8_bf16(hv);
             }
         }
-        __syncthreads();
+        __syncthreads();  // A: the H1 tile is complete
+        W3_STAMP(0, 2);
         // ---- layer 2 on the MFMA: this wave's 32 columns for the tile's 64 rows; bias + activation ----
         f32x16 h2[2];
 #pragma unroll
@@ -240,17 +316,37 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) h2[rt][q] = act_fwd_t<ACT>(h2[rt][q] + b2v);
-        // ---- head: this wave's share of sum_j W3[o, j] h2[j] per row (32 columns: DPP row sums + lane ^ 16) ----
+        W3_STAMP(0, 3);
+        // ---- head: this wave's share of sum_j W3[o, j] h2[j] per row.  The wave's 64 x 32 block of H2 goes through its
+        //      private LDS block (D layout in, one row per lane out): 32 FMAs per output and lane, no cross-lane sums
+        //      (the DPP row reductions this replaces were 35 % of the tile) ----
+        wave_lds_fence();
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < 16; ++q) l_tw[(32 * rt + mfma_row(q, kb)) * TPW + r] = h2[rt][q];
+        wave_lds_fence();
+        {
+            float pa[NOUT];
 #pragma unroll
-                for (int o = 0; o < NOUT; ++o) {
-                    const float a = swap16_add(reduce16_dpp(w3[o] * h2[rt][q]));
-                    if (r == 0) l_part[(w * MAXO + o) * RW + 32 * rt + mfma_row(q, kb)] = a;
-                }
-        __syncthreads();
+            for (int o = 0; o < NOUT; ++o) pa[o] = 0.0f;
+            const float* hrow = l_tw + lane * TPW;
+            const float* w3p = m.W3 + NOUT * 32 * w;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const float4 v = *reinterpret_cast<const float4*>(hrow + 4 * c4);
+                const float hv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) pa[o] = fmaf(w3p[o + NOUT * (4 * c4 + e)], hv[e], pa[o]);
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) l_part[(w * MAXO + o) * RW + lane] = pa[o];
+        }
+        wave_lds_fence();
+        __syncthreads();  // C: every wave's partial sums
+        W3_STAMP(0, 4);
         // ---- the loss line of each sample and dL/d(head outputs): wave 0, one row per lane ----
         if (tid < RW) {
             const int s = tid;
@@ -265,8 +361,8 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
             if (NET == 0) {
                 float dl[MAXO] = {0.f, 0.f, 0.f, 0.f};
-                const float lp_old = fmaxf(l_s[s], g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
-                const float A = l_s[RW + s];
+                const float lp_old = fmaxf(ls[s], g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
+                const float A = ls[RW + s];
                 float ent, surr_min;
                 if (!CONT) {
                     const int na = g.na;
@@ -282,7 +378,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                         pr[k] = expf(logp[k]);
                         ent -= pr[k] * logp[k];
                     }
-                    const int a = __float_as_int(l_s[3 * RW + s]);
+                    const int a = __float_as_int(ls[3 * RW + s]);
                     float lp_new = 0.f;
                     for (int k = 0; k < na; ++k)
                         if (k == a) lp_new = logp[k];
@@ -300,13 +396,13 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                     }
                 } else {
                     const float eps = 1.0e-8f;
-                    const float mu = oa[0], ls = oa[1];
-                    const float sg = expf(ls);
-                    const float z = l_s[3 * RW + s];
+                    const float mu = oa[0], lsg = oa[1];
+                    const float sg = expf(lsg);
+                    const float z = ls[3 * RW + s];
                     const float se = sg + eps;
                     const float zz = (z - mu) / se;
                     const float lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
-                    ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
+                    ent = ((LOG2PI_F + 1.0f) + lsg) / 2.0f;
                     const float dmu = (z - mu) / (se * se);
                     const float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
                     const float ratio = expf(lp_new - lp_old);
@@ -332,7 +428,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 s_red[NOUT] += surr_min;
                 s_red[NOUT + 1] += ent;
             } else {
-                const float dv = l_s[2 * RW + s] - oa[0];
+                const float dv = ls[2 * RW + s] - oa[0];
                 float dvout = -2.0f * g.wc * g.inv_b * dv;
                 float sq = dv * dv;
                 if (!valid) {
@@ -344,8 +440,10 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 s_red[NOUT] += sq;
             }
         }
-        __syncthreads();
-        // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32) -> db2; dz2 -> bf16, rows (LDS) + fragments ----
+        __syncthreads();  // D: dL/d(head outputs) of the tile
+        W3_STAMP(0, 5);
+        // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32) -> db2; dz2 -> bf16: fragments straight to global,
+        //      rows through the wave's private block (64 rows x 64 B of this wave's columns, no workgroup barrier) ----
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
@@ -364,7 +462,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 const float dz = dh * act_bwd_t<ACT>(hv, hv);  // relu: h2 > 0 <=> z2 > 0
                 a_db2 += dz;
                 h2[rt][q] = dz;  // the register is free: keep dz for the packed stores below
-                l_H[row * PW + col] = f32_to_bf16_rne(dz);
+                l_zw[row * ZPW + r] = f32_to_bf16_rne(dz);
             }
             // fragment order: samples 32 rt + 8 gq + 4 kb + {0..3} of column `col` = bytes 8 kb .. 8 kb + 7 of slot
             // (k-step 2 rt + (gq >> 1), column tile w, lane 32 (gq & 1) + r)
@@ -377,19 +475,23 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 *reinterpret_cast<uint2*>(g.dz_frag + slot * 8 + 4 * kb) = v2;
             }
         }
-        __syncthreads();
-        // ---- dZ2 rows -> global, 16 B per lane ----
+        W3_STAMP(0, 6);
+        wave_lds_fence();
         {
-            uint16_t* dst = g.dz_rows + (int64_t)tile * RW * HW;
+            uint16_t* dst = g.dz_rows + (int64_t)tile * RW * HW + 32 * w;
 #pragma unroll
-            for (int i = 0; i < RW * HW / 8 / NTW; ++i) {
-                const int c = tid + NTW * i, row = c >> 5, cc = c & 31;
-                *reinterpret_cast<uint4*>(dst + row * HW + 8 * cc) = *reinterpret_cast<const uint4*>(l_H + row * PW + 8 * cc);
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i, row = c >> 2, cc = c & 3;
+                *reinterpret_cast<uint4*>(dst + row * HW + 8 * cc) = *reinterpret_cast<const uint4*>(l_zw + row * ZPW + 8 * cc);
             }
         }
-        // the next pass writes l_x / l_s (last read before the previous barrier) and then waits at its first barrier,
-        // which every thread reaches only after the copy above
+        wave_lds_fence();
+        W3_STAMP(0, 7);
+        // no barrier: the next pass writes l_H (last read before barrier C), the other l_x / l_s buffer, and this wave's
+        // private block in program order
     }
+#undef W3_STRIDE
+    W3_MARK(0, 10, NET == 0);
     // ---- this workgroup's partial row: b2, W3, b3 and the loss sums ----
     const int sb2 = HW * NS + HW, sW3 = sb2 + HW, sb3 = sW3 + NOUT * HW;
     float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + (NET ? g.nS_a : 0);
@@ -419,23 +521,63 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------ dH1 -> dW1 / db1
-constexpr size_t BWDW_LDS = (4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)RW * PW * sizeof(uint16_t);
+constexpr size_t BWDW_LDS = (2 * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * RW * PW * sizeof(uint16_t);
+
+// this thread's four 16-byte chunks of a 64 x 256 bf16 tile: chunk c = tid + 512 i -> row c >> 5, column 8 (c & 31)
+__device__ __forceinline__ void load_dz_tile(const uint16_t* __restrict__ dz_rows, int tile, int tid, nt_u32x4 (&d)[4]) {
+    const uint16_t* src = dz_rows + (int64_t)tile * RW * HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTW * i, row = c >> 5, cc = c & 31;
+        d[i] = *reinterpret_cast<const nt_u32x4*>(src + row * HW + 8 * cc);
+    }
+}
+__device__ __forceinline__ void store_dz_tile(uint16_t* lH, int tid, const nt_u32x4 (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTW * i, row = c >> 5, cc = c & 31;
+        *reinterpret_cast<nt_u32x4*>(lH + row * PW + 8 * cc) = d[i];
+    }
+}
 
 template <int NS, int ACT>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
     extern __shared__ __attribute__((aligned(16))) char smw[];
-    float* l_x = reinterpret_cast<float*>(smw);  // [4][RW]
-    float* l_w = l_x + 4 * RW;                   // W1 | b1
-    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [RW][PW] dZ2 rows
+    float* l_x = reinterpret_cast<float*>(smw);  // [2][4][RW]
+    float* l_w = l_x + 2 * 4 * RW;               // W1 | b1
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [2][RW][PW] dZ2 rows, double-buffered
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int k = 32 * w + r;  // this lane's hidden unit of layer 1
+    W3_MARK(1, 8, net == 0);
     const float* pnet = g.params + (net ? g.np_a : 0);
     for (int i = tid; i < HW * NS + HW; i += NTW) l_w[i] = pnet[i];
     bf16x8 bw[KSW];
     load_frags_w(g.packed + (net ? 2 * HW * HW : 0) + HW * HW, w, lane, bw);
+    const int stride = gridDim.x;
+    // Two register sets keep the tiles of the next two passes in flight (a tile's loads take ~4000 cycles, a pass ~2000):
+    // pass `it` lands set it & 1 (tile + 1) in the other LDS buffer and re-issues it with tile + 3.  The gather of the
+    // observations alternates between waves 7 and 6 the same way.
+    nt_u32x4 dzs[2][4];
+    Staged stg;
+    {
+        const int t0 = blockIdx.x;
+        nt_u32x4 d0[4];
+        load_dz_tile(g.dz_rows, t0, tid, d0);
+        if (t0 + stride < g.ntiles) load_dz_tile(g.dz_rows, t0 + stride, tid, dzs[0]);
+        if (t0 + 2 * stride < g.ntiles) load_dz_tile(g.dz_rows, t0 + 2 * stride, tid, dzs[1]);
+        if (w == WV - 1) {
+            stage_issue<NS, 0, 0>(g, t0, lane, stg);
+            stage_write<NS, 0>(stg, l_x, nullptr, lane);
+            if (t0 + stride < g.ntiles) stage_issue<NS, 0, 0>(g, t0 + stride, lane, stg);
+        } else if (w == WV - 2) {
+            if (t0 + 2 * stride < g.ntiles) stage_issue<NS, 0, 0>(g, t0 + 2 * stride, lane, stg);
+        }
+        store_dz_tile(l_H, tid, d0);
+    }
     __syncthreads();
+    W3_MARK(1, 9, net == 0);
     float w1[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) w1[i] = l_w[k + HW * i];
@@ -444,36 +586,38 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) a_dw1[i] = 0.0f;
 
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        if (tid < RW) {
-            bool valid;
-            gather_x(g, NS, tile, tid, l_x, &valid);
-        }
-        {
-            const uint16_t* src = g.dz_rows + (int64_t)tile * RW * HW;
-#pragma unroll
-            for (int i = 0; i < RW * HW / 8 / NTW; ++i) {
-                const int c = tid + NTW * i, row = c >> 5, cc = c & 31;
-                *reinterpret_cast<uint4*>(l_H + row * PW + 8 * cc) = *reinterpret_cast<const uint4*>(src + row * HW + 8 * cc);
+#define W3_STRIDE (net == 0 ? 2 * gridDim.x : 0x7fffffff)
+    int tile = blockIdx.x;
+    auto pass = [&](auto PC) __attribute__((always_inline)) {
+        constexpr int p = decltype(PC)::value;
+        W3_STAMP(1, 0);
+        const float* lx = l_x + p * 4 * RW;
+        const uint16_t* lH = l_H + p * RW * PW;
+        if (tile + stride < g.ntiles) {
+            store_dz_tile(l_H + (p ^ 1) * RW * PW, tid, dzs[p]);
+            if (tile + 3 * stride < g.ntiles) load_dz_tile(g.dz_rows, tile + 3 * stride, tid, dzs[p]);
+            if (w == WV - 1 - p) {
+                stage_write<NS, 0>(stg, l_x + (p ^ 1) * 4 * RW, nullptr, lane);
+                if (tile + 3 * stride < g.ntiles) stage_issue<NS, 0, 0>(g, tile + 3 * stride, lane, stg);
             }
         }
-        __syncthreads();
+        W3_STAMP(1, 1);
         f32x16 dh[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) dh[rt][q] = 0.0f;
         {
-            const uint16_t* ap = l_H + r * PW + 8 * kb;
+            const uint16_t* ap = lH + r * PW + 8 * kb;
 #pragma unroll
             for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PW + 16 * ks);
                     dh[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], dh[rt], 0, 0, 0);
-                    if (rt == 1 && (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 8 A fragments in flight
                 }
         }
+        W3_STAMP(1, 2);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -481,7 +625,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
                 const int row = 32 * rt + mfma_row(q, kb);
                 float x[NS];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) x[i] = l_x[i * RW + row];
+                for (int i = 0; i < NS; ++i) x[i] = lx[i * RW + row];
                 float z = b1v;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) z = fmaf(w1[i], x[i], z);
@@ -494,8 +638,19 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
                 // and the live x values spill)
                 if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-        __syncthreads();  // l_x / l_H are rewritten by the next pass
+        W3_STAMP(1, 3);
+        __syncthreads();  // the one barrier of a pass: buffers p are free, buffers p ^ 1 are complete
+        W3_STAMP(1, 4);
+    };
+    while (tile < g.ntiles) {
+        pass(std::integral_constant<int, 0>{});
+        tile += stride;
+        if (tile >= g.ntiles) break;
+        pass(std::integral_constant<int, 1>{});
+        tile += stride;
     }
+#undef W3_STRIDE
+    W3_MARK(1, 10, net == 0);
     const int nS_net = net ? g.nS_a : 0;
     float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + nS_net;
     a_db1 += __shfl_xor(a_db1, 32, 64);
@@ -509,18 +664,26 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
 }
 
 // ------------------------------------------------------------------------------------------------ dW2 = H1^T dZ2
-constexpr size_t DW2W_LDS = (4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)(HW / 2) * PT * sizeof(uint16_t);
+constexpr size_t DW2W_LDS = (2 * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * (HW / 2) * PT * sizeof(uint16_t);
+
+__device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_frag, int tile, int w, int lane,
+                                              bf16x8 (&b)[RW / 16]) {
+#pragma unroll
+    for (int ks = 0; ks < RW / 16; ++ks)
+        b[ks] = *reinterpret_cast<const bf16x8*>(dz_frag + ((((int64_t)tile * (RW / 16) + ks) * WV + w) * 64 + lane) * 8);
+}
 
 template <int NS, int ACT>
-__global__ __launch_bounds__(NTW, 4) void ppo3w_dw2_kernel(P3WArgs g, int net, int nsr) {
+__global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, int nsr) {
     extern __shared__ __attribute__((aligned(16))) char smw[];
-    float* l_x = reinterpret_cast<float*>(smw);  // [4][RW]
-    float* l_w = l_x + 4 * RW;                   // W1 | b1
-    uint16_t* l_T = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [HW / 2][PT]: H1^T of this k half
+    float* l_x = reinterpret_cast<float*>(smw);  // [2][4][RW]
+    float* l_w = l_x + 2 * 4 * RW;               // W1 | b1
+    uint16_t* l_T = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [2][HW / 2][PT]: H1^T of this k half
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int kh = blockIdx.x & 1, sr = blockIdx.x >> 1;
+    W3_MARK(2, 8, net == 0);
     const float* pnet = g.params + (net ? g.np_a : 0);
     for (int i = tid; i < HW * NS + HW; i += NTW) l_w[i] = pnet[i];
     f32x16 acc[4];
@@ -528,21 +691,40 @@ __global__ __launch_bounds__(NTW, 4) void ppo3w_dw2_kernel(P3WArgs g, int net, i
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[kt][q] = 0.0f;
-
-    for (int tile = sr; tile < g.ntiles; tile += nsr) {
-        if (tid < RW) {
-            bool valid;
-            gather_x(g, NS, tile, tid, l_x, &valid);
+    // this wave's column tile of dZ2 for a tile's four k-steps, two sets: set it & 1 feeds pass `it` and is re-issued with
+    // the tile of pass it + 2 right after its MFMAs (two passes in flight); the gather alternates between waves 7 and 6
+    bf16x8 bq[2][RW / 16];
+    Staged stg;
+    if (sr < g.ntiles) {
+        load_dz_frags(g.dz_frag, sr, w, lane, bq[0]);
+        if (sr + nsr < g.ntiles) load_dz_frags(g.dz_frag, sr + nsr, w, lane, bq[1]);
+        if (w == WV - 1) {
+            stage_issue<NS, 0, 0>(g, sr, lane, stg);
+            stage_write<NS, 0>(stg, l_x, nullptr, lane);
+            if (sr + nsr < g.ntiles) stage_issue<NS, 0, 0>(g, sr + nsr, lane, stg);
+        } else if (w == WV - 2) {
+            if (sr + 2 * nsr < g.ntiles) stage_issue<NS, 0, 0>(g, sr + 2 * nsr, lane, stg);
         }
-        bf16x8 b[RW / 16];  // this wave's column tile of dZ2 for the tile's four k-steps: in flight during layer 1
-#pragma unroll
-        for (int ks = 0; ks < RW / 16; ++ks)
-            b[ks] = *reinterpret_cast<const bf16x8*>(g.dz_frag + ((((int64_t)tile * (RW / 16) + ks) * WV + w) * 64 + lane) * 8);
-        __syncthreads();
+    }
+    __syncthreads();
+    W3_MARK(2, 9, net == 0);
+
+#define W3_STRIDE (net == 0 ? 2 * nsr : 0x7fffffff)
+    int tile = sr;
+    auto pass = [&](auto PC) __attribute__((always_inline)) {
+        constexpr int p = decltype(PC)::value;
+        W3_STAMP(2, 0);
+        const float* lx = l_x + p * 4 * RW;
+        uint16_t* lT = l_T + p * (HW / 2) * PT;
+        if (w == WV - 1 - p && tile + nsr < g.ntiles) {
+            stage_write<NS, 0>(stg, l_x + (p ^ 1) * 4 * RW, nullptr, lane);
+            if (tile + 3 * nsr < g.ntiles) stage_issue<NS, 0, 0>(g, tile + 3 * nsr, lane, stg);
+        }
+        W3_STAMP(2, 1);
         // ---- layer 1 in [k][sample] order for the 128 hidden units of this half: 8 samples of one unit per item ----
 #pragma unroll
-        for (int it = 0; it < (HW / 2) * (RW / 8) / NTW; ++it) {
-            const int item = tid + NTW * it, rg = item & 7, kl = item >> 3;
+        for (int i2 = 0; i2 < (HW / 2) * (RW / 8) / NTW; ++i2) {
+            const int item = tid + NTW * i2, rg = item & 7, kl = item >> 3;
             const int k = (HW / 2) * kh + kl;
             float w1[NS];
 #pragma unroll
@@ -553,21 +735,33 @@ __global__ __launch_bounds__(NTW, 4) void ppo3w_dw2_kernel(P3WArgs g, int net, i
             for (int u = 0; u < 8; ++u) {
                 float z = bb;
 #pragma unroll
-                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], l_x[i * RW + 8 * rg + u], z);
+                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], lx[i * RW + 8 * rg + u], z);
                 hv[u] = act_fwd_t<ACT>(z);
             }
-            *reinterpret_cast<uint4*>(l_T + kl * PT + 8 * rg) = pack8_bf16(hv);
+            *reinterpret_cast<uint4*>(lT + kl * PT + 8 * rg) = pack8_bf16(hv);
         }
-        __syncthreads();
+        __syncthreads();  // the one barrier of a pass
+        W3_STAMP(2, 2);
 #pragma unroll
         for (int ks = 0; ks < RW / 16; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(l_T + (32 * kt + r) * PT + 16 * ks + 8 * kb);
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc[kt], 0, 0, 0);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(lT + (32 * kt + r) * PT + 16 * ks + 8 * kb);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[p][ks], acc[kt], 0, 0, 0);
             }
-        __syncthreads();  // l_x / l_T are rewritten by the next pass
+        W3_STAMP(2, 3);
+        if (tile + 2 * nsr < g.ntiles) load_dz_frags(g.dz_frag, tile + 2 * nsr, w, lane, bq[p]);
+        W3_STAMP(2, 4);
+    };
+    while (tile < g.ntiles) {
+        pass(std::integral_constant<int, 0>{});
+        tile += nsr;
+        if (tile >= g.ntiles) break;
+        pass(std::integral_constant<int, 1>{});
+        tile += nsr;
     }
+#undef W3_STRIDE
+    W3_MARK(2, 10, net == 0);
     // D[row = k (local)][col = j]: dW2[j + HW k]
     float* out = g.partW + ((int64_t)sr * 2 + net) * HW * HW;
     const int j = 32 * w + r;
@@ -575,6 +769,7 @@ __global__ __launch_bounds__(NTW, 4) void ppo3w_dw2_kernel(P3WArgs g, int net, i
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) out[j + HW * ((HW / 2) * kh + 32 * kt + mfma_row(q, kb))] = acc[kt][q];
+    W3_MARK(2, 11, net == 0);
 }
 
 // ------------------------------------------------------------------------------------------------ partial rows -> gradient
@@ -896,6 +1091,14 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     L.bytes = o + 256;
     return L;
 }
+
+#ifdef RLHIP_W3_TIMING
+extern "C" int32_t rlhip_debug_w3_stamps(long long* out_host) {
+    RLHIP_CHECK_HIP(hipDeviceSynchronize());
+    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_w3_stamps), 3 * 16 * sizeof(long long)));
+    return RLHIP_OK;
+}
+#endif
 
 int64_t ppo3w_nparams(int ns, int nout_a) { return mlp3w_np(ns, nout_a) + mlp3w_np(ns, 1); }
 
