@@ -105,6 +105,8 @@ struct P3WArgs {
     const int32_t* action_i;
     const float* params;     // [actor | critic]
     const uint16_t* packed;  // actor W2jk | actor W2kj | critic W2jk | critic W2kj   (MFMA B-fragment order, HW * HW each)
+    float* xg;               // [NS][npad] the micro-batch's observations in sample order (ppo3w_gather_kernel), npad = ntiles RW
+    float* sg;               // [4][npad]  old log-prob | advantage (0 on padding) | return | action (float or int bits)
     uint16_t* dz_rows;       // [ntiles * RW][HW] bf16
     uint16_t* dz_frag;       // [ntiles][RW / 16][WV][64 lanes][8] bf16
     float* partS;            // [rows][npS]: partial gradients of the small tensors, [actor small | critic small]
@@ -112,7 +114,7 @@ struct P3WArgs {
     float* loss_partials;    // [rows][4] {sum min(surr1, surr2), sum (ret - v)^2, sum entropy, -}
     int64_t n, np_a;
     uint32_t total, bm, pos0;
-    int ntiles, npS, nS_a, na;
+    int ntiles, npS, nS_a, na, npad;
     float lo, hi, wa, wc, we, inv_b, min_logp;
     PermKeys pk;
 };
@@ -154,43 +156,62 @@ __device__ __forceinline__ void load_frags_f32(const float* __restrict__ W2, int
     }
 }
 
-// One sample of a tile gathered into registers.  stage_issue computes f = perm(pos0 + q) and issues the global loads;
-// stage_write lands them in LDS one tile pass later, so the ~4000-cycle dependent chain (permutation -> index -> load) of
-// tile i + 2 runs under the compute of tile i (measured with the s_memtime stamps of tools/w3timing.py: the exposed
-// gather was 19 % of the forward tile and 56 - 65 % of the backward / dW2 tiles).  MODE 0: observation only; 1: + old
-// log-prob, advantage, action (actor); 2: + return (critic).
-struct Staged {
-    float x[4];
-    float s0, s1, s2;
-};
-template <int NS, int MODE, int CONT>
-__device__ __forceinline__ void stage_issue(const P3WArgs& g, int tile, int lane, Staged& st) {
-    const uint32_t q = (uint32_t)tile * RW + (uint32_t)lane;
+// The shuffled micro-batch is gathered ONCE per optimiser step into sample-ordered arrays (6 tile kernels read it): the
+// keyed permutation and the dependent random loads (~4000 cycles, measured 19 % of a forward tile and 56 - 65 % of the
+// backward / dW2 tiles when done in place) leave the tile loops, whose inputs become coalesced 256-byte wave loads at
+// addresses that depend on the tile index only.
+template <int NS, int CONT>
+__global__ __launch_bounds__(256) void ppo3w_gather_kernel(P3WArgs g) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= (uint32_t)g.npad) return;
     const bool valid = q < g.bm;
     const uint32_t f = permute(g.pk, g.pos0 + (valid ? q : 0u));
     const uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) st.x[k] = g.obs[((int64_t)t * NS + k) * g.n + i];
-    if (MODE == 1) {
-        st.s0 = g.logp[f];
-        st.s1 = g.adv[f];
-        if (!valid) st.s1 = 0.0f;
-        st.s2 = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
-    } else if (MODE == 2) {
-        st.s0 = g.ret[f];
-    }
+    for (int k = 0; k < NS; ++k) g.xg[(int64_t)k * g.npad + q] = g.obs[((int64_t)t * NS + k) * g.n + i];
+    g.sg[q] = g.logp[f];
+    g.sg[(int64_t)g.npad + q] = valid ? g.adv[f] : 0.0f;
+    g.sg[2 * (int64_t)g.npad + q] = g.ret[f];
+    g.sg[3 * (int64_t)g.npad + q] = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
 }
-template <int NS, int MODE>
-__device__ __forceinline__ void stage_write(const Staged& st, float* l_x, float* l_s, int lane) {
+
+// lane = sample of the tile.  Every wave issues these loads (uniform instruction streams keep the compiler's vmcnt
+// bookkeeping exact across the pass loop; a wave-conditional load made it fall back to vmcnt(0), which exposed the latency
+// of the youngest prefetch instead of the oldest)
+template <int NS>
+__device__ __forceinline__ void load_x(const P3WArgs& g, int tile, int lane, float (&x)[NS]) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) l_x[k * RW + lane] = st.x[k];
-    if (MODE == 1) {
-        l_s[lane] = st.s0;
-        l_s[RW + lane] = st.s1;
-        l_s[3 * RW + lane] = st.s2;
-    } else if (MODE == 2) {
-        l_s[2 * RW + lane] = st.s0;
-    }
+    for (int k = 0; k < NS; ++k) x[k] = g.xg[(int64_t)k * g.npad + (int64_t)tile * RW + lane];
+}
+// this wave's private copy [NS][RW] of a tile's observations
+template <int NS>
+__device__ __forceinline__ void store_x(float* l_xw, int lane, const float (&x)[NS]) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) l_xw[k * RW + lane] = x[k];
+}
+// N floats global -> LDS by the whole workgroup, every load issued before the first store
+template <int N>
+__device__ __forceinline__ void copy_to_lds(const float* __restrict__ src, float* dst, int tid) {
+    constexpr int IT = (N + NTW - 1) / NTW;
+    float v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) v[i] = (tid + NTW * i < N) ? src[tid + NTW * i] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        if (tid + NTW * i < N) dst[tid + NTW * i] = v[i];
+}
+template <int NS, int NOUT>
+__device__ __forceinline__ Mlp3W stage_small_w2(const float* __restrict__ p, float* l_w, int tid) {
+    constexpr int n1 = HW * NS + HW, n2 = HW + NOUT * HW + NOUT;
+    copy_to_lds<n1>(p, l_w, tid);
+    copy_to_lds<n2>(p + n1 + HW * HW, l_w + n1, tid);
+    Mlp3W v;
+    v.W1 = l_w;
+    v.b1 = l_w + HW * NS;
+    v.b2 = l_w + n1;
+    v.W3 = v.b2 + HW;
+    v.b3 = v.W3 + NOUT * HW;
+    return v;
 }
 
 // LDS exchange inside ONE wave (its private block): LDS instructions of a wave execute in order, so no workgroup barrier
@@ -204,7 +225,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ------------------------------------------------------------------------------------------------ forward + loss + dZ2
 constexpr int TPW = 36;  // f32 pitch of a wave's private 64 x 32 transposition block (144 B rows)
 constexpr int ZPW = 40;  // bf16 pitch of the same block when it holds the wave's dZ2 columns (80 B rows)
-constexpr size_t FWDW_LDS = (2 * 4 * RW + 2 * 4 * RW + MAXO * RW + WV * MAXO * RW + SMALLWW + WV * RW * TPW) * sizeof(float) +
+constexpr size_t FWDW_LDS = (MAXO * RW + WV * MAXO * RW + SMALLWW + WV * RW * TPW) * sizeof(float) +
                             (size_t)RW * PW * sizeof(uint16_t);
 
 template <int NS, int NOUT, int ACT, int CONT, int NET>
@@ -212,9 +233,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     constexpr int MODE = NET == 0 ? 1 : 2;
     W3_MARK(0, 8, NET == 0);
     extern __shared__ __attribute__((aligned(16))) char smw[];
-    float* l_x = reinterpret_cast<float*>(smw);  // [2][4][RW]   (double-buffered: the tile after this one lands meanwhile)
-    float* l_s = l_x + 2 * 4 * RW;               // [2][4][RW]: old log-prob, advantage, return, action
-    float* l_dq = l_s + 2 * 4 * RW;              // [MAXO][RW] dL/d(head outputs)
+    float* l_dq = reinterpret_cast<float*>(smw);  // [MAXO][RW] dL/d(head outputs)
     float* l_part = l_dq + MAXO * RW;            // [WV][MAXO][RW] head partial sums per wave
     float* l_w = l_part + WV * MAXO * RW;        // [SMALLWW]
     float* l_t = l_w + SMALLWW;                  // [WV][RW][TPW] wave-private transposition blocks
@@ -226,20 +245,26 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     float* l_tw = l_t + w * RW * TPW;
     uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);
     const float* pnet = g.params + (NET ? g.np_a : 0);
-    const Mlp3W m = stage_small_w(pnet, NS, NOUT, l_w, tid);
+    // every global load of the prologue is issued before the first wait: fragments, tile 0's inputs, the small tensors
     bf16x8 bw[KSW];
     load_frags_w(g.packed + (NET ? 2 * HW * HW : 0), w, lane, bw);
-    const int stride = gridDim.x;
-    Staged stg;
-    // two gather waves take turns (wave 7: the tiles of odd passes, wave 6: of even passes), so a tile's loads are in flight
-    // for TWO passes: tile 0 goes straight into buffer 0, tiles 1 and 2 into the registers of waves 7 and 6
-    if (w == WV - 1) {
-        stage_issue<NS, MODE, CONT>(g, blockIdx.x, lane, stg);
-        stage_write<NS, MODE>(stg, l_x, l_s, lane);
-        if ((int)blockIdx.x + stride < g.ntiles) stage_issue<NS, MODE, CONT>(g, blockIdx.x + stride, lane, stg);
-    } else if (w == WV - 2) {
-        if ((int)blockIdx.x + 2 * stride < g.ntiles) stage_issue<NS, MODE, CONT>(g, blockIdx.x + 2 * stride, lane, stg);
+    const int stride = gridDim.x, last = g.ntiles - 1;
+    // lane = sample row: the observation feeds layer 1 straight from registers (row1 == lane); log-prob / advantage / action
+    // or the return feed the loss line on wave 0.  Each is re-requested for the NEXT tile right after its last use, i.e.
+    // most of a pass (~9000 cycles) ahead of its next use.
+    float xr[NS], sr0, sr1 = 0.0f, sr2 = 0.0f;
+    load_x<NS>(g, blockIdx.x, lane, xr);
+    {
+        const int64_t q0 = (int64_t)blockIdx.x * RW + lane;
+        if (MODE == 1) {
+            sr0 = g.sg[q0];
+            sr1 = g.sg[(int64_t)g.npad + q0];
+            sr2 = g.sg[3 * (int64_t)g.npad + q0];
+        } else {
+            sr0 = g.sg[2 * (int64_t)g.npad + q0];
+        }
     }
+    const Mlp3W m = stage_small_w2<NS, NOUT>(pnet, l_w, tid);
     __syncthreads();
     W3_MARK(0, 9, NET == 0);
     const float b2v = m.b2[col];
@@ -252,25 +277,20 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     float s_red[NOUT + 2];  // wave 0, one sample row per lane: sum dq[o] (= db3), loss terms
 #pragma unroll
     for (int o = 0; o < NOUT + 2; ++o) s_red[o] = 0.0f;
-    const int row1 = tid & (RW - 1), u0 = 32 * (tid >> 6);  // layer 1: this thread's sample row and its 32 hidden units
+    const int row1 = lane, u0 = 32 * w;  // layer 1: this thread's sample row (= lane) and its 32 hidden units
 
 #define W3_STRIDE (NET == 0 ? gridDim.x : 0x7fffffff)
     int it = 0;
     for (int tile = blockIdx.x; tile < g.ntiles; tile += stride, ++it) {
         W3_STAMP(0, 0);
-        const int p = it & 1;
-        const float* lx = l_x + p * 4 * RW;
-        const float* ls = l_s + p * 4 * RW;
-        if (w == WV - 1 - p && tile + stride < g.ntiles) {  // pass `it`: wave 7 - (it & 1) lands tile + 1 and requests tile + 3
-            stage_write<NS, MODE>(stg, l_x + (p ^ 1) * 4 * RW, l_s + (p ^ 1) * 4 * RW, lane);
-            if (tile + 3 * stride < g.ntiles) stage_issue<NS, MODE, CONT>(g, tile + 3 * stride, lane, stg);
-        }
+        const int tnext = min(tile + stride, last);  // (clamped: the tail re-reads the last tile instead of branching)
         W3_STAMP(0, 1);
         // ---- layer 1: h1 = act(b1 + W1 x) (the fmaf chain of mlp2 / the oracle), bf16 rows ----
         {
             float x[NS];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) x[i] = lx[i * RW + row1];
+            for (int i = 0; i < NS; ++i) x[i] = xr[i];
+            load_x<NS>(g, tnext, lane, xr);
             uint16_t* dst = l_H + row1 * PW + u0;
 #pragma unroll
             for (int h8 = 0; h8 < 4; ++h8) {
@@ -361,8 +381,8 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
             if (NET == 0) {
                 float dl[MAXO] = {0.f, 0.f, 0.f, 0.f};
-                const float lp_old = fmaxf(ls[s], g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
-                const float A = ls[RW + s];
+                const float lp_old = fmaxf(sr0, g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
+                const float A = sr1;
                 float ent, surr_min;
                 if (!CONT) {
                     const int na = g.na;
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                         pr[k] = expf(logp[k]);
                         ent -= pr[k] * logp[k];
                     }
-                    const int a = __float_as_int(ls[3 * RW + s]);
+                    const int a = __float_as_int(sr2);
                     float lp_new = 0.f;
                     for (int k = 0; k < na; ++k)
                         if (k == a) lp_new = logp[k];
@@ -398,7 +418,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                     const float eps = 1.0e-8f;
                     const float mu = oa[0], lsg = oa[1];
                     const float sg = expf(lsg);
-                    const float z = ls[3 * RW + s];
+                    const float z = sr2;
                     const float se = sg + eps;
                     const float zz = (z - mu) / se;
                     const float lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 s_red[NOUT] += surr_min;
                 s_red[NOUT + 1] += ent;
             } else {
-                const float dv = ls[2 * RW + s] - oa[0];
+                const float dv = sr0 - oa[0];
                 float dvout = -2.0f * g.wc * g.inv_b * dv;
                 float sq = dv * dv;
                 if (!valid) {
@@ -438,6 +458,16 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 l_dq[s] = dvout;
                 s_red[0] += dvout;
                 s_red[NOUT] += sq;
+            }
+        }
+        {  // the next tile's loss inputs (every wave: uniform streams; wave 0 uses them)
+            const int64_t qn = (int64_t)tnext * RW + lane;
+            if (MODE == 1) {
+                sr0 = g.sg[qn];
+                sr1 = g.sg[(int64_t)g.npad + qn];
+                sr2 = g.sg[3 * (int64_t)g.npad + qn];
+            } else {
+                sr0 = g.sg[2 * (int64_t)g.npad + qn];
             }
         }
         __syncthreads();  // D: dL/d(head outputs) of the tile
@@ -487,8 +517,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
         }
         wave_lds_fence();
         W3_STAMP(0, 7);
-        // no barrier: the next pass writes l_H (last read before barrier C), the other l_x / l_s buffer, and this wave's
-        // private block in program order
+        // no barrier: the next pass writes l_H (last read before barrier C) and this wave's private block in program order
     }
 #undef W3_STRIDE
     W3_MARK(0, 10, NET == 0);
@@ -521,7 +550,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------ dH1 -> dW1 / db1
-constexpr size_t BWDW_LDS = (2 * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * RW * PW * sizeof(uint16_t);
+constexpr size_t BWDW_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * RW * PW * sizeof(uint16_t);
 
 // this thread's four 16-byte chunks of a 64 x 256 bf16 tile: chunk c = tid + 512 i -> row c >> 5, column 8 (c & 31)
 __device__ __forceinline__ void load_dz_tile(const uint16_t* __restrict__ dz_rows, int tile, int tid, nt_u32x4 (&d)[4]) {
@@ -543,8 +572,8 @@ __device__ __forceinline__ void store_dz_tile(uint16_t* lH, int tid, const nt_u3
 template <int NS, int ACT>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
     extern __shared__ __attribute__((aligned(16))) char smw[];
-    float* l_x = reinterpret_cast<float*>(smw);  // [2][4][RW]
-    float* l_w = l_x + 2 * 4 * RW;               // W1 | b1
+    float* l_x = reinterpret_cast<float*>(smw);  // [2][WV][4][RW]: every wave keeps its own copy of the tile's observations
+    float* l_w = l_x + 2 * WV * 4 * RW;          // W1 | b1
     uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [2][RW][PW] dZ2 rows, double-buffered
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -552,29 +581,36 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
     const int k = 32 * w + r;  // this lane's hidden unit of layer 1
     W3_MARK(1, 8, net == 0);
     const float* pnet = g.params + (net ? g.np_a : 0);
-    for (int i = tid; i < HW * NS + HW; i += NTW) l_w[i] = pnet[i];
     bf16x8 bw[KSW];
     load_frags_w(g.packed + (net ? 2 * HW * HW : 0) + HW * HW, w, lane, bw);
-    const int stride = gridDim.x;
+    const int stride = gridDim.x, last = g.ntiles - 1;
+    float* l_xw = l_x + w * 4 * RW;
     // Two register sets keep the tiles of the next two passes in flight (a tile's loads take ~4000 cycles, a pass ~2000):
-    // pass `it` lands set it & 1 (tile + 1) in the other LDS buffer and re-issues it with tile + 3.  The gather of the
-    // observations alternates between waves 7 and 6 the same way.
+    // pass `it` lands set it & 1 (tile + 1) in the other LDS buffer and re-issues it with tile + 3.
+    // (tile indices are clamped to the last tile instead of branching: unconditional loads keep the vmcnt bookkeeping exact)
     nt_u32x4 dzs[2][4];
-    Staged stg;
+    float xr[2][NS];
     {
         const int t0 = blockIdx.x;
         nt_u32x4 d0[4];
+        float x0[NS];
+        // issue order = the steady state of the pass loop (older: everything the prologue itself consumes; then set 0, then
+        // set 1), so that the loop is entered with exactly the outstanding loads its back edge carries
         load_dz_tile(g.dz_rows, t0, tid, d0);
-        if (t0 + stride < g.ntiles) load_dz_tile(g.dz_rows, t0 + stride, tid, dzs[0]);
-        if (t0 + 2 * stride < g.ntiles) load_dz_tile(g.dz_rows, t0 + 2 * stride, tid, dzs[1]);
-        if (w == WV - 1) {
-            stage_issue<NS, 0, 0>(g, t0, lane, stg);
-            stage_write<NS, 0>(stg, l_x, nullptr, lane);
-            if (t0 + stride < g.ntiles) stage_issue<NS, 0, 0>(g, t0 + stride, lane, stg);
-        } else if (w == WV - 2) {
-            if (t0 + 2 * stride < g.ntiles) stage_issue<NS, 0, 0>(g, t0 + 2 * stride, lane, stg);
-        }
+        load_x<NS>(g, t0, lane, x0);
+        constexpr int NWL = (HW * NS + HW + NTW - 1) / NTW;
+        float wv[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wv[i] = (tid + NTW * i < HW * NS + HW) ? pnet[tid + NTW * i] : 0.0f;
+        load_dz_tile(g.dz_rows, min(t0 + stride, last), tid, dzs[0]);
+        load_x<NS>(g, min(t0 + stride, last), lane, xr[0]);
+        load_dz_tile(g.dz_rows, min(t0 + 2 * stride, last), tid, dzs[1]);
+        load_x<NS>(g, min(t0 + 2 * stride, last), lane, xr[1]);
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if (tid + NTW * i < HW * NS + HW) l_w[tid + NTW * i] = wv[i];
         store_dz_tile(l_H, tid, d0);
+        store_x<NS>(l_xw, lane, x0);
     }
     __syncthreads();
     W3_MARK(1, 9, net == 0);
@@ -591,15 +627,15 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
     auto pass = [&](auto PC) __attribute__((always_inline)) {
         constexpr int p = decltype(PC)::value;
         W3_STAMP(1, 0);
-        const float* lx = l_x + p * 4 * RW;
+        const float* lx = l_xw + p * WV * 4 * RW;
         const uint16_t* lH = l_H + p * RW * PW;
-        if (tile + stride < g.ntiles) {
+        {
+            int t3 = tile + 3 * stride;  // past the end: re-read this workgroup's OWN first tile (never one tile for all)
+            if (t3 > last) t3 = blockIdx.x;
             store_dz_tile(l_H + (p ^ 1) * RW * PW, tid, dzs[p]);
-            if (tile + 3 * stride < g.ntiles) load_dz_tile(g.dz_rows, tile + 3 * stride, tid, dzs[p]);
-            if (w == WV - 1 - p) {
-                stage_write<NS, 0>(stg, l_x + (p ^ 1) * 4 * RW, nullptr, lane);
-                if (tile + 3 * stride < g.ntiles) stage_issue<NS, 0, 0>(g, tile + 3 * stride, lane, stg);
-            }
+            store_x<NS>(l_xw + (p ^ 1) * WV * 4 * RW, lane, xr[p]);
+            load_dz_tile(g.dz_rows, t3, tid, dzs[p]);
+            load_x<NS>(g, t3, lane, xr[p]);
         }
         W3_STAMP(1, 1);
         f32x16 dh[2];
@@ -642,6 +678,11 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
         __syncthreads();  // the one barrier of a pass: buffers p are free, buffers p ^ 1 are complete
         W3_STAMP(1, 4);
     };
+    // pairs of passes without an exit in between (a straight-line loop body lets the compiler count the outstanding loads
+    // exactly: with an exit between the two passes it waited for the YOUNGER register set in every second pass)
+    const int npass = (g.ntiles - (int)blockIdx.x + stride - 1) / stride;
+#ifdef RLHIP_W3_E1
+    (void)npass;
     while (tile < g.ntiles) {
         pass(std::integral_constant<int, 0>{});
         tile += stride;
@@ -649,6 +690,15 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
         pass(std::integral_constant<int, 1>{});
         tile += stride;
     }
+#else
+    for (int it2 = 0; it2 + 1 < npass; it2 += 2) {
+        pass(std::integral_constant<int, 0>{});
+        tile += stride;
+        pass(std::integral_constant<int, 1>{});
+        tile += stride;
+    }
+    if (npass & 1) pass(std::integral_constant<int, 0>{});
+#endif
 #undef W3_STRIDE
     W3_MARK(1, 10, net == 0);
     const int nS_net = net ? g.nS_a : 0;
@@ -664,7 +714,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
 }
 
 // ------------------------------------------------------------------------------------------------ dW2 = H1^T dZ2
-constexpr size_t DW2W_LDS = (2 * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * (HW / 2) * PT * sizeof(uint16_t);
+constexpr size_t DW2W_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * (HW / 2) * PT * sizeof(uint16_t);
 
 __device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_frag, int tile, int w, int lane,
                                               bf16x8 (&b)[RW / 16]) {
@@ -676,8 +726,8 @@ __device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_fr
 template <int NS, int ACT>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, int nsr) {
     extern __shared__ __attribute__((aligned(16))) char smw[];
-    float* l_x = reinterpret_cast<float*>(smw);  // [2][4][RW]
-    float* l_w = l_x + 2 * 4 * RW;               // W1 | b1
+    float* l_x = reinterpret_cast<float*>(smw);  // [2][WV][4][RW]: wave-private copies of the tile's observations
+    float* l_w = l_x + 2 * WV * 4 * RW;          // W1 | b1
     uint16_t* l_T = reinterpret_cast<uint16_t*>(l_w + HW * 4 + HW);  // [2][HW / 2][PT]: H1^T of this k half
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -685,7 +735,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
     const int kh = blockIdx.x & 1, sr = blockIdx.x >> 1;
     W3_MARK(2, 8, net == 0);
     const float* pnet = g.params + (net ? g.np_a : 0);
-    for (int i = tid; i < HW * NS + HW; i += NTW) l_w[i] = pnet[i];
+    float* l_xw = l_x + w * 4 * RW;
     f32x16 acc[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -693,18 +743,28 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
         for (int q = 0; q < 16; ++q) acc[kt][q] = 0.0f;
     // this wave's column tile of dZ2 for a tile's four k-steps, two sets: set it & 1 feeds pass `it` and is re-issued with
     // the tile of pass it + 2 right after its MFMAs (two passes in flight); the gather alternates between waves 7 and 6
+    // observations: set it & 1 holds tile + 1 at the top of pass `it`, lands in the other LDS copy, is re-issued with tile + 3
+    // (indices clamped to the last tile instead of branching: unconditional loads keep the vmcnt bookkeeping exact)
     bf16x8 bq[2][RW / 16];
-    Staged stg;
-    if (sr < g.ntiles) {
-        load_dz_frags(g.dz_frag, sr, w, lane, bq[0]);
-        if (sr + nsr < g.ntiles) load_dz_frags(g.dz_frag, sr + nsr, w, lane, bq[1]);
-        if (w == WV - 1) {
-            stage_issue<NS, 0, 0>(g, sr, lane, stg);
-            stage_write<NS, 0>(stg, l_x, nullptr, lane);
-            if (sr + nsr < g.ntiles) stage_issue<NS, 0, 0>(g, sr + nsr, lane, stg);
-        } else if (w == WV - 2) {
-            if (sr + 2 * nsr < g.ntiles) stage_issue<NS, 0, 0>(g, sr + 2 * nsr, lane, stg);
-        }
+    float xr[2][NS];
+    const int last = g.ntiles - 1;
+    {
+        float x0[NS];
+        // issue order = the steady state of the pass loop: what the prologue consumes first, then x set 0, fragment set 0
+        // (tile 0; re-issued at the END of a pass), x set 1, fragment set 1
+        load_x<NS>(g, min(sr, last), lane, x0);
+        constexpr int NWL = (HW * NS + HW + NTW - 1) / NTW;
+        float wv[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wv[i] = (tid + NTW * i < HW * NS + HW) ? pnet[tid + NTW * i] : 0.0f;
+        load_x<NS>(g, min(sr + nsr, last), lane, xr[0]);
+        load_dz_frags(g.dz_frag, min(sr, last), w, lane, bq[0]);
+        load_x<NS>(g, min(sr + 2 * nsr, last), lane, xr[1]);
+        load_dz_frags(g.dz_frag, min(sr + nsr, last), w, lane, bq[1]);
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if (tid + NTW * i < HW * NS + HW) l_w[tid + NTW * i] = wv[i];
+        store_x<NS>(l_xw, lane, x0);
     }
     __syncthreads();
     W3_MARK(2, 9, net == 0);
@@ -714,12 +774,11 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
     auto pass = [&](auto PC) __attribute__((always_inline)) {
         constexpr int p = decltype(PC)::value;
         W3_STAMP(2, 0);
-        const float* lx = l_x + p * 4 * RW;
+        const float* lx = l_xw + p * WV * 4 * RW;
         uint16_t* lT = l_T + p * (HW / 2) * PT;
-        if (w == WV - 1 - p && tile + nsr < g.ntiles) {
-            stage_write<NS, 0>(stg, l_x + (p ^ 1) * 4 * RW, nullptr, lane);
-            if (tile + 3 * nsr < g.ntiles) stage_issue<NS, 0, 0>(g, tile + 3 * nsr, lane, stg);
-        }
+        store_x<NS>(l_xw + (p ^ 1) * WV * 4 * RW, lane, xr[p]);
+        load_x<NS>(g, min(tile + 3 * nsr, last), lane, xr[p]);
+        wave_lds_fence();
         W3_STAMP(2, 1);
         // ---- layer 1 in [k][sample] order for the 128 hidden units of this half: 8 samples of one unit per item ----
 #pragma unroll
@@ -750,16 +809,17 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
                 acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[p][ks], acc[kt], 0, 0, 0);
             }
         W3_STAMP(2, 3);
-        if (tile + 2 * nsr < g.ntiles) load_dz_frags(g.dz_frag, tile + 2 * nsr, w, lane, bq[p]);
+        load_dz_frags(g.dz_frag, min(tile + 2 * nsr, last), w, lane, bq[p]);
         W3_STAMP(2, 4);
     };
-    while (tile < g.ntiles) {
+    const int npass = (g.ntiles - sr + nsr - 1) / nsr;
+    for (int it2 = 0; it2 + 1 < npass; it2 += 2) {
         pass(std::integral_constant<int, 0>{});
         tile += nsr;
-        if (tile >= g.ntiles) break;
         pass(std::integral_constant<int, 1>{});
         tile += nsr;
     }
+    if (npass & 1) pass(std::integral_constant<int, 0>{});
 #undef W3_STRIDE
     W3_MARK(2, 10, net == 0);
     // D[row = k (local)][col = j]: dW2[j + HW k]
@@ -1043,7 +1103,7 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-constexpr int P3W_ROWS_S = 512;  // persistent workgroups (= partial rows) of the forward / backward kernels: two per CU
+constexpr int P3W_ROWS_S = 512;  // upper bound of the persistent workgroups (= partial rows) of the forward / backward kernels
 constexpr int P3W_ROWS_W = 128;  // sample ranges (= partial rows) of the dW2 kernel; its grid is twice that (two k halves)
 constexpr int64_t P3W_MAX_TILES = 1 << 20;
 
@@ -1067,7 +1127,7 @@ static int p3w_rows_w() {
 }
 
 struct P3WLayout {
-    int64_t ntiles, off_rows, off_frag, off_partS, off_partW, off_loss, bytes;
+    int64_t ntiles, off_xg, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, bytes;
     int npS, nS_a;
 };
 
@@ -1078,6 +1138,10 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     L.nS_a = mlp3w_ns_small(ns, nout_a);
     L.npS = L.nS_a + mlp3w_ns_small(ns, 1);
     int64_t o = 4 * (int64_t)HW * HW * sizeof(uint16_t);
+    L.off_xg = o;
+    o += 4 * L.ntiles * RW * (int64_t)sizeof(float);
+    L.off_sg = o;
+    o += 4 * L.ntiles * RW * (int64_t)sizeof(float);
     L.off_rows = o;
     o += L.ntiles * RW * HW * (int64_t)sizeof(uint16_t);
     L.off_frag = o;
@@ -1175,6 +1239,9 @@ int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd,
     g.params = params;
     uint16_t* packed = (uint16_t*)ws;
     g.packed = packed;
+    g.xg = (float*)(ws + L.off_xg);
+    g.sg = (float*)(ws + L.off_sg);
+    g.npad = (int)(L.ntiles * RW);
     g.dz_rows = (uint16_t*)(ws + L.off_rows);
     g.dz_frag = (uint16_t*)(ws + L.off_frag);
     g.partS = (float*)(ws + L.off_partS);
@@ -1200,7 +1267,24 @@ int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd,
     g.pk = perm_keys(seed, epoch_ctr, (uint32_t)total);
     int32_t rc = ppo3w_pack(params, ns, g.np_a, packed, s);
     if (rc) return rc;
-    const int nrowsS = (int)(L.ntiles < P3W_ROWS_S ? L.ntiles : P3W_ROWS_S);
+    // one persistent workgroup per CU (the kernels hold 160 - 220 registers per lane: 2 waves per SIMD = one 8-wave workgroup):
+    // a second round of workgroups would pay the ~6000-cycle prologue (weights, fragments, first tile) twice
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        RLHIP_CHECK_HIP(hipGetDevice(&dev));
+        RLHIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        const char* e = getenv("RLHIP_PPO3W_WGS");
+        if (e && atoi(e) > 0) n_cu = atoi(e);
+        if (n_cu < 1) n_cu = 1;
+        if (n_cu > P3W_ROWS_S) n_cu = P3W_ROWS_S;
+    }
+    const int nrowsS = (int)(L.ntiles < n_cu ? L.ntiles : n_cu);
+    {
+        const int gb = (g.npad + 255) / 256;
+        if (kind == 0) hipLaunchKernelGGL((ppo3w_gather_kernel<4, 0>), dim3(gb), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((ppo3w_gather_kernel<3, 1>), dim3(gb), dim3(256), 0, s, g);
+    }
     const int nsr = (int)(L.ntiles < p3w_rows_w() ? L.ntiles : p3w_rows_w());
 #define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
     do {                                                                                                              \
