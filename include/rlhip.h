@@ -610,8 +610,9 @@ typedef struct {
     int32_t continuous;          /* 0 categorical actor; 1 gaussian actor (mu, log sigma) */
     int32_t normalize_advantage; /* reserved, must be 0 */
     int32_t layers;              /* 2 (default; 0 means 2): ns -> hidden -> nout on the VALU (ppo.hip / ppo_grad.hip);
-                                  * 3: ns -> 128 -> 128 -> nout actor and critic with the hidden x hidden layer on the
-                                  * bf16 MFMA (ppo3.hip), BASELINE configs[2] "actor/critic MLP in bf16 MFMA" */
+                                  * 3: ns -> hidden -> hidden -> nout actor and critic with the hidden x hidden layer on the
+                                  * bf16 MFMA, hidden = 128 (ppo3.hip) or 256 (ppo3w.hip), BASELINE configs[2]
+                                  * "actor/critic MLP in bf16 MFMA"; CartPole (categorical) and Pendulum (Gaussian) */
 } rlhip_ppo_cfg;
 int32_t rlhip_ppo_default(rlhip_ppo_cfg* cfg_host);
 /* parameter count of ActorCritic(actor = ns->hidden->na_out, critic = ns->hidden->1), flat = [actor | critic] */

@@ -56,7 +56,9 @@ __host__ __device__ __forceinline__ int64_t mlp3w_np(int64_t ns, int64_t nout) {
 // "small" parameter space of one net = everything except W2, in parameter order: W1 | b1 | b2 | W3 | b3
 __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { return HW * ns + 2 * HW + nout * HW + nout; }
 
-// per-phase cycle stamps of one steady-state tile (workgroup 0, thread 0, its second tile): -DRLHIP_W3_TIMING
+// per-phase cycle stamps of one steady-state tile (workgroup 0, thread 0, its second / third tile): -DRLHIP_W3_TIMING.
+// PROPORTIONS ONLY: the stamps change the register allocation (the backward kernel spilled 584 bytes per lane in one timing
+// build and ran 4x slower than the shipped one) -- kernel times come from rocprofv3 on the normal build.
 #ifdef RLHIP_W3_TIMING
 __device__ long long g_w3_stamps[3][16];
 #define W3_STAMP(kern, k)                                                                                  \
@@ -681,16 +683,6 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
     // pairs of passes without an exit in between (a straight-line loop body lets the compiler count the outstanding loads
     // exactly: with an exit between the two passes it waited for the YOUNGER register set in every second pass)
     const int npass = (g.ntiles - (int)blockIdx.x + stride - 1) / stride;
-#ifdef RLHIP_W3_E1
-    (void)npass;
-    while (tile < g.ntiles) {
-        pass(std::integral_constant<int, 0>{});
-        tile += stride;
-        if (tile >= g.ntiles) break;
-        pass(std::integral_constant<int, 1>{});
-        tile += stride;
-    }
-#else
     for (int it2 = 0; it2 + 1 < npass; it2 += 2) {
         pass(std::integral_constant<int, 0>{});
         tile += stride;
@@ -698,7 +690,6 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
         tile += stride;
     }
     if (npass & 1) pass(std::integral_constant<int, 0>{});
-#endif
 #undef W3_STRIDE
     W3_MARK(1, 10, net == 0);
     const int nS_net = net ? g.nS_a : 0;

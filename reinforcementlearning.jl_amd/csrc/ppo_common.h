@@ -27,7 +27,7 @@ struct PolicyDesc {
     float gamma, lambda;  // for the GAE scan fused into the tail of the rollout kernels
 };
 
-// cfg.layers == 3: actor / critic ns -> 128 -> 128 -> nout with the MFMA hidden layer (ppo3.hip)
+// cfg.layers == 3: actor / critic ns -> h -> h -> nout with the MFMA hidden layer, h = 128 (ppo3.hip) or 256 (ppo3w.hip)
 static inline bool is_layers3(const rlhip_ppo_cfg* c) { return c != nullptr && c->layers == 3; }
 int64_t ppo3_nparams(int32_t kind, const rlhip_ppo_cfg* c);
 int64_t ppo3_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* c, int64_t n, int64_t T);

@@ -78,7 +78,7 @@ class PPOPolicy:
         ns = env.odim
         self.na = 1 if env.continuous else len(env.action_space())
         nout_a = 2 * self.na if env.continuous else self.na
-        # cfg.layers = 3: actor / critic ns -> 128 -> 128 -> nout with the hidden layer on the bf16 MFMA (ppo3.hip)
+        # cfg.layers = 3: actor / critic ns -> h -> h -> nout, h = 128 (ppo3.hip) or 256 (ppo3w.hip), hidden layer on the bf16 MFMA
         self.layers = 3 if self.cfg.layers == 3 else 2
         nparams_fn, init_fn = ("rlhip_mlp2_nparams", "rlhip_mlp2_init_f32") if self.layers == 2 else \
             ("rlhip_mlp3_nparams", "rlhip_mlp3_init_f32")
