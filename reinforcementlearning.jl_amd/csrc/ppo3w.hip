@@ -587,8 +587,10 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
     load_frags_w(g.packed + (net ? 2 * HW * HW : 0) + HW * HW, w, lane, bw);
     const int stride = gridDim.x, last = g.ntiles - 1;
     float* l_xw = l_x + w * 4 * RW;
-    // Two register sets keep the tiles of the next two passes in flight (a tile's loads take ~4000 cycles, a pass ~2000):
-    // pass `it` lands set it & 1 (tile + 1) in the other LDS buffer and re-issues it with tile + 3.
+    // Two register sets keep the tiles of the next two passes in flight (a tile's loads take ~4000 cycles, a pass ~3000):
+    // pass `it` lands set it & 1 (tile + 1) in the other LDS buffer and re-issues it with tile + 3.  (Three sets / three
+    // passes in flight were measured too: 29.8 vs 28.9 us -- with two sets the kernel is no longer waiting for memory; per
+    // pass and SIMD it issues 2 x 354 VALU instructions (4 cycles each) beside 2048 cycles of MFMA.)
     // (tile indices are clamped to the last tile instead of branching: unconditional loads keep the vmcnt bookkeeping exact)
     nt_u32x4 dzs[2][4];
     float xr[2][NS];
@@ -723,7 +725,19 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
-    const int kh = blockIdx.x & 1, sr = blockIdx.x >> 1;
+    // The two k halves of a sample range read the SAME dZ2 fragments.  Workgroups are dealt to the 8 XCDs round-robin
+    // (workgroup b -> XCD b % 8, each XCD with its own L2), so the pair is placed on ONE XCD, back to back in its dispatch
+    // order: the second read of every fragment can hit that XCD's L2 instead of crossing the fabric twice (measured: within
+    // noise, 28.0 -> 27.5 us -- the kernel is bound by its instruction streams, not by the fabric).
+    int kh, sr;
+    if ((nsr & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        kh = j & 1;
+        sr = (j >> 1) * 8 + xcd;
+    } else {
+        kh = blockIdx.x & 1;
+        sr = blockIdx.x >> 1;
+    }
     W3_MARK(2, 8, net == 0);
     const float* pnet = g.params + (net ? g.np_a : 0);
     float* l_xw = l_x + w * 4 * RW;
