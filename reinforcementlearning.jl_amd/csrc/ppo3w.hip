@@ -669,8 +669,19 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
                 float z = b1v;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) z = fmaf(w1[i], x[i], z);
-                const float hv = act_fwd_t<ACT>(z);
-                const float dz = dh[rt][q] * act_bwd_t<ACT>(z, hv);
+                // tanh: 1 - h1^2 = 4 t / (t + 1)^2 with t = exp(2 |z|), branch-free on the hardware exponential.  The library
+                // tanhf (96 inlined copies of a branchy routine in this kernel) left 446 registers per lane in scratch and
+                // the launch at 266 us against 29 us for relu; the factor agrees with 1 - tanhf(z)^2 to ~1e-6 relative
+                // (the bar on this gradient is 5e-4 of max |g|); the FORWARD passes keep tanhf (bf16 rounding parity)
+                float dact;
+                if (ACT == 0) {
+                    dact = z > 0.0f ? 1.0f : 0.0f;
+                } else {
+                    const float t = __expf(2.0f * fminf(fabsf(z), 40.0f));
+                    const float u = __builtin_amdgcn_rcpf(t + 1.0f);  // v_rcp_f32: 1 ulp
+                    dact = 4.0f * t * u * u;
+                }
+                const float dz = dh[rt][q] * dact;
                 a_db1 += dz;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) a_dw1[i] = fmaf(dz, x[i], a_dw1[i]);
