@@ -33,6 +33,7 @@
 #include "ppo_common.h"
 #include "ppo_sample_device.h"
 #include "mlp3_device.h"
+#include "optim_device.h"
 #include <type_traits>
 
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow, int64_t n,
@@ -908,6 +909,143 @@ __global__ __launch_bounds__(256) void ppo3w_reduce_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ optimiser tail
+// optimise! after the six tile kernels, in TWO launches with no grid barrier between or inside them (the kernel boundary is
+// the barrier), bit-identical to ppo3w_reduce_kernel + rlhip_clip_adam_f32 + ppo3w_pack_kernel (four launches):
+//   ppo3w_reduce_sumsq_kernel  256 workgroups, element i = 256 b + t + 65536 k (the element-to-thread map of
+//       sumsq_scaled_partial_kernel): partial rows -> gradient in the order of ppo3w_reduce_kernel (four row groups,
+//       ascending inside a group, ((a0 + a1) + a2) + a3), 64 loads in flight per trip; the Float64 sum of squares of the
+//       workgroup's elements in the same order as the stand-alone kernel; the PPO loss line
+//   ppo3w_adam_pack_kernel     clip_adam_grid_kernel (norm from the 256 partials, clip, Adam, beta powers by the last workgroup
+//       out) + the bf16 re-pack of both nets' W2 in both fragment orientations (parameter-centric)
+constexpr int W3T_BLOCKS = 256;
+
+// one row group (quarter) of an element's partial rows, ascending, up to 64 loads in flight
+__device__ __forceinline__ float sum_rows_quarter(const float* __restrict__ src, int64_t stride, int nrows, int qtr) {
+    const int per = (nrows + 3) / 4;
+    const int b0 = qtr * per, b1 = min(nrows, b0 + per);
+    float acc = 0.f;
+    for (int off = b0; off < b1; off += 64) {
+        float t[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) t[u] = (off + u < b1) ? src[(int64_t)(off + u) * stride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc += t[u];  // x + 0.0f is exact: the padded slots change no bit
+    }
+    return acc;
+}
+
+// 1024 threads: thread (t = tid & 255, qtr = tid >> 8) sums row group `qtr` of element 256 b + t + 65536 k; threads of group 0
+// (waves 0..3, i.e. exactly the 256-thread workgroup of sumsq_scaled_partial_kernel) combine and carry the squares
+__global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* __restrict__ partS, const float* __restrict__ partW,
+                                                                  const float* __restrict__ loss_partials, int nrowsS,
+                                                                  int nrowsW, int npS, int nS_a, int np, int np_a, int ns,
+                                                                  float* __restrict__ grad, float* __restrict__ losses,
+                                                                  float wa, float wc, float we, float inv_b, float grad_scale,
+                                                                  double* __restrict__ sumsq) {
+    __shared__ double scratch[16];
+    __shared__ float l_q[3][256];
+    __shared__ float l_loss[4];
+    const int tid = threadIdx.x, t = tid & 255, qtr = tid >> 8, lane = tid & 63, wv = tid >> 6;
+    double acc = 0.0;
+    const int64_t stride_t = (int64_t)gridDim.x * 256;
+    const int nk = (int)((np + stride_t - 1) / stride_t);
+    for (int k = 0; k < nk; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + t + k * stride_t;
+        float part = 0.f;
+        if (i < np) {
+            const int p = (int)i;
+            const int net = p >= np_a ? 1 : 0;
+            const int q = p - net * np_a;
+            const int nA = HW * ns + HW;
+            if (q < nA) part = sum_rows_quarter(partS + (net ? nS_a : 0) + q, npS, nrowsS, qtr);
+            else if (q < nA + HW * HW) part = sum_rows_quarter(partW + (int64_t)net * HW * HW + (q - nA), 2 * HW * HW, nrowsW, qtr);
+            else part = sum_rows_quarter(partS + (net ? nS_a : 0) + (q - HW * HW), npS, nrowsS, qtr);
+        }
+        if (qtr > 0) l_q[qtr - 1][t] = part;
+        __syncthreads();
+        if (qtr == 0 && i < np) {
+            const float gi = ((part + l_q[0][t]) + l_q[1][t]) + l_q[2][t];
+            grad[i] = gi;
+            const float x = gi * grad_scale;
+            acc += (double)x * (double)x;
+        }
+        __syncthreads();
+    }
+    // block_sum of a 256-thread workgroup, on waves 0..3
+    acc = wave_sum(acc);
+    if (qtr == 0 && lane == 0) scratch[wv] = acc;
+    __syncthreads();
+    if (tid == 0) sumsq[blockIdx.x] = ((0.0 + scratch[0]) + scratch[1] + scratch[2]) + scratch[3];
+    if (blockIdx.x == 0 && losses != nullptr) {
+        if (wv < 3) {
+            float a = 0.f;
+            for (int b = lane; b < nrowsS; b += 64) a += loss_partials[(int64_t)b * 4 + wv];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) l_loss[wv] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float actor_loss = -l_loss[0] * inv_b;
+            const float critic_loss = l_loss[1] * inv_b;
+            const float ent_loss = l_loss[2] * inv_b;
+            losses[0] = wa * actor_loss + wc * critic_loss - we * ent_loss;
+            losses[1] = actor_loss;
+            losses[2] = critic_loss;
+            losses[3] = ent_loss;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, float* __restrict__ beta_pow, int np,
+                                                              int np_a, int ns, float grad_scale, float clip_norm, float lr,
+                                                              float b1, float b2, float eps, const double* __restrict__ sumsq,
+                                                              int npart, unsigned int* __restrict__ departed,
+                                                              uint16_t* __restrict__ packed) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npart; i += blockDim.x) acc += sumsq[i];
+    acc = block_sum(acc, scratch);
+    const float gn = (float)sqrt(acc);
+    const float scale = (clip_norm > 0.0f && clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
+    const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += stride) {
+        float gi = g[i] * grad_scale;
+        if (scale != 1.0f) gi *= scale;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam1(pi, gi, mi, vi, lr, b1, b2, eps, c1, c2);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+        g[i] = gi;
+        // ppo3w_pack_kernel, parameter-centric: W2[j + HW k] goes to one slot of each fragment orientation
+        const int net = i >= np_a ? 1 : 0;
+        const int e = (int)i - net * np_a - (HW * ns + HW);
+        if (e >= 0 && e < HW * HW) {
+            const int j = e & (HW - 1), k = e / HW;
+            const uint16_t hb = f32_to_bf16_rne(pi);
+            const int q1 = ((((k >> 4) * WV + (j >> 5)) * 64) + ((j & 31) + 32 * ((k >> 3) & 1))) * 8 + (k & 7);
+            const int q2 = ((((j >> 4) * WV + (k >> 5)) * 64) + ((k & 31) + 32 * ((j >> 3) & 1))) * 8 + (j & 7);
+            uint16_t* pk = packed + (int64_t)net * 2 * HW * HW;
+            pk[q1] = hb;
+            pk[HW * HW + q2] = hb;
+        }
+    }
+    __syncthreads();  // every thread of this workgroup has read beta_pow
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
+            beta_pow[0] *= b1;
+            beta_pow[1] *= b2;
+            __hip_atomic_store(departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ rollout
 // 32 env instances per workgroup for all T vec-steps (ppo3_rollout32_kernel at width 256): 8 waves share the 32-row tile,
 // wave w multiplies it by its 32-column block of W2 -- both nets' blocks live in registers for the whole launch.
@@ -1143,7 +1281,7 @@ static int p3w_rows_w() {
 }
 
 struct P3WLayout {
-    int64_t ntiles, off_xg, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, bytes;
+    int64_t ntiles, off_xg, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, off_tail, bytes;
     int npS, nS_a;
 };
 
@@ -1168,6 +1306,9 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     o += (int64_t)256 * 2 * HW * HW * (int64_t)sizeof(float);
     L.off_loss = o;
     o += (int64_t)P3W_ROWS_S * 4 * (int64_t)sizeof(float);
+    o = (o + 63) & ~(int64_t)63;
+    L.off_tail = o;  // W3T_BLOCKS Float64 partial sums of squares + the departure counter (zero-initialised workspace: ABI)
+    o += W3T_BLOCKS * (int64_t)sizeof(double) + 64;
     L.bytes = o + 256;
     return L;
 }
@@ -1231,9 +1372,27 @@ int32_t ppo3w_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* 
                                                  env_id_base, vec_step0, traj, s);
 }
 
+// optimise! state for the two-launch tail (ppo3w_update); NULL: plain reduce into grad_out (the caller applies)
+struct P3WTail {
+    float *params, *m, *v, *beta_pow;
+};
+
+static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
+                               const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb,
+                               void* workspace, float* grad_out, float* losses_out, bool do_pack, const P3WTail* tail,
+                               rlhip_stream_t stream);
+
 int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
                    const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb,
                    void* workspace, float* grad_out, float* losses_out, rlhip_stream_t stream) {
+    return ppo3w_grad_impl(kind, cfg, pd, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_out, losses_out, true, nullptr,
+                           stream);
+}
+
+static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
+                               const rlhip_ppo_traj* traj, const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb,
+                               void* workspace, float* grad_out, float* losses_out, bool do_pack, const P3WTail* tail,
+                               rlhip_stream_t stream) {
     const int ns = kind == 0 ? 4 : 3;
     const int64_t total = n * T;
     RLHIP_REQUIRE(total >= 1 && total <= 0x7FFFFFFFll, "n * T out of range");
@@ -1281,8 +1440,10 @@ int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd,
     g.inv_b = 1.0f / (float)bm;
     g.min_logp = (float)::log(1e-8);
     g.pk = perm_keys(seed, epoch_ctr, (uint32_t)total);
-    int32_t rc = ppo3w_pack(params, ns, g.np_a, packed, s);
-    if (rc) return rc;
+    if (do_pack) {
+        int32_t rc = ppo3w_pack(params, ns, g.np_a, packed, s);
+        if (rc) return rc;
+    }
     // one persistent workgroup per CU (the kernels hold 160 - 220 registers per lane: 2 waves per SIMD = one 8-wave workgroup):
     // a second round of workgroups would pay the ~6000-cycle prologue (weights, fragments, first tile) twice
     static int n_cu = 0;
@@ -1327,9 +1488,24 @@ int32_t ppo3w_grad(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd,
         else LAUNCH_GW(3, 1, 1);
     }
 #undef LAUNCH_GW
+    if (tail != nullptr && !RLHIP_ENV_FLAG("RLHIP_PPO3W_UNFUSED_TAIL")) {
+        double* sumsq = (double*)(ws + L.off_tail);
+        unsigned int* departed = (unsigned int*)(sumsq + W3T_BLOCKS);
+        const int nbt = (int)((np + 255) / 256 < W3T_BLOCKS ? (np + 255) / 256 : W3T_BLOCKS);  // grid_for(np, 256, 256)
+        hipLaunchKernelGGL(ppo3w_reduce_sumsq_kernel, dim3(nbt), dim3(1024), 0, s, g.partS, g.partW, g.loss_partials, nrowsS, nsr,
+                           g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b, 1.0f, sumsq);
+        hipLaunchKernelGGL(ppo3w_adam_pack_kernel, dim3(nbt), dim3(256), 0, s, tail->params, grad_out, tail->m, tail->v,
+                           tail->beta_pow, np, (int)g.np_a, ns, 1.0f, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2,
+                           cfg->adam_eps, (const double*)sumsq, nbt, departed, packed);
+        RLHIP_LAUNCH_CHECK();
+        return RLHIP_OK;
+    }
     hipLaunchKernelGGL(ppo3w_reduce_kernel, dim3((np + 63) / 64), dim3(256), 0, s, g.partS, g.partW, g.loss_partials, nrowsS,
                        nsr, g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b);
     RLHIP_LAUNCH_CHECK();
+    if (tail != nullptr)
+        return rlhip_clip_adam_f32(tail->params, grad_out, tail->m, tail->v, tail->beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr,
+                                   cfg->beta1, cfg->beta2, cfg->adam_eps, nullptr, stream);
     return RLHIP_OK;
 }
 
@@ -1338,15 +1514,17 @@ int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& p
                      uint32_t update_ctr, void* workspace, float* grad_scratch, float* losses_out, rlhip_stream_t stream) {
     const int ns = kind == 0 ? 4 : 3;
     const int64_t np = ppo3w_nparams(ns, pd.nout_a);
+    (void)np;
+    const P3WTail tail{params, m, v, beta_pow};
+    const bool fused = !RLHIP_ENV_FLAG("RLHIP_PPO3W_UNFUSED_TAIL");
+    bool packed_fresh = false;  // the previous optimiser step's tail left the bf16 images of both W2 up to date
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
         for (int32_t mb = 0; mb < cfg->n_microbatches; ++mb) {
-            int32_t rc = ppo3w_grad(kind, cfg, pd, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_scratch, losses_out,
-                                    stream);
+            int32_t rc = ppo3w_grad_impl(kind, cfg, pd, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_scratch,
+                                         losses_out, /*do_pack=*/!packed_fresh, &tail, stream);
             if (rc) return rc;
-            rc = rlhip_clip_adam_f32(params, grad_scratch, m, v, beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr, cfg->beta1,
-                                     cfg->beta2, cfg->adam_eps, nullptr, stream);
-            if (rc) return rc;
+            packed_fresh = fused;
         }
     }
     return RLHIP_OK;
