@@ -134,6 +134,30 @@ def test_grad_many_tiles_per_workgroup_matches_oracle():
         assert np.array_equal(pol.grad.cpu().numpy(), g)
 
 
+@pytest.mark.parametrize("kind,cont,n,T,nmb", [("pendulum", True, 16, 3, 1),    # 48 samples: one ragged tile, one workgroup
+                                               ("cartpole", False, 33, 4, 2),   # 66 per micro-batch: a tile with 2 valid rows
+                                               ("cartpole", False, 2048, 17, 2)])  # 272 tiles: one or two passes per workgroup
+def test_grad_edge_shapes_match_oracle(kind, cont, n, T, nmb):
+    """ragged / tiny micro-batches and a tile count just above the number of persistent workgroups (the clamped prefetch of
+    the tail passes, the odd-pass remainder of the pass pairs, a dW2 grid that is not a multiple of 8)"""
+    env, pol = _setup(kind, n, T, n_microbatches=nmb)
+    pol.rollout_()
+    pol.gae_()
+    ocfg = oracle.ppo_default(hidden=H, continuous=int(cont), layers=3, n_microbatches=nmb)
+    total, bm = n * T, (n * T) // nmb
+    mb = nmb - 1
+    pol.grad_(2, mb)
+    g = pol.grad.cpu().numpy()
+    losses = pol.losses.cpu().numpy()
+    og, ol = _oracle_grad(pol, env, cont, ocfg, 2, mb, bm, total, n, T)
+    assert np.all(np.abs(losses - ol) <= 2e-4 * (1 + np.abs(ol))), (losses, ol)
+    _check_grad(pol, g, og, env.odim, f"{kind} n={n} T={T}")
+    p0 = pol.params.clone()
+    pol.update_()
+    torch.cuda.synchronize()
+    assert torch.isfinite(pol.params).all() and not torch.equal(pol.params, p0)
+
+
 @pytest.mark.parametrize("kind", ["cartpole", "pendulum"])
 def test_update_runs_and_equals_the_microbatch_protocol(kind):
     """full iterations through the unchanged rlhip_ppo_* entry points: parameters move, stay finite, the fused update
