@@ -108,6 +108,7 @@ struct P3WArgs {
     const int32_t* action_i;
     const float* params;     // [actor | critic]
     const uint16_t* packed;  // actor W2jk | actor W2kj | critic W2jk | critic W2kj   (MFMA B-fragment order, HW * HW each)
+    const float* rec;        // [n T][8] {x0..x3, old log-prob, advantage, return, action}: ppo3w_update's record copy, or NULL
     float* xg;               // [NS][npad] the micro-batch's observations in sample order (ppo3w_gather_kernel), npad = ntiles RW
     float* sg;               // [4][npad]  old log-prob | advantage (0 on padding) | return | action (float or int bits)
     uint16_t* dz_rows;       // [ntiles * RW][HW] bf16
@@ -176,6 +177,45 @@ __global__ __launch_bounds__(256) void ppo3w_gather_kernel(P3WArgs g) {
     g.sg[(int64_t)g.npad + q] = valid ? g.adv[f] : 0.0f;
     g.sg[2 * (int64_t)g.npad + q] = g.ret[f];
     g.sg[3 * (int64_t)g.npad + q] = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
+}
+
+// optimise! walks the trajectory 16 times (4 epochs x 4 micro-batches) in shuffled order: seven 4-byte reads from seven arrays
+// per sample = seven 64-byte sectors, 58 MB of sector traffic for 3.7 MB of payload, 13 us per optimiser step.  ppo3w_update
+// therefore copies the trajectory ONCE per update into 32-byte records (coalesced, 31 MB, ~8 us); the shuffled gather then
+// touches one sector per sample.
+template <int NS, int CONT>
+__global__ __launch_bounds__(256) void ppo3w_build_rec_kernel(P3WArgs g, float* __restrict__ rec) {
+    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+    if (f >= g.total) return;
+    const uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b;
+    a.x = g.obs[((int64_t)t * NS + 0) * g.n + i];
+    a.y = g.obs[((int64_t)t * NS + 1) * g.n + i];
+    if (NS > 2) a.z = g.obs[((int64_t)t * NS + 2) * g.n + i];
+    if (NS > 3) a.w = g.obs[((int64_t)t * NS + 3) * g.n + i];
+    b.x = g.logp[f];
+    b.y = g.adv[f];
+    b.z = g.ret[f];
+    b.w = CONT ? g.action_f[f] : __int_as_float(g.action_i[f]);
+    reinterpret_cast<float4*>(rec)[2 * (int64_t)f] = a;
+    reinterpret_cast<float4*>(rec)[2 * (int64_t)f + 1] = b;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void ppo3w_gather_rec_kernel(P3WArgs g) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= (uint32_t)g.npad) return;
+    const bool valid = q < g.bm;
+    const uint32_t f = permute(g.pk, g.pos0 + (valid ? q : 0u));
+    const float4 a = reinterpret_cast<const float4*>(g.rec)[2 * (int64_t)f];
+    const float4 b = reinterpret_cast<const float4*>(g.rec)[2 * (int64_t)f + 1];
+    const float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < NS; ++k) g.xg[(int64_t)k * g.npad + q] = x[k];
+    g.sg[q] = b.x;
+    g.sg[(int64_t)g.npad + q] = valid ? b.y : 0.0f;
+    g.sg[2 * (int64_t)g.npad + q] = b.z;
+    g.sg[3 * (int64_t)g.npad + q] = b.w;
 }
 
 // lane = sample of the tile.  Every wave issues these loads (uniform instruction streams keep the compiler's vmcnt
@@ -1281,7 +1321,7 @@ static int p3w_rows_w() {
 }
 
 struct P3WLayout {
-    int64_t ntiles, off_xg, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, off_tail, bytes;
+    int64_t ntiles, off_xg, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, off_tail, off_rec, bytes;
     int npS, nS_a;
 };
 
@@ -1303,12 +1343,14 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     L.off_partS = o;
     o += (int64_t)P3W_ROWS_S * L.npS * (int64_t)sizeof(float);
     L.off_partW = o;
-    o += (int64_t)256 * 2 * HW * HW * (int64_t)sizeof(float);
+    o += (L.ntiles < 256 ? L.ntiles : 256) * 2 * (int64_t)HW * HW * (int64_t)sizeof(float);  // <= 256 dW2 sample ranges
     L.off_loss = o;
     o += (int64_t)P3W_ROWS_S * 4 * (int64_t)sizeof(float);
     o = (o + 63) & ~(int64_t)63;
     L.off_tail = o;  // W3T_BLOCKS Float64 partial sums of squares + the departure counter (zero-initialised workspace: ABI)
     o += W3T_BLOCKS * (int64_t)sizeof(double) + 64;
+    L.off_rec = o;  // ppo3w_update's 32-byte records of the whole trajectory
+    o += n * T * 8 * (int64_t)sizeof(float);
     L.bytes = o + 256;
     return L;
 }
@@ -1375,6 +1417,7 @@ int32_t ppo3w_rollout(int32_t kind, const void* env_cfg, const rlhip_env_state* 
 // optimise! state for the two-launch tail (ppo3w_update); NULL: plain reduce into grad_out (the caller applies)
 struct P3WTail {
     float *params, *m, *v, *beta_pow;
+    bool rec_ready;  // the workspace holds the record copy of THIS trajectory (ppo3w_update built it)
 };
 
 static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& pd, int64_t n, int64_t T,
@@ -1417,6 +1460,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     g.xg = (float*)(ws + L.off_xg);
     g.sg = (float*)(ws + L.off_sg);
     g.npad = (int)(L.ntiles * RW);
+    g.rec = (tail != nullptr && tail->rec_ready) ? (const float*)(ws + L.off_rec) : nullptr;
     g.dz_rows = (uint16_t*)(ws + L.off_rows);
     g.dz_frag = (uint16_t*)(ws + L.off_frag);
     g.partS = (float*)(ws + L.off_partS);
@@ -1459,8 +1503,13 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     const int nrowsS = (int)(L.ntiles < n_cu ? L.ntiles : n_cu);
     {
         const int gb = (g.npad + 255) / 256;
-        if (kind == 0) hipLaunchKernelGGL((ppo3w_gather_kernel<4, 0>), dim3(gb), dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((ppo3w_gather_kernel<3, 1>), dim3(gb), dim3(256), 0, s, g);
+        if (g.rec != nullptr) {
+            if (kind == 0) hipLaunchKernelGGL((ppo3w_gather_rec_kernel<4>), dim3(gb), dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((ppo3w_gather_rec_kernel<3>), dim3(gb), dim3(256), 0, s, g);
+        } else {
+            if (kind == 0) hipLaunchKernelGGL((ppo3w_gather_kernel<4, 0>), dim3(gb), dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((ppo3w_gather_kernel<3, 1>), dim3(gb), dim3(256), 0, s, g);
+        }
     }
     const int nsr = (int)(L.ntiles < p3w_rows_w() ? L.ntiles : p3w_rows_w());
 #define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
@@ -1515,7 +1564,30 @@ int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& p
     const int ns = kind == 0 ? 4 : 3;
     const int64_t np = ppo3w_nparams(ns, pd.nout_a);
     (void)np;
-    const P3WTail tail{params, m, v, beta_pow};
+    bool rec_ready = false;
+    if (!RLHIP_ENV_FLAG("RLHIP_PPO3W_NO_REC")) {
+        RLHIP_REQUIRE(traj->obs && traj->logp && traj->adv && traj->ret && (pd.cont ? (const void*)traj->action_f : (const void*)traj->action_i),
+                      "trajectory array is NULL");
+        const int64_t total = n * T;
+        RLHIP_REQUIRE(total >= 1 && total <= 0x7FFFFFFFll, "n * T out of range");
+        const P3WLayout L = p3w_layout(ns, pd.nout_a, cfg, n, T);
+        P3WArgs g{};
+        g.obs = traj->obs;
+        g.logp = traj->logp;
+        g.adv = traj->adv;
+        g.ret = traj->ret;
+        g.action_f = traj->action_f;
+        g.action_i = traj->action_i;
+        g.n = n;
+        g.total = (uint32_t)total;
+        float* rec = (float*)((char*)workspace + L.off_rec);
+        const int gb = (int)((total + 255) / 256);
+        hipStream_t s = as_stream(stream);
+        if (kind == 0) hipLaunchKernelGGL((ppo3w_build_rec_kernel<4, 0>), dim3(gb), dim3(256), 0, s, g, rec);
+        else hipLaunchKernelGGL((ppo3w_build_rec_kernel<3, 1>), dim3(gb), dim3(256), 0, s, g, rec);
+        rec_ready = true;
+    }
+    const P3WTail tail{params, m, v, beta_pow, rec_ready};
     const bool fused = !RLHIP_ENV_FLAG("RLHIP_PPO3W_UNFUSED_TAIL");
     bool packed_fresh = false;  // the previous optimiser step's tail left the bf16 images of both W2 up to date
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
