@@ -1005,6 +1005,20 @@ int32_t ppo3_apply_fused(const float* partials, const float* loss_partials, int 
     return RLHIP_OK;
 }
 
+// hidden = 256: the streaming kernels of ppo3w.hip (same loss, same precision contract, one operand register-resident per GEMM)
+constexpr int HWIDE = 256;
+int64_t dqn3w_workspace_bytes(int64_t ns, int64_t na, int64_t batch);
+int32_t dqn3w_pack(const float* params, int64_t ns, uint16_t* packed, rlhip_stream_t stream);
+int32_t dqn3w_plan(const float* params, const uint16_t* packed, int64_t ns, int64_t na, int32_t act, const float* obs, int64_t n,
+                   double eps, uint64_t seed, uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
+                   rlhip_stream_t stream);
+int32_t dqn3w_grad_entry(const rlhip_ring* rb, int64_t na, int32_t act, const float* params, const uint16_t* packed,
+                         const float* target_params, const uint16_t* target_packed, int64_t batch, const int64_t* idx,
+                         float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
+                         float* loss_out, float* td_out, rlhip_stream_t stream, float* apply_p, uint16_t* apply_packed,
+                         float* m, float* v, float* beta_pow, float* gn_out, float grad_scale, float clip_norm, float lr,
+                         float b1, float b2, float eps);
+
 constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
 constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
                             3 * TILE_ELEMS * sizeof(uint16_t);
@@ -1049,8 +1063,9 @@ int32_t rlhip_mlp3_init_f32(float* params, int64_t ns, int64_t h, int64_t na, ui
 int32_t rlhip_mlp3_pack_bf16(const float* params, int64_t ns, int64_t h, int64_t na, uint16_t* packed,
                              rlhip_stream_t stream) {
     RLHIP_REQUIRE(params && packed, "NULL argument");
-    RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
+    RLHIP_REQUIRE(h == H3 || h == HWIDE, "the MFMA Q-network path is built for hidden = 128 or 256");
     RLHIP_REQUIRE(ns >= 2 && ns <= 4 && na >= 1 && na <= MAXO, "obs dim must be 2..4, na <= 4");
+    if (h == HWIDE) return dqn3w_pack(params, ns, packed, stream);
     hipLaunchKernelGGL(mlp3_pack_kernel, dim3(H3 * H3 / 256), dim3(256), 0, as_stream(stream), params, (int)ns, packed);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
@@ -1061,12 +1076,13 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
                             uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
                             rlhip_stream_t stream) {
     RLHIP_REQUIRE(params && packed && obs && (actions || q_out), "NULL argument");
-    RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
+    RLHIP_REQUIRE(h == H3 || h == HWIDE, "the MFMA Q-network path is built for hidden = 128 or 256");
     RLHIP_REQUIRE((ns == 4 && na == 2) || (ns == 2 && na == 3) || (ns == 3 && na == 3),
                   "(obs dim, actions) must be (4, 2) CartPole, (2, 3) MountainCar or (3, 3) Pendulum");
     RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
     RLHIP_REQUIRE((((uintptr_t)packed) & 15) == 0, "packed weights must be 16-byte aligned");
     if (n == 0) return RLHIP_OK;
+    if (h == HWIDE) return dqn3w_plan(params, packed, ns, na, act, obs, n, eps, seed, env_id_base, step, actions, q_out, stream);
     hipStream_t s = as_stream(stream);
     dim3 grid((unsigned)((n + TR - 1) / TR));
     const bool small = n <= (1 << 15) && !RLHIP_ENV_FLAG("RLHIP_DQN3_PLAN128");
@@ -1094,6 +1110,7 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
 }
 
 int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
+    if (h == HWIDE) return dqn3w_workspace_bytes(ns, na, batch);
     // rows of partials: the larger of what the 32-sample kernel (persistent, <= D3_GRAD32_BLOCKS) and the 128-row kernel use
     int64_t nb = (batch + G32 - 1) / G32;
     if (nb > D3_GRAD32_BLOCKS) nb = D3_GRAD32_BLOCKS;
@@ -1114,14 +1131,24 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     RLHIP_REQUIRE(rb && params && packed && target_params && target_packed && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
-    RLHIP_REQUIRE(h == H3, "the MFMA Q-network path is built for hidden = 128");
+    RLHIP_REQUIRE(h == H3 || h == HWIDE, "the MFMA Q-network path is built for hidden = 128 or 256");
     RLHIP_REQUIRE((rb->obs_dim == 4 && na == 2) || (rb->obs_dim == 2 && na == 3) || (rb->obs_dim == 3 && na == 3),
                   "(obs dim, actions) must be (4, 2) CartPole, (2, 3) MountainCar or (3, 3) Pendulum");
     RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
     RLHIP_REQUIRE(batch >= 1, "empty batch");
-    RLHIP_REQUIRE(batch <= (int64_t)D3_MAX_BLOCKS * TR, "batch too large for one launch");
     RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
     RLHIP_REQUIRE(((((uintptr_t)packed) | ((uintptr_t)target_packed)) & 15) == 0, "packed weights must be 16-byte aligned");
+    if (h == HWIDE) {
+        if (apply)
+            return dqn3w_grad_entry(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta,
+                                    seed, draw_ctr, workspace, grad_out, loss_out, td_out, stream, apply->p, apply->packed,
+                                    apply->m, apply->v, apply->beta_pow, apply->gn_out, apply->grad_scale, apply->clip_norm,
+                                    apply->lr, apply->b1, apply->b2, apply->eps);
+        return dqn3w_grad_entry(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, seed,
+                                draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, nullptr, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    RLHIP_REQUIRE(batch <= (int64_t)D3_MAX_BLOCKS * TR, "batch too large for one launch");
     const int ns = (int)rb->obs_dim;
     const int64_t np = mlp3_nparams(ns, h, na);
     // measured (gradient + reduce, us; 32-sample persistent / 128-row): batch 512: 14.2 / 24.0, 4096: 19.0 / 25.3,

@@ -108,6 +108,11 @@ struct P3WArgs {
     const int32_t* action_i;
     const float* params;     // [actor | critic]
     const uint16_t* packed;  // actor W2jk | actor W2kj | critic W2jk | critic W2kj   (MFMA B-fragment order, HW * HW each)
+    const float* tparams;    // DQN: the target network's parameters (forward mode 2)
+    const uint16_t* tpacked;  // DQN: its W2 fragments (W2jk | W2kj)
+    float* xg2;              // DQN: [NS][npad] the next observations s'
+    float* td_out;           // DQN: optional |Q(s, a) - y| per sample (priority write-back)
+    float gamma, delta;      // DQN: discount, Huber threshold
     const float* rec;        // [n T][8] {x0..x3, old log-prob, advantage, return, action}: ppo3w_update's record copy, or NULL
     float* xg;               // [NS][npad] the micro-batch's observations in sample order (ppo3w_gather_kernel), npad = ntiles RW
     float* sg;               // [4][npad]  old log-prob | advantage (0 on padding) | return | action (float or int bits)
@@ -118,7 +123,7 @@ struct P3WArgs {
     float* loss_partials;    // [rows][4] {sum min(surr1, surr2), sum (ret - v)^2, sum entropy, -}
     int64_t n, np_a;
     uint32_t total, bm, pos0;
-    int ntiles, npS, nS_a, na, npad;
+    int ntiles, npS, nS_a, na, npad, wnets;  // wnets: nets per partial dW2 row (2: actor | critic; 1: the DQN learner)
     float lo, hi, wa, wc, we, inv_b, min_logp;
     PermKeys pk;
 };
@@ -222,9 +227,13 @@ __global__ __launch_bounds__(256) void ppo3w_gather_rec_kernel(P3WArgs g) {
 // bookkeeping exact across the pass loop; a wave-conditional load made it fall back to vmcnt(0), which exposed the latency
 // of the youngest prefetch instead of the oldest)
 template <int NS>
-__device__ __forceinline__ void load_x(const P3WArgs& g, int tile, int lane, float (&x)[NS]) {
+__device__ __forceinline__ void load_x_from(const float* __restrict__ xg, int npad, int tile, int lane, float (&x)[NS]) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) x[k] = g.xg[(int64_t)k * g.npad + (int64_t)tile * RW + lane];
+    for (int k = 0; k < NS; ++k) x[k] = xg[(int64_t)k * npad + (int64_t)tile * RW + lane];
+}
+template <int NS>
+__device__ __forceinline__ void load_x(const P3WArgs& g, int tile, int lane, float (&x)[NS]) {
+    load_x_from<NS>(g.xg, g.npad, tile, lane, x);
 }
 // this wave's private copy [NS][RW] of a tile's observations
 template <int NS>
@@ -273,7 +282,9 @@ constexpr size_t FWDW_LDS = (MAXO * RW + WV * MAXO * RW + SMALLWW + WV * RW * TP
 
 template <int NS, int NOUT, int ACT, int CONT, int NET>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
-    constexpr int MODE = NET == 0 ? 1 : 2;
+    // NET: 0 PPO actor, 1 PPO critic (second net of the pair), 2 DQN target network (forward only: TD target y -> sg[0]),
+    // 3 DQN online network (Huber loss on Q(s, a) - y).  Per-sample inputs sg[0..3]: PPO {old log-prob, advantage, return,
+    // action}; DQN {y, reward, terminal (0 / 1), action bits}
     W3_MARK(0, 8, NET == 0);
     extern __shared__ __attribute__((aligned(16))) char smw[];
     float* l_dq = reinterpret_cast<float*>(smw);  // [MAXO][RW] dL/d(head outputs)
@@ -287,26 +298,34 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     const int col = 32 * w + r;
     float* l_tw = l_t + w * RW * TPW;
     uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);
-    const float* pnet = g.params + (NET ? g.np_a : 0);
+    const float* pnet = NET == 2 ? g.tparams : g.params + (NET == 1 ? g.np_a : 0);
+    const float* xsrc = NET == 2 ? g.xg2 : g.xg;
     // every global load of the prologue is issued before the first wait: fragments, tile 0's inputs, the small tensors
     bf16x8 bw[KSW];
-    load_frags_w(g.packed + (NET ? 2 * HW * HW : 0), w, lane, bw);
+    load_frags_w(NET == 2 ? g.tpacked : g.packed + (NET == 1 ? 2 * HW * HW : 0), w, lane, bw);
     const int stride = gridDim.x, last = g.ntiles - 1;
     // lane = sample row: the observation feeds layer 1 straight from registers (row1 == lane); log-prob / advantage / action
     // or the return feed the loss line on wave 0.  Each is re-requested for the NEXT tile right after its last use, i.e.
     // most of a pass (~9000 cycles) ahead of its next use.
     float xr[NS], sr0, sr1 = 0.0f, sr2 = 0.0f;
-    load_x<NS>(g, blockIdx.x, lane, xr);
-    {
-        const int64_t q0 = (int64_t)blockIdx.x * RW + lane;
-        if (MODE == 1) {
+    load_x_from<NS>(xsrc, g.npad, blockIdx.x, lane, xr);
+    auto load_s = [&](int tile_) __attribute__((always_inline)) {
+        const int64_t q0 = (int64_t)tile_ * RW + lane;
+        if (NET == 0) {
             sr0 = g.sg[q0];
             sr1 = g.sg[(int64_t)g.npad + q0];
             sr2 = g.sg[3 * (int64_t)g.npad + q0];
-        } else {
+        } else if (NET == 1) {
             sr0 = g.sg[2 * (int64_t)g.npad + q0];
+        } else if (NET == 2) {
+            sr0 = g.sg[(int64_t)g.npad + q0];
+            sr1 = g.sg[2 * (int64_t)g.npad + q0];
+        } else {
+            sr0 = g.sg[q0];
+            sr2 = g.sg[3 * (int64_t)g.npad + q0];
         }
-    }
+    };
+    load_s(blockIdx.x);
     const Mlp3W m = stage_small_w2<NS, NOUT>(pnet, l_w, tid);
     __syncthreads();
     W3_MARK(0, 9, NET == 0);
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             float x[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) x[i] = xr[i];
-            load_x<NS>(g, tnext, lane, xr);
+            load_x_from<NS>(xsrc, g.npad, tnext, lane, xr);
             uint16_t* dst = l_H + row1 * PW + u0;
 #pragma unroll
             for (int h8 = 0; h8 < 4; ++h8) {
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 }
                 s_red[NOUT] += surr_min;
                 s_red[NOUT + 1] += ent;
-            } else {
+            } else if (NET == 1) {
                 const float dv = sr0 - oa[0];
                 float dvout = -2.0f * g.wc * g.inv_b * dv;
                 float sq = dv * dv;
@@ -501,18 +520,39 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 l_dq[s] = dvout;
                 s_red[0] += dvout;
                 s_red[NOUT] += sq;
+            } else if (NET == 2) {  // y = r + gamma (1 - terminal) max_a' Qt(s', a')
+                float mx = oa[0];
+#pragma unroll
+                for (int k = 1; k < NOUT; ++k) mx = fmaxf(mx, oa[k]);
+                const float cont = sr1 != 0.0f ? 0.f : 1.f;
+                g.sg[(int64_t)tile * RW + s] = sr0 + g.gamma * cont * mx;
+            } else {  // Huber(delta) on Q(s, a) - y, mean over the batch
+                const int a = __float_as_int(sr2);
+                float qa = 0.f;
+#pragma unroll
+                for (int k = 0; k < NOUT; ++k)
+                    if (k == a) qa = oa[k];
+                const float d = qa - sr0;
+                const float e = fabsf(d);
+                float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
+                float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
+                gi *= g.inv_b;
+                if (!valid) {
+                    gi = 0.f;
+                    l = 0.f;
+                }
+                if (valid && g.td_out) g.td_out[(int64_t)tile * RW + s] = e;
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float dl = (o == a) ? gi : 0.f;
+                    l_dq[o * RW + s] = dl;
+                    s_red[o] += dl;
+                }
+                s_red[NOUT] += l;
             }
         }
-        {  // the next tile's loss inputs (every wave: uniform streams; wave 0 uses them)
-            const int64_t qn = (int64_t)tnext * RW + lane;
-            if (MODE == 1) {
-                sr0 = g.sg[qn];
-                sr1 = g.sg[(int64_t)g.npad + qn];
-                sr2 = g.sg[3 * (int64_t)g.npad + qn];
-            } else {
-                sr0 = g.sg[2 * (int64_t)g.npad + qn];
-            }
-        }
+        load_s(tnext);  // the next tile's loss inputs (every wave: uniform streams; wave 0 uses them)
+        if (NET == 2) continue;  // forward only: the other waves are already in the next pass's layer 1
         __syncthreads();  // D: dL/d(head outputs) of the tile
         W3_STAMP(0, 5);
         // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32) -> db2; dz2 -> bf16: fragments straight to global,
@@ -564,9 +604,10 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     }
 #undef W3_STRIDE
     W3_MARK(0, 10, NET == 0);
+    if (NET == 2) return;
     // ---- this workgroup's partial row: b2, W3, b3 and the loss sums ----
     const int sb2 = HW * NS + HW, sW3 = sb2 + HW, sb3 = sW3 + NOUT * HW;
-    float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + (NET ? g.nS_a : 0);
+    float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + (NET == 1 ? g.nS_a : 0);
     a_db2 += __shfl_xor(a_db2, 32, 64);
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) a_dw3[o] += __shfl_xor(a_dw3[o], 32, 64);
@@ -585,8 +626,10 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             if (NET == 0) {
                 lp[0] = s_red[NOUT];
                 lp[2] = s_red[NOUT + 1];
-            } else {
+            } else if (NET == 1) {
                 lp[1] = s_red[NOUT];
+            } else {
+                lp[0] = s_red[NOUT];
             }
         }
     }
@@ -880,7 +923,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
 #undef W3_STRIDE
     W3_MARK(2, 10, net == 0);
     // D[row = k (local)][col = j]: dW2[j + HW k]
-    float* out = g.partW + ((int64_t)sr * 2 + net) * HW * HW;
+    float* out = g.partW + ((int64_t)sr * g.wnets + net) * HW * HW;
     const int j = 32 * w + r;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -894,7 +937,7 @@ __global__ __launch_bounds__(256) void ppo3w_reduce_kernel(const float* __restri
                                                            const float* __restrict__ loss_partials, int nrowsS, int nrowsW,
                                                            int npS, int nS_a, int np, int np_a, int ns,
                                                            float* __restrict__ grad, float* __restrict__ losses, float wa,
-                                                           float wc, float we, float inv_b) {
+                                                           float wc, float we, float inv_b, int wnets) {
     __shared__ float l_g[4][64];
     __shared__ float l_loss[4];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -913,7 +956,7 @@ __global__ __launch_bounds__(256) void ppo3w_reduce_kernel(const float* __restri
             nrows = nrowsS;
         } else if (q < nA + HW * HW) {
             src = partW + (int64_t)net * HW * HW + (q - nA);
-            stride = 2 * HW * HW;
+            stride = (int64_t)wnets * HW * HW;
             nrows = nrowsW;
         } else {
             src = partS + (net ? nS_a : 0) + (q - HW * HW);
@@ -937,7 +980,9 @@ __global__ __launch_bounds__(256) void ppo3w_reduce_kernel(const float* __restri
             if (lane == 0) l_loss[grp] = a;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && wa < 0.0f) {  // DQN (marked by a negative actor weight): the mean Huber loss, one number
+            losses[0] = l_loss[0] * inv_b;
+        } else if (threadIdx.x == 0) {
             const float actor_loss = -l_loss[0] * inv_b;
             const float critic_loss = l_loss[1] * inv_b;
             const float ent_loss = l_loss[2] * inv_b;
@@ -982,7 +1027,7 @@ __global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* _
                                                                   int nrowsW, int npS, int nS_a, int np, int np_a, int ns,
                                                                   float* __restrict__ grad, float* __restrict__ losses,
                                                                   float wa, float wc, float we, float inv_b, float grad_scale,
-                                                                  double* __restrict__ sumsq) {
+                                                                  double* __restrict__ sumsq, int wnets) {
     __shared__ double scratch[16];
     __shared__ float l_q[3][256];
     __shared__ float l_loss[4];
@@ -999,7 +1044,7 @@ __global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* _
             const int q = p - net * np_a;
             const int nA = HW * ns + HW;
             if (q < nA) part = sum_rows_quarter(partS + (net ? nS_a : 0) + q, npS, nrowsS, qtr);
-            else if (q < nA + HW * HW) part = sum_rows_quarter(partW + (int64_t)net * HW * HW + (q - nA), 2 * HW * HW, nrowsW, qtr);
+            else if (q < nA + HW * HW) part = sum_rows_quarter(partW + (int64_t)net * HW * HW + (q - nA), (int64_t)wnets * HW * HW, nrowsW, qtr);
             else part = sum_rows_quarter(partS + (net ? nS_a : 0) + (q - HW * HW), npS, nrowsS, qtr);
         }
         if (qtr > 0) l_q[qtr - 1][t] = part;
@@ -1026,7 +1071,9 @@ __global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* _
             if (lane == 0) l_loss[wv] = a;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && wa < 0.0f) {  // DQN (marked by a negative actor weight): the mean Huber loss, one number
+            losses[0] = l_loss[0] * inv_b;
+        } else if (tid == 0) {
             const float actor_loss = -l_loss[0] * inv_b;
             const float critic_loss = l_loss[1] * inv_b;
             const float ent_loss = l_loss[2] * inv_b;
@@ -1043,7 +1090,7 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
                                                               int np_a, int ns, float grad_scale, float clip_norm, float lr,
                                                               float b1, float b2, float eps, const double* __restrict__ sumsq,
                                                               int npart, unsigned int* __restrict__ departed,
-                                                              uint16_t* __restrict__ packed) {
+                                                              uint16_t* __restrict__ packed, float* __restrict__ gn_out) {
     __shared__ double scratch[16];
     double acc = 0.0;
     for (int i = threadIdx.x; i < npart; i += blockDim.x) acc += sumsq[i];
@@ -1076,6 +1123,7 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
     }
     __syncthreads();  // every thread of this workgroup has read beta_pow
     if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && gn_out) gn_out[0] = gn;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
@@ -1460,6 +1508,13 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     g.xg = (float*)(ws + L.off_xg);
     g.sg = (float*)(ws + L.off_sg);
     g.npad = (int)(L.ntiles * RW);
+    g.wnets = 2;
+    g.tparams = nullptr;
+    g.tpacked = nullptr;
+    g.xg2 = nullptr;
+    g.td_out = nullptr;
+    g.gamma = 0.0f;
+    g.delta = 0.0f;
     g.rec = (tail != nullptr && tail->rec_ready) ? (const float*)(ws + L.off_rec) : nullptr;
     g.dz_rows = (uint16_t*)(ws + L.off_rows);
     g.dz_frag = (uint16_t*)(ws + L.off_frag);
@@ -1542,15 +1597,15 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         unsigned int* departed = (unsigned int*)(sumsq + W3T_BLOCKS);
         const int nbt = (int)((np + 255) / 256 < W3T_BLOCKS ? (np + 255) / 256 : W3T_BLOCKS);  // grid_for(np, 256, 256)
         hipLaunchKernelGGL(ppo3w_reduce_sumsq_kernel, dim3(nbt), dim3(1024), 0, s, g.partS, g.partW, g.loss_partials, nrowsS, nsr,
-                           g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b, 1.0f, sumsq);
+                           g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b, 1.0f, sumsq, 2);
         hipLaunchKernelGGL(ppo3w_adam_pack_kernel, dim3(nbt), dim3(256), 0, s, tail->params, grad_out, tail->m, tail->v,
                            tail->beta_pow, np, (int)g.np_a, ns, 1.0f, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2,
-                           cfg->adam_eps, (const double*)sumsq, nbt, departed, packed);
+                           cfg->adam_eps, (const double*)sumsq, nbt, departed, packed, (float*)nullptr);
         RLHIP_LAUNCH_CHECK();
         return RLHIP_OK;
     }
     hipLaunchKernelGGL(ppo3w_reduce_kernel, dim3((np + 63) / 64), dim3(256), 0, s, g.partS, g.partW, g.loss_partials, nrowsS,
-                       nsr, g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b);
+                       nsr, g.npS, g.nS_a, np, (int)g.np_a, ns, grad_out, losses_out, g.wa, g.wc, g.we, g.inv_b, 2);
     RLHIP_LAUNCH_CHECK();
     if (tail != nullptr)
         return rlhip_clip_adam_f32(tail->params, grad_out, tail->m, tail->v, tail->beta_pow, np, 1.0f, cfg->max_grad_norm, cfg->lr,
@@ -1600,6 +1655,364 @@ int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& p
         }
     }
     return RLHIP_OK;
+}
+
+// ================================================================================================ DQN learner at hidden = 256
+// The same three streaming kernels serve the 3-layer Q-network ns -> 256 -> 256 -> na of the QBasedPolicy / DQN learner
+// (dqn3.hip dispatches here on h == 256; reference code replaced, loss and precision contract: see dqn3.hip):
+//   dqn3w_gather_kernel   the batch drawn (or taken from `idx`) and gathered once from the HBM ring: s, s', a, r, terminal
+//   ppo3w_fwd_kernel<..., 2>  target network on s' (forward only): y = r + gamma (1 - terminal) max_a' Qt(s', a')
+//   ppo3w_fwd_kernel<..., 3>  online network on s: Huber(delta) on Q(s, a) - y, dZ2
+//   ppo3w_bwd_kernel / ppo3w_dw2_kernel, then the reduce (or the two-launch tail with clip + Adam + bf16 re-pack)
+// and dqn3w_plan_kernel is plan!: forward + eps-greedy selection for n env instances.
+struct D3WRing {
+    const float* state;
+    const int32_t* action;
+    const float* reward;
+    const uint8_t* terminal;
+    int64_t capacity, n_env, head_sa, head_rt;
+    uint64_t total;
+    const int64_t* idx;
+    uint64_t seed;
+    uint32_t draw_ctr;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void dqn3w_gather_kernel(D3WRing rb, P3WArgs g) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= (uint32_t)g.npad) return;
+    const bool valid = q < g.bm;
+    const int64_t b = valid ? (int64_t)q : 0;
+    int64_t fj;
+    if (rb.idx) {
+        fj = rb.idx[b];
+    } else {  // the uniform BatchSampler draw of dqn3.hip: SAMPLER stream, multiply-high
+        const u32x4 wd = philox4x32_10(rb.seed, (uint32_t)b, 0, rb.draw_ctr, TAG_SAMPLER);
+        const uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
+        fj = (int64_t)__umul64hi(xr, rb.total);
+    }
+    const int64_t li = fj / rb.n_env, e = fj - li * rb.n_env;
+    const int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
+    const int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
+    const int64_t pt = (rb.head_rt + li) % rb.capacity;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        g.xg[(int64_t)k * g.npad + q] = rb.state[(ps * NS + k) * rb.n_env + e];
+        g.xg2[(int64_t)k * g.npad + q] = rb.state[(pn * NS + k) * rb.n_env + e];
+    }
+    g.sg[(int64_t)g.npad + q] = rb.reward[pt * rb.n_env + e];
+    g.sg[2 * (int64_t)g.npad + q] = rb.terminal[pt * rb.n_env + e] ? 1.0f : 0.0f;
+    g.sg[3 * (int64_t)g.npad + q] = __int_as_float(rb.action[pt * rb.n_env + e]);
+}
+
+// one net's W2 -> bf16 MFMA B fragments, both orientations (the layout of ppo3w_pack_kernel)
+__global__ __launch_bounds__(256) void mlp3w_pack_kernel(const float* __restrict__ params, int ns, uint16_t* __restrict__ pk) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= HW * HW) return;
+    const float* W2 = params + HW * ns + HW;
+    const int u = q & 7, l = (q >> 3) & 63, f = q >> 9;
+    const int t = f % WV, ks = f / WV;
+    const int col = 32 * t + (l & 31), kk = 16 * ks + 8 * (l >> 5) + u;
+    pk[q] = f32_to_bf16_rne(W2[col + HW * kk]);
+    pk[HW * HW + q] = f32_to_bf16_rne(W2[kk + HW * col]);
+}
+
+struct RegQW {
+    const float* q;
+    __device__ __forceinline__ float operator()(int k) const { return q[k]; }
+};
+
+constexpr size_t PLANW_LDS = (WV * MAXO * RW + SMALLWW + WV * RW * TPW) * sizeof(float) + (size_t)RW * PW * sizeof(uint16_t);
+
+// plan!(policy, env) of the Q-network: forward of one 64-env tile per workgroup + eps-greedy on the EXPLORE stream
+template <int NS, int NA, int ACT>
+__global__ __launch_bounds__(NTW) void dqn3w_plan_kernel(const float* __restrict__ params, const uint16_t* __restrict__ packed,
+                                                         const float* __restrict__ obs, int64_t n, double eps, uint64_t seed,
+                                                         uint32_t env_id_base, uint32_t step, int32_t* __restrict__ actions,
+                                                         float* __restrict__ q_out) {
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    float* l_part = reinterpret_cast<float*>(smw);  // [WV][MAXO][RW]
+    float* l_w = l_part + WV * MAXO * RW;           // [SMALLWW]
+    float* l_t = l_w + SMALLWW;                     // [WV][RW][TPW]
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_t + WV * RW * TPW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int col = 32 * w + r;
+    float* l_tw = l_t + w * RW * TPW;
+    bf16x8 bw[KSW];
+    load_frags_w(packed, w, lane, bw);
+    const int64_t e0 = (int64_t)blockIdx.x * RW;
+    float x[NS];
+    {
+        int64_t e = e0 + lane;
+        if (e >= n) e = n - 1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = obs[(int64_t)i * n + e];
+    }
+    const Mlp3W m = stage_small_w2<NS, NA>(params, l_w, tid);
+    __syncthreads();
+    {
+        uint16_t* dst = l_H + lane * PW + 32 * w;
+#pragma unroll
+        for (int h8 = 0; h8 < 4; ++h8) {
+            float hv[8];
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const int u = 32 * w + 8 * h8 + 4 * q4;
+                const float4 b = *reinterpret_cast<const float4*>(m.b1 + u);
+                float z[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const float4 wv = *reinterpret_cast<const float4*>(m.W1 + u + HW * i);
+                    z[0] = fmaf(wv.x, x[i], z[0]);
+                    z[1] = fmaf(wv.y, x[i], z[1]);
+                    z[2] = fmaf(wv.z, x[i], z[2]);
+                    z[3] = fmaf(wv.w, x[i], z[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+            }
+            *reinterpret_cast<uint4*>(dst + 8 * h8) = pack8_bf16(hv);
+        }
+    }
+    __syncthreads();
+    f32x16 h2[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h2[rt][q] = 0.0f;
+    {
+        const uint16_t* ap = l_H + r * PW + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PW + 16 * ks);
+                h2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], h2[rt], 0, 0, 0);
+            }
+    }
+    const float b2v = m.b2[col];
+    wave_lds_fence();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l_tw[(32 * rt + mfma_row(q, kb)) * TPW + r] = act_fwd_t<ACT>(h2[rt][q] + b2v);
+    wave_lds_fence();
+    {
+        float pa[NA];
+#pragma unroll
+        for (int o = 0; o < NA; ++o) pa[o] = 0.0f;
+        const float* hrow = l_tw + lane * TPW;
+        const float* w3p = m.W3 + NA * 32 * w;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const float4 v = *reinterpret_cast<const float4*>(hrow + 4 * c4);
+            const float hv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int o = 0; o < NA; ++o) pa[o] = fmaf(w3p[o + NA * (4 * c4 + e)], hv[e], pa[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < NA; ++o) l_part[(w * MAXO + o) * RW + lane] = pa[o];
+    }
+    __syncthreads();
+    if (tid < RW && e0 + tid < n) {
+        const int64_t e = e0 + tid;
+        float q[MAXO] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < NA; ++o) {
+            float acc = l_part[o * RW + tid];
+#pragma unroll
+            for (int ww = 1; ww < WV; ++ww) acc += l_part[(ww * MAXO + o) * RW + tid];
+            q[o] = acc + m.b3[o];
+        }
+        if (q_out)
+            for (int o = 0; o < NA; ++o) q_out[(int64_t)o * n + e] = q[o];
+        if (actions) actions[e] = eps_greedy_select1(RegQW{q}, NoMask{}, NA, eps, false, seed, env_id_base + (uint32_t)e, step);
+    }
+}
+
+struct D3WLayout {
+    int64_t ntiles, npad, off_xg, off_xg2, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, off_tail, bytes;
+    int nS;
+};
+
+static D3WLayout d3w_layout(int ns, int na, int64_t batch) {
+    D3WLayout L;
+    L.ntiles = (batch + RW - 1) / RW;
+    if (L.ntiles < 1) L.ntiles = 1;
+    L.npad = L.ntiles * RW;
+    L.nS = mlp3w_ns_small(ns, na);
+    int64_t o = 0;
+    L.off_xg = o;
+    o += 4 * L.npad * (int64_t)sizeof(float);
+    L.off_xg2 = o;
+    o += 4 * L.npad * (int64_t)sizeof(float);
+    L.off_sg = o;
+    o += 4 * L.npad * (int64_t)sizeof(float);
+    L.off_rows = o;
+    o += L.npad * HW * (int64_t)sizeof(uint16_t);
+    L.off_frag = o;
+    o += L.npad * HW * (int64_t)sizeof(uint16_t);
+    L.off_partS = o;
+    o += (L.ntiles < P3W_ROWS_S ? L.ntiles : P3W_ROWS_S) * (int64_t)L.nS * (int64_t)sizeof(float);
+    L.off_partW = o;
+    o += (L.ntiles < 256 ? L.ntiles : 256) * (int64_t)HW * HW * (int64_t)sizeof(float);
+    L.off_loss = o;
+    o += (int64_t)P3W_ROWS_S * 4 * (int64_t)sizeof(float);
+    o = (o + 63) & ~(int64_t)63;
+    L.off_tail = o;  // zero-initialised by the host (as the 128-wide workspace): Float64 partial sums + departure counter
+    o += W3T_BLOCKS * (int64_t)sizeof(double) + 64;
+    L.bytes = o + 256;
+    return L;
+}
+
+int64_t dqn3w_workspace_bytes(int64_t ns, int64_t na, int64_t batch) { return d3w_layout((int)ns, (int)na, batch).bytes; }
+
+int32_t dqn3w_pack(const float* params, int64_t ns, uint16_t* packed, rlhip_stream_t stream) {
+    hipLaunchKernelGGL(mlp3w_pack_kernel, dim3(HW * HW / 256), dim3(256), 0, as_stream(stream), params, (int)ns, packed);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t dqn3w_plan(const float* params, const uint16_t* packed, int64_t ns, int64_t na, int32_t act, const float* obs, int64_t n,
+                   double eps, uint64_t seed, uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
+                   rlhip_stream_t stream) {
+    hipStream_t s = as_stream(stream);
+    const dim3 grid((unsigned)((n + RW - 1) / RW));
+#define LAUNCH_PW(NS_, NA_, ACT_)                                                                                       \
+    do {                                                                                                                \
+        static bool done_ = false;                                                                                      \
+        int32_t rc_ = allow_lds_w(dqn3w_plan_kernel<NS_, NA_, ACT_>, PLANW_LDS, &done_);                                \
+        if (rc_) return rc_;                                                                                            \
+        hipLaunchKernelGGL((dqn3w_plan_kernel<NS_, NA_, ACT_>), grid, dim3(NTW), PLANW_LDS, s, params, packed, obs, n, eps, \
+                           seed, env_id_base, step, actions, q_out);                                                    \
+    } while (0)
+    if (ns == 4 && na == 2) { if (act == 0) LAUNCH_PW(4, 2, 0); else LAUNCH_PW(4, 2, 1); }
+    else if (ns == 2 && na == 3) { if (act == 0) LAUNCH_PW(2, 3, 0); else LAUNCH_PW(2, 3, 1); }
+    else { if (act == 0) LAUNCH_PW(3, 3, 0); else LAUNCH_PW(3, 3, 1); }
+#undef LAUNCH_PW
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+// optimise! state of rlhip_dqn3_update_f32 (NULL: gradient only)
+struct D3WApply {
+    float *p, *m, *v, *beta_pow, *gn_out;
+    uint16_t* packed;
+    float grad_scale, clip_norm, lr, b1, b2, eps;
+};
+
+int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* params, const uint16_t* packed,
+                   const float* target_params, const uint16_t* target_packed, int64_t batch, const int64_t* idx, float gamma,
+                   float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,
+                   float* td_out, rlhip_stream_t stream, const D3WApply* apply) {
+    const int ns = (int)rb->obs_dim;
+    RLHIP_REQUIRE(batch <= (int64_t)P3W_MAX_TILES * RW, "batch too large for one launch");
+    const D3WLayout L = d3w_layout(ns, (int)na, batch);
+    hipStream_t s = as_stream(stream);
+    char* ws = (char*)workspace;
+    D3WRing r;
+    r.state = (const float*)rb->state;
+    r.action = rb->action;
+    r.reward = rb->reward;
+    r.terminal = rb->terminal;
+    r.capacity = rb->capacity;
+    r.n_env = rb->n_env;
+    r.head_sa = rb->head_sa;
+    r.head_rt = rb->head_rt;
+    r.total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
+    r.idx = idx;
+    r.seed = seed;
+    r.draw_ctr = draw_ctr;
+    P3WArgs g{};
+    g.params = params;
+    g.packed = packed;
+    g.tparams = target_params;
+    g.tpacked = target_packed;
+    g.xg = (float*)(ws + L.off_xg);
+    g.xg2 = (float*)(ws + L.off_xg2);
+    g.sg = (float*)(ws + L.off_sg);
+    g.dz_rows = (uint16_t*)(ws + L.off_rows);
+    g.dz_frag = (uint16_t*)(ws + L.off_frag);
+    g.partS = (float*)(ws + L.off_partS);
+    g.partW = (float*)(ws + L.off_partW);
+    g.loss_partials = (float*)(ws + L.off_loss);
+    g.td_out = td_out;
+    const int np = (int)mlp3w_np(ns, na);
+    g.np_a = np;  // a single net: every parameter index belongs to "net 0"
+    g.bm = (uint32_t)batch;
+    g.ntiles = (int)L.ntiles;
+    g.npad = (int)L.npad;
+    g.npS = L.nS;
+    g.nS_a = L.nS;
+    g.na = (int)na;
+    g.wnets = 1;
+    g.wa = -1.0f;  // marks the DQN loss line for the reduce kernels
+    g.inv_b = 1.0f / (float)batch;
+    g.gamma = gamma;
+    g.delta = huber_delta;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        RLHIP_CHECK_HIP(hipGetDevice(&dev));
+        RLHIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu < 1) n_cu = 1;
+        if (n_cu > P3W_ROWS_S) n_cu = P3W_ROWS_S;
+    }
+    const int nrowsS = (int)(L.ntiles < n_cu ? L.ntiles : n_cu);
+    const int nsr = (int)(L.ntiles < p3w_rows_w() ? L.ntiles : p3w_rows_w());
+    const int gb = (g.npad + 255) / 256;
+#define LAUNCH_DW(NS_, NA_, ACT_)                                                                                      \
+    do {                                                                                                               \
+        static bool d0_ = false, d1_ = false, d2_ = false, d3_ = false;                                                \
+        int32_t rc_;                                                                                                   \
+        if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>, FWDW_LDS, &d0_))) return rc_;                   \
+        if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>, FWDW_LDS, &d1_))) return rc_;                   \
+        if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                              \
+        if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                              \
+        hipLaunchKernelGGL((dqn3w_gather_kernel<NS_>), dim3(gb), dim3(256), 0, s, r, g);                               \
+        hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
+        hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
+        hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                 \
+        hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 0, nsr);           \
+    } while (0)
+    if (ns == 4 && na == 2) { if (act == 0) LAUNCH_DW(4, 2, 0); else LAUNCH_DW(4, 2, 1); }
+    else if (ns == 2 && na == 3) { if (act == 0) LAUNCH_DW(2, 3, 0); else LAUNCH_DW(2, 3, 1); }
+    else { if (act == 0) LAUNCH_DW(3, 3, 0); else LAUNCH_DW(3, 3, 1); }
+#undef LAUNCH_DW
+    if (apply != nullptr) {
+        double* sumsq = (double*)(ws + L.off_tail);
+        unsigned int* departed = (unsigned int*)(sumsq + W3T_BLOCKS);
+        const int nbt = (int)((np + 255) / 256 < W3T_BLOCKS ? (np + 255) / 256 : W3T_BLOCKS);
+        hipLaunchKernelGGL(ppo3w_reduce_sumsq_kernel, dim3(nbt), dim3(1024), 0, s, g.partS, g.partW, g.loss_partials, nrowsS, nsr,
+                           g.npS, g.nS_a, np, np, ns, grad_out, loss_out, g.wa, 0.0f, 0.0f, g.inv_b, apply->grad_scale, sumsq, 1);
+        hipLaunchKernelGGL(ppo3w_adam_pack_kernel, dim3(nbt), dim3(256), 0, s, apply->p, grad_out, apply->m, apply->v,
+                           apply->beta_pow, np, np, ns, apply->grad_scale, apply->clip_norm, apply->lr, apply->b1, apply->b2,
+                           apply->eps, (const double*)sumsq, nbt, departed, apply->packed, apply->gn_out);
+    } else {
+        hipLaunchKernelGGL(ppo3w_reduce_kernel, dim3((np + 63) / 64), dim3(256), 0, s, g.partS, g.partW, g.loss_partials, nrowsS,
+                           nsr, g.npS, g.nS_a, np, np, ns, grad_out, loss_out, g.wa, 0.0f, 0.0f, g.inv_b, 1);
+    }
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+// flat-argument entry for dqn3.hip (apply_p == NULL: gradient only; otherwise the two-launch optimiser tail follows)
+int32_t dqn3w_grad_entry(const rlhip_ring* rb, int64_t na, int32_t act, const float* params, const uint16_t* packed,
+                         const float* target_params, const uint16_t* target_packed, int64_t batch, const int64_t* idx,
+                         float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
+                         float* loss_out, float* td_out, rlhip_stream_t stream, float* apply_p, uint16_t* apply_packed,
+                         float* m, float* v, float* beta_pow, float* gn_out, float grad_scale, float clip_norm, float lr,
+                         float b1, float b2, float eps) {
+    if (apply_p == nullptr)
+        return dqn3w_grad(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, seed,
+                          draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr);
+    const D3WApply ap{apply_p, m, v, beta_pow, gn_out, apply_packed, grad_scale, clip_norm, lr, b1, b2, eps};
+    return dqn3w_grad(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, seed, draw_ctr,
+                      workspace, grad_out, loss_out, td_out, stream, &ap);
 }
 
 }  // namespace rlhip
