@@ -373,6 +373,24 @@ def roofline_extras(torch, rlhip):
                              "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                              "note": "MFMA flops only; first layer, heads, loss and all bias/W1/W3 gradients run on the "
                                      "VALU in the same kernel"}
+    # the same learner step at hidden = 256 (4 -> 256 -> 256 -> 2): the streaming kernels of csrc/ppo3w.hip behind the same entry
+    # points (ring gather, target forward -> TD target, online forward -> Huber -> dZ2, dH1 -> dW1, dW2, reduce)
+    net256 = rlhip.HipApproximator(4, 256, 2, seed=5, layers=3)
+    tn256 = rlhip.TargetNetwork(net256, sync_freq=100)
+    ws256 = _dqn.dqn3_workspace(4, 256, 2, bm)
+    g256 = torch.empty_like(net256.params)
+
+    def gk256():
+        _dqn.dqn3_grad(tr2, 256, 2, 0, net256.params, net256.packed, tn256.target, tn256.target_packed, bm, 0.99, 1.0, 1, 0,
+                       workspace=ws256, grad=g256, loss=lbuf)
+
+    gk256()
+    ms256 = event_time_ms(gk256, 5, lib, s)
+    tf256 = 4 * 2 * 256 * 256 * bm / (ms256 * 1e-3) / 1e12
+    out["dqn3w_grad_mfma_hidden256"] = {"bound": "mfma", "kernel": "dqn3w_gather_kernel + ppo3w_fwd_kernel<target> + ppo3w_fwd_kernel<online> + "
+                                        "ppo3w_bwd_kernel + ppo3w_dw2_kernel + ppo3w_reduce_kernel (csrc/ppo3w.hip)", "batch": bm,
+                                        "us_per_launch": round(ms256 * 1e3, 1), "achieved": round(tf256, 1), "peak": 2500.0,
+                                        "unit": "TFLOP/s", "frac": round(tf256 / 2500.0, 4)}
     del agent, policy, learner, net, env, ws, gbuf
     # BASELINE configs[2]: 4096-way PendulumEnv + PPOPolicy (GAE lambda = 0.95), T = 128, clip 0.1, 4 x 4
     # micro-batches of 131072, actor 3 -> 256 -> (mu, log sigma), critic 3 -> 256 -> 1.  fp32 VALU: a

@@ -459,7 +459,7 @@ typedef struct {
     float* obs;                /* (obs_dim, n): current observation in, next observation out */
     float* last_obs;           /* (obs_dim, n) pre-reset observation of the step, may be NULL */
     rlhip_ring* ring;          /* host struct; its counters advance */
-    int32_t layers;            /* 2: ns -> h -> na (dqn.hip); 3: ns -> 128 -> 128 -> na (dqn3.hip, MFMA) */
+    int32_t layers;            /* 2: ns -> h -> na (dqn.hip); 3: ns -> h -> h -> na, h = 128 or 256 (dqn3.hip / ppo3w.hip, MFMA) */
     int64_t h, na;
     int32_t act;               /* 0 relu, 1 tanh */
     float* params;
@@ -492,7 +492,7 @@ int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* args, rlhip_stream_t stream)
  * Flux.destructure order W1 (h x ns) | b1 | W2 (h x h) | b2 | W3 (na x h) | b3.  The hidden x hidden layer runs
  * on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate) from a packed bf16 copy of W2 in both operand
  * orders: uint16[rlhip_mlp3_packed_elems(h)], 16-byte aligned, refreshed by rlhip_mlp3_pack_bf16 after every
- * parameter update.  hidden must be 128. */
+ * parameter update.  hidden must be 128 (dqn3.hip) or 256 (the streaming kernels of ppo3w.hip). */
 int64_t rlhip_mlp3_nparams(int64_t ns, int64_t h, int64_t na);
 int64_t rlhip_mlp3_packed_elems(int64_t h);
 int32_t rlhip_mlp3_init_f32(float* params, int64_t ns, int64_t h, int64_t na, uint64_t seed, uint32_t net_id,

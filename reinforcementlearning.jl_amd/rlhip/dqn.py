@@ -156,7 +156,7 @@ class HipApproximator:
     def __init__(self, n_in, hidden, n_out, act="relu", lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, seed=0,
                  net_id=0, device="cuda", params=None, layers=2):
         """layers = 3: Chain(Dense(n_in, h, act), Dense(h, h, act), Dense(h, n_out)) -- the blog's DQN model; the
-        hidden x hidden layer runs in bf16 on the MFMA (dqn3.hip), hidden must be 128."""
+        hidden x hidden layer runs in bf16 on the MFMA (dqn3.hip at hidden = 128, the streaming kernels of ppo3w.hip at 256)."""
         if layers not in (2, 3):
             raise ValueError("layers must be 2 or 3")
         self.n_in, self.hidden, self.n_out, self.layers = n_in, hidden, n_out, layers

@@ -159,8 +159,9 @@ def test_two_ranks_one_gpu_gradient_allreduce(rl, mode):
     assert np.quantile(d, 0.9) < 5e-3
 
 
-@pytest.mark.parametrize("layers,kind", [(2, "cartpole"), (3, "cartpole"), (2, "mountaincar"), (3, "mountaincar")])
-def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, kind):
+@pytest.mark.parametrize("layers,kind,hidden", [(2, "cartpole", 128), (3, "cartpole", 128), (2, "mountaincar", 128),
+                                                (3, "mountaincar", 128), (3, "cartpole", 256)])
+def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, kind, hidden):
     """rlhip_dqn_vec_step_f32 (one C call per vec-step) against run(): same kernels in the same order, so the
     parameters, target network, replay ring, env state and every counter must end bit-identical."""
     import rlhip
@@ -169,7 +170,7 @@ def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, ki
         n = 192
         env = rlhip.HipVecEnv(kind, n, seed=4)
         na = len(env.action_space())
-        net = rlhip.HipApproximator(env.odim, 128, na, seed=4, layers=layers)
+        net = rlhip.HipApproximator(env.odim, hidden, na, seed=4, layers=layers)
         tn = rlhip.TargetNetwork(net, sync_freq=7)
         learner = rlhip.DQNLearner(tn, batchsize=256, min_replay_history=5 * n, seed=4, max_grad_norm=1.0)
         policy = rlhip.QBasedPolicy(learner, rlhip.EpsilonGreedyExplorer(0.05, kind="exp", decay_steps=20, seed=4))
