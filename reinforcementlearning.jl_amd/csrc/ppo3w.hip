@@ -1005,23 +1005,25 @@ __global__ __launch_bounds__(256) void ppo3w_reduce_kernel(const float* __restri
 //       out) + the bf16 re-pack of both nets' W2 in both fragment orientations (parameter-centric)
 constexpr int W3T_BLOCKS = 256;
 
-// one row group (quarter) of an element's partial rows, ascending, up to 64 loads in flight
+// one row group (quarter) of an element's partial rows, ascending, 32 loads in flight per trip
 __device__ __forceinline__ float sum_rows_quarter(const float* __restrict__ src, int64_t stride, int nrows, int qtr) {
     const int per = (nrows + 3) / 4;
     const int b0 = qtr * per, b1 = min(nrows, b0 + per);
     float acc = 0.f;
-    for (int off = b0; off < b1; off += 64) {
-        float t[64];
+    for (int off = b0; off < b1; off += 32) {
+        float t[32];
 #pragma unroll
-        for (int u = 0; u < 64; ++u) t[u] = (off + u < b1) ? src[(int64_t)(off + u) * stride] : 0.0f;
+        for (int u = 0; u < 32; ++u) t[u] = (off + u < b1) ? src[(int64_t)(off + u) * stride] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 64; ++u) acc += t[u];  // x + 0.0f is exact: the padded slots change no bit
+        for (int u = 0; u < 32; ++u) acc += t[u];  // x + 0.0f is exact: the padded slots change no bit
     }
     return acc;
 }
 
 // 1024 threads: thread (t = tid & 255, qtr = tid >> 8) sums row group `qtr` of element 256 b + t + 65536 k; threads of group 0
-// (waves 0..3, i.e. exactly the 256-thread workgroup of sumsq_scaled_partial_kernel) combine and carry the squares
+// (waves 0..3, i.e. exactly the 256-thread workgroup of sumsq_scaled_partial_kernel) combine and carry the squares.  The row
+// sums of a thread's (up to W3T_EPT) elements are independent: they are all issued before the one exchange through LDS.
+constexpr int W3T_EPT = 3;
 __global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* __restrict__ partS, const float* __restrict__ partW,
                                                                   const float* __restrict__ loss_partials, int nrowsS,
                                                                   int nrowsW, int npS, int nS_a, int np, int np_a, int ns,
@@ -1029,31 +1031,45 @@ __global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* _
                                                                   float wa, float wc, float we, float inv_b, float grad_scale,
                                                                   double* __restrict__ sumsq, int wnets) {
     __shared__ double scratch[16];
-    __shared__ float l_q[3][256];
+    __shared__ float l_q[W3T_EPT][3][256];
     __shared__ float l_loss[4];
     const int tid = threadIdx.x, t = tid & 255, qtr = tid >> 8, lane = tid & 63, wv = tid >> 6;
     double acc = 0.0;
     const int64_t stride_t = (int64_t)gridDim.x * 256;
     const int nk = (int)((np + stride_t - 1) / stride_t);
-    for (int k = 0; k < nk; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * 256 + t + k * stride_t;
-        float part = 0.f;
-        if (i < np) {
-            const int p = (int)i;
-            const int net = p >= np_a ? 1 : 0;
-            const int q = p - net * np_a;
-            const int nA = HW * ns + HW;
-            if (q < nA) part = sum_rows_quarter(partS + (net ? nS_a : 0) + q, npS, nrowsS, qtr);
-            else if (q < nA + HW * HW) part = sum_rows_quarter(partW + (int64_t)net * HW * HW + (q - nA), (int64_t)wnets * HW * HW, nrowsW, qtr);
-            else part = sum_rows_quarter(partS + (net ? nS_a : 0) + (q - HW * HW), npS, nrowsS, qtr);
+    for (int k0 = 0; k0 < nk; k0 += W3T_EPT) {
+        float part[W3T_EPT];
+#pragma unroll
+        for (int u = 0; u < W3T_EPT; ++u) {
+            const int64_t i = (int64_t)blockIdx.x * 256 + t + (k0 + u) * stride_t;
+            part[u] = 0.f;
+            if (k0 + u < nk && i < np) {
+                const int p = (int)i;
+                const int net = p >= np_a ? 1 : 0;
+                const int q = p - net * np_a;
+                const int nA = HW * ns + HW;
+                if (q < nA) part[u] = sum_rows_quarter(partS + (net ? nS_a : 0) + q, npS, nrowsS, qtr);
+                else if (q < nA + HW * HW)
+                    part[u] = sum_rows_quarter(partW + (int64_t)net * HW * HW + (q - nA), (int64_t)wnets * HW * HW, nrowsW, qtr);
+                else part[u] = sum_rows_quarter(partS + (net ? nS_a : 0) + (q - HW * HW), npS, nrowsS, qtr);
+            }
         }
-        if (qtr > 0) l_q[qtr - 1][t] = part;
+        if (qtr > 0) {
+#pragma unroll
+            for (int u = 0; u < W3T_EPT; ++u) l_q[u][qtr - 1][t] = part[u];
+        }
         __syncthreads();
-        if (qtr == 0 && i < np) {
-            const float gi = ((part + l_q[0][t]) + l_q[1][t]) + l_q[2][t];
-            grad[i] = gi;
-            const float x = gi * grad_scale;
-            acc += (double)x * (double)x;
+        if (qtr == 0) {
+#pragma unroll
+            for (int u = 0; u < W3T_EPT; ++u) {  // ascending k: the accumulation order of the stand-alone kernel
+                const int64_t i = (int64_t)blockIdx.x * 256 + t + (k0 + u) * stride_t;
+                if (k0 + u < nk && i < np) {
+                    const float gi = ((part[u] + l_q[u][0][t]) + l_q[u][1][t]) + l_q[u][2][t];
+                    grad[i] = gi;
+                    const float x = gi * grad_scale;
+                    acc += (double)x * (double)x;
+                }
+            }
         }
         __syncthreads();
     }
@@ -1099,26 +1115,41 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
     const float scale = (clip_norm > 0.0f && clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
     const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += stride) {
-        float gi = g[i] * grad_scale;
-        if (scale != 1.0f) gi *= scale;
-        float pi = p[i], mi = m[i], vi = v[i];
-        adam1(pi, gi, mi, vi, lr, b1, b2, eps, c1, c2);
-        p[i] = pi;
-        m[i] = mi;
-        v[i] = vi;
-        g[i] = gi;
-        // ppo3w_pack_kernel, parameter-centric: W2[j + HW k] goes to one slot of each fragment orientation
-        const int net = i >= np_a ? 1 : 0;
-        const int e = (int)i - net * np_a - (HW * ns + HW);
-        if (e >= 0 && e < HW * HW) {
-            const int j = e & (HW - 1), k = e / HW;
-            const uint16_t hb = f32_to_bf16_rne(pi);
-            const int q1 = ((((k >> 4) * WV + (j >> 5)) * 64) + ((j & 31) + 32 * ((k >> 3) & 1))) * 8 + (k & 7);
-            const int q2 = ((((j >> 4) * WV + (k >> 5)) * 64) + ((k & 31) + 32 * ((j >> 3) & 1))) * 8 + (j & 7);
-            uint16_t* pk = packed + (int64_t)net * 2 * HW * HW;
-            pk[q1] = hb;
-            pk[HW * HW + q2] = hb;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < np; i0 += W3T_EPT * stride) {
+        float gv[W3T_EPT], pv[W3T_EPT], mv[W3T_EPT], vv[W3T_EPT];
+#pragma unroll
+        for (int u = 0; u < W3T_EPT; ++u) {  // every load of the trip before the first dependent instruction
+            const int64_t i = i0 + u * stride;
+            const bool own = i < np;
+            gv[u] = own ? g[i] : 0.f;
+            pv[u] = own ? p[i] : 0.f;
+            mv[u] = own ? m[i] : 0.f;
+            vv[u] = own ? v[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < W3T_EPT; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= np) continue;
+            float gi = gv[u] * grad_scale;
+            if (scale != 1.0f) gi *= scale;
+            float pi = pv[u], mi = mv[u], vi = vv[u];
+            adam1(pi, gi, mi, vi, lr, b1, b2, eps, c1, c2);
+            p[i] = pi;
+            m[i] = mi;
+            v[i] = vi;
+            g[i] = gi;
+            // ppo3w_pack_kernel, parameter-centric: W2[j + HW k] goes to one slot of each fragment orientation
+            const int net = i >= np_a ? 1 : 0;
+            const int e = (int)i - net * np_a - (HW * ns + HW);
+            if (e >= 0 && e < HW * HW) {
+                const int j = e & (HW - 1), k = e / HW;
+                const uint16_t hb = f32_to_bf16_rne(pi);
+                const int q1 = ((((k >> 4) * WV + (j >> 5)) * 64) + ((j & 31) + 32 * ((k >> 3) & 1))) * 8 + (k & 7);
+                const int q2 = ((((j >> 4) * WV + (k >> 5)) * 64) + ((k & 31) + 32 * ((j >> 3) & 1))) * 8 + (j & 7);
+                uint16_t* pk = packed + (int64_t)net * 2 * HW * HW;
+                pk[q1] = hb;
+                pk[HW * HW + q2] = hb;
+            }
         }
     }
     __syncthreads();  // every thread of this workgroup has read beta_pow
