@@ -108,6 +108,37 @@ def test_default_configs_match_reference_defaults():
     assert _lib.lib.rlhip_mlp2_nparams(4, 128, 2) == 4 * 128 + 128 + 2 * 128 + 2
 
 
+def test_three_layer_widths_accepted_by_the_host_side_of_the_abi():
+    """layers = 3 (MFMA hidden layer): hidden 128 (dqn3.hip / ppo3.hip) and 256 (ppo3w.hip) -- parameter counts equal the
+    oracle's, workspace sizes are positive and grow with the micro-batch, other widths and 3-action PPO heads are refused
+    (pure host logic: no device is touched)"""
+    import oracle
+
+    for kind, name, cont, ns in ((0, "cartpole", 0, 4), (1, "pendulum", 1, 3)):
+        for h in (128, 256):
+            q = _lib.PPOCfg()
+            _lib.call("rlhip_ppo_default", C.byref(q))
+            q.hidden, q.layers, q.continuous = h, 3, cont
+            np_ = _lib.lib.rlhip_ppo_nparams(kind, C.byref(q))
+            per = lambda nout: h * ns + h + h * h + h + nout * h + nout  # noqa: E731
+            assert np_ == per(2) + per(1)
+            assert np_ == oracle.ppo_nparams(oracle.KIND[name], oracle.ppo_default(hidden=h, continuous=cont, layers=3))
+            w1 = _lib.lib.rlhip_ppo_workspace_bytes(kind, C.byref(q), 256, 16)
+            w2 = _lib.lib.rlhip_ppo_workspace_bytes(kind, C.byref(q), 4096, 128)
+            assert 0 < w1 < w2 < (1 << 31)
+        q.hidden = 64
+        assert _lib.lib.rlhip_ppo_nparams(kind, C.byref(q)) < 0 and "128 or 256" in _lib.last_error()
+    q = _lib.PPOCfg()
+    _lib.call("rlhip_ppo_default", C.byref(q))
+    q.hidden, q.layers = 256, 3
+    assert _lib.lib.rlhip_ppo_nparams(2, C.byref(q)) < 0  # MountainCar: three actions, not instantiated for layers = 3
+    for h in (128, 256):
+        assert _lib.lib.rlhip_mlp3_nparams(4, h, 2) == oracle.mlp3_nparams(4, h, 2)
+        assert _lib.lib.rlhip_mlp3_packed_elems(h) == 2 * h * h
+        a, b = _lib.lib.rlhip_dqn3_workspace_bytes(4, h, 2, 512), _lib.lib.rlhip_dqn3_workspace_bytes(4, h, 2, 131072)
+        assert 0 < a < b
+
+
 def test_get_eps_host_function_golden():
     with open(os.path.join(G, "select.json")) as f:
         S = json.load(f)
