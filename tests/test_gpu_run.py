@@ -115,7 +115,10 @@ def _gpu_worker(rank, world, port, q, extra_env=None):
     n_per, T = 256, 8
     base, n = rdist.env_shard(rank, n_per)
     env = rlhip.CartPoleEnv(n, seed=77, env_id_base=base)
-    pol = rlhip.PPOPolicy(env, update_freq=T, seed=77, process_group=dist.group.WORLD)
+    import json
+
+    kw = json.loads(os.environ.get("RLHIP_TEST_PPO_KW", "{}"))
+    pol = rlhip.PPOPolicy(env, update_freq=T, seed=77, process_group=dist.group.WORLD, **kw)
     pol.rollout_()
     pol.update_()
     torch.cuda.synchronize()
@@ -126,14 +129,20 @@ def _gpu_worker(rank, world, port, q, extra_env=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["p2p_fused", "p2p_unfused", "p2p_host_loop", "library_allreduce"])
+@pytest.mark.parametrize("mode", ["p2p_fused", "p2p_unfused", "p2p_host_loop", "library_allreduce", "layers3_hidden256",
+                                  "layers3_hidden256_library"])
 def test_two_ranks_one_gpu_gradient_allreduce(rl, mode):
     """every variant of the exchange step: the fused reduce + peer exchange + clip + Adam kernel, the separate p2p
-    kernel (one C call / host loop), and the torch.distributed all-reduce fallback"""
+    kernel (one C call / host loop), and the torch.distributed all-reduce fallback; and the 3-layer 256-wide actor / critic
+    (csrc/ppo3w.hip: gradient kernels -> exchange of the 134 403-float gradient -> clip + Adam per optimiser step)"""
+    import json
+
     import torch.multiprocessing as mp
 
+    wide = {"RLHIP_TEST_PPO_KW": json.dumps({"layers": 3, "hidden": 256})}
     extra = {"p2p_fused": {}, "p2p_unfused": {"RLHIP_P2P_UNFUSED": "1"}, "p2p_host_loop": {"RLHIP_P2P_HOST_LOOP": "1"},
-             "library_allreduce": {"RLHIP_NO_P2P": "1"}}[mode]
+             "library_allreduce": {"RLHIP_NO_P2P": "1"}, "layers3_hidden256": wide,
+             "layers3_hidden256_library": dict(wide, RLHIP_NO_P2P="1")}[mode]
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -149,9 +158,11 @@ def test_two_ranks_one_gpu_gradient_allreduce(rl, mode):
     # one process owning both shards: same rollouts (global env ids), nearly the same update
     n_per, T = 256, 8
     env = rl.CartPoleEnv(2 * n_per, seed=77)
-    pol = rl.PPOPolicy(env, update_freq=T, seed=77)
+    pol = rl.PPOPolicy(env, update_freq=T, seed=77, **json.loads(extra.get("RLHIP_TEST_PPO_KW", "{}")))
     pol.rollout_()
     assert np.array_equal(pol.trajectory.obs.cpu().numpy(), np.concatenate([obs0, obs1], axis=2))
+    if "RLHIP_TEST_PPO_KW" in extra:
+        return
     # (the micro-batch composition differs -- each rank permutes its own shard -- so parameters are close,
     #  not equal: both are valid PPO updates of the same data)
     pol.update_()
