@@ -1,34 +1,39 @@
-// ppo3w.hip -- the three-layer PPO actor / critic at hidden width 256 (rlhip_ppo_cfg.layers = 3, hidden = 256):
-//     actor  ns -> 256 -> 256 -> nout_a      critic  ns -> 256 -> 256 -> 1
-// Same reference code, precision contract and oracle as ppo3.hip (bf16 operands / f32 accumulate on
+// ppo3w.hip -- the three-layer networks at hidden width 256 (layers = 3, hidden = 256), for both learners:
+//     PPO   actor  ns -> 256 -> 256 -> nout_a,  critic  ns -> 256 -> 256 -> 1      (rlhip_ppo_*: ppo3.hip dispatches here)
+//     DQN   Q-network  ns -> 256 -> 256 -> na  (online + target)                   (rlhip_dqn3_*: dqn3.hip dispatches here)
+// Same reference code, precision contract and oracle as ppo3.hip / dqn3.hip (bf16 operands / f32 accumulate on
 // v_mfma_f32_32x32x16_bf16 for the hidden x hidden layer and its two backward GEMMs, f32 master weights, everything else
-// f32; oracle/rlo_learn.c with cfg.layers = 3, hidden = 256), selected behind the unchanged rlhip_ppo_* entry points.
+// f32; oracle/rlo_learn.c, oracle/rlo_mlp3.c with h = 256), behind the unchanged entry points.
 //
-// Why a separate design.  At 128 the learner tile of ppo3.hip keeps both bf16 images of W2 (64 KB) in LDS and the whole
-// forward -> loss -> backward chain of a sample tile inside one workgroup.  At 256 one net's two images are 256 KB: they
-// do not fit the 160 KB of LDS, and the dW2 accumulators alone (256 x 256 f32) are 128 registers per lane of an 8-wave
-// workgroup.  So the width-256 learner is THREE streaming kernels per net, each with exactly one operand resident in
-// registers for the lifetime of a persistent workgroup (the scheme of dense_persist_kernel, dense_mfma.hip), 8 waves per
-// workgroup, wave w owning the 32 output columns [32 w, 32 w + 32) of its GEMM, 64-sample tiles:
-//   ppo3w_fwd_kernel  W2 fragments resident (64 VGPRs).  gather -> layer 1 (VALU) -> H1 tile in LDS -> MFMA -> H2 in
-//                     registers -> head (DPP) -> PPO loss line per sample -> dZ2 in the MFMA D layout; db2 / dW3 / db3
-//                     and the loss sums stay in registers across tiles.  dZ2 leaves as bf16 twice: row-major (A operand
-//                     of dH1 = dZ2 W2, via the consumed H1 tile: 16 B per lane) and in MFMA B-fragment order (B operand of
-//                     dW2 = H1^T dZ2: the D layout holds 4 consecutive samples of one column per register group, which
-//                     IS 8 of the 16 bytes of a fragment slot -- 512 B contiguous per store instruction, no transposition).
-//   ppo3w_bwd_kernel  W2^T fragments resident.  dZ2 rows tile -> LDS -> MFMA -> dH1 in registers; z1 is recomputed from
-//                     the gathered observation (ns <= 4 FMAs per element: cheaper than 2 bytes of HBM), dz1, db1 / dW1
-//                     in registers across tiles.
-//   ppo3w_dw2_kernel  the 256 x 256 f32 accumulator resident: a workgroup owns one half of the k range (128 x 256
-//                     outputs = 64 accumulator registers per lane) for a strided set of sample tiles; A = H1^T recomputed
-//                     into LDS in [k][sample] order, B = the dZ2 fragments straight from global memory (1 KB per wave load,
-//                     every element fetched once per workgroup).
-// Partial gradients are rows (one per persistent workgroup) summed in a fixed order by ppo3w_reduce_kernel: deterministic,
-// no atomics.  HBM traffic per sample and net: 2 x 512 B written + 2 x 512 B read (+ 512 B for the second k half) against
-// 0.39 MFLOP of MFMA work -- the path is MFMA / L2 bound, not HBM bound.
+// Why a separate design.  At 128 the learner tiles keep both bf16 images of W2 (64 KB) in LDS and the whole forward -> loss
+// -> backward chain of a sample tile inside one workgroup.  At 256 one net's two images are 256 KB: they do not fit the
+// 160 KB of LDS, and the dW2 accumulators alone (256 x 256 f32) are 128 registers per lane of an 8-wave workgroup.  So the
+// width-256 learner is THREE streaming kernels per net, each with exactly one operand resident in registers for the
+// lifetime of a persistent workgroup (the scheme of dense_persist_kernel, dense_mfma.hip), 8 waves per workgroup, wave w
+// owning the 32 output columns [32 w, 32 w + 32) of its GEMM, 64-sample tiles, ONE workgroup per CU:
+//   ppo3w_fwd_kernel  W2 fragments resident (64 VGPRs).  layer 1 (VALU, the observation in registers: lane = sample) ->
+//                     H1 tile in LDS -> MFMA -> H2 in registers -> head through a wave-private LDS transposition of the
+//                     wave's own 64 x 32 block -> loss line per sample on wave 0 (modes: PPO actor, PPO critic, DQN target
+//                     network = forward only, DQN online network) -> dZ2 in the MFMA D layout; db2 / dW3 / db3 and the loss
+//                     sums stay in registers across tiles.  dZ2 leaves as bf16 twice: row-major (A operand of dH1 = dZ2 W2;
+//                     64-byte row segments through the wave's private block) and in MFMA B-fragment order (B operand of dW2 =
+//                     H1^T dZ2: the D layout holds 4 consecutive samples of one column per register group, which IS 8 of
+//                     the 16 bytes of a fragment slot -- 512 B contiguous per store instruction, no transposition).
+//   ppo3w_bwd_kernel  W2^T fragments resident.  dZ2 rows tile -> LDS (double-buffered, register-staged two passes ahead) ->
+//                     MFMA -> dH1 in registers; z1 is recomputed from the observation (ns <= 4 FMAs per element: cheaper
+//                     than 2 bytes of HBM), dz1, db1 / dW1 in registers across tiles; one barrier per pass.
+//   ppo3w_dw2_kernel  the f32 accumulator resident: a workgroup owns one half of the k range (128 x 256 outputs = 64
+//                     registers per lane) for a strided set of sample tiles; A = H1^T recomputed into LDS in [k][sample]
+//                     order, B = the dZ2 fragments straight from global memory (two register sets in flight); the two
+//                     halves of a sample range run on ONE XCD so that its L2 serves the second read.
+// Tile inputs come from a once-per-step gather in sample order (ppo3w_gather*_kernel / dqn3w_gather_kernel) as coalesced
+// wave loads at addresses that depend on the tile index only, issued unconditionally by every wave (see load_x).
+// Partial gradients are rows (one per persistent workgroup) summed in a fixed order (ppo3w_reduce_kernel, or the two-launch
+// tail ppo3w_reduce_sumsq_kernel + ppo3w_adam_pack_kernel): deterministic, no atomics, no grid barrier.
+// Measurements, counters and the negative results: profiles/r02_ppo3w.md; DESIGN.md section 5.
 // ppo3w_rollout_kernel  the rollout of ppo3.hip's 32-env workgroups at width 256: 8 waves, BOTH nets' W2 fragments in
 //                     registers (2 x 64 VGPRs, converted from the f32 master weights at kernel entry) for all T vec-steps,
-//                     f32 H2 tiles in LDS for the heads.
+//                     f32 H2 tiles in LDS for the heads.      dqn3w_plan_kernel  plan! of the Q-network (forward + eps-greedy).
 #include "env_device.h"
 #include "ppo_common.h"
 #include "ppo_sample_device.h"
