@@ -183,3 +183,24 @@ def test_update_runs_and_equals_the_microbatch_protocol(kind):
         pol.rollout_()
         pol.update_()
     assert torch.isfinite(pol.params).all() and torch.isfinite(pol.losses).all()
+
+
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_three_layer_ppo_learns_cartpole(hidden):
+    """End-to-end sanity of the 3-layer MFMA paths (rollout kernel + learner kernels of the same policy): the mean episode
+    length of CartPole rises within a few dozen updates (tests/test_gpu_learners.py::test_ppo_learns_cartpole for layers = 3)"""
+    import rlhip
+
+    n, T = 1024, 32
+    env = rlhip.HipVecEnv("cartpole", n, seed=1)
+    pol = rlhip.PPOPolicy(env, update_freq=T, lr=1e-3, hidden=hidden, layers=3, seed=1)
+    first = None
+    for it in range(40):
+        pol.rollout_()
+        pol.update_()
+        ep_len = (n * T) / max(1.0, float(pol.trajectory.terminal.sum()))
+        if it == 0:
+            first = ep_len
+    print(f"hidden {hidden}: episode length {first:.1f} -> {ep_len:.1f}")
+    assert torch.isfinite(pol.params).all()
+    assert ep_len > 2.0 * first, f"episode length {first:.1f} -> {ep_len:.1f}"
