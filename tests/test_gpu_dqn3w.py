@@ -63,7 +63,7 @@ def test_init_and_pack_bit_exact():
 
 
 @pytest.mark.parametrize("act", [0, 1])
-@pytest.mark.parametrize("ns,na,n", [(4, 2, 4096), (4, 2, 1), (2, 3, 130), (3, 3, 257)])
+@pytest.mark.parametrize("ns,na,n", [(4, 2, 4096), (4, 2, 1), (2, 3, 130), (3, 3, 257), (4, 2, 70001)])
 def test_forward_and_plan(ns, na, n, act):
     from rlhip import dqn
 
