@@ -39,7 +39,7 @@ def test_bf16_round_matches_torch():
 
 
 @pytest.mark.parametrize("act", [0, 1])
-@pytest.mark.parametrize("ns,h,na", [(4, 128, 2), (2, 32, 3)])
+@pytest.mark.parametrize("ns,h,na", [(4, 128, 2), (2, 32, 3), (3, 256, 3)])
 def test_forward_matches_torch(ns, h, na, act):
     p = oracle.mlp3_init(ns, h, na, 3, 0)
     assert p.size == oracle.mlp3_nparams(ns, h, na) == h * ns + h + h * h + h + na * h + na
@@ -52,9 +52,10 @@ def test_forward_matches_torch(ns, h, na, act):
     np.testing.assert_allclose(q, ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("h", [128, 256])
 @pytest.mark.parametrize("act", [0, 1])
-def test_dqn3_loss_and_gradient_match_autograd(act):
-    ns, h, na, b = 4, 128, 2, 96
+def test_dqn3_loss_and_gradient_match_autograd(act, h):
+    ns, na, b = 4, 2, 96
     rng = np.random.default_rng(2)
     p = oracle.mlp3_init(ns, h, na, 5, 0)
     tp = oracle.mlp3_init(ns, h, na, 6, 0)
@@ -80,12 +81,14 @@ def test_dqn3_loss_and_gradient_match_autograd(act):
     np.testing.assert_allclose(q, qt.detach().numpy(), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("h", [128, 256])
 @pytest.mark.parametrize("continuous,kind", [(False, "cartpole"), (True, "pendulum")])
-def test_ppo_loss_gradient_with_three_layer_nets_matches_autograd(continuous, kind):
-    """oracle PPO loss / gradient with cfg.layers = 3 (actor and critic ns -> 128 -> 128 -> nout, bf16 hidden layer)
-    against torch autograd with straight-through bf16 roundings (tolerance: the oracle also rounds dz2 to bf16)."""
+def test_ppo_loss_gradient_with_three_layer_nets_matches_autograd(continuous, kind, h):
+    """oracle PPO loss / gradient with cfg.layers = 3 (actor and critic ns -> h -> h -> nout, bf16 hidden layer; h = 128 and
+    the 256 of csrc/ppo3w.hip) against torch autograd with straight-through bf16 roundings (tolerance: the oracle also rounds
+    dz2 to bf16)."""
     ns = 4 if kind == "cartpole" else 3
-    na, h, b = (2, 128, 200) if not continuous else (1, 128, 200)
+    na, b = (2, 200) if not continuous else (1, 200)
     nout_a = 2 * na if continuous else na
     cfg = oracle.ppo_default(hidden=h, continuous=int(continuous), layers=3)
     rng = np.random.default_rng(7)
