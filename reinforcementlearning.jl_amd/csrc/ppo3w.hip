@@ -122,7 +122,8 @@ struct P3WArgs {
     float* xg;               // [NS][npad] the micro-batch's observations in sample order (ppo3w_gather_kernel), npad = ntiles RW
     float* sg;               // [4][npad]  old log-prob | advantage (0 on padding) | return | action (float or int bits)
     uint16_t* dz_rows;       // [ntiles * RW][HW] bf16
-    uint16_t* dz_frag;       // [ntiles][RW / 16][WV][64 lanes][8] bf16
+    uint16_t* dz_frag;       // [nets][ntiles][RW / 16][WV][64 lanes][8] bf16 (PPO: one buffer per net, frag_stride apart)
+    int64_t frag_stride;     // elements between the nets' fragment buffers (0: one net)
     float* partS;            // [rows][npS]: partial gradients of the small tensors, [actor small | critic small]
     float* partW;            // [rows][2][HW * HW]: partial dW2 (Flux order W2[j + HW k])
     float* loss_partials;    // [rows][4] {sum min(surr1, surr2), sum (ret - v)^2, sum entropy, -}
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 v2.x = pack2_bf16(h2[rt][4 * gq + 0], h2[rt][4 * gq + 1]);
                 v2.y = pack2_bf16(h2[rt][4 * gq + 2], h2[rt][4 * gq + 3]);
                 const int64_t slot = (((int64_t)tile * (RW / 16) + 2 * rt + (gq >> 1)) * WV + w) * 64 + 32 * (gq & 1) + r;
-                *reinterpret_cast<uint2*>(g.dz_frag + slot * 8 + 4 * kb) = v2;
+                *reinterpret_cast<uint2*>(g.dz_frag + (NET == 1 ? g.frag_stride : 0) + slot * 8 + 4 * kb) = v2;
             }
         }
         W3_STAMP(0, 6);
@@ -817,7 +818,11 @@ __device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_fr
 }
 
 template <int NS, int ACT>
-__global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, int nsr) {
+// net < 0: one launch for BOTH nets of a PPO pair, net = blockIdx.y (half as many sample ranges per net, hence half as many
+// partial rows for the reduction: 64 instead of 128 MB per optimiser step, and twice as many passes per prologue)
+__global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_arg, int nsr) {
+    const int net = net_arg < 0 ? (int)blockIdx.y : net_arg;
+    const uint16_t* const dzf = g.dz_frag + (net ? g.frag_stride : 0);
     extern __shared__ __attribute__((aligned(16))) char smw[];
     float* l_x = reinterpret_cast<float*>(smw);  // [2][WV][4][RW]: wave-private copies of the tile's observations
     float* l_w = l_x + 2 * WV * 4 * RW;          // W1 | b1
@@ -863,9 +868,9 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
 #pragma unroll
         for (int i = 0; i < NWL; ++i) wv[i] = (tid + NTW * i < HW * NS + HW) ? pnet[tid + NTW * i] : 0.0f;
         load_x<NS>(g, min(sr + nsr, last), lane, xr[0]);
-        load_dz_frags(g.dz_frag, min(sr, last), w, lane, bq[0]);
+        load_dz_frags(dzf, min(sr, last), w, lane, bq[0]);
         load_x<NS>(g, min(sr + 2 * nsr, last), lane, xr[1]);
-        load_dz_frags(g.dz_frag, min(sr + nsr, last), w, lane, bq[1]);
+        load_dz_frags(dzf, min(sr + nsr, last), w, lane, bq[1]);
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
             if (tid + NTW * i < HW * NS + HW) l_w[tid + NTW * i] = wv[i];
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net, i
                 acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[p][ks], acc[kt], 0, 0, 0);
             }
         W3_STAMP(2, 3);
-        load_dz_frags(g.dz_frag, min(tile + 2 * nsr, last), w, lane, bq[p]);
+        load_dz_frags(dzf, min(tile + 2 * nsr, last), w, lane, bq[p]);
         W3_STAMP(2, 4);
     };
     const int npass = (g.ntiles - sr + nsr - 1) / nsr;
@@ -1423,7 +1428,7 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     L.off_rows = o;
     o += L.ntiles * RW * HW * (int64_t)sizeof(uint16_t);
     L.off_frag = o;
-    o += L.ntiles * RW * HW * (int64_t)sizeof(uint16_t);
+    o += 2 * L.ntiles * RW * HW * (int64_t)sizeof(uint16_t);  // one fragment buffer per net (the dW2 launch reads both)
     L.off_partS = o;
     o += (int64_t)P3W_ROWS_S * L.npS * (int64_t)sizeof(float);
     L.off_partW = o;
@@ -1554,6 +1559,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     g.rec = (tail != nullptr && tail->rec_ready) ? (const float*)(ws + L.off_rec) : nullptr;
     g.dz_rows = (uint16_t*)(ws + L.off_rows);
     g.dz_frag = (uint16_t*)(ws + L.off_frag);
+    g.frag_stride = L.ntiles * RW * HW;
     g.partS = (float*)(ws + L.off_partS);
     g.partW = (float*)(ws + L.off_partW);
     g.loss_partials = (float*)(ws + L.off_loss);
@@ -1602,7 +1608,10 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
             else hipLaunchKernelGGL((ppo3w_gather_kernel<3, 1>), dim3(gb), dim3(256), 0, s, g);
         }
     }
-    const int nsr = (int)(L.ntiles < p3w_rows_w() ? L.ntiles : p3w_rows_w());
+    // the dW2 launch covers both nets (blockIdx.y): 2 k halves x nsr sample ranges x 2 nets = one workgroup per CU at nsr = 64
+    const bool merged = !RLHIP_ENV_FLAG("RLHIP_PPO3W_SPLIT_DW2");
+    const int rows_w = merged ? (p3w_rows_w() + 1) / 2 : p3w_rows_w();
+    const int nsr = (int)(L.ntiles < rows_w ? L.ntiles : rows_w);
 #define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
     do {                                                                                                              \
         static bool d0_ = false, d1_ = false, d2_ = false, d3_ = false;                                               \
@@ -1613,10 +1622,11 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                             \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                \
-        hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 0, nsr);          \
+        if (!merged) hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 0, nsr); \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 1);                \
-        hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 1, nsr);          \
+        if (merged) hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr, 2), dim3(NTW), DW2W_LDS, s, g, -1, nsr); \
+        else hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 1, nsr);     \
     } while (0)
     if (kind == 0) {
         RLHIP_REQUIRE(!pd.cont, "layers = 3: CartPole uses the categorical head");
@@ -1982,6 +1992,7 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
     g.partW = (float*)(ws + L.off_partW);
     g.loss_partials = (float*)(ws + L.off_loss);
     g.td_out = td_out;
+    g.frag_stride = 0;
     const int np = (int)mlp3w_np(ns, na);
     g.np_a = np;  // a single net: every parameter index belongs to "net 0"
     g.bm = (uint32_t)batch;
