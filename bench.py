@@ -487,8 +487,9 @@ def roofline_extras(torch, rlhip):
         "n_params": ppol.np, "rollout_us": round(ms_r * 1e3, 1), "update_us": round(ms_u * 1e3, 1),
         "per_microbatch_us": round(per_step_us, 1), "microbatch": bm3,
         "kernels": "ppo3w_build_rec_kernel once per update; per optimiser step: ppo3w_gather_rec_kernel; per net ppo3w_fwd_kernel + "
-                   "ppo3w_bwd_kernel + ppo3w_dw2_kernel (csrc/ppo3w.hip: one operand register-resident per kernel, persistent "
-                   "8-wave workgroups, one per CU); ppo3w_reduce_sumsq_kernel; ppo3w_adam_pack_kernel; rollout: ppo3w_rollout_kernel",
+                   "ppo3w_bwd_kernel; ppo3w_dw2_kernel (both nets, one launch) (csrc/ppo3w.hip: one operand register-resident per "
+                   "kernel, persistent 8-wave workgroups, one per CU); ppo3w_reduce_sumsq_kernel; ppo3w_adam_pack_kernel; rollout: "
+                   "ppo3w_rollout_kernel",
         "learner_mfma_tflops": round(mf / (per_step_us * 1e-6) / 1e12, 1),
         "frac_of_bf16_peak": round(mf / (per_step_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
         "final_loss": float(ppol.losses[0])}
