@@ -1532,6 +1532,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     RLHIP_REQUIRE(bm >= 1, "empty micro-batch");
     const P3WLayout L = p3w_layout(ns, pd.nout_a, cfg, n, T);
     RLHIP_REQUIRE(L.ntiles <= P3W_MAX_TILES, "micro-batch too large for one launch");
+    RLHIP_REQUIRE(cfg->actor_loss_weight >= 0.0f, "actor_loss_weight must be >= 0 (a negative value marks the DQN loss line)");
     hipStream_t s = as_stream(stream);
     char* ws = (char*)workspace;
     P3WArgs g;
