@@ -7,25 +7,14 @@
 // then clip_by_global_norm! (RLCore/utils/basic.jl:19-29) and Flux.Optimise.update! with Adam
 // (RLCore/policies/learners/flux_approximator.jl:46).
 //
-// ppo_grad_kernel (256 threads = 4 waves, persistent over 64-sample tiles):
-//   prologue  every hidden unit's weights go to LDS as one 32-byte record per net
-//             {W1[j,0..3], b1[j], W2[0..2,j]} -- phase 1 reads them with two broadcast ds_read_b128 per
-//             unit per net (conflict-free: all lanes read one address) instead of 13 dependent scalar
-//             loads (the first version's bottleneck: 47.8 us/launch, profiles/r01_a_*).
-//   phase 0   64 threads fetch the tile's samples f = perm(pos) (keyed bijection, no index array) from
-//             the trajectory into registers ONE TILE AHEAD -- the HBM/L2 latency of the scattered gather
-//             hides under phases 1-2 of the current tile -- and publish them to a double-buffered LDS tile.
-//   phase 1a  lane = sample, wave w walks its quarter of the hidden units; partial output sums -> LDS.
-//   phase 1b  wave 0 finishes logits / value, evaluates the loss terms and dL/d(outputs) per sample.
-//   phase 2   lane = hidden unit j (weights in registers); the 64 samples stream from LDS as two
-//             broadcast b128 reads each; weight gradients accumulate in registers: no atomics, no
-//             cross-lane reductions, fixed summation order.
-//   epilogue  each workgroup writes one partial gradient (parameter layout); summation across
-//             workgroups is done in a fixed order by reduce_apply_kernel / reduce_partials_kernel, so
-//             the result is run-to-run deterministic and replicas on different GPUs stay bit-identical.
+// ppo_grad_kernel: teams of 8 waves walk 64-sample tiles (tile code and its phase description: ppo_grad_tile.h) and
+// write one partial gradient row per workgroup; reduce_apply_kernel sums the rows in a fixed order, takes the global
+// norm behind a grid barrier (or in the last-arriving workgroup), clips, runs Adam and refreshes the unit records.
+// The whole update (all n_epochs x n_microbatches steps) as ONE persistent launch: ppo_persist.hip (same tile code,
+// same summation order, hence the same bits); this file's two launches per step are its fallback and the sharded path.
 // Roofline: VALU-f32 bound by construction (K = ns <= 4 and N = nout <= 3 are far below an MFMA tile);
 // algorithmic work 6*h*((ns+nout)+(ns+1)) flop per sample.
-#include "ppo_common.h"
+#include "ppo_grad_tile.h"
 
 #include <stdlib.h>
 
@@ -36,521 +25,76 @@ extern "C" int64_t rlhip_ppo_nparams(int32_t kind, const rlhip_ppo_cfg* c);
 
 namespace rlhip {
 
-constexpr float LOG2PI_F = 1.8378770664093453f;  // log(2f0 * pi) as Float32 (RLCore/utils/distributions.jl:9)
-constexpr int TILE = 64;
-constexpr int MAX_GRAD_BLOCKS = 512;
-constexpr int NW = 8;     // waves per workgroup (per 64-sample tile)
-constexpr int GMAXO = 3;  // actor outputs handled by the fused gradient kernel (na <= 3, or (mu, log sigma))
-
-struct GradArgs {
-    const float* obs;
-    const float* logp;
-    const float* adv;
-    const float* ret;
-    const float* action_f;
-    const int32_t* action_i;
-    const float* params;
-    const float* packed;   // unit records: actor [h][8] | critic [h][8] | {b2a0, b2a1, b2a2, b2c}
-    float* partials;       // [nb][np]
-    float* loss_partials;  // [nb][4]
-    int64_t n;
-    uint32_t total, bm, pos0;
-    int num_tiles, np;
-    PolicyDesc pd;
-    float lo, hi, wa, wc, we, inv_b, min_logp;
-    PermKeys pk;           // epoch permutation keys, evaluated on the host (2 Philox blocks) ...
-    const uint32_t* ctr;   // ... or, when non-NULL, in the kernel from the device update counter ctr[1]:
-    uint64_t seed;         //     epoch = epoch_local + ctr[1] * n_epochs  (HIP-graph replayable)
-    uint32_t epoch_local, n_epochs;
-    long long* dbg;  // optional per-block phase timestamps (s_memtime), 8 per block; NULL in production
-};
-
-// Phase timestamps are a compile-time option (-DRLHIP_GRAD_TIMING).  They are kept in (scalar) registers and stored at
-// the very end: a global store at kernel entry makes every later uniform global load "possibly clobbered", which turns
-// the s_load_dwordx8 record fetches of phase 1 into per-lane global_load_dwordx4 (measured: 22 -> 29.6 us per launch,
-// all of it in phase 1a).
-#ifdef RLHIP_GRAD_TIMING
-#define DBG_DECL long long dbg_t[6] = {0, 0, 0, 0, 0, 0}
-#define DBG_STAMP(k) dbg_t[(k)] = __builtin_amdgcn_s_memtime()
-#define DBG_FLUSH()                                                                          \
-    do {                                                                                     \
-        if (g.dbg && threadIdx.x == 0) {                                                     \
-            _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) g.dbg[(int64_t)blockIdx.x * 8 + k_] = dbg_t[k_]; \
-        }                                                                                    \
-    } while (0)
-#else
-#define DBG_DECL \
-    do {         \
-    } while (0)
-#define DBG_STAMP(k) \
-    do {             \
-    } while (0)
-#define DBG_FLUSH() \
-    do {            \
-    } while (0)
-#endif
-
-struct TileRegs {  // one sample's trajectory entries, held in registers one tile ahead
-    float4 x;
-    float4 misc;  // {logp_old, adv, ret, action (int bits or float)}
-};
-
-template <int NS>
-__device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKeys& pk, int tile, int s) {
-    uint32_t q = (uint32_t)tile * TILE + (uint32_t)s;
-    bool valid = q < g.bm;
-    uint32_t f = permute(pk, g.pos0 + (valid ? q : 0u));
-    uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
-    TileRegs r;
-    float xv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NS; ++k) xv[k] = g.obs[((int64_t)t * NS + k) * g.n + i];
-    r.x = make_float4(xv[0], xv[1], xv[2], xv[3]);
-    float a = g.pd.cont ? g.action_f[f] : __int_as_float(g.action_i[f]);
-    r.misc = make_float4(g.logp[f], valid ? g.adv[f] : 0.0f, g.ret[f], a);
-    return r;
-}
-
-// LDS of one team of 8 waves: x[2][TILE] | misc[2][TILE] | part[8][TILE] | dL[TILE] (float4) | comb[14][256] + 16 scalars (float)
-__host__ __device__ constexpr size_t grad_team_smem_bytes() {
-    return sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE) + sizeof(float) * (14 * 256 + 16);
-}
-
-// NO = 2: the actor has at most two outputs (two actions, or (mu, log sigma)) -- the third output's FMAs (zero weights,
-// zero dL/dout: exact no-ops) are not issued; NO = 3: three actions.
 // NT: teams of 8 waves per workgroup.  NT = 2: a 1024-thread workgroup walks TWO 64-sample tiles side by side (same code,
 // same barriers, its own LDS carve per team) and folds both into ONE partial row: half the rows to write at the end of
 // the launch (512 rows x 13 KB cost 2.7 us of an 18.8 us launch: the launch cannot retire before they are flushed) and
 // half the rows for the optimiser tail to read back.  The two-workgroups-per-CU occupancy of NT = 1 is kept (16 waves).
+// Tile code: ppo_grad_tile.h.  Epilogue: each workgroup writes one partial gradient (parameter layout); summation across
+// workgroups is done in a fixed order by reduce_apply_kernel, so the result is run-to-run deterministic and replicas on
+// different GPUs stay bit-identical.
 template <int NS, int ACT, int NO, int NT>
 __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DBG_DECL;
-    DBG_STAMP(0);
     const int h = g.pd.h;
-    const int gtid = threadIdx.x;
-    const int team = NT > 1 ? __builtin_amdgcn_readfirstlane(gtid >> 9) : 0;
-    // LDS carve per team (all 16-byte aligned): x[2][TILE] | misc[2][TILE] | part[8][TILE] | dL[TILE] | comb[14][256]
-    char* tsm = smem + (size_t)team * grad_team_smem_bytes();
-    float4* l_x = reinterpret_cast<float4*>(tsm);            // [2][TILE]
-    float4* l_misc = l_x + 2 * TILE;                         // [2][TILE]
-    float4* l_part = l_misc + 2 * TILE;                      // [8][TILE]  {a0, a1, a2, v} partial sums
-    float4* l_dL = l_part + NW * TILE;                       // [TILE]     {dl0, dl1, dl2, dv}
-    float* l_comb = reinterpret_cast<float*>(l_dL + TILE);   // [14][256] second-half accumulators
-
-    const int tid = gtid & 511;  // thread within the team
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TeamIds id = team_ids<NT>(h);
+    const TeamLds L = team_lds(smem, id.team);
     const int nout = g.pd.nout_a;
-    const int hq = h / NW;               // hidden units per wave in phase 1a
-    const int uidx = tid & 255;          // phase 2: hidden unit of this thread
-    const int shalf = w >> 2;            // phase 2: which half of the tile's samples (0: 0..31, 1: 32..63)
-    const float* __restrict__ recA = (const float*)__builtin_assume_aligned(g.packed, 32);
-    const float* __restrict__ recC = recA + 8 * h;
-    const float* __restrict__ tailb = recC + 8 * h;
+    const float* __restrict__ rec = (const float*)__builtin_assume_aligned(g.packed, 64);
+    const float* __restrict__ tailb = rec + REC * h;
 
     // ---- prologue: the first tile's scattered gather is issued first; this thread's unit (phase 2)
     // comes from its two records ----
     const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
-    int tile = blockIdx.x * NT + team;
+    const int tile0 = blockIdx.x * NT + id.team;
     TileRegs first;
-    const bool first_loader = tid < TILE && tile < g.num_tiles;
-    if (first_loader) first = fetch_sample<NS>(g, pk, tile, tid);
-    const bool owner = uidx < h;
-    const int jown = owner ? uidx : 0;
-    const float4 oa0 = *reinterpret_cast<const float4*>(recA + 8 * jown);
-    const float4 oa1 = *reinterpret_cast<const float4*>(recA + 8 * jown + 4);
-    const float4 oc0 = *reinterpret_cast<const float4*>(recC + 8 * jown);
-    const float4 oc1 = *reinterpret_cast<const float4*>(recC + 8 * jown + 4);
-    const float rw1a[4] = {oa0.x, oa0.y, oa0.z, oa0.w}, rw1c[4] = {oc0.x, oc0.y, oc0.z, oc0.w};
-    const float rw2a[GMAXO] = {oa1.y, oa1.z, oa1.w};
-    const float rb1a = oa1.x, rb1c = oc1.x, rw2c = oc1.y;
-    float gw1a[4] = {0.f, 0.f, 0.f, 0.f}, gw1c[4] = {0.f, 0.f, 0.f, 0.f}, gw2a[GMAXO] = {0.f, 0.f, 0.f};
-    float gb1a = 0.f, gb1c = 0.f, gw2c = 0.f;
-    // wave-0 per-sample-lane accumulators: output-bias gradients and loss sums
-    float gb2a[GMAXO] = {0.f, 0.f, 0.f};
-    float gb2c = 0.f, s_actor = 0.f, s_critic = 0.f, s_ent = 0.f;
-    const float b2a0 = tailb[0], b2a1 = tailb[1], b2a2 = tailb[2], b2cv = tailb[3];
+    const bool first_loader = id.tid < TILE && tile0 < g.num_tiles;
+    if (first_loader) first = fetch_sample<NS>(g, pk, g.pos0, tile0, id.tid);
+    const UnitW W = unit_from_record(rec + REC * (id.owner ? id.uidx : 0));
+    UnitG G;
+    G.zero();
+    HeadG Hd;
+    Hd.zero();
+    const float b2[4] = {tailb[0], tailb[1], tailb[2], tailb[3]};
 
-    int buf = 0;
-    if (first_loader) {
-        l_x[tid] = first.x;
-        l_misc[tid] = first.misc;
-    } else if (NT > 1 && tid < TILE) {  // a team without a tile: finite operands, so that its (all-zero-weight) sums stay exact zeros
-        l_x[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        l_misc[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        l_x[TILE + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        l_misc[TILE + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    DBG_STAMP(1);
-
-    // both teams run the same number of trips (the barriers are workgroup-wide); a team without a tile left computes on
-    // stale LDS with all-invalid samples: dL = 0, nothing is accumulated
-    for (int base = blockIdx.x * NT; base < g.num_tiles; base += gridDim.x * NT, tile += gridDim.x * NT) {
-        const int next = tile + gridDim.x * NT;
-        const float4* cx = l_x + buf * TILE;
-        const float4* cm = l_misc + buf * TILE;
-        // ---- phase 0 (next tile): wave 1 issues the gather now, publishes it after phase 2 ----
-        TileRegs pre;
-        const bool prefetcher = (w == 1) && (next < g.num_tiles);
-        if (prefetcher) pre = fetch_sample<NS>(g, pk, next, lane);
-        // ---- phase 1a: lane = sample, wave w walks hidden units [w*hq, (w+1)*hq) ----
-        {
-            const float4 xv = cx[lane];
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accv = 0.f;
-#pragma unroll 8
-            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
-                // wave-uniform addresses: these become s_load_dwordx8 (SGPR operands of the FMAs below)
-                const float* pa_ = recA + 8 * jj;
-                const float* pc_ = recC + 8 * jj;
-                const float4 wa_ = make_float4(pa_[0], pa_[1], pa_[2], pa_[3]);
-                const float4 ra_ = make_float4(pa_[4], pa_[5], pa_[6], pa_[7]);
-                const float4 wc_ = make_float4(pc_[0], pc_[1], pc_[2], pc_[3]);
-                const float4 rc_ = make_float4(pc_[4], pc_[5], pc_[6], pc_[7]);
-                float za = ra_.x, zc = rc_.x;
-                za = fmaf(wa_.x, xv.x, za);
-                zc = fmaf(wc_.x, xv.x, zc);
-                if (NS > 1) {
-                    za = fmaf(wa_.y, xv.y, za);
-                    zc = fmaf(wc_.y, xv.y, zc);
-                }
-                if (NS > 2) {
-                    za = fmaf(wa_.z, xv.z, za);
-                    zc = fmaf(wc_.z, xv.z, zc);
-                }
-                if (NS > 3) {
-                    za = fmaf(wa_.w, xv.w, za);
-                    zc = fmaf(wc_.w, xv.w, zc);
-                }
-                const float ha = act_fwd_t<ACT>(za), hc = act_fwd_t<ACT>(zc);
-                acc0 = fmaf(ra_.y, ha, acc0);
-                acc1 = fmaf(ra_.z, ha, acc1);
-                if (NO > 2) acc2 = fmaf(ra_.w, ha, acc2);
-                accv = fmaf(rc_.y, hc, accv);
-            }
-            l_part[w * TILE + lane] = make_float4(acc0, acc1, acc2, accv);
-        }
-        __syncthreads();
-        DBG_STAMP(2);
-        // ---- phase 1b: wave 0 finishes the forward, evaluates the loss and dL/d(outputs) ----
-        if (w == 0) {
-            const int s = lane;
-            const bool valid = ((uint32_t)tile * TILE + (uint32_t)s) < g.bm;
-            float4 ps = l_part[s];
-#pragma unroll
-            for (int q = 1; q < NW; ++q) {  // fixed summation order over the NW waves' partial sums
-                const float4 pq = l_part[q * TILE + s];
-                ps.x += pq.x;
-                ps.y += pq.y;
-                ps.z += pq.z;
-                ps.w += pq.w;
-            }
-            float oa[GMAXO], dl[GMAXO] = {0.f, 0.f, 0.f};
-            oa[0] = ps.x + b2a0;
-            oa[1] = ps.y + b2a1;
-            oa[2] = ps.z + b2a2;
-            const float v = ps.w + b2cv;
-            const float4 mi = cm[s];
-            const float lp_old = fmaxf(mi.x, g.min_logp);  // clamp!(log_p, log(1e-8), Inf)
-            const float A = mi.y;
-            float lp_new, ent;
-            if (!g.pd.cont) {
-                const int na = g.pd.na;
-                float mx = oa[0];
-                for (int k = 1; k < na; ++k) mx = fmaxf(mx, oa[k]);
-                float se = 0.f;
-                for (int k = 0; k < na; ++k) se += expf(oa[k] - mx);
-                const float lse = logf(se);
-                float logp[GMAXO], pr[GMAXO];
-                ent = 0.f;
-                for (int k = 0; k < na; ++k) {
-                    logp[k] = (oa[k] - mx) - lse;
-                    pr[k] = expf(logp[k]);
-                    ent -= pr[k] * logp[k];
-                }
-                const int a = __float_as_int(mi.w);
-                lp_new = 0.f;
-                for (int k = 0; k < na; ++k)
-                    if (k == a) lp_new = logp[k];
-                const float ratio = expf(lp_new - lp_old);
-                const float surr1 = ratio * A;
-                const float rc = fminf(fmaxf(ratio, g.lo), g.hi);
-                const float surr2 = rc * A;
-                const bool inside = ratio >= g.lo && ratio <= g.hi;
-                const float dobj = (inside || surr1 < surr2) ? A : 0.f;
-                const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
-                if (valid) s_actor += fminf(surr1, surr2);
-                for (int k = 0; k < na; ++k) {
-                    const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
-                    const float dent = -pr[k] * (logp[k] + ent);
-                    dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
-                }
-            } else {
-                const float eps = 1.0e-8f;
-                const float mu = oa[0], ls = oa[1];
-                const float sg = expf(ls);
-                const float z = mi.w;
-                const float se = sg + eps;
-                const float zz = (z - mu) / se;
-                lp_new = -(zz * zz + LOG2PI_F) / 2.0f - logf(se);
-                ent = ((LOG2PI_F + 1.0f) + ls) / 2.0f;
-                const float dmu = (z - mu) / (se * se);
-                const float dls = ((z - mu) * (z - mu) / (se * se * se) - 1.0f / se) * sg;
-                const float ratio = expf(lp_new - lp_old);
-                const float surr1 = ratio * A;
-                const float rc = fminf(fmaxf(ratio, g.lo), g.hi);
-                const float surr2 = rc * A;
-                const bool inside = ratio >= g.lo && ratio <= g.hi;
-                const float dobj = (inside || surr1 < surr2) ? A : 0.f;
-                const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
-                if (valid) s_actor += fminf(surr1, surr2);
-                dl[0] = dL_dlp * dmu;
-                dl[1] = dL_dlp * dls - g.we * g.inv_b * 0.5f;
-            }
-            const float dv = mi.z - v;
-            float dvout = -2.0f * g.wc * g.inv_b * dv;
-            if (valid) {
-                s_critic += dv * dv;
-                s_ent += ent;
-            } else {
-                dl[0] = dl[1] = dl[2] = 0.f;
-                dvout = 0.f;
-            }
-            l_dL[s] = make_float4(dl[0], dl[1], dl[2], dvout);
-            gb2a[0] += dl[0];
-            gb2a[1] += dl[1];
-            gb2a[2] += dl[2];
-            gb2c += dvout;
-        }
-        __syncthreads();
-        DBG_STAMP(3);
-        // ---- phase 2: lane = hidden unit j; the tile's samples stream from LDS (broadcast reads) ----
-        if (owner) {
-#pragma unroll 4
-            for (int s = shalf * (TILE / 2); s < (shalf + 1) * (TILE / 2); ++s) {
-                const float4 xv = cx[s];
-                const float4 d = l_dL[s];
-                float za = rb1a, zc = rb1c;
-                za = fmaf(rw1a[0], xv.x, za);
-                zc = fmaf(rw1c[0], xv.x, zc);
-                if (NS > 1) {
-                    za = fmaf(rw1a[1], xv.y, za);
-                    zc = fmaf(rw1c[1], xv.y, zc);
-                }
-                if (NS > 2) {
-                    za = fmaf(rw1a[2], xv.z, za);
-                    zc = fmaf(rw1c[2], xv.z, zc);
-                }
-                if (NS > 3) {
-                    za = fmaf(rw1a[3], xv.w, za);
-                    zc = fmaf(rw1c[3], xv.w, zc);
-                }
-                const float ha = act_fwd_t<ACT>(za), hc = act_fwd_t<ACT>(zc);
-                gw2a[0] = fmaf(d.x, ha, gw2a[0]);
-                gw2a[1] = fmaf(d.y, ha, gw2a[1]);
-                if (NO > 2) gw2a[2] = fmaf(d.z, ha, gw2a[2]);
-                float dh = d.x * rw2a[0];
-                dh = fmaf(d.y, rw2a[1], dh);
-                if (NO > 2) dh = fmaf(d.z, rw2a[2], dh);
-                // relu: dh * [z > 0] as a select (the product differs only in the sign of a zero)
-                const float dza = ACT == 0 ? (za > 0.0f ? dh : 0.0f) : dh * act_bwd_t<ACT>(za, ha);
-                gw2c = fmaf(d.w, hc, gw2c);
-                const float dhc = d.w * rw2c;
-                const float dzc = ACT == 0 ? (zc > 0.0f ? dhc : 0.0f) : dhc * act_bwd_t<ACT>(zc, hc);
-                gb1a += dza;
-                gb1c += dzc;
-                gw1a[0] = fmaf(dza, xv.x, gw1a[0]);
-                gw1c[0] = fmaf(dzc, xv.x, gw1c[0]);
-                if (NS > 1) {
-                    gw1a[1] = fmaf(dza, xv.y, gw1a[1]);
-                    gw1c[1] = fmaf(dzc, xv.y, gw1c[1]);
-                }
-                if (NS > 2) {
-                    gw1a[2] = fmaf(dza, xv.z, gw1a[2]);
-                    gw1c[2] = fmaf(dzc, xv.z, gw1c[2]);
-                }
-                if (NS > 3) {
-                    gw1a[3] = fmaf(dza, xv.w, gw1a[3]);
-                    gw1c[3] = fmaf(dzc, xv.w, gw1c[3]);
-                }
-            }
-        }
-        // publish the prefetched next tile into the other buffer (nobody reads it before the barrier)
-        if (prefetcher) {
-            l_x[(buf ^ 1) * TILE + lane] = pre.x;
-            l_misc[(buf ^ 1) * TILE + lane] = pre.misc;
-        }
-        __syncthreads();
-        DBG_STAMP(4);
-        buf ^= 1;
-    }
+    publish_first_tile<NT>(L, id, first_loader, first);
+    grad_tile_loop<NS, ACT, NO, NT>(g, pk, g.pos0, L, id, rec, b2, W, G, Hd);
+    grad_fold<NT>(smem, L, id, G, Hd);
+    if (id.team != 0) return;
 
     // ---- epilogue: this workgroup's partial gradient (fixed layout = parameter layout) ----
-    // waves 4..7 (second half of the samples) hand their accumulators to waves 0..3 through LDS
-    if (shalf == 1) {
-        float* c = l_comb + uidx;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c[(k)*256] = gw1a[k];
-            c[(4 + k) * 256] = gw1c[k];
-        }
-        c[8 * 256] = gb1a;
-        c[9 * 256] = gb1c;
-        c[10 * 256] = gw2a[0];
-        c[11 * 256] = gw2a[1];
-        c[12 * 256] = gw2a[2];
-        c[13 * 256] = gw2c;
-    }
-    __syncthreads();
-    if (shalf == 0) {
-        const float* c = l_comb + uidx;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            gw1a[k] += c[(k)*256];
-            gw1c[k] += c[(4 + k) * 256];
-        }
-        gb1a += c[8 * 256];
-        gb1c += c[9 * 256];
-        gw2a[0] += c[10 * 256];
-        gw2a[1] += c[11 * 256];
-        gw2a[2] += c[12 * 256];
-        gw2c += c[13 * 256];
-    }
-    float* l_sc = l_comb + 14 * 256;  // [16] scalars of this team's wave 0
-    if (w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
-#pragma unroll
-        for (int o = 0; o < GMAXO; ++o) gb2a[o] = wave_sum_f32(gb2a[o]);
-        gb2c = wave_sum_f32(gb2c);
-        s_actor = wave_sum_f32(s_actor);
-        s_critic = wave_sum_f32(s_critic);
-        s_ent = wave_sum_f32(s_ent);
-    }
-    if (NT > 1) {
-        // team 1 hands its (already half-combined) accumulators to team 0 through its own comb area, fixed order
-        __syncthreads();  // the readers of the comb areas (above) are done
-        if (team == 1) {
-            if (shalf == 0) {
-                float* c = l_comb + uidx;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    c[(k)*256] = gw1a[k];
-                    c[(4 + k) * 256] = gw1c[k];
-                }
-                c[8 * 256] = gb1a;
-                c[9 * 256] = gb1c;
-                c[10 * 256] = gw2a[0];
-                c[11 * 256] = gw2a[1];
-                c[12 * 256] = gw2a[2];
-                c[13 * 256] = gw2c;
-            }
-            if (w == 0 && lane == 0) {
-                l_sc[0] = gb2a[0];
-                l_sc[1] = gb2a[1];
-                l_sc[2] = gb2a[2];
-                l_sc[3] = gb2c;
-                l_sc[4] = s_actor;
-                l_sc[5] = s_critic;
-                l_sc[6] = s_ent;
-            }
-        }
-        __syncthreads();
-        if (team == 1) return;
-        const float* c1 = reinterpret_cast<const float*>(smem + grad_team_smem_bytes() + sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE));
-        if (shalf == 0) {
-            const float* c = c1 + uidx;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                gw1a[k] += c[(k)*256];
-                gw1c[k] += c[(4 + k) * 256];
-            }
-            gb1a += c[8 * 256];
-            gb1c += c[9 * 256];
-            gw2a[0] += c[10 * 256];
-            gw2a[1] += c[11 * 256];
-            gw2a[2] += c[12 * 256];
-            gw2c += c[13 * 256];
-        }
-        if (w == 0) {
-            const float* sc1 = c1 + 14 * 256;
-            gb2a[0] += sc1[0];
-            gb2a[1] += sc1[1];
-            gb2a[2] += sc1[2];
-            gb2c += sc1[3];
-            s_actor += sc1[4];
-            s_critic += sc1[5];
-            s_ent += sc1[6];
-        }
-    }
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
-    if (owner && shalf == 0) {
-        const int j = uidx;
+    if (id.owner && id.shalf == 0) {
+        const int j = id.uidx;
         float* oa_ = out;
         float* oc_ = out + g.pd.np_a;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            oa_[j + h * k] = gw1a[k];
-            oc_[j + h * k] = gw1c[k];
+            oa_[j + h * k] = G.w1[k].x;
+            oc_[j + h * k] = G.w1[k].y;
         }
-        oa_[h * NS + j] = gb1a;
-        oc_[h * NS + j] = gb1c;
+        oa_[h * NS + j] = G.b1.x;
+        oc_[h * NS + j] = G.b1.y;
+        oa_[h * NS + h + 0 + nout * j] = G.w2p.x;
+        if (1 < nout) oa_[h * NS + h + 1 + nout * j] = G.w2a1;
+        if (2 < nout) oa_[h * NS + h + 2 + nout * j] = G.w2a2;
+        oc_[h * NS + h + j] = G.w2p.y;
+    }
+    if (id.w == 0 && id.lane == 0) {
 #pragma unroll
         for (int o = 0; o < GMAXO; ++o)
-            if (o < nout) oa_[h * NS + h + o + nout * j] = gw2a[o];
-        oc_[h * NS + h + j] = gw2c;
-    }
-    if (w == 0 && lane == 0) {
-        for (int o = 0; o < nout; ++o) out[h * NS + h + nout * h + o] = gb2a[o];
-        out[g.pd.np_a + h * NS + h + h] = gb2c;
+            if (o < nout) out[h * NS + h + nout * h + o] = Hd.b2a[o];
+        out[g.pd.np_a + h * NS + h + h] = Hd.b2c;
         float* lo_ = g.loss_partials + (int64_t)blockIdx.x * 4;
-        lo_[0] = s_actor;
-        lo_[1] = s_critic;
-        lo_[2] = s_ent;
+        lo_[0] = Hd.s_actor;
+        lo_[1] = Hd.s_critic;
+        lo_[2] = Hd.s_ent;
         lo_[3] = 0.f;
     }
-    DBG_STAMP(5);
-    DBG_FLUSH();
 }
 
 static size_t grad_smem_bytes(int h) {
     (void)h;
     return grad_team_smem_bytes();
-}
-
-// unit records {W1[j,0..3], b1[j], W2[0..2,j]} per net + the output biases; any thread count
-__device__ __forceinline__ void pack_records(const float* __restrict__ params, float* __restrict__ packed, int h,
-                                             int ns, int nout, int64_t np_a, int tid, int nthreads) {
-    const float* W1a = params;
-    const float* b1a = W1a + h * ns;
-    const float* W2a = b1a + h;
-    const float* b2a = W2a + nout * h;
-    const float* W1c = params + np_a;
-    const float* b1c = W1c + h * ns;
-    const float* W2c = b1c + h;
-    const float* b2c = W2c + h;
-    for (int q = tid; q < 2 * h; q += nthreads) {
-        const int net = q / h, j = q - net * h;
-        float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (net == 0) {
-            for (int k = 0; k < ns; ++k) rec[k] = W1a[j + h * k];
-            rec[4] = b1a[j];
-            for (int o = 0; o < nout; ++o) rec[5 + o] = W2a[o + nout * j];
-        } else {
-            for (int k = 0; k < ns; ++k) rec[k] = W1c[j + h * k];
-            rec[4] = b1c[j];
-            rec[5] = W2c[j];
-        }
-        float4* dst = reinterpret_cast<float4*>(packed + 8 * (int64_t)q);
-        dst[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
-        dst[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
-    }
-    if (tid == 0) {
-        float* t = packed + 16 * (int64_t)h;
-        t[0] = (0 < nout) ? b2a[0] : 0.f;
-        t[1] = (1 < nout) ? b2a[1] : 0.f;
-        t[2] = (2 < nout) ? b2a[2] : 0.f;
-        t[3] = b2c[0];
-    }
 }
 
 __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ packed,
@@ -591,19 +135,6 @@ struct XchgArgs {
     int* status;
     float inv_world;
 };
-
-// position of flat parameter q in the unit-record copy (see pack_records)
-__device__ __forceinline__ int64_t record_slot(int64_t q, int h, int ns, int nout, int64_t np_a) {
-    const int net = q >= np_a ? 1 : 0;
-    const int64_t r = q - (net ? np_a : 0);
-    const int no = net ? 1 : nout;
-    const int64_t base = 8 * (int64_t)net * h;
-    if (r < (int64_t)h * ns) return base + 8 * (r % h) + (r / h);               // W1[j + h k] -> rec[j][k]
-    if (r < (int64_t)h * ns + h) return base + 8 * (r - (int64_t)h * ns) + 4;   // b1[j]       -> rec[j][4]
-    const int64_t w = r - ((int64_t)h * ns + h);
-    if (w < (int64_t)no * h) return base + 8 * (w / no) + 5 + (w % no);         // W2[o + no j] -> rec[j][5 + o]
-    return 16 * (int64_t)h + (net ? 3 : (w - (int64_t)no * h));                 // output biases -> tail
-}
 
 template <int APPLY>
 __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restrict__ partials,
@@ -924,15 +455,6 @@ static float* workspace_packed(void* workspace, int64_t np) {
     return (float*)pq;
 }
 
-struct GradLaunch {
-    GradArgs g;
-    int nb, ns, nt;  // partial rows (= workgroups), observation size, teams (tiles side by side) per workgroup
-    int64_t np;
-    unsigned int* counter;
-    double* sumsq;
-    float* packed;
-};
-
 static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                             const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace,
                             GradLaunch* out, const uint32_t* ctr = nullptr) {
@@ -994,10 +516,7 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     q = (q + 15) & ~(uintptr_t)15;
     out->sumsq = (double*)q;
     out->counter = (unsigned int*)(out->sumsq + 4096);
-    static int dbg_on = -1;
-    if (dbg_on < 0) dbg_on = getenv("RLHIP_GRAD_DEBUG") ? 1 : 0;
-    long long* dbgp = (long long*)(out->counter + 16);
-    g.dbg = dbg_on ? dbgp : nullptr;
+    long long* dbgp = (long long*)(out->counter + 16);  // (reserved: MAX_GRAD_BLOCKS x 8 words)
     uintptr_t pq = (uintptr_t)(dbgp + (int64_t)MAX_GRAD_BLOCKS * 8);
     pq = (pq + 63) & ~(uintptr_t)63;
     out->packed = (float*)pq;
@@ -1084,12 +603,35 @@ using namespace rlhip;
 
 extern "C" {
 
+// bytes of the two-launch path's carve (prepare_grad); the persistent kernel's buffers follow, 256-byte aligned
+static int64_t grad_workspace_bytes(int64_t np) {
+    const int64_t b = (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float) + 16 + 4096 * (int64_t)sizeof(double) + 64 +
+                      (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long) + 64 + (16 * 256 + 8) * (int64_t)sizeof(float);
+    return (b + 255) / 256 * 256;
+}
+
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T) {
     if (is_layers3(cfg)) return ppo3_workspace_bytes(kind, cfg, n, T);
     int64_t np = rlhip_ppo_nparams(kind, cfg);
     if (np < 0) return -1;
-    return (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float) + 16 + 4096 * (int64_t)sizeof(double) + 64 +
-           (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long) + 64 + (16 * 256 + 8) * (int64_t)sizeof(float);
+    return grad_workspace_bytes(np) + ppo_persist_bytes(np, cfg->hidden);
+}
+
+/* Did a persistent update (ppo_persist.hip) ever give up on a hand-off in this workspace?  Synchronises `stream`.
+ * *status_host = 0, or RLHIP_ETIMEOUT (sticky until the workspace is zeroed again; the parameters are NaN by then). */
+int32_t rlhip_ppo_update_status(int32_t kind, const rlhip_ppo_cfg* cfg, void* workspace, int32_t* status_host,
+                                rlhip_stream_t stream) {
+    RLHIP_REQUIRE(cfg && workspace && status_host, "NULL argument");
+    *status_host = 0;
+    if (is_layers3(cfg)) return RLHIP_OK;
+    const int64_t np = rlhip_ppo_nparams(kind, cfg);
+    RLHIP_REQUIRE(np > 0, "bad configuration");
+    unsigned int word = 0;
+    const unsigned int* st = (const unsigned int*)((const char*)workspace + grad_workspace_bytes(np));
+    RLHIP_CHECK_HIP(hipMemcpyAsync(&word, st + 3, sizeof(word), hipMemcpyDeviceToHost, as_stream(stream)));
+    RLHIP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (word != 0) *status_host = RLHIP_ETIMEOUT;
+    return RLHIP_OK;
 }
 
 static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
@@ -1286,6 +828,16 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
                            losses_out, stream);
     }
     hipStream_t s = as_stream(stream);
+    {   // the whole update as ONE persistent launch (ppo_persist.hip) when the device admits the grid ...
+        GradLaunch L0;
+        int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, ctr ? 0u : update_ctr * (uint32_t)cfg->n_epochs, 0,
+                                  workspace, &L0, ctr);
+        if (rc) return rc;
+        rc = ppo_persist_update(L0, cfg, params, m, v, beta_pow, update_ctr, (char*)workspace + grad_workspace_bytes(L0.np),
+                                grad_scratch, losses_out, s);
+        if (rc <= 0) return rc;
+    }
+    // ... otherwise two launches per optimiser step
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         uint32_t epoch_ctr = ctr ? (uint32_t)e : update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
