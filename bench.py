@@ -248,40 +248,6 @@ def roofline_extras(torch, rlhip):
         "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "samples_per_sec": round(batch / (ms * 1e-3), 1)}
     del tr1, outs, idx1
     torch.cuda.empty_cache()
-    # bf16 MFMA Dense layer (hidden x hidden), batch = one PPO trajectory (131072 rows), 256 -> 256, fused bias + relu
-    Bm, Km, Nm = N_ENVS * T_ROLLOUT, 256, 256
-    xr = torch.randn((Bm, Km), device="cuda").to(torch.bfloat16)
-    wt = (torch.randn((Nm, Km), device="cuda") / 16).to(torch.bfloat16)
-    bias = torch.randn(Nm, device="cuda")
-    y = torch.empty((Bm, Nm), dtype=torch.bfloat16, device="cuda")
-
-    def mf():
-        rlhip._lib.call("rlhip_dense_bf16_forward", ops.ptr(xr), ops.ptr(wt), ops.ptr(bias), 0, Bm, Km, Nm, ops.ptr(y), 1, s)
-
-    for _ in range(3):
-        mf()
-    ms = event_time_ms(mf, 20, lib, s)
-    tf = 2.0 * Bm * Km * Nm / (ms * 1e-3) / 1e12
-    out["dense_bf16_mfma_simple"] = {"kernel": "dense_mfma_kernel<relu,bf16> (fragments straight from global)",
-                                     "us_per_launch": round(ms * 1e3, 1), "achieved": round(tf, 1), "unit": "TFLOP/s"}
-    wf = ops.dense_frag_weight_bf16(wt)
-
-    def mt():
-        rlhip._lib.call("rlhip_dense_bf16_forward_tiled", ops.ptr(xr), ops.ptr(wf), ops.ptr(bias), 0, Bm, Km, Nm,
-                        ops.ptr(y), 1, s)
-
-    for _ in range(3):
-        mt()
-    ms = event_time_ms(mt, 20, lib, s)
-    tf = 2.0 * Bm * Km * Nm / (ms * 1e-3) / 1e12
-    hbm = 2.0 * Bm * (Km + Nm) / (ms * 1e-3) / 1e9
-    out["dense_bf16_mfma"] = {"bound": "mfma", "kernel": "dense_persist_kernel<16,relu,RT=2> (v_mfma_f32_32x32x16_bf16; weights in registers, 64-row X tiles double-buffered in LDS, 2 workgroups per CU)",
-                              "batch": Bm, "k": Km, "n": Nm, "us_per_launch": round(ms * 1e3, 1),
-                              "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                              "hbm_gbs": round(hbm, 1),
-                              "note": "this shape is HBM-bound (128 flop/B): 2 (K + N) B per row, ceiling ~1 PFLOP/s at 8 TB/s"}
-    del wf
-    del xr, wt, y
     # BASELINE configs[1]: 4096-way CartPole + QBasedPolicy(DQN, 4->128->2), batch 512, 1 update per vec-step
     n = N_ENVS
     env = rlhip.CartPoleEnv(n, seed=5)

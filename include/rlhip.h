@@ -573,32 +573,6 @@ int32_t rlhip_mlp2_forward_f32(const float* params, int64_t n_in, int64_t h, int
 int32_t rlhip_mlp2_init_f32(float* params, int64_t n_in, int64_t h, int64_t n_out, uint64_t seed,
                             uint32_t net_id, rlhip_stream_t stream);
 
-/* bf16 MFMA path for GEMM-shaped Dense layers (hidden x hidden): Y = act(X * W + b), f32 accumulate.
- *   x_rows : bf16 (batch x k) row-major (k contiguous), batch % 128 == 0, k % 16 == 0
- *   wt     : bf16 (n x k) = the Flux Dense weight (n out x k in) stored k-contiguous
- *            (rlhip_dense_pack_weight_bf16 makes it from the column-major Float32 weight), n % 128 == 0
- *   bias   : f32[n] or NULL;  act: 0 relu, 1 tanh, 2 identity
- *   y_rows : (batch x n) row-major, bf16 (y_is_bf16 != 0) or f32
- * Replaces Flux `Dense` inside `A.model(x)` (flux_approximator.jl:43) for layers with a GEMM shape. */
-int32_t rlhip_dense_bf16_forward(const uint16_t* x_rows, const uint16_t* wt, const float* bias,
-                                 int32_t act, int64_t batch, int32_t k, int32_t n, void* y_rows,
-                                 int32_t y_is_bf16, rlhip_stream_t stream);
-/* layout / precision converters around it (SoA f32 activations <-> bf16 rows, zero padding) */
-int32_t rlhip_soa_f32_to_bf16_rows(const float* x_soa, int64_t batch, int32_t k, int32_t k_pad,
-                                   uint16_t* out_rows, rlhip_stream_t stream);
-int32_t rlhip_bf16_rows_to_soa_f32(const uint16_t* y_rows, int64_t batch, int32_t n, int32_t ld,
-                                   float* out_soa, rlhip_stream_t stream);
-int32_t rlhip_dense_pack_weight_bf16(const float* w_flux, int32_t k, int32_t n, int32_t k_pad,
-                                     int32_t n_pad, uint16_t* wt, rlhip_stream_t stream);
-/* Tiled variant (X tile staged through LDS, coalesced bf16 output): weights in MFMA fragment order, produced
- * from the row-major Wt of rlhip_dense_pack_weight_bf16 by rlhip_dense_frag_weight_bf16 (same element count).
- * batch % 128 == 0, 16 <= k <= 512 with k % 16 == 0, n % 128 == 0. */
-int32_t rlhip_dense_frag_weight_bf16(const uint16_t* wt, int32_t k, int32_t n, uint16_t* w_frag,
-                                     rlhip_stream_t stream);
-int32_t rlhip_dense_bf16_forward_tiled(const uint16_t* x_rows, const uint16_t* w_frag, const float* bias,
-                                       int32_t act, int64_t batch, int32_t k, int32_t n, void* y_rows,
-                                       int32_t y_is_bf16, rlhip_stream_t stream);
-
 /* ------------------------------------------------------------------------------ PPO path -- */
 /* PPOPolicy hyper-parameters (removed Zoo; blog a_practical_introduction_to_RL.jl/index.html:15257-15278) */
 typedef struct {

@@ -996,7 +996,7 @@ int32_t ppo3_apply_fused(const float* partials, const float* loss_partials, int 
         if (e) cap = atoi(e);
     }
     const int grid = (np + 255) / 256;
-    if (grid > cap || grid > 256 || RLHIP_ENV_FLAG("RLHIP_PPO3_UNFUSED_TAIL")) return 1;
+    if (grid > cap || grid > 256) return 1;
     D3Apply ap{params, m, v, beta_pow, nullptr, packed, (double*)tail, (unsigned int*)((double*)tail + 256), 1.0f,
                clip_norm, lr, b1, b2, eps, ns, np_a, wa, wc, we};
     hipLaunchKernelGGL(d3_apply_kernel, dim3(grid), dim3(256), 0, s, partials, loss_partials, nb, np, grad, losses, inv_b,
@@ -1085,7 +1085,7 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
     if (h == HWIDE) return dqn3w_plan(params, packed, ns, na, act, obs, n, eps, seed, env_id_base, step, actions, q_out, stream);
     hipStream_t s = as_stream(stream);
     dim3 grid((unsigned)((n + TR - 1) / TR));
-    const bool small = n <= (1 << 15) && !RLHIP_ENV_FLAG("RLHIP_DQN3_PLAN128");
+    const bool small = n <= (1 << 15);
     const dim3 grid32((unsigned)((n + P32 - 1) / P32));
 #define LAUNCH_P(NS_, NA_, ACT_)                                                                               \
     do {                                                                                                       \
@@ -1155,8 +1155,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     // 8192: 27.0 / 27.2, 16384: 39.7 / 32.1, 32768: 52.3 / 37.0, 65536: 76.2 / 69.3, 131072: 121.7 / 131.9 -- the
     // 32-sample kernel (280 VGPRs persistent: one workgroup per CU) wins where latency or the partial-row volume decide;
     // with two workgroups per CU (256 VGPRs, some spills) it is 66.2 us at 65536 and 106.4 us at 131072 (161 TFLOP/s)
-    const bool small = !RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD128") &&
-                       (batch <= 8192 || batch >= 65536 || RLHIP_ENV_FLAG("RLHIP_DQN3_GRAD32"));
+    const bool small = batch <= 8192 || batch >= 65536;
     const int64_t tiles32 = (batch + G32 - 1) / G32;
     const int nb = small ? (int)(tiles32 < D3_GRAD32_BLOCKS ? tiles32 : D3_GRAD32_BLOCKS) : (int)((batch + TR - 1) / TR);
     Dqn3Args g;

@@ -55,7 +55,7 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
     const int64_t ns = rlhip_env_obs_dim(a->kind);
     RLHIP_REQUIRE(ns == a->ring->obs_dim && a->n == a->ring->n_env, "ring geometry does not match the env");
     int32_t rc;
-    if (a->layers == 2 && rlhip_dqn_act_supported(a->kind, a->n, a->h) && !RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_ACT")) {
+    if (a->layers == 2 && rlhip_dqn_act_supported(a->kind, a->n, a->h)) {
         // plan! + act! + push! in one launch (dqn_act.hip): same device functions, same slots, bit-identical
         rc = rlhip_dqn_act_f32(a->kind, a->env_cfg, a->st, a->n, a->params, a->h, a->na, a->act, a->eps,
                                a->explorer_seed, a->explorer_step, a->env_seed, a->env_id_base, a->ring, a->actions,
@@ -72,29 +72,21 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
         if (rc) return rc;
         // act!(env, action) with auto-reset + push!(trajectory, (state = s', action, reward, terminal)): one launch
         // (dqn_act.hip; same device functions and slots as rlhip_env_step + rlhip_ring_push_transition)
-        if (!RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_ACT")) {
-            rc = rlhip_env_act_push_f32(a->kind, a->env_cfg, a->st, a->n, a->actions, a->env_seed, a->env_id_base, a->ring,
-                                        a->obs, a->last_obs, stream);
-            if (rc) return rc;
-        } else {
-            rc = rlhip_env_step(a->kind, 0, a->env_cfg, a->st, a->n, a->actions, 1, a->env_seed, a->env_id_base,
-                                a->last_obs, a->obs, stream);
-            if (rc) return rc;
-            rc = rlhip_ring_push_transition(a->ring, a->obs, a->actions, (const float*)a->st->reward, a->st->done, stream);
-            if (rc) return rc;
-        }
+        rc = rlhip_env_act_push_f32(a->kind, a->env_cfg, a->st, a->n, a->actions, a->env_seed, a->env_id_base, a->ring,
+                                    a->obs, a->last_obs, stream);
+        if (rc) return rc;
     }
     if (!a->do_update) return RLHIP_OK;
     // optimise!(learner, trajectory): sample + TD target + Huber + gradient, then clip + Adam
     int64_t np;
-    if (a->layers == 2 && !RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_APPLY")) {
+    if (a->layers == 2) {
         // gradient partials, then reduce + clip + Adam in one launch (bit-identical to the two calls below)
         np = rlhip_mlp2_nparams(ns, a->h, a->na);
         rc = rlhip_dqn_update_f32(a->ring, a->h, a->na, a->act, a->params, a->target, a->batch, a->gamma, a->huber_delta,
                                   a->sampler_seed, a->draw_ctr, a->workspace, a->grad, a->loss, a->m, a->v, a->beta_pow,
                                   a->grad_scale, a->max_grad_norm, a->lr, a->beta1, a->beta2, a->adam_eps, a->gn, stream);
         if (rc) return rc;
-    } else if (a->layers == 3 && !RLHIP_ENV_FLAG("RLHIP_DQN_UNFUSED_APPLY")) {
+    } else if (a->layers == 3) {
         // gradient, then reduce + clip + Adam + bf16 re-pack in one launch (bit-identical to the calls below)
         np = rlhip_mlp3_nparams(ns, a->h, a->na);
         rc = rlhip_dqn3_update_f32(a->ring, a->h, a->na, a->act, a->params, a->packed, a->target, a->target_packed,

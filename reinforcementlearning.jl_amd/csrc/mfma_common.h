@@ -1,4 +1,4 @@
-// mfma_common.h -- bf16 helpers and the gfx950 MFMA fragment types shared by dense_mfma.hip / dqn3.hip.
+// mfma_common.h -- bf16 helpers and the gfx950 MFMA fragment types shared by the MFMA learners (dqn3.hip, ppo3.hip, ppo3w.hip).
 //
 // v_mfma_f32_32x32x16_bf16: D(32x32) += A(32x16) * B(16x32), one wave.  Register layout (MI355X guide
 // section 3; verified against a torch reference in tests/test_gpu_mfma.py):

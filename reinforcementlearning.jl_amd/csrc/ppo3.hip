@@ -607,10 +607,8 @@ constexpr size_t GRAD3_LDS = (4 * TR + 2 * MAXO * TR + 4 * TR + 16 + 4 * 5 * H3 
 
 }  // namespace rlhip
 #include "ppo3t_kernel.h"
-#include "ppo3p_kernel.h"
 namespace rlhip {
 static bool g_ppo3_force128 = false;  // test hook (rlhip_debug_ppo3_force128): the round-1 tile for A / B comparisons
-static int g_ppo3_variant = -1;       // test hook (rlhip_debug_ppo3_variant): 0 = chained 4-wave tile, 1 = producer / consumer tile
 
 // both nets' W2 -> bf16 MFMA fragments: [actor W2jk | actor W2kj | critic W2jk | critic W2kj]
 __global__ __launch_bounds__(256) void ppo3_pack_kernel(const float* __restrict__ params, int ns, int64_t np_a,
@@ -697,7 +695,7 @@ static int32_t rollout3_impl(const typename P::cfg_t* cfg, const rlhip_env_state
     EnvArrays<float> a = EnvArrays<float>::from(*st);
     TrajPtrs tr = TrajPtrs::from(*traj);
     // up to 2^15 envs the 32-env workgroups fill more of the chip and have the shorter per-step chain
-    const bool small = n <= (1 << 15) && !RLHIP_ENV_FLAG("RLHIP_PPO3_ROLLOUT128");
+    const bool small = n <= (1 << 15);
     dim3 grid((unsigned)(small ? (n + R32 - 1) / R32 : (n + TR - 1) / TR));
 #define LAUNCH_R3(ACT_)                                                                                           \
     do {                                                                                                          \
@@ -838,45 +836,30 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
     g.pk = perm_keys(seed, epoch_ctr, (uint32_t)total);
     if (do_pack)
         hipLaunchKernelGGL(ppo3_pack_kernel, dim3(2 * H3 * H3 / 256), dim3(256), 0, s, params, ns, g.np_a, packed);
-    // default: the register-chained tile (ppo3t_kernel.h), persistent workgroups, one partial row per workgroup and net;
-    // RLHIP_PPO3_GRAD128=1 keeps the round-1 kernel (one 128-row tile per workgroup) for A/B comparison
-    // (relu only: the tanh instantiations of the chained tile need 64 more live registers for act'(h1), spill ~300
-    //  dwords per lane and -- cartpole / tanh -- came out of the compiler computing a wrong actor loss; they stay on the
-    //  round-1 tile, which tests/test_gpu_ppo3.py pins against the oracle)
-    const bool chained = (pd.act == 0 || RLHIP_ENV_FLAG("RLHIP_PPO3_CHAINED_TANH")) &&
-                         !(g_ppo3_force128 || RLHIP_ENV_FLAG("RLHIP_PPO3_GRAD128"));
+    // relu: the register-chained tile (ppo3t_kernel.h), persistent workgroups, one partial row per workgroup and net.
+    // tanh: the round-1 kernel (one 128-row tile per workgroup) -- the chained tile needs 64 more live registers for
+    // act'(h1) there, spills ~300 dwords per lane and measured 693 us against 326 us (profiles/r02_ppo3_gradT.md).
+    // rlhip_debug_ppo3_force128 (test hook) keeps the round-1 kernel for relu too: A / B comparisons in tests/.
+    const bool chained = pd.act == 0 && !g_ppo3_force128;
     const int ntiles = (int)nb;
     static int t3_wg_cap = -1;
     if (t3_wg_cap < 0) {
-        const char* e = getenv("RLHIP_PPO3_WGS");
+        const char* e = getenv("RLHIP_PPO3_WGS");  // test hook: many tiles per persistent workgroup at small sizes
         t3_wg_cap = e ? atoi(e) : 128;
         if (t3_wg_cap < 1 || t3_wg_cap > 1024) t3_wg_cap = 128;
     }
-    if (g_ppo3_variant < 0) g_ppo3_variant = RLHIP_ENV_FLAG("RLHIP_PPO3_GRADP") ? 1 : 0;
-    const bool pc = chained && g_ppo3_variant == 1;  // producer / consumer tile (ppo3p_kernel.h), rounds of 192 samples
-    const int nrounds = (int)((bm + P3P_ROUND - 1) / P3P_ROUND);
-    const int nunits = pc ? nrounds : ntiles;
-    const int nwg = nunits < t3_wg_cap ? nunits : t3_wg_cap;  // per net
+    const int nwg = ntiles < t3_wg_cap ? ntiles : t3_wg_cap;  // per net
     const int nrows = chained ? nwg : (int)nb;
     g.loss_partials = g.partials + (int64_t)nrows * g.np;
+#define LAUNCH_G3T(NS_, CONT_)                                                                            \
+    do {                                                                                                  \
+        static bool donet_ = false;                                                                       \
+        int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, 0, CONT_>, GRADT_LDS, &donet_);                   \
+        if (rc_) return rc_;                                                                              \
+        hipLaunchKernelGGL((ppo3_gradT_kernel<NS_, 0, CONT_>), dim3(2 * nwg), dim3(256), GRADT_LDS, s, g, nwg, ntiles); \
+    } while (0)
 #define LAUNCH_G3(NS_, ACT_, CONT_)                                                                       \
     do {                                                                                                  \
-        if (pc) {                                                                                         \
-            static bool donep_ = false;                                                                   \
-            int32_t rc_ = allow_lds3(ppo3_gradP_kernel<NS_, CONT_>, GRADP_LDS, &donep_);                  \
-            if (rc_) return rc_;                                                                          \
-            hipLaunchKernelGGL((ppo3_gradP_kernel<NS_, CONT_>), dim3(2 * nwg), dim3(512), GRADP_LDS, s, g, nwg, \
-                               nrounds);                                                                  \
-            break;                                                                                        \
-        }                                                                                                 \
-        if (chained) {                                                                                    \
-            static bool donet_ = false;                                                                   \
-            int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, ACT_, CONT_>, GRADT_LDS, &donet_);            \
-            if (rc_) return rc_;                                                                          \
-            hipLaunchKernelGGL((ppo3_gradT_kernel<NS_, ACT_, CONT_>), dim3(2 * nwg), dim3(256), GRADT_LDS, s, g, nwg, \
-                               ntiles);                                                                   \
-            break;                                                                                        \
-        }                                                                                                 \
         static bool done_ = false;                                                                        \
         int32_t rc_ = allow_lds3(ppo3_grad_kernel<NS_, 2, ACT_, CONT_>, GRAD3_LDS, &done_);               \
         if (rc_) return rc_;                                                                              \
@@ -884,14 +867,17 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
     } while (0)
     if (kind == 0) {
         RLHIP_REQUIRE(!pd.cont, "layers = 3: CartPole uses the categorical head");
-        if (pd.act == 0) LAUNCH_G3(4, 0, 0);
+        if (chained) LAUNCH_G3T(4, 0);
+        else if (pd.act == 0) LAUNCH_G3(4, 0, 0);
         else LAUNCH_G3(4, 1, 0);
     } else {
         RLHIP_REQUIRE(pd.cont, "layers = 3: Pendulum uses the Gaussian head");
-        if (pd.act == 0) LAUNCH_G3(3, 0, 1);
+        if (chained) LAUNCH_G3T(3, 1);
+        else if (pd.act == 0) LAUNCH_G3(3, 0, 1);
         else LAUNCH_G3(3, 1, 1);
     }
 #undef LAUNCH_G3
+#undef LAUNCH_G3T
     if (tail) {
         // reduce + PPO loss line + Float64 norm + clip + Adam + bf16 re-pack of both W2 in one launch (dqn3.hip)
         char* tp = (char*)workspace + ppo3_workspace_bytes(kind, cfg, n, T) - P3_TAIL_BYTES;
@@ -915,20 +901,6 @@ extern "C" int32_t rlhip_debug_ppo3_force128(int32_t on) {
     g_ppo3_force128 = on != 0;
     return RLHIP_OK;
 }
-
-/* test hook: 0 = the chained 4-wave tile (default), 1 = the producer / consumer tile */
-extern "C" int32_t rlhip_debug_ppo3_variant(int32_t v) {
-    g_ppo3_variant = v;
-    return RLHIP_OK;
-}
-
-#ifdef RLHIP_P3P_TIMING
-extern "C" int32_t rlhip_debug_p3p_stamps(long long* out_host) {
-    RLHIP_CHECK_HIP(hipDeviceSynchronize());
-    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_p3p_stamps), 3 * 16 * sizeof(long long)));
-    return RLHIP_OK;
-}
-#endif
 
 #ifdef RLHIP_T3_TIMING
 extern "C" int32_t rlhip_debug_t3_stamps(long long* out_host) {

@@ -1399,15 +1399,7 @@ static int32_t allow_lds_w(K kernel, size_t bytes, bool* done) {
     return RLHIP_OK;
 }
 
-static int p3w_rows_w() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("RLHIP_PPO3W_NSR");
-        v = e ? atoi(e) : P3W_ROWS_W;
-        if (v < 1 || v > 256) v = P3W_ROWS_W;
-    }
-    return v;
-}
+static int p3w_rows_w() { return P3W_ROWS_W; }
 
 struct P3WLayout {
     int64_t ntiles, off_xg, off_sg, off_rows, off_frag, off_partS, off_partW, off_loss, off_tail, off_rec, bytes;
@@ -1593,8 +1585,6 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         int dev = 0;
         RLHIP_CHECK_HIP(hipGetDevice(&dev));
         RLHIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        const char* e = getenv("RLHIP_PPO3W_WGS");
-        if (e && atoi(e) > 0) n_cu = atoi(e);
         if (n_cu < 1) n_cu = 1;
         if (n_cu > P3W_ROWS_S) n_cu = P3W_ROWS_S;
     }
@@ -1610,8 +1600,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         }
     }
     // the dW2 launch covers both nets (blockIdx.y): 2 k halves x nsr sample ranges x 2 nets = one workgroup per CU at nsr = 64
-    const bool merged = !RLHIP_ENV_FLAG("RLHIP_PPO3W_SPLIT_DW2");
-    const int rows_w = merged ? (p3w_rows_w() + 1) / 2 : p3w_rows_w();
+    const int rows_w = (p3w_rows_w() + 1) / 2;
     const int nsr = (int)(L.ntiles < rows_w ? L.ntiles : rows_w);
 #define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
     do {                                                                                                              \
@@ -1623,11 +1612,9 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                             \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                \
-        if (!merged) hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 0, nsr); \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 1);                \
-        if (merged) hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr, 2), dim3(NTW), DW2W_LDS, s, g, -1, nsr); \
-        else hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 1, nsr);     \
+        hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr, 2), dim3(NTW), DW2W_LDS, s, g, -1, nsr);      \
     } while (0)
     if (kind == 0) {
         RLHIP_REQUIRE(!pd.cont, "layers = 3: CartPole uses the categorical head");
@@ -1639,7 +1626,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         else LAUNCH_GW(3, 1, 1);
     }
 #undef LAUNCH_GW
-    if (tail != nullptr && !RLHIP_ENV_FLAG("RLHIP_PPO3W_UNFUSED_TAIL")) {
+    if (tail != nullptr) {
         double* sumsq = (double*)(ws + L.off_tail);
         unsigned int* departed = (unsigned int*)(sumsq + W3T_BLOCKS);
         const int nbt = (int)((np + 255) / 256 < W3T_BLOCKS ? (np + 255) / 256 : W3T_BLOCKS);  // grid_for(np, 256, 256)
@@ -1667,7 +1654,7 @@ int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& p
     const int64_t np = ppo3w_nparams(ns, pd.nout_a);
     (void)np;
     bool rec_ready = false;
-    if (!RLHIP_ENV_FLAG("RLHIP_PPO3W_NO_REC")) {
+    {
         RLHIP_REQUIRE(traj->obs && traj->logp && traj->adv && traj->ret && (pd.cont ? (const void*)traj->action_f : (const void*)traj->action_i),
                       "trajectory array is NULL");
         const int64_t total = n * T;
@@ -1690,7 +1677,7 @@ int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& p
         rec_ready = true;
     }
     const P3WTail tail{params, m, v, beta_pow, rec_ready};
-    const bool fused = !RLHIP_ENV_FLAG("RLHIP_PPO3W_UNFUSED_TAIL");
+    const bool fused = true;
     bool packed_fresh = false;  // the previous optimiser step's tail left the bf16 images of both W2 up to date
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         const uint32_t epoch_ctr = update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;

@@ -431,15 +431,7 @@ static int grid_apply_max_blocks() {
     return cap;
 }
 
-static int grad_blocks(int num_tiles) {
-    static int cap = -1;
-    if (cap < 0) {
-        const char* e = getenv("RLHIP_GRAD_BLOCKS");
-        cap = e ? atoi(e) : 512;
-        if (cap < 1 || cap > MAX_GRAD_BLOCKS) cap = MAX_GRAD_BLOCKS;
-    }
-    return num_tiles < cap ? num_tiles : cap;
-}
+static int grad_blocks(int num_tiles) { return num_tiles < MAX_GRAD_BLOCKS ? num_tiles : MAX_GRAD_BLOCKS; }
 
 // location of the unit-record copy inside the workspace (the carve of prepare_grad)
 static float* workspace_packed(void* workspace, int64_t np) {
@@ -499,13 +491,8 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     g.epoch_local = epoch_ctr;  // with ctr: the epoch index inside this update call
     g.n_epochs = (uint32_t)cfg->n_epochs;
     // two tiles side by side per workgroup (one partial row for both) once there are more tiles than CUs can take one
-    // 8-wave workgroup each: below that, more (smaller) workgroups fill the chip better.  RLHIP_GRAD_TEAMS=1 / 2 forces.
-    static int teams_env = -1;
-    if (teams_env < 0) {
-        const char* e = getenv("RLHIP_GRAD_TEAMS");
-        teams_env = e ? atoi(e) : 0;
-    }
-    out->nt = teams_env == 1 ? 1 : (teams_env == 2 ? 2 : (g.num_tiles > 256 ? 2 : 1));
+    // 8-wave workgroup each: below that, more (smaller) workgroups fill the chip better
+    out->nt = g.num_tiles > 256 ? 2 : 1;
     out->nb = grad_blocks((g.num_tiles + out->nt - 1) / out->nt);
     out->ns = ns;
     out->np = np;
@@ -855,7 +842,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                          L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
             const int rblocks = (int)((L.np + RP - 1) / RP);
-            if (rblocks <= grid_apply_max_blocks<APPLY_GRID>() && !RLHIP_ENV_FLAG("RLHIP_APPLY_LAST_ARRIVER"))
+            if (rblocks <= grid_apply_max_blocks<APPLY_GRID>())
                 hipLaunchKernelGGL((reduce_apply_kernel<APPLY_GRID>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,
                                    L.g.loss_partials, L.nb, (int)L.np, grad_scratch, losses_out, L.g.wa, L.g.wc, L.g.we,
                                    L.g.inv_b, ap, XchgArgs{});

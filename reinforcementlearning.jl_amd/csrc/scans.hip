@@ -218,7 +218,7 @@ static int32_t gae_impl(T* adv, T* ret, const T* r, const T* v, int64_t n1, int6
     if constexpr (sizeof(T) == 4) {
         const bool env_major = g.slice_stride == 1 && g.v_slice_stride == 1 && g.elem_stride == g.n_slices;
         const uintptr_t al = (uintptr_t)adv | (uintptr_t)r | (uintptr_t)v | (uintptr_t)(ret ? ret : adv);
-        if (!RLHIP_ENV_FLAG("RLHIP_GAE_SCALAR") && streaming && env_major && g.n_slices % 4 == 0 && (al & 15) == 0 && (!term || ((uintptr_t)term & 3) == 0)) {
+        if (streaming && env_major && g.n_slices % 4 == 0 && (al & 15) == 0 && (!term || ((uintptr_t)term & 3) == 0)) {
             dim3 g4((int)((g.n_slices / 4 + 255) / 256));
             if (ret)
                 hipLaunchKernelGGL((gae_vec4_kernel<true, 8>), g4, dim3(256), 0, s, (float*)adv, (float*)ret,

@@ -215,12 +215,6 @@ _PROTOS = {
     "rlhip_mlp2_nparams": (i64, [i64, i64, i64]),
     "rlhip_mlp2_forward_f32": (i32, [vp, i64, i64, i64, i32, vp, i64, vp, vp]),
     "rlhip_mlp2_init_f32": (i32, [vp, i64, i64, i64, u64, u32, vp]),
-    "rlhip_dense_bf16_forward": (i32, [vp, vp, vp, i32, i64, i32, i32, vp, i32, vp]),
-    "rlhip_soa_f32_to_bf16_rows": (i32, [vp, i64, i32, i32, vp, vp]),
-    "rlhip_bf16_rows_to_soa_f32": (i32, [vp, i64, i32, i32, vp, vp]),
-    "rlhip_dense_pack_weight_bf16": (i32, [vp, i32, i32, i32, i32, vp, vp]),
-    "rlhip_dense_frag_weight_bf16": (i32, [vp, i32, i32, vp, vp]),
-    "rlhip_dense_bf16_forward_tiled": (i32, [vp, vp, vp, i32, i64, i32, i32, vp, i32, vp]),
     "rlhip_ppo_default": (i32, [P(PPOCfg)]),
     "rlhip_ppo_nparams": (i64, [i32, P(PPOCfg)]),
     "rlhip_ppo_plan_f32": (i32, [i32, P(PPOCfg), vp, vp, i64, u64, u32, u32, vp, vp, vp, vp, vp]),

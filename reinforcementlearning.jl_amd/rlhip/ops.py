@@ -227,60 +227,3 @@ def mlp2_forward(params, n_in, h, n_out, act, x):
     return out
 
 
-# ------------------------------------------------------------------------------- bf16 MFMA dense
-def _round_up(x, m):
-    return (x + m - 1) // m * m
-
-
-def dense_pack_weight_bf16(w_flux, k, n):
-    """Flux Dense weight (n x k column-major flat f32) -> bf16 Wt (n_pad x k_pad), k contiguous."""
-    k_pad, n_pad = _round_up(k, 16), _round_up(n, 128)
-    wt = torch.empty((n_pad, k_pad), dtype=torch.bfloat16, device=w_flux.device)
-    call("rlhip_dense_pack_weight_bf16", ptr(w_flux), k, n, k_pad, n_pad, ptr(wt), stream_ptr())
-    return wt
-
-
-def soa_to_bf16_rows(x_soa, k_pad=None, batch_pad=None):
-    """(k, batch) f32 SoA -> (batch_pad, k_pad) bf16 rows (zero padded)."""
-    k, batch = x_soa.shape
-    k_pad = k_pad or _round_up(k, 16)
-    batch_pad = batch_pad or _round_up(batch, 128)
-    out = torch.zeros((batch_pad, k_pad), dtype=torch.bfloat16, device=x_soa.device)
-    call("rlhip_soa_f32_to_bf16_rows", ptr(x_soa), batch, k, k_pad, ptr(out), stream_ptr())
-    return out
-
-
-def dense_bf16_forward(x_rows, wt, bias=None, act="relu", out_dtype=torch.bfloat16):
-    """Y = act(X W + b) on the bf16 MFMA path.  x_rows (batch, k) bf16, wt (n, k) bf16 -> (batch, n)."""
-    batch, k = x_rows.shape
-    n = wt.shape[0]
-    y = torch.empty((batch, n), dtype=out_dtype, device=x_rows.device)
-    a = {"relu": 0, "tanh": 1, "identity": 2}[act] if isinstance(act, str) else int(act)
-    call("rlhip_dense_bf16_forward", ptr(x_rows), ptr(wt), ptr(bias), a, batch, k, n, ptr(y),
-         int(out_dtype == torch.bfloat16), stream_ptr())
-    return y
-
-
-def dense_frag_weight_bf16(wt):
-    """row-major bf16 Wt (n, k) -> MFMA B-fragment order (same element count) for dense_bf16_forward_tiled."""
-    n, k = wt.shape
-    wf = torch.empty(n * k, dtype=torch.bfloat16, device=wt.device)
-    call("rlhip_dense_frag_weight_bf16", ptr(wt), k, n, ptr(wf), stream_ptr())
-    return wf
-
-
-def dense_bf16_forward_tiled(x_rows, w_frag, n, bias=None, act="relu", out_dtype=torch.bfloat16):
-    """Y = act(X W + b), LDS-staged tiled MFMA kernel.  x_rows (batch, k) bf16, w_frag from dense_frag_weight_bf16."""
-    batch, k = x_rows.shape
-    y = torch.empty((batch, n), dtype=out_dtype, device=x_rows.device)
-    a = {"relu": 0, "tanh": 1, "identity": 2}[act] if isinstance(act, str) else int(act)
-    call("rlhip_dense_bf16_forward_tiled", ptr(x_rows), ptr(w_frag), ptr(bias), a, batch, k, n, ptr(y),
-         int(out_dtype == torch.bfloat16), stream_ptr())
-    return y
-
-
-def bf16_rows_to_soa(y_rows, n):
-    batch, ld = y_rows.shape
-    out = torch.empty((n, batch), dtype=torch.float32, device=y_rows.device)
-    call("rlhip_bf16_rows_to_soa_f32", ptr(y_rows), batch, n, ld, ptr(out), stream_ptr())
-    return out

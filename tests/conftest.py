@@ -41,14 +41,23 @@ def pytest_collection_modifyitems(config, items):
 # north_star: "within 1e-5 rel for fp32".  For a gradient vector the meaningful relative measure is against the
 # largest entry of the tensor (entries near zero are sums with cancellation): |g - o| <= tol * max|o|.
 # F32_GRAD_TOL is the bar of every f32 VALU path (fixed summation order on the GPU, double accumulation in the
-# oracle); the bf16 MFMA paths round operands to bf16 exactly like the oracle does and differ only by the MFMA's
-# internal summation order: BF16_GRAD_TOL.  Every check appends what it measured to gpurun_out/grad_err.jsonl
-# (scratch) so that the margins are known numbers, not guesses.
-# Measured on MI355X (gpurun_out/grad_err.jsonl, round 2): f32 paths <= 9.4e-8, bf16 MFMA paths <= 1.9e-4 (median 1e-7;
-# the tail is a bf16 rounding flip next to a tanh ulp difference between ocml and glibc).  The bars below keep a 10x /
-# 2.5x margin over what was measured -- a regression by an order of magnitude fails.
+# oracle): measured <= 9.4e-8 (gpurun_out/grad_err.jsonl), bar 1e-6.
+# The bf16 MFMA paths round operands to bf16 exactly like the oracle does and differ only by the MFMA's internal
+# summation order -- EXCEPT where that last-bit difference lands on a decision: a pre-activation within an ulp of zero
+# (relu' flips for one (sample, unit) pair), a bf16 rounding tie, an ocml-vs-glibc tanh ulp.  A flip moves the rows /
+# columns of ONE hidden unit by up to a few 1e-4 of max|g| and leaves every other element at the 1e-7 level.  So the bar
+# has two parts (round-2 verdict: one number for both hid a 2x regression and sat 1.09x above the worst flip):
+#   bulk   the BF16_BULK_Q quantile of |g - o| / max|o| stays below BF16_BULK_TOL  -- arithmetic regressions move this
+#   flips  the elements above the bulk bar are few (a unit's share of the tensor) and below BF16_FLIP_TOL -- a wrong
+#          unit / a wrong tile moves them by O(1e-1)
+# Every check appends what it measured (max, quantiles, count over the bulk bar) to gpurun_out/grad_err.jsonl (scratch)
+# so that the margins are known numbers, not guesses; the values measured in round 3 are in profiles/r03_parity_margins.md.
 F32_GRAD_TOL = 1e-6
-BF16_GRAD_TOL = 5e-4
+BF16_GRAD_TOL = 5e-4   # kept as the name the tests pass; assert_grad_close applies the two-part bar for it
+BF16_BULK_Q = 0.99
+BF16_BULK_TOL = 2e-5
+BF16_FLIP_TOL = 2e-3
+BF16_FLIP_SHARE = 0.01
 
 
 def assert_grad_close(g, o, tol, tag=""):
@@ -61,12 +70,23 @@ def assert_grad_close(g, o, tol, tag=""):
     assert g.shape == o.shape, (g.shape, o.shape)
     assert np.isfinite(g).all(), f"{tag}: non-finite gradient"
     scale = max(float(np.abs(o).max()), 1e-30)
-    err = float(np.abs(g - o).max()) / scale
+    e = np.abs(g - o) / scale
+    err = float(e.max())
+    two_part = tol == BF16_GRAD_TOL
+    bulk = float(np.quantile(e, BF16_BULK_Q))
+    n_over = int((e > BF16_BULK_TOL).sum())
     try:
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "grad_err.jsonl"), "a") as f:
-            f.write(json.dumps({"tag": tag, "n": int(g.size), "err_over_max": err, "tol": tol}) + "\n")
+            f.write(json.dumps({"tag": tag, "n": int(g.size), "err_over_max": err, "tol": tol, "q99": bulk,
+                                "q999": float(np.quantile(e, 0.999)), "n_over_bulk": n_over}) + "\n")
     except OSError:
         pass
-    assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"
+    if not two_part:
+        assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"
+        return
+    assert bulk <= BF16_BULK_TOL, f"{tag}: {BF16_BULK_Q} quantile of |g - o| / max|o| = {bulk:.3e} > {BF16_BULK_TOL:.1e}"
+    assert err <= BF16_FLIP_TOL, f"{tag}: max|g - o| / max|o| = {err:.3e} > {BF16_FLIP_TOL:.1e} (no decision flip is that large)"
+    assert n_over <= max(4, int(BF16_FLIP_SHARE * g.size)), \
+        f"{tag}: {n_over} of {g.size} elements above {BF16_BULK_TOL:.1e} -- more than the rows of a few flipped units"

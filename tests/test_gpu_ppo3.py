@@ -141,23 +141,18 @@ def test_layers3_rejects_unsupported_configs():
         rlhip.PPOPolicy(env, update_freq=4, hidden=128, layers=3)       # 3 actions: not instantiated
 
 
-@pytest.mark.parametrize("tile", ["chained", "producer_consumer"])
 @pytest.mark.parametrize("kind,cont,n,T", [("cartpole", False, 1024, 16), ("pendulum", True, 2048, 24), ("cartpole", False, 100, 7)])
-def test_chained_tile_equals_the_round1_tile(kind, cont, n, T, tile):
+def test_chained_tile_equals_the_round1_tile(kind, cont, n, T):
     """ppo3_gradT_kernel (register-chained tile, persistent workgroups, csrc/ppo3t_kernel.h) against ppo3_grad_kernel
     (one 128-row tile per workgroup) on the same micro-batches: identical roundings, different summation order ->
     gradients within BF16_GRAD_TOL of max|g| per tensor (measured: 1e-7 typical, 1.6e-4 when one of the ~10^6 relu decisions of a 12288-sample micro-batch sits within an ulp of zero and flips), loss numbers within 1e-5; both are pinned to the oracle above.
     Sizes: many tiles per persistent workgroup (pendulum: 12288-sample micro-batches = 96 tiles over <= 128 workgroups
-    with RLHIP_PPO3_WGS unset) and a ragged single-tile case.
-    tile = "producer_consumer": ppo3_gradP_kernel (csrc/ppo3p_kernel.h: six producer waves + two dW2 consumer waves,
-    rounds of 192 samples) under the same bar."""
+    with RLHIP_PPO3_WGS unset) and a ragged single-tile case.  (A / B of two kernels, not parity: both are pinned to
+    the oracle by the tests above.)"""
     import rlhip
 
     force = rlhip._lib.lib.rlhip_debug_ppo3_force128
     force.restype = C.c_int32
-    pick = rlhip._lib.lib.rlhip_debug_ppo3_variant
-    pick.restype = C.c_int32
-    assert pick(1 if tile == "producer_consumer" else 0) == 0
     env, pol = _setup(kind, n, T, n_microbatches=4)
     pol.rollout_()
     pol.gae_()
@@ -173,7 +168,6 @@ def test_chained_tile_equals_the_round1_tile(kind, cont, n, T, tile):
                 out[(variant, mb)] = (pol.grad.cpu().numpy().copy(), pol.losses.cpu().numpy().copy())
     finally:
         force(0)
-        pick(-1)
     for mb in (0, 3):
         (g0, l0), (g1, l1) = out[(0, mb)], out[(1, mb)]
         assert np.all(np.abs(l0 - l1) <= 1e-5 * (1 + np.abs(l1))), (l0, l1)
@@ -191,21 +185,20 @@ def test_chained_tile_equals_the_round1_tile(kind, cont, n, T, tile):
 
 @pytest.mark.parametrize("kind,n,T", [("cartpole", 1024, 16), ("pendulum", 4096, 64)])
 def test_learner_tiles_are_bit_deterministic_run_to_run(kind, n, T):
-    """All three gradient kernels of layers = 3 sum in a fixed order, so two launches on the same micro-batch must agree
-    bit for bit.  This pins a hazard seen while building the producer / consumer tile: with SLP-packed v_pk_fma_f32
-    (op_sel picking the high half of an LDS-loaded register pair) at two waves per SIMD, dW1[:, 1] of 16 lanes came out
-    different from run to run by up to 2e-2 of max|dW1| -- csrc/ppo3.hip is built with -fno-slp-vectorize since."""
+    """Both gradient kernels of layers = 3 sum in a fixed order, so two launches on the same micro-batch must agree bit
+    for bit.  This pins a hazard seen in round 2 (profiles/attic/ppo3p_kernel.h): with SLP-packed v_pk_fma_f32 beside
+    MFMAs, dW1[:, 1] of 16 lanes came out different from run to run by up to 2e-2 of max|dW1| -- every MFMA learner
+    source is built with -fno-slp-vectorize since (build.py; tests/test_no_packed_f32_beside_mfma.py)."""
     import rlhip
 
     force = rlhip._lib.lib.rlhip_debug_ppo3_force128
-    pick = rlhip._lib.lib.rlhip_debug_ppo3_variant
-    force.restype = pick.restype = C.c_int32
+    force.restype = C.c_int32
     env, pol = _setup(kind, n, T, n_microbatches=4)
     pol.rollout_()
     pol.gae_()
     try:
-        for name, f, v in (("round-1 tile", 1, 0), ("chained tile", 0, 0), ("producer / consumer tile", 0, 1)):
-            assert force(f) == 0 and pick(v) == 0
+        for name, f in (("round-1 tile", 1), ("chained tile", 0)):
+            assert force(f) == 0
             runs = []
             for rep in range(6):
                 pol.grad_(rep & 1, 1 + (rep & 1))
@@ -216,4 +209,3 @@ def test_learner_tiles_are_bit_deterministic_run_to_run(kind, n, T):
                 assert np.array_equal(runs[rep][1], runs[rep & 1][1]), f"{name}: losses differ run to run"
     finally:
         force(0)
-        pick(-1)
