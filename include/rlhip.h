@@ -419,7 +419,9 @@ int32_t rlhip_p2p_allreduce_f32(float* data, int64_t n, int64_t cap, int32_t ran
  * rlhip_allreduce_grads: in-place SUM, enqueued on `stream`, bit-identical on every rank on the peer-to-peer path
  * (rank-order summation).  A peer that does not arrive within the timeout makes the call's result NaN and
  * rlhip_comm_check return RLHIP_ETIMEOUT (it reads a host-pinned word: no synchronisation).
- * rlhip_comm_destroy unmaps the peers and frees the own buffer: call it on every rank after a host-side barrier. */
+ * Tear-down, two phases with a host-side barrier before each: barrier -> rlhip_comm_unmap (closes this rank's mappings of
+ * the peers' buffers and its RCCL communicator) -> barrier -> rlhip_comm_destroy (frees the own, IPC-exported buffer: no
+ * peer may still have it mapped).  rlhip_comm_destroy alone does both (world = 1, error paths). */
 typedef void* rlhip_comm_t;
 typedef struct rlhip_comm_desc {
     int32_t rank, world, device, p2p_active, rccl_active;
@@ -441,6 +443,7 @@ int32_t rlhip_comm_check(rlhip_comm_t comm);
 int32_t rlhip_comm_info(rlhip_comm_t comm, rlhip_comm_desc* out_host);
 int32_t rlhip_comm_set_timeout(rlhip_comm_t comm, int64_t timeout_polls);
 int32_t rlhip_comm_advance_seq(rlhip_comm_t comm, uint32_t n_steps);
+int32_t rlhip_comm_unmap(rlhip_comm_t comm);
 int32_t rlhip_comm_destroy(rlhip_comm_t comm);
 
 /* ------------------------------------------------- one DQN vec-step as a single call -- */

@@ -63,6 +63,56 @@ static inline int grid_barrier_capacity(K kernel, int block_threads, size_t dyna
     return (per_cu * cus) / 2;
 }
 
+// Per-DEVICE facts are cached per device: a process may drive several (hipSetDevice), and the LDS opt-in, the CU count and
+// a grid barrier's capacity are properties of the device a launch goes to (process-wide statics made a second
+// device miss the opt-in and inherit the first one's barrier capacity -- too high a capacity deadlocks a spin barrier).
+constexpr int RLHIP_MAX_DEVICES = 64;
+static inline int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % RLHIP_MAX_DEVICES;
+}
+struct PerDeviceInt {  // value per device, -1 = not yet known
+    int v[RLHIP_MAX_DEVICES];
+    PerDeviceInt() {
+        for (int i = 0; i < RLHIP_MAX_DEVICES; ++i) v[i] = -1;
+    }
+};
+// grid-barrier capacity of `kernel` on the current device (RLHIP_GRID_BARRIER_CAP: test hook, forces the barrier-free
+// variants (0) or a small device)
+template <class K>
+static inline int grid_barrier_capacity_cached(PerDeviceInt& cache, K kernel, int block_threads, size_t dynamic_lds = 0) {
+    int& c = cache.v[current_device_slot()];
+    if (c < 0) {
+        c = grid_barrier_capacity(kernel, block_threads, dynamic_lds);
+        const char* e = getenv("RLHIP_GRID_BARRIER_CAP");
+        if (e) c = atoi(e);
+    }
+    return c;
+}
+static inline int device_cu_count() {
+    static PerDeviceInt cache;
+    int& c = cache.v[current_device_slot()];
+    if (c < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 1;
+        c = n < 1 ? 1 : n;
+    }
+    return c;
+}
+// gfx950 has 160 KB of LDS per workgroup; anything above 64 KB of dynamic LDS must be opted into per kernel AND device.
+// done_mask: one static word per call site (= per kernel instantiation), bit = device.
+template <class K>
+static inline int32_t allow_big_lds(K kernel, size_t bytes, unsigned long long* done_mask) {
+    const unsigned long long bit = 1ull << current_device_slot();
+    if (*done_mask & bit) return RLHIP_OK;
+    RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bytes));
+    *done_mask |= bit;
+    return RLHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10, ctr = {idx, blk, t, tag}, key = {seed_lo, seed_hi}.  Same specification as the
 // oracle (oracle/rlo_rng.c) -- shared by specification, not by code; checked by tests/.

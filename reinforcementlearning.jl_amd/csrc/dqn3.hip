@@ -989,12 +989,8 @@ int32_t ppo3_apply_fused(const float* partials, const float* loss_partials, int 
                          float* losses, float inv_b, float wa, float wc, float we, float* params, float* m, float* v,
                          float* beta_pow, uint16_t* packed, void* tail, float clip_norm, float lr, float b1, float b2,
                          float eps, hipStream_t s) {
-    static int cap = -1;
-    if (cap < 0) {
-        cap = grid_barrier_capacity(d3_apply_kernel, 256);
-        const char* e = getenv("RLHIP_GRID_BARRIER_CAP");
-        if (e) cap = atoi(e);
-    }
+    static PerDeviceInt cap_cache;
+    const int cap = grid_barrier_capacity_cached(cap_cache, d3_apply_kernel, 256);
     const int grid = (np + 255) / 256;
     if (grid > cap || grid > 256) return 1;
     D3Apply ap{params, m, v, beta_pow, nullptr, packed, (double*)tail, (unsigned int*)((double*)tail + 256), 1.0f,
@@ -1023,15 +1019,8 @@ constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE
 constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
                             3 * TILE_ELEMS * sizeof(uint16_t);
 
-// gfx950 has 160 KB of LDS per workgroup; anything above 64 KB of dynamic LDS must be opted into per kernel
 template <typename K>
-static int32_t allow_lds(K kernel, size_t bytes, bool* done) {
-    if (*done) return RLHIP_OK;
-    RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    *done = true;
-    return RLHIP_OK;
-}
+static int32_t allow_lds(K kernel, size_t bytes, unsigned long long* done) { return allow_big_lds(kernel, bytes, done); }
 
 }  // namespace rlhip
 
@@ -1094,7 +1083,7 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
                                packed, obs, n, eps, seed, env_id_base, step, actions, q_out);                  \
             break;                                                                                             \
         }                                                                                                      \
-        static bool done_ = false;                                                                             \
+        static unsigned long long done_ = 0;                                                                             \
         int32_t rc_ = allow_lds(mlp3_plan_kernel<NS_, NA_, ACT_>, PLAN_LDS, &done_);                           \
         if (rc_) return rc_;                                                                                   \
         hipLaunchKernelGGL((mlp3_plan_kernel<NS_, NA_, ACT_>), grid, dim3(256), PLAN_LDS, s, params, packed,   \
@@ -1190,19 +1179,19 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     do {                                                                                                \
         if (small) {                                                                                    \
             if (batch >= 65536) {                                                                       \
-                static bool done32b_ = false;                                                           \
+                static unsigned long long done32b_ = 0;                                                           \
                 int32_t rc_ = allow_lds(dqn3_grad32_kernel<NS_, NA_, ACT_, 2>, GRAD32_LDS, &done32b_);   \
                 if (rc_) return rc_;                                                                    \
                 hipLaunchKernelGGL((dqn3_grad32_kernel<NS_, NA_, ACT_, 2>), dim3(nb), dim3(256), GRAD32_LDS, s, g); \
                 break;                                                                                  \
             }                                                                                           \
-            static bool done32_ = false;                                                                \
+            static unsigned long long done32_ = 0;                                                                \
             int32_t rc_ = allow_lds(dqn3_grad32_kernel<NS_, NA_, ACT_, 1>, GRAD32_LDS, &done32_);       \
             if (rc_) return rc_;                                                                        \
             hipLaunchKernelGGL((dqn3_grad32_kernel<NS_, NA_, ACT_, 1>), dim3(nb), dim3(256), GRAD32_LDS, s, g); \
             break;                                                                                      \
         }                                                                                               \
-        static bool done_ = false;                                                                      \
+        static unsigned long long done_ = 0;                                                                      \
         int32_t rc_ = allow_lds(dqn3_grad_kernel<NS_, NA_, ACT_>, GRAD_LDS, &done_);                    \
         if (rc_) return rc_;                                                                            \
         hipLaunchKernelGGL((dqn3_grad_kernel<NS_, NA_, ACT_>), dim3(nb), dim3(256), GRAD_LDS, s, g);    \
@@ -1219,12 +1208,8 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
         // the kernel spins on a grid-wide counter: every workgroup must be resident at once (69 for np = 17 410) --
         // checked against the occupancy of this kernel on this device (grid_barrier_capacity, common.h); beyond it the
         // tail runs as the launches it fuses (bit-identical): reduce, clip + Adam, bf16 re-pack
-        static int cap = -1;
-        if (cap < 0) {
-            cap = grid_barrier_capacity(d3_apply_kernel, 256);
-            const char* e = getenv("RLHIP_GRID_BARRIER_CAP");
-            if (e) cap = atoi(e);
-        }
+        static PerDeviceInt cap_cache;
+        const int cap = grid_barrier_capacity_cached(cap_cache, d3_apply_kernel, 256);
         if ((np + 255) / 256 <= cap) {
             hipLaunchKernelGGL(d3_apply_kernel, dim3((int)((np + 255) / 256)), dim3(256), 0, s, g.partials, g.loss_partials,
                                nb, (int)np, grad_out, loss_out, g.inv_b, *apply);

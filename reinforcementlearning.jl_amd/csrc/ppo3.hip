@@ -668,13 +668,7 @@ __global__ __launch_bounds__(256) void ppo3_reduce_kernel(const float* __restric
 }
 
 template <typename K>
-static int32_t allow_lds3(K kernel, size_t bytes, bool* done) {
-    if (*done) return RLHIP_OK;
-    RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    *done = true;
-    return RLHIP_OK;
-}
+static int32_t allow_lds3(K kernel, size_t bytes, unsigned long long* done) { return allow_big_lds(kernel, bytes, done); }
 
 static int32_t check3(int32_t kind, const rlhip_ppo_cfg* c, PolicyDesc* pd) {
     int32_t rc = make_desc(kind, c, pd);
@@ -700,14 +694,14 @@ static int32_t rollout3_impl(const typename P::cfg_t* cfg, const rlhip_env_state
 #define LAUNCH_R3(ACT_)                                                                                           \
     do {                                                                                                          \
         if (small) {                                                                                              \
-            static bool done32_ = false;                                                                          \
+            static unsigned long long done32_ = 0;                                                                          \
             int32_t rc_ = allow_lds3(ppo3_rollout32_kernel<P, 2, ACT_>, ROLL32_LDS, &done32_);                    \
             if (rc_) return rc_;                                                                                  \
             hipLaunchKernelGGL((ppo3_rollout32_kernel<P, 2, ACT_>), grid, dim3(256), ROLL32_LDS, s, p, a, n, (int)T, \
                                pd.cont, pd.na, params, pd.np_a, seed, env_id_base, vec_step0, tr, pd.gamma, pd.lambda); \
             break;                                                                                                \
         }                                                                                                         \
-        static bool done_ = false;                                                                                \
+        static unsigned long long done_ = 0;                                                                                \
         int32_t rc_ = allow_lds3(ppo3_rollout_kernel<P, 2, ACT_>, ROLL3_LDS, &done_);                             \
         if (rc_) return rc_;                                                                                      \
         hipLaunchKernelGGL((ppo3_rollout_kernel<P, 2, ACT_>), grid, dim3(256), ROLL3_LDS, s, p, a, n, (int)T, pd.cont, \
@@ -853,14 +847,14 @@ static int32_t ppo3_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n,
     g.loss_partials = g.partials + (int64_t)nrows * g.np;
 #define LAUNCH_G3T(NS_, CONT_)                                                                            \
     do {                                                                                                  \
-        static bool donet_ = false;                                                                       \
+        static unsigned long long donet_ = 0;                                                                       \
         int32_t rc_ = allow_lds3(ppo3_gradT_kernel<NS_, 0, CONT_>, GRADT_LDS, &donet_);                   \
         if (rc_) return rc_;                                                                              \
         hipLaunchKernelGGL((ppo3_gradT_kernel<NS_, 0, CONT_>), dim3(2 * nwg), dim3(256), GRADT_LDS, s, g, nwg, ntiles); \
     } while (0)
 #define LAUNCH_G3(NS_, ACT_, CONT_)                                                                       \
     do {                                                                                                  \
-        static bool done_ = false;                                                                        \
+        static unsigned long long done_ = 0;                                                                        \
         int32_t rc_ = allow_lds3(ppo3_grad_kernel<NS_, 2, ACT_, CONT_>, GRAD3_LDS, &done_);               \
         if (rc_) return rc_;                                                                              \
         hipLaunchKernelGGL((ppo3_grad_kernel<NS_, 2, ACT_, CONT_>), dim3((int)nb), dim3(256), GRAD3_LDS, s, g); \

@@ -1391,13 +1391,7 @@ constexpr int P3W_ROWS_W = 128;  // sample ranges (= partial rows) of the dW2 ke
 constexpr int64_t P3W_MAX_TILES = 1 << 20;
 
 template <typename K>
-static int32_t allow_lds_w(K kernel, size_t bytes, bool* done) {
-    if (*done) return RLHIP_OK;
-    RLHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)bytes));
-    *done = true;
-    return RLHIP_OK;
-}
+static int32_t allow_lds_w(K kernel, size_t bytes, unsigned long long* done) { return allow_big_lds(kernel, bytes, done); }
 
 static int p3w_rows_w() { return P3W_ROWS_W; }
 
@@ -1468,7 +1462,7 @@ static int32_t rollout3w_impl(const typename P::cfg_t* cfg, const rlhip_env_stat
     dim3 grid((unsigned)((n + R32W - 1) / R32W));
 #define LAUNCH_RW(ACT_)                                                                                            \
     do {                                                                                                           \
-        static bool done_ = false;                                                                                 \
+        static unsigned long long done_ = 0;                                                                                 \
         int32_t rc_ = allow_lds_w(ppo3w_rollout_kernel<P, 2, ACT_>, ROLLW_LDS, &done_);                            \
         if (rc_) return rc_;                                                                                       \
         hipLaunchKernelGGL((ppo3w_rollout_kernel<P, 2, ACT_>), grid, dim3(NTW), ROLLW_LDS, s, p, a, n, (int)T, pd.cont, \
@@ -1580,14 +1574,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     }
     // one persistent workgroup per CU (the kernels hold 160 - 220 registers per lane: 2 waves per SIMD = one 8-wave workgroup):
     // a second round of workgroups would pay the ~6000-cycle prologue (weights, fragments, first tile) twice
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        RLHIP_CHECK_HIP(hipGetDevice(&dev));
-        RLHIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu < 1) n_cu = 1;
-        if (n_cu > P3W_ROWS_S) n_cu = P3W_ROWS_S;
-    }
+    const int n_cu = device_cu_count() < P3W_ROWS_S ? device_cu_count() : P3W_ROWS_S;
     const int nrowsS = (int)(L.ntiles < n_cu ? L.ntiles : n_cu);
     {
         const int gb = (g.npad + 255) / 256;
@@ -1604,7 +1591,7 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     const int nsr = (int)(L.ntiles < rows_w ? L.ntiles : rows_w);
 #define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
     do {                                                                                                              \
-        static bool d0_ = false, d1_ = false, d2_ = false, d3_ = false;                                               \
+        static unsigned long long d0_ = 0, d1_ = 0, d2_ = 0, d3_ = 0;                                               \
         int32_t rc_;                                                                                                  \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>, FWDW_LDS, &d0_))) return rc_;                \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>, FWDW_LDS, &d1_))) return rc_;                \
@@ -1923,7 +1910,7 @@ int32_t dqn3w_plan(const float* params, const uint16_t* packed, int64_t ns, int6
     const dim3 grid((unsigned)(pt < 512 ? pt : 512));
 #define LAUNCH_PW(NS_, NA_, ACT_)                                                                                       \
     do {                                                                                                                \
-        static bool done_ = false;                                                                                      \
+        static unsigned long long done_ = 0;                                                                                      \
         int32_t rc_ = allow_lds_w(dqn3w_plan_kernel<NS_, NA_, ACT_>, PLANW_LDS, &done_);                                \
         if (rc_) return rc_;                                                                                            \
         hipLaunchKernelGGL((dqn3w_plan_kernel<NS_, NA_, ACT_>), grid, dim3(NTW), PLANW_LDS, s, params, packed, obs, n, eps, \
@@ -1994,20 +1981,13 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
     g.inv_b = 1.0f / (float)batch;
     g.gamma = gamma;
     g.delta = huber_delta;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        RLHIP_CHECK_HIP(hipGetDevice(&dev));
-        RLHIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu < 1) n_cu = 1;
-        if (n_cu > P3W_ROWS_S) n_cu = P3W_ROWS_S;
-    }
+    const int n_cu = device_cu_count() < P3W_ROWS_S ? device_cu_count() : P3W_ROWS_S;
     const int nrowsS = (int)(L.ntiles < n_cu ? L.ntiles : n_cu);
     const int nsr = (int)(L.ntiles < p3w_rows_w() ? L.ntiles : p3w_rows_w());
     const int gb = (g.npad + 255) / 256;
 #define LAUNCH_DW(NS_, NA_, ACT_)                                                                                      \
     do {                                                                                                               \
-        static bool d0_ = false, d1_ = false, d2_ = false, d3_ = false;                                                \
+        static unsigned long long d0_ = 0, d1_ = 0, d2_ = 0, d3_ = 0;                                                \
         int32_t rc_;                                                                                                   \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>, FWDW_LDS, &d0_))) return rc_;                   \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>, FWDW_LDS, &d1_))) return rc_;                   \

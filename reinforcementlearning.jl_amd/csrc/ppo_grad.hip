@@ -419,16 +419,11 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
 }
 
 // all workgroups of the grid-barrier variants must be co-resident: the bound comes from the occupancy of the kernel on the
-// device at hand (grid_barrier_capacity, common.h), queried once per process
+// device at hand (grid_barrier_capacity, common.h), queried once per device
 template <int APPLY>
 static int grid_apply_max_blocks() {
-    static int cap = -1;
-    if (cap < 0) {
-        cap = grid_barrier_capacity(reduce_apply_kernel_ptr<APPLY>(), 1024);
-        const char* e = getenv("RLHIP_GRID_BARRIER_CAP");  // test hook: force the barrier-free variants (0) or a small device
-        if (e) cap = atoi(e);
-    }
-    return cap;
+    static PerDeviceInt cap_cache;
+    return grid_barrier_capacity_cached(cap_cache, reduce_apply_kernel_ptr<APPLY>(), 1024);
 }
 
 static int grad_blocks(int num_tiles) { return num_tiles < MAX_GRAD_BLOCKS ? num_tiles : MAX_GRAD_BLOCKS; }
@@ -703,6 +698,16 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
     RLHIP_REQUIRE(np > 0 && np <= comm_cap, "the gradient does not fit the comm buffer");
     uint32_t seq = seq0;
     bool first = true;
+    if (!is_layers3(cfg)) {
+        // every argument check of the loop below, once, BEFORE the first exchange is enqueued: an invalid call then fails
+        // on every rank alike without consuming a sequence number (a failure after k exchanges would leave this
+        // rank's sequence behind its peers')
+        GradLaunch L;
+        int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, update_ctr * (uint32_t)cfg->n_epochs, 0, workspace, &L,
+                                  nullptr);
+        if (rc) return rc;
+        for (int q = 0; q < world; ++q) RLHIP_REQUIRE(comm_bufs_host[q] != nullptr, "peer buffer is NULL");
+    }
     const int rblocks = (int)((np + RP - 1) / RP);
     const bool fused = !is_layers3(cfg) && rblocks <= grid_apply_max_blocks<APPLY_XCHG>() && world <= 16 &&
                        comm_cap <= (1 << 24) && !RLHIP_ENV_FLAG("RLHIP_P2P_UNFUSED");
@@ -774,8 +779,10 @@ int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
         rc = rlhip_ppo_update_p2p_f32(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace,
                                       grad_scratch, losses_out, d.rank, d.world, d.bufs, d.cap, d.seq, d.timeout_polls,
                                       d.status, stream);
-        if (rc) return rc;
-        return rlhip_comm_advance_seq(comm, n_steps);
+        // the call validates everything before its first exchange; whatever fails later (a launch error) fails with
+        // exchanges already enqueued on the peers: keep this rank's sequence in step with theirs either way
+        const int32_t rc2 = (rc == RLHIP_EINVAL) ? RLHIP_OK : rlhip_comm_advance_seq(comm, n_steps);
+        return rc ? rc : rc2;
     }
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {

@@ -523,7 +523,9 @@ forward(L::HipDQNLearner, x, batch) = forward(L.approximator, x, batch)
 target sync.  Sampling + gather are fused into the gradient launch (same draws as `for batch in trajectory`)."
 function optimise!(L::HipDQNLearner, ::PostActStage, t::HipTrajectory)
     L.vec_steps += 1
-    (length(t) * t.rb.n_env >= L.min_replay_history && L.vec_steps % L.update_freq == 0) || return false
+    # the gate of rlhip/dqn.py should_update_: warm-up, every update_freq-th vec-step, then the trajectory's
+    # InsertSampleRatioController (the reference's `for batch in trajectory` draws a batch only when it allows one)
+    (length(t) * t.rb.n_env >= L.min_replay_history && L.vec_steps % L.update_freq == 0 && on_sample!(t.controller)) || return false
     tn, net = L.approximator, L.approximator.network
     if net.layers == 2
         chk(ccall((:rlhip_dqn_update_f32, LIB), Int32,
@@ -758,7 +760,8 @@ allreduce_grads!(c::HipComm, g::DevBuf{Float32}) =
     chk(ccall((:rlhip_allreduce_grads, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), c.h, g.ptr, g.n, stream()))
 "throws RLHipError(-4) if a peer never arrived at an exchange (the result was NaN-poisoned): no synchronisation"
 check(c::HipComm) = chk(ccall((:rlhip_comm_check, LIB), Int32, (Ptr{Cvoid},), c.h))
-"collective: call on every rank after a barrier of the host's own"
+"collective tear-down in two phases: barrier (the host's own) -> unmap!(c) on every rank -> barrier -> destroy!(c)"
+unmap!(c::HipComm) = (synchronize(); chk(ccall((:rlhip_comm_unmap, LIB), Int32, (Ptr{Cvoid},), c.h)))
 destroy!(c::HipComm) = (synchronize(); chk(ccall((:rlhip_comm_destroy, LIB), Int32, (Ptr{Cvoid},), c.h)); c.h = C_NULL)
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -931,7 +934,8 @@ function _run(agent::Agent{<:HipQBasedPolicy,<:HipTrajectory}, env::HipVecEnv{K,
             on_insert!(t.controller, 1)
             L.vec_steps += 1
             frames = min(length(t) + 1, capacity(t))
-            a.do_update = (frames * env.n >= L.min_replay_history && L.vec_steps % L.update_freq == 0) ? 1 : 0
+            a.do_update = (frames * env.n >= L.min_replay_history && L.vec_steps % L.update_freq == 0 &&
+                           on_sample!(t.controller)) ? 1 : 0
             a.draw_ctr = L.draw_ctr
             a.do_sync = (a.do_update == 1 && (tn.n_optimise + 1) % tn.sync_freq == 0) ? 1 : 0
             chk(ccall((:rlhip_dqn_vec_step_f32, LIB), Int32, (Ref{DqnStepArgs}, Ptr{Cvoid}), a, stream()))

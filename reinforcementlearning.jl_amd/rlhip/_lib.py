@@ -193,6 +193,7 @@ _PROTOS = {
     "rlhip_comm_info": (i32, [vp, P(CommDesc)]),
     "rlhip_comm_set_timeout": (i32, [vp, i64]),
     "rlhip_comm_advance_seq": (i32, [vp, u32]),
+    "rlhip_comm_unmap": (i32, [vp]),
     "rlhip_comm_destroy": (i32, [vp]),
     "rlhip_ppo_update_comm_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp, vp, vp, vp,
                                         vp]),

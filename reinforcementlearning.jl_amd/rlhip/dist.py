@@ -199,7 +199,8 @@ class HipComm:
         return False
 
     def close(self):
-        """collective: every rank unmaps its peers and frees its own buffer after a barrier"""
+        """collective: barrier -> every rank unmaps its peers -> barrier -> every rank frees its own (IPC-exported)
+        buffer: no rank frees a buffer a slower rank still has mapped"""
         import torch.distributed as dist
 
         from ._lib import call
@@ -207,10 +208,16 @@ class HipComm:
         if self.h is None:
             return
         torch.cuda.synchronize()
-        try:
-            dist.barrier(group=self.group)
-        except Exception:  # noqa: BLE001
-            pass
+
+        def barrier():
+            try:
+                dist.barrier(group=self.group)
+            except Exception:  # noqa: BLE001
+                pass
+
+        barrier()
+        call("rlhip_comm_unmap", self.h)
+        barrier()
         call("rlhip_comm_destroy", self.h)
         self.h = None
 

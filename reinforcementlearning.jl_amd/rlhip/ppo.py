@@ -224,7 +224,8 @@ class PPOPolicy:
                     else:  # no transport behind the ABI (e.g. a gloo group whose peer-to-peer validation failed)
                         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                     self.apply_(grad_scale=1.0 / world)
-            comm.check()
+            if comm.ok:  # the torch.distributed fallback never touched the communicator's status word
+                comm.check()
         self.update_ctr += 1
 
     def update_status(self):

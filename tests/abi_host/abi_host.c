@@ -459,6 +459,9 @@ static int run_comm_rank(int rank, int world, const char* dir, int use_rccl) {
     fclose(g_out);
     /* every rank must have stopped using its peers' buffers before anyone frees its own */
     file_barrier(dir, "done", rank, world);
+    CK(rlhip_comm_unmap(comm));
+    /* ... and every rank must have unmapped before anyone frees the buffer it exported */
+    file_barrier(dir, "unmapped", rank, world);
     CK(rlhip_comm_destroy(comm));
     printf("rank %d of %d: p2p %s, rccl %s, 20 exact sums + 2 sharded PPO iterations through the C ABI only\n", rank, world,
            active ? "active" : "off", d.rccl_active ? "yes" : "no");

@@ -41,23 +41,29 @@ def pytest_collection_modifyitems(config, items):
 # north_star: "within 1e-5 rel for fp32".  For a gradient vector the meaningful relative measure is against the
 # largest entry of the tensor (entries near zero are sums with cancellation): |g - o| <= tol * max|o|.
 # F32_GRAD_TOL is the bar of every f32 VALU path (fixed summation order on the GPU, double accumulation in the
-# oracle): measured <= 9.4e-8 (gpurun_out/grad_err.jsonl), bar 1e-6.
+# oracle): measured <= 9.4e-8 (17 checks), bar 1e-6.
 # The bf16 MFMA paths round operands to bf16 exactly like the oracle does and differ only by the MFMA's internal
-# summation order -- EXCEPT where that last-bit difference lands on a decision: a pre-activation within an ulp of zero
-# (relu' flips for one (sample, unit) pair), a bf16 rounding tie, an ocml-vs-glibc tanh ulp.  A flip moves the rows /
-# columns of ONE hidden unit by up to a few 1e-4 of max|g| and leaves every other element at the 1e-7 level.  So the bar
-# has two parts (round-2 verdict: one number for both hid a 2x regression and sat 1.09x above the worst flip):
-#   bulk   the BF16_BULK_Q quantile of |g - o| / max|o| stays below BF16_BULK_TOL  -- arithmetic regressions move this
-#   flips  the elements above the bulk bar are few (a unit's share of the tensor) and below BF16_FLIP_TOL -- a wrong
-#          unit / a wrong tile moves them by O(1e-1)
-# Every check appends what it measured (max, quantiles, count over the bulk bar) to gpurun_out/grad_err.jsonl (scratch)
-# so that the margins are known numbers, not guesses; the values measured in round 3 are in profiles/r03_parity_margins.md.
+# summation order -- EXCEPT where that last-bit difference lands on a decision: a layer-2 pre-activation within an ulp of
+# zero (relu' flips for one (sample, unit) pair), a bf16 rounding tie, an ocml-vs-glibc tanh ulp.  A flip changes ONE
+# sample's backward pass: the flipped unit's W2 row by up to a few 1e-4 of max|g|, and -- through dH1 -- every layer-1
+# element by ~1 / batch of it.  Measured over the 420 bf16 checks of the GPU suite (round 3, profiles/r03_parity_margins.md):
+# median of max|g - o| / max|o| 1.5e-7, 5 % of the checks above 2e-5 (all with the flip signature), worst 1.7e-4
+# (round 2 saw 4.6e-4 once).  Hence two bars (round-2 verdict: one number for both hid a 2x regression and sat 1.09x above
+# the worst flip):
+#   per check   max|g - o| / max|o| <= BF16_GRAD_TOL = 1e-3   (2.2x the worst flip ever seen; a wrong unit / tile is O(1e-1))
+#   per suite   tests/test_gpu_zz_margins.py: the MEDIAN over all bf16 checks of a run <= BF16_MEDIAN_TOL = 5e-7 (3.3x
+#               measured) and at most BF16_FLIP_SHARE = 15 % of them above 2e-5 (3x measured) -- an arithmetic regression
+#               moves every check, a decision flip moves a few
+# Every check appends what it measured to gpurun_out/grad_err.jsonl (scratch), tagged with the pytest session.
+import uuid
+
+SESSION_ID = uuid.uuid4().hex[:12]
 F32_GRAD_TOL = 1e-6
-BF16_GRAD_TOL = 5e-4   # kept as the name the tests pass; assert_grad_close applies the two-part bar for it
-BF16_BULK_Q = 0.99
-BF16_BULK_TOL = 2e-5
-BF16_FLIP_TOL = 2e-3
-BF16_FLIP_SHARE = 0.01
+BF16_GRAD_TOL = 1e-3
+BF16_MEDIAN_TOL = 5e-7
+BF16_FLIP_LEVEL = 2e-5
+BF16_FLIP_SHARE = 0.15
+GRAD_ERR_LOG = os.path.join(ROOT, "gpurun_out", "grad_err.jsonl")
 
 
 def assert_grad_close(g, o, tol, tag=""):
@@ -72,21 +78,11 @@ def assert_grad_close(g, o, tol, tag=""):
     scale = max(float(np.abs(o).max()), 1e-30)
     e = np.abs(g - o) / scale
     err = float(e.max())
-    two_part = tol == BF16_GRAD_TOL
-    bulk = float(np.quantile(e, BF16_BULK_Q))
-    n_over = int((e > BF16_BULK_TOL).sum())
     try:
-        d = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "grad_err.jsonl"), "a") as f:
-            f.write(json.dumps({"tag": tag, "n": int(g.size), "err_over_max": err, "tol": tol, "q99": bulk,
-                                "q999": float(np.quantile(e, 0.999)), "n_over_bulk": n_over}) + "\n")
+        os.makedirs(os.path.dirname(GRAD_ERR_LOG), exist_ok=True)
+        with open(GRAD_ERR_LOG, "a") as f:
+            f.write(json.dumps({"session": SESSION_ID, "tag": tag, "n": int(g.size), "err_over_max": err, "tol": tol,
+                                "q99": float(np.quantile(e, 0.99)), "n_over_2e-5": int((e > BF16_FLIP_LEVEL).sum())}) + "\n")
     except OSError:
         pass
-    if not two_part:
-        assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"
-        return
-    assert bulk <= BF16_BULK_TOL, f"{tag}: {BF16_BULK_Q} quantile of |g - o| / max|o| = {bulk:.3e} > {BF16_BULK_TOL:.1e}"
-    assert err <= BF16_FLIP_TOL, f"{tag}: max|g - o| / max|o| = {err:.3e} > {BF16_FLIP_TOL:.1e} (no decision flip is that large)"
-    assert n_over <= max(4, int(BF16_FLIP_SHARE * g.size)), \
-        f"{tag}: {n_over} of {g.size} elements above {BF16_BULK_TOL:.1e} -- more than the rows of a few flipped units"
+    assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"

@@ -453,3 +453,25 @@ def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip):
         for k in ("p", "m", "v", "g", "bp", "loss", "gn"):
             assert torch.equal(a[k], b[k]), (it, k)
     assert not torch.equal(a["p"], ops.mlp2_init(ns, h, na, 1, 0))
+
+
+@pytest.mark.parametrize("kind,continuous,hidden,act", [("cartpole", False, 256, 0), ("pendulum", True, 256, 1),
+                                                        ("mountaincar", False, 128, 0), ("pendulum", False, 64, 1)])
+def test_two_layer_ppo_gradient_is_bit_deterministic_run_to_run(rl, kind, continuous, hidden, act):
+    """The two-layer learner tile packs actor / critic pairs into v_pk_fma_f32 on purpose (csrc/ppo_grad_tile.h), with
+    the broadcast operands (x_k, dL) taken from either half of LDS-loaded register pairs by op_sel -- the operand form
+    round 2's run-to-run sighting sat on (there: beside MFMAs, at two waves per SIMD).  Fixed summation order, no
+    atomics: eight launches on two alternating micro-batches must agree bit for bit."""
+    n, T = 2048, 16
+    env, pol, _, _ = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden, act=act)
+    pol.rollout_()
+    pol.gae_()
+    runs = []
+    for rep in range(8):
+        pol.grad_(rep & 1, 1 + (rep & 1))
+        torch.cuda.synchronize()
+        runs.append((host(pol.grad).copy(), host(pol.losses).copy()))
+    for rep in range(2, 8):
+        assert np.array_equal(runs[rep][0], runs[rep & 1][0]), "gradient differs run to run"
+        assert np.array_equal(runs[rep][1], runs[rep & 1][1]), "losses differ run to run"
+    assert not np.array_equal(runs[0][0], runs[1][0])

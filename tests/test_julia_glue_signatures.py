@@ -185,3 +185,16 @@ def test_struct_mirrors_have_the_c_layout(jl, c):
     cs, js = c_structs(), jl_structs()
     assert c in cs and jl in js
     assert js[jl] == cs[c], f"{jl} vs {c}:\n julia {js[jl]}\n c     {cs[c]}"
+
+
+def test_julia_dqn_update_gates_consult_the_sample_ratio_controller():
+    """ADVICE r2: both DQN loops of the Julia host (optimise!(::HipDQNLearner) and the fused _run) must gate an update on
+    InsertSampleRatioController.on_sample! like rlhip/dqn.py should_update_ (and the reference's `for batch in trajectory`)"""
+    src = open(GLUE).read()
+    opt = src[src.index("function optimise!(L::HipDQNLearner"):]
+    opt = opt[:opt.index("\nend\n")]
+    assert "on_sample!(t.controller)" in opt
+    fused = src[src.index("a.do_update = ("):]
+    assert "on_sample!(t.controller)" in fused[:300]
+    py = open(os.path.join(ROOT, "reinforcementlearning.jl_amd", "rlhip", "dqn.py")).read()
+    assert "trajectory.controller.on_sample_()" in py
