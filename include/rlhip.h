@@ -134,7 +134,8 @@ int32_t rlhip_mountaincar_default(rlhip_mountaincar_cfg* cfg_host, int32_t conti
  *   episode u32[n] number of resets so far (Philox time counter of the next reset)
  * PACKED MODE (episode == NULL; rlhip_env_reset / rlhip_env_step / rlhip_env_obs only): the reset counter lives in
  * the bits of t[i] that max_steps leaves free -- t[i] = step | episode << tbits, tbits = the smallest b >= 1 with
- * 2^b > max_steps + 1 (CartPole default 200: 8 bits of step, 24 bits = 16.7 M episodes; the counter wraps there).
+ * 2^b > max_steps + 1 (CartPole default 200: 8 bits of step, 24 bits = 16.7 M episodes; the counter SATURATES there --
+ * rlhip_env_packed_episode_capacity -- so a host that may step an instance that often must keep episode[]).
  * Same states, rewards, flags and reset draws as the separate array; an auto-reset then touches no memory that the
  * step kernel does not stream anyway (with episode[] every reset is a scattered 4-byte read-modify-write: +9 % HBM
  * traffic at 2^24 CartPole envs under a random policy).  max_steps < 2^20 - 1.                  */
@@ -146,6 +147,7 @@ typedef struct {
     uint32_t* episode;
 } rlhip_env_state;
 
+int64_t rlhip_env_packed_episode_capacity(int64_t max_steps); /* 2^(32 - tbits) - 1, or -1 (max_steps out of range) */
 int32_t rlhip_env_obs_dim(int32_t kind);   /* cartpole 4, pendulum 3 (sin, cos, thetadot), mountaincar 2, acrobot 6 */
 int32_t rlhip_env_state_dim(int32_t kind); /* cartpole 4, pendulum 2, mountaincar 2, acrobot 4 */
 
@@ -227,6 +229,14 @@ int32_t rlhip_categorical_sample_f32(const float* logits, int64_t na, int64_t n,
                                      int64_t i_stride, const uint8_t* mask, uint64_t seed,
                                      uint32_t env_id_base, uint32_t step, int32_t* actions,
                                      float* logp_out, rlhip_stream_t stream);
+
+/* (net::CategoricalNetwork)(state[, mask]; is_sampling, is_return_log_prob)  RLCore/utils/networks.jl:405-432, masked
+ * methods :459-472, on (na, n) component-major logits in one launch: masked_logits_out (nullable) = logits +
+ * ifelse(mask, 0, typemin) (:461; mask NULL = all true); actions (nullable) = the Gumbel-max draw from them (0-based, same
+ * draws as rlhip_categorical_sample_f32); onehot_out (nullable, needs actions) = Flux.onehotbatch(draw, 1:na). */
+int32_t rlhip_categorical_network_f32(const float* logits, int64_t na, int64_t n, const uint8_t* mask, uint64_t seed,
+                                      uint32_t env_id_base, uint32_t step, float* masked_logits_out, int32_t* actions,
+                                      float* onehot_out, rlhip_stream_t stream);
 
 /* The remaining explorers as batched kernels (BatchExplorer semantics: the inner explorer applied to each column,
  * RLCore/src/policies/explorers/batch_explorer.jl:14-21).  values / mask addressing as rlhip_eps_greedy_select.
@@ -627,6 +637,14 @@ int32_t rlhip_ppo_plan_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, const fl
                            const float* obs, int64_t n, uint64_t seed, uint32_t env_id_base,
                            uint32_t vec_step, int32_t* action_i, float* action_f, float* logp,
                            float* value, rlhip_stream_t stream);
+/* The per-step protocol's pushes into slot t of the time-major PPO traces, one launch each (agent_base.jl:45-59):
+ * PreActStage: state (ns x n SoA), value, action_log_prob, action (action_i or action_f, the other NULL);
+ * logp == NULL and no action = the bootstrap push of (state, value) into slot T.  PostActStage: reward, terminal. */
+int32_t rlhip_ppo_push_preact_f32(const rlhip_ppo_traj* traj_host, int64_t t, int64_t ns, int64_t n, const float* obs,
+                                  const float* value, const float* logp, const int32_t* action_i, const float* action_f,
+                                  rlhip_stream_t stream);
+int32_t rlhip_ppo_push_postact_f32(const rlhip_ppo_traj* traj_host, int64_t t, int64_t n, const float* reward,
+                                   const uint8_t* done, rlhip_stream_t stream);
 /* generalized_advantage_estimation(reward, values, gamma, lambda; dims = 2, terminal) + returns */
 int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                           const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
     for (int k = 0; k < P::SDIM; ++k) stv<T, EPL, NT>(st.s[k], base, s[k]);
     if constexpr (PK) {
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) tv.v[j] = (int32_t)((uint32_t)tv.v[j] | (epv[j] << tbits));
+        for (int j = 0; j < EPL; ++j)  // the counter SATURATES at its field's maximum (it never wraps into the step bits)
+            tv.v[j] = (int32_t)((uint32_t)tv.v[j] | (min(epv[j], 0xFFFFFFFFu >> tbits) << tbits));
     }
     stv<int32_t, EPL, NT>(st.t, base, tv);
     stv<T, EPL, NT>(st.reward, base, rew);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(P p, EnvArrays<T> st, in
 #pragma unroll
     for (int k = 0; k < P::SDIM; ++k) st.s[k][i] = e.s[k];
     if (packed) {
-        st.t[i] = (int32_t)(e.episode << tbits);
+        st.t[i] = (int32_t)(min(e.episode, 0xFFFFFFFFu >> tbits) << tbits);
     } else {
         st.t[i] = 0;
         st.episode[i] = e.episode;
@@ -390,6 +391,15 @@ int32_t rlhip_acrobot_default(rlhip_acrobot_cfg* c) {
     c->max_steps = 200;
     c->nips = 0;
     return RLHIP_OK;
+}
+
+/* resets an instance can count in packed mode before its counter saturates (then every further reset of that instance
+ * re-draws the same initial state): 2^(32 - tbits) - 1.  A host that steps that long must use the episode[] array. */
+int64_t rlhip_env_packed_episode_capacity(int64_t max_steps) {
+    if (max_steps < 1) return -1;
+    const int tbits = packed_tbits(max_steps);
+    if (tbits > 20) return -1;
+    return ((int64_t)1 << (32 - tbits)) - 1;
 }
 
 int32_t rlhip_env_obs_dim(int32_t kind) { return kind == 0 ? 4 : (kind == 1 ? 3 : (kind == 2 ? 2 : 6)); }

@@ -381,6 +381,28 @@ __global__ __launch_bounds__(256) void mlp2_init_kernel(float* __restrict__ p, i
     p[q] = val;
 }
 
+// per-step protocol: one env per lane, grid-stride
+__global__ __launch_bounds__(256) void ppo_push_preact_kernel(TrajPtrs tr, int64_t t, int ns, int64_t n,
+                                                              const float* __restrict__ obs, const float* __restrict__ value,
+                                                              const float* __restrict__ logp,
+                                                              const int32_t* __restrict__ a_i, const float* __restrict__ a_f) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        for (int k = 0; k < ns; ++k) tr.obs[(t * ns + k) * n + i] = obs[(int64_t)k * n + i];
+        tr.value[t * n + i] = value[i];
+        if (logp) tr.logp[t * n + i] = logp[i];
+        if (a_i) tr.action_i[t * n + i] = a_i[i];
+        if (a_f) tr.action_f[t * n + i] = a_f[i];
+    }
+}
+__global__ __launch_bounds__(256) void ppo_push_postact_kernel(TrajPtrs tr, int64_t t, int64_t n,
+                                                               const float* __restrict__ reward,
+                                                               const uint8_t* __restrict__ done) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        tr.reward[t * n + i] = reward[i];
+        tr.terminal[t * n + i] = done[i];
+    }
+}
+
 }  // namespace rlhip
 
 using namespace rlhip;
@@ -459,6 +481,35 @@ int32_t rlhip_ppo_plan_f32(int32_t kind, const rlhip_ppo_cfg* cfg, const float* 
     if (kind == 0) return plan_impl<4>(n, pd, params, obs, seed, env_id_base, vec_step, action_i, action_f, logp, value, s);
     if (kind == 1) return plan_impl<3>(n, pd, params, obs, seed, env_id_base, vec_step, action_i, action_f, logp, value, s);
     return plan_impl<2>(n, pd, params, obs, seed, env_id_base, vec_step, action_i, action_f, logp, value, s);
+}
+
+/* The per-step protocol's pushes into slot t of the time-major PPO traces, one launch each (the fused rollout writes the
+ * same slots itself).  Agent push protocol: RLCore/src/policies/agent/agent_base.jl:45-59 -- PreActStage: state, action,
+ * action_log_prob (+ the critic's value); PostActStage: reward, terminal.  logp == NULL and no action: the bootstrap
+ * push of (state, value) into slot T after the last step. */
+int32_t rlhip_ppo_push_preact_f32(const rlhip_ppo_traj* traj, int64_t t, int64_t ns, int64_t n, const float* obs,
+                                  const float* value, const float* logp, const int32_t* action_i, const float* action_f,
+                                  rlhip_stream_t stream) {
+    RLHIP_REQUIRE(traj && traj->obs && traj->value && obs && value, "NULL argument");
+    RLHIP_REQUIRE(t >= 0 && ns >= 1 && ns <= 8 && n >= 0, "bad slot / shape");
+    RLHIP_REQUIRE(!logp || traj->logp, "trajectory has no logp trace");
+    RLHIP_REQUIRE((!action_i || traj->action_i) && (!action_f || traj->action_f), "trajectory has no action trace");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(ppo_push_preact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), TrajPtrs::from(*traj),
+                       t, (int)ns, n, obs, value, logp, action_i, action_f);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ppo_push_postact_f32(const rlhip_ppo_traj* traj, int64_t t, int64_t n, const float* reward,
+                                   const uint8_t* done, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(traj && traj->reward && traj->terminal && reward && done, "NULL argument");
+    RLHIP_REQUIRE(t >= 0 && n >= 0, "bad slot / shape");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(ppo_push_postact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream),
+                       TrajPtrs::from(*traj), t, n, reward, done);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
 }
 
 static int32_t rollout_entry(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, int64_t T,

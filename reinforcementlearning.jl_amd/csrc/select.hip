@@ -44,6 +44,34 @@ __global__ __launch_bounds__(256) void categorical_kernel(const float* __restric
     if (logp_out) logp_out[i] = lp;
 }
 
+// (net::CategoricalNetwork)(state[, mask]; is_sampling, is_return_log_prob)  RLCore/src/utils/networks.jl:405-432 and the
+// masked methods :459-472 in ONE launch on (na, n) component-major logits: masked logits = logits + ifelse(mask, 0, typemin)
+// (:461); the Gumbel-max draw (sample_categorical :425-432) from them; z = Flux.onehotbatch(draw, 1:na).
+__global__ __launch_bounds__(256) void categorical_network_kernel(const float* __restrict__ logits, int na, int64_t n,
+                                                                  const uint8_t* __restrict__ mask, uint64_t seed,
+                                                                  uint32_t env_id_base, uint32_t step,
+                                                                  float* __restrict__ masked_out,
+                                                                  int32_t* __restrict__ actions, float* __restrict__ onehot) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (masked_out) {
+        for (int k = 0; k < na; ++k) {
+            const float l = logits[(int64_t)k * n + i];
+            const bool m = mask == nullptr || mask[(int64_t)k * n + i] != 0;
+            masked_out[(int64_t)k * n + i] = l + (m ? 0.0f : -__builtin_inff());
+        }
+    }
+    if (actions) {
+        StridedValues l{logits + i, n};
+        StridedMask mk{mask ? mask + i : nullptr, n};
+        float lp;
+        const int a = categorical_sample1(l, mk, na, seed, env_id_base + (uint32_t)i, step, &lp);
+        actions[i] = a;
+        if (onehot)
+            for (int k = 0; k < na; ++k) onehot[(int64_t)k * n + i] = k == a ? 1.0f : 0.0f;
+    }
+}
+
 // ---- the remaining explorers, one lane per env (BatchExplorer: "apply the inner explorer to each column") ----
 //   WeightedExplorer{is_normalized}   RLCore/src/policies/explorers/weighted_explorer.jl:19-33
 //       sample(rng, Weights(values[, 1])): t = rand(rng) * sum; walk the cumulative weights while cw < t
@@ -220,6 +248,19 @@ int32_t rlhip_categorical_sample_f32(const float* logits, int64_t na, int64_t n,
     hipLaunchKernelGGL(categorical_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
                        logits, na, n, k_stride, i_stride, mask, seed, env_id_base, step, actions,
                        logp_out);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_categorical_network_f32(const float* logits, int64_t na, int64_t n, const uint8_t* mask, uint64_t seed,
+                                      uint32_t env_id_base, uint32_t step, float* masked_logits_out, int32_t* actions,
+                                      float* onehot_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(logits != nullptr && (masked_logits_out != nullptr || actions != nullptr), "NULL array");
+    RLHIP_REQUIRE(onehot_out == nullptr || actions != nullptr, "the one-hot output needs the action output");
+    RLHIP_REQUIRE(na >= 1 && na <= 0x7FFFFFFF && n >= 0, "bad shape");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(categorical_network_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream), logits,
+                       (int)na, n, mask, seed, env_id_base, step, masked_logits_out, actions, onehot_out);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

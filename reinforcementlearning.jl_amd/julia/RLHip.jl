@@ -23,7 +23,7 @@ import ReinforcementLearningCore: _run, check!, forward, target, model, PreExper
     EpsilonGreedyExplorer, get_ϵ
 using Random, DomainSets
 
-export HipVecEnv, HipCartPoleEnv, HipPendulumEnv, HipMountainCarEnv, HipAcrobotEnv, HipTrajectory, HipApproximator,
+export HipVecEnv, HipCartPoleEnv, HipPendulumEnv, HipMountainCarEnv, HipAcrobotRK4Env, HipTrajectory, HipApproximator,
     HipTargetNetwork, HipDQNLearner, HipQBasedPolicy, HipPPOPolicy, HipComm, HipEpisodeStats, DevBuf, to_host, to_dev!
 
 const LIB = get(ENV, "RLHIP_LIB", "librlhip.so")
@@ -237,7 +237,7 @@ function HipMountainCarEnv(n::Integer; T = Float32, continuous = false, seed = 0
     make_env(:mountaincar, with_kwargs(c[]; kwargs...), n, T, seed, env_id_base)
 end
 "AcrobotEnv(; T, ...)  x n   RLEnvs/3rd_party/AcrobotEnv.jl:22-70 -- ONE classic RK4 step per act!: parity unpinned"
-function HipAcrobotEnv(n::Integer; T = Float32, seed = 0, env_id_base = 0, kwargs...)
+function HipAcrobotRK4Env(n::Integer; T = Float32, seed = 0, env_id_base = 0, kwargs...)
     c = Ref{AcrobotCfg}()
     chk(ccall((:rlhip_acrobot_default, LIB), Int32, (Ref{AcrobotCfg},), c))
     make_env(:acrobot, with_kwargs(c[]; kwargs...), n, T, seed, env_id_base)
@@ -658,18 +658,17 @@ d2d!(dst::Ptr{Cvoid}, src::Ptr{Cvoid}, bytes) =
     chk(ccall((:rlhip_memcpy_d2d, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst, src, bytes, stream()))
 "PreActStage push: (state, action, action_log_prob) + value of the step about to be taken (blog index.html:15280-15286)"
 function Base.push!(p::HipPPOPolicy, ::PreActStage, env::HipVecEnv)
-    t, n = p.n_pushed, p.n
-    d2d!(offset(p.obs, t * p.ns * n), device_state(env).ptr, 4 * p.ns * n)
-    d2d!(offset(p.value, t * n), p.val.ptr, 4n)
-    d2d!(offset(p.logp, t * n), p.lp.ptr, 4n)
-    is_continuous(env) ? d2d!(offset(p.action_f, t * n), p.a_f.ptr, 4n) : d2d!(offset(p.action_i, t * n), p.a_i.ptr, 4n)
+    cont = is_continuous(env)
+    chk(ccall((:rlhip_ppo_push_preact_f32, LIB), Int32,
+              (Ref{PPOTraj}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              p.traj, p.n_pushed, p.ns, p.n, device_state(env).ptr, p.val.ptr, p.lp.ptr, cont ? C_NULL : p.a_i.ptr,
+              cont ? p.a_f.ptr : C_NULL, stream()))
     nothing
 end
 "PostActStage push: reward, terminal"
 function Base.push!(p::HipPPOPolicy, ::PostActStage, env::HipVecEnv, action = nothing)
-    t, n = p.n_pushed, p.n
-    d2d!(offset(p.rew, t * n), env.rew.ptr, 4n)
-    d2d!(offset(p.terminal, t * n), env.done.ptr, n)
+    chk(ccall((:rlhip_ppo_push_postact_f32, LIB), Int32, (Ref{PPOTraj}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              p.traj, p.n_pushed, p.n, env.rew.ptr, env.done.ptr, stream()))
     p.n_pushed += 1
     p.vec_step += 1
     nothing
@@ -696,8 +695,9 @@ function optimise!(p::HipPPOPolicy, ::PostActStage, env::HipVecEnv; fused_rollou
     p.n_pushed == p.T || return false
     if !fused_rollout           # per-step protocol: bootstrap state / value of step T + 1, then the scan
         plan!(p, env)
-        d2d!(offset(p.obs, p.T * p.ns * p.n), device_state(env).ptr, 4 * p.ns * p.n)
-        d2d!(offset(p.value, p.T * p.n), p.val.ptr, 4 * p.n)
+        chk(ccall((:rlhip_ppo_push_preact_f32, LIB), Int32,
+                  (Ref{PPOTraj}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                  p.traj, p.T, p.ns, p.n, device_state(env).ptr, p.val.ptr, C_NULL, C_NULL, C_NULL, stream()))
         chk(ccall((:rlhip_ppo_gae_f32, LIB), Int32, (Ref{PPOCfg}, Int64, Int64, Ref{PPOTraj}, Ptr{Cvoid}),
                   p.cfg, p.n, p.T, p.traj, stream()))
     end

@@ -4,7 +4,7 @@ declared in include/rlhip.h; importing this package fails loudly if that library
 """
 from . import _lib  # noqa: F401  (raises ImportError when librlhip.so is absent)
 from ._lib import RLHipArgumentError, RLHipError  # noqa: F401
-from .envs import (AcrobotEnv, CartPoleEnv, ContinuousMountainCarEnv, HipVecEnv, MountainCarEnv,  # noqa: F401
+from .envs import (AcrobotRK4Env, CartPoleEnv, ContinuousMountainCarEnv, HipVecEnv, MountainCarEnv,  # noqa: F401
                    PendulumEnv, Space)
 from .core import (Agent, BatchStepsPerEpisode, ComposedHook, DeviceEpisodeStats, DoEveryNSteps, EmptyHook,  # noqa: F401
                    PPOAgent, RandomPolicy, StepsPerEpisode, StopAfterNEpisodes, StopAfterNSeconds,

@@ -136,6 +136,7 @@ _PROTOS = {
     "rlhip_pendulum_default": (i32, [P(PendulumCfg)]),
     "rlhip_mountaincar_default": (i32, [P(MountainCarCfg), i32]),
     "rlhip_acrobot_default": (i32, [P(AcrobotCfg)]),
+    "rlhip_env_packed_episode_capacity": (i64, [i64]),
     "rlhip_env_obs_dim": (i32, [i32]),
     "rlhip_env_state_dim": (i32, [i32]),
     "rlhip_env_reset": (i32, [i32, i32, vp, P(EnvState), i64, u64, u32, vp, vp]),
@@ -230,6 +231,9 @@ _PROTOS = {
     "rlhip_ppo_update_p2p_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp, vp, vp, i32,
                                        i32, vp, i64, u32, i64, vp, vp]),
     "rlhip_ppo_apply_f32": (i32, [i32, P(PPOCfg), i64, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp]),
+    "rlhip_ppo_push_preact_f32": (i32, [P(PPOTraj), i64, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "rlhip_ppo_push_postact_f32": (i32, [P(PPOTraj), i64, i64, vp, vp, vp]),
+    "rlhip_categorical_network_f32": (i32, [vp, i64, i64, vp, u64, u32, u32, vp, vp, vp, vp]),
     "rlhip_ppo_update_status": (i32, [i32, P(PPOCfg), vp, P(i32), vp]),
     "rlhip_ppo_update_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp,
                                    vp, vp, vp]),

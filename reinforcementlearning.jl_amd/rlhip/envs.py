@@ -94,7 +94,7 @@ class HipVecEnv:
         touches no memory the step kernel does not stream anyway.  For the stand-alone env (`act_` / `reset_` / `state`);
         the fused policy kernels (PPOPolicy.rollout_, the fused DQN step) need the separate array."""
         self.kind = KIND[kind] if isinstance(kind, str) else int(kind)
-        self.name = {0: "CartPoleEnv", 1: "PendulumEnv", 2: "MountainCarEnv", 3: "AcrobotEnv"}[self.kind]
+        self.name = {0: "CartPoleEnv", 1: "PendulumEnv", 2: "MountainCarEnv", 3: "AcrobotRK4Env"}[self.kind]
         if T not in (torch.float32, torch.float64):
             raise TypeError("T must be torch.float32 or torch.float64")
         self.T = T
@@ -114,6 +114,9 @@ class HipVecEnv:
             self.tbits += 1
         if self.packed_episode and self.tbits > 20:
             raise ValueError("packed_episode needs max_steps < 2^20 - 1")
+        # packed mode: an instance resets at most once per reset! / act! call, so this many calls cannot saturate a counter
+        self._reset_budget = int(_lib.lib.rlhip_env_packed_episode_capacity(int(self.cfg.max_steps))) if self.packed_episode else None
+        self._reset_calls = 0
         self.device = torch.device(device)
         self.sdim = int(_lib.lib.rlhip_env_state_dim(self.kind))
         self.odim = int(_lib.lib.rlhip_env_obs_dim(self.kind))
@@ -184,6 +187,7 @@ class HipVecEnv:
     def reset_(self, is_force=True):
         """reset!(env).  is_force=False resets only the terminated instances (MultiThreadEnv.reset!)."""
         mask = None if is_force else self._done
+        self._count_reset_call()
         call("rlhip_env_reset", self.kind, self.is_f64, C.byref(self.cfg), C.byref(self._st), self.n,
              self.seed, self.env_id_base, ptr(mask), stream_ptr())
         self._obs_valid = False
@@ -204,10 +208,23 @@ class HipVecEnv:
 
     def act0_(self, actions0):
         """ABI-level act!: 0-based int32 (discrete) or T (continuous) device tensor, no checks."""
+        if self.auto_reset:
+            self._count_reset_call()
         call("rlhip_env_step", self.kind, self.is_f64, C.byref(self.cfg), C.byref(self._st), self.n,
              ptr(actions0), int(self.auto_reset), self.seed, self.env_id_base, ptr(self._last_obs),
              ptr(self._obs), stream_ptr())
         self._obs_valid = True
+
+    def _count_reset_call(self):
+        """packed episode counters saturate after rlhip_env_packed_episode_capacity resets of one instance (every further
+        reset would re-draw the same initial state): refuse the call that could get there instead of going on silently"""
+        if self._reset_budget is None:
+            return
+        self._reset_calls += 1
+        if self._reset_calls > self._reset_budget:
+            raise _lib.RLHipArgumentError(
+                f"packed_episode: {self._reset_calls} reset opportunities exceed the {self._reset_budget} episodes the packed "
+                "counter can number (include/rlhip.h, rlhip_env_state): create the env with packed_episode=False")
 
     def state(self):
         """state(env): (obs_dim, N) device tensor (component-major)."""
@@ -250,6 +267,7 @@ class HipVecEnv:
         self.seed = int(seed)
         if self.packed_episode:
             self._t &= (1 << self.tbits) - 1
+            self._reset_calls = 0
         else:
             self._episode.zero_()
 
@@ -302,8 +320,11 @@ def MountainCarEnv(n_envs=1, **kw):
     return HipVecEnv("mountaincar", n_envs, **kw)
 
 
-def AcrobotEnv(n_envs=1, **kw):
-    """AcrobotEnv(; T, link_length_a, ..., max_torque_noise, max_vel_a, max_vel_b, g, dt, max_steps, book_or_nips)
+def AcrobotRK4Env(n_envs=1, **kw):
+    """NOT the reference's AcrobotEnv: its `act!` integrates with OrdinaryDiffEq's adaptive `solve(ode, RK4())`
+    (AcrobotEnv.jl:128-129, un-vendored step-size control); this env takes ONE classic RK4 step of dt over the same
+    dsdt -- velocities differ by up to ~0.03 rad/s from a converged solution (tests/test_oracle_acrobot.py) -- hence the
+    name.  AcrobotEnv(; T, link_length_a, ..., max_torque_noise, max_vel_a, max_vel_b, g, dt, max_steps, book_or_nips)
     (3rd_party/AcrobotEnv.jl:22-70) x n_envs.  One classic RK4 step per act! (parity unpinned: include/rlhip.h)."""
     return HipVecEnv("acrobot", n_envs, **kw)
 

@@ -102,16 +102,21 @@ class CategoricalNetwork:
         self.actions = None
 
     def __call__(self, state, mask=None, is_sampling=False, is_return_log_prob=False):
-        from .ops import categorical_sample
+        from ._lib import call
+        from .ops import _u8, ptr, stream_ptr
 
-        logits = self.model(state)
-        if mask is not None:
-            logits = logits + torch.where(mask.bool(), 0.0, float("-inf")).to(logits.dtype)
+        lg = self.model(state).contiguous()
+        na, n = lg.shape
+        m8 = _u8(mask)
+        logits = torch.empty_like(lg) if mask is not None else lg
+        z = torch.empty_like(lg) if is_sampling else None
+        if is_sampling:
+            self.actions = torch.empty(n, dtype=torch.int32, device=lg.device)
+        if mask is not None or is_sampling:  # masked logits, Gumbel-max draw and one-hot in ONE launch behind the ABI
+            call("rlhip_categorical_network_f32", ptr(lg), na, n, ptr(m8), self.seed, self.env_id_base, self.step,
+                 ptr(logits) if mask is not None else None, ptr(self.actions) if is_sampling else None, ptr(z),
+                 stream_ptr())
         if not is_sampling:
             return logits
-        lg = logits.contiguous()
-        self.actions, _ = categorical_sample(lg, self.seed, self.step, self.env_id_base, mask=mask, soa=True)
         self.step += 1
-        z = torch.zeros_like(lg)
-        z.scatter_(0, self.actions.long().unsqueeze(0), 1.0)  # Flux.onehotbatch(z, 1:na)
         return (z, logits) if is_return_log_prob else z

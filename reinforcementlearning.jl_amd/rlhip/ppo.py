@@ -124,25 +124,17 @@ class PPOPolicy:
         return self._a_f if env.continuous else self._a_i + 1
 
     def push_preact_(self, env=None):
-        """PreActStage push: state, action, action_log_prob (+ value) of the step about to be taken."""
+        """PreActStage push: state, action, action_log_prob (+ value) of the step about to be taken (one launch)."""
         env = env or self.env
-        t = self.n_pushed
-        tr = self.trajectory
-        tr.obs[t].copy_(env.state())
-        tr.value[t].copy_(self._value)
-        tr.logp[t].copy_(self._logp)
-        if env.continuous:
-            tr.action_f[t, 0].copy_(self._a_f)
-        else:
-            tr.action_i[t].copy_(self._a_i)
+        call("rlhip_ppo_push_preact_f32", C.byref(self.trajectory.c), self.n_pushed, env.odim, env.n, ptr(env.state()),
+             ptr(self._value), ptr(self._logp), None if env.continuous else ptr(self._a_i),
+             ptr(self._a_f) if env.continuous else None, stream_ptr())
 
     def push_postact_(self, env=None):
-        """PostActStage push: reward, terminal."""
+        """PostActStage push: reward, terminal (one launch)."""
         env = env or self.env
-        t = self.n_pushed
-        tr = self.trajectory
-        tr.reward[t].copy_(env.reward())
-        tr.terminal[t].copy_(env._done)
+        call("rlhip_ppo_push_postact_f32", C.byref(self.trajectory.c), self.n_pushed, env.n, ptr(env.reward()),
+             ptr(env._done), stream_ptr())
         self.n_pushed += 1
         self.vec_step += 1
 
@@ -150,8 +142,8 @@ class PPOPolicy:
         """Bootstrap state/value after the last pushed step (the reference pushes state T+1 lazily)."""
         env = env or self.env
         self.plan_(env)  # fills self._value for the current state; draws are not consumed (same step redrawn)
-        self.trajectory.obs[self.T].copy_(env.state())
-        self.trajectory.value[self.T].copy_(self._value)
+        call("rlhip_ppo_push_preact_f32", C.byref(self.trajectory.c), self.T, env.odim, env.n, ptr(env.state()),
+             ptr(self._value), None, None, None, stream_ptr())
         self.n_pushed = 0
         self._adv_ready = False  # per-step protocol: adv / ret are computed by gae_() in update_()
 

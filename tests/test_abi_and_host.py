@@ -291,3 +291,17 @@ def test_debug_timer_sections_follow_the_reference_labels():
     assert "plan!" in str(t) and isinstance(rlhip.timer, tmod.TimerOutput)
     t.reset_()
     assert not t.sections
+
+
+def test_packed_episode_counter_capacity_and_host_guard():
+    """the packed reset counter has 32 - tbits bits.  The ABI states its capacity, the kernels saturate (GPU
+    test), and the host mirror refuses the call that could reach it instead of silently repeating reset draws."""
+    import ctypes as C
+
+    from rlhip import _lib
+
+    cap = _lib.lib.rlhip_env_packed_episode_capacity
+    assert cap(200) == (1 << 24) - 1          # CartPole default: 8 step bits (t reaches 201), 24 counter bits
+    assert cap(1) == (1 << 30) - 1            # 2 step bits
+    assert cap((1 << 20) - 2) == (1 << 12) - 1
+    assert cap((1 << 20) - 1) == -1 and cap(0) == -1

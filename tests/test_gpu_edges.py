@@ -150,3 +150,36 @@ def test_tiny_policies_and_updates(n):
     ocfg = oracle.ppo_default(hidden=64, n_microbatches=2)
     oracle.ppo_rollout(oracle.VecEnv("cartpole", n, seed=1), 4, ocfg, host(p0), otr, 0)
     assert (host(tr.action_i) == otr.action_i).mean() > 0.99
+
+
+def test_packed_episode_counter_saturates_and_the_host_refuses_to_get_there():
+    """packed mode (rlhip_env_state.episode == NULL): the reset counter shares the step-counter word.  At the end of its
+    field it SATURATES -- it never spills into the step bits or wraps to 0 silently -- and the host mirror raises before
+    a run can reach that point (include/rlhip.h; VERDICT r2 hygiene item)."""
+    import rlhip
+    from rlhip._lib import RLHipArgumentError
+
+    n = 512
+    env = rlhip.HipVecEnv("cartpole", n, seed=3, packed_episode=True, max_steps=2)  # tbits = 2: t reaches 3
+    assert env.tbits == 2
+    cap = (1 << 30) - 1
+    env.reset_()
+    # put every counter two short of the end of its field (the step bits stay what reset! wrote)
+    env._t.copy_((env._t & 3) | ((cap - 2) << 2))
+    a = torch.zeros(n, dtype=torch.int32, device="cuda")
+    seen = []
+    for _ in range(12):  # max_steps = 2: every instance terminates (t > 2) and auto-resets every third step
+        env.act0_(a)
+        torch.cuda.synchronize()
+        seen.append(int(env.episode_counter().max()))
+        assert int(env.step_counter().max()) <= 3 and int(env.step_counter().min()) >= 0
+    assert seen[-1] == cap and max(seen) == cap, seen          # reached the maximum and stayed there
+    assert sorted(seen) == seen                                 # never went backwards (no wrap)
+    # the host guard: the call that could saturate a counter is refused
+    env2 = rlhip.HipVecEnv("cartpole", 64, seed=3, packed_episode=True)
+    assert env2._reset_budget == (1 << 24) - 1
+    env2._reset_calls = env2._reset_budget
+    with pytest.raises(RLHipArgumentError):
+        env2.act0_(torch.zeros(64, dtype=torch.int32, device="cuda"))
+    env2.seed_(5)  # Random.seed! restarts the counters
+    env2.act0_(torch.zeros(64, dtype=torch.int32, device="cuda"))

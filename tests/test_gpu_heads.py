@@ -149,7 +149,7 @@ def test_kernels_match_the_frozen_oracle_pins(rl):
         kw = dict(case["kw"])
         if "nips" in kw:
             kw = {"book_or_nips": "nips"}
-        env = rl.AcrobotEnv(6, T=T, seed=21, env_id_base=3, **kw)
+        env = rl.AcrobotRK4Env(6, T=T, seed=21, env_id_base=3, **kw)
         for a, want in zip(case["actions"], case["steps"]):
             env.act0_(torch.tensor(a, dtype=torch.int32, device="cuda"))
             for k in range(4):

@@ -284,9 +284,9 @@ def test_acrobot_torque_noise_and_wrapper(rl, T):
     n = 1000
     for kw in (dict(max_torque_noise=0.7), dict(book_or_nips="nips"), dict(max_torque_noise=0.3, dt=0.1, link_moi=0.8)):
         okw = {("nips" if k == "book_or_nips" else k): (1 if v == "nips" else v) for k, v in kw.items()}
-        env = rl.AcrobotEnv(n, T=T, seed=9, env_id_base=40, max_steps=20, **kw)
+        env = rl.AcrobotRK4Env(n, T=T, seed=9, env_id_base=40, max_steps=20, **kw)
         ref = oracle.VecEnv("acrobot", n, seed=9, env_id_base=40, dtype=npdt, max_steps=20, **okw)
-        assert env.name == "AcrobotEnv" and len(env.action_space()) == 3 and len(env.state_space()) == 6
+        assert env.name == "AcrobotRK4Env" and len(env.action_space()) == 3 and len(env.state_space()) == 6
         assert (host(env.reward()) == -1).all() and not host(env.is_terminated()).any()
         assert host(env.state()) in env.state_space()
         rng = np.random.default_rng(2)

@@ -125,7 +125,7 @@ def test_the_integration_table_entry_points_are_bound():
         src = f.read()
     for t in ("mutable struct HipVecEnv", "mutable struct HipTrajectory", "mutable struct HipApproximator",
               "mutable struct HipTargetNetwork", "mutable struct HipQBasedPolicy", "mutable struct HipPPOPolicy",
-              "function HipCartPoleEnv", "function HipPendulumEnv", "function HipMountainCarEnv", "function HipAcrobotEnv",
+              "function HipCartPoleEnv", "function HipPendulumEnv", "function HipMountainCarEnv", "function HipAcrobotRK4Env",
               "state_space(env::HipVecEnv{:cartpole})", "Base.copy(env::HipVecEnv", "Random.seed!(env::HipVecEnv",
               "function Base.iterate(t::HipTrajectory", "function _run(policy::AbstractPolicy, env::HipVecEnv"):
         assert t in src, f"RLHip.jl lacks `{t}`"
