@@ -216,6 +216,47 @@ def roofline_extras(torch, rlhip):
                               "priority_update_us": round(ms_u * 1e3, 1),
                               "sample_gather_update_us": round(ms_all * 1e3, 1),
                               "prioritized_samples_per_sec": round(batch / (ms_all * 1e-3), 1)}
+    # batch in {32, 512, 4096} -- the small batches are the latency regime of the same kernels
+    # (32 samples = 32 workgroup pairs: a handful of CUs busy; the time is the launch + one HBM round trip per frame pair)
+    small = {}
+    for b in (32, 512):
+        idx_b, key_b, prio_b = tr.sample_prioritized(b, 11, 0)
+        bufs_b = tr.gather(idx_b)
+        cb = [1]
+
+        def smp_b():
+            rlhip._lib.call("rlhip_ring_sample_prioritized", C.byref(tr.rb), ops.ptr(tr.priorities), b, 11, cb[0],
+                            ops.ptr(idx_b), ops.ptr(key_b), ops.ptr(prio_b), s)
+            cb[0] += 1
+
+        def g_b():
+            rlhip._lib.call("rlhip_ring_gather", C.byref(tr.rb), ops.ptr(idx_b), b, ops.ptr(bufs_b[0]), ops.ptr(bufs_b[1]),
+                            ops.ptr(bufs_b[2]), ops.ptr(bufs_b[3]), ops.ptr(bufs_b[4]), s)
+
+        def u_b():
+            rlhip._lib.call("rlhip_sumtree_update", ops.ptr(tr.priorities), cap, ops.ptr(key_b), ops.ptr(prio_b), b, s)
+
+        def all_b():
+            smp_b()
+            g_b()
+            u_b()
+
+        def fresh_b():
+            smp_b()
+            g_b()
+
+        t_s = event_time_ms(smp_b, 20, lib, s)
+        t_g = event_time_ms(fresh_b, 20, lib, s) - t_s
+        t_u = event_time_ms(u_b, 20, lib, s)
+        t_all = event_time_ms(all_b, 20, lib, s)
+        gbb = 2 * (2 * fb + 9) * b / 1e9
+        small[str(b)] = {"batch": b, "us_per_launch": round(t_g * 1e3, 1), "achieved": round(gbb / (t_g * 1e-3), 1),
+                         "unit": "GB/s", "frac": round(gbb / (t_g * 1e-3) / HBM_PEAK_GBS, 4),
+                         "prioritized_sample_us": round(t_s * 1e3, 1), "priority_update_us": round(t_u * 1e3, 1),
+                         "sample_gather_update_us": round(t_all * 1e3, 1),
+                         "prioritized_samples_per_sec": round(b / (t_all * 1e-3), 1)}
+        del idx_b, key_b, prio_b, bufs_b
+    out["frame_gather_u8"]["small_batches"] = small
     del key, prio, keys
     del tr, bufs, idx
     torch.cuda.empty_cache()
@@ -579,14 +620,48 @@ def allreduce_report(torch, pol, world):
             out["abi_rccl"] = {"bytes": big.numel() * 4, "us": round(us, 2),
                                "busbw_gbs": round(2.0 * (world - 1) / world * big.numel() * 4 / us / 1e3, 2)}
             del big
+    SIZES = (4 << 10, 64 << 10, 1 << 20, 16 << 20, 256 << 20)
     sweep = []
-    for nbytes in (4 << 10, 64 << 10, 1 << 20, 16 << 20, 256 << 20):
+    for nbytes in SIZES:
         x = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
         us = timed(lambda: dist.all_reduce(x), 20 if nbytes <= (1 << 20) else 5)
         sweep.append({"bytes": nbytes, "us": round(us, 2),
                       "busbw_gbs": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 2)})
         del x
-    out["library_sweep"] = sweep
+    out["library_sweep"] = sweep  # torch.distributed (RCCL through PyTorch), for reference
+    # the same sweep through the PRODUCT's collective, rlhip_allreduce_grads (csrc/comm.hip), on a communicator whose
+    # exchange buffer takes vectors up to 16 MB: the one-shot peer-to-peer kernel up to there (every rank reads every
+    # peer's buffer: latency-optimal, not bandwidth-optimal), ncclAllReduce of the dlopen'ed RCCL beyond
+    try:
+        from rlhip.dist import HipComm
+
+        big_comm = HipComm.create(pol.process_group, (16 << 20) // 4, g.device)
+        bd = big_comm.info()
+        abi = []
+        for nbytes in SIZES:
+            via_p2p = bool(bd.p2p_active) and nbytes // 4 <= int(bd.cap)
+            if not via_p2p and not bd.rccl_active:  # e.g. a gloo group (no RCCL behind the ABI): nothing carries this size
+                abi.append({"bytes": nbytes, "transport": "none (no RCCL communicator, beyond the exchange buffer)"})
+                continue
+            x = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+            us = timed(lambda: big_comm.all_reduce_(x), 20 if nbytes <= (1 << 20) else 5)
+            abi.append({"bytes": nbytes, "us": round(us, 2), "transport": "p2p kernel" if via_p2p else "ncclAllReduce",
+                        "busbw_gbs": round(2.0 * (world - 1) / world * nbytes / us / 1e3, 2)})
+            del x
+        out["abi_sweep"] = abi
+        out["abi_sweep_p2p"] = {"active": bool(bd.p2p_active), "why": bd.why.decode(), "cap_bytes": int(bd.cap) * 4}
+        if bd.rccl_active and bd.p2p_active:  # both transports at the real gradient size (the small communicator has the p2p one)
+            os.environ["RLHIP_NO_P2P"] = "1"
+            try:
+                rc_comm = HipComm.create(pol.process_group, int(pol.np), g.device)
+                out["abi_us_at_gradient_size_rccl"] = round(timed(lambda: rc_comm.all_reduce_(g), 50), 2)
+                rc_comm.close()
+            finally:
+                del os.environ["RLHIP_NO_P2P"]
+        big_comm.failed() and out.setdefault("abi_sweep_timeout", True)
+        big_comm.close()
+    except Exception as exc:  # noqa: BLE001  -- the report must not cost the bench line
+        out["abi_sweep"] = {"error": repr(exc)}
     out["bounds"] = "ring: one xGMI link (~153 GB/s); direct reduce-scatter + all-gather over 7 links: ~1.07 TB/s egress per GPU"
     return out
 

@@ -428,6 +428,14 @@ def test_bench_two_ranks_on_one_device_prints_the_contract_line():
     assert ar["library_us_at_gradient_size"] > 0 and len(ar["library_sweep"]) == 5
     if d["gradient_allreduce"].startswith("p2p"):
         assert d["p2p_timeouts"] is False and ar["p2p_us_at_gradient_size"] > 0
+    # the sweep through the product's own collective (rlhip_allreduce_grads), next to torch.distributed's
+    sweep = ar["abi_sweep"]
+    assert isinstance(sweep, list) and [r["bytes"] for r in sweep] == [4 << 10, 64 << 10, 1 << 20, 16 << 20, 256 << 20], sweep
+    assert ar["abi_sweep_p2p"]["cap_bytes"] == 16 << 20
+    if ar["abi_sweep_p2p"]["active"]:
+        assert all(r["transport"] == "p2p kernel" and r["us"] > 0 for r in sweep[:4]), sweep
+    assert sweep[4]["transport"].startswith("none")  # gloo group: no RCCL behind the ABI for 256 MB
+    assert "abi_sweep_timeout" not in ar
 
 
 def _grid_barrier_probe():
