@@ -157,12 +157,29 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
     const uint4* src1 = (const uint4*)((const uint8_t*)rb.state + l_off[1]);
     uint4* d0 = (uint4*)(s + b * frame_bytes);
     uint4* d1 = (uint4*)(sn + b * frame_bytes);
-    int64_t n16 = frame_bytes / 16;
-    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {  // streamed once: non-temporal both ways
-        nt_u32x4 x = nt_load16(src0 + i);
-        nt_u32x4 y = nt_load16(src1 + i);
-        nt_store16(d0 + i, x);
-        nt_store16(d1 + i, y);
+    const int64_t n16 = frame_bytes / 16;
+    // Sources are read once: non-temporal loads (no allocation in L2 on the way through).  The destination is a pure
+    // write stream: ORDINARY 16-byte stores -- the L2 then writes whole lines back; non-temporal stores of the same
+    // chunks measured 85 us against 70.5 us per 4096-sample launch (5.4 -> 6.55 TB/s; profiles/r03_store_policy.md).
+    constexpr int U = 2;  // chunk pairs in flight per thread and trip
+    for (int64_t i0 = threadIdx.x; i0 < n16; i0 += 256 * U) {
+        nt_u32x4 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + 256 * u;
+            if (i < n16) {
+                x[u] = nt_load16(src0 + i);
+                y[u] = nt_load16(src1 + i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + 256 * u;
+            if (i < n16) {
+                *reinterpret_cast<nt_u32x4*>(d0 + i) = x[u];
+                *reinterpret_cast<nt_u32x4*>(d1 + i) = y[u];
+            }
+        }
     }
 }
 
@@ -218,23 +235,23 @@ __global__ __launch_bounds__(256) void gather_stacked_kernel(RingView rb, const 
         }
     }
     __syncthreads();
-    const int64_t n16 = frame_bytes / 16;
-    // every lane moves chunk i of ALL frames per trip: n_stack + 1 loads in flight instead of one
-    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
-        nt_u32x4 x[MAX_STACK + 1];
-        const nt_u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int j = 0; j <= MAX_STACK; ++j) {
-            x[j] = zero;
-            if (j <= n_stack && (l_vn[j] | l_vs[j])) x[j] = nt_load16((const uint4*)((const uint8_t*)rb.state + l_off[j]) + i);
-        }
-#pragma unroll
-        for (int j = 0; j <= MAX_STACK; ++j) {
-            if (j > n_stack) continue;
-            // stacks are oldest-first (StackFrames: the newest frame is the last slice)
-            if (j < n_stack) nt_store16((uint4*)(sn + (b * n_stack + (n_stack - 1 - j)) * frame_bytes) + i, l_vn[j] ? x[j] : zero);
-            if (j >= 1) nt_store16((uint4*)(s + (b * n_stack + (n_stack - j)) * frame_bytes) + i, l_vs[j] ? x[j] : zero);
-        }
+    const uint32_t n16 = (uint32_t)(frame_bytes / 16);
+    const uint32_t total = n16 * (uint32_t)(n_stack + 1);
+    const nt_u32x4 zero = {0u, 0u, 0u, 0u};
+    // thread t moves the chunks q = t, t + 256, ... of the flat (frame, chunk) space, so every trip but the last is full
+    // (a 7056-byte frame is 441 chunks: per-frame trips of 256 threads would leave 28 % of the second one idle).  Each
+    // source chunk is read once (non-temporal) and written to both stacks with ORDINARY stores: the outputs are pure
+    // write streams, and non-temporal stores measured 81.5 us against 60.4 us per launch (4.6 -> 6.2 TB/s;
+    // profiles/r03_store_policy.md).
+    for (uint32_t q = threadIdx.x; q < total; q += 256) {
+        const uint32_t j = q / n16, i = q - j * n16;
+        nt_u32x4 x = zero;
+        if (l_vn[j] | l_vs[j]) x = nt_load16((const uint4*)((const uint8_t*)rb.state + l_off[j]) + i);
+        // stacks are oldest-first (StackFrames: the newest frame is the last slice)
+        if ((int)j < n_stack)
+            *reinterpret_cast<nt_u32x4*>((uint4*)(sn + (b * n_stack + (n_stack - 1 - (int)j)) * frame_bytes) + i) = l_vn[j] ? x : zero;
+        if (j >= 1)
+            *reinterpret_cast<nt_u32x4*>((uint4*)(s + (b * n_stack + (n_stack - (int)j)) * frame_bytes) + i) = l_vs[j] ? x : zero;
     }
 }
 

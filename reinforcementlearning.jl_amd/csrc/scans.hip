@@ -90,13 +90,9 @@ __global__ __launch_bounds__(256) void gae_kernel(T* __restrict__ adv, T* __rest
                 T delta = r_[c] + boot - vi;                            // :412
                 T glc = strong_zero_mul(gl, is_continue);
                 gae = delta + glc * gae;                                // :413
-                if (NT) {
-                    __builtin_nontemporal_store(gae, adv + sl * slice_stride + i * elem_stride);  // :414
-                    if (WITH_RETURNS) __builtin_nontemporal_store(gae + vi, ret + sl * slice_stride + i * elem_stride);
-                } else {
-                    adv[sl * slice_stride + i * elem_stride] = gae;     // :414
-                    if (WITH_RETURNS) ret[sl * slice_stride + i * elem_stride] = gae + vi;
-                }
+                // (NT: non-temporal LOADS only -- write streams take ordinary stores, see gae_vec4_kernel)
+                adv[sl * slice_stride + i * elem_stride] = gae;         // :414
+                if (WITH_RETURNS) ret[sl * slice_stride + i * elem_stride] = gae + vi;
                 vnext = vi;
             }
         }
@@ -118,8 +114,10 @@ __global__ __launch_bounds__(256) void gae_vec4_kernel(float* __restrict__ adv, 
         return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
     };
     auto st4 = [](float* p, float a, float b, float c, float d) {
+        // the outputs are pure write streams: ordinary stores (the L2 writes whole lines back) -- non-temporal stores
+        // measured 106 us against 87 us per 2^20 x 32 scan (5.4 -> 6.6 TB/s; profiles/r03_store_policy.md)
         nt_u32x4 u = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
-        nt_store16(p, u);
+        *reinterpret_cast<nt_u32x4*>(p) = u;
     };
     float gae[4] = {0.f, 0.f, 0.f, 0.f};
     float vnext[4];
