@@ -122,9 +122,9 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
             "terminated_per_step": round(done_frac, 4), "without_terminations": no_term}
 
 
-# PMC measurement of the env-step kernel (tools/pmc.sh + tools/envstep.py; profiles/r02_pmc_env_step.md), valid for
+# PMC measurement of the env-step kernel (tools/pmc_env.sh + tools/envstep.py; profiles/r03_pmc.md), valid for
 # the kernel sources whose sha256 (first 16 hex digits over csrc/envs.hip + csrc/env_device.h) is `sha`
-PMC_TRAFFIC = {"sha": "79f48aed59ea847b", "n_envs": 1 << 24, "bytes": 822261248.0, "source": "profiles/r02_pmc_env_step.md"}
+PMC_TRAFFIC = {"sha": "07354178c3f248c4", "n_envs": 1 << 24, "bytes": 822206566.4, "source": "profiles/r03_pmc.md"}
 
 
 def env_kernel_sha():
