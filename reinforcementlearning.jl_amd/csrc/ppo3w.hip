@@ -237,6 +237,16 @@ __device__ __forceinline__ void load_x_from(const float* __restrict__ xg, int np
 #pragma unroll
     for (int k = 0; k < NS; ++k) x[k] = xg[(int64_t)k * npad + (int64_t)tile * RW + lane];
 }
+// the same from the time-major trajectory traces obs (T + 1, NS, n): sample q = t n + env (value pass, NET == 4)
+template <int NS>
+__device__ __forceinline__ void load_x_traj(const float* __restrict__ obs, int64_t n, uint32_t total, int tile, int lane,
+                                            float (&x)[NS]) {
+    uint32_t q = (uint32_t)tile * RW + (uint32_t)lane;
+    q = q < total ? q : total - 1;  // padding rows of the last tile re-read the last sample (their output is not stored)
+    const uint32_t t = q / (uint32_t)n, e = q - t * (uint32_t)n;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) x[k] = obs[((int64_t)t * NS + k) * n + e];
+}
 template <int NS>
 __device__ __forceinline__ void load_x(const P3WArgs& g, int tile, int lane, float (&x)[NS]) {
     load_x_from<NS>(g.xg, g.npad, tile, lane, x);
@@ -289,7 +299,9 @@ constexpr size_t FWDW_LDS = (MAXO * RW + WV * MAXO * RW + SMALLWW + WV * RW * TP
 template <int NS, int NOUT, int ACT, int CONT, int NET>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     // NET: 0 PPO actor, 1 PPO critic (second net of the pair), 2 DQN target network (forward only: TD target y -> sg[0]),
-    // 3 DQN online network (Huber loss on Q(s, a) - y).  Per-sample inputs sg[0..3]: PPO {old log-prob, advantage, return,
+    // 3 DQN online network (Huber loss on Q(s, a) - y), 4 PPO critic forward only over the trajectory's observations
+    // (the rollout's batched value pass: V(s) -> sg[q], sg = the value trace; W2 fragments converted from the f32 master
+    // weights, no packed image needed).  Per-sample inputs sg[0..3]: PPO {old log-prob, advantage, return,
     // action}; DQN {y, reward, terminal (0 / 1), action bits}
     W3_MARK(0, 8, NET == 0);
     extern __shared__ __attribute__((aligned(16))) char smw[];
@@ -304,20 +316,23 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     const int col = 32 * w + r;
     float* l_tw = l_t + w * RW * TPW;
     uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);
-    const float* pnet = NET == 2 ? g.tparams : g.params + (NET == 1 ? g.np_a : 0);
+    const float* pnet = NET == 2 ? g.tparams : g.params + ((NET == 1 || NET == 4) ? g.np_a : 0);
     const float* xsrc = NET == 2 ? g.xg2 : g.xg;
     // every global load of the prologue is issued before the first wait: fragments, tile 0's inputs, the small tensors
     bf16x8 bw[KSW];
-    load_frags_w(NET == 2 ? g.tpacked : g.packed + (NET == 1 ? 2 * HW * HW : 0), w, lane, bw);
+    if (NET == 4) load_frags_f32(pnet + HW * NS + HW, w, lane, bw);
+    else load_frags_w(NET == 2 ? g.tpacked : g.packed + (NET == 1 ? 2 * HW * HW : 0), w, lane, bw);
     const int stride = gridDim.x, last = g.ntiles - 1;
     // lane = sample row: the observation feeds layer 1 straight from registers (row1 == lane); log-prob / advantage / action
     // or the return feed the loss line on wave 0.  Each is re-requested for the NEXT tile right after its last use, i.e.
     // most of a pass (~9000 cycles) ahead of its next use.
     float xr[NS], sr0, sr1 = 0.0f, sr2 = 0.0f;
-    load_x_from<NS>(xsrc, g.npad, blockIdx.x, lane, xr);
+    if (NET == 4) load_x_traj<NS>(g.obs, g.n, g.bm, blockIdx.x, lane, xr);
+    else load_x_from<NS>(xsrc, g.npad, blockIdx.x, lane, xr);
     auto load_s = [&](int tile_) __attribute__((always_inline)) {
         const int64_t q0 = (int64_t)tile_ * RW + lane;
-        if (NET == 0) {
+        if (NET == 4) {
+        } else if (NET == 0) {
             sr0 = g.sg[q0];
             sr1 = g.sg[(int64_t)g.npad + q0];
             sr2 = g.sg[3 * (int64_t)g.npad + q0];
@@ -358,7 +373,8 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             float x[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) x[i] = xr[i];
-            load_x_from<NS>(xsrc, g.npad, tnext, lane, xr);
+            if (NET == 4) load_x_traj<NS>(g.obs, g.n, g.bm, tnext, lane, xr);
+            else load_x_from<NS>(xsrc, g.npad, tnext, lane, xr);
             uint16_t* dst = l_H + row1 * PW + u0;
 #pragma unroll
             for (int h8 = 0; h8 < 4; ++h8) {
@@ -526,6 +542,8 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 l_dq[s] = dvout;
                 s_red[0] += dvout;
                 s_red[NOUT] += sq;
+            } else if (NET == 4) {  // V(s) of sample q = t n + env: the value trace is (T + 1, n) contiguous
+                if (valid) g.sg[(int64_t)tile * RW + s] = oa[0];
             } else if (NET == 2) {  // y = r + gamma (1 - terminal) max_a' Qt(s', a')
                 float mx = oa[0];
 #pragma unroll
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
         }
         load_s(tnext);  // the next tile's loss inputs (every wave: uniform streams; wave 0 uses them)
-        if (NET == 2) continue;  // forward only: the other waves are already in the next pass's layer 1
+        if (NET == 2 || NET == 4) continue;  // forward only: the other waves are already in the next pass's layer 1
         __syncthreads();  // D: dL/d(head outputs) of the tile
         W3_STAMP(0, 5);
         // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32) -> db2; dz2 -> bf16: fragments straight to global,
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     }
 #undef W3_STRIDE
     W3_MARK(0, 10, NET == 0);
-    if (NET == 2) return;
+    if (NET == 2 || NET == 4) return;
     // ---- this workgroup's partial row: b2, W3, b3 and the loss sums ----
     const int sb2 = HW * NS + HW, sW3 = sb2 + HW, sb3 = sW3 + NOUT * HW;
     float* rowS = g.partS + (int64_t)blockIdx.x * g.npS + (NET == 1 ? g.nS_a : 0);
@@ -1186,7 +1204,10 @@ constexpr size_t ROLLW_NOISE_OFF = (((4 * R32W + NPARTW * 4 * R32W + 2 * R32W * 
                                      (2 * R32W * PW) * sizeof(uint16_t)) + 15) & ~(size_t)15;
 constexpr size_t ROLLW_LDS = ROLLW_NOISE_OFF + 2 * NCHW * R32W * MAXO * sizeof(double);
 
-template <class P, int NOUT_A, int ACT>
+// CRIT = false: the actor alone (one set of W2 fragments resident: no register spills, half the layer-1 / MFMA / head work
+// on the per-step critical path); the values V(s_0 .. s_T) then come from ONE batched pass over the trajectory's
+// observations (ppo3w_fwd_kernel<.., 4>) and the GAE scan from its own launch -- V is needed by nobody during the rollout.
+template <class P, int NOUT_A, int ACT, bool CRIT>
 __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float> st, int64_t n, int T, int cont, int na,
                                                             const float* __restrict__ params, int64_t np_a, uint64_t seed,
                                                             uint32_t env_id_base, uint32_t vec_step0, TrajPtrs tr, float gamma,
@@ -1206,9 +1227,9 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
     const int r = lane & 31, kb = lane >> 5;
     const Mlp3W ma = stage_small_w(params, NS, NOUT_A, l_w, tid);
     const Mlp3W mc = stage_small_w(params + np_a, NS, 1, l_w + SMALLWW, tid);
-    bf16x8 bwa[KSW], bwc[KSW];
+    bf16x8 bwa[KSW], bwc[CRIT ? KSW : 1];
     load_frags_f32(params + HW * NS + HW, w, lane, bwa);
-    load_frags_f32(params + np_a + HW * NS + HW, w, lane, bwc);
+    if constexpr (CRIT) load_frags_f32(params + np_a + HW * NS + HW, w, lane, bwc);
 
     const int64_t env = (int64_t)blockIdx.x * R32W + tid;
     const bool active = tid < R32W && env < n;
@@ -1250,6 +1271,7 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
                 if (active) tr.obs[((int64_t)t * NS + k) * n + env] = x[k];
             }
         }
+        if (!CRIT && t == T) break;  // the last pass only records s_T (its value comes from the batched pass)
         __syncthreads();
         // ---- layer 1 of both nets, 16 units per thread ----
         {
@@ -1257,7 +1279,7 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
 #pragma unroll
             for (int i = 0; i < NS; ++i) x[i] = l_x[i * R32W + row1];
 #pragma unroll
-            for (int net = 0; net < 2; ++net) {
+            for (int net = 0; net < (CRIT ? 2 : 1); ++net) {
                 if (net == 0 && t == T) continue;  // the last pass only needs V(s_T)
                 const Mlp3W& m = net ? mc : ma;
                 uint16_t* dst = (net ? l_Hc : l_Ha) + row1 * PW + u0;
@@ -1298,14 +1320,16 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(apa + 16 * ks);
                     aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwa[ks], aa, 0, 0, 0);
                 }
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(apc + 16 * ks);
-                ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bwc[ks], ac, 0, 0, 0);
+                if constexpr (CRIT) {
+                    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(apc + 16 * ks);
+                    ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bwc[ks], ac, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = mfma_row(q, kb);
                 if (t < T) l_h2a[row * LDH2W + colw] = act_fwd_t<ACT>(aa[q] + b2a);
-                l_h2c[row * LDH2W + colw] = act_fwd_t<ACT>(ac[q] + b2c);
+                if constexpr (CRIT) l_h2c[row * LDH2W + colw] = act_fwd_t<ACT>(ac[q] + b2c);
             }
         }
         __syncthreads();
@@ -1318,8 +1342,11 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
             const float* hc = l_h2c + row1 * LDH2W + 16 * part;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 vc = *reinterpret_cast<const float4*>(hc + 4 * c4);
-                const float hcv[4] = {vc.x, vc.y, vc.z, vc.w};
+                float hcv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (CRIT) {
+                    const float4 vc = *reinterpret_cast<const float4*>(hc + 4 * c4);
+                    hcv[0] = vc.x, hcv[1] = vc.y, hcv[2] = vc.z, hcv[3] = vc.w;
+                }
                 float hav[4] = {0.f, 0.f, 0.f, 0.f};
                 if (t < T) {
                     const float4 va = *reinterpret_cast<const float4*>(ha + 4 * c4);
@@ -1328,27 +1355,29 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int j = 16 * part + 4 * c4 + c;
-                    pc = fmaf(mc.W3[j], hcv[c], pc);
+                    if constexpr (CRIT) pc = fmaf(mc.W3[j], hcv[c], pc);
 #pragma unroll
                     for (int o = 0; o < NOUT_A; ++o) pa[o] = fmaf(ma.W3[o + NOUT_A * j], hav[c], pa[o]);
                 }
             }
 #pragma unroll
             for (int o = 0; o < NOUT_A; ++o) l_part[(part * 4 + o) * R32W + row1] = pa[o];
-            l_part[(part * 4 + NOUT_A) * R32W + row1] = pc;
+            if constexpr (CRIT) l_part[(part * 4 + NOUT_A) * R32W + row1] = pc;
         }
         __syncthreads();
         if (tid < R32W) {
             float out[NO];
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
+            for (int o = 0; o < (CRIT ? NO : NOUT_A); ++o) {
                 float acc = l_part[o * R32W + tid];
 #pragma unroll
                 for (int pp = 1; pp < NPARTW; ++pp) acc += l_part[(pp * 4 + o) * R32W + tid];
                 out[o] = acc + (o < NOUT_A ? ma.b3[o] : mc.b3[0]);
             }
-            const float v = out[NOUT_A];
-            if (active) tr.value[(int64_t)t * n + env] = v;
+            if constexpr (CRIT) {
+                const float v = out[NOUT_A];
+                if (active) tr.value[(int64_t)t * n + env] = v;
+            }
             if (t < T) {
                 float oa[MAXO];
 #pragma unroll
@@ -1371,7 +1400,7 @@ __global__ __launch_bounds__(NTW) void ppo3w_rollout_kernel(P p, EnvArrays<float
         // no barrier here (as ppo3_rollout32_kernel): the next pass rewrites l_x from the same 32 lanes in program order and
         // every other buffer only after the next pass's barriers
     }
-    if (active && T > 0 && tr.adv && tr.ret)  // GAE + returns fused into the rollout launch (gae_device.h)
+    if (CRIT && active && T > 0 && tr.adv && tr.ret)  // GAE + returns fused into the rollout launch (gae_device.h)
         gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, gamma, lambda);
     if (active) {
 #pragma unroll
@@ -1460,18 +1489,42 @@ static int32_t rollout3w_impl(const typename P::cfg_t* cfg, const rlhip_env_stat
     EnvArrays<float> a = EnvArrays<float>::from(*st);
     TrajPtrs tr = TrajPtrs::from(*traj);
     dim3 grid((unsigned)((n + R32W - 1) / R32W));
+    constexpr int NS = P::ODIM;
+    // 1. the actor's rollout: T vec-steps in one launch (obs, action, log-prob, reward, terminal traces)
+    // 2. V(s_0 .. s_T): one batched critic pass over the (T + 1) n recorded observations (MFMA forward, persistent
+    //    workgroups, one per CU)
+    // 3. the GAE + returns scan (the kernel of rlhip_ppo_gae_f32)
+    P3WArgs g{};
+    g.obs = traj->obs;
+    g.params = params;
+    g.np_a = pd.np_a;
+    g.n = n;
+    g.sg = traj->value;
+    const int64_t total = (T + 1) * n;
+    RLHIP_REQUIRE(traj->value != nullptr && traj->obs != nullptr, "trajectory array is NULL");
+    RLHIP_REQUIRE(total <= 0x7FFFFFFFll, "(T + 1) n out of range");
+    g.bm = (uint32_t)total;
+    g.ntiles = (int)((total + RW - 1) / RW);
+    g.npad = g.ntiles * RW;
+    const int n_cu = device_cu_count() < P3W_ROWS_S ? device_cu_count() : P3W_ROWS_S;
+    const int nwg = g.ntiles < n_cu ? g.ntiles : n_cu;
 #define LAUNCH_RW(ACT_)                                                                                            \
     do {                                                                                                           \
-        static unsigned long long done_ = 0;                                                                                 \
-        int32_t rc_ = allow_lds_w(ppo3w_rollout_kernel<P, 2, ACT_>, ROLLW_LDS, &done_);                            \
+        static unsigned long long done_ = 0, donev_ = 0;                                                           \
+        int32_t rc_ = allow_lds_w(ppo3w_rollout_kernel<P, 2, ACT_, false>, ROLLW_LDS, &done_);                     \
         if (rc_) return rc_;                                                                                       \
-        hipLaunchKernelGGL((ppo3w_rollout_kernel<P, 2, ACT_>), grid, dim3(NTW), ROLLW_LDS, s, p, a, n, (int)T, pd.cont, \
+        if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS, 1, ACT_, 0, 4>, FWDW_LDS, &donev_))) return rc_;               \
+        hipLaunchKernelGGL((ppo3w_rollout_kernel<P, 2, ACT_, false>), grid, dim3(NTW), ROLLW_LDS, s, p, a, n, (int)T, pd.cont, \
                            pd.na, params, pd.np_a, seed, env_id_base, vec_step0, tr, pd.gamma, pd.lambda);         \
+        hipLaunchKernelGGL((ppo3w_fwd_kernel<NS, 1, ACT_, 0, 4>), dim3(nwg), dim3(NTW), FWDW_LDS, s, g);           \
     } while (0)
     if (pd.act == 0) LAUNCH_RW(0);
     else LAUNCH_RW(1);
 #undef LAUNCH_RW
     RLHIP_LAUNCH_CHECK();
+    if (T > 0 && traj->adv && traj->ret)
+        return rlhip_gae_returns_f32(traj->adv, traj->ret, traj->reward, traj->value, traj->terminal, n, T, pd.gamma,
+                                     pd.lambda, (rlhip_stream_t)s);
     return RLHIP_OK;
 }
 

@@ -50,7 +50,11 @@ def pytest_collection_modifyitems(config, items):
 # median of max|g - o| / max|o| 1.5e-7, 5 % of the checks above 2e-5 (all with the flip signature), worst 1.7e-4
 # (round 2 saw 4.6e-4 once).  Hence two bars (round-2 verdict: one number for both hid a 2x regression and sat 1.09x above
 # the worst flip):
-#   per check   max|g - o| / max|o| <= BF16_GRAD_TOL = 1e-3   (2.2x the worst flip ever seen; a wrong unit / tile is O(1e-1))
+#   per check   max|g - o| / max|o| <= BF16_GRAD_TOL = 2^-8 = 3.9e-3: ONE bf16 ulp.  A flipped rounding of dz2[s][j] moves
+#               column j of dW2 by ulp(dz2[s][j]) x h1[s][:], i.e. by at most one bf16 ulp of that sample's share of max|g|
+#               -- when one sample dominates a small micro-batch (432 samples, an advantage of -65 against a typical -5:
+#               tests/test_gpu_ppo3w.py pendulum / tanh, measured 2.6e-3 with the signature "one column, every row")
+#               the share approaches 1.  A wrong unit / wrong tile is O(1e-1): 25x above the bar.
 #   per suite   tests/test_gpu_zz_margins.py: the MEDIAN over all bf16 checks of a run <= BF16_MEDIAN_TOL = 5e-7 (3.3x
 #               measured) and at most BF16_FLIP_SHARE = 15 % of them above 2e-5 (3x measured) -- an arithmetic regression
 #               moves every check, a decision flip moves a few
@@ -59,7 +63,7 @@ import uuid
 
 SESSION_ID = uuid.uuid4().hex[:12]
 F32_GRAD_TOL = 1e-6
-BF16_GRAD_TOL = 1e-3
+BF16_GRAD_TOL = 2.0 ** -8
 BF16_MEDIAN_TOL = 5e-7
 BF16_FLIP_LEVEL = 2e-5
 BF16_FLIP_SHARE = 0.15

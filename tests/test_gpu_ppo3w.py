@@ -204,3 +204,26 @@ def test_three_layer_ppo_learns_cartpole(hidden):
     print(f"hidden {hidden}: episode length {first:.1f} -> {ep_len:.1f}")
     assert torch.isfinite(pol.params).all()
     assert ep_len > 2.0 * first, f"episode length {first:.1f} -> {ep_len:.1f}"
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+@pytest.mark.parametrize("kind,cont,n,T", [("cartpole", False, 96, 9), ("pendulum", True, 96, 9), ("pendulum", True, 4096, 5)])
+def test_value_trace_is_the_critic_forward_on_the_recorded_observations(kind, cont, n, T, act):
+    """round 3: the rollout kernel runs the actor alone; V(s_0 .. s_T) come from ONE batched critic pass over the
+    (T + 1) n recorded observations (ppo3w_fwd_kernel mode 4).  Every entry of the value trace -- every time step, every
+    env, the ragged last tile -- against the oracle's 3-layer forward on the SAME observations."""
+    a = {"relu": 0, "tanh": 1}[act]
+    env, pol = _setup(kind, n, T, act=a)
+    pol.rollout_()
+    tr = pol.trajectory
+    obs = tr.obs.cpu().numpy()                      # (T + 1, ns, n)
+    ns = env.odim
+    x = obs.transpose(1, 0, 2).reshape(ns, (T + 1) * n)
+    pc = pol.params.cpu().numpy()[pol.np_actor:]
+    ref = oracle.mlp3_forward(pc, ns, H, 1, a, x).reshape(T + 1, n)
+    v = tr.value.cpu().numpy()
+    err = np.abs(v - ref) / (1 + np.abs(ref))
+    if act == "relu":
+        assert err.max() <= 2e-5, err.max()
+    else:  # tanh: the rare bf16 rounding flip of an h1 element (ocml vs glibc tanhf ulps)
+        assert (err <= 2e-5).mean() >= 0.999 and err.max() <= 5e-3, ((err <= 2e-5).mean(), err.max())
