@@ -247,6 +247,38 @@ __device__ __forceinline__ void load_x_traj(const float* __restrict__ obs, int64
 #pragma unroll
     for (int k = 0; k < NS; ++k) x[k] = obs[((int64_t)t * NS + k) * n + e];
 }
+// The observations of a tile as the B operand of layer 1 on v_mfma_f32_32x32x2_f32 (D[unit][sample] = b1 + W1 x):
+// lane (r = lane & 31, kb = lane >> 5) holds x[component kb + 2 ks] of sample 32 rt + r in xm[rt][ks] -- NS loads per lane
+// like the row-per-lane layout, straight from the component planes.  A component index >= NS (odd NS) is clamped to a real
+// component; its A operand (the W1 column) is zero.
+template <int NS>
+__device__ __forceinline__ void load_xm_from(const float* __restrict__ xg, int npad, int tile, int lane,
+                                             float (&xm)[2][(NS + 1) / 2]) {
+    const int r = lane & 31, kb = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < (NS + 1) / 2; ++ks) {
+            const int kk = min(2 * ks + kb, NS - 1);
+            xm[rt][ks] = xg[(int64_t)kk * npad + (int64_t)tile * RW + 32 * rt + r];
+        }
+}
+template <int NS>
+__device__ __forceinline__ void load_xm_traj(const float* __restrict__ obs, int64_t n, uint32_t total, int tile, int lane,
+                                             float (&xm)[2][(NS + 1) / 2]) {
+    const int r = lane & 31, kb = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        uint32_t q = (uint32_t)tile * RW + (uint32_t)(32 * rt + r);
+        q = q < total ? q : total - 1;
+        const uint32_t t = q / (uint32_t)n, e = q - t * (uint32_t)n;
+#pragma unroll
+        for (int ks = 0; ks < (NS + 1) / 2; ++ks) {
+            const int kk = min(2 * ks + kb, NS - 1);
+            xm[rt][ks] = obs[((int64_t)t * NS + kk) * n + e];
+        }
+    }
+}
 template <int NS>
 __device__ __forceinline__ void load_x(const P3WArgs& g, int tile, int lane, float (&x)[NS]) {
     load_x_from<NS>(g.xg, g.npad, tile, lane, x);
@@ -326,9 +358,10 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     // lane = sample row: the observation feeds layer 1 straight from registers (row1 == lane); log-prob / advantage / action
     // or the return feed the loss line on wave 0.  Each is re-requested for the NEXT tile right after its last use, i.e.
     // most of a pass (~9000 cycles) ahead of its next use.
-    float xr[NS], sr0, sr1 = 0.0f, sr2 = 0.0f;
-    if (NET == 4) load_x_traj<NS>(g.obs, g.n, g.bm, blockIdx.x, lane, xr);
-    else load_x_from<NS>(xsrc, g.npad, blockIdx.x, lane, xr);
+    constexpr int KS1 = (NS + 1) / 2;
+    float xr[2][KS1], sr0, sr1 = 0.0f, sr2 = 0.0f;
+    if (NET == 4) load_xm_traj<NS>(g.obs, g.n, g.bm, blockIdx.x, lane, xr);
+    else load_xm_from<NS>(xsrc, g.npad, blockIdx.x, lane, xr);
     auto load_s = [&](int tile_) __attribute__((always_inline)) {
         const int64_t q0 = (int64_t)tile_ * RW + lane;
         if (NET == 4) {
@@ -360,7 +393,18 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     float s_red[NOUT + 2];  // wave 0, one sample row per lane: sum dq[o] (= db3), loss terms
 #pragma unroll
     for (int o = 0; o < NOUT + 2; ++o) s_red[o] = 0.0f;
-    const int row1 = lane, u0 = 32 * w;  // layer 1: this thread's sample row (= lane) and its 32 hidden units
+    // layer 1 on the f32 MFMA, D[unit][sample]: A = this wave's 32 rows of W1 (lane r = unit 32 w + r, component kb + 2 ks),
+    // C = b1 by register row -- both loop-invariant
+    const int u0 = 32 * w;
+    float w1a[KS1], b1q[16];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        const int kk = 2 * ks + kb;
+        const float v = m.W1[u0 + r + HW * min(kk, NS - 1)];
+        w1a[ks] = kk < NS ? v : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b1q[q] = m.b1[u0 + mfma_row(q, kb)];
 
 #define W3_STRIDE (NET == 0 ? gridDim.x : 0x7fffffff)
     int it = 0;
@@ -368,34 +412,32 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
         W3_STAMP(0, 0);
         const int tnext = min(tile + stride, last);  // (clamped: the tail re-reads the last tile instead of branching)
         W3_STAMP(0, 1);
-        // ---- layer 1: h1 = act(b1 + W1 x) (the fmaf chain of mlp2 / the oracle), bf16 rows ----
+        // ---- layer 1: h1 = act(b1 + W1 x), bf16 rows.  v_mfma_f32_32x32x2_f32 with the bias as the accumulator's initial
+        //      value is the fmaf chain of mlp2 / the oracle bit for bit (tools/micro/mfma_f32_l1.hip); lane (r, kb) ends up
+        //      with sample 32 rt + r's units u0 + 8 g + 4 kb + {0..3}: four 8-byte stores per 32 samples ----
         {
-            float x[NS];
+            float x[2][KS1];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) x[i] = xr[i];
-            if (NET == 4) load_x_traj<NS>(g.obs, g.n, g.bm, tnext, lane, xr);
-            else load_x_from<NS>(xsrc, g.npad, tnext, lane, xr);
-            uint16_t* dst = l_H + row1 * PW + u0;
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int h8 = 0; h8 < 4; ++h8) {
-                float hv[8];
+                for (int ks = 0; ks < KS1; ++ks) x[rt][ks] = xr[rt][ks];
+            if (NET == 4) load_xm_traj<NS>(g.obs, g.n, g.bm, tnext, lane, xr);
+            else load_xm_from<NS>(xsrc, g.npad, tnext, lane, xr);
 #pragma unroll
-                for (int q4 = 0; q4 < 2; ++q4) {
-                    const int u = u0 + 8 * h8 + 4 * q4;
-                    const float4 b = *reinterpret_cast<const float4*>(m.b1 + u);
-                    float z[4] = {b.x, b.y, b.z, b.w};
+            for (int rt = 0; rt < 2; ++rt) {
+                f32x16 z;
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const float4 wv = *reinterpret_cast<const float4*>(m.W1 + u + HW * i);
-                        z[0] = fmaf(wv.x, x[i], z[0]);
-                        z[1] = fmaf(wv.y, x[i], z[1]);
-                        z[2] = fmaf(wv.z, x[i], z[2]);
-                        z[3] = fmaf(wv.w, x[i], z[3]);
-                    }
+                for (int q = 0; q < 16; ++q) z[q] = b1q[q];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
+                for (int ks = 0; ks < KS1; ++ks) z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[ks], x[rt][ks], z, 0, 0, 0);
+                uint16_t* dst = l_H + (32 * rt + r) * PW + u0 + 4 * kb;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    uint2 o;
+                    o.x = pack2_bf16(act_fwd_t<ACT>(z[4 * g4 + 0]), act_fwd_t<ACT>(z[4 * g4 + 1]));
+                    o.y = pack2_bf16(act_fwd_t<ACT>(z[4 * g4 + 2]), act_fwd_t<ACT>(z[4 * g4 + 3]));
+                    *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
                 }
-                *reinterpret_cast<uint4*>(dst + 8 * h8) = pack8_bf16(hv);
             }
         }
         __syncthreads();  // A: the H1 tile is complete
@@ -766,17 +808,32 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
                 }
         }
         W3_STAMP(1, 2);
+        // z1 = b1 + W1 x of the tile in the layout of dH1 (lane = hidden unit, registers = sample rows) on the f32 MFMA:
+        // v_mfma_f32_32x32x2_f32 with the bias as the accumulator's initial value IS the oracle's fmaf chain, bit for bit
+        // (tools/micro/mfma_f32_l1.hip: 0 of 1.2 M values differ), and takes the 3 - 4 FMAs per element off the VALU, which
+        // is what this kernel is bound by (2 x 354 VALU instructions per pass beside 2048 cycles of MFMA)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16 z1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) z1[q] = b1v;
+#pragma unroll
+            for (int ks = 0; ks < (NS + 1) / 2; ++ks) {
+                const int kk = 2 * ks + kb;  // A[m = sample row][k = kk], B[k = kk][n = this lane's unit]
+                const float av = lx[(kk < NS ? kk : NS - 1) * RW + 32 * rt + r];
+                const float a = kk < NS ? av : 0.0f;
+                float b = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) b = (i == kk) ? w1[i] : b;
+                z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z1, 0, 0, 0);
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = 32 * rt + mfma_row(q, kb);
                 float x[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) x[i] = lx[i * RW + row];
-                float z = b1v;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], x[i], z);
+                const float z = z1[q];
                 // tanh: 1 - h1^2 = 4 t / (t + 1)^2 with t = exp(2 |z|), branch-free on the hardware exponential.  The library
                 // tanhf (96 inlined copies of a branchy routine in this kernel) left 446 registers per lane in scratch and
                 // the launch at 266 us against 29 us for relu; the factor agrees with 1 - tanhf(z)^2 to ~1e-6 relative
@@ -797,6 +854,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
                 // and the live x values spill)
                 if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        }
         W3_STAMP(1, 3);
         __syncthreads();  // the one barrier of a pass: buffers p are free, buffers p ^ 1 are complete
         W3_STAMP(1, 4);
@@ -897,6 +955,18 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
     __syncthreads();
     W3_MARK(2, 9, net == 0);
 
+    // layer 1 of a pass: wave w owns units 32 (w & 3) .. + 31 of this k half for samples 32 (w >> 2) .. + 31.  B operand = this
+    // lane's unit's W1 row (component kb + 2 ks; zero beyond NS), C = its bias: loop-invariant registers
+    const int kt1 = w & 3, rt1 = w >> 2;
+    float w1k[(NS + 1) / 2];
+    const int k1 = (HW / 2) * kh + 32 * kt1 + r;
+#pragma unroll
+    for (int ks = 0; ks < (NS + 1) / 2; ++ks) {
+        const float v = l_w[k1 + HW * min(2 * ks + kb, NS - 1)];
+        w1k[ks] = 2 * ks + kb < NS ? v : 0.0f;
+    }
+    const float b1k = l_w[HW * NS + k1];
+
 #define W3_STRIDE (net == 0 ? 2 * nsr : 0x7fffffff)
     int tile = sr;
     auto pass = [&](auto PC) __attribute__((always_inline)) {
@@ -908,24 +978,26 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
         load_x<NS>(g, min(tile + 3 * nsr, last), lane, xr[p]);
         wave_lds_fence();
         W3_STAMP(2, 1);
-        // ---- layer 1 in [k][sample] order for the 128 hidden units of this half: 8 samples of one unit per item ----
+        // ---- layer 1 in [k][sample] order for the 128 hidden units of this half, on the f32 MFMA (bit-identical to the
+        //      fmaf chain, see ppo3w_bwd_kernel): one 32-sample x 32-unit block per wave, D[sample][unit] with lane = unit,
+        //      so a lane's four consecutive sample rows of a register group are 8 contiguous bytes of H1^T ----
+        {
+            f32x16 z;
 #pragma unroll
-        for (int i2 = 0; i2 < (HW / 2) * (RW / 8) / NTW; ++i2) {
-            const int item = tid + NTW * i2, rg = item & 7, kl = item >> 3;
-            const int k = (HW / 2) * kh + kl;
-            float w1[NS];
+            for (int q = 0; q < 16; ++q) z[q] = b1k;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) w1[i] = l_w[k + HW * i];
-            const float bb = l_w[HW * NS + k];
-            float hv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float z = bb;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) z = fmaf(w1[i], lx[i * RW + 8 * rg + u], z);
-                hv[u] = act_fwd_t<ACT>(z);
+            for (int ks = 0; ks < (NS + 1) / 2; ++ks) {
+                const float av = lx[min(2 * ks + kb, NS - 1) * RW + 32 * rt1 + r];
+                z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w1k[ks], z, 0, 0, 0);
             }
-            *reinterpret_cast<uint4*>(lT + kl * PT + 8 * rg) = pack8_bf16(hv);
+            uint16_t* dst = lT + (32 * kt1 + r) * PT + 32 * rt1 + 4 * kb;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 o;
+                o.x = pack2_bf16(act_fwd_t<ACT>(z[4 * g4 + 0]), act_fwd_t<ACT>(z[4 * g4 + 1]));
+                o.y = pack2_bf16(act_fwd_t<ACT>(z[4 * g4 + 2]), act_fwd_t<ACT>(z[4 * g4 + 3]));
+                *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
+            }
         }
         __syncthreads();  // the one barrier of a pass
         W3_STAMP(2, 2);
