@@ -29,7 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # f32 VALU op inside a kernel that contains an MFMA.  (The two-layer PPO learner -- ppo_grad.hip, ppo_persist.hip: no
 # MFMA -- packs actor / critic pairs ON PURPOSE with explicit float2 code; its bit-identity and run-to-run tests cover it.)
 NO_SLP = ["-fno-slp-vectorize", "-fno-vectorize"]  # (the loop vectorizer packs 2-trip loops over the actions the same way)
-EXTRA = {"ppo3.hip": NO_SLP, "dqn3.hip": NO_SLP, "ppo3w.hip": NO_SLP}
+EXTRA = {"ppo3.hip": NO_SLP, "dqn3.hip": NO_SLP, "ppo3w.hip": NO_SLP, "ppo_grad.hip": NO_SLP, "ppo_persist.hip": NO_SLP}
 
 
 def sources():

@@ -1,7 +1,7 @@
 // mfma_common.h -- bf16 helpers and the gfx950 MFMA fragment types shared by the MFMA learners (dqn3.hip, ppo3.hip, ppo3w.hip).
 //
 // v_mfma_f32_32x32x16_bf16: D(32x32) += A(32x16) * B(16x32), one wave.  Register layout (MI355X guide
-// section 3; verified against a torch reference in tests/test_gpu_mfma.py):
+// section 3; pinned by every parity test of the MFMA learners and by tools/micro/mfma_f32_l1.hip for the f32 form):
 //   A: lane l holds A[row = l & 31][k = 8 * (l >> 5) .. +7]          (8 bf16 = one 16-byte load)
 //   B: lane l holds B[k = 8 * (l >> 5) .. +7][col = l & 31]
 //   D: lane l holds D[row = (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)][col = l & 31],  q = 0..15

@@ -42,23 +42,32 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     const float* __restrict__ rec = (const float*)__builtin_assume_aligned(g.packed, 64);
     const float* __restrict__ tailb = rec + REC * h;
 
-    // ---- prologue: the first tile's scattered gather is issued first; this thread's unit (phase 2)
-    // comes from its two records ----
+    // ---- prologue: the first tile's scattered gather is issued first; the unit records go to LDS ----
     const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
     const int tile0 = blockIdx.x * NT + id.team;
     TileRegs first;
     const bool first_loader = id.tid < TILE && tile0 < g.num_tiles;
     if (first_loader) first = fetch_sample<NS>(g, pk, g.pos0, tile0, id.tid);
-    const UnitW W = unit_from_record(rec + REC * (id.owner ? id.uidx : 0));
+    float* l_rec = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());
+    stage_records<NT>(l_rec, rec, h);  // phase 1a's copy of the records (complete behind publish_first_tile's barrier)
     UnitG G;
     G.zero();
     HeadG Hd;
     Hd.zero();
     const float b2[4] = {tailb[0], tailb[1], tailb[2], tailb[3]};
 
+    long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g.dbg) ts[0] = __builtin_amdgcn_s_memtime();
     publish_first_tile<NT>(L, id, first_loader, first);
-    grad_tile_loop<NS, ACT, NO, NT>(g, pk, g.pos0, L, id, rec, b2, W, G, Hd);
+    grad_tile_loop<NS, ACT, NO, NT>(g, pk, g.pos0, L, id, l_rec, b2, G, Hd, g.dbg ? ts + 1 : nullptr);
+    if (g.dbg) ts[5] = __builtin_amdgcn_s_memtime();
     grad_fold<NT>(smem, L, id, G, Hd);
+    if (g.dbg && threadIdx.x == 0) {
+        ts[6] = __builtin_amdgcn_s_memtime();
+        long long* d = g.dbg + (int64_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) d[k] = ts[k];
+    }
     if (id.team != 0) return;
 
     // ---- epilogue: this workgroup's partial gradient (fixed layout = parameter layout) ----
@@ -92,10 +101,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     }
 }
 
-static size_t grad_smem_bytes(int h) {
-    (void)h;
-    return grad_team_smem_bytes();
-}
+static size_t grad_smem_bytes(int nt) { return grad_wg_smem_bytes(nt); }
 
 __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ packed,
                                                           int h, int ns, int nout, int64_t np_a) {
@@ -498,7 +504,8 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     q = (q + 15) & ~(uintptr_t)15;
     out->sumsq = (double*)q;
     out->counter = (unsigned int*)(out->sumsq + 4096);
-    long long* dbgp = (long long*)(out->counter + 16);  // (reserved: MAX_GRAD_BLOCKS x 8 words)
+    long long* dbgp = (long long*)(out->counter + 16);  // MAX_GRAD_BLOCKS x 8 words
+    g.dbg = RLHIP_ENV_FLAG("RLHIP_GRAD_DEBUG") ? dbgp : nullptr;
     uintptr_t pq = (uintptr_t)(dbgp + (int64_t)MAX_GRAD_BLOCKS * 8);
     pq = (pq + 63) & ~(uintptr_t)63;
     out->packed = (float*)pq;
@@ -553,25 +560,32 @@ __global__ __launch_bounds__(1024) void apply_pack_kernel(float* __restrict__ gr
     }
 }
 
-static void launch_grad(const GradLaunch& L, hipStream_t s) {
-    size_t smem = grad_smem_bytes(L.g.pd.h);
+static int32_t launch_grad(const GradLaunch& L, hipStream_t s) {
+    // two teams: 2 x 35 KB of tile areas + the 20 KB record copy = 90 KB of dynamic LDS (above the 64 KB default: opt-in per
+    // kernel and device)
+#define LAUNCH_GK(NS_, ACT_, NO_, NT_)                                                                                 \
+    do {                                                                                                              \
+        static unsigned long long done_ = 0;                                                                          \
+        const size_t smem_ = grad_smem_bytes(NT_);                                                                    \
+        int32_t rc_ = allow_big_lds(ppo_grad_kernel<NS_, ACT_, NO_, NT_>, smem_, &done_);                             \
+        if (rc_) return rc_;                                                                                          \
+        hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, NO_, NT_>), dim3(L.nb), dim3(64 * NW * NT_), smem_, s, L.g);   \
+    } while (0)
 #define LAUNCH_G(NS_, ACT_)                                                                                            \
     do {                                                                                                              \
         if (L.nt == 2) {                                                                                              \
-            if (L.g.pd.nout_a > 2)                                                                                    \
-                hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 3, 2>), dim3(L.nb), dim3(64 * NW * 2), 2 * smem, s, L.g); \
-            else                                                                                                      \
-                hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 2, 2>), dim3(L.nb), dim3(64 * NW * 2), 2 * smem, s, L.g); \
-        } else if (L.g.pd.nout_a > 2)                                                                                 \
-            hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 3, 1>), dim3(L.nb), dim3(64 * NW), smem, s, L.g);           \
-        else                                                                                                          \
-            hipLaunchKernelGGL((ppo_grad_kernel<NS_, ACT_, 2, 1>), dim3(L.nb), dim3(64 * NW), smem, s, L.g);           \
+            if (L.g.pd.nout_a > 2) LAUNCH_GK(NS_, ACT_, 3, 2);                                                        \
+            else LAUNCH_GK(NS_, ACT_, 2, 2);                                                                          \
+        } else if (L.g.pd.nout_a > 2) LAUNCH_GK(NS_, ACT_, 3, 1);                                                     \
+        else LAUNCH_GK(NS_, ACT_, 2, 1);                                                                              \
     } while (0)
     const int a = L.g.pd.act;
     if (L.ns == 4) { if (a == 0) LAUNCH_G(4, 0); else LAUNCH_G(4, 1); }
     else if (L.ns == 3) { if (a == 0) LAUNCH_G(3, 0); else LAUNCH_G(3, 1); }
     else { if (a == 0) LAUNCH_G(2, 0); else LAUNCH_G(2, 1); }
 #undef LAUNCH_G
+#undef LAUNCH_GK
+    return RLHIP_OK;
 }
 
 static void launch_pack(const GradLaunch& L, hipStream_t s) {
@@ -630,7 +644,7 @@ static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
     if (do_pack) launch_pack(L, s);
-    launch_grad(L, s);
+    if ((rc = launch_grad(L, s))) return rc;
     ApplyArgs ap{};
     hipLaunchKernelGGL((reduce_apply_kernel<APPLY_NONE>), dim3((int)((L.np + RP - 1) / RP)), dim3(1024), 0, s, L.g.partials,
                        L.g.loss_partials, L.nb, (int)L.np, grad_out, losses_out, L.g.wa, L.g.wc, L.g.we, L.g.inv_b,
@@ -722,7 +736,7 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
                 hipStream_t s = as_stream(stream);
                 if (first) launch_pack(L, s);
                 first = false;
-                launch_grad(L, s);
+                if ((rc = launch_grad(L, s))) return rc;
                 ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                              L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
                 XchgArgs xa{};
@@ -845,7 +859,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
                 launch_pack(L, s);
                 first = false;
             }
-            launch_grad(L, s);
+            if ((rc = launch_grad(L, s))) return rc;
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                          L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
             const int rblocks = (int)((L.np + RP - 1) / RP);

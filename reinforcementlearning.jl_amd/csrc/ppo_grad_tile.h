@@ -9,21 +9,24 @@
 // A team = 8 waves walking 64-sample tiles:
 //   phase 0   64 threads fetch the tile's samples f = perm(pos) (keyed bijection, no index array) from the trajectory
 //             into registers ONE TILE AHEAD and publish them to a double-buffered LDS tile.
-//   phase 1a  lane = sample, wave w walks its eighth of the hidden units; the unit records (below) are wave-uniform and
-//             come through the scalar cache (s_load -> SGPR operands of the FMAs: broadcast LDS reads of the records
-//             would cost more LDS clocks than the unit costs VALU clocks).
+//   phase 1a  layer 1 on the f32 MFMA: wave w owns 32 unit slots, D[unit][sample] = b1 + W1 x by two
+//             v_mfma_f32_32x32x2_f32 per net and 32-sample half (the bias is the accumulator's initial value, so the
+//             result IS the oracle's fmaf chain b1 + w0 x0 + w1 x1 + ..., bit for bit: tools/micro/mfma_f32_l1.hip).  A
+//             lane ends up with two samples x 16 units of both nets; its units' bias / head weights come from the
+//             workgroup's LDS copy of the unit records.  (Round 2 walked the records through the scalar cache, 8 records
+//             per s_waitcnt: 4 exposed L2 round trips per wave made this phase 10 us of an 18 us tile.)
 //   phase 1b  wave 0 finishes logits / value, evaluates the loss terms and dL/d(outputs) per sample.
 //   phase 2   lane = hidden unit j (weights in registers); the 64 samples stream from LDS as two broadcast b128 reads
 //             each; weight gradients accumulate in registers: no atomics, no cross-lane reductions, fixed order.
 //
-// Packed f32: actor and critic walk the same (sample, unit) pairs with the same operation sequence, so every actor /
-// critic pair of FMAs is ONE v_pk_fma_f32 on a register pair (actor in the low half, critic in the high half): the unit
-// record interleaves the two nets -- {(w1a0, w1c0) .. (w1a3, w1c3), (b1a, b1c), (w2a0, w2c), w2a1, w2a2, 0, 0}, 16 floats
-// -- so that a pair is one aligned SGPR pair (phase 1a) or VGPR pair (phase 2), broadcast operands (x_k, dL) need no
-// move (op_sel), and each half is the IEEE operation the scalar code did: the same bits.  Measured on gfx950 at 4 waves
-// per SIMD (tools/micro/valu_pk.hip): v_fma_f32 87 TFLOP/s, v_pk_fma_f32 114-129 TFLOP/s -- a packed FMA costs ~1.4
-// scalar ones, not 2.
+// The unit record interleaves the two nets -- {(w1a0, w1c0) .. (w1a3, w1c3), (b1a, b1c), (w2a0, w2c), w2a1, w2a2, 0, 0},
+// 16 floats -- one 64-byte read per unit for phase 2's registers, 8-byte reads of a pair for phase 1a.  Round 3 (first
+// half) issued every actor / critic pair as one v_pk_fma_f32 (a packed FMA costs ~1.4 scalar ones on gfx950:
+// tools/micro/valu_pk.hip; -2.5 % on the iteration); with the MFMA in phase 1a the kernel falls under the repo's rule "no
+// packed f32 VALU beside an MFMA" and the pairs are two scalar FMAs again -- the MFMA phase saves five times what the
+// packing did (profiles/r03_tile_mfma.md).
 #pragma once
+#include "mfma_common.h"
 #include "ppo_common.h"
 
 namespace rlhip {
@@ -54,6 +57,7 @@ struct GradArgs {
     const uint32_t* ctr;   // ... or, when non-NULL, in the kernel from the device update counter ctr[1]:
     uint64_t seed;         //     epoch = epoch_local + ctr[1] * n_epochs  (HIP-graph replayable)
     uint32_t epoch_local, n_epochs;
+    long long* dbg;        // RLHIP_GRAD_DEBUG: [workgroup][8] s_memtime stamps of thread 0 (tools/grad_timeline.py), else NULL
 };
 
 struct TileRegs {  // one sample's trajectory entries, held in registers one tile ahead
@@ -78,16 +82,22 @@ __device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKe
     return r;
 }
 
-// LDS of one team of 8 waves: x[2][TILE] | misc[2][TILE] | part[8][TILE] | dL[TILE] (float4) | comb[14][256] + 16 scalars (float)
+// LDS of one team of 8 waves: x[2][TILE] | misc[2][TILE] | part[16][TILE] | dL[TILE] (float4) | comb[14][256] + 16 scalars (float)
+constexpr int NPART = 2 * NW;  // partial head sums per sample: one per wave and lane half (phase 1a)
 __host__ __device__ constexpr size_t grad_team_smem_bytes() {
-    return sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NW * TILE + TILE) + sizeof(float) * (14 * 256 + 16);
+    return sizeof(float4) * (size_t)(2 * TILE + 2 * TILE + NPART * TILE + TILE) + sizeof(float) * (14 * 256 + 16);
 }
+// ... and, shared by the workgroup's teams, behind their areas: the unit records as phase 1a reads them, [NW][32] slots of
+// RS floats (slot 32 w + m = unit w (h / NW) + m; slots m >= h / NW stay zero: an absent unit adds exact zeros)
+constexpr int RS = 20;  // record pitch in LDS (80 B: 16-byte aligned, and 32 consecutive slots spread over the banks)
+constexpr size_t GRAD_REC_LDS_BYTES = sizeof(float) * (size_t)(NW * 32 * RS);
+__host__ __device__ constexpr size_t grad_wg_smem_bytes(int nt) { return (size_t)nt * grad_team_smem_bytes() + GRAD_REC_LDS_BYTES; }
 constexpr int GRAD_COMB_FLOATS = 14 * 256 + 16;  // the comb area + its 16 scalars, contiguous
 
 struct TeamLds {
     float4* x;     // [2][TILE]
     float4* misc;  // [2][TILE]
-    float4* part;  // [8][TILE]  {a0, a1, a2, v} partial sums
+    float4* part;  // [16][TILE] {a0, a1, a2, v} partial sums
     float4* dL;    // [TILE]     {dl0, dv, dl1, dl2}
     float* comb;   // [14][256] second-half accumulators, then 16 scalars of the team's wave 0
 };
@@ -97,14 +107,19 @@ __device__ __forceinline__ TeamLds team_lds(char* smem, int team) {
     L.x = reinterpret_cast<float4*>(tsm);
     L.misc = L.x + 2 * TILE;
     L.part = L.misc + 2 * TILE;
-    L.dL = L.part + NW * TILE;
+    L.dL = L.part + NPART * TILE;
     L.comb = reinterpret_cast<float*>(L.dL + TILE);
     return L;
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));  // (actor, critic)
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+// (actor, critic) pair.  A plain struct on purpose: every operation below is written per component and the file is built
+// without the vectorizers (build.py), so that no packed f32 VALU instruction can appear in a kernel that issues MFMAs
+// (tests/test_no_packed_f32_beside_mfma.py; round 2 paired these as v_pk_fma_f32 when the tile had no MFMA in it).
+struct f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ f2 fma2s(f2 a, float b, f2 c) { return f2{fmaf(a.x, b, c.x), fmaf(a.y, b, c.y)}; }
 constexpr int REC = 16;  // floats per unit record
 
 struct UnitW {  // this thread's hidden unit (phase 2), both nets
@@ -117,7 +132,8 @@ struct UnitG {  // its gradient accumulators, same pairing
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int k = 0; k < 4; ++k) w1[k] = f2{0.f, 0.f};
-        b1 = w2p = f2{0.f, 0.f};
+        b1 = f2{0.f, 0.f};
+        w2p = f2{0.f, 0.f};
         w2a1 = w2a2 = 0.f;
     }
 };
@@ -179,58 +195,161 @@ __device__ __forceinline__ void publish_first_tile(const TeamLds& L, const TeamI
     __syncthreads();
 }
 
+// The hidden activation of the tile.  tanh: ocml's tanhf restated without its branches -- the same two evaluations
+// (odd polynomial below 0.625, 1 - 2 / (exp(2 |x|) + 1) above; constants and operation order read off the library's
+// code for gfx950), both computed, one select: the same bits as tanhf (tools/micro/tanh_sel.hip checks all 2^32 inputs'
+// worth of a stride), and no control flow between the reads of an MFMA accumulator tuple (with the library's branches the
+// register allocator spilled 170 - 190 registers per lane in the tanh instantiations of phase 1a).
+__device__ __forceinline__ float tanh_sel(float x) {
+    const float y = fabsf(x), y2 = x * x;
+    float p = fmaf(y2, __uint_as_float(0xbbbac73du), __uint_as_float(0x3ca908c9u));
+    p = fmaf(y2, p, __uint_as_float(0xbd5c1c4eu));
+    p = fmaf(y2, p, __uint_as_float(0x3e088382u));
+    p = fmaf(y2, p, __uint_as_float(0xbeaaaa99u));
+    const float zs = fmaf(y2, y * p, y);
+    const float e = expf(y + y);
+    const float zb = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
+    return copysignf(y < 0.625f ? zs : zb, x);
+}
+template <int ACT>
+__device__ __forceinline__ float tile_act(float z) {
+    return ACT == 0 ? act_fwd_t<0>(z) : tanh_sel(z);
+}
+
+// ---- the workgroup's LDS copy of the unit records for phase 1a: slot 32 w + m <- unit w hq + m (hq = h / NW), zeros beyond hq ----
+// from the packed global image (two-launch kernel prologue); every thread of the workgroup; no barrier inside
+template <int NT>
+__device__ __forceinline__ void stage_records(float* l_rec, const float* __restrict__ rec, int h) {
+    const int hq = h / NW;
+#pragma unroll
+    for (int i = 0; i < (NW * 32 * 4) / (512 * NT); ++i) {
+        const int idx = (int)threadIdx.x + 512 * NT * i, slot = idx >> 2, part = idx & 3;
+        const int m = slot & 31, j = (slot >> 5) * hq + m;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < hq) v = *reinterpret_cast<const float4*>(rec + REC * j + 4 * part);
+        *reinterpret_cast<float4*>(l_rec + slot * RS + 4 * part) = v;
+    }
+}
+__device__ __forceinline__ int record_lds_slot(int j, int h) {
+    const int hq = h / NW;
+    return (j / hq) * 32 + (j % hq);
+}
+// one unit's record from registers (persistent kernel: the weights never leave the CU); the padding slots are zeroed once
+__device__ __forceinline__ void store_record_lds(float* l_rec, int j, int h, const UnitW& W) {
+    float4* d = reinterpret_cast<float4*>(l_rec + record_lds_slot(j, h) * RS);
+    d[0] = make_float4(W.w1[0].x, W.w1[0].y, W.w1[1].x, W.w1[1].y);
+    d[1] = make_float4(W.w1[2].x, W.w1[2].y, W.w1[3].x, W.w1[3].y);
+    d[2] = make_float4(W.b1.x, W.b1.y, W.w2p.x, W.w2p.y);
+    d[3] = make_float4(W.w2a1, W.w2a2, 0.0f, 0.0f);
+}
+
 // The tile loop of one workgroup (NT teams side by side, same trip count: the barriers are workgroup-wide; a team
 // without a tile left computes on stale LDS with all-invalid samples: dL = 0, nothing is accumulated).
-// RecP: pointer type of the unit records -- `const float*` to memory the kernel never writes (the compiler then proves
-// the loads scalar), or a constant-address-space pointer (ppo_persist.hip).  b2: {b2a0, b2a1, b2a2, b2c}.
+// l_rec: the workgroup's LDS copy of the unit records (stage_records / store_record_lds below).  b2: {b2a0, b2a1, b2a2, b2c}.
 // NO = 2: the actor has at most two outputs (two actions, or (mu, log sigma)) -- the third output's FMAs (zero weights,
 // zero dL/dout: exact no-ops) are not issued; NO = 3: three actions.
-template <int NS, int ACT, int NO, int NT, class RecP>
+template <int NS, int ACT, int NO, int NT>
 __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys& pk, uint32_t pos0, const TeamLds& L,
-                                               const TeamIds& id, RecP rec, const float (&b2)[4], const UnitW& W,
-                                               UnitG& G, HeadG& Hd) {
-    const int h = g.pd.h;
-    const int hq = h / NW;  // hidden units per wave in phase 1a
+                                               const TeamIds& id, const float* l_rec, const float (&b2)[4], UnitG& G,
+                                               HeadG& Hd, long long* tl = nullptr) {
+    // tl (debug builds of the persistent kernel only): s_memtime at the loop's four barriers of the LAST pass
     const int lane = id.lane, w = id.w;
+    const int r = lane & 31, kb = lane >> 5;
     int tile = blockIdx.x * NT + id.team;
     int buf = 0;
     for (int base = blockIdx.x * NT; base < g.num_tiles; base += gridDim.x * NT, tile += gridDim.x * NT) {
         const int next = tile + gridDim.x * NT;
         const float4* cx = L.x + buf * TILE;
         const float4* cm = L.misc + buf * TILE;
+        if (tl) tl[0] = __builtin_amdgcn_s_memtime();
         // ---- phase 0 (next tile): wave 1 issues the gather now, publishes it after phase 2 ----
         TileRegs pre;
         const bool prefetcher = (w == 1) && (next < g.num_tiles);
         if (prefetcher) pre = fetch_sample<NS>(g, pk, pos0, next, lane);
-        // ---- phase 1a: lane = sample, wave w walks hidden units [w*hq, (w+1)*hq) ----
+        // ---- phase 1a: D[unit slot 32 w + m][sample] = b1 + W1 x on the f32 MFMA, both nets, both 32-sample halves.
+        //      A: lane (r, kb) = W1[slot 32 w + r][k = kb + 2 ks]; B: x[k][sample 32 rt + r]; C: the bias by register row.
+        //      The lane then holds z of samples r and 32 + r for its 16 slots 32 w + 8 g + 4 kb + e: activation and
+        //      head-weight FMAs on the VALU, weights by 8-byte LDS reads (the same address in every lane of a half) ----
         {
-            const float4 xv = cx[lane];
-            f2 accp = {0.f, 0.f};  // (actor output 0, value)
-            float acc1 = 0.f, acc2 = 0.f;
-#pragma unroll 8
-            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
-                // wave-uniform addresses: scalar loads; the pairs are SGPR-pair operands of the packed FMAs below
-                const RecP r = rec + REC * jj;
-                f2 z = {r[8], r[9]};
-                z = pk_fma(f2{r[0], r[1]}, splat(xv.x), z);
-                if (NS > 1) z = pk_fma(f2{r[2], r[3]}, splat(xv.y), z);
-                if (NS > 2) z = pk_fma(f2{r[4], r[5]}, splat(xv.z), z);
-                if (NS > 3) z = pk_fma(f2{r[6], r[7]}, splat(xv.w), z);
-                const f2 hh = {act_fwd_t<ACT>(z.x), act_fwd_t<ACT>(z.y)};
-                accp = pk_fma(f2{r[10], r[11]}, hh, accp);
-                acc1 = fmaf(r[12], hh.x, acc1);
-                if (NO > 2) acc2 = fmaf(r[13], hh.x, acc2);
+            const float* rA = l_rec + (32 * w + r) * RS + 2 * kb;
+            const f2 a0 = *reinterpret_cast<const f2*>(rA);      // (W1a, W1c)[slot r][k = kb]
+            const f2 a1 = *reinterpret_cast<const f2*>(rA + 4);  //                   [k = kb + 2]
+            const float* xf = reinterpret_cast<const float*>(cx);
+            float xb[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xb[rt][ks] = xf[4 * (32 * rt + r) + kb + 2 * ks];
+            const float* rq = l_rec + (32 * w + 4 * kb) * RS;  // slot of register row q: + ((q & 3) + 8 (q >> 2)) RS
+            // one net at a time (32 accumulator registers live instead of 64: the 1024-thread workgroup has 128 per lane)
+            float ac0[2] = {0.f, 0.f}, ac1[2] = {0.f, 0.f}, ac2[2] = {0.f, 0.f}, acv[2] = {0.f, 0.f};
+            {  // actor
+                f32x16 z[2];
+                {
+                    f32x16 bq;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) bq[q] = rq[((q & 3) + 8 * (q >> 2)) * RS + 8];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, xb[rt][0], bq, 0, 0, 0);
+                }
+                if (NS > 2) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, xb[rt][1], z[rt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float* u = rq + ((q & 3) + 8 * (q >> 2)) * RS;
+                    const float w20 = u[10];                              // W2a[0, j]
+                    const f2 w2x = *reinterpret_cast<const f2*>(u + 12);  // (W2a[1, j], W2a[2, j])
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const float ha = tile_act<ACT>(z[rt][q]);
+                        ac0[rt] = fmaf(w20, ha, ac0[rt]);
+                        ac1[rt] = fmaf(w2x.x, ha, ac1[rt]);
+                        if (NO > 2) ac2[rt] = fmaf(w2x.y, ha, ac2[rt]);
+                    }
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four units' weights in flight
+                }
             }
-            L.part[w * TILE + lane] = make_float4(accp.x, acc1, acc2, accp.y);
+            {  // critic.  Its record reads start from an offset the compiler cannot see through, tied to the actor's last
+               // sum: otherwise the (b1a, b1c, w2a0, w2c) quadruples are fetched as one 16-byte read per unit for both nets
+               // up front and the critic's halves stay live across the actor's pass (118 spilled registers)
+                int co = 9;
+                asm volatile("" : "+v"(co), "+v"(ac0[1]));
+                const float* rqc = rq + co;
+                f32x16 z[2];
+                {
+                    f32x16 bq;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) bq[q] = rqc[((q & 3) + 8 * (q >> 2)) * RS];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, xb[rt][0], bq, 0, 0, 0);
+                }
+                if (NS > 2) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, xb[rt][1], z[rt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float w2c = rqc[((q & 3) + 8 * (q >> 2)) * RS + 2];  // W2c[j]
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acv[rt] = fmaf(w2c, tile_act<ACT>(z[rt][q]), acv[rt]);
+                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                L.part[(2 * w + kb) * TILE + 32 * rt + r] = make_float4(ac0[rt], ac1[rt], ac2[rt], acv[rt]);
         }
         __syncthreads();
+        if (tl) tl[1] = __builtin_amdgcn_s_memtime();
         // ---- phase 1b: wave 0 finishes the forward, evaluates the loss and dL/d(outputs) ----
         if (w == 0) {
             const int s = lane;
             const bool valid = ((uint32_t)tile * TILE + (uint32_t)s) < g.bm;
             float4 ps = L.part[s];
 #pragma unroll
-            for (int q = 1; q < NW; ++q) {  // fixed summation order over the NW waves' partial sums
+            for (int q = 1; q < NPART; ++q) {  // fixed summation order over the partial sums (wave, lane half)
                 const float4 pq = L.part[q * TILE + s];
                 ps.x += pq.x;
                 ps.y += pq.y;
@@ -315,36 +434,40 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
             Hd.b2c += dvout;
         }
         __syncthreads();
+        if (tl) tl[2] = __builtin_amdgcn_s_memtime();
         // ---- phase 2: lane = hidden unit j; the tile's samples stream from LDS (broadcast reads) ----
         if (id.owner) {
+            // this thread's unit, both nets: its record from the workgroup's copy (not held across phase 1: registers)
+            const UnitW W = unit_from_record(l_rec + record_lds_slot(id.uidx, g.pd.h) * RS);
 #pragma unroll 4
             for (int s = id.shalf * (TILE / 2); s < (id.shalf + 1) * (TILE / 2); ++s) {
                 const float4 xv = cx[s];
                 const float4 d = L.dL[s];  // {dl0, dv, dl1, dl2}
                 f2 z = W.b1;
-                z = pk_fma(W.w1[0], splat(xv.x), z);
-                if (NS > 1) z = pk_fma(W.w1[1], splat(xv.y), z);
-                if (NS > 2) z = pk_fma(W.w1[2], splat(xv.z), z);
-                if (NS > 3) z = pk_fma(W.w1[3], splat(xv.w), z);
-                const f2 hh = {act_fwd_t<ACT>(z.x), act_fwd_t<ACT>(z.y)};
+                z = fma2s(W.w1[0], xv.x, z);
+                if (NS > 1) z = fma2s(W.w1[1], xv.y, z);
+                if (NS > 2) z = fma2s(W.w1[2], xv.z, z);
+                if (NS > 3) z = fma2s(W.w1[3], xv.w, z);
+                const f2 hh = {tile_act<ACT>(z.x), tile_act<ACT>(z.y)};
                 const f2 d0v = {d.x, d.y};
-                G.w2p = pk_fma(d0v, hh, G.w2p);
+                G.w2p = fma2(d0v, hh, G.w2p);
                 G.w2a1 = fmaf(d.z, hh.x, G.w2a1);
                 if (NO > 2) G.w2a2 = fmaf(d.w, hh.x, G.w2a2);
-                f2 dh = d0v * W.w2p;
+                f2 dh = {d0v.x * W.w2p.x, d0v.y * W.w2p.y};
                 dh.x = fmaf(d.z, W.w2a1, dh.x);
                 if (NO > 2) dh.x = fmaf(d.w, W.w2a2, dh.x);
                 f2 dz;
                 if (ACT == 0) {  // relu: dh * [z > 0] as a select (the product differs only in the sign of a zero)
                     dz = f2{z.x > 0.0f ? dh.x : 0.0f, z.y > 0.0f ? dh.y : 0.0f};
                 } else {
-                    dz = dh * (splat(1.0f) - hh * hh);
+                    dz = f2{dh.x * (1.0f - hh.x * hh.x), dh.y * (1.0f - hh.y * hh.y)};
                 }
-                G.b1 += dz;
-                G.w1[0] = pk_fma(dz, splat(xv.x), G.w1[0]);
-                if (NS > 1) G.w1[1] = pk_fma(dz, splat(xv.y), G.w1[1]);
-                if (NS > 2) G.w1[2] = pk_fma(dz, splat(xv.z), G.w1[2]);
-                if (NS > 3) G.w1[3] = pk_fma(dz, splat(xv.w), G.w1[3]);
+                G.b1.x += dz.x;
+                G.b1.y += dz.y;
+                G.w1[0] = fma2s(dz, xv.x, G.w1[0]);
+                if (NS > 1) G.w1[1] = fma2s(dz, xv.y, G.w1[1]);
+                if (NS > 2) G.w1[2] = fma2s(dz, xv.z, G.w1[2]);
+                if (NS > 3) G.w1[3] = fma2s(dz, xv.w, G.w1[3]);
             }
         }
         // publish the prefetched next tile into the other buffer (nobody reads it before the barrier)
@@ -353,6 +476,7 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
             L.misc[(buf ^ 1) * TILE + lane] = pre.misc;
         }
         __syncthreads();
+        if (tl) tl[3] = __builtin_amdgcn_s_memtime();
         buf ^= 1;
     }
 }

@@ -18,10 +18,8 @@
 //   A  all-gather: every workgroup sweeps all np granules of gsl, takes the global norm (same Float64 tree as
 //      reduce_apply_kernel), clips, and runs Adam on ALL parameters redundantly (4 per thread: same operations in every
 //      workgroup, hence the same bits -- nobody has to wait for a parameter broadcast); the new parameters go to LDS
-//      (phase 2's per-thread unit weights) and to a workgroup-private record copy in global memory that phase 1a reads
-//      back through the scalar cache (s_dcache_inv first; the copy is addressed through a constant-address-space pointer
-//      re-derived from an opaque register every step, so the compiler emits s_load_dwordx8 but cannot hoist a load
-//      across the step's stores)
+//      (phase 2's per-thread unit weights, and the workgroup's record copy that phase 1a reads: the weights never
+//      leave the CU between steps)
 //
 // The next step's first tile is gathered from the trajectory while R and A wait (sample indices do not depend on the
 // parameters).  Results are bit-identical to the two-launch path whenever both run the same grid (same tile -> row
@@ -37,7 +35,6 @@
 
 namespace rlhip {
 
-typedef const __attribute__((address_space(4))) float* crec_t;  // constant address space: uniform loads go scalar
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
@@ -57,7 +54,6 @@ struct PersistArgs {
     int n_mb, rowlen;
     unsigned long long* rows;  // [grid][rowlen] granules: a partial gradient row + {s_actor, s_critic, s_ent}
     unsigned long long* gsl;   // [np] granules: the reduced gradient
-    float* rec_priv;           // [grid][16 h + 8] workgroup-private unit records
     unsigned int* state;       // [0] epoch base, [1] abort, [2] departures, [3] sticky status
     float* packed;             // the two-launch path's shared record copy (left current at exit)
     float* grad_out;
@@ -141,7 +137,8 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
     const TeamLds L = team_lds(smem, id.team);
     // the learner's state, complete in every workgroup, after the teams' tile areas: parameters (flat Flux.destructure
     // layout) | Adam m | Adam v, PERSIST_MAX_NP floats each
-    float* l_par = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());
+    float* l_rec = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());  // phase 1a's unit records
+    float* l_par = reinterpret_cast<float*>(smem + grad_wg_smem_bytes(NT));
     float* l_m = l_par + PERSIST_MAX_NP;
     float* l_v = l_m + PERSIST_MAX_NP;
     const int gtid = threadIdx.x, lane = gtid & 63, wv = __builtin_amdgcn_readfirstlane(gtid >> 6);
@@ -167,7 +164,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
         }
     }
     float bp1 = a.beta_pow[0], bp2 = a.beta_pow[1];
-    float* myrec = a.rec_priv + (int64_t)blockIdx.x * (16 * h + 8);
+    for (int i = gtid; i < NW * 32 * RS; i += NTHR) l_rec[i] = 0.0f;  // the padding slots (units beyond h / 8 per wave) stay zero
     const uint32_t upd = g.ctr ? g.ctr[1] : a.update_ctr;
     const int n_mb = a.n_mb;
     const int nsteps = (int)g.n_epochs * n_mb;
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
         const unsigned ep = base + (unsigned)s + 1u;
         const bool last = s + 1 == nsteps;
         const uint32_t pos0 = (uint32_t)(s % n_mb) * g.bm;
-        // ---- this step's weights: phase 2's unit in registers, phase 1a's records through the private copy ----
+        // ---- this step's weights: phase 2's unit in registers, phase 1a's records in the workgroup's LDS copy ----
         UnitW W;
         const int ot0 = opaque(gtid);
         const int uo = ot0 & 255;  // = id.uidx
@@ -206,19 +203,8 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
 #pragma unroll
         for (int o = 0; o < GMAXO; ++o) b2[o] = o < nout ? l_par[h * NS + h + nout * h + o] : 0.0f;
         b2[3] = l_par[np_a + h * NS + h + h];
-        if (ot0 < 256 && uo < h) {  // team 0, first half: one thread per hidden unit
-            float4* r = reinterpret_cast<float4*>(myrec + REC * uo);
-            r[0] = make_float4(W.w1[0].x, W.w1[0].y, W.w1[1].x, W.w1[1].y);
-            r[1] = make_float4(W.w1[2].x, W.w1[2].y, W.w1[3].x, W.w1[3].y);
-            r[2] = make_float4(W.b1.x, W.b1.y, W.w2p.x, W.w2p.y);
-            r[3] = make_float4(W.w2a1, W.w2a2, 0.0f, 0.0f);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record stores have reached L2
-        __syncthreads();
-        __builtin_amdgcn_s_dcache_inv();  // last step's records may still sit in the scalar cache
-        unsigned long long rec_bits = (unsigned long long)myrec;
-        asm volatile("" : "+s"(rec_bits)::"memory");  // opaque per step: no record load can be hoisted above this point
-        const crec_t rec = (crec_t)rec_bits;
+        if (ot0 < 256 && uo < h) store_record_lds(l_rec, uo, h, W);  // team 0, first half: one thread per hidden unit
+        // (complete behind publish_first_tile's barrier; its previous readers left phase 1a three barriers ago)
 
         UnitG G;
         G.zero();
@@ -226,8 +212,11 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
         Hd.zero();
         STAMP(1);
         publish_first_tile<NT>(L, id, first_loader, first);
-        grad_tile_loop<NS, ACT, NO, NT>(g, pk, pos0, L, id, rec, b2, W, G, Hd);
+        long long tl[4] = {0, 0, 0, 0};
+        grad_tile_loop<NS, ACT, NO, NT>(g, pk, pos0, L, id, l_rec, b2, G, Hd, a.dbg ? tl : nullptr);
         STAMP(2);
+        // slot 7: the tile loop's phases, 16 bits each: 1a | 1b | 2 (ticks)
+        ts[7] = (tl[1] - tl[0]) | ((tl[2] - tl[1]) << 16) | ((tl[3] - tl[2]) << 32) | ((tl[0] - ts[1]) << 48);
         grad_fold<NT>(smem, L, id, G, Hd);
 
         // ---- G -> R: the partial row, as granules ----
@@ -384,7 +373,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
         if (a.dbg && gtid == 0 && s < 64) {
             long long* d = a.dbg + ((int64_t)blockIdx.x * 64 + s) * 8;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) d[k] = ts[k];
+            for (int k = 0; k < 8; ++k) d[k] = ts[k];
         }
     }
 #undef STAMP
@@ -428,8 +417,9 @@ constexpr size_t PERSIST_DEBUG_BYTES = (size_t)PERSIST_MAX_GRID * 64 * 8 * 8;  /
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int64_t ppo_persist_bytes(int64_t np, int h) {
+    (void)h;
     return (int64_t)(256 + align_up((size_t)PERSIST_MAX_GRID * (size_t)(np + 4) * 8, 256) + align_up(4096 * 8, 256) +
-                     align_up((size_t)PERSIST_MAX_GRID * (size_t)(16 * h + 8) * 4, 256) + PERSIST_DEBUG_BYTES);
+                     PERSIST_DEBUG_BYTES);
 }
 
 template <class K>
@@ -460,7 +450,7 @@ static int persist_capacity(K kernel, int threads, size_t lds) {
 template <int NS, int ACT, int NO, int NT>
 static int32_t launch_persist(const PersistArgs& a, int grid_wanted, hipStream_t s, bool* launched) {
     auto kernel = &ppo_update_persist_kernel<NS, ACT, NO, NT>;
-    const size_t lds = (size_t)NT * grad_team_smem_bytes() + 3 * sizeof(float) * PERSIST_MAX_NP;
+    const size_t lds = grad_wg_smem_bytes(NT) + 3 * sizeof(float) * PERSIST_MAX_NP;
     int cap = persist_capacity(kernel, 512 * NT, lds);
     if (cap > PERSIST_MAX_GRID) cap = PERSIST_MAX_GRID;
     static int cap_env = -2;
@@ -513,8 +503,6 @@ int32_t ppo_persist_update(const GradLaunch& L0, const rlhip_ppo_cfg* cfg, float
     w += align_up((size_t)PERSIST_MAX_GRID * (size_t)(np + 4) * 8, 256);
     a.gsl = (unsigned long long*)w;
     w += align_up(4096 * 8, 256);
-    a.rec_priv = (float*)w;
-    w += align_up((size_t)PERSIST_MAX_GRID * (size_t)(16 * L0.g.pd.h + 8) * 4, 256);
     a.dbg = RLHIP_ENV_FLAG("RLHIP_PERSIST_DEBUG") ? (long long*)w : nullptr;
     a.packed = L0.packed;
     a.grad_out = grad_out;

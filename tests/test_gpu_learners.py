@@ -458,10 +458,9 @@ def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip):
 @pytest.mark.parametrize("kind,continuous,hidden,act", [("cartpole", False, 256, 0), ("pendulum", True, 256, 1),
                                                         ("mountaincar", False, 128, 0), ("pendulum", False, 64, 1)])
 def test_two_layer_ppo_gradient_is_bit_deterministic_run_to_run(rl, kind, continuous, hidden, act):
-    """The two-layer learner tile packs actor / critic pairs into v_pk_fma_f32 on purpose (csrc/ppo_grad_tile.h), with
-    the broadcast operands (x_k, dL) taken from either half of LDS-loaded register pairs by op_sel -- the operand form
-    round 2's run-to-run sighting sat on (there: beside MFMAs, at two waves per SIMD).  Fixed summation order, no
-    atomics: eight launches on two alternating micro-batches must agree bit for bit."""
+    """The two-layer learner tile (csrc/ppo_grad_tile.h): layer 1 on the f32 MFMA, head sums by (wave, lane half) through
+    LDS, weight gradients in registers -- fixed summation order, no atomics: eight launches on two alternating micro-batches
+    must agree bit for bit (round 2's run-to-run sighting sat beside MFMAs at two waves per SIMD)."""
     n, T = 2048, 16
     env, pol, _, _ = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden, act=act)
     pol.rollout_()

@@ -49,6 +49,10 @@ for k, nm in enumerate(names):
     print(f"{nm:22s} {x.mean():6.2f} {x.min():6.2f} {x.max():6.2f}")
 step = (d[:, 1:, 0] - d[:, :-1, 0]) * tick_us
 print(f"step period            {step.mean():6.2f} {step.min():6.2f} {step.max():6.2f}")
+t7 = dbg[:, 1:nsteps, 7]
+for k, nm in enumerate(["tile: phase 1a + barrier", "tile: phase 1b + barrier", "tile: phase 2 + barrier", "tile: publish first tile"]):
+    x = ((t7 >> (16 * k)) & 0xFFFF).astype(np.float64) * tick_us
+    print(f"{nm:26s} {x.mean():6.2f} {x.min():6.2f} {x.max():6.2f}")
 own = np.arange(G) < (3331 + 15) // 16
 print(f"R phase, slice owners: {ph[own, 1:, 3].mean():.2f} us; non-owners {ph[~own, 1:, 3].mean():.2f} us")
 print(f"A sweep, slice owners: {ph[own, 1:, 4].mean():.2f} us; non-owners {ph[~own, 1:, 4].mean():.2f} us")
