@@ -211,9 +211,16 @@ __device__ __forceinline__ float tanh_sel(float x) {
     const float zb = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
     return copysignf(y < 0.625f ? zs : zb, x);
 }
+// relu as ONE integer max on the bit pattern (negative floats are negative integers; -0 -> +0; a positive-sign NaN stays NaN):
+// fmaxf on an MFMA result costs two v_max_f32 (the compiler cannot prove the accumulator free of signalling NaNs and
+// canonicalises it first) -- 64 of the ~220 VALU instructions of phase 1a.  Same value as fmaxf(z, 0) for every non-NaN z.
 template <int ACT>
 __device__ __forceinline__ float tile_act(float z) {
-    return ACT == 0 ? act_fwd_t<0>(z) : tanh_sel(z);
+    if (ACT == 0) {
+        const int b = __float_as_int(z);
+        return __int_as_float(b > 0 ? b : 0);
+    }
+    return tanh_sel(z);
 }
 
 // ---- the workgroup's LDS copy of the unit records for phase 1a: slot 32 w + m <- unit w hq + m (hq = h / NW), zeros beyond hq ----
@@ -296,19 +303,32 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, xb[rt][1], z[rt], 0, 0, 0);
                 }
+                // head weights of two slots at a time, the next two requested before the current two are used
+                float w20[2][2];
+                f2 w2x[2][2];
+                auto load2 = [&](int g2, float (&a)[2], f2 (&b)[2]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float* u = rq + ((q & 3) + 8 * (q >> 2)) * RS;
-                    const float w20 = u[10];                              // W2a[0, j]
-                    const f2 w2x = *reinterpret_cast<const f2*>(u + 12);  // (W2a[1, j], W2a[2, j])
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
-                        const float ha = tile_act<ACT>(z[rt][q]);
-                        ac0[rt] = fmaf(w20, ha, ac0[rt]);
-                        ac1[rt] = fmaf(w2x.x, ha, ac1[rt]);
-                        if (NO > 2) ac2[rt] = fmaf(w2x.y, ha, ac2[rt]);
+                    for (int e = 0; e < 2; ++e) {
+                        const int q = 2 * g2 + e;
+                        const float* u = rq + ((q & 3) + 8 * (q >> 2)) * RS;
+                        a[e] = u[10];                                 // W2a[0, j]
+                        b[e] = *reinterpret_cast<const f2*>(u + 12);  // (W2a[1, j], W2a[2, j])
                     }
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four units' weights in flight
+                };
+                load2(0, w20[0], w2x[0]);
+#pragma unroll
+                for (int g2 = 0; g2 < 8; ++g2) {
+                    if (g2 < 7) load2(g2 + 1, w20[(g2 + 1) & 1], w2x[(g2 + 1) & 1]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
+                            const float ha = tile_act<ACT>(z[rt][2 * g2 + e]);
+                            ac0[rt] = fmaf(w20[g2 & 1][e], ha, ac0[rt]);
+                            ac1[rt] = fmaf(w2x[g2 & 1][e].x, ha, ac1[rt]);
+                            if (NO > 2) ac2[rt] = fmaf(w2x[g2 & 1][e].y, ha, ac2[rt]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             {  // critic.  Its record reads start from an offset the compiler cannot see through, tied to the actor's last
@@ -329,12 +349,20 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, xb[rt][1], z[rt], 0, 0, 0);
                 }
+                float w2c[2][4];  // W2c[j], four slots at a time, the next four requested before the current four are used
+                auto load4c = [&](int g4, float (&a)[4]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float w2c = rqc[((q & 3) + 8 * (q >> 2)) * RS + 2];  // W2c[j]
+                    for (int e = 0; e < 4; ++e) a[e] = rqc[(e + 8 * g4) * RS + 2];
+                };
+                load4c(0, w2c[0]);
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) acv[rt] = fmaf(w2c, tile_act<ACT>(z[rt][q]), acv[rt]);
-                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (g4 < 3) load4c(g4 + 1, w2c[(g4 + 1) & 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) acv[rt] = fmaf(w2c[g4 & 1][e], tile_act<ACT>(z[rt][4 * g4 + e]), acv[rt]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
