@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     publish_first_tile<NT>(L, id, first_loader, first);
     grad_tile_loop<NS, ACT, NO, NT>(g, pk, g.pos0, L, id, l_rec, b2, G, Hd, g.dbg ? ts + 1 : nullptr);
     if (g.dbg) ts[5] = __builtin_amdgcn_s_memtime();
-    grad_fold<NT>(smem, L, id, G, Hd);
+    grad_fold<NT>(smem, L, id, h, G, Hd);
     if (g.dbg && threadIdx.x == 0) {
         ts[6] = __builtin_amdgcn_s_memtime();
         long long* d = g.dbg + (int64_t)blockIdx.x * 8;

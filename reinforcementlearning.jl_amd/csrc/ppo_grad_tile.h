@@ -16,8 +16,14 @@
 //             workgroup's LDS copy of the unit records.  (Round 2 walked the records through the scalar cache, 8 records
 //             per s_waitcnt: 4 exposed L2 round trips per wave made this phase 10 us of an 18 us tile.)
 //   phase 1b  wave 0 finishes logits / value, evaluates the loss terms and dL/d(outputs) per sample.
-//   phase 2   lane = hidden unit j (weights in registers); the 64 samples stream from LDS as two broadcast b128 reads
-//             each; weight gradients accumulate in registers: no atomics, no cross-lane reductions, fixed order.
+//   phase 2   the transpose of phase 1a on the same operands: D[sample][unit] = b1 + W1 x (A = x, B = W1 rows, C = the
+//             lane's bias): lane (r, kb) of wave w = unit slot 32 w + r with the z of 32 of the tile's samples (rows
+//             (q & 3) + 8 (q >> 2) + 4 kb of each 32-sample half) in the accumulator registers.  The first half's MFMAs
+//             are issued BEFORE the barrier of phase 1b (they need nothing from it and run in its shadow), the second
+//             half's while the first half's rows are consumed.  Per row: activation, dW2 / dh / dz / db1 / dW1 on the
+//             VALU (x and dL by 16-byte LDS reads, two addresses per instruction), accumulators in registers: 22
+//             VALU instructions per (sample, unit) pair of nets instead of 30.  The two lanes of a unit are added once,
+//             in grad_fold: no atomics, fixed order.
 //
 // The unit record interleaves the two nets -- {(w1a0, w1c0) .. (w1a3, w1c3), (b1a, b1c), (w2a0, w2c), w2a1, w2a2, 0, 0},
 // 16 floats -- one 64-byte read per unit for phase 2's registers, 8-byte reads of a pair for phase 1a.  Round 3 (first
@@ -273,12 +279,13 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
         TileRegs pre;
         const bool prefetcher = (w == 1) && (next < g.num_tiles);
         if (prefetcher) pre = fetch_sample<NS>(g, pk, pos0, next, lane);
+        const float* rU = l_rec + (32 * w + r) * RS;  // record of this lane's unit slot (A operand of 1a, B operand of 2)
         // ---- phase 1a: D[unit slot 32 w + m][sample] = b1 + W1 x on the f32 MFMA, both nets, both 32-sample halves.
         //      A: lane (r, kb) = W1[slot 32 w + r][k = kb + 2 ks]; B: x[k][sample 32 rt + r]; C: the bias by register row.
         //      The lane then holds z of samples r and 32 + r for its 16 slots 32 w + 8 g + 4 kb + e: activation and
         //      head-weight FMAs on the VALU, weights by 8-byte LDS reads (the same address in every lane of a half) ----
         {
-            const float* rA = l_rec + (32 * w + r) * RS + 2 * kb;
+            const float* rA = rU + 2 * kb;
             const f2 a0 = *reinterpret_cast<const f2*>(rA);      // (W1a, W1c)[slot r][k = kb]
             const f2 a1 = *reinterpret_cast<const f2*>(rA + 4);  //                   [k = kb + 2]
             const float* xf = reinterpret_cast<const float*>(cx);
@@ -463,27 +470,28 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
         }
         __syncthreads();
         if (tl) tl[2] = __builtin_amdgcn_s_memtime();
-        // ---- phase 2: lane = hidden unit j; the tile's samples stream from LDS (broadcast reads) ----
-        if (id.owner) {
-            // this thread's unit, both nets: its record from the workgroup's copy (not held across phase 1: registers)
-            const UnitW W = unit_from_record(l_rec + record_lds_slot(id.uidx, g.pd.h) * RS);
-#pragma unroll 4
-            for (int s = id.shalf * (TILE / 2); s < (id.shalf + 1) * (TILE / 2); ++s) {
-                const float4 xv = cx[s];
-                const float4 d = L.dL[s];  // {dl0, dv, dl1, dl2}
-                f2 z = W.b1;
-                z = fma2s(W.w1[0], xv.x, z);
-                if (NS > 1) z = fma2s(W.w1[1], xv.y, z);
-                if (NS > 2) z = fma2s(W.w1[2], xv.z, z);
-                if (NS > 3) z = fma2s(W.w1[3], xv.w, z);
+        // publish the prefetched next tile into the other buffer (nobody reads it before the pass's last barrier; the gather
+        // had phases 1a and 1b to arrive).  BEFORE phase 2: with a conditional block between phase 2 and the barrier the
+        // compiler sinks phase 2's arithmetic below it while the LDS reads stay above the stores: 266 spilled registers.
+        if (prefetcher) {
+            L.x[(buf ^ 1) * TILE + lane] = pre.x;
+            L.misc[(buf ^ 1) * TILE + lane] = pre.misc;
+        }
+        // ---- phase 2: lane (r, kb) = unit slot 32 w + r, its rows of the tile's samples (see the top of the file) ----
+        {
+            const f2 w2p = *reinterpret_cast<const f2*>(rU + 10);  // (W2a[0, j], W2c[j])
+            const f2 w2x = *reinterpret_cast<const f2*>(rU + 12);  // (W2a[1, j], W2a[2, j])
+            // one row: everything that depends on the sample's dL and x
+            auto row = [&](float za, float zc, const float4& xv, const float4& d) __attribute__((always_inline)) {
+                const f2 z = {za, zc};
                 const f2 hh = {tile_act<ACT>(z.x), tile_act<ACT>(z.y)};
-                const f2 d0v = {d.x, d.y};
+                const f2 d0v = {d.x, d.y};  // d = {dl0, dv, dl1, dl2}
                 G.w2p = fma2(d0v, hh, G.w2p);
                 G.w2a1 = fmaf(d.z, hh.x, G.w2a1);
                 if (NO > 2) G.w2a2 = fmaf(d.w, hh.x, G.w2a2);
-                f2 dh = {d0v.x * W.w2p.x, d0v.y * W.w2p.y};
-                dh.x = fmaf(d.z, W.w2a1, dh.x);
-                if (NO > 2) dh.x = fmaf(d.w, W.w2a2, dh.x);
+                f2 dh = {d0v.x * w2p.x, d0v.y * w2p.y};
+                dh.x = fmaf(d.z, w2x.x, dh.x);
+                if (NO > 2) dh.x = fmaf(d.w, w2x.y, dh.x);
                 f2 dz;
                 if (ACT == 0) {  // relu: dh * [z > 0] as a select (the product differs only in the sign of a zero)
                     dz = f2{z.x > 0.0f ? dh.x : 0.0f, z.y > 0.0f ? dh.y : 0.0f};
@@ -496,12 +504,50 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
                 if (NS > 1) G.w1[1] = fma2s(dz, xv.y, G.w1[1]);
                 if (NS > 2) G.w1[2] = fma2s(dz, xv.z, G.w1[2]);
                 if (NS > 3) G.w1[3] = fma2s(dz, xv.w, G.w1[3]);
+            };
+            // the operands of the next row are requested before the current row is consumed
+            const float4* xrow = cx + 4 * kb;
+            const float4* drow = L.dL + 4 * kb;
+            auto fetch = [&](int P, float4& xv, float4& dd) __attribute__((always_inline)) {
+                const int q = P & 15, o = 32 * (P >> 4) + (q & 3) + 8 * (q >> 2);
+                xv = xrow[o];
+                dd = drow[o];
+            };
+            // one 32-sample half at a time (32 accumulator registers); its MFMAs first
+            float4 xv[2], dd[2];
+            fetch(0, xv[0], dd[0]);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f2 a0 = *reinterpret_cast<const f2*>(rU + 2 * kb);
+                const f2 a1 = *reinterpret_cast<const f2*>(rU + 4 + 2 * kb);
+                const f2 bu = *reinterpret_cast<const f2*>(rU + 8);  // (b1a, b1c) of the lane's unit
+                const float* xf = reinterpret_cast<const float*>(cx) + 4 * (32 * rt + r) + kb;
+                f32x16 ya, yc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ya[q] = bu.x;
+                    yc[q] = bu.y;
+                }
+                ya = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[0], a0.x, ya, 0, 0, 0);
+                yc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[0], a0.y, yc, 0, 0, 0);
+                if (NS > 2) {
+                    ya = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[2], a1.x, ya, 0, 0, 0);
+                    yc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[2], a1.y, yc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int P = 16 * rt + q;
+                    if (P < 31) fetch(P + 1, xv[(P + 1) & 1], dd[(P + 1) & 1]);
+                    row(ya[q], yc[q], xv[P & 1], dd[P & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
-        // publish the prefetched next tile into the other buffer (nobody reads it before the barrier)
-        if (prefetcher) {
-            L.x[(buf ^ 1) * TILE + lane] = pre.x;
-            L.misc[(buf ^ 1) * TILE + lane] = pre.misc;
+            // the accumulators are "used" here: without this the compiler sinks the rows' arithmetic (results needed only
+            // after the loop) below the barrier and the conditional blocks that follow it, while the LDS reads stay above
+            // them -- every row's operands then live in scratch (266 spilled registers)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(G.w1[k].x), "v"(G.w1[k].y));
+            asm volatile("" ::"v"(G.b1.x), "v"(G.b1.y), "v"(G.w2p.x), "v"(G.w2p.y), "v"(G.w2a1), "v"(G.w2a2));
         }
         __syncthreads();
         if (tl) tl[3] = __builtin_amdgcn_s_memtime();
@@ -536,15 +582,41 @@ __device__ __forceinline__ void comb_add(const float* c, UnitG& G) {
     G.w2p.y += c[13 * 256];
 }
 
-// Fold the workgroup's accumulators into ONE partial row, fixed order: waves 4..7 (second half of the samples) hand
-// theirs to waves 0..3 through LDS, wave 0 sums its per-sample-lane accumulators over the 64 lanes, then team 1 hands
-// its (half-combined) values to team 0.  Afterwards the threads with team == 0, shalf == 0 hold the row's unit
+// v[lane & 31] + v[32 + (lane & 31)] in every lane (lower half first): v_permlane32_swap exchanges the upper half of one
+// register with the lower half of another on the VALU (gfx950); ds_bpermute would take the same 14 values of all 16 waves
+// through the LDS crossbar (measured: +0.7 us on the fold)
+__device__ __forceinline__ float half_sum(float v) {
+    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+
+// Fold the workgroup's accumulators into ONE partial row, fixed order: the two lanes of a unit (phase 2) are added and
+// handed through LDS to thread j of the team (j = unit), wave 0 sums its per-sample-lane accumulators over the 64 lanes,
+// then team 1 hands its values to team 0.  Afterwards the threads with team == 0, shalf == 0 hold the row's unit
 // gradients and every lane of team 0's wave 0 holds the head sums.  Contains workgroup barriers.
 template <int NT>
-__device__ __forceinline__ void grad_fold(char* smem, const TeamLds& L, const TeamIds& id, UnitG& G, HeadG& Hd) {
-    if (id.shalf == 1) comb_store(L.comb + id.uidx, G);
+__device__ __forceinline__ void grad_fold(char* smem, const TeamLds& L, const TeamIds& id, int h, UnitG& G, HeadG& Hd) {
+    {   // the two lanes of a unit hold its sums over complementary rows: add them (lane half 0 first), hand the unit's
+        // gradients to the thread that writes them out (unit j of the first 256 threads of the team)
+        const int r = id.lane & 31, kb = id.lane >> 5, hq = h / NW;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            G.w1[k].x = half_sum(G.w1[k].x);
+            G.w1[k].y = half_sum(G.w1[k].y);
+        }
+        G.b1.x = half_sum(G.b1.x);
+        G.b1.y = half_sum(G.b1.y);
+        G.w2p.x = half_sum(G.w2p.x);
+        G.w2p.y = half_sum(G.w2p.y);
+        G.w2a1 = half_sum(G.w2a1);
+        G.w2a2 = half_sum(G.w2a2);
+        if (kb == 0 && r < hq) comb_store(L.comb + id.w * hq + r, G);
+    }
     __syncthreads();
-    if (id.shalf == 0) comb_add(L.comb + id.uidx, G);
+    if (id.shalf == 0) {
+        G.zero();
+        comb_add(L.comb + id.uidx, G);
+    }
     float* l_sc = L.comb + 14 * 256;  // [16] scalars of this team's wave 0
     if (id.w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
 #pragma unroll

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_update_persist_kernel(PersistArg
         STAMP(2);
         // slot 7: the tile loop's phases, 16 bits each: 1a | 1b | 2 (ticks)
         ts[7] = (tl[1] - tl[0]) | ((tl[2] - tl[1]) << 16) | ((tl[3] - tl[2]) << 32) | ((tl[0] - ts[1]) << 48);
-        grad_fold<NT>(smem, L, id, G, Hd);
+        grad_fold<NT>(smem, L, id, h, G, Hd);
 
         // ---- G -> R: the partial row, as granules ----
         const int ot1 = opaque(gtid);
