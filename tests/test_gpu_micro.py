@@ -1,0 +1,24 @@
+"""The instruction-level facts the learner kernels rely on, checked on the GPU by stand-alone programs (tools/micro/*.hip,
+cross-compiled by __graft_entry__.build()):
+
+  mfma_f32_l1    v_mfma_f32_32x32x2_f32 with the bias as the accumulator's initial value == the oracle's fmaf chain
+                 b1 + w0 x0 + w1 x1 + ... bit for bit, in both operand orders (layer 1 of ppo3w.hip and of the PPO tile)
+  mfma_f32_4x4   the same for v_mfma_f32_4x4x1_16b_f32 (operand images + exactness; measured no faster than the VALU, not used)
+  tanh_sel       the PPO tile's branch-free tanh == ocml tanhf for all 2^32 float bit patterns
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mfma_f32_l1", "mfma_f32_4x4", "tanh_sel"])
+def test_micro_check(name):
+    exe = os.path.join(ROOT, "tools", "micro", name + ".bin")
+    assert os.path.exists(exe), f"{exe} is missing: run python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr  # every program exits non-zero on the first kind of mismatch it counts
