@@ -120,6 +120,7 @@ struct ApplyArgs {
     float* packed;          // unit records to refresh after the step
     int h, ns, nout;
     int64_t np_a;
+    long long* dbg;  // RLHIP_GRAD_DEBUG: [workgroup][8] s_memtime stamps of thread 0 (tools/grad_timeline.py), else NULL
 };
 
 // grad[p] = sum_b partials[b][p] (fixed order); losses folded by block 0.
@@ -158,10 +159,11 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
                                                             float* __restrict__ losses, float wa, float wc,
                                                             float we, float inv_b, ApplyArgs ap, XchgArgs xa) {
     __shared__ float l_g[RG][RP];
-    __shared__ float l_loss[4];
     __shared__ double l_d[16];
     __shared__ int l_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (APPLY == APPLY_GRID && ap.dbg) ts[0] = __builtin_amdgcn_s_memtime();
     const int pl = threadIdx.x % RP, grp = threadIdx.x / RP;  // RG groups of RP parameters
     const int p = blockIdx.x * RP + pl;
     const int per = (nb + RG - 1) / RG;
@@ -177,8 +179,10 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             for (int q = 0; q < 32; ++q) acc += t[q];
         }
     }
+    if (APPLY == APPLY_GRID && ap.dbg) ts[1] = __builtin_amdgcn_s_memtime();
     l_g[grp][pl] = acc;
     __syncthreads();
+    if (APPLY == APPLY_GRID && ap.dbg) ts[2] = __builtin_amdgcn_s_memtime();
     float gsum = 0.f;
     if (grp == 0) {
 #pragma unroll
@@ -186,20 +190,22 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         if (p < np) grad[p] = gsum;
         else gsum = 0.f;
     }
-    if (blockIdx.x == 0 && losses != nullptr) {
-        if (wv >= 1 && wv <= 3) {
-            const int c = wv - 1;
+    if (blockIdx.x == 0 && losses != nullptr && wv == 1) {
+        // the loss line: wave 1 of workgroup 0, alone (no workgroup barrier: wave 0 must not arrive late at the norm exchange
+        // every other workgroup waits on; same sums in the same order as when three waves shared the columns)
+        float col[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
             float a = 0.f;
             for (int b = lane; b < nb; b += 64) a += loss_partials[(int64_t)b * 4 + c];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
-            if (lane == 0) l_loss[c] = a;
+            col[c] = a;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float actor_loss = -l_loss[0] * inv_b;
-            const float critic_loss = l_loss[1] * inv_b;
-            const float ent_loss = l_loss[2] * inv_b;
+        if (lane == 0) {
+            const float actor_loss = -col[0] * inv_b;
+            const float critic_loss = col[1] * inv_b;
+            const float ent_loss = col[2] * inv_b;
             losses[0] = wa * actor_loss + wc * critic_loss - we * ent_loss;
             losses[1] = actor_loss;
             losses[2] = critic_loss;
@@ -304,30 +310,50 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         double sq = (grp == 0) ? (double)gsum * (double)gsum : 0.0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
-        if (lane == 0) ap.sumsq[blockIdx.x] = sq;
+        if (lane == 0) {
+            if (APPLY == APPLY_GRID) {
+                // the partial IS its own arrival flag: two 8-byte {epoch, half of the double} granules, write-through
+                // (device-scope relaxed atomic stores); epoch = launches of this variant so far + 1 (device-resident word,
+                // advanced by the last workgroup to leave: replay-safe), so a stale granule never matches
+                typedef unsigned long long u64;
+                const u64 ep = (u64)(__hip_atomic_load(ap.counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) << 32;
+                const u64 bits = (u64)__double_as_longlong(sq);
+                u64* gr = reinterpret_cast<u64*>(ap.sumsq) + 2 * blockIdx.x;
+                __hip_atomic_store(gr, ep | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gr + 1, ep | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                ap.sumsq[blockIdx.x] = sq;
+            }
+        }
     }
     if (APPLY == APPLY_GRID) {
-        // ---- every workgroup applies Adam to ITS OWN 64 parameters after a grid-wide barrier on the norm ----
-        // All workgroups are co-resident (the host launches this variant only for gridDim <= grid_apply_max_blocks()), so a spin barrier on an
-        // agent-scope counter is safe.  Only wave 0 (which holds the 64 reduced gradient values in registers)
-        // continues; the other 15 waves are done.  The serial tail of the last-arriver variant (one workgroup running
-        // Adam over all np parameters + re-packing every record) becomes 53 parallel 64-lane updates.
+        // ---- every workgroup applies Adam to ITS OWN 64 parameters once it has every workgroup's sum of squares ----
+        // All workgroups are co-resident (the host launches this variant only for gridDim <= grid_apply_max_blocks()), so
+        // polling is safe.  Only wave 0 (which holds the 64 reduced gradient values in registers) continues; the other 15
+        // waves are done.  The exchange is ONE hop: lane b polls workgroup b's two granules until their epoch is this
+        // launch's (round 2: arrival counter -> spin on the counter -> read the partials: three dependent round trips,
+        // 3.1 us of a 9.7 us launch by the stamps of tools/grad_timeline.py).
         if (wv != 0) return;
         const bool own = p < np;
-        // operands of this lane's parameter do not depend on the barrier: issue the loads first
+        // operands of this lane's parameter do not depend on the exchange: issue the loads first
         const float m0 = own ? ap.m[p] : 0.0f, v0 = own ? ap.v[p] : 0.0f, p0 = own ? ap.params[p] : 0.0f;
         const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
-        if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(ap.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
-                __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        typedef unsigned long long u64;
+        const unsigned int epoch = __hip_atomic_load(ap.counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (ap.dbg) ts[3] = __builtin_amdgcn_s_memtime();
         double part = 0.0;  // same summation order in every workgroup -> the same norm, bit for bit
-        for (int b = lane; b < (int)gridDim.x; b += 64)
-            part += __hip_atomic_load(ap.sumsq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = lane; b < (int)gridDim.x; b += 64) {
+            const u64* gr = reinterpret_cast<const u64*>(ap.sumsq) + 2 * b;
+            u64 hi, lo;
+            for (;;) {
+                hi = __hip_atomic_load(gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo = __hip_atomic_load(gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(hi >> 32) == epoch && (unsigned int)(lo >> 32) == epoch) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            part += __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
+        }
+        if (ap.dbg) ts[4] = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
         const float gn = (float)sqrt(part);
@@ -345,6 +371,12 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             grad[p] = g1;
             ap.packed[record_slot(p, ap.h, ap.ns, ap.nout, ap.np_a)] = pn;
         }
+        if (ap.dbg && lane == 0) {
+            ts[5] = __builtin_amdgcn_s_memtime();
+            long long* d = ap.dbg + (int64_t)blockIdx.x * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = ts[k];
+        }
         // departure: the last workgroup out re-arms both counters and advances the running beta powers (every
         // workgroup has read beta_pow above, before its departure increment)
         if (lane == 0) {
@@ -353,8 +385,8 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             if (prev == gridDim.x - 1) {
                 ap.beta_pow[0] *= ap.b1;
                 ap.beta_pow[1] *= ap.b2;
-                __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ap.counter + 3, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch: epoch + 1
             }
         }
         return;
@@ -861,7 +893,8 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             }
             if ((rc = launch_grad(L, s))) return rc;
             ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
-                         L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a};
+                         L.counter, L.sumsq, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a, L.g.pd.np_a,
+                         L.g.dbg ? L.g.dbg + 256 * 8 : nullptr};
             const int rblocks = (int)((L.np + RP - 1) / RP);
             if (rblocks <= grid_apply_max_blocks<APPLY_GRID>())
                 hipLaunchKernelGGL((reduce_apply_kernel<APPLY_GRID>), dim3(rblocks), dim3(1024), 0, s, L.g.partials,

@@ -49,3 +49,13 @@ for k, nm in enumerate(names):
     if nm != "-":
         print(f"{nm:32s} {ph[:, k].mean():6.2f} {ph[:, k].min():6.2f} {ph[:, k].max():6.2f}")
 print(f"{'stamped span':32s} {(d[:, 6] - d[:, 0]).mean() * tick_us:6.2f}")
+
+# reduce + norm barrier + Adam launch (reduce_apply_kernel<APPLY_GRID>): stamps of lane 0 of wave 0 of its 53 workgroups
+R = (np_ + 63) // 64
+e = pol.workspace[off + 256 * 8 * 8:off + (256 + R) * 8 * 8].view(torch.int64).cpu().numpy().reshape(R, 8)[:, :6].astype(np.float64)
+pe = np.diff(e, axis=1) * tick_us
+print("reduce_apply_kernel:")
+for k, nm in enumerate(["partial-row loads + adds", "LDS hand-over + barrier", "group sums, grad store, sumsq", "grid barrier on the norm",
+                        "norm + Adam + stores"]):
+    print(f"{nm:32s} {pe[:, k].mean():6.2f} {pe[:, k].min():6.2f} {pe[:, k].max():6.2f}")
+print(f"{'stamped span':32s} {(e[:, 5] - e[:, 0]).mean() * tick_us:6.2f}")
