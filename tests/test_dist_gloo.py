@@ -94,7 +94,7 @@ def test_two_rank_gradient_allreduce_equals_single_rank_double_batch():
     obs = traj.obs[:T].transpose(1, 0, 2).reshape(4, T * 2 * n_per)
     g, _ = oracle.ppo_loss_grad(cfg, 4, 2, params, obs, traj.action_i.reshape(-1), traj.logp.reshape(-1),
                                 traj.adv.reshape(-1), traj.ret.reshape(-1))
-    np.testing.assert_allclose(gm0 * (np.float32(1.0) if True else 1), _pre_clip(g, cfg.max_grad_norm), rtol=2e-4,
+    np.testing.assert_allclose(gm0, _pre_clip(g, cfg.max_grad_norm), rtol=2e-4,
                                atol=1e-6)
 
 
