@@ -591,9 +591,10 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 // Fold the workgroup's accumulators into ONE partial row, fixed order: the two lanes of a unit (phase 2) are added and
-// handed through LDS to thread j of the team (j = unit), wave 0 sums its per-sample-lane accumulators over the 64 lanes,
-// then team 1 hands its values to team 0.  Afterwards the threads with team == 0, shalf == 0 hold the row's unit
-// gradients and every lane of team 0's wave 0 holds the head sums.  Contains workgroup barriers.
+// handed through LDS to thread j of team 0 (j = unit), which adds team 0's and then team 1's value; wave 0 of each team
+// sums its per-sample-lane accumulators over the 64 lanes, team 1's go to team 0 the same way.  Afterwards the threads
+// with team == 0, shalf == 0 hold the row's unit gradients and every lane of team 0's wave 0 holds the head sums.
+// Contains one workgroup barrier.
 template <int NT>
 __device__ __forceinline__ void grad_fold(char* smem, const TeamLds& L, const TeamIds& id, int h, UnitG& G, HeadG& Hd) {
     {   // the two lanes of a unit hold its sums over complementary rows: add them (lane half 0 first), hand the unit's
@@ -612,11 +613,6 @@ __device__ __forceinline__ void grad_fold(char* smem, const TeamLds& L, const Te
         G.w2a2 = half_sum(G.w2a2);
         if (kb == 0 && r < hq) comb_store(L.comb + id.w * hq + r, G);
     }
-    __syncthreads();
-    if (id.shalf == 0) {
-        G.zero();
-        comb_add(L.comb + id.uidx, G);
-    }
     float* l_sc = L.comb + 14 * 256;  // [16] scalars of this team's wave 0
     if (id.w == 0) {  // wave 0: reduce the per-sample-lane accumulators over the 64 lanes
 #pragma unroll
@@ -625,35 +621,32 @@ __device__ __forceinline__ void grad_fold(char* smem, const TeamLds& L, const Te
         Hd.s_actor = wave_sum_f32(Hd.s_actor);
         Hd.s_critic = wave_sum_f32(Hd.s_critic);
         Hd.s_ent = wave_sum_f32(Hd.s_ent);
-    }
-    if (NT > 1) {
-        __syncthreads();  // the readers of the comb areas (above) are done
-        if (id.team == 1) {
-            if (id.shalf == 0) comb_store(L.comb + id.uidx, G);
-            if (id.w == 0 && id.lane == 0) {
-                l_sc[0] = Hd.b2a[0];
-                l_sc[1] = Hd.b2a[1];
-                l_sc[2] = Hd.b2a[2];
-                l_sc[3] = Hd.b2c;
-                l_sc[4] = Hd.s_actor;
-                l_sc[5] = Hd.s_critic;
-                l_sc[6] = Hd.s_ent;
-            }
+        if (NT > 1 && id.team == 1 && id.lane == 0) {
+            l_sc[0] = Hd.b2a[0];
+            l_sc[1] = Hd.b2a[1];
+            l_sc[2] = Hd.b2a[2];
+            l_sc[3] = Hd.b2c;
+            l_sc[4] = Hd.s_actor;
+            l_sc[5] = Hd.s_critic;
+            l_sc[6] = Hd.s_ent;
         }
-        __syncthreads();
-        if (id.team == 0) {
-            const float* c1 = team_lds(smem, 1).comb;
-            if (id.shalf == 0) comb_add(c1 + id.uidx, G);
-            if (id.w == 0) {
-                const float* sc1 = c1 + 14 * 256;
-                Hd.b2a[0] += sc1[0];
-                Hd.b2a[1] += sc1[1];
-                Hd.b2a[2] += sc1[2];
-                Hd.b2c += sc1[3];
-                Hd.s_actor += sc1[4];
-                Hd.s_critic += sc1[5];
-                Hd.s_ent += sc1[6];
-            }
+    }
+    __syncthreads();  // ONE barrier: every team's unit sums and team 1's head sums are in LDS
+    if (id.team == 0) {
+        if (id.shalf == 0) {
+            G.zero();
+            comb_add(L.comb + id.uidx, G);  // team 0 first, then team 1: the order of the three-barrier fold it replaces
+            if (NT > 1) comb_add(team_lds(smem, 1).comb + id.uidx, G);
+        }
+        if (NT > 1 && id.w == 0) {
+            const float* sc1 = team_lds(smem, 1).comb + 14 * 256;
+            Hd.b2a[0] += sc1[0];
+            Hd.b2a[1] += sc1[1];
+            Hd.b2a[2] += sc1[2];
+            Hd.b2c += sc1[3];
+            Hd.s_actor += sc1[4];
+            Hd.s_critic += sc1[5];
+            Hd.s_ent += sc1[6];
         }
     }
 }
