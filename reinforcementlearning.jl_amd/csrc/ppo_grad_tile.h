@@ -401,23 +401,32 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
             const float A = mi.y;
             float lp_new, ent;
             if (!g.pd.cont) {
+                // na <= NO (compile time): every loop over the actions is unrolled to NO trips with a uniform predicate, so
+                // that logp / pr / dl live in registers (run-time trip counts made them indexed arrays)
                 const int na = g.pd.na;
                 float mx = oa[0];
-                for (int k = 1; k < na; ++k) mx = fmaxf(mx, oa[k]);
+#pragma unroll
+                for (int k = 1; k < NO; ++k)
+                    if (k < na) mx = fmaxf(mx, oa[k]);
                 float se = 0.f;
-                for (int k = 0; k < na; ++k) se += expf(oa[k] - mx);
+#pragma unroll
+                for (int k = 0; k < NO; ++k)
+                    if (k < na) se += expf(oa[k] - mx);
                 const float lse = logf(se);
-                float logp[GMAXO], pr[GMAXO];
+                float logp[GMAXO] = {0.f, 0.f, 0.f}, pr[GMAXO] = {0.f, 0.f, 0.f};
                 ent = 0.f;
-                for (int k = 0; k < na; ++k) {
-                    logp[k] = (oa[k] - mx) - lse;
-                    pr[k] = expf(logp[k]);
-                    ent -= pr[k] * logp[k];
-                }
+#pragma unroll
+                for (int k = 0; k < NO; ++k)
+                    if (k < na) {
+                        logp[k] = (oa[k] - mx) - lse;
+                        pr[k] = expf(logp[k]);
+                        ent -= pr[k] * logp[k];
+                    }
                 const int a = __float_as_int(mi.w);
                 lp_new = 0.f;
-                for (int k = 0; k < na; ++k)
-                    if (k == a) lp_new = logp[k];
+#pragma unroll
+                for (int k = 0; k < NO; ++k)
+                    if (k < na && k == a) lp_new = logp[k];
                 const float ratio = expf(lp_new - lp_old);
                 const float surr1 = ratio * A;
                 const float rc = fminf(fmaxf(ratio, g.lo), g.hi);
@@ -426,11 +435,13 @@ __device__ __forceinline__ void grad_tile_loop(const GradArgs& g, const PermKeys
                 const float dobj = (inside || surr1 < surr2) ? A : 0.f;
                 const float dL_dlp = -g.wa * g.inv_b * dobj * ratio;
                 if (valid) Hd.s_actor += fminf(surr1, surr2);
-                for (int k = 0; k < na; ++k) {
-                    const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
-                    const float dent = -pr[k] * (logp[k] + ent);
-                    dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
-                }
+#pragma unroll
+                for (int k = 0; k < NO; ++k)
+                    if (k < na) {
+                        const float dlp = ((k == a) ? 1.f : 0.f) - pr[k];
+                        const float dent = -pr[k] * (logp[k] + ent);
+                        dl[k] = dL_dlp * dlp - g.we * g.inv_b * dent;
+                    }
             } else {
                 const float eps = 1.0e-8f;
                 const float mu = oa[0], ls = oa[1];
