@@ -44,10 +44,12 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
 
     // ---- prologue: the first tile's scattered gather is issued first; the unit records go to LDS ----
     const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
-    const int tile0 = blockIdx.x * NT + id.team;
+    // the first tiles of the workgroup's teams are gathered by its FIRST waves (wave t for team t): waves start ~0.1 us apart,
+    // team 1's own wave 0 is the workgroup's ninth
+    const int lw = (int)threadIdx.x >> 6, ltile = blockIdx.x * NT + lw;
     TileRegs first;
-    const bool first_loader = id.tid < TILE && tile0 < g.num_tiles;
-    if (first_loader) first = fetch_sample<NS>(g, pk, g.pos0, tile0, id.tid);
+    const bool first_loader = lw < NT && ltile < g.num_tiles;
+    if (first_loader) first = fetch_sample<NS>(g, pk, g.pos0, ltile, (int)threadIdx.x & 63);
     float* l_rec = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());
     stage_records<NT>(l_rec, rec, h);  // phase 1a's copy of the records (complete behind publish_first_tile's barrier)
     UnitG G;
@@ -58,7 +60,20 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
 
     long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g.dbg) ts[0] = __builtin_amdgcn_s_memtime();
-    publish_first_tile<NT>(L, id, first_loader, first);
+    {   // publish into the owning team's buffer 0; a team without a tile gets finite operands (publish_first_tile)
+        if (first_loader) {
+            const TeamLds Lw = team_lds(smem, lw);
+            Lw.x[(int)threadIdx.x & 63] = first.x;
+            Lw.misc[(int)threadIdx.x & 63] = first.misc;
+        }
+        if (NT > 1 && id.tid < TILE && blockIdx.x * NT + id.team >= g.num_tiles) {
+            L.x[id.tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.misc[id.tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.x[TILE + id.tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.misc[TILE + id.tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+    }
     grad_tile_loop<NS, ACT, NO, NT>(g, pk, g.pos0, L, id, l_rec, b2, G, Hd, g.dbg ? ts + 1 : nullptr);
     if (g.dbg) ts[5] = __builtin_amdgcn_s_memtime();
     grad_fold<NT>(smem, L, id, h, G, Hd);
