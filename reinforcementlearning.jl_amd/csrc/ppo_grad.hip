@@ -392,10 +392,10 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 6; ++k) d[k] = ts[k];
         }
-        // departure: the last workgroup out re-arms both counters and advances the running beta powers (every
-        // workgroup has read beta_pow above, before its departure increment)
+        // departure: the last workgroup out re-arms the counter and advances the running beta powers and the epoch (every
+        // workgroup has USED beta_pow and the epoch above, before its departure increment -- a data dependence, no fence:
+        // nothing this workgroup stored is read by another workgroup of this launch; the end of the launch publishes it)
         if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == gridDim.x - 1) {
                 ap.beta_pow[0] *= ap.b1;
