@@ -928,13 +928,14 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
     double acc = own ? (double)x * (double)x : 0.0;
     acc = block_sum(acc, scratch);
     if (tid == 0) {
+        // the only data other workgroups read is this partial: a device-scope (write-through) store, drained before the
+        // arrival count goes up, read back by device-scope loads -- no release / acquire fences (an L2 write-back and an
+        // invalidate per workgroup)
         __hip_atomic_store(ap.sumsq + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(ap.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
             __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     // clip_adam_grid_kernel
@@ -969,7 +970,6 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
     __syncthreads();  // every lane of this workgroup has read beta_pow
     if (tid == 0) {
         if (blockIdx.x == 0 && ap.gn_out) ap.gn_out[0] = gn;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow or the arrival counter any more
             ap.beta_pow[0] *= ap.b1;

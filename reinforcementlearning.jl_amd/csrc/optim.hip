@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void clip_adam_grid_kernel(float* __restrict__
     __syncthreads();  // every thread of this workgroup has read beta_pow
     if (threadIdx.x == 0) {
         if (blockIdx.x == 0 && gn_out) gn_out[0] = gn;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // (no release fence: nothing this workgroup stored is read by another workgroup of the launch, and an L2 write-back
+        // on every workgroup's tail costs ~1 us per launch -- measured on reduce_apply_kernel, profiles/r03_tile_mfma.md)
         unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
             beta_pow[0] *= b1;

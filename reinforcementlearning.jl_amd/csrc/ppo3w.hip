@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
     __syncthreads();  // every thread of this workgroup has read beta_pow
     if (threadIdx.x == 0) {
         if (blockIdx.x == 0 && gn_out) gn_out[0] = gn;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // (no release fence: nothing this workgroup stored is read by another workgroup of the launch)
         const unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
             beta_pow[0] *= b1;
