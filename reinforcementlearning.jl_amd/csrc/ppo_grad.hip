@@ -35,6 +35,8 @@ namespace rlhip {
 template <int NS, int ACT, int NO, int NT>
 __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long t_entry = 0;
+    if (g.dbg) t_entry = __builtin_amdgcn_s_memtime();
     const int h = g.pd.h;
     const TeamIds id = team_ids<NT>(h);
     const TeamLds L = team_lds(smem, id.team);
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
         long long* d = g.dbg + (int64_t)blockIdx.x * 8;
 #pragma unroll
         for (int k = 0; k < 7; ++k) d[k] = ts[k];
+        d[7] = t_entry;
     }
     if (id.team != 0) return;
 

@@ -40,7 +40,10 @@ off = MAXB * np_ * 4 + MAXB * 4 * 4
 off = (off + 15) & ~15
 off += 4096 * 8 + 16 * 4
 G = 256
-d = pol.workspace[off:off + MAXB * 8 * 8].view(torch.int64).cpu().numpy().reshape(MAXB, 8)[:G, :7].astype(np.float64)
+d8 = pol.workspace[off:off + MAXB * 8 * 8].view(torch.int64).cpu().numpy().reshape(MAXB, 8)[:G].astype(np.float64)
+d = d8[:, :7]
+pro = (d8[:, 0] - d8[:, 7]) * float(os.environ.get("RLHIP_TICK_NS", "0.47")) * 1e-3
+print(f"gradient launch, thread 0: kernel entry -> records staged (keys, gather issued, records) {pro.mean():6.2f} {pro.min():6.2f} {pro.max():6.2f}")
 tick_us = 1e-3 * float(os.environ.get("RLHIP_TICK_NS", "0.47"))  # s_memtime tick (tools/persist_timeline.py measures it)
 names = ["publish first tile (+ barrier)", "phase 1a (+ barrier)", "phase 1b (+ barrier)", "phase 2 (+ barrier)", "-", "fold"]
 ph = np.diff(d, axis=1) * tick_us
