@@ -45,6 +45,10 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     const float* __restrict__ tailb = rec + REC * h;
 
     // ---- prologue: the first tile's scattered gather is issued first; the unit records go to LDS ----
+    // (the record image is requested first -- its address costs nothing; the gather's addresses are ~150 instructions away)
+    float* l_rec = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());
+    float4 recv[(NW * 32 * 4) / (512 * NT)];
+    stage_records_load<NT>(recv, rec, h);
     const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
     // the first tiles of the workgroup's teams are gathered by its FIRST waves (wave t for team t): waves start ~0.1 us apart,
     // team 1's own wave 0 is the workgroup's ninth
@@ -52,8 +56,7 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     TileRegs first;
     const bool first_loader = lw < NT && ltile < g.num_tiles;
     if (first_loader) first = fetch_sample<NS>(g, pk, g.pos0, ltile, (int)threadIdx.x & 63);
-    float* l_rec = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());
-    stage_records<NT>(l_rec, rec, h);  // phase 1a's copy of the records (complete behind publish_first_tile's barrier)
+    stage_records_store<NT>(l_rec, recv);  // phase 1a's copy of the records (complete behind the first barrier)
     UnitG G;
     G.zero();
     HeadG Hd;

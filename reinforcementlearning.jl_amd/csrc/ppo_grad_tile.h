@@ -243,6 +243,26 @@ __device__ __forceinline__ void stage_records(float* l_rec, const float* __restr
         *reinterpret_cast<float4*>(l_rec + slot * RS + 4 * part) = v;
     }
 }
+// the same in two halves: request early, store late (the gradient kernel puts the first tile's gather in between)
+template <int NT>
+__device__ __forceinline__ void stage_records_load(float4 (&v)[(NW * 32 * 4) / (512 * NT)], const float* __restrict__ rec, int h) {
+    const int hq = h / NW;
+#pragma unroll
+    for (int i = 0; i < (NW * 32 * 4) / (512 * NT); ++i) {
+        const int idx = (int)threadIdx.x + 512 * NT * i, slot = idx >> 2, part = idx & 3;
+        const int m = slot & 31, j = (slot >> 5) * hq + m;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < hq) v[i] = *reinterpret_cast<const float4*>(rec + REC * j + 4 * part);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stage_records_store(float* l_rec, const float4 (&v)[(NW * 32 * 4) / (512 * NT)]) {
+#pragma unroll
+    for (int i = 0; i < (NW * 32 * 4) / (512 * NT); ++i) {
+        const int idx = (int)threadIdx.x + 512 * NT * i, slot = idx >> 2, part = idx & 3;
+        *reinterpret_cast<float4*>(l_rec + slot * RS + 4 * part) = v[i];
+    }
+}
 __device__ __forceinline__ int record_lds_slot(int j, int h) {
     const int hq = h / NW;
     return (j / hq) * 32 + (j % hq);
