@@ -374,8 +374,13 @@ __global__ __launch_bounds__(1024) void dqn_reduce_apply_kernel(const float* __r
     }
     __syncthreads();
     if (grp == 0) {
+        // read back by the last workgroup through device-scope loads: a device-scope (write-through) store, drained before
+        // the arrival count goes up -- instead of release / acquire fences (an L2 write-back per workgroup, an invalidate)
         const int p = blockIdx.x * 64 + lane;
-        if (p < np) grad[p] = ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane];
+        if (p < np)
+            __hip_atomic_store(grad + p, ((l_g[0][lane] + l_g[1][lane]) + l_g[2][lane]) + l_g[3][lane], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (blockIdx.x == 0 && loss != nullptr && grp == 1) {
         float a = 0.f;
@@ -385,15 +390,10 @@ __global__ __launch_bounds__(1024) void dqn_reduce_apply_kernel(const float* __r
         if (lane == 0) loss[0] = a * inv_b;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {  // (behind the workgroup barrier above: wave 0's gradient stores have drained)
         unsigned int prev = __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         l_last = (prev == gridDim.x - 1) ? 1 : 0;
-        if (l_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        }
+        if (l_last) __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     }
     __syncthreads();
     if (!l_last) return;
