@@ -18,6 +18,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow,
                                        int64_t n, float grad_scale, float clip_norm, float lr, float beta1,
                                        float beta2, float eps, float* gn_out, rlhip_stream_t stream);
@@ -127,6 +129,27 @@ static size_t grad_smem_bytes(int nt) { return grad_wg_smem_bytes(nt); }
 __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ packed,
                                                           int h, int ns, int nout, int64_t np_a) {
     pack_records(params, packed, h, ns, nout, np_a, threadIdx.x, blockDim.x);
+}
+
+// Once per update call: workgroup 0 packs the unit records (pack_params_kernel), the others write one 32-byte record per
+// trajectory entry f = t n + i -- {x0..x3}, {logp, adv, ret, action bits} -- from the eight planes of the trajectory (coalesced
+// reads and writes).  The 16 optimiser steps then gather a shuffled sample with two 16-byte reads of ONE cache line instead
+// of eight 4-byte reads of eight lines: 32768 samples x 8 lines x 64 B = 16.8 MB through the fabric per step otherwise.
+__global__ __launch_bounds__(256) void pack_update_kernel(const float* __restrict__ params, float* __restrict__ packed, int h,
+                                                          int ns, int nout, int64_t np_a, GradArgs g, float4* __restrict__ samples) {
+    if (blockIdx.x == 0) {
+        pack_records(params, packed, h, ns, nout, np_a, threadIdx.x, blockDim.x);
+        return;
+    }
+    const uint32_t n = (uint32_t)g.n;
+    for (uint32_t f = (blockIdx.x - 1) * 256 + threadIdx.x; f < g.total; f += (gridDim.x - 1) * 256) {
+        const uint32_t t = f / n, i = f - t * n;
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < ns; ++k) xv[k] = g.obs[((int64_t)t * ns + k) * g.n + i];
+        const float a = g.pd.cont ? g.action_f[f] : __int_as_float(g.action_i[f]);
+        samples[2 * (int64_t)f] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        samples[2 * (int64_t)f + 1] = make_float4(g.logp[f], g.adv[f], g.ret[f], a);
+    }
 }
 
 // ------------------------------------------------------------------------- reduce (+ apply) ----
@@ -559,6 +582,7 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     out->counter = (unsigned int*)(out->sumsq + 4096);
     long long* dbgp = (long long*)(out->counter + 16);  // MAX_GRAD_BLOCKS x 8 words
     g.dbg = RLHIP_ENV_FLAG("RLHIP_GRAD_DEBUG") ? dbgp : nullptr;
+    g.samples = nullptr;
     uintptr_t pq = (uintptr_t)(dbgp + (int64_t)MAX_GRAD_BLOCKS * 8);
     pq = (pq + 63) & ~(uintptr_t)63;
     out->packed = (float*)pq;
@@ -653,6 +677,12 @@ using namespace rlhip;
 extern "C" {
 
 // bytes of the two-launch path's carve (prepare_grad); the persistent kernel's buffers follow, 256-byte aligned
+// sample records of an update call (pack_update_kernel), behind the persistent kernel's area: 32 B per trajectory entry, up
+// to 2^24 entries (512 MB); beyond that the steps gather from the planes
+static int64_t sample_record_bytes(int64_t n, int64_t T) {
+    const int64_t total = n * T;
+    return (total >= 1 && total <= ((int64_t)1 << 24)) ? 32 * total : 0;
+}
 static int64_t grad_workspace_bytes(int64_t np) {
     const int64_t b = (int64_t)MAX_GRAD_BLOCKS * (np + 4) * (int64_t)sizeof(float) + 16 + 4096 * (int64_t)sizeof(double) + 64 +
                       (int64_t)MAX_GRAD_BLOCKS * 8 * (int64_t)sizeof(long long) + 64 + (16 * 256 + 8) * (int64_t)sizeof(float);
@@ -663,7 +693,7 @@ int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
     if (is_layers3(cfg)) return ppo3_workspace_bytes(kind, cfg, n, T);
     int64_t np = rlhip_ppo_nparams(kind, cfg);
     if (np < 0) return -1;
-    return grad_workspace_bytes(np) + ppo_persist_bytes(np, cfg->hidden);
+    return grad_workspace_bytes(np) + ppo_persist_bytes(np, cfg->hidden) + sample_record_bytes(n, T);
 }
 
 /* Did a persistent update (ppo_persist.hip) ever give up on a hand-off in this workspace?  Synchronises `stream`.
@@ -899,6 +929,12 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
         if (rc <= 0) return rc;
     }
     // ... otherwise two launches per optimiser step
+    float4* samples = nullptr;
+    {
+        const int64_t np_ = rlhip_ppo_nparams(kind, cfg);
+        if (sample_record_bytes(n, T) > 0 && np_ > 0)
+            samples = (float4*)((char*)workspace + grad_workspace_bytes(np_) + ppo_persist_bytes(np_, cfg->hidden));
+    }
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         uint32_t epoch_ctr = ctr ? (uint32_t)e : update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
@@ -906,10 +942,19 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             GradLaunch L;
             int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, ctr);
             if (rc) return rc;
-            if (first) {  // pack the unit records once per call; the Adam tail refreshes them after every step.
-                          // The arrival counter needs no per-call memset: the workspace is zero-initialised
-                          // by its owner (ABI contract) and the last-arriving workgroup re-arms it in-kernel.
-                launch_pack(L, s);
+            if (samples) L.g.samples = samples;
+            if (first) {  // pack the unit records (and the sample records) once per call; the Adam tail refreshes the unit
+                          // records after every step.  The arrival counter needs no per-call memset: the workspace is
+                          // zero-initialised by its owner (ABI contract) and the last-arriving workgroup re-arms it in-kernel.
+                if (samples) {
+                    const int nblk = 1 + (int)std::min<int64_t>(((int64_t)L.g.total + 255) / 256, 2048);
+                    GradArgs ga = L.g;
+                    ga.samples = nullptr;
+                    hipLaunchKernelGGL(pack_update_kernel, dim3(nblk), dim3(256), 0, s, L.g.params, L.packed, L.g.pd.h, L.ns,
+                                       L.g.pd.nout_a, L.g.pd.np_a, ga, samples);
+                } else {
+                    launch_pack(L, s);
+                }
                 first = false;
             }
             if ((rc = launch_grad(L, s))) return rc;

@@ -63,6 +63,9 @@ struct GradArgs {
     const uint32_t* ctr;   // ... or, when non-NULL, in the kernel from the device update counter ctr[1]:
     uint64_t seed;         //     epoch = epoch_local + ctr[1] * n_epochs  (HIP-graph replayable)
     uint32_t epoch_local, n_epochs;
+    const float4* samples; // sample records {x0..x3}, {logp, adv, ret, action bits} per trajectory entry f = t n + i, or NULL:
+                           // written once per update call (pack_update_kernel); a shuffled sample is then ONE 32-byte
+                           // read instead of eight 4-byte reads from eight planes (eight cache lines)
     long long* dbg;        // RLHIP_GRAD_DEBUG: [workgroup][8] s_memtime stamps of thread 0 (tools/grad_timeline.py), else NULL
 };
 
@@ -77,8 +80,14 @@ __device__ __forceinline__ TileRegs fetch_sample(const GradArgs& g, const PermKe
     uint32_t q = (uint32_t)tile * TILE + (uint32_t)s;
     bool valid = q < g.bm;
     uint32_t f = permute(pk, pos0 + (valid ? q : 0u));
-    uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
     TileRegs r;
+    if (g.samples) {
+        r.x = g.samples[2 * (int64_t)f];
+        r.misc = g.samples[2 * (int64_t)f + 1];
+        if (!valid) r.misc.y = 0.0f;
+        return r;
+    }
+    uint32_t t = f / (uint32_t)g.n, i = f - t * (uint32_t)g.n;
     float xv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NS; ++k) xv[k] = g.obs[((int64_t)t * NS + k) * g.n + i];

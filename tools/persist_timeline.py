@@ -32,7 +32,9 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3
 G, S = 256, 64
-dbg = pol.workspace[-G * S * 8 * 8:].view(torch.int64).cpu().numpy().reshape(G, S, 8)
+tail = 32 * n * T  # the update call's sample records sit behind the persistent kernel's area (csrc/ppo_grad.hip)
+end = pol.workspace.numel() - tail
+dbg = pol.workspace[end - G * S * 8 * 8:end].view(torch.int64).cpu().numpy().reshape(G, S, 8)
 nsteps = pol.n_updates_per_call()
 d = dbg[:, :nsteps, :7].astype(np.float64)
 # s_memtime counters are per XCD (not synchronised across them): only differences inside one workgroup mean anything
