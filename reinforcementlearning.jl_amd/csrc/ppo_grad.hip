@@ -689,6 +689,25 @@ static int64_t grad_workspace_bytes(int64_t np) {
     return (b + 255) / 256 * 256;
 }
 
+// where the sample records of an update call live in the learner's workspace (NULL: too many entries, gather from the planes)
+static float4* update_samples_ptr(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, void* workspace) {
+    const int64_t np_ = rlhip_ppo_nparams(kind, cfg);
+    if (sample_record_bytes(n, T) <= 0 || np_ <= 0) return nullptr;
+    return (float4*)((char*)workspace + grad_workspace_bytes(np_) + ppo_persist_bytes(np_, cfg->hidden));
+}
+// first launch of an update call: unit records (+ the sample records, same launch)
+static void pack_for_update(const GradLaunch& L, float4* samples, hipStream_t s) {
+    if (!samples) {
+        launch_pack(L, s);
+        return;
+    }
+    const int nblk = 1 + (int)std::min<int64_t>(((int64_t)L.g.total + 255) / 256, 2048);
+    GradArgs ga = L.g;
+    ga.samples = nullptr;
+    hipLaunchKernelGGL(pack_update_kernel, dim3(nblk), dim3(256), 0, s, L.g.params, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a,
+                       L.g.pd.np_a, ga, samples);
+}
+
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T) {
     if (is_layers3(cfg)) return ppo3_workspace_bytes(kind, cfg, n, T);
     int64_t np = rlhip_ppo_nparams(kind, cfg);
@@ -806,6 +825,7 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
         for (int q = 0; q < world; ++q) RLHIP_REQUIRE(comm_bufs_host[q] != nullptr, "peer buffer is NULL");
     }
     const int rblocks = (int)((np + RP - 1) / RP);
+    float4* samples = is_layers3(cfg) ? nullptr : update_samples_ptr(kind, cfg, n, T, workspace);
     const bool fused = !is_layers3(cfg) && rblocks <= grid_apply_max_blocks<APPLY_XCHG>() && world <= 16 &&
                        comm_cap <= (1 << 24) && !RLHIP_ENV_FLAG("RLHIP_P2P_UNFUSED");
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
@@ -817,7 +837,8 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
                 int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, nullptr);
                 if (rc) return rc;
                 hipStream_t s = as_stream(stream);
-                if (first) launch_pack(L, s);
+                L.g.samples = samples;
+                if (first) pack_for_update(L, samples, s);
                 first = false;
                 if ((rc = launch_grad(L, s))) return rc;
                 ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
@@ -929,12 +950,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
         if (rc <= 0) return rc;
     }
     // ... otherwise two launches per optimiser step
-    float4* samples = nullptr;
-    {
-        const int64_t np_ = rlhip_ppo_nparams(kind, cfg);
-        if (sample_record_bytes(n, T) > 0 && np_ > 0)
-            samples = (float4*)((char*)workspace + grad_workspace_bytes(np_) + ppo_persist_bytes(np_, cfg->hidden));
-    }
+    float4* samples = update_samples_ptr(kind, cfg, n, T, workspace);
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {
         uint32_t epoch_ctr = ctr ? (uint32_t)e : update_ctr * (uint32_t)cfg->n_epochs + (uint32_t)e;
@@ -946,15 +962,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             if (first) {  // pack the unit records (and the sample records) once per call; the Adam tail refreshes the unit
                           // records after every step.  The arrival counter needs no per-call memset: the workspace is
                           // zero-initialised by its owner (ABI contract) and the last-arriving workgroup re-arms it in-kernel.
-                if (samples) {
-                    const int nblk = 1 + (int)std::min<int64_t>(((int64_t)L.g.total + 255) / 256, 2048);
-                    GradArgs ga = L.g;
-                    ga.samples = nullptr;
-                    hipLaunchKernelGGL(pack_update_kernel, dim3(nblk), dim3(256), 0, s, L.g.params, L.packed, L.g.pd.h, L.ns,
-                                       L.g.pd.nout_a, L.g.pd.np_a, ga, samples);
-                } else {
-                    launch_pack(L, s);
-                }
+                pack_for_update(L, samples, s);
                 first = false;
             }
             if ((rc = launch_grad(L, s))) return rc;
