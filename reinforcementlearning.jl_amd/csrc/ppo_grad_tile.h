@@ -152,18 +152,6 @@ struct UnitG {  // its gradient accumulators, same pairing
         w2a1 = w2a2 = 0.f;
     }
 };
-// a unit's weights from its record (any pointer type)
-template <class P>
-__device__ __forceinline__ UnitW unit_from_record(P r) {
-    UnitW W;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) W.w1[k] = f2{r[2 * k], r[2 * k + 1]};
-    W.b1 = f2{r[8], r[9]};
-    W.w2p = f2{r[10], r[11]};
-    W.w2a1 = r[12];
-    W.w2a2 = r[13];
-    return W;
-}
 struct HeadG {  // wave 0 of a team, lane = sample: output-bias gradients and loss sums
     float b2a[GMAXO];
     float b2c, s_actor, s_critic, s_ent;
@@ -239,20 +227,8 @@ __device__ __forceinline__ float tile_act(float z) {
 }
 
 // ---- the workgroup's LDS copy of the unit records for phase 1a: slot 32 w + m <- unit w hq + m (hq = h / NW), zeros beyond hq ----
-// from the packed global image (two-launch kernel prologue); every thread of the workgroup; no barrier inside
-template <int NT>
-__device__ __forceinline__ void stage_records(float* l_rec, const float* __restrict__ rec, int h) {
-    const int hq = h / NW;
-#pragma unroll
-    for (int i = 0; i < (NW * 32 * 4) / (512 * NT); ++i) {
-        const int idx = (int)threadIdx.x + 512 * NT * i, slot = idx >> 2, part = idx & 3;
-        const int m = slot & 31, j = (slot >> 5) * hq + m;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < hq) v = *reinterpret_cast<const float4*>(rec + REC * j + 4 * part);
-        *reinterpret_cast<float4*>(l_rec + slot * RS + 4 * part) = v;
-    }
-}
-// the same in two halves: request early, store late (the gradient kernel puts the first tile's gather in between)
+// from the packed global image (two-launch kernel prologue), every thread of the workgroup, in two halves: request early,
+// store late (the gradient kernel puts the first tile's gather in between); no barrier inside
 template <int NT>
 __device__ __forceinline__ void stage_records_load(float4 (&v)[(NW * 32 * 4) / (512 * NT)], const float* __restrict__ rec, int h) {
     const int hq = h / NW;
