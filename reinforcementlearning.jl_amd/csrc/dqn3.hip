@@ -843,6 +843,12 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = blockIdx.x * 256 + tid;
     const bool own = i < np;
+    // the norm exchange: up to 128 workgroups publish their sum of squares as two 8-byte {epoch, half of the double} granules
+    // that the others poll directly (one hop; epoch = launches so far + 1, device-resident, advanced by the last workgroup
+    // out) -- larger grids keep the arrival counter (the tail holds 256 doubles)
+    const bool gran = 2 * gridDim.x <= 256;
+    unsigned int epoch = 0;
+    if (gran) epoch = __hip_atomic_load(ap.counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     // operands that do not depend on the barrier
     const float p0 = own ? ap.p[i] : 0.f, m0 = own ? ap.m[i] : 0.f, v0 = own ? ap.v[i] : 0.f;
     const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
@@ -903,20 +909,22 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
         if (lane == 0) loss[0] = a * inv_b;
     }
-    if (blockIdx.x == 0 && loss != nullptr && ap.np_a > 0) {  // ppo3_reduce_kernel's loss line (block-uniform branch)
-        __shared__ float l_loss[4];
-        if (wv < 3) {
+    if (blockIdx.x == 0 && loss != nullptr && ap.np_a > 0 && wv == 1) {
+        // ppo3_reduce_kernel's loss line: wave 1 alone, no workgroup barrier (workgroup 0 must not arrive late at the norm
+        // exchange every other workgroup waits on); the same sums in the same order as with one wave per column
+        float col[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
             float a = 0.f;
-            for (int b = lane; b < nb; b += 64) a += loss_partials[(int64_t)b * 4 + wv];
+            for (int b = lane; b < nb; b += 64) a += loss_partials[(int64_t)b * 4 + c];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
-            if (lane == 0) l_loss[wv] = a;
+            col[c] = a;
         }
-        __syncthreads();
-        if (tid == 0) {
-            const float actor_loss = -l_loss[0] * inv_b;
-            const float critic_loss = l_loss[1] * inv_b;
-            const float ent_loss = l_loss[2] * inv_b;
+        if (lane == 0) {
+            const float actor_loss = -col[0] * inv_b;
+            const float critic_loss = col[1] * inv_b;
+            const float ent_loss = col[2] * inv_b;
             loss[0] = ap.wa * actor_loss + ap.wc * critic_loss - ap.we * ent_loss;
             loss[1] = actor_loss;
             loss[2] = critic_loss;
@@ -927,21 +935,42 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
     const float x = own ? g * ap.grad_scale : 0.0f;
     double acc = own ? (double)x * (double)x : 0.0;
     acc = block_sum(acc, scratch);
-    if (tid == 0) {
-        // the only data other workgroups read is this partial: a device-scope (write-through) store, drained before the
-        // arrival count goes up, read back by device-scope loads -- no release / acquire fences (an L2 write-back and an
-        // invalidate per workgroup)
-        __hip_atomic_store(ap.sumsq + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(ap.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
-            __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-    // clip_adam_grid_kernel
+    typedef unsigned long long u64;
     double tot = 0.0;
-    for (int q = tid; q < (int)gridDim.x; q += 256)
-        tot += __hip_atomic_load(ap.sumsq + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gran) {
+        if (tid == 0) {
+            const u64 bits = (u64)__double_as_longlong(acc), ep = (u64)epoch << 32;
+            u64* gr = reinterpret_cast<u64*>(ap.sumsq) + 2 * blockIdx.x;
+            __hip_atomic_store(gr, ep | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gr + 1, ep | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // clip_adam_grid_kernel's sum over the partials, thread q takes workgroup q's
+        for (int q = tid; q < (int)gridDim.x; q += 256) {
+            const u64* gr = reinterpret_cast<const u64*>(ap.sumsq) + 2 * q;
+            u64 hi, lo;
+            for (;;) {
+                hi = __hip_atomic_load(gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo = __hip_atomic_load(gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(hi >> 32) == epoch && (unsigned int)(lo >> 32) == epoch) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            tot += __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
+        }
+    } else {
+        if (tid == 0) {
+            // the only data other workgroups read is this partial: a device-scope (write-through) store, drained before the
+            // arrival count goes up, read back by device-scope loads -- no release / acquire fences
+            __hip_atomic_store(ap.sumsq + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(ap.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        // clip_adam_grid_kernel
+        for (int q = tid; q < (int)gridDim.x; q += 256)
+            tot += __hip_atomic_load(ap.sumsq + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     tot = block_sum(tot, scratch);
     const float gn = (float)sqrt(tot);
     const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
@@ -976,6 +1005,7 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
             ap.beta_pow[1] *= ap.b2;
             __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gran) __hip_atomic_store(ap.counter + 3, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
