@@ -648,8 +648,10 @@ int32_t rlhip_ppo_push_postact_f32(const rlhip_ppo_traj* traj_host, int64_t t, i
 /* generalized_advantage_estimation(reward, values, gamma, lambda; dims = 2, terminal) + returns */
 int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                           const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);
-/* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes.  The caller must
- * ZERO-INITIALISE it once after allocation (it holds an arrival counter that the kernels re-arm themselves). */
+/* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes, for trajectories of up to n x T entries
+ * (two-layer nets: partial gradient rows, the unit-record image, the persistent kernel's hand-off words and 32 bytes per
+ * trajectory entry for the sample records an update call packs once -- none above 2^24 entries).  The caller must
+ * ZERO-INITIALISE it once after allocation (it holds counters and epoch words that the kernels maintain themselves). */
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T);
 /* loss + flat gradient of micro-batch `mb` of epoch `epoch_ctr` (samples = keyed permutation of the
  * T*n transitions).  grad_out: f32[nparams]; losses_out (nullable): f32[4] = loss, actor, critic, entropy */
