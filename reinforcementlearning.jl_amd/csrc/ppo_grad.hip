@@ -306,18 +306,28 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         double sq = (double)gx * (double)gx;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
+        // the rank-local exchange of the sums of squares: like APPLY_GRID, each partial is its own arrival flag -- two 8-byte
+        // {sequence number of this exchange, half of the double} granules (in their own part of the sumsq area: the
+        // sequence numbers are the communicator's, not this workspace's launch count), polled directly by every workgroup
+        typedef unsigned long long u64;
         if (lane == 0) {
-            ap.sumsq[blockIdx.x] = sq;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(ap.counter + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(ap.counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
-                __builtin_amdgcn_s_sleep(1);
+            const u64 bits = (u64)__double_as_longlong(sq), ep = (u64)xa.seq << 32;
+            u64* gr = reinterpret_cast<u64*>(ap.sumsq) + 512 + 2 * blockIdx.x;
+            __hip_atomic_store(gr, ep | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gr + 1, ep | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         double part = 0.0;
-        for (int b = lane; b < (int)gridDim.x; b += 64)
-            part += __hip_atomic_load(ap.sumsq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = lane; b < (int)gridDim.x; b += 64) {
+            const u64* gr = reinterpret_cast<const u64*>(ap.sumsq) + 512 + 2 * b;
+            u64 hi, lo;
+            for (;;) {
+                hi = __hip_atomic_load(gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo = __hip_atomic_load(gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(hi >> 32) == xa.seq && (unsigned int)(lo >> 32) == xa.seq) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            part += __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
         const float gn = (float)sqrt(part);
@@ -335,8 +345,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             grad[p] = g1;
             ap.packed[record_slot(p, ap.h, ap.ns, ap.nout, ap.np_a)] = pn;
         }
-        if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) {  // (no release fence: see APPLY_GRID's departure)
             unsigned int prev = __hip_atomic_fetch_add(ap.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == gridDim.x - 1) {
                 ap.beta_pow[0] *= ap.b1;
