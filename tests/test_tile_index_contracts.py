@@ -75,3 +75,47 @@ def test_row_operand_fetch_order_matches_the_register_order():
         for P in range(32):
             q, rt = P & 15, P >> 4
             assert 32 * (P >> 4) + (q & 3) + 8 * (q >> 2) + 4 * kb == 32 * rt + mfma_row(q, kb)
+
+
+def test_sample_records_are_the_planes_transposed():
+    """pack_update_kernel: record f = t n + i holds {obs[(t ns + k) n + i], k < ns; 0 ...}, {logp[f], adv[f], ret[f], action[f]}:
+    gathering record f equals gathering the eight planes at (t, i) -- for every ns the fused learner supports"""
+    rng = np.random.default_rng(3)
+    for ns in (2, 3, 4):
+        n, T = 37, 5
+        obs = rng.standard_normal(((T + 1) * ns * n)).astype(np.float32)
+        logp, adv, ret = (rng.standard_normal(T * n).astype(np.float32) for _ in range(3))
+        act = rng.integers(0, 3, T * n).astype(np.int32)
+        rec = np.zeros((T * n, 8), np.float32)
+        for f in range(T * n):
+            t, i = divmod(f, n)
+            for k in range(ns):
+                rec[f, k] = obs[(t * ns + k) * n + i]
+            rec[f, 4:7] = logp[f], adv[f], ret[f]
+            rec[f, 7] = act[f:f + 1].view(np.float32)[0]
+        for f in rng.permutation(T * n)[:50]:
+            t, i = divmod(int(f), n)
+            x = [obs[(t * ns + k) * n + i] if k < ns else 0.0 for k in range(4)]
+            assert list(rec[f, :4]) == [np.float32(v) for v in x]
+            assert rec[f, 7:8].view(np.int32)[0] == act[f]
+            assert (rec[f, 4], rec[f, 5], rec[f, 6]) == (logp[f], adv[f], ret[f])
+
+
+def test_norm_partial_granules_round_trip_and_never_match_a_stale_epoch():
+    """reduce_apply_kernel<APPLY_GRID> / d3_apply_kernel: a workgroup's Float64 sum of squares travels as two 8-byte granules
+    {epoch << 32 | high half}, {epoch << 32 | low half}; the reader accepts a pair only when BOTH tags equal this launch's epoch"""
+    rng = np.random.default_rng(4)
+    vals = np.concatenate([rng.standard_normal(64) ** 2 * 1e3, [0.0, 1e-300, 1e300, np.inf]])
+    for epoch in (1, 2, 0x7FFFFFFF, 0xFFFFFFFF):
+        for v in vals:
+            bits = np.float64(v).view(np.uint64)
+            hi = (np.uint64(epoch) << np.uint64(32)) | (bits >> np.uint64(32))
+            lo = (np.uint64(epoch) << np.uint64(32)) | (bits & np.uint64(0xFFFFFFFF))
+            assert int(hi >> np.uint64(32)) == epoch and int(lo >> np.uint64(32)) == epoch
+            back = ((hi & np.uint64(0xFFFFFFFF)) << np.uint64(32)) | (lo & np.uint64(0xFFFFFFFF))
+            assert back == bits
+            # a torn pair (one granule from the previous launch) is never accepted
+            stale = (np.uint64((epoch - 1) & 0xFFFFFFFF) << np.uint64(32)) | (bits >> np.uint64(32))
+            assert int(stale >> np.uint64(32)) != epoch
+    # a zero-initialised workspace never matches the first launch (epoch = stored count + 1 >= 1)
+    assert int(np.uint64(0) >> np.uint64(32)) != 1
