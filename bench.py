@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s + learner updates/s of the 4096-env CartPole PPO hot path on N x MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: re-executes itself under the launcher below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -674,14 +674,28 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / breakdown legs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on a free
+        # loopback port, same arguments (the ranks see WORLD_SIZE and take the branch below).  exec: the launcher's exit
+        # status, stdout (rank 0's JSON line) and signals are this process's.
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch one rank per GPU (or run `python bench.py "
+                         f"--gpus N` bare: it launches torch.distributed.run itself)")
     # test hooks (not used by the driver): all ranks on device 0 / gloo instead of RCCL, to exercise the
     # N > 1 code path on a single-GPU box
     if os.environ.get("RLHIP_BENCH_SINGLE_DEVICE", "0") == "1":

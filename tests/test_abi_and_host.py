@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import pytest
 
@@ -12,6 +13,7 @@ import rlhip
 from rlhip import _lib
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -305,3 +307,37 @@ def test_packed_episode_counter_capacity_and_host_guard():
     assert cap(1) == (1 << 30) - 1            # 2 step bits
     assert cap((1 << 20) - 2) == (1 << 12) - 1
     assert cap((1 << 20) - 1) == -1 and cap(0) == -1
+
+
+def test_bare_bench_with_gpus_n_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus 8` without WORLD_SIZE (the form the driver uses at N = 1) must not die on
+    plumbing: it re-executes itself under torch.distributed.run, one rank per GPU, loopback rendezvous, same arguments"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class _Stop(Exception):
+        pass
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, argv
+        raise _Stop()
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "3"])
+    with pytest.raises(_Stop):
+        bench.main()
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and 0 < int(a[a.index("--master-port") + 1]) < 65536
+    assert a[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "3"]
+    # under the launcher (WORLD_SIZE set) a mismatch is still an error, not a silent single-rank run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit):
+        bench.main()

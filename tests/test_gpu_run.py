@@ -405,17 +405,24 @@ def test_debug_timer_reports_device_time_per_run_loop_section():
     assert rlhip.timer.todict()["plan!"]["ncalls"] == 700 and len(rlhip.timer.todict()) == n_before
 
 
-def test_bench_two_ranks_on_one_device_prints_the_contract_line():
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), both ranks on this
-    box's single GPU via the RLHIP_BENCH_SINGLE_DEVICE test hook: the JSON contract line, the exchange mode, the
-    all-reduce report of SURVEY 8(e), no peer-to-peer timeouts"""
+@pytest.mark.parametrize("form", ["torch.distributed.run", "bare"])
+def test_bench_two_ranks_on_one_device_prints_the_contract_line(form):
+    """bench.py --gpus 2 as the driver launches it -- under torch.distributed.run (one rank per process), and BARE
+    (`python bench.py --gpus 2`, the form the driver uses at N = 1: bench.py must then launch its ranks itself, VERDICT r3
+    item 3) -- both ranks on this box's single GPU via the RLHIP_BENCH_SINGLE_DEVICE test hook: the JSON contract line, the
+    exchange mode, the all-reduce report of SURVEY 8(e), no peer-to-peer timeouts"""
     import json
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RLHIP_BENCH_SINGLE_DEVICE="1", RLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")  # RCCL refuses two ranks on one device
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5",
-           "--warmup", "2"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+    if form == "bare":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + tail
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
