@@ -503,6 +503,111 @@ def roofline_extras(torch, rlhip):
     return out
 
 
+def roofline_hbm_side(torch, rlhip):
+    """The rest of SURVEY 8(d)'s HBM list, each at a size that leaves the caches, algorithmic bytes per
+    unit from SURVEY 8(d): Pendulum / MountainCar env-step at 2^24 envs (45 / 33 B per env-step), Adam (28 B / param) and
+    Polyak (12 B / param) at 2^22 and 2^26 parameters, the replay push with the 2-frame max-pool at config 5's frame size
+    (84 x 84 x 4 u8, 4096 transitions per launch: 2 screens read, 1 frame + 9 B written per transition), and the small
+    (CartPole) transition gather, 82 B per sample x 2^20 samples out of a 2^20-transition ring."""
+    from rlhip import ops
+    from rlhip._lib import call
+    from rlhip.ops import ptr, stream_ptr
+    from rlhip.trajectory import CircularArraySARTSTraces
+
+    lib, s = rlhip._lib.lib, stream_ptr()
+    out = {}
+
+    def entry(gb, ms, **kw):
+        d = {"bound": "hbm", "us_per_launch": round(ms * 1e3, 2), "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(gb * 1e9)}
+        d.update(kw)
+        return d
+
+    # --- env-step of the other two classic-control envs (same kernel template as `roofline`, same protocol: random actions,
+    # episodes de-synchronised before the timed launches, packed episode counters)
+    n = 1 << 24
+    for kind, na, nbytes, with_obs in (("pendulum", 3, 45, True), ("mountaincar", 3, 33, False)):
+        env = rlhip.HipVecEnv(kind, n, seed=1, packed_episode=True)
+        actions = torch.randint(0, na, (8, n), dtype=torch.int32, device="cuda")
+        a_ptrs = [ptr(actions[k]) for k in range(8)]
+        obs = torch.empty((3, n), dtype=torch.float32, device="cuda") if with_obs else None
+        k = [0]
+
+        def step():
+            k[0] += 1
+            call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, a_ptrs[k[0] & 7], 1, env.seed, 0,
+                 None, ptr(obs) if with_obs else None, s)
+
+        for _ in range(40):  # clocks, TLB; the 200-step episodes of 2^24 envs stay synchronised (time limit only) -- see note
+            step()
+        torch.cuda.synchronize()
+        ms = event_time_ms(step, 20, lib, s)
+        out[f"env_step_{kind}"] = entry(nbytes * n / 1e9, ms, n_envs=n, bytes_per_unit=nbytes,
+                                        kernel=f"env_step_kernel<{kind},f32,EPL=4,non-temporal,packed>",
+                                        env_steps_per_sec=round(n / (ms * 1e-3), 1),
+                                        note=("state(env) = (cos, sin, thetadot) written by the same launch (obs_out)" if with_obs else
+                                              "state(env) IS the state arrays") + "; uniformly random discrete actions")
+        del env, actions, obs
+        torch.cuda.empty_cache()
+    # --- Adam (Optimisers.Adam, 28 B / param) and Polyak (TargetNetwork soft sync, 12 B / param)
+    for logn in (22, 26):
+        n = 1 << logn
+        p, g, m, v = (torch.randn(n, device="cuda") for _ in range(4))
+        v.abs_()
+        bp = torch.tensor([0.9, 0.999], device="cuda")
+        ops.adam_(p, g, m, v, bp)
+        ms = event_time_ms(lambda: ops.adam_(p, g, m, v, bp), 20, lib, s)
+        out[f"adam_2p{logn}"] = entry(28 * n / 1e9, ms, n_params=n, bytes_per_unit=28,
+                                      kernel="adam_vec4_kernel + beta_pow_advance_kernel (one call = two launches)",
+                                      note="2^22 parameters (117 MB per call) fit the 256 MB Infinity Cache: the 2^26 entry is the HBM one" if logn == 22 else "")
+        ops.polyak_(p, g, 0.995)
+        ms = event_time_ms(lambda: ops.polyak_(p, g, 0.995), 20, lib, s)
+        out[f"polyak_2p{logn}"] = entry(12 * n / 1e9, ms, n_params=n, bytes_per_unit=12, kernel="polyak_vec4_kernel")
+        del p, g, m, v
+        torch.cuda.empty_cache()
+    # --- replay push with the 2-frame max-pool (AtariEnv.act! fused into push!), config 5's frame size, 4096 envs
+    fb, n_env = 84 * 84 * 4, 4096
+    tr = CircularArraySARTSTraces(capacity=6, n_env=n_env, obs_dim=fb, dtype=torch.uint8)
+    s1 = torch.randint(0, 256, (fb, n_env), dtype=torch.uint8, device="cuda")
+    s2 = torch.randint(0, 256, (fb, n_env), dtype=torch.uint8, device="cuda")
+    a = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    r = torch.zeros(n_env, dtype=torch.float32, device="cuda")
+    t = torch.zeros(n_env, dtype=torch.uint8, device="cuda")
+    tr.push_state_maxpool_(s1, s2)
+    for _ in range(8):
+        tr.push_transition_maxpool_(s1, s2, a, r, t)
+    ms = event_time_ms(lambda: tr.push_transition_maxpool_(s1, s2, a, r, t), 10, lib, s)
+    out["push_transition_maxpool"] = entry((3 * fb + 18) * n_env / 1e9, ms, frame_bytes=fb, transitions_per_launch=n_env,
+                                           bytes_per_unit=3 * fb + 18, kernel="push_transition_maxpool_kernel (one launch)",
+                                           transitions_per_sec=round(n_env / (ms * 1e-3), 1))
+    del tr, s1, s2
+    torch.cuda.empty_cache()
+    # --- small-observation gather: CartPole transitions (ns = 4), 2^20 samples from a 256 x 4096 ring
+    n_env, cap, batch = 4096, 256, 1 << 20
+    tr = CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=4)
+    tr.state.normal_()
+    tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap
+    idx = tr.sample_indices(batch, seed=11, draw_ctr=0)
+    bufs = tr.gather(idx)
+    c = [1]
+
+    def smp():
+        call("rlhip_ring_sample_indices", C.byref(tr.rb), batch, 11, c[0], ptr(idx), s)
+        c[0] += 1
+
+    def sg():
+        smp()
+        call("rlhip_ring_gather", C.byref(tr.rb), ptr(idx), batch, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]),
+             ptr(bufs[4]), s)
+
+    ms = event_time_ms(sg, 10, lib, s) - event_time_ms(smp, 10, lib, s)
+    out["gather_small"] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env,
+                                kernel="gather_small_kernel<float>", samples_per_sec=round(batch / (ms * 1e-3), 1),
+                                note="random 4-byte reads out of a 27 MB ring (cache-resident); the 82 B per sample are the "
+                                     "algorithmic bytes, every 4-byte read moves a 64 B line")
+    return out
+
+
 def kernel_breakdown(torch, rlhip, pol, env):
     """Device time of the three enqueue units of one step (HIP events on the launch stream).  Each unit is
     ONE C-ABI call, so the numbers are not host-paced: rollout (1 launch), GAE (1 launch), update
@@ -790,6 +895,7 @@ def main():
         result["kernels"] = kernel_breakdown(torch, rlhip, pol, env)
         result["roofline"] = roofline_env_step(torch, rlhip)
         result["roofline_extra"] = roofline_extras(torch, rlhip)
+        result["roofline_extra"].update(roofline_hbm_side(torch, rlhip))
         result["cpu_baseline"] = cpu_baseline()
     if world > 1 and not args.no_extras:
         try:  # collective on every rank; a local failure must not cost the bench line

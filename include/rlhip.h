@@ -649,7 +649,7 @@ int32_t rlhip_ppo_push_postact_f32(const rlhip_ppo_traj* traj_host, int64_t t, i
 int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                           const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);
 /* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes, for trajectories of up to n x T entries
- * (two-layer nets: partial gradient rows, the unit-record image, the persistent kernel's hand-off words and 32 bytes per
+ * (two-layer nets: partial gradient rows, the unit-record image, and 32 bytes per
  * trajectory entry for the sample records an update call packs once -- none above 2^24 entries).  The caller must
  * ZERO-INITIALISE it once after allocation (it holds counters and epoch words that the kernels maintain themselves). */
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T);
@@ -690,19 +690,14 @@ int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, i
                                   float* grad_scratch, float* losses_out, rlhip_comm_t comm, rlhip_stream_t stream);
 /* n_epochs x n_microbatches of { grad -> clip_by_global_norm! -> Adam } (single-GPU optimise!; multi-GPU hosts call
  * rlhip_ppo_update_comm_f32, or rlhip_ppo_grad_f32, all-reduce, rlhip_ppo_apply_f32).  update_ctr = number of previous
- * update calls.  Two-layer networks: ONE persistent launch for the whole update when every workgroup of the grid can be
- * resident on the device (csrc/ppo_persist.hip; one workgroup per CU -- do not run two such updates concurrently on one
- * device), otherwise two launches per optimiser step; same results bit for bit.  RLHIP_PPO_PERSIST=0 forces the latter. */
+ * update calls.  Two-layer networks: one pack launch per call, then two launches per optimiser step (gradient tiles; partial
+ * reduction + norm exchange + clip + Adam + record refresh).  WORKSPACE SIZE: the call writes 32 bytes per trajectory entry
+ * (n * T of THIS call) of sample records behind the fixed part of the workspace -- the workspace must have been sized by
+ * rlhip_ppo_workspace_bytes(kind, cfg, n, T) for the LARGEST n * T it is ever used with; the ABI carries no size to check. */
 int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                              const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
                              float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,
                              float* grad_scratch, float* losses_out, rlhip_stream_t stream);
-
-/* Sticky health word of the persistent update: *status_host = 0, or RLHIP_ETIMEOUT when some earlier rlhip_ppo_update_f32 /
- * _dc_f32 on this workspace gave up waiting for a workgroup that never became resident (the parameters are NaN by then: the
- * step is never kept silently).  Synchronises `stream`. */
-int32_t rlhip_ppo_update_status(int32_t kind, const rlhip_ppo_cfg* cfg_host, void* workspace, int32_t* status_host,
-                                rlhip_stream_t stream);
 
 /* Device-resident counters: the same three calls with the vec-step counter (counters[0]) and the update
  * counter (counters[1]) read from device memory by the kernels instead of being baked into the launch

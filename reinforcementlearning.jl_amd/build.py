@@ -26,11 +26,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # and three wrong-result sightings in rounds 1-2 (a deterministic one in dqn3.hip, a deterministic one and a run-to-run
 # one in the MFMA PPO tiles: DESIGN.md section 5) all sat on SLP-packed ops beside MFMAs -- root cause not established, so the
 # combination is banned outright: tests/test_no_packed_f32_beside_mfma.py disassembles build/*.o and fails on any packed
-# f32 VALU op inside a kernel that contains an MFMA.  (The two-layer PPO learner -- ppo_grad.hip, ppo_persist.hip -- runs
+# f32 VALU op inside a kernel that contains an MFMA.  (The two-layer PPO learner -- ppo_grad.hip -- runs
 # layer 1 of both of its phases on the f32 MFMA since round 3 and falls under the same rule: its actor / critic pairs are
 # two scalar FMAs, not one v_pk_fma_f32.)
 NO_SLP = ["-fno-slp-vectorize", "-fno-vectorize"]  # (the loop vectorizer packs 2-trip loops over the actions the same way)
-EXTRA = {"ppo3.hip": NO_SLP, "dqn3.hip": NO_SLP, "ppo3w.hip": NO_SLP, "ppo_grad.hip": NO_SLP, "ppo_persist.hip": NO_SLP}
+EXTRA = {"ppo3.hip": NO_SLP, "dqn3.hip": NO_SLP, "ppo3w.hip": NO_SLP, "ppo_grad.hip": NO_SLP}
 
 
 def sources():

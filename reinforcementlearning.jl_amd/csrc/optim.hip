@@ -82,6 +82,78 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Streaming variants for parameter vectors that leave the caches (n >= STREAM_MIN_N floats, 16-byte aligned): four
+// parameters per lane, 16-byte non-temporal LOADS (every byte is read once), element-wise arithmetic identical to the
+// scalar kernels (same adam1 per element: bit-identical results).  NT_ST: non-temporal stores as well (in-place
+// read-modify-write streams; profiles/r04_pmc.md has the A / B).  Tail elements (n % 4) by the first lanes, scalar.
+constexpr int64_t STREAM_MIN_N = 1 << 16;
+union f32x4_bits {
+    nt_u32x4 u;
+    float f[4];
+};
+template <bool NT_ST>
+__device__ __forceinline__ void st16(void* p, const f32x4_bits& x) {
+    if (NT_ST) nt_store16(p, x.u);
+    else *reinterpret_cast<nt_u32x4*>(p) = x.u;
+}
+
+template <bool NT_ST>
+__global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ beta_pow, int64_t n, float lr,
+                                                        float b1, float b2, float eps) {
+    const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4_bits pi, gi, mi, vi;
+        pi.u = nt_load16(p + 4 * i);
+        gi.u = nt_load16(g + 4 * i);
+        mi.u = nt_load16(m + 4 * i);
+        vi.u = nt_load16(v + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adam1(pi.f[k], gi.f[k], mi.f[k], vi.f[k], lr, b1, b2, eps, c1, c2);
+        st16<NT_ST>(p + 4 * i, pi);
+        st16<NT_ST>(m + 4 * i, mi);
+        st16<NT_ST>(v + 4 * i, vi);
+    }
+    const int64_t t = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float pi = p[t], mi = m[t], vi = v[t];
+        adam1(pi, g[t], mi, vi, lr, b1, b2, eps, c1, c2);
+        p[t] = pi;
+        m[t] = mi;
+        v[t] = vi;
+    }
+}
+
+template <bool NT_ST>
+__global__ __launch_bounds__(256) void polyak_vec4_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          int64_t n, float rho) {
+    const float om = 1.0f - rho;
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4_bits d, x;
+        d.u = nt_load16(dst + 4 * i);
+        x.u = nt_load16(src + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d.f[k] = rho * d.f[k] + om * x.f[k];
+        st16<NT_ST>(dst + 4 * i, d);
+    }
+    const int64_t t = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = rho * dst[t] + om * src[t];
+}
+
+static bool stream_nt_stores() {  // A / B switch of the store policy (default: ordinary stores; set by the measurement scripts)
+    static const int v = [] {
+        const char* e = getenv("RLHIP_STREAM_NT_STORES");
+        return e ? atoi(e) : 0;
+    }();
+    return v != 0;
+}
+static bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0);
+}
+
 __global__ void beta_pow_advance_kernel(float* beta_pow, float b1, float b2) {
     beta_pow[0] *= b1;  // bt = bt .* b
     beta_pow[1] *= b2;
@@ -394,8 +466,12 @@ int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlh
     RLHIP_REQUIRE(dst != nullptr && src != nullptr && n >= 0, "bad arguments");
     RLHIP_REQUIRE(rho >= 0.0f && rho <= 1.0f, "rho must be in [0,1] (AssertionError in the reference, target_network.jl:50)");
     if (n == 0) return RLHIP_OK;
-    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, src, n,
-                       rho);
+    if (n >= STREAM_MIN_N && aligned16(dst, src)) {
+        const int grid = grid_for(n / 4, 256, 256 * 16);
+        if (stream_nt_stores()) hipLaunchKernelGGL((polyak_vec4_kernel<true>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
+        else hipLaunchKernelGGL((polyak_vec4_kernel<false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
+    } else
+        hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -421,7 +497,13 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
                        float lr, float beta1, float beta2, float eps, rlhip_stream_t stream) {
     RLHIP_REQUIRE(params && grad && m && v && beta_pow && n >= 0, "bad arguments");
     hipStream_t s = as_stream(stream);
-    if (n > 0)
+    if (n >= STREAM_MIN_N && aligned16(params, grad, m, v)) {
+        const int grid = grid_for(n / 4, 256, 256 * 16);
+        if (stream_nt_stores())
+            hipLaunchKernelGGL((adam_vec4_kernel<true>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
+        else
+            hipLaunchKernelGGL((adam_vec4_kernel<false>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
+    } else if (n > 0)
         hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, params, grad, m, v, beta_pow,
                            n, lr, beta1, beta2, eps);
     hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);

@@ -10,8 +10,8 @@
 // ppo_grad_kernel: teams of 8 waves walk 64-sample tiles (tile code and its phase description: ppo_grad_tile.h) and
 // write one partial gradient row per workgroup; reduce_apply_kernel sums the rows in a fixed order, takes the global
 // norm behind a grid barrier (or in the last-arriving workgroup), clips, runs Adam and refreshes the unit records.
-// The whole update (all n_epochs x n_microbatches steps) as ONE persistent launch: ppo_persist.hip (same tile code,
-// same summation order, hence the same bits); this file's two launches per step are its fallback and the sharded path.
+// (A persistent whole-update kernel built from the same tile was measured in round 3, tied / lost, and left the product in
+// round 4: profiles/attic/ppo_persist.hip, profiles/r03_persist.md.)
 // Roofline: VALU-f32 bound by construction (K = ns <= 4 and N = nout <= 3 are far below an MFMA tile);
 // algorithmic work 6*h*((ns+nout)+(ns+1)) flop per sample.
 #include "ppo_grad_tile.h"
@@ -307,11 +307,15 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
         // the rank-local exchange of the sums of squares: like APPLY_GRID, each partial is its own arrival flag -- two 8-byte
-        // {sequence number of this exchange, half of the double} granules (in their own part of the sumsq area: the
-        // sequence numbers are the communicator's, not this workspace's launch count), polled directly by every workgroup
+        // {epoch, half of the double} granules in their own part of the sumsq area, polled directly by every workgroup.
+        // The epoch is a WORKSPACE-resident word (counter[4] = launches of this variant on this workspace so far; advanced by
+        // the last workgroup out, like counter[3] of APPLY_GRID) -- round 3 tagged with the communicator's sequence number,
+        // which repeats when a communicator is re-created for the same policy or a caller retries a seq0: a poller could then
+        // accept the stale granule of an earlier exchange
         typedef unsigned long long u64;
+        const unsigned int xepoch = __hip_atomic_load(ap.counter + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         if (lane == 0) {
-            const u64 bits = (u64)__double_as_longlong(sq), ep = (u64)xa.seq << 32;
+            const u64 bits = (u64)__double_as_longlong(sq), ep = (u64)xepoch << 32;
             u64* gr = reinterpret_cast<u64*>(ap.sumsq) + 512 + 2 * blockIdx.x;
             __hip_atomic_store(gr, ep | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gr + 1, ep | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             for (;;) {
                 hi = __hip_atomic_load(gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lo = __hip_atomic_load(gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned int)(hi >> 32) == xa.seq && (unsigned int)(lo >> 32) == xa.seq) break;
+                if ((unsigned int)(hi >> 32) == xepoch && (unsigned int)(lo >> 32) == xepoch) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             part += __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
                 __hip_atomic_store(ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ap.counter + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ap.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ap.counter + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch: xepoch + 1
             }
         }
         return;
@@ -514,7 +519,10 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
 template <int APPLY>
 static int grid_apply_max_blocks() {
     static PerDeviceInt cap_cache;
-    return grid_barrier_capacity_cached(cap_cache, reduce_apply_kernel_ptr<APPLY>(), 1024);
+    // never above 256: the granule areas of APPLY_GRID (u64 words 0 .. 511 of sumsq) and APPLY_XCHG (512 .. 1023) hold two
+    // words per workgroup and must not overlap, whatever a future device's occupancy says
+    const int cap = grid_barrier_capacity_cached(cap_cache, reduce_apply_kernel_ptr<APPLY>(), 1024);
+    return cap < 256 ? cap : 256;
 }
 
 static int grad_blocks(int num_tiles) { return num_tiles < MAX_GRAD_BLOCKS ? num_tiles : MAX_GRAD_BLOCKS; }
@@ -685,9 +693,8 @@ using namespace rlhip;
 
 extern "C" {
 
-// bytes of the two-launch path's carve (prepare_grad); the persistent kernel's buffers follow, 256-byte aligned
-// sample records of an update call (pack_update_kernel), behind the persistent kernel's area: 32 B per trajectory entry, up
-// to 2^24 entries (512 MB); beyond that the steps gather from the planes
+// bytes of the carve of prepare_grad (256-byte aligned); behind it the sample records of an update call
+// (pack_update_kernel): 32 B per trajectory entry, up to 2^24 entries (512 MB); beyond that the steps gather from the planes
 static int64_t sample_record_bytes(int64_t n, int64_t T) {
     const int64_t total = n * T;
     return (total >= 1 && total <= ((int64_t)1 << 24)) ? 32 * total : 0;
@@ -702,7 +709,7 @@ static int64_t grad_workspace_bytes(int64_t np) {
 static float4* update_samples_ptr(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, void* workspace) {
     const int64_t np_ = rlhip_ppo_nparams(kind, cfg);
     if (sample_record_bytes(n, T) <= 0 || np_ <= 0) return nullptr;
-    return (float4*)((char*)workspace + grad_workspace_bytes(np_) + ppo_persist_bytes(np_, cfg->hidden));
+    return (float4*)((char*)workspace + grad_workspace_bytes(np_));
 }
 // first launch of an update call: unit records (+ the sample records, same launch)
 static void pack_for_update(const GradLaunch& L, float4* samples, hipStream_t s) {
@@ -721,25 +728,9 @@ int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
     if (is_layers3(cfg)) return ppo3_workspace_bytes(kind, cfg, n, T);
     int64_t np = rlhip_ppo_nparams(kind, cfg);
     if (np < 0) return -1;
-    return grad_workspace_bytes(np) + ppo_persist_bytes(np, cfg->hidden) + sample_record_bytes(n, T);
+    return grad_workspace_bytes(np) + sample_record_bytes(n, T);
 }
 
-/* Did a persistent update (ppo_persist.hip) ever give up on a hand-off in this workspace?  Synchronises `stream`.
- * *status_host = 0, or RLHIP_ETIMEOUT (sticky until the workspace is zeroed again; the parameters are NaN by then). */
-int32_t rlhip_ppo_update_status(int32_t kind, const rlhip_ppo_cfg* cfg, void* workspace, int32_t* status_host,
-                                rlhip_stream_t stream) {
-    RLHIP_REQUIRE(cfg && workspace && status_host, "NULL argument");
-    *status_host = 0;
-    if (is_layers3(cfg)) return RLHIP_OK;
-    const int64_t np = rlhip_ppo_nparams(kind, cfg);
-    RLHIP_REQUIRE(np > 0, "bad configuration");
-    unsigned int word = 0;
-    const unsigned int* st = (const unsigned int*)((const char*)workspace + grad_workspace_bytes(np));
-    RLHIP_CHECK_HIP(hipMemcpyAsync(&word, st + 3, sizeof(word), hipMemcpyDeviceToHost, as_stream(stream)));
-    RLHIP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    if (word != 0) *status_host = RLHIP_ETIMEOUT;
-    return RLHIP_OK;
-}
 
 static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                           const float* params, uint64_t seed, uint32_t epoch_ctr, const uint32_t* ctr, int32_t mb,
@@ -949,16 +940,6 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
                            losses_out, stream);
     }
     hipStream_t s = as_stream(stream);
-    {   // the whole update as ONE persistent launch (ppo_persist.hip) when the device admits the grid ...
-        GradLaunch L0;
-        int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, ctr ? 0u : update_ctr * (uint32_t)cfg->n_epochs, 0,
-                                  workspace, &L0, ctr);
-        if (rc) return rc;
-        rc = ppo_persist_update(L0, cfg, params, m, v, beta_pow, update_ctr, (char*)workspace + grad_workspace_bytes(L0.np),
-                                grad_scratch, losses_out, s);
-        if (rc <= 0) return rc;
-    }
-    // ... otherwise two launches per optimiser step
     float4* samples = update_samples_ptr(kind, cfg, n, T, workspace);
     bool first = true;
     for (int32_t e = 0; e < cfg->n_epochs; ++e) {

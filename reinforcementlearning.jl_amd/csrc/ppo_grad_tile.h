@@ -723,7 +723,7 @@ __device__ __forceinline__ void pack_records(const float* __restrict__ params, f
     }
 }
 
-// ---- what ppo_grad.hip and ppo_persist.hip share on the host ----
+// ---- host-side launch description (ppo_grad.hip) ----
 struct GradLaunch {
     GradArgs g;
     int nb, ns, nt;  // partial rows (= workgroups), observation size, teams (tiles side by side) per workgroup
@@ -732,13 +732,5 @@ struct GradLaunch {
     double* sumsq;
     float* packed;
 };
-
-// the persistent whole-update kernel (ppo_persist.hip).  persist_bytes: what it adds to the learner's workspace;
-// ppo_persist_update: enqueue all n_epochs x n_microbatches optimiser steps as ONE launch, or return +1 when the
-// configuration / device does not admit it (the caller then takes the two-launch-per-step path), < 0 on error.
-int64_t ppo_persist_bytes(int64_t np, int h);
-int32_t ppo_persist_update(const GradLaunch& L0, const rlhip_ppo_cfg* cfg, float* params, float* m, float* v,
-                           float* beta_pow, uint32_t update_ctr, void* persist_ws, float* grad_out, float* losses_out,
-                           hipStream_t s);
 
 }  // namespace rlhip

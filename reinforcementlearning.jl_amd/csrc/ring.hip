@@ -275,6 +275,26 @@ __global__ __launch_bounds__(256) void maxpool_u8_kernel(uint4* __restrict__ dst
     }
 }
 
+// push!(trajectory, (state = max.(screen1, screen2), action, reward, terminal)) in ONE launch (round 4: was push_art + maxpool):
+// the two screens are read once (16-byte non-temporal loads), the pooled frame and the three per-env traces written
+__global__ __launch_bounds__(256) void push_transition_maxpool_kernel(uint4* __restrict__ dst, const uint4* __restrict__ s1,
+                                                                      const uint4* __restrict__ s2, int64_t n16,
+                                                                      int32_t* __restrict__ a_dst, float* __restrict__ r_dst,
+                                                                      uint8_t* __restrict__ t_dst, const int32_t* __restrict__ a,
+                                                                      const float* __restrict__ r, const uint8_t* __restrict__ t,
+                                                                      int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = g0; i < n16; i += stride) {
+        const nt_u32x4 x = nt_load16(s1 + i), y = nt_load16(s2 + i);
+        dst[i] = make_uint4(max_u8x4(x[0], y[0]), max_u8x4(x[1], y[1]), max_u8x4(x[2], y[2]), max_u8x4(x[3], y[3]));
+    }
+    for (int64_t i = g0; i < n; i += stride) {
+        a_dst[i] = a[i];
+        r_dst[i] = r[i];
+        t_dst[i] = t[i];
+    }
+}
+
 static RingView view_of(const rlhip_ring* rb) {
     return {rb->capacity, rb->n_env, rb->obs_dim, rb->head_sa, rb->head_rt,
             rb->state,    rb->action, rb->reward, rb->terminal};
@@ -448,6 +468,9 @@ int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb, const void* screen1, 
     RLHIP_REQUIRE(rb && screen1 && screen2 && action && reward && terminal, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 1, "the max-pool push is defined for UInt8 frames");
     hipStream_t s = as_stream(stream);
+    const int64_t fbytes = rb->obs_dim * rb->n_env;
+    RLHIP_REQUIRE(fbytes % 16 == 0 && ((((uintptr_t)screen1 | (uintptr_t)screen2 | (uintptr_t)rb->state) & 15) == 0),
+                  "frames must be 16-byte aligned multiples of 16 bytes");
     int64_t frames = rb->capacity, n = rb->n_env, phys;
     if (rb->len_rt < frames) {
         phys = (rb->head_rt + rb->len_rt) % frames;
@@ -456,10 +479,21 @@ int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb, const void* screen1, 
         phys = rb->head_rt;
         rb->head_rt = (rb->head_rt + 1) % frames;
     }
-    hipLaunchKernelGGL(push_art_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, rb->action + phys * n,
-                       rb->reward + phys * n, rb->terminal + phys * n, action, reward, terminal, n);
+    const int64_t sframes = rb->capacity + 1;
+    int64_t sphys;  // slot of the new state frame (same bookkeeping as push_state_frame)
+    if (rb->len_sa < sframes) {
+        sphys = (rb->head_sa + rb->len_sa) % sframes;
+        rb->len_sa += 1;
+    } else {
+        sphys = rb->head_sa;
+        rb->head_sa = (rb->head_sa + 1) % sframes;
+    }
+    const int64_t n16 = fbytes / 16;
+    hipLaunchKernelGGL(push_transition_maxpool_kernel, dim3(grid_for(n16 > n ? n16 : n, 256, 256 * 16)), dim3(256), 0, s,
+                       (uint4*)((uint8_t*)rb->state + sphys * fbytes), (const uint4*)screen1, (const uint4*)screen2, n16,
+                       rb->action + phys * n, rb->reward + phys * n, rb->terminal + phys * n, action, reward, terminal, n);
     RLHIP_LAUNCH_CHECK();
-    return maxpool_into_next_state_slot(rb, screen1, screen2, s);
+    return RLHIP_OK;
 }
 
 }  // extern "C"

@@ -234,7 +234,6 @@ _PROTOS = {
     "rlhip_ppo_push_preact_f32": (i32, [P(PPOTraj), i64, i64, i64, vp, vp, vp, vp, vp, vp]),
     "rlhip_ppo_push_postact_f32": (i32, [P(PPOTraj), i64, i64, vp, vp, vp]),
     "rlhip_categorical_network_f32": (i32, [vp, i64, i64, vp, u64, u32, u32, vp, vp, vp, vp]),
-    "rlhip_ppo_update_status": (i32, [i32, P(PPOCfg), vp, P(i32), vp]),
     "rlhip_ppo_update_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, vp, vp, vp, u64, u32, vp,
                                    vp, vp, vp]),
     "rlhip_ppo_rollout_dc_f32": (i32, [i32, vp, P(EnvState), i64, i64, P(PPOCfg), vp, u64, u32, vp, P(PPOTraj),

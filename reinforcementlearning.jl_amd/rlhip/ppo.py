@@ -220,13 +220,6 @@ class PPOPolicy:
                 comm.check()
         self.update_ctr += 1
 
-    def update_status(self):
-        """0, or RLHIP_ETIMEOUT if a persistent update on this policy's workspace ever gave up on a hand-off (the
-        parameters are NaN by then).  Synchronises the stream."""
-        st = C.c_int32(0)
-        call("rlhip_ppo_update_status", self.kind, C.byref(self.cfg), ptr(self.workspace), C.byref(st), stream_ptr())
-        return int(st.value)
-
     def _comm(self, world):
         """The communicator of this policy's gradient exchange (rlhip.dist.HipComm over csrc/comm.hip), created on
         first use -- a collective: every rank reaches its first update_ together."""

@@ -58,12 +58,22 @@ def pytest_collection_modifyitems(config, items):
 #   per suite   tests/test_gpu_zz_margins.py: the MEDIAN over all bf16 checks of a run <= BF16_MEDIAN_TOL = 5e-7 (3.3x
 #               measured) and at most BF16_FLIP_SHARE = 15 % of them above 2e-5 (3x measured) -- an arithmetic regression
 #               moves every check, a decision flip moves a few
+# Round 4: the max bar alone cannot see a wrong tile / fragment slot at 1e-3 of max|g| in ONE instantiation,
+# so (a) every bf16 check also asserts its BULK: tensors of >= 4096 elements (the hidden x hidden matrices, where a wrong
+# fragment slot is at least 1/64 of the elements) q99 <= BF16_Q99_TOL = 1e-4 (measured <= 1.5e-5 outside one conditioning
+# outlier); smaller tensors (sums over all samples: a flip reaches every element through dH1, q99 ~ max) max <= BF16_SMALL_TOL
+# = 1e-3 (measured <= 4.6e-4); and (b) tests/test_gpu_bf16_tight.py gives every instantiation a decision-free case with the
+# per-check bar BF16_TIGHT_TOL = 2e-5 (profiles/r04_parity_margins.md).  2^-8 stays the max bar of the flip-prone cases only.
 # Every check appends what it measured to gpurun_out/grad_err.jsonl (scratch), tagged with the pytest session.
 import uuid
 
 SESSION_ID = uuid.uuid4().hex[:12]
 F32_GRAD_TOL = 1e-6
 BF16_GRAD_TOL = 2.0 ** -8
+BF16_TIGHT_TOL = 2e-5
+BF16_Q99_TOL = 1e-4
+BF16_SMALL_TOL = 1e-3
+BF16_BULK_MIN_N = 4096
 BF16_MEDIAN_TOL = 5e-7
 BF16_FLIP_LEVEL = 2e-5
 BF16_FLIP_SHARE = 0.15
@@ -82,11 +92,17 @@ def assert_grad_close(g, o, tol, tag=""):
     scale = max(float(np.abs(o).max()), 1e-30)
     e = np.abs(g - o) / scale
     err = float(e.max())
+    q99 = float(np.quantile(e, 0.99))
     try:
         os.makedirs(os.path.dirname(GRAD_ERR_LOG), exist_ok=True)
         with open(GRAD_ERR_LOG, "a") as f:
             f.write(json.dumps({"session": SESSION_ID, "tag": tag, "n": int(g.size), "err_over_max": err, "tol": tol,
-                                "q99": float(np.quantile(e, 0.99)), "n_over_2e-5": int((e > BF16_FLIP_LEVEL).sum())}) + "\n")
+                                "q99": q99, "n_over_2e-5": int((e > BF16_FLIP_LEVEL).sum())}) + "\n")
     except OSError:
         pass
     assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"
+    if tol == BF16_GRAD_TOL:  # the flip-prone bf16 cases: the max bar admits a flipped decision, the bulk must not move
+        if g.size >= BF16_BULK_MIN_N:
+            assert q99 <= BF16_Q99_TOL, f"{tag}: q99 of |g - o| / max|o| = {q99:.3e} > {BF16_Q99_TOL:.0e} (n = {g.size})"
+        else:
+            assert err <= BF16_SMALL_TOL, f"{tag}: max|g - o| / max|o| = {err:.3e} > {BF16_SMALL_TOL:.0e} (n = {g.size} < {BF16_BULK_MIN_N})"

@@ -570,6 +570,12 @@ def test_polyak_and_target_sync(rl):
         assert np.array_equal(host(d), o)
     with pytest.raises(ValueError):
         ops.polyak_(dev(dst), dev(src), 1.5)  # @assert 0 <= rho <= 1 (target_network.jl:50)
+    # the 16-byte streaming kernel (n >= 65536, three tail elements): bit-exact like the scalar one
+    n = (1 << 17) + 3
+    src, dst = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    d = dev(dst.copy())
+    ops.polyak_(d, dev(src), 0.995)
+    assert np.array_equal(host(d), oracle.polyak(dst.copy(), src, 0.995))
 
 
 @pytest.mark.parametrize("n", [3331, 17410, 300000])
@@ -589,7 +595,7 @@ def test_clip_by_global_norm(rl, n):
             assert np.array_equal(host(d), g)  # untouched when not clipped
 
 
-@pytest.mark.parametrize("n", [3331, 100000])
+@pytest.mark.parametrize("n", [3331, 100000, 65536 + 3, 1 << 20])
 def test_adam_matches_oracle_and_torch(rl, n):
     from rlhip import ops
 

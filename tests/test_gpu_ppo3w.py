@@ -101,6 +101,10 @@ def test_grad_matches_oracle(kind, cont, act):
     env, pol = _setup(kind, n, T, n_microbatches=2, act=a)
     pol.rollout_()
     pol.gae_()
+    # round 4: |advantage| <= 10.  Unclamped, Pendulum's first steps give one sample an advantage of -65 against a typical -5;
+    # in a 432-sample micro-batch that ONE sample is then most of max|g| and the check measures the conditioning of its
+    # (a - mu) / sigma (cancellation amplifies the 1e-6 head difference of the bf16 layer to 1e-4), not the kernels
+    pol.trajectory.adv.clamp_(-10.0, 10.0)
     ocfg = oracle.ppo_default(hidden=H, continuous=int(cont), layers=3, n_microbatches=2, act=a)
     total, bm = n * T, (n * T) // 2
     for mb, epoch in ((0, 0), (1, 3)):

@@ -57,10 +57,10 @@ def test_no_packed_f32_valu_op_in_any_kernel_that_issues_mfmas(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-objdump"), reason="no llvm-objdump")
 def test_the_two_layer_ppo_tile_runs_layer_one_on_the_f32_mfma(tmp_path):
-    """the headline learner's tile (csrc/ppo_grad_tile.h, phase 1a): every instantiation of the gradient kernel and of the
-    persistent update kernel issues v_mfma_f32_32x32x2_f32 -- and, being MFMA kernels now, no packed f32 op (the first half
-    of round 3 paired actor / critic FMAs as v_pk_fma_f32; the rule above took that back when the MFMA phase came in)"""
-    for obj, needle in (("ppo_grad.o", "ppo_grad_kernel"), ("ppo_persist.o", "ppo_update_persist_kernel")):
+    """the headline learner's tile (csrc/ppo_grad_tile.h, phase 1a): every instantiation of the gradient kernel issues
+    v_mfma_f32_32x32x2_f32 -- and, being MFMA kernels now, no packed f32 op (the first half of round 3 paired actor / critic
+    FMAs as v_pk_fma_f32; the rule above took that back when the MFMA phase came in)"""
+    for obj, needle in (("ppo_grad.o", "ppo_grad_kernel"),):
         k = {n: v for n, v in _kernels(os.path.join(OBJ, obj), str(tmp_path)).items() if needle in n}
         assert len(k) >= 12, (obj, sorted(k))
         assert all(v[0] >= 4 and v[1] == 0 for v in k.values()), k
