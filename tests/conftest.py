@@ -63,14 +63,16 @@ def pytest_collection_modifyitems(config, items):
 # fragment slot is at least 1/64 of the elements) q99 <= BF16_Q99_TOL = 1e-4 (measured <= 1.5e-5 outside one conditioning
 # outlier); smaller tensors (sums over all samples: a flip reaches every element through dH1, q99 ~ max) max <= BF16_SMALL_TOL
 # = 1e-3 (measured <= 4.6e-4); and (b) tests/test_gpu_bf16_tight.py gives every instantiation a decision-free case with the
-# per-check bar BF16_TIGHT_TOL = 2e-5 (profiles/r04_parity_margins.md).  2^-8 stays the max bar of the flip-prone cases only.
+# per-check bars 1e-6 (relu: exact forward) / 5e-5 max + 1e-5 q99 (tanh) (profiles/r04_parity_margins.md).  2^-8 stays the max bar of the flip-prone cases only.
 # Every check appends what it measured to gpurun_out/grad_err.jsonl (scratch), tagged with the pytest session.
 import uuid
 
 SESSION_ID = uuid.uuid4().hex[:12]
 F32_GRAD_TOL = 1e-6
 BF16_GRAD_TOL = 2.0 ** -8
-BF16_TIGHT_TOL = 2e-5
+BF16_TIGHT_TOL = 5e-5        # decision-proof tanh cases (tests/test_gpu_bf16_tight.py): max; measured <= 1.4e-5 (isolated roundings)
+BF16_TIGHT_Q99_TOL = 1e-5    # ... and their bulk (tensors of >= 4096 elements): measured <= 3.3e-6
+BF16_TIGHT_RELU_TOL = 1e-6   # decision-proof relu cases: everything up to the head outputs is exact on both sides; measured <= 1.6e-7
 BF16_Q99_TOL = 1e-4
 BF16_SMALL_TOL = 1e-3
 BF16_BULK_MIN_N = 4096
@@ -101,6 +103,8 @@ def assert_grad_close(g, o, tol, tag=""):
     except OSError:
         pass
     assert err <= tol, f"{tag}: max|g - o| / max|o| = {err:.3e} > {tol:.1e}"
+    if tol == BF16_TIGHT_TOL and g.size >= BF16_BULK_MIN_N:
+        assert q99 <= BF16_TIGHT_Q99_TOL, f"{tag}: q99 of |g - o| / max|o| = {q99:.3e} > {BF16_TIGHT_Q99_TOL:.0e} (n = {g.size})"
     if tol == BF16_GRAD_TOL:  # the flip-prone bf16 cases: the max bar admits a flipped decision, the bulk must not move
         if g.size >= BF16_BULK_MIN_N:
             assert q99 <= BF16_Q99_TOL, f"{tag}: q99 of |g - o| / max|o| = {q99:.3e} > {BF16_Q99_TOL:.0e} (n = {g.size})"
