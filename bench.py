@@ -517,6 +517,17 @@ def roofline_hbm_side(torch, rlhip):
     lib, s = rlhip._lib.lib, stream_ptr()
     out = {}
 
+    def carve(sizes_bytes, dtype):
+        """arrays of one streaming launch carved from ONE allocation at offsets staggered by 4352 B, like the env arrays of a
+        large vector env (rlhip/envs.py): separately allocated 2^k-byte arrays start a multiple of 64 MB apart and their
+        streams then walk the HBM channels in lock-step"""
+        stag, offs, o = 4352, [], 0
+        for b in sizes_bytes:
+            offs.append(o)
+            o += (b + stag + 255) // 256 * 256
+        buf = torch.empty(o, dtype=torch.uint8, device="cuda")
+        return [buf[a:a + b].view(dtype) for a, b in zip(offs, sizes_bytes)], buf
+
     def entry(gb, ms, **kw):
         d = {"bound": "hbm", "us_per_launch": round(ms * 1e3, 2), "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(gb * 1e9)}
@@ -530,7 +541,8 @@ def roofline_hbm_side(torch, rlhip):
         env = rlhip.HipVecEnv(kind, n, seed=1, packed_episode=True)
         actions = torch.randint(0, na, (8, n), dtype=torch.int32, device="cuda")
         a_ptrs = [ptr(actions[k]) for k in range(8)]
-        obs = torch.empty((3, n), dtype=torch.float32, device="cuda") if with_obs else None
+        # (the observation planes: three more write streams; offset from the allocation's natural alignment like the env's own arrays)
+        obs = carve([4352 * 5, 3 * n * 4], torch.float32)[0][1].view(3, n) if with_obs else None
         k = [0]
 
         def step():
@@ -552,24 +564,28 @@ def roofline_hbm_side(torch, rlhip):
     # --- Adam (Optimisers.Adam, 28 B / param) and Polyak (TargetNetwork soft sync, 12 B / param)
     for logn in (22, 26):
         n = 1 << logn
-        p, g, m, v = (torch.randn(n, device="cuda") for _ in range(4))
-        v.abs_()
+        (p, g, m, v), _keep = carve([4 * n] * 4, torch.float32)
+        for t_ in (p, g, m):
+            t_.normal_()
+        v.uniform_(0.01, 1.0)
         bp = torch.tensor([0.9, 0.999], device="cuda")
         ops.adam_(p, g, m, v, bp)
         ms = event_time_ms(lambda: ops.adam_(p, g, m, v, bp), 20, lib, s)
         out[f"adam_2p{logn}"] = entry(28 * n / 1e9, ms, n_params=n, bytes_per_unit=28,
-                                      kernel="adam_vec4_kernel + beta_pow_advance_kernel (one call = two launches)",
+                                      kernel="adam_vec4_kernel<non-temporal stores, 2 chunks per lane> + beta_pow_advance_kernel (one call = two launches)",
                                       note="2^22 parameters (117 MB per call) fit the 256 MB Infinity Cache: the 2^26 entry is the HBM one" if logn == 22 else "")
         ops.polyak_(p, g, 0.995)
         ms = event_time_ms(lambda: ops.polyak_(p, g, 0.995), 20, lib, s)
         out[f"polyak_2p{logn}"] = entry(12 * n / 1e9, ms, n_params=n, bytes_per_unit=12, kernel="polyak_vec4_kernel")
-        del p, g, m, v
+        del p, g, m, v, _keep
         torch.cuda.empty_cache()
     # --- replay push with the 2-frame max-pool (AtariEnv.act! fused into push!), config 5's frame size, 4096 envs
     fb, n_env = 84 * 84 * 4, 4096
     tr = CircularArraySARTSTraces(capacity=6, n_env=n_env, obs_dim=fb, dtype=torch.uint8)
-    s1 = torch.randint(0, 256, (fb, n_env), dtype=torch.uint8, device="cuda")
-    s2 = torch.randint(0, 256, (fb, n_env), dtype=torch.uint8, device="cuda")
+    (s1, s2), _keep = carve([fb * n_env] * 2, torch.uint8)
+    s1, s2 = s1.view(fb, n_env), s2.view(fb, n_env)
+    s1.random_(0, 256)
+    s2.random_(0, 256)
     a = torch.zeros(n_env, dtype=torch.int32, device="cuda")
     r = torch.zeros(n_env, dtype=torch.float32, device="cuda")
     t = torch.zeros(n_env, dtype=torch.uint8, device="cuda")
@@ -580,7 +596,7 @@ def roofline_hbm_side(torch, rlhip):
     out["push_transition_maxpool"] = entry((3 * fb + 18) * n_env / 1e9, ms, frame_bytes=fb, transitions_per_launch=n_env,
                                            bytes_per_unit=3 * fb + 18, kernel="push_transition_maxpool_kernel (one launch)",
                                            transitions_per_sec=round(n_env / (ms * 1e-3), 1))
-    del tr, s1, s2
+    del tr, s1, s2, _keep
     torch.cuda.empty_cache()
     # --- small-observation gather: CartPole transitions (ns = 4), 2^20 samples from a 256 x 4096 ring
     n_env, cap, batch = 4096, 256, 1 << 20
@@ -603,8 +619,10 @@ def roofline_hbm_side(torch, rlhip):
     ms = event_time_ms(sg, 10, lib, s) - event_time_ms(smp, 10, lib, s)
     out["gather_small"] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env,
                                 kernel="gather_small_kernel<float>", samples_per_sec=round(batch / (ms * 1e-3), 1),
-                                note="random 4-byte reads out of a 27 MB ring (cache-resident); the 82 B per sample are the "
-                                     "algorithmic bytes, every 4-byte read moves a 64 B line")
+                                note="11 random 4-byte reads per sample out of a 27 MB frame-major ring (Infinity-Cache resident): the 82 B "
+                                     "per sample are the algorithmic bytes, the fabric moves a 64 B line per read (704 B per sample = "
+                                     f"{round(704 * batch / (ms * 1e-3) / 1e9, 1)} GB/s of line traffic); lane-per-sample and tile-staged "
+                                     "kernels tie (168 vs 164 us): the bound is the line rate, the lever would be a transition-major layout")
     return out
 
 

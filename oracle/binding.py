@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "librl_oracle.so")
+# RLO_ORACLE_SO: an alternative build of the same sources (the sanitizer build of `make asan`, tests/test_asan.py)
+_SO = os.environ.get("RLO_ORACLE_SO") or os.path.join(_HERE, "_build", "librl_oracle.so")
 _SO_OMP = os.path.join(_HERE, "_build", "librl_oracle_omp.so")
 _lib = None
 _lib_serial = None

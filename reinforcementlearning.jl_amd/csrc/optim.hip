@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // Streaming variants for parameter vectors that leave the caches (n >= STREAM_MIN_N floats, 16-byte aligned): four
 // parameters per lane, 16-byte non-temporal LOADS (every byte is read once), element-wise arithmetic identical to the
-// scalar kernels (same adam1 per element: bit-identical results).  NT_ST: non-temporal stores as well (in-place
-// read-modify-write streams; profiles/r04_pmc.md has the A / B).  Tail elements (n % 4) by the first lanes, scalar.
+// scalar kernels (same adam1 per element: bit-identical results).  NT_ST: non-temporal stores as well (chosen per kernel
+// by A / B, see the launches).  Tail elements (n % 4) by the first lanes, scalar.
 constexpr int64_t STREAM_MIN_N = 1 << 16;
 union f32x4_bits {
     nt_u32x4 u;
@@ -97,24 +97,37 @@ __device__ __forceinline__ void st16(void* p, const f32x4_bits& x) {
     else *reinterpret_cast<nt_u32x4*>(p) = x.u;
 }
 
-template <bool NT_ST>
+template <bool NT_ST, int U>
 __global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         const float* __restrict__ beta_pow, int64_t n, float lr,
                                                         float b1, float b2, float eps) {
     const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4_bits pi, gi, mi, vi;
-        pi.u = nt_load16(p + 4 * i);
-        gi.u = nt_load16(g + 4 * i);
-        mi.u = nt_load16(m + 4 * i);
-        vi.u = nt_load16(v + 4 * i);
+    // U 16-byte chunks per lane and iteration, `stride` apart (each chunk row stays coalesced): 4 U loads in flight per lane
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += (int64_t)U * stride) {
+        f32x4_bits pi[U], gi[U], mi[U], vi[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) adam1(pi.f[k], gi.f[k], mi.f[k], vi.f[k], lr, b1, b2, eps, c1, c2);
-        st16<NT_ST>(p + 4 * i, pi);
-        st16<NT_ST>(m + 4 * i, mi);
-        st16<NT_ST>(v + 4 * i, vi);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+                pi[u].u = nt_load16(p + 4 * i);
+                gi[u].u = nt_load16(g + 4 * i);
+                mi[u].u = nt_load16(m + 4 * i);
+                vi[u].u = nt_load16(v + 4 * i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) adam1(pi[u].f[k], gi[u].f[k], mi[u].f[k], vi[u].f[k], lr, b1, b2, eps, c1, c2);
+                st16<NT_ST>(p + 4 * i, pi[u]);
+                st16<NT_ST>(m + 4 * i, mi[u]);
+                st16<NT_ST>(v + 4 * i, vi[u]);
+            }
+        }
     }
     const int64_t t = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
@@ -143,13 +156,6 @@ __global__ __launch_bounds__(256) void polyak_vec4_kernel(float* __restrict__ ds
     if (t < n) dst[t] = rho * dst[t] + om * src[t];
 }
 
-static bool stream_nt_stores() {  // A / B switch of the store policy (default: ordinary stores; set by the measurement scripts)
-    static const int v = [] {
-        const char* e = getenv("RLHIP_STREAM_NT_STORES");
-        return e ? atoi(e) : 0;
-    }();
-    return v != 0;
-}
 static bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
     return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0);
 }
@@ -468,8 +474,8 @@ int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlh
     if (n == 0) return RLHIP_OK;
     if (n >= STREAM_MIN_N && aligned16(dst, src)) {
         const int grid = grid_for(n / 4, 256, 256 * 16);
-        if (stream_nt_stores()) hipLaunchKernelGGL((polyak_vec4_kernel<true>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
-        else hipLaunchKernelGGL((polyak_vec4_kernel<false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
+        // ordinary stores: 128 us at 2^26 parameters against 154 with non-temporal ones (the opposite of Adam's seven streams)
+        hipLaunchKernelGGL((polyak_vec4_kernel<false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     } else
         hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     RLHIP_LAUNCH_CHECK();
@@ -499,10 +505,9 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
     hipStream_t s = as_stream(stream);
     if (n >= STREAM_MIN_N && aligned16(params, grad, m, v)) {
         const int grid = grid_for(n / 4, 256, 256 * 16);
-        if (stream_nt_stores())
-            hipLaunchKernelGGL((adam_vec4_kernel<true>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
-        else
-            hipLaunchKernelGGL((adam_vec4_kernel<false>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
+        // store policy and unroll by A / B on one box (profiles/r04_pmc.md): non-temporal stores + two chunks per lane 375 us at
+        // 2^26 parameters against 412 (ordinary stores, one chunk), 413 (non-temporal, one chunk), 436 (ordinary, two chunks)
+        hipLaunchKernelGGL((adam_vec4_kernel<true, 2>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
     } else if (n > 0)
         hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, params, grad, m, v, beta_pow,
                            n, lr, beta1, beta2, eps);

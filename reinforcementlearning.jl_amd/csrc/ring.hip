@@ -132,6 +132,45 @@ __global__ __launch_bounds__(256) void gather_small_kernel(RingView rb, const in
     }
 }
 
+// small observations with a compile-time size (OD <= 8 components: the classic-control envs): one LANE per sample, every
+// load of the sample (2 OD state components, action, reward, terminal: 11 for CartPole) issued before the first store --
+// the gather is a chain of dependent cache misses otherwise (the generic kernel above keeps two loads in flight per lane:
+// 163 us for 2^20 CartPole samples; profiles/r04_pmc.md).  Stores are coalesced (consecutive lanes = consecutive samples).
+template <typename E, int OD>
+__global__ __launch_bounds__(256) void gather_small_lane_kernel(RingView rb, const int64_t* __restrict__ idx, int64_t batch,
+                                                                E* __restrict__ s, int32_t* __restrict__ a,
+                                                                float* __restrict__ r, uint8_t* __restrict__ term,
+                                                                E* __restrict__ sn) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int64_t j = idx[b];
+    const int64_t li = j / rb.n_env, e = j - li * rb.n_env;
+    const int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
+    const int64_t pn = (ps + 1 == rb.capacity + 1) ? 0 : ps + 1;
+    const int64_t pt = (rb.head_rt + li) % rb.capacity;
+    const E* st = (const E*)rb.state;
+    const E* p0 = st + ps * OD * rb.n_env + e;
+    const E* p1 = st + pn * OD * rb.n_env + e;
+    E v0[OD], v1[OD];
+#pragma unroll
+    for (int k = 0; k < OD; ++k) {
+        v0[k] = p0[k * rb.n_env];
+        v1[k] = p1[k * rb.n_env];
+    }
+    const int64_t o = pt * rb.n_env + e;
+    const int32_t av = rb.action[o];
+    const float rv = rb.reward[o];
+    const uint8_t tv = rb.terminal[o];
+#pragma unroll
+    for (int k = 0; k < OD; ++k) {
+        s[k * batch + b] = v0[k];
+        sn[k * batch + b] = v1[k];
+    }
+    a[b] = av;
+    r[b] = rv;
+    term[b] = tv;
+}
+
 // large contiguous frames (n_env == 1): one workgroup per sample, 16 B/lane streaming copy.
 // Output layout here is sample-major: s[b * frame_bytes ...] (a frame stays contiguous).
 __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const int64_t* __restrict__ idx,
@@ -277,6 +316,7 @@ __global__ __launch_bounds__(256) void maxpool_u8_kernel(uint4* __restrict__ dst
 
 // push!(trajectory, (state = max.(screen1, screen2), action, reward, terminal)) in ONE launch (round 4: was push_art + maxpool):
 // the two screens are read once (16-byte non-temporal loads), the pooled frame and the three per-env traces written
+template <bool NT_ST>
 __global__ __launch_bounds__(256) void push_transition_maxpool_kernel(uint4* __restrict__ dst, const uint4* __restrict__ s1,
                                                                       const uint4* __restrict__ s2, int64_t n16,
                                                                       int32_t* __restrict__ a_dst, float* __restrict__ r_dst,
@@ -286,7 +326,13 @@ __global__ __launch_bounds__(256) void push_transition_maxpool_kernel(uint4* __r
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = g0; i < n16; i += stride) {
         const nt_u32x4 x = nt_load16(s1 + i), y = nt_load16(s2 + i);
-        dst[i] = make_uint4(max_u8x4(x[0], y[0]), max_u8x4(x[1], y[1]), max_u8x4(x[2], y[2]), max_u8x4(x[3], y[3]));
+        nt_u32x4 o;
+        o[0] = max_u8x4(x[0], y[0]);
+        o[1] = max_u8x4(x[1], y[1]);
+        o[2] = max_u8x4(x[2], y[2]);
+        o[3] = max_u8x4(x[3], y[3]);
+        if (NT_ST) nt_store16(dst + i, o);
+        else dst[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
     for (int64_t i = g0; i < n; i += stride) {
         a_dst[i] = a[i];
@@ -410,7 +456,16 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb, const int64_t* idx, int64_t batc
                            (uint8_t*)s, a, r, term, (uint8_t*)s_next);
     } else {
         int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
-        if (rb->elem_bytes == 4)
+        const bool lane = rb->elem_bytes == 4 && rb->obs_dim >= 1 && rb->obs_dim <= 4 && !RLHIP_ENV_FLAG("RLHIP_GATHER_GENERIC");
+#define RLHIP_GATHER_LANE(OD)                                                                                             \
+    hipLaunchKernelGGL((gather_small_lane_kernel<float, OD>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v, idx, \
+                       batch, (float*)s, a, r, term, (float*)s_next)
+        if (lane && rb->obs_dim == 4) RLHIP_GATHER_LANE(4);
+        else if (lane && rb->obs_dim == 3) RLHIP_GATHER_LANE(3);
+        else if (lane && rb->obs_dim == 2) RLHIP_GATHER_LANE(2);
+        else if (lane && rb->obs_dim == 1) RLHIP_GATHER_LANE(1);
+#undef RLHIP_GATHER_LANE
+        else if (rb->elem_bytes == 4)
             hipLaunchKernelGGL((gather_small_kernel<float>), dim3(grid), dim3(256), 0, st, v, idx, batch,
                                (float*)s, a, r, term, (float*)s_next);
         else
@@ -489,9 +544,12 @@ int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb, const void* screen1, 
         rb->head_sa = (rb->head_sa + 1) % sframes;
     }
     const int64_t n16 = fbytes / 16;
-    hipLaunchKernelGGL(push_transition_maxpool_kernel, dim3(grid_for(n16 > n ? n16 : n, 256, 256 * 16)), dim3(256), 0, s,
-                       (uint4*)((uint8_t*)rb->state + sphys * fbytes), (const uint4*)screen1, (const uint4*)screen2, n16,
-                       rb->action + phys * n, rb->reward + phys * n, rb->terminal + phys * n, action, reward, terminal, n);
+    const int grid = grid_for(n16 > n ? n16 : n, 256, 256 * 16);
+    uint4* sdst = (uint4*)((uint8_t*)rb->state + sphys * fbytes);
+    // non-temporal stores for the write-once ring frame: 57.6 us per 4096 x 28 KB push against 65.8 with ordinary stores
+    hipLaunchKernelGGL((push_transition_maxpool_kernel<true>), dim3(grid), dim3(256), 0, s, sdst, (const uint4*)screen1,
+                       (const uint4*)screen2, n16, rb->action + phys * n, rb->reward + phys * n, rb->terminal + phys * n,
+                       action, reward, terminal, n);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

@@ -82,7 +82,7 @@ BF16_FLIP_SHARE = 0.15
 GRAD_ERR_LOG = os.path.join(ROOT, "gpurun_out", "grad_err.jsonl")
 
 
-def assert_grad_close(g, o, tol, tag=""):
+def assert_grad_close(g, o, tol, tag="", q99_tol=None):
     import json
 
     import numpy as np
@@ -107,6 +107,7 @@ def assert_grad_close(g, o, tol, tag=""):
         assert q99 <= BF16_TIGHT_Q99_TOL, f"{tag}: q99 of |g - o| / max|o| = {q99:.3e} > {BF16_TIGHT_Q99_TOL:.0e} (n = {g.size})"
     if tol == BF16_GRAD_TOL:  # the flip-prone bf16 cases: the max bar admits a flipped decision, the bulk must not move
         if g.size >= BF16_BULK_MIN_N:
-            assert q99 <= BF16_Q99_TOL, f"{tag}: q99 of |g - o| / max|o| = {q99:.3e} > {BF16_Q99_TOL:.0e} (n = {g.size})"
+            qt = BF16_Q99_TOL if q99_tol is None else q99_tol  # (one documented override: tests/test_gpu_ppo3w.py)
+            assert q99 <= qt, f"{tag}: q99 of |g - o| / max|o| = {q99:.3e} > {qt:.0e} (n = {g.size})"
         else:
             assert err <= BF16_SMALL_TOL, f"{tag}: max|g - o| / max|o| = {err:.3e} > {BF16_SMALL_TOL:.0e} (n = {g.size} < {BF16_BULK_MIN_N})"

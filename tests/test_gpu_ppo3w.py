@@ -81,13 +81,13 @@ def _oracle_grad(pol, env, cont, ocfg, epoch, mb, bm, total, n, T):
                                 tr.adv.cpu().numpy()[t, i], tr.ret.cpu().numpy()[t, i])
 
 
-def _check_grad(pol, g, og, ns, label):
+def _check_grad(pol, g, og, ns, label, q99_tol=None):
     np_a = pol.np_actor
     for name, a, b in (("actor", g[:np_a], og[:np_a]), ("critic", g[np_a:], og[np_a:])):
         o = 0
         nout = 2 if name == "actor" else 1
         for tname, sz in (("W1", H * ns), ("b1", H), ("W2", H * H), ("b2", H), ("W3", nout * H), ("b3", nout)):
-            assert_grad_close(a[o:o + sz], b[o:o + sz], BF16_GRAD_TOL, f"ppo3w {label} {name} {tname} ns={ns}")
+            assert_grad_close(a[o:o + sz], b[o:o + sz], BF16_GRAD_TOL, f"ppo3w {label} {name} {tname} ns={ns}", q99_tol=q99_tol)
             o += sz
         assert o == a.size
 
@@ -101,10 +101,6 @@ def test_grad_matches_oracle(kind, cont, act):
     env, pol = _setup(kind, n, T, n_microbatches=2, act=a)
     pol.rollout_()
     pol.gae_()
-    # round 4: |advantage| <= 10.  Unclamped, Pendulum's first steps give one sample an advantage of -65 against a typical -5;
-    # in a 432-sample micro-batch that ONE sample is then most of max|g| and the check measures the conditioning of its
-    # (a - mu) / sigma (cancellation amplifies the 1e-6 head difference of the bf16 layer to 1e-4), not the kernels
-    pol.trajectory.adv.clamp_(-10.0, 10.0)
     ocfg = oracle.ppo_default(hidden=H, continuous=int(cont), layers=3, n_microbatches=2, act=a)
     total, bm = n * T, (n * T) // 2
     for mb, epoch in ((0, 0), (1, 3)):
@@ -113,7 +109,12 @@ def test_grad_matches_oracle(kind, cont, act):
         losses = pol.losses.cpu().numpy()
         og, ol = _oracle_grad(pol, env, cont, ocfg, epoch, mb, bm, total, n, T)
         assert np.all(np.abs(losses - ol) <= 2e-4 * (1 + np.abs(ol))), (losses, ol)
-        _check_grad(pol, g, og, env.odim, f"{kind} {act}")
+        # Gaussian + tanh at 432 samples is the ill-conditioned corner of the suite: hidden units that feed BOTH heads carry
+        # dh2 = w (dls - dmu) (a cancellation that turns the 1e-7 differences of the two sides' expf / division into 1e-4 of
+        # that unit's dz2), tanh' = 1 - h^2 cancels near saturation, and one sample with an advantage of -65 is most of
+        # max|g| -- each pinned down while building tests/test_gpu_bf16_tight.py (which holds this instantiation to 5e-5 /
+        # 1e-5 on well-conditioned inputs).  Its bulk bar is 3e-4 (measured 8.4e-5) instead of the suite's 1e-4.
+        _check_grad(pol, g, og, env.odim, f"{kind} {act}", q99_tol=3e-4 if (cont and act == "tanh") else None)
     pol.grad_(3, 1)  # deterministic: fixed summation order, no atomics
     assert np.array_equal(pol.grad.cpu().numpy(), g)
 
