@@ -24,7 +24,8 @@ import ReinforcementLearningCore: _run, check!, forward, target, model, PreExper
 using Random, DomainSets
 
 export HipVecEnv, HipCartPoleEnv, HipPendulumEnv, HipMountainCarEnv, HipAcrobotRK4Env, HipTrajectory, HipApproximator,
-    HipTargetNetwork, HipDQNLearner, HipQBasedPolicy, HipPPOPolicy, HipComm, HipEpisodeStats, DevBuf, to_host, to_dev!
+    HipTargetNetwork, HipDQNLearner, HipQBasedPolicy, HipPPOPolicy, HipComm, HipEpisodeStats, DevBuf, to_host, to_dev!,
+    HipPrioritizedTraces, HipStackFrames, DevValues, sample
 
 const LIB = get(ENV, "RLHIP_LIB", "librlhip.so")
 
@@ -861,6 +862,108 @@ gaussian_logp!(logp::DevBuf{Float32}, mu::DevBuf{Float32}, raw_sigma::DevBuf{Flo
     chk(ccall((:rlhip_gaussian_head_logp_f32, LIB), Int32,
               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Float32, Float32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
               mu.ptr, raw_sigma.ptr, action.ptr, d, n, K, min_sigma, max_sigma, squash, soft, logp.ptr, stream()))
+
+# ---- the same rows on the REFERENCE's types (round 4): what a user of the reference writes keeps working when the values /
+# traces live on the device.  These are methods, not new entry points: each one forwards to a free function above.
+
+"""
+    HipPrioritizedTraces(traces::HipTrajectory; default_priority = 100f0)
+
+`CircularPrioritizedTraces(CircularArraySARTSTraces(...); default_priority)` of RLTrajectories 0.4 with the priorities in a
+device sum-tree: `push!` gives every new transition `default_priority`, `sample(traces, batchsize)` is the prioritized
+`BatchSampler` draw (`inds, priorities = rand(rng, sumtree, batchsize)`) and `traces[:priority, keys] = p` the write-back.
+"""
+mutable struct HipPrioritizedTraces
+    traces::HipTrajectory
+    tree::DevBuf{Float32}
+    n_leaves::Int
+    default_priority::Float32
+    seed::UInt64
+    draw_ctr::UInt32
+end
+function HipPrioritizedTraces(t::HipTrajectory; default_priority = 100f0, seed = 0)
+    default_priority > 0 || throw(ArgumentError("default_priority must be > 0"))
+    n = Int(t.rb.capacity * t.rb.n_env)
+    HipPrioritizedTraces(t, DevBuf{Float32}(sumtree_nodes(n)), n, Float32(default_priority), UInt64(seed), UInt32(0))
+end
+Base.length(p::HipPrioritizedTraces) = length(p.traces)
+Base.push!(p::HipPrioritizedTraces, x::NamedTuple{(:state,)}) = (push!(p.traces, x); p)
+"push!(traces, (state = s', action, reward, terminal)): the trajectory's push, then the new leaves := default_priority"
+function Base.push!(p::HipPrioritizedTraces, x::NamedTuple{(:state, :action, :reward, :terminal)})
+    push!(p.traces, x)
+    push_priority!(p.traces, p.tree, p.default_priority)
+    p
+end
+"the prioritized BatchSampler: (inds for the gather, keys for the write-back, priorities) as device buffers"
+function sample(p::HipPrioritizedTraces, batchsize::Integer)
+    idx, key, prio = DevBuf{Int64}(batchsize), DevBuf{Int64}(batchsize), DevBuf{Float32}(batchsize)
+    sample_prioritized!(idx, key, prio, p.traces, p.tree, batchsize, p.seed, p.draw_ctr)
+    p.draw_ctr += UInt32(1)
+    (inds = idx, key = key, priority = prio)
+end
+"trajectory[:priority, keys] = p  (sequential semantics: the last duplicate key wins)"
+function Base.setindex!(p::HipPrioritizedTraces, v::DevBuf{Float32}, name::Symbol, keys::DevBuf{Int64})
+    name === :priority || throw(ArgumentError("only the :priority trace can be assigned"))
+    keys.n == v.n || throw(DimensionMismatch("keys and priorities differ in length"))
+    set_priority!(p.tree, p.n_leaves, keys, v, keys.n)
+    v
+end
+
+"""
+    HipStackFrames(n_stack)
+
+`StackFrames(T, d..., n_stack)` (RLCore/src/utils/stack_frames.jl:11-44) moved from the way INTO the trajectory to the way
+OUT: the ring stores single frames (4x less HBM for n_stack = 4); `sample(sf, traces, inds)` returns what the reference's
+agent would have stored -- the last n_stack frames ending at each index, zero frames before an episode's first observation
+(`reset!(::StackFrames)` fills the buffer with zeros, :36-39).
+"""
+struct HipStackFrames
+    n_stack::Int
+end
+function sample(sf::HipStackFrames, t::HipTrajectory, inds::DevBuf{Int64})
+    b, fb = inds.n, Int(t.rb.obs_dim)
+    T = t.rb.elem_bytes == 1 ? UInt8 : Float32
+    s, sn = DevBuf{T}(b * sf.n_stack * fb), DevBuf{T}(b * sf.n_stack * fb)
+    a, r, term = DevBuf{Int32}(b), DevBuf{Float32}(b), DevBuf{UInt8}(b)
+    gather_stacked!(t, inds, b, sf.n_stack, s, a, r, term, sn)
+    (state = s, action = a, reward = r, terminal = term, next_state = sn)
+end
+
+# plan!(explorer, values[, mask]) with `values` a device (na, n) SoA matrix = one column per env: the BatchExplorer form
+# (`[x.explorer(v) for v in eachcol(values)]`, batch_explorer.jl:15-18).  The explorer object keeps its hyper-parameters;
+# its `rng` field is replaced by the shared Philox streams (seed / step keywords), like every other draw of this path.
+struct DevValues          # a device value matrix and its shape (na actions x n envs), 1-based actions come back
+    values::DevBuf{Float32}
+    na::Int
+    n::Int
+end
+_plan_dev(kind, v::DevValues, mask; is_normalized = false, seed = 0, env_id_base = 0, step = 1) = begin
+    a = DevBuf{Int32}(v.n)
+    plan_explorer!(kind, a, v.values, v.na, v.n; mask = mask, is_normalized = is_normalized, seed = seed,
+                   env_id_base = env_id_base, step = step)
+    a   # 0-based on the device; `to_host(a) .+ 1` are the reference's action indices
+end
+plan!(s::ReinforcementLearningCore.WeightedExplorer{N}, v::DevValues, mask = nothing; kw...) where {N} =
+    _plan_dev(0, v, mask; is_normalized = N, kw...)                       # weighted_explorer.jl:25-34
+plan!(s::ReinforcementLearningCore.WeightedSoftmaxExplorer, v::DevValues, mask = nothing; kw...) =
+    _plan_dev(1, v, mask; kw...)                                          # weighted_softmax_explorer.jl:20-26
+plan!(s::ReinforcementLearningCore.GumbelSoftmaxExplorer, v::DevValues, mask = nothing; kw...) =
+    _plan_dev(2, v, mask; kw...)                                          # gumbel_softmax_explorer.jl:12-22
+function plan!(s::EpsilonGreedyExplorer, v::DevValues, mask = nothing; seed = 0, env_id_base = 0)
+    ϵ = get_ϵ(s)                                                          # epsilon_greedy_explorer.jl:69-90
+    s.step += 1                                                           # :104, :119: one explorer step per vec-step
+    a = DevBuf{Int32}(v.n)
+    plan_eps_greedy!(a, v.values, v.na, v.n, ϵ; mask = mask, seed = seed, env_id_base = env_id_base, step = s.step)
+    a
+end
+"UCBExplorer (UCB_explorer.jl:24-28): `counts` is the explorer's per-env action counter on the device (na, n), Float64"
+function plan!(s::ReinforcementLearningCore.UCBExplorer, v::DevValues, counts::DevBuf{Float64}; seed = 0, env_id_base = 0)
+    a = DevBuf{Int32}(v.n)
+    plan_ucb!(a, v.values, counts, v.na, v.n, s.c, s.step; seed = seed, env_id_base = env_id_base)
+    s.step += 1
+    a
+end
+plan!(x::ReinforcementLearningCore.BatchExplorer, v::DevValues, args...; kw...) = plan!(x.explorer, v, args...; kw...)
 
 # ------------------------------------------------------------------------------------------------------------------
 # hooks: TotalRewardPerEpisode + BatchStepsPerEpisode (RLCore/core/hooks.jl:146-231) with device accumulators

@@ -198,3 +198,43 @@ def test_julia_dqn_update_gates_consult_the_sample_ratio_controller():
     assert "on_sample!(t.controller)" in fused[:300]
     py = open(os.path.join(ROOT, "reinforcementlearning.jl_amd", "rlhip", "dqn.py")).read()
     assert "trajectory.controller.on_sample_()" in py
+
+
+def test_f_rows_are_methods_on_the_reference_types_and_match_integration_md():
+    """INTEGRATION.md promises methods on HipPrioritizedTraces / on the reference's explorer types / a
+    StackFrames-shaped sampler.  The Julia module must define exactly those, each forwarding to a free function whose ccall
+    the signature tests above already pinned against include/rlhip.h, and INTEGRATION.md must name them."""
+    src = re.sub(r"#[^\n]*", "", open(GLUE).read())
+    # prioritized traces: type, push! on both NamedTuple shapes, sample, setindex!(:priority)
+    assert re.search(r"mutable struct HipPrioritizedTraces\b", src)
+    assert re.search(r"Base\.push!\(p::HipPrioritizedTraces, x::NamedTuple\{\(:state,\)\}\)", src)
+    body = src[src.index("function Base.push!(p::HipPrioritizedTraces, x::NamedTuple{(:state, :action, :reward, :terminal)})"):]
+    body = body[:body.index("\nend")]
+    assert "push!(p.traces, x)" in body and "push_priority!(p.traces, p.tree, p.default_priority)" in body
+    smp = src[src.index("function sample(p::HipPrioritizedTraces, batchsize::Integer)"):]
+    smp = smp[:smp.index("\nend")]
+    assert "sample_prioritized!(idx, key, prio, p.traces, p.tree, batchsize, p.seed, p.draw_ctr)" in smp and "p.draw_ctr +=" in smp
+    seti = src[src.index("function Base.setindex!(p::HipPrioritizedTraces, v::DevBuf{Float32}, name::Symbol, keys::DevBuf{Int64})"):]
+    assert "set_priority!(p.tree, p.n_leaves, keys, v, keys.n)" in seti[:seti.index("\nend")]
+    # StackFrames at sample time
+    assert re.search(r"struct HipStackFrames\b", src)
+    sf = src[src.index("function sample(sf::HipStackFrames, t::HipTrajectory, inds::DevBuf{Int64})"):]
+    assert "gather_stacked!(t, inds, b, sf.n_stack, s, a, r, term, sn)" in sf[:sf.index("\nend")]
+    # explorers: plan! methods on the reference's own types (kinds 0 / 1 / 2 of rlhip_explorer_select_f32)
+    for typ, kind in (("WeightedExplorer{N}", 0), ("WeightedSoftmaxExplorer", 1), ("GumbelSoftmaxExplorer", 2)):
+        m = re.search(r"plan!\(s::ReinforcementLearningCore\." + re.escape(typ) + r", v::DevValues, mask = nothing; kw\.\.\.\)[^=]*=\s*_plan_dev\((\d)", src)
+        assert m and int(m.group(1)) == kind, typ
+    assert "function plan!(s::EpsilonGreedyExplorer, v::DevValues, mask = nothing" in src
+    assert "function plan!(s::ReinforcementLearningCore.UCBExplorer, v::DevValues, counts::DevBuf{Float64}" in src
+    assert "plan!(x::ReinforcementLearningCore.BatchExplorer, v::DevValues, args...; kw...) = plan!(x.explorer, v, args...; kw...)" in src
+    # the reference's explorer types really have the fields the methods read
+    ref = "/root/reference/src/ReinforcementLearningCore/src/policies/explorers"
+    if os.path.isdir(ref):  # (absent on the GPU box; this is a CPU test)
+        ucb = open(os.path.join(ref, "UCB_explorer.jl")).read()
+        assert re.search(r"\bc::Float64", ucb) and re.search(r"\bstep::Int", ucb)
+        assert "struct WeightedExplorer{T,R<:AbstractRNG}" in open(os.path.join(ref, "weighted_explorer.jl")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for needle in ("HipPrioritizedTraces(traces; default_priority)", "HipStackFrames(n_stack)", "v::DevValues[, mask]"):
+        assert needle in doc, needle
+    for name in ("HipPrioritizedTraces", "HipStackFrames", "DevValues", "sample"):
+        assert re.search(r"export[^#]*\b" + name + r"\b", open(GLUE).read(), flags=re.S), name
