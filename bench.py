@@ -191,9 +191,14 @@ def roofline_extras(torch, rlhip):
     def upd():
         rlhip._lib.call("rlhip_sumtree_update", ops.ptr(tr.priorities), cap, ops.ptr(key), ops.ptr(prio), batch, s)
 
+    def sg():  # round 4: the prioritized draw inside the gather launch (one launch instead of two)
+        rlhip._lib.call("rlhip_ring_sample_gather_prioritized", C.byref(tr.rb), ops.ptr(tr.priorities), batch, 11, ctr[0],
+                        ops.ptr(idx), ops.ptr(key), ops.ptr(prio), ops.ptr(bufs[0]), ops.ptr(bufs[1]), ops.ptr(bufs[2]),
+                        ops.ptr(bufs[3]), ops.ptr(bufs[4]), s)
+        ctr[0] += 1
+
     def both():
-        smp()
-        g()
+        sg()
         upd()
 
     def fresh_gather():  # new indices every launch: no Infinity-Cache hits from a repeated batch
@@ -205,6 +210,7 @@ def roofline_extras(torch, rlhip):
     ms_rep = event_time_ms(g, 10, lib, s)
     ms_u = event_time_ms(upd, 10, lib, s)
     ms_all = event_time_ms(both, 10, lib, s)
+    ms_sg = event_time_ms(sg, 10, lib, s)
     gb = 2 * (2 * fb + 9) * batch / 1e9
     out["frame_gather_u8"] = {"bound": "hbm", "capacity": cap, "frame_bytes": fb, "batch": batch,
                               "ring_state_gb": round((cap + 1) * fb / 1e9, 2),
@@ -214,7 +220,9 @@ def roofline_extras(torch, rlhip):
                               "us_per_launch_repeated_batch": round(ms_rep * 1e3, 1),
                               "prioritized_sample_us": round(ms_s * 1e3, 1),
                               "priority_update_us": round(ms_u * 1e3, 1),
+                              "sample_gather_fused_us": round(ms_sg * 1e3, 1),
                               "sample_gather_update_us": round(ms_all * 1e3, 1),
+                              "sample_gather_update_note": "two launches: rlhip_ring_sample_gather_prioritized (draw inside the gather) + rlhip_sumtree_update",
                               "prioritized_samples_per_sec": round(batch / (ms_all * 1e-3), 1)}
     # batch in {32, 512, 4096} -- the small batches are the latency regime of the same kernels
     # (32 samples = 32 workgroup pairs: a handful of CUs busy; the time is the launch + one HBM round trip per frame pair)
@@ -236,9 +244,14 @@ def roofline_extras(torch, rlhip):
         def u_b():
             rlhip._lib.call("rlhip_sumtree_update", ops.ptr(tr.priorities), cap, ops.ptr(key_b), ops.ptr(prio_b), b, s)
 
+        def sg_b():
+            rlhip._lib.call("rlhip_ring_sample_gather_prioritized", C.byref(tr.rb), ops.ptr(tr.priorities), b, 11, cb[0],
+                            ops.ptr(idx_b), ops.ptr(key_b), ops.ptr(prio_b), ops.ptr(bufs_b[0]), ops.ptr(bufs_b[1]),
+                            ops.ptr(bufs_b[2]), ops.ptr(bufs_b[3]), ops.ptr(bufs_b[4]), s)
+            cb[0] += 1
+
         def all_b():
-            smp_b()
-            g_b()
+            sg_b()
             u_b()
 
         def fresh_b():

@@ -572,6 +572,14 @@ int32_t rlhip_ring_push_priority(const rlhip_ring* rb_host, float* tree, float p
 int32_t rlhip_ring_sample_prioritized(const rlhip_ring* rb_host, const float* tree, int64_t batch,
                                       uint64_t seed, uint32_t draw_ctr, int64_t* idx_out, int64_t* key_out,
                                       float* prio_out, rlhip_stream_t stream);
+/* The prioritized BatchSampler AND the gather of its batch in ONE launch (round 4): the draw of sample b is made by the
+ * workgroup / lane that gathers it (same Philox draw, same descent: idx_out / key_out / prio_out and the gathered batch are
+ * bit-identical to rlhip_ring_sample_prioritized followed by rlhip_ring_gather).  Frame-major rings (n_env = 1, frames of
+ * >= 1 KB) and Float32 rings with <= 4 components; other layouts run the two launches.  Outputs as rlhip_ring_gather. */
+int32_t rlhip_ring_sample_gather_prioritized(const rlhip_ring* rb_host, const float* tree, int64_t batch, uint64_t seed,
+                                             uint32_t draw_ctr, int64_t* idx_out, int64_t* key_out, float* prio_out,
+                                             void* s, int32_t* a, float* r, uint8_t* term, void* s_next,
+                                             rlhip_stream_t stream);
 
 /* ---------------------------------------------------------------------------------- MLP -- */
 /* Chain(Dense(n_in, h, act), Dense(h, n_out)) with flat parameters in Flux.destructure order:

@@ -132,6 +132,41 @@ __global__ __launch_bounds__(256) void gather_small_kernel(RingView rb, const in
     }
 }
 
+// PRIO (round 4): the prioritized BatchSampler's draw happens HERE -- thread 0 of the sample's workgroup walks the sum-tree
+// (the same Philox draw and descent as sumtree_sample_kernel: bit-identical indices), writes idx / key / priority and goes
+// on; the 20 dependent 8-byte reads of a descent (~7 us) hide behind the frame streams of the other resident workgroups, so
+// "sample + gather" is one launch instead of two.
+struct PrioDraw {
+    const float* tree;  // NULL: indices come from idx (uniform sampler / caller-supplied)
+    int64_t P, n_leaves;
+    uint64_t seed;
+    uint32_t draw_ctr;
+    int64_t* idx_out;
+    int64_t* key_out;  // may be NULL
+    float* prio_out;   // may be NULL
+};
+__device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingView& rb, int64_t b) {
+    const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
+    float v = u01_f32(w.z) * pd.tree[1];
+    int64_t node = 1;
+    while (node < pd.P) {  // sumtree_descend (sumtree.hip), restated: never enters a zero-sum subtree
+        const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * node);
+        const bool right = (v > c.x && c.y > 0.0f) || c.x == 0.0f;
+        if (right) v -= c.x;
+        node = 2 * node + (right ? 1 : 0);
+    }
+    int64_t leaf = node - pd.P;
+    if (leaf >= pd.n_leaves) leaf = pd.n_leaves - 1;
+    if (pd.key_out) pd.key_out[b] = leaf;
+    if (pd.prio_out) pd.prio_out[b] = pd.tree[pd.P + leaf];
+    const int64_t pt = leaf / rb.n_env, e = leaf - pt * rb.n_env;
+    int64_t li = pt - rb.head_rt;
+    if (li < 0) li += rb.capacity;
+    const int64_t flat = li * rb.n_env + e;
+    pd.idx_out[b] = flat;
+    return flat;
+}
+
 // small observations with a compile-time size (OD <= 8 components: the classic-control envs): one LANE per sample, every
 // load of the sample (2 OD state components, action, reward, terminal: 11 for CartPole) issued before the first store --
 // the gather is a chain of dependent cache misses otherwise (the generic kernel above keeps two loads in flight per lane:
@@ -140,10 +175,10 @@ template <typename E, int OD>
 __global__ __launch_bounds__(256) void gather_small_lane_kernel(RingView rb, const int64_t* __restrict__ idx, int64_t batch,
                                                                 E* __restrict__ s, int32_t* __restrict__ a,
                                                                 float* __restrict__ r, uint8_t* __restrict__ term,
-                                                                E* __restrict__ sn) {
+                                                                E* __restrict__ sn, PrioDraw pd) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const int64_t j = idx[b];
+    const int64_t j = pd.tree ? prio_draw_one(pd, rb, b) : idx[b];
     const int64_t li = j / rb.n_env, e = j - li * rb.n_env;
     const int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
     const int64_t pn = (ps + 1 == rb.capacity + 1) ? 0 : ps + 1;
@@ -177,11 +212,11 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
                                                             int64_t batch, int64_t frame_bytes,
                                                             uint8_t* __restrict__ s, int32_t* __restrict__ a,
                                                             float* __restrict__ r, uint8_t* __restrict__ term,
-                                                            uint8_t* __restrict__ sn) {
+                                                            uint8_t* __restrict__ sn, PrioDraw pd) {
     __shared__ int64_t l_off[2];
     int64_t b = blockIdx.x;
     if (threadIdx.x == 0) {
-        int64_t li = idx[b];
+        int64_t li = pd.tree ? prio_draw_one(pd, rb, b) : idx[b];
         int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
         int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
         int64_t pt = (rb.head_rt + li) % rb.capacity;
@@ -441,9 +476,36 @@ int32_t rlhip_ring_gather_is_frame_major(const rlhip_ring* rb) {
     return (rb->n_env == 1 && frame_bytes >= 1024 && (frame_bytes % 16 == 0)) ? 1 : 0;
 }
 
+static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_t batch, void* s, int32_t* a, float* r,
+                                uint8_t* term, void* s_next, const PrioDraw& pd, rlhip_stream_t stream);
+
 int32_t rlhip_ring_gather(const rlhip_ring* rb, const int64_t* idx, int64_t batch, void* s, int32_t* a,
                           float* r, uint8_t* term, void* s_next, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb && idx && s && a && r && term && s_next && batch >= 0, "bad arguments");
+    return ring_gather_impl(rb, idx, batch, s, a, r, term, s_next, PrioDraw{}, stream);
+}
+
+int32_t rlhip_ring_sample_gather_prioritized(const rlhip_ring* rb, const float* tree, int64_t batch, uint64_t seed,
+                                             uint32_t draw_ctr, int64_t* idx_out, int64_t* key_out, float* prio_out,
+                                             void* s, int32_t* a, float* r, uint8_t* term, void* s_next,
+                                             rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && tree && idx_out && s && a && r && term && s_next && batch >= 0, "bad arguments");
+    RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
+    const int64_t n_leaves = rb->capacity * rb->n_env;
+    int64_t P = 1;
+    while (P < n_leaves) P <<= 1;
+    const bool fused = rlhip_ring_gather_is_frame_major(rb) || (rb->elem_bytes == 4 && rb->obs_dim >= 1 && rb->obs_dim <= 4);
+    if (!fused) {  // layouts without a fused kernel (u8 / wide small observations): the two launches
+        int32_t rc = rlhip_ring_sample_prioritized(rb, tree, batch, seed, draw_ctr, idx_out, key_out, prio_out, stream);
+        if (rc) return rc;
+        return rlhip_ring_gather(rb, idx_out, batch, s, a, r, term, s_next, stream);
+    }
+    return ring_gather_impl(rb, idx_out, batch, s, a, r, term, s_next,
+                            PrioDraw{tree, P, n_leaves, seed, draw_ctr, idx_out, key_out, prio_out}, stream);
+}
+
+static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_t batch, void* s, int32_t* a, float* r,
+                                uint8_t* term, void* s_next, const PrioDraw& pd, rlhip_stream_t stream) {
     if (batch == 0) return RLHIP_OK;
     hipStream_t st = as_stream(stream);
     RingView v = view_of(rb);
@@ -453,13 +515,13 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb, const int64_t* idx, int64_t batc
         RLHIP_REQUIRE(((((uintptr_t)rb->state | (uintptr_t)s | (uintptr_t)s_next) & 15) == 0),
                       "frame-major gather needs 16-byte aligned buffers");
         hipLaunchKernelGGL(gather_frames_kernel, dim3((int)batch), dim3(256), 0, st, v, idx, batch, frame_bytes,
-                           (uint8_t*)s, a, r, term, (uint8_t*)s_next);
+                           (uint8_t*)s, a, r, term, (uint8_t*)s_next, pd);
     } else {
         int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
-        const bool lane = rb->elem_bytes == 4 && rb->obs_dim >= 1 && rb->obs_dim <= 4 && !RLHIP_ENV_FLAG("RLHIP_GATHER_GENERIC");
+        const bool lane = rb->elem_bytes == 4 && rb->obs_dim >= 1 && rb->obs_dim <= 4;
 #define RLHIP_GATHER_LANE(OD)                                                                                             \
     hipLaunchKernelGGL((gather_small_lane_kernel<float, OD>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v, idx, \
-                       batch, (float*)s, a, r, term, (float*)s_next)
+                       batch, (float*)s, a, r, term, (float*)s_next, pd)
         if (lane && rb->obs_dim == 4) RLHIP_GATHER_LANE(4);
         else if (lane && rb->obs_dim == 3) RLHIP_GATHER_LANE(3);
         else if (lane && rb->obs_dim == 2) RLHIP_GATHER_LANE(2);

@@ -67,91 +67,169 @@ __global__ __launch_bounds__(1024) void sumtree_range_kernel(float* tree, int64_
     }
 }
 
-// Priority write-back `t[keys] .= ps`.  The ancestor chain is latency- AND issue-bound: one dependent global round
-// trip per level, and a level's random 8-byte accesses of all keys through ONE CU's memory pipeline (measured: 67 us
-// for 4096 keys on a 2^20-leaf tree, growing linearly with the key count).  So:
-//  * the tree is cut at the first level with <= TOPN nodes.  Keys below different cut nodes never share a node, so
-//    gridDim.x workgroups each take the cut nodes c with (c mod gridDim.x) == blockIdx.x and run election + the
-//    sparse levels on their own keys with workgroup barriers only (duplicates of a leaf land in one workgroup);
-//    membership is re-evaluated from the key array on every pass (coalesced, L2-resident) instead of building lists;
-//  * the child pairs of the sparse levels are touched once up front so that the dependent loads hit the L2;
-//  * the workgroup that arrives last (counter in the unused heap slot tree[0], re-armed to 0) recomputes the top of
-//    the tree WHOLE in LDS: one load of the 2 TOPN cut-level values, 13 LDS levels, stores on the way.
+// Priority write-back `t[keys] .= ps`.  Round 1-3: election on the leaf tags with global atomics (four dependent passes),
+// then one dependent global round trip per sparse level behind a workgroup barrier: 30 us for 4096 keys on a 2^20-leaf tree.
+// Round 4:
+//  * the tree is cut at the first level with <= TOPN nodes (ltop).  Keys below different cut nodes never share a node, so
+//    gridDim.x workgroups each take the level-(ltop - 1) nodes c with (c mod gridDim.x) == blockIdx.x -- duplicates of a
+//    leaf and all keys of a subtree land in ONE workgroup, whose phases need workgroup barriers only;
+//  * ELECTION in LDS: a workgroup's keys (item number + leaf) are compacted into an LDS list while the key array streams by
+//    once; "the last occurrence of a leaf wins" (the sequential `for (k, p) in zip(keys, ps); t[k] = p; end`) is then a scan
+//    of that short list.  A workgroup whose share exceeds LCAP = 1024 items falls back to the election on the leaf tags
+//    (zero the tag, atomicMax the item number, the winner replaces the tag by its priority): any key distribution works;
+//  * the sparse levels are not walked: every winner's 2^bl-leaf BLOCK (bl = min(ltop - 1, 7): 128 leaves = 512 contiguous
+//    bytes) is recomputed WHOLE by one wave -- one load per lane, bl shuffle-add levels (left + right, the order of the
+//    sequential reference), bl coalesced stores -- no dependent global round trip at all (trees above 2^20 leaves walk the
+//    remaining ltop - 1 - bl levels the old way);
+//  * the workgroup that arrives last (counter in the unused heap slot tree[0], re-armed to 0) recomputes the top of the
+//    tree WHOLE in LDS: one load of the 2 TOPN cut-level values, 13 LDS levels, stores on the way.
 // Parents are always left + right of the stored children: bit-identical to the sequential reference.
 __global__ __launch_bounds__(1024) void sumtree_update_kernel(float* tree, int64_t P, int logP, int64_t n_leaves,
                                                               const int64_t* __restrict__ leaf,
                                                               const float* __restrict__ prio, int64_t n) {
     constexpr int TOPN = 4096;
+    constexpr int LCAP = 1024;  // local (item, leaf) list (the election scans it once per entry: one entry per thread at most)
     __shared__ float l_a[2 * TOPN], l_b[TOPN];  // ping-pong: 2 TOPN children -> TOPN nodes -> TOPN / 2 -> ...
-    __shared__ int l_last;
+    __shared__ int l_last, l_cnt, l_nw;
     uint32_t* bits = reinterpret_cast<uint32_t*>(tree);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NT = blockDim.x, NWV = NT >> 6;  // 256 .. 1024 threads (the grid of a 4096-key update is 256 workgroups: wave dispatch is part of its latency)
     const int ltop = logP > 12 ? logP - 12 : 1;  // first level (counted from the leaves) with <= TOPN nodes
+    const int sl = ltop - 1;                      // sparse levels 1 .. sl
+    const int bl = sl < 7 ? sl : 7;               // levels recomputed block-wise by one wave
     const int64_t gmask = (int64_t)gridDim.x - 1;  // gridDim.x is a power of two <= 2 TOPN
     const int64_t mine = blockIdx.x;
     auto key = [&](int64_t i) -> int64_t {  // out-of-range keys are ignored (never written); -1 also for other
         int64_t k = leaf[i];               // workgroups' keys
         if (k < 0 || k >= n_leaves) return -1;
-        return ((((P + k) >> (ltop - 1)) & gmask) == mine) ? k : -1;
+        return ((((P + k) >> sl) & gmask) == mine) ? k : -1;
     };
-    // this workgroup's view of the first 2 TOPN keys (-1 = not mine / out of range) is kept in LDS: every pass below
-    // walks the whole key array, and re-deriving membership from global memory costs a round trip per pass
-    int32_t* l_keys = reinterpret_cast<int32_t*>(l_a);  // l_a is not needed before the top-of-tree phase
-    const int64_t KC = n_leaves < (1ll << 31) ? 2 * TOPN : 0;  // (leaf indices fit the int32 cache)
-    for (int64_t i = tid; i < n && i < KC; i += 1024) l_keys[i] = (int32_t)key(i);
-    __syncthreads();
-    auto keyc = [&](int64_t i) -> int64_t { return i < KC ? (int64_t)l_keys[i] : key(i); };
-    // duplicate keys: the LAST occurrence wins (sequential `for (k, p) in zip(keys, ps); t[k] = p; end`).
-    // The leaf itself carries the election: zero it, atomicMax the 1-based item number into it, then the
-    // winner replaces the tag by its priority.
-    for (int64_t i = tid; i < n; i += 1024) {
-        int64_t k = keyc(i);
-        if (k >= 0) bits[P + k] = 0u;
+    int32_t* l_item = reinterpret_cast<int32_t*>(l_a);          // [LCAP] item numbers of this workgroup's keys
+    int32_t* l_leaf = reinterpret_cast<int32_t*>(l_a) + LCAP;   // [LCAP] their leaves
+    int32_t* l_win = reinterpret_cast<int32_t*>(l_b);           // [TOPN] leaves of this round's winners (block recompute)
+    if (tid == 0) {
+        l_cnt = 0;
+        l_nw = 0;
     }
     __syncthreads();
-    for (int64_t i = tid; i < n; i += 1024) {
-        int64_t k = keyc(i);
-        if (k >= 0) atomicMax(&bits[P + k], (uint32_t)(i + 1));
-    }
-    // chunks of MAXR * 1024 items: every item of a chunk reads its verdict before any winner of that chunk
-    // overwrites a tag (a winner is the highest-numbered item of its leaf, so no later chunk reads that leaf)
-    constexpr int MAXR = 8;
-    for (int64_t base = 0; base < n; base += (int64_t)MAXR * 1024) {
-        __syncthreads();
-        bool own[MAXR];
+    const bool small_idx = n_leaves < (1ll << 31) && n < (1ll << 31);
+    // ---- pass 1: this workgroup's share of the key array -> LDS list (order irrelevant: the item number decides) ----
+    // (four keys per thread and trip, every load issued before the first use)
+    for (int64_t base = 0; base < n; base += 4 * NT) {
+        int64_t kk[4];
 #pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
-            int64_t i = base + tid + (int64_t)r * 1024;
-            int64_t k = i < n ? keyc(i) : -1;
-            own[r] = k >= 0 && bits[P + k] == (uint32_t)(i + 1);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + tid + NT * u;
+            kk[u] = i < n ? leaf[i] : -1;
         }
-        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
-            int64_t i = base + tid + (int64_t)r * 1024;
-            if (own[r]) tree[P + leaf[i]] = prio[i];
-        }
-    }
-    // sparse levels 1 .. ltop - 1
-    if (ltop > 2) {
-        for (int64_t i = tid; i < n; i += 1024) {
-            int64_t k = keyc(i);
-            if (k < 0) continue;
-            for (int l = 2; l < ltop; ++l) {  // level 1's pairs are the leaves just written
-                float2 c = *reinterpret_cast<const float2*>(tree + 2 * ((P + k) >> l));
-                asm volatile("" ::"v"(c.x), "v"(c.y));
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + tid + NT * u, k = kk[u];
+            if (k >= 0 && k < n_leaves && (((P + k) >> sl) & gmask) == mine) {
+                const int pos = atomicAdd(&l_cnt, 1);
+                if (pos < LCAP && small_idx) {
+                    l_item[pos] = (int32_t)i;
+                    l_leaf[pos] = (int32_t)k;
+                }
             }
         }
     }
     __syncthreads();
-    for (int l = 1; l < ltop; ++l) {
-        for (int64_t i = tid; i < n; i += 1024) {
-            int64_t k = keyc(i);
+    const int cnt = l_cnt;
+    // one wave recomputes the 2^bl-leaf blocks of up to four leaves: levels 1 .. bl (agent-scope loads: past this CU's L1; the
+    // loads of all four blocks are issued before the first add -- one round trip per four blocks)
+    auto blocks_recompute = [&](const int32_t* list, int first, int count, bool is_block_number) {
+        if (bl < 1) return;
+        const int half = 1 << (bl - 1);  // level-1 nodes of a block (<= 64)
+        int64_t base[4];
+        float cx[4], cy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t kq = u < count ? (int64_t)list[first + u] : 0;
+            const int64_t k = is_block_number ? (kq << bl) : kq;
+            base[u] = P + ((k >> bl) << bl);  // heap position of the block's first leaf
+            cx[u] = cy[u] = 0.0f;
+            if (u < count && lane < half) {
+                cx[u] = __hip_atomic_load(tree + base[u] + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cy[u] = __hip_atomic_load(tree + base[u] + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u >= count) break;
+            float v = cx[u] + cy[u];
+            if (lane < half) tree[(base[u] >> 1) + lane] = v;
+            for (int m = 2; m <= bl; ++m) {
+                const int stride = 1 << (m - 1);
+                const float right = __shfl_down(v, stride >> 1, 64);
+                v = v + right;  // left + right; meaningful in lanes that are multiples of `stride`
+                if (lane < half && (lane & (stride - 1)) == 0) tree[(base[u] >> m) + (lane >> (m - 1))] = v;
+            }
+        }
+    };
+    auto recompute_list = [&](const int32_t* list, int nw, bool is_block_number) {
+        // wave w takes entries 4 (w + NWV j) .. + 3
+        for (int e = 4 * wv; e < nw; e += 4 * NWV) blocks_recompute(list, e, min(4, nw - e), is_block_number);
+    };
+    if (cnt <= LCAP && small_idx) {
+        // ---- election in LDS: entry e wins its leaf iff no other entry of the same leaf has a larger item number ----
+        for (int e = tid; e < cnt; e += NT) {
+            const int32_t k = l_leaf[e], it = l_item[e];
+            bool win = true;
+            for (int q = 0; q < cnt; ++q) win = win && !(l_leaf[q] == k && l_item[q] > it);
+            if (win) {
+                tree[P + k] = prio[it];
+                l_win[atomicAdd(&l_nw, 1)] = k;  // cnt <= LCAP = TOPN entries
+            }
+        }
+        __syncthreads();  // the leaves are written (workgroup scope; the block loads below bypass the L1)
+        recompute_list(l_win, l_nw, false);
+    } else {
+        // ---- fallback (a share above LCAP items): election on the leaf tags, rounds of MAXR * 1024 items ----
+        for (int64_t i = tid; i < n; i += NT) {
+            const int64_t k = key(i);
+            if (k >= 0) bits[P + k] = 0u;
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += NT) {
+            const int64_t k = key(i);
+            if (k >= 0) atomicMax(&bits[P + k], (uint32_t)(i + 1));
+        }
+        // every item of a round reads its verdict before any winner of that round overwrites a tag (a winner is the
+        // highest-numbered item of its leaf, so no later round reads that leaf)
+        constexpr int MAXR = 4;
+        for (int64_t base = 0; base < n; base += (int64_t)MAXR * NT) {
+            __syncthreads();
+            if (tid == 0) l_nw = 0;
+            bool own[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int64_t i = base + tid + (int64_t)r * NT;
+                const int64_t k = i < n ? key(i) : -1;
+                own[r] = k >= 0 && bits[P + k] == (uint32_t)(i + 1);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int64_t i = base + tid + (int64_t)r * NT;
+                if (own[r]) {
+                    tree[P + leaf[i]] = prio[i];
+                    l_win[atomicAdd(&l_nw, 1)] = (int32_t)(leaf[i] >> bl);  // block number (fits: P >> bl <= 2^31 for P <= 2^38)
+                }
+            }
+            __syncthreads();
+            recompute_list(l_win, l_nw, true);
+        }
+    }
+    __syncthreads();
+    // sparse levels above the blocks (trees with more than 2^20 leaves): one dependent round trip per level
+    for (int l = bl + 1; l <= sl; ++l) {
+        for (int64_t i = tid; i < n; i += NT) {
+            const int64_t k = key(i);
             if (k < 0) continue;
-            int64_t node = (P + k) >> l;
-            // agent-scope loads: past the L1, which may hold the line from the touch pass above
-            float cx = __hip_atomic_load(tree + 2 * node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float cy = __hip_atomic_load(tree + 2 * node + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t node = (P + k) >> l;
+            const float cx = __hip_atomic_load(tree + 2 * node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float cy = __hip_atomic_load(tree + 2 * node + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tree[node] = cx + cy;  // duplicates write the same value
         }
         __syncthreads();
@@ -172,17 +250,30 @@ __global__ __launch_bounds__(1024) void sumtree_update_kernel(float* tree, int64
         if (!l_last) return;
     }
     {
-        __syncthreads();  // l_keys (aliasing l_a) is dead from here
+        __syncthreads();  // the lists (aliasing l_a / l_b) are dead from here
         // children of level ltop: level ltop - 1, nodes [P >> (ltop - 1), 2 * that)
         const int64_t cfirst = P >> (ltop - 1), cn = P >> (ltop - 1);
-        for (int64_t q = tid; q < cn; q += 1024)
+        for (int64_t q = tid; q < cn; q += NT)
             l_a[q] = __hip_atomic_load(tree + cfirst + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         int64_t m = cn >> 1;  // nodes on level ltop
         float* src = l_a;
         float* dst = l_b;
         for (int l = ltop; l <= logP; ++l) {
-            for (int64_t q = tid; q < m; q += 1024) {
+            if (m == 64) {
+                // the last seven levels (64 .. 1 nodes) in ONE wave: shuffle-adds instead of six more barrier + LDS rounds
+                if (wv == 0) {
+                    float v = src[2 * lane] + src[2 * lane + 1];
+                    tree[(P >> l) + lane] = v;
+                    for (int st = 1, ll = l + 1; st < 64; st <<= 1, ++ll) {
+                        const float right = __shfl_down(v, st, 64);
+                        v = v + right;  // left + right; meaningful in lanes that are multiples of 2 st
+                        if ((lane & (2 * st - 1)) == 0) tree[(P >> ll) + (lane >> (ll - l))] = v;
+                    }
+                }
+                break;
+            }
+            for (int64_t q = tid; q < m; q += NT) {
                 const float v = src[2 * q] + src[2 * q + 1];
                 dst[q] = v;
                 tree[(P >> l) + q] = v;
@@ -285,8 +376,15 @@ int32_t rlhip_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf,
     const int64_t P = pow2_ge(n_leaves);
     const int logP = log2_of(P);
     // several workgroups only when there are sparse levels to split (P > 8192) and enough keys to pay for it
-    const int groups = (logP <= 13 || n < 1024) ? 1 : (n < 16384 ? 64 : 256);
-    hipLaunchKernelGGL(sumtree_update_kernel, dim3(groups), dim3(1024), 0, as_stream(stream), tree, P, logP, n_leaves, leaf,
+    // several workgroups whenever there are sparse levels to split (P > 8192): a workgroup's 16 waves recompute its winners'
+    // blocks one after the other (a dependent load -> stores chain each), so the share per workgroup should stay near 16
+    // (measured for 4096 keys on a 2^20-leaf tree: 16 / 32 / 64 / 128 / 256 workgroups = 44.9 / 30.7 / 22.8 / 17.2 / 17.9 us:
+    // the per-workgroup work decides, not the 256 same-address arrival atomics; tools/sumtree_update_time.py)
+    const int groups = logP <= 13 ? 1 : (n < 64 ? 32 : (n < 2048 ? 128 : 256));
+    // 1024 threads (us per update of 32 / 512 / 4096 / 65536 keys: 1024 threads 10.2 / 12.2 / 18.2 / 63.9, 512: 11.5 / 14.2 /
+    // 20.2 / 85.0, 256: 14.3 / 18.3 / 27.6 / 152 -- the top of the tree wants the threads)
+    const int nt = 1024;
+    hipLaunchKernelGGL(sumtree_update_kernel, dim3(groups), dim3(nt), 0, as_stream(stream), tree, P, logP, n_leaves, leaf,
                        prio, n);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;

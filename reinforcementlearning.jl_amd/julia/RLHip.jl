@@ -804,6 +804,13 @@ sample_prioritized!(idx::DevBuf{Int64}, key::DevBuf{Int64}, prio::DevBuf{Float32
     chk(ccall((:rlhip_ring_sample_prioritized, LIB), Int32,
               (Ref{Ring}, Ptr{Cvoid}, Int64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
               t.rb, tree.ptr, batch, seed, ctr, idx.ptr, key.ptr, prio.ptr, stream()))
+"the same draw AND the gather of its batch in one launch (outputs as `sample_prioritized!` + the ring gather)"
+sample_gather_prioritized!(idx::DevBuf{Int64}, key::DevBuf{Int64}, prio::DevBuf{Float32}, t::HipTrajectory, tree, batch, seed,
+                           ctr, s, a, r, term, s_next) =
+    chk(ccall((:rlhip_ring_sample_gather_prioritized, LIB), Int32,
+              (Ref{Ring}, Ptr{Cvoid}, Int64, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+               Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, tree.ptr, batch, seed, ctr, idx.ptr, key.ptr, prio.ptr, s.ptr, a.ptr, r.ptr, term.ptr, s_next.ptr, stream()))
 "priority write-back value (|td| + eps)^alpha of PrioritizedDQN"
 per_priority!(out::DevBuf{Float32}, td::DevBuf{Float32}, eps::Float32, alpha::Float32) =
     chk(ccall((:rlhip_per_priority_f32, LIB), Int32, (Ptr{Cvoid}, Int64, Float32, Float32, Ptr{Cvoid}, Ptr{Cvoid}),

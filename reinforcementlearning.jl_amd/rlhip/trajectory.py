@@ -129,6 +129,23 @@ class CircularPrioritizedTraces(CircularArraySARTSTraces):
              ptr(idx), ptr(key), ptr(prio), stream_ptr())
         return idx, key, prio
 
+    def sample_gather_prioritized(self, batch, seed, draw_ctr):
+        """the prioritized draw and the gather of its batch in ONE launch (bit-identical to sample_prioritized + gather)
+        -> (idx, key, priority), (state, action0, reward, terminal, next_state)"""
+        dev = self.state.device
+        idx = torch.empty(batch, dtype=torch.int64, device=dev)
+        key = torch.empty(batch, dtype=torch.int64, device=dev)
+        prio = torch.empty(batch, dtype=torch.float32, device=dev)
+        shape = (batch, self.obs_dim) if self.frame_major else (self.obs_dim, batch)
+        s = torch.empty(shape, dtype=self.dtype, device=dev)
+        sn = torch.empty(shape, dtype=self.dtype, device=dev)
+        a = torch.empty(batch, dtype=torch.int32, device=dev)
+        r = torch.empty(batch, dtype=torch.float32, device=dev)
+        t = torch.empty(batch, dtype=torch.uint8, device=dev)
+        call("rlhip_ring_sample_gather_prioritized", C.byref(self.rb), ptr(self.priorities), batch, seed, draw_ctr, ptr(idx),
+             ptr(key), ptr(prio), ptr(s), ptr(a), ptr(r), ptr(t), ptr(sn), stream_ptr())
+        return (idx, key, prio), (s, a, r, t, sn)
+
     def set_priority_(self, keys, prio):
         """trajectory[:priority, keys] = prio  (sequential semantics: the last duplicate key wins)"""
         if keys.dtype != torch.int64 or prio.dtype != torch.float32:
@@ -153,8 +170,9 @@ class BatchSampler:
     def sample(self, traces):
         extra = {}
         if isinstance(traces, CircularPrioritizedTraces):
-            idx, key, prio = traces.sample_prioritized(self.batchsize, self.seed, self.draw_ctr)
-            extra = dict(key=key, priority=prio)
+            (idx, key, prio), (s, a, r, t, sn) = traces.sample_gather_prioritized(self.batchsize, self.seed, self.draw_ctr)
+            self.draw_ctr += 1
+            return dict(state=s, action=a + 1, reward=r, terminal=t.view(torch.bool), next_state=sn, key=key, priority=prio)
         else:
             idx = traces.sample_indices(self.batchsize, self.seed, self.draw_ctr)
             extra = dict(key=idx)

@@ -167,3 +167,71 @@ def test_prioritized_traces_round_trip_vs_oracle():
         st.update(key, newp)
         assert np.array_equal(tr.priorities.cpu().numpy(), st.tree)
     assert abs(tr.total_priority() - float(st.tree[1])) == 0.0
+
+
+@pytest.mark.parametrize("n_leaves,n_upd,spread", [(1 << 20, 4096, "uniform"), (1 << 20, 4096, "one_block"), (1 << 20, 4096, "few_blocks"),
+                                                   (1 << 20, 32, "uniform"), (1 << 20, 512, "uniform"), (1 << 20, 9000, "one_block"),
+                                                   (1 << 22, 4096, "uniform"), ((1 << 21) + 12345, 3000, "few_blocks"),
+                                                   (1 << 14, 2048, "uniform"), (1 << 13, 5000, "uniform")])
+def test_update_block_recompute_paths_bit_exact(n_leaves, n_upd, spread):
+    """round 4 update kernel: election in LDS (a workgroup's share <= 1024 items) and on the leaf tags (above), whole
+    128-leaf blocks recomputed by one wave, the path walk above the blocks for trees beyond 2^20 leaves -- every path
+    against the sequential oracle, bit for bit, on a tree that already holds priorities everywhere"""
+    rng = np.random.default_rng(n_upd + (n_leaves % 1000))
+    ref = oracle.SumTree(n_leaves)
+    tree = _dev_tree(n_leaves)
+    base_k = np.arange(0, n_leaves, max(1, n_leaves // 50000))
+    base_p = rng.random(base_k.size).astype(np.float32)
+    ref.update(base_k, base_p)
+    _update(tree, n_leaves, base_k, base_p)
+    if spread == "uniform":
+        keys = rng.integers(0, n_leaves, n_upd)
+    elif spread == "one_block":  # every key inside one 128-leaf block: ONE workgroup owns all of them, heavy duplication
+        keys = 77 * 128 + rng.integers(0, 128, n_upd)
+    else:  # a handful of blocks, some keys repeated many times
+        keys = rng.choice(rng.integers(0, n_leaves, 40), n_upd) + rng.integers(0, 3, n_upd)
+        keys = np.minimum(keys, n_leaves - 1)
+    prio = (rng.random(n_upd).astype(np.float32) + 0.01) ** 0.6
+    ref.update(keys, prio)
+    _update(tree, n_leaves, keys, prio)
+    assert np.array_equal(tree.cpu().numpy(), ref.tree)
+    _update(tree, n_leaves, keys[::-1].copy(), prio)  # the same keys in the opposite order: other winners
+    ref.update(keys[::-1], prio)
+    assert np.array_equal(tree.cpu().numpy(), ref.tree)
+    assert tree[0].item() == 0.0  # the arrival counter is re-armed
+
+
+@pytest.mark.parametrize("layout", ["frames_u8", "cartpole_f32", "wide_f32"])
+def test_fused_sample_gather_equals_the_two_launches(layout):
+    """rlhip_ring_sample_gather_prioritized: indices, keys, priorities and the gathered batch are bit-identical to
+    rlhip_ring_sample_prioritized + rlhip_ring_gather (frame-major u8 ring, Float32 ring with 4 components = the fused
+    kernels; 6 components = the documented two-launch route behind the same entry point)"""
+    import rlhip
+
+    if layout == "frames_u8":
+        cap, n_env, od, dt = 300, 1, 84 * 84, torch.uint8
+    elif layout == "cartpole_f32":
+        cap, n_env, od, dt = 64, 37, 4, torch.float32
+    else:
+        cap, n_env, od, dt = 64, 5, 6, torch.float32
+    tr = rlhip.CircularPrioritizedTraces(capacity=cap, n_env=n_env, obs_dim=od, dtype=dt, default_priority=1.0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    if dt == torch.uint8:
+        tr.state.random_(0, 256, generator=g)
+    else:
+        tr.state.normal_(generator=g)
+    tr.action.random_(0, 3, generator=g)
+    tr.reward.normal_(generator=g)
+    tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda", generator=g) < 0.1).to(torch.uint8))
+    tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap
+    tr.rb.head_sa, tr.rb.head_rt = 5, 5  # a wrapped ring
+    n = cap * n_env
+    keys = torch.arange(n, dtype=torch.int64, device="cuda")
+    tr.set_priority_(keys, torch.rand(n, device="cuda", generator=g) ** 0.6 + 0.01)
+    for batch, ctr in ((1, 0), (33, 1), (512, 2), (4096, 3)):
+        idx, key, prio = tr.sample_prioritized(batch, 9, ctr)
+        ref = tr.gather(idx)
+        (idx2, key2, prio2), got = tr.sample_gather_prioritized(batch, 9, ctr)
+        assert torch.equal(idx, idx2) and torch.equal(key, key2) and torch.equal(prio, prio2)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
