@@ -528,6 +528,12 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, in
                             int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
                             uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
                             rlhip_stream_t stream);
+/* the same with importance-sampling weights (rlhip_per_is_weights_f32): loss = mean(weights .* huber(Q(s,a) - y)),
+ * every sample's gradient scaled by its weight; td_out stays the unweighted |Q(s,a) - y| */
+int32_t rlhip_dqn3_grad_w_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act, const float* params,
+                              const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                              int64_t batch, const int64_t* idx, const float* weights, float gamma, float huber_delta,
+                              void* workspace, float* grad_out, float* loss_out, float* td_out, rlhip_stream_t stream);
 /* optimise!(learner, batch) of the 3-layer learner complete, in two launches: the gradient (as rlhip_dqn3_grad_f32
  * with the inline uniform draw), then reduce + clip-by-global-norm + Adam + the bf16 re-pack of W2 in one launch;
  * bit-identical to rlhip_dqn3_grad_f32, rlhip_clip_adam_f32, rlhip_mlp3_pack_bf16 in sequence.  `packed` is updated
@@ -563,6 +569,10 @@ int32_t rlhip_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch,
 /* PrioritizedDQN priority write-back value: out = (|td| + eps)^alpha (power in Float64, rounded once) */
 int32_t rlhip_per_priority_f32(const float* td, int64_t n, float eps, float alpha, float* out,
                                rlhip_stream_t stream);
+/* importance-sampling weights of the sampled batch (PrioritizedDQN, removed Zoo; Schaul et al. 2016):
+ *   w = 1 ./ ((priorities .+ 1f-10) .^ beta);  w ./= maximum(w)      (powers in Float64, rounded once)
+ * -- the N and total-priority factors of (N P(i))^-beta cancel in the normalisation.  PARITY UNPINNED. */
+int32_t rlhip_per_is_weights_f32(const float* prio, int64_t n, float beta, float* w_out, rlhip_stream_t stream);
 /* after rlhip_ring_push_transition: the n_env leaves of the newest transition frame := priority
  * (CircularPrioritizedTraces `default_priority`) */
 int32_t rlhip_ring_push_priority(const rlhip_ring* rb_host, float* tree, float priority,
@@ -752,6 +762,12 @@ int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb_host, int64_t h, int64_t na,
                                const float* params, const float* target_params, int64_t batch,
                                const int64_t* idx, float gamma, float huber_delta, void* workspace,
                                float* grad_out, float* loss_out, float* td_out, rlhip_stream_t stream);
+/* ... and with importance-sampling weights (prioritized replay with beta > 0): loss = mean(weights .* huber) */
+int32_t rlhip_dqn_grad_idx_w_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act,
+                                 const float* params, const float* target_params, int64_t batch,
+                                 const int64_t* idx, const float* weights, float gamma, float huber_delta,
+                                 void* workspace, float* grad_out, float* loss_out, float* td_out,
+                                 rlhip_stream_t stream);
 /* plan!(QBasedPolicy, env) for the vector env in one launch: q = forward(learner, state(env)) then
  * eps-greedy selection (q_based_policy.jl:30-32, abstract_learner.jl:37-39, epsilon_greedy_explorer.jl:108-112).
  * q_out (nullable): SoA (na x n). */

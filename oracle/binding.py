@@ -522,6 +522,13 @@ def per_priority(td, eps, alpha):
     return out
 
 
+def per_is_weights(prio, beta):
+    prio = np.ascontiguousarray(prio, np.float32)
+    out = np.empty_like(prio)
+    lib().rlo_per_is_weights_f32(_p(prio), C.c_int64(prio.size), C.c_float(beta), _p(out))
+    return out
+
+
 def ring_push_priority(ring, st, priority):
     lib().rlo_ring_push_priority(C.byref(ring.rb), _p(st.tree), C.c_float(priority))
 
@@ -611,7 +618,7 @@ def ppo_loss_grad(cfg, ns, na, params, obs, action, logp_old, adv, ret):
     return grad, losses
 
 
-def dqn_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, gamma, delta=1.0):
+def dqn_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, gamma, delta=1.0, weights=None):
     s = np.ascontiguousarray(s, np.float32)
     s_next = np.ascontiguousarray(s_next, np.float32)
     grad = np.zeros_like(params)
@@ -620,7 +627,8 @@ def dqn_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, 
                                        _p(np.ascontiguousarray(a, np.int32)),
                                        _p(np.ascontiguousarray(r, np.float32)), _p(_u8(term)),
                                        _p(s_next), C.c_int64(s.shape[1]), C.c_float(gamma),
-                                       C.c_float(delta), _p(grad))
+                                       C.c_float(delta), _p(grad),
+                                       _p(None if weights is None else np.ascontiguousarray(weights, np.float32)))
     return float(loss), grad
 
 
@@ -653,7 +661,7 @@ def mlp3_forward(p, ns, h, na, act, x):
     return out
 
 
-def dqn3_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, gamma, delta=1.0):
+def dqn3_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next, gamma, delta=1.0, weights=None):
     s = np.ascontiguousarray(s, np.float32)
     s_next = np.ascontiguousarray(s_next, np.float32)
     params = np.ascontiguousarray(params, np.float32)
@@ -664,7 +672,8 @@ def dqn3_loss_grad(ns, h, na, act, params, target_params, s, a, r, term, s_next,
     f.restype = C.c_float
     loss = f(C.c_int64(ns), C.c_int64(h), C.c_int64(na), C.c_int(act), _p(params), _p(target_params), _p(s),
              _p(np.ascontiguousarray(a, np.int32)), _p(np.ascontiguousarray(r, np.float32)), _p(_u8(term)),
-             _p(s_next), C.c_int64(s.shape[1]), C.c_float(gamma), C.c_float(delta), _p(grad), _p(q))
+             _p(s_next), C.c_int64(s.shape[1]), C.c_float(gamma), C.c_float(delta), _p(grad), _p(q),
+             _p(None if weights is None else np.ascontiguousarray(weights, np.float32)))
     return float(loss), grad, q
 
 

@@ -278,7 +278,7 @@ void rlo_mlp3_backward1(const float* p, int64_t ns, int64_t h, int64_t na, int a
 float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
                              const float* target_params, const float* s, const int32_t* a, const float* r,
                              const uint8_t* term, const float* s_next, int64_t b, float gamma, float huber_delta,
-                             float* grad, float* q_out);
+                             float* grad, float* q_out, const float* isw /* nullable: importance-sampling weights */);
 
 /* ---------------------------------------------------- priority sum-tree -- */
 /* CircularArrayBuffers.SumTree (0.1.12) / RLTrajectories 0.4 prioritized BatchSampler, un-vendored: PARITY
@@ -292,6 +292,9 @@ void rlo_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf, cons
 void rlo_sumtree_sample(const float* tree, int64_t n_leaves, int64_t batch, uint64_t seed, uint32_t draw_ctr,
                         int64_t* leaf_out, float* prio_out);
 void rlo_per_priority_f32(const float* td, int64_t n, float eps, float alpha, float* out);
+/* importance-sampling weights of the sampled batch (removed Zoo PrioritizedDQN, from memory -- PARITY UNPINNED):
+ * w = 1 ./ ((priorities .+ 1f-10) .^ beta); w ./= maximum(w)   (powers in Float64, rounded once) */
+void rlo_per_is_weights_f32(const float* prio, int64_t n, float beta, float* out);
 /* leaf of the newest transition frame gets `priority`; prioritized draw mapped to logical flat indices */
 void rlo_ring_push_priority(const rlo_ring* rb, float* tree, float priority);
 void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t batch, uint64_t seed,
@@ -344,7 +347,8 @@ void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const f
 float rlo_dqn_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
                             const float* target_params, const float* s, const int32_t* a,
                             const float* r, const uint8_t* term, const float* s_next, int64_t b,
-                            float gamma, float huber_delta, float* grad);
+                            float gamma, float huber_delta, float* grad,
+                            const float* isw /* nullable: importance-sampling weights, loss = mean(w .* huber) */);
 
 /* Whole vectorised PPO iteration on the CPU (rollout of T vec-steps with the MultiThreadEnv
  * protocol, GAE, n_epochs x n_microbatches updates).  Used as the cpu_baseline ("port") and

@@ -186,6 +186,15 @@ void rlo_per_priority_f32(const float* td, int64_t n, float eps, float alpha, fl
     }
 }
 
+void rlo_per_is_weights_f32(const float* prio, int64_t n, float beta, float* out) {
+    float mx = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        out[i] = (float)(1.0 / pow((double)(prio[i] + 1e-10f), (double)beta));
+        if (out[i] > mx) mx = out[i];
+    }
+    for (int64_t i = 0; i < n; ++i) out[i] = out[i] / mx;
+}
+
 /* ------------------------------------------------------------- stack-at-sample gather --
  * StackFrames (RLCore/src/utils/stack_frames.jl:11-44) keeps the latest n frames in a CircularArrayBuffer that
  * starts zero-filled (:22-26) and is zero-filled again by reset! (:33-36); the newest frame is the last slice

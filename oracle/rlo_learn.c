@@ -360,7 +360,7 @@ void rlo_ppo_loss_grad_f32(const rlo_ppo_cfg* c, int64_t ns, int64_t na, const f
 float rlo_dqn_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
                             const float* target_params, const float* s, const int32_t* a,
                             const float* r, const uint8_t* term, const float* s_next, int64_t b,
-                            float gamma, float huber_delta, float* grad) {
+                            float gamma, float huber_delta, float* grad, const float* isw) {
     int64_t np = rlo_mlp2_nparams(ns, h, na);
     double* ga = (double*)calloc((size_t)np, sizeof(double));
     float* hid = (float*)malloc(sizeof(float) * (size_t)h * 2);
@@ -378,10 +378,15 @@ float rlo_dqn_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const fl
         float d = q[a[i]] - G;
         float e = fabsf(d);
         float l = (e < huber_delta) ? (e * e) * 0.5f : huber_delta * (e - 0.5f * huber_delta);
-        acc += (double)l;
         float gi = (e < huber_delta) ? d : (d > 0.0f ? huber_delta : (d < 0.0f ? -huber_delta : 0.0f));
+        gi = gi / (float)b;
+        if (isw) { /* PrioritizedDQN: loss = mean(w .* huber(td)); every sample's gradient scaled by its weight */
+            gi *= isw[i];
+            l *= isw[i];
+        }
+        acc += (double)l;
         for (int64_t k = 0; k < na; ++k) dout[k] = 0.0f;
-        dout[a[i]] = gi / (float)b;
+        dout[a[i]] = gi;
         mlp2_backward1(params, ns, h, na, act, s + i, b, dout, 1, ga, hid, zb);
     }
     for (int64_t qq = 0; qq < np; ++qq) grad[qq] = (float)ga[qq];

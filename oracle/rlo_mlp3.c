@@ -143,7 +143,7 @@ void rlo_mlp3_backward1(const float* p, int64_t ns, int64_t h, int64_t na, int a
 float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
                              const float* target_params, const float* s, const int32_t* a, const float* r,
                              const uint8_t* term, const float* s_next, int64_t b, float gamma, float huber_delta,
-                             float* grad, float* q_out) {
+                             float* grad, float* q_out, const float* isw) {
     int64_t np = rlo_mlp3_nparams(ns, h, na);
     double* ga = (double*)calloc((size_t)np, sizeof(double));
     float* buf = (float*)malloc(sizeof(float) * (size_t)h * 5);
@@ -163,10 +163,15 @@ float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const f
         float d = q[a[i]] - G;
         float e = fabsf(d);
         float l = (e < huber_delta) ? (e * e) * 0.5f : huber_delta * (e - 0.5f * huber_delta);
-        acc += (double)l;
         float gi = (e < huber_delta) ? d : (d > 0.0f ? huber_delta : (d < 0.0f ? -huber_delta : 0.0f));
+        gi = gi / (float)b;
+        if (isw) { /* importance-sampling weights of prioritized replay: mean(w .* huber(td)) */
+            gi *= isw[i];
+            l *= isw[i];
+        }
+        acc += (double)l;
         for (int64_t k = 0; k < na; ++k) dout[k] = 0.0f;
-        dout[a[i]] = gi / (float)b;
+        dout[a[i]] = gi;
         rlo_mlp3_backward1(params, ns, h, na, act, s + i, b, dout, ga, buf, buf + h, buf + 2 * h, buf + 3 * h, buf + 4 * h,
                        dh1);
     }

@@ -45,6 +45,7 @@ struct DqnArgs {
     uint32_t draw_ctr;
     const int64_t* idx;  // optional explicit flat logical indices (prioritized sampler); NULL = inline uniform draw
     float* td_out;       // optional |Q(s,a) - y| per sample (priority write-back)
+    const float* isw;    // optional importance-sampling weights per sample (prioritized replay, beta > 0): loss = mean(w .* huber)
 };
 
 // One workgroup = one 64-sample tile (a 512-sample batch is 8 workgroups, so the kernel is a latency chain, not a
@@ -226,6 +227,11 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
             float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
             gi *= g.inv_b;
+            if (valid && g.isw) {  // PrioritizedDQN: the weighted batch loss  mean(w .* huber(td))
+                const float wis = g.isw[(int64_t)tile * DTILE + s];
+                gi *= wis;
+                l *= wis;
+            }
             if (!valid) {
                 gi = 0.f;
                 l = 0.f;
@@ -530,7 +536,8 @@ int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t bat
 static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
                              const float* target_params, int64_t batch, const int64_t* idx, float gamma,
                              float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
-                             float* loss_out, float* td_out, rlhip_stream_t stream, DqnApply* apply = nullptr) {
+                             float* loss_out, float* td_out, rlhip_stream_t stream, DqnApply* apply = nullptr,
+                             const float* isw = nullptr) {
     RLHIP_REQUIRE(rb && params && target_params && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
@@ -566,6 +573,7 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
     g.draw_ctr = draw_ctr;
     g.idx = idx;
     g.td_out = td_out;
+    g.isw = isw;
     int nb = g.num_tiles < DQN_MAX_BLOCKS ? g.num_tiles : DQN_MAX_BLOCKS;
     g.partials = (float*)workspace;
     g.loss_partials = g.partials + (int64_t)DQN_MAX_BLOCKS * np;
@@ -626,6 +634,15 @@ int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb, int64_t h, int64_t na, int3
     RLHIP_REQUIRE(idx != nullptr, "idx is NULL");
     return dqn_grad_impl(rb, h, na, act, params, target_params, batch, idx, gamma, huber_delta, 0, 0, workspace,
                          grad_out, loss_out, td_out, stream);
+}
+
+int32_t rlhip_dqn_grad_idx_w_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                                 const float* target_params, int64_t batch, const int64_t* idx, const float* weights,
+                                 float gamma, float huber_delta, void* workspace, float* grad_out, float* loss_out,
+                                 float* td_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(idx != nullptr && weights != nullptr, "idx / weights is NULL");
+    return dqn_grad_impl(rb, h, na, act, params, target_params, batch, idx, gamma, huber_delta, 0, 0, workspace,
+                         grad_out, loss_out, td_out, stream, nullptr, weights);
 }
 
 int32_t rlhip_dqn_plan_f32(const float* params, int64_t ns, int64_t h, int64_t na, int32_t act, const float* obs,

@@ -253,6 +253,7 @@ struct Dqn3Args {
     float* partials;          // [nb][np]
     float* loss_partials;     // [nb]
     float* td_out;            // optional |Q(s,a) - y| per sample (priority write-back), may be NULL
+    const float* isw;         // optional importance-sampling weights per sample (prioritized replay): loss = mean(w .* huber)
     int na, np;
     int num_tiles;            // dqn3_grad32_kernel: 32-sample tiles of the batch (a workgroup walks several)
     int64_t batch;
@@ -360,6 +361,11 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
         float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
         float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
         gi *= g.inv_b;
+        if (valid && g.isw) {
+            const float wis = g.isw[b];
+            gi *= wis;
+            l *= wis;
+        }
         if (!valid) {
             gi = 0.f;
             l = 0.f;
@@ -607,6 +613,11 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
         float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
         float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
         gi *= g.inv_b;
+        if (valid && g.isw) {
+            const float wis = g.isw[b];
+            gi *= wis;
+            l *= wis;
+        }
         if (!valid) {
             gi = 0.f;
             l = 0.f;
@@ -1043,7 +1054,7 @@ int32_t dqn3w_grad_entry(const rlhip_ring* rb, int64_t na, int32_t act, const fl
                          float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
                          float* loss_out, float* td_out, rlhip_stream_t stream, float* apply_p, uint16_t* apply_packed,
                          float* m, float* v, float* beta_pow, float* gn_out, float grad_scale, float clip_norm, float lr,
-                         float b1, float b2, float eps);
+                         float b1, float b2, float eps, const float* isw);
 
 constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE_ELEMS * sizeof(uint16_t);
 constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
@@ -1146,7 +1157,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
                               const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
                               int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
                               uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
-                              rlhip_stream_t stream, D3Apply* apply) {
+                              rlhip_stream_t stream, D3Apply* apply, const float* isw = nullptr) {
     RLHIP_REQUIRE(rb && params && packed && target_params && target_packed && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
@@ -1162,10 +1173,10 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
             return dqn3w_grad_entry(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta,
                                     seed, draw_ctr, workspace, grad_out, loss_out, td_out, stream, apply->p, apply->packed,
                                     apply->m, apply->v, apply->beta_pow, apply->gn_out, apply->grad_scale, apply->clip_norm,
-                                    apply->lr, apply->b1, apply->b2, apply->eps);
+                                    apply->lr, apply->b1, apply->b2, apply->eps, isw);
         return dqn3w_grad_entry(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, seed,
                                 draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr, nullptr, nullptr, nullptr,
-                                nullptr, nullptr, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+                                nullptr, nullptr, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, isw);
     }
     RLHIP_REQUIRE(batch <= (int64_t)D3_MAX_BLOCKS * TR, "batch too large for one launch");
     const int ns = (int)rb->obs_dim;
@@ -1195,6 +1206,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     g.partials = (float*)workspace;
     g.loss_partials = g.partials + (int64_t)nb * np;
     g.td_out = td_out;
+    g.isw = isw;
     g.na = (int)na;
     g.np = (int)np;
     g.num_tiles = (int)tiles32;
@@ -1269,6 +1281,16 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t
                             rlhip_stream_t stream) {
     return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta,
                           seed, draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr);
+}
+
+/* rlhip_dqn3_grad_f32 with importance-sampling weights: loss = mean(weights .* huber(td)) (prioritized replay, beta > 0) */
+int32_t rlhip_dqn3_grad_w_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t act, const float* params,
+                              const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
+                              int64_t batch, const int64_t* idx, const float* weights, float gamma, float huber_delta,
+                              void* workspace, float* grad_out, float* loss_out, float* td_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(idx != nullptr && weights != nullptr, "idx / weights is NULL");
+    return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, 0, 0,
+                          workspace, grad_out, loss_out, td_out, stream, nullptr, weights);
 }
 
 /* optimise!(learner, batch) of the 3-layer learner in two launches: gradient, then reduce + clip + Adam + bf16

@@ -117,6 +117,7 @@ struct P3WArgs {
     const uint16_t* tpacked;  // DQN: its W2 fragments (W2jk | W2kj)
     float* xg2;              // DQN: [NS][npad] the next observations s'
     float* td_out;           // DQN: optional |Q(s, a) - y| per sample (priority write-back)
+    const float* isw;        // DQN: optional importance-sampling weights per sample (prioritized replay): mean(w .* huber)
     float gamma, delta;      // DQN: discount, Huber threshold
     const float* rec;        // [n T][8] {x0..x3, old log-prob, advantage, return, action}: ppo3w_update's record copy, or NULL
     float* xg;               // [NS][npad] the micro-batch's observations in sample order (ppo3w_gather_kernel), npad = ntiles RW
@@ -603,6 +604,11 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
                 float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
                 gi *= g.inv_b;
+                if (valid && g.isw) {
+                    const float wis = g.isw[(int64_t)tile * RW + s];
+                    gi *= wis;
+                    l *= wis;
+                }
                 if (!valid) {
                     gi = 0.f;
                     l = 0.f;
@@ -2059,7 +2065,7 @@ struct D3WApply {
 int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* params, const uint16_t* packed,
                    const float* target_params, const uint16_t* target_packed, int64_t batch, const int64_t* idx, float gamma,
                    float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,
-                   float* td_out, rlhip_stream_t stream, const D3WApply* apply) {
+                   float* td_out, rlhip_stream_t stream, const D3WApply* apply, const float* isw = nullptr) {
     const int ns = (int)rb->obs_dim;
     RLHIP_REQUIRE(batch <= (int64_t)P3W_MAX_TILES * RW, "batch too large for one launch");
     const D3WLayout L = d3w_layout(ns, (int)na, batch);
@@ -2092,6 +2098,7 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
     g.partW = (float*)(ws + L.off_partW);
     g.loss_partials = (float*)(ws + L.off_loss);
     g.td_out = td_out;
+    g.isw = isw;
     g.frag_stride = 0;
     const int np = (int)mlp3w_np(ns, na);
     g.np_a = np;  // a single net: every parameter index belongs to "net 0"
@@ -2151,13 +2158,13 @@ int32_t dqn3w_grad_entry(const rlhip_ring* rb, int64_t na, int32_t act, const fl
                          float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out,
                          float* loss_out, float* td_out, rlhip_stream_t stream, float* apply_p, uint16_t* apply_packed,
                          float* m, float* v, float* beta_pow, float* gn_out, float grad_scale, float clip_norm, float lr,
-                         float b1, float b2, float eps) {
+                         float b1, float b2, float eps, const float* isw) {
     if (apply_p == nullptr)
         return dqn3w_grad(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, seed,
-                          draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr);
+                          draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr, isw);
     const D3WApply ap{apply_p, m, v, beta_pow, gn_out, apply_packed, grad_scale, clip_norm, lr, b1, b2, eps};
     return dqn3w_grad(rb, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, seed, draw_ctr,
-                      workspace, grad_out, loss_out, td_out, stream, &ap);
+                      workspace, grad_out, loss_out, td_out, stream, &ap, isw);
 }
 
 }  // namespace rlhip

@@ -307,6 +307,29 @@ __global__ __launch_bounds__(256) void per_priority_kernel(const float* __restri
     out[i] = (alpha == 1.0f) ? x : (float)pow((double)x, (double)alpha);
 }
 
+// Importance-sampling weights of prioritized replay (Schaul et al. 2016; the removed Zoo's PrioritizedDQN, from memory --
+// PARITY UNPINNED like the rest of the prioritized path):  w = 1 ./ ((priorities .+ 1f-10) .^ beta);  w ./= maximum(w).
+// (N and the total priority of the textbook form (N P(i))^-beta cancel in the normalisation by the maximum.)
+// One workgroup: the powers in Float64, rounded once; the maximum over the batch behind one barrier.
+__global__ __launch_bounds__(1024) void per_is_weights_kernel(const float* __restrict__ prio, int64_t n, float beta,
+                                                              float* __restrict__ out) {
+    __shared__ float l_m[16];
+    float mx = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float w = (float)(1.0 / pow((double)(prio[i] + 1e-10f), (double)beta));
+        out[i] = w;
+        mx = fmaxf(mx, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) l_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = l_m[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, l_m[w]);
+    for (int64_t i = threadIdx.x; i < n; i += 1024) out[i] = out[i] / mx;  // each thread re-reads what it wrote itself
+}
+
 struct RingGeom {
     int64_t capacity, n_env, head_rt;
 };
@@ -410,6 +433,15 @@ int32_t rlhip_per_priority_f32(const float* td, int64_t n, float eps, float alph
     RLHIP_REQUIRE(td && out, "NULL array");
     hipLaunchKernelGGL(per_priority_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream), td, n, eps,
                        alpha, out);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_per_is_weights_f32(const float* prio, int64_t n, float beta, float* w_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(n >= 0 && beta >= 0.0f, "bad arguments");
+    if (n == 0) return RLHIP_OK;
+    RLHIP_REQUIRE(prio && w_out, "NULL array");
+    hipLaunchKernelGGL(per_is_weights_kernel, dim3(1), dim3(1024), 0, as_stream(stream), prio, n, beta, w_out);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

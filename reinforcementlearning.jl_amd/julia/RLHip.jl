@@ -815,6 +815,28 @@ sample_gather_prioritized!(idx::DevBuf{Int64}, key::DevBuf{Int64}, prio::DevBuf{
 per_priority!(out::DevBuf{Float32}, td::DevBuf{Float32}, eps::Float32, alpha::Float32) =
     chk(ccall((:rlhip_per_priority_f32, LIB), Int32, (Ptr{Cvoid}, Int64, Float32, Float32, Ptr{Cvoid}, Ptr{Cvoid}),
               td.ptr, td.n, eps, alpha, out.ptr, stream()))
+"importance-sampling weights of the sampled batch: w = 1 ./ ((priority .+ 1f-10) .^ β); w ./= maximum(w)  (PrioritizedDQN)"
+is_weights!(w::DevBuf{Float32}, prio::DevBuf{Float32}, β::Float32) =
+    chk(ccall((:rlhip_per_is_weights_f32, LIB), Int32, (Ptr{Cvoid}, Int64, Float32, Ptr{Cvoid}, Ptr{Cvoid}),
+              prio.ptr, prio.n, β, w.ptr, stream()))
+"the DQN gradient on explicit indices with importance-sampling weights: loss = mean(w .* huber(td)) (2-layer Q-network)"
+dqn_grad_weighted!(t::HipTrajectory, h, na, act, params::DevBuf{Float32}, target::DevBuf{Float32}, batch, idx::DevBuf{Int64},
+                   w::DevBuf{Float32}, γ::Float32, δ::Float32, workspace, grad::DevBuf{Float32}, loss::DevBuf{Float32},
+                   td::DevBuf{Float32}) =
+    chk(ccall((:rlhip_dqn_grad_idx_w_f32, LIB), Int32,
+              (Ref{Ring}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Ptr{Cvoid},
+               Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, h, na, act, params.ptr, target.ptr, batch, idx.ptr, w.ptr, γ, δ, workspace.ptr, grad.ptr, loss.ptr, td.ptr,
+              stream()))
+"the same for the 3-layer (bf16 MFMA) Q-network"
+dqn3_grad_weighted!(t::HipTrajectory, h, na, act, params::DevBuf{Float32}, packed::DevBuf{UInt16}, target::DevBuf{Float32},
+                    tpacked::DevBuf{UInt16}, batch, idx::DevBuf{Int64}, w::DevBuf{Float32}, γ::Float32, δ::Float32, workspace,
+                    grad::DevBuf{Float32}, loss::DevBuf{Float32}, td::DevBuf{Float32}) =
+    chk(ccall((:rlhip_dqn3_grad_w_f32, LIB), Int32,
+              (Ref{Ring}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float32,
+               Float32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, h, na, act, params.ptr, packed.ptr, target.ptr, tpacked.ptr, batch, idx.ptr, w.ptr, γ, δ, workspace.ptr, grad.ptr,
+              loss.ptr, td.ptr, stream()))
 "trajectory[:priority, keys] = p   (0-based physical leaf keys from the sampler)"
 set_priority!(tree::DevBuf{Float32}, n_leaves, key::DevBuf{Int64}, p::DevBuf{Float32}, n) =
     chk(ccall((:rlhip_sumtree_update, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),

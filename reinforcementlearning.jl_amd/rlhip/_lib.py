@@ -175,6 +175,7 @@ _PROTOS = {
     "rlhip_dqn3_workspace_bytes": (i64, [i64, i64, i64, i64]),
     "rlhip_dqn3_grad_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, f32, f32, u64, u32, vp, vp, vp,
                                   vp, vp]),
+    "rlhip_dqn3_grad_w_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
     "rlhip_dqn_vec_step_f32": (i32, [vp, vp]),
     "rlhip_p2p_alloc": (i32, [i64, P(vp)]),
     "rlhip_p2p_free": (i32, [vp]),
@@ -212,6 +213,7 @@ _PROTOS = {
     "rlhip_sumtree_update": (i32, [vp, i64, vp, vp, i64, vp]),
     "rlhip_sumtree_sample": (i32, [vp, i64, i64, u64, u32, vp, vp, vp]),
     "rlhip_per_priority_f32": (i32, [vp, i64, f32, f32, vp, vp]),
+    "rlhip_per_is_weights_f32": (i32, [vp, i64, f32, vp, vp]),
     "rlhip_ring_push_priority": (i32, [P(Ring), vp, f32, vp]),
     "rlhip_ring_sample_prioritized": (i32, [P(Ring), vp, i64, u64, u32, vp, vp, vp, vp]),
     "rlhip_ring_sample_gather_prioritized": (i32, [P(Ring), vp, i64, u64, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -255,6 +257,7 @@ _PROTOS = {
     "rlhip_dqn_update_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, i64, f32, f32, u64, u32, vp, vp, vp, vp, vp, vp,
                                    f32, f32, f32, f32, f32, f32, vp, vp]),
     "rlhip_dqn_grad_idx_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp, vp]),
+    "rlhip_dqn_grad_idx_w_f32": (i32, [P(Ring), i64, i64, i32, vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
     "rlhip_dqn_plan_f32": (i32, [vp, i64, i64, i64, i32, vp, i64, f64, u64, u32, u32, vp, vp, vp]),
 }
 

@@ -229,14 +229,15 @@ class DQNLearner:
     `for batch in trajectory` may yield several to catch up after a warm-up; a vec-step already inserts
     n_env transitions at once).
 
-    Prioritized replay (CircularPrioritizedTraces): batches are drawn in proportion to the stored priorities
-    and (|td| + per_eps)^per_alpha is written back, WITHOUT importance-sampling weights in the loss
-    (beta = 0 in the PER paper's notation): the update is the proportional-sampling variant, not
-    annealed-IS PrioritizedDQN."""
+    Prioritized replay (CircularPrioritizedTraces): batches are drawn in proportion to the stored priorities,
+    (|td| + per_eps)^per_alpha is written back, and -- round 4 -- the loss carries the importance-sampling weights
+    of PrioritizedDQN when `per_beta > 0`: w = 1 ./ ((priority .+ 1f-10) .^ beta), w ./= maximum(w),
+    loss = mean(w .* huber(td)) (`per_beta` may be a callable n_updates -> beta for the usual annealing towards 1;
+    per_beta = 0, the default, is the proportional-sampling variant without weights)."""
 
     def __init__(self, approximator, batchsize=32, gamma=0.99, huber_delta=1.0, min_replay_history=100,
-                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None, per_eps=1e-6, per_alpha=0.6):
-        self.per_eps, self.per_alpha = float(per_eps), float(per_alpha)
+                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None, per_eps=1e-6, per_alpha=0.6, per_beta=0.0):
+        self.per_eps, self.per_alpha, self.per_beta = float(per_eps), float(per_alpha), per_beta
         self.approximator = approximator  # a TargetNetwork
         net = approximator.network
         self.batchsize, self.gamma, self.delta = batchsize, gamma, huber_delta
@@ -252,6 +253,7 @@ class DQNLearner:
         self.workspace = ws(net.n_in, net.hidden, net.n_out, batchsize, net.params.device)
         dev = net.params.device
         self.td = torch.zeros(batchsize, dtype=torch.float32, device=dev)
+        self.is_weights = torch.ones(batchsize, dtype=torch.float32, device=dev)
         self._idx = self._key = self._prio = None
 
     def forward(self, x):
@@ -272,22 +274,38 @@ class DQNLearner:
             return False
         net = self.approximator.network
         prioritized = hasattr(traces, "sample_prioritized")
+        beta = 0.0
+        if prioritized:
+            beta = float(self.per_beta(self.n_updates)) if callable(self.per_beta) else float(self.per_beta)
         if net.layers == 3:
             idx = None
             if prioritized:  # prioritized BatchSampler: keys + priorities from the device sum-tree
                 idx, self._key, self._prio = traces.sample_prioritized(self.batchsize, self.seed, self.draw_ctr)
-            dqn3_grad(traces, net.hidden, net.n_out, net.act, net.params, net.packed, self.approximator.target,
-                      self.approximator.target_packed, self.batchsize, self.gamma, self.delta, self.seed,
-                      self.draw_ctr, idx, self.workspace, self.grad, self.loss, self.td)
+            if prioritized and beta > 0.0:
+                call("rlhip_per_is_weights_f32", ptr(self._prio), self.batchsize, beta, ptr(self.is_weights), stream_ptr())
+                call("rlhip_dqn3_grad_w_f32", C.byref(traces.rb), net.hidden, net.n_out, net.act, ptr(net.params), ptr(net.packed),
+                     ptr(self.approximator.target), ptr(self.approximator.target_packed), self.batchsize, ptr(idx),
+                     ptr(self.is_weights), self.gamma, self.delta, ptr(self.workspace), ptr(self.grad), ptr(self.loss),
+                     ptr(self.td), stream_ptr())
+            else:
+                dqn3_grad(traces, net.hidden, net.n_out, net.act, net.params, net.packed, self.approximator.target,
+                          self.approximator.target_packed, self.batchsize, self.gamma, self.delta, self.seed,
+                          self.draw_ctr, idx, self.workspace, self.grad, self.loss, self.td)
             if prioritized:  # trajectory[:priority, keys] = (|td| + eps)^alpha  (PrioritizedDQN write-back)
                 call("rlhip_per_priority_f32", ptr(self.td), self.batchsize, self.per_eps, self.per_alpha,
                      ptr(self.td), stream_ptr())
                 traces.set_priority_(self._key, self.td)
         elif prioritized:
             idx, self._key, self._prio = traces.sample_prioritized(self.batchsize, self.seed, self.draw_ctr)
-            call("rlhip_dqn_grad_idx_f32", C.byref(traces.rb), net.hidden, net.n_out, net.act, ptr(net.params),
-                 ptr(self.approximator.target), self.batchsize, ptr(idx), self.gamma, self.delta, ptr(self.workspace),
-                 ptr(self.grad), ptr(self.loss), ptr(self.td), stream_ptr())
+            if beta > 0.0:
+                call("rlhip_per_is_weights_f32", ptr(self._prio), self.batchsize, beta, ptr(self.is_weights), stream_ptr())
+                call("rlhip_dqn_grad_idx_w_f32", C.byref(traces.rb), net.hidden, net.n_out, net.act, ptr(net.params),
+                     ptr(self.approximator.target), self.batchsize, ptr(idx), ptr(self.is_weights), self.gamma, self.delta,
+                     ptr(self.workspace), ptr(self.grad), ptr(self.loss), ptr(self.td), stream_ptr())
+            else:
+                call("rlhip_dqn_grad_idx_f32", C.byref(traces.rb), net.hidden, net.n_out, net.act, ptr(net.params),
+                     ptr(self.approximator.target), self.batchsize, ptr(idx), self.gamma, self.delta, ptr(self.workspace),
+                     ptr(self.grad), ptr(self.loss), ptr(self.td), stream_ptr())
             call("rlhip_per_priority_f32", ptr(self.td), self.batchsize, self.per_eps, self.per_alpha, ptr(self.td),
                  stream_ptr())
             traces.set_priority_(self._key, self.td)

@@ -235,3 +235,86 @@ def test_fused_sample_gather_equals_the_two_launches(layout):
         assert torch.equal(idx, idx2) and torch.equal(key, key2) and torch.equal(prio, prio2)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+def test_is_weights_bit_exact_and_weighted_gradients_match_oracle():
+    """rlhip_per_is_weights_f32 against the oracle (bit-exact: Float64 power, rounded once, one division), and the three DQN
+    gradient paths with weights -- 2-layer (rlhip_dqn_grad_idx_w_f32), 3-layer h = 128 and h = 256 (rlhip_dqn3_grad_w_f32)
+    -- against oracle.dqn*_loss_grad(weights = w): same bars as the unweighted cases; weights of 1 reproduce the unweighted
+    entry points bit for bit"""
+    import ctypes as C
+
+    import rlhip
+    from conftest import BF16_GRAD_TOL, F32_GRAD_TOL, assert_grad_close
+    from rlhip import dqn
+    from rlhip._lib import call
+    from rlhip.ops import ptr, stream_ptr
+
+    rng = np.random.default_rng(12)
+    for n in (1, 32, 1000, 4096, 70000):
+        prio = ((rng.random(n).astype(np.float32) + 1e-4) ** 0.6).astype(np.float32)
+        for beta in (0.0, 0.4, 1.0):
+            w, prio_d = torch.empty(n, device="cuda"), torch.as_tensor(prio, device="cuda")
+            call("rlhip_per_is_weights_f32", ptr(prio_d), n, beta, ptr(w), stream_ptr())
+            assert np.array_equal(w.cpu().numpy(), oracle.per_is_weights(prio, beta)), (n, beta)
+    ns, na, n_env, cap, batch = 4, 2, 64, 40, 1000
+    traces = rlhip.CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=ns)
+    oring = oracle.Ring(cap, n_env, ns)
+    obs = rng.standard_normal((ns, n_env)).astype(np.float32)
+    traces.push_state_(torch.as_tensor(obs, device="cuda"))
+    oring.push_state(obs)
+    for _ in range(57):
+        nobs = rng.standard_normal((ns, n_env)).astype(np.float32)
+        a = rng.integers(0, na, n_env).astype(np.int32)
+        r = (rng.standard_normal(n_env) * 2).astype(np.float32)
+        term = (rng.random(n_env) < 0.2).astype(np.uint8)
+        traces.push_transition_(torch.as_tensor(nobs, device="cuda"), torch.as_tensor(a, device="cuda"),
+                                torch.as_tensor(r, device="cuda"), torch.as_tensor(term, device="cuda"))
+        oring.push_transition(nobs, a, r, term)
+    idx = oring.sample_indices(batch, 7, 3)
+    s, a, r, t, sn = oring.gather(idx)
+    idx_d = torch.as_tensor(idx, device="cuda")
+    w = oracle.per_is_weights((rng.random(batch).astype(np.float32) + 1e-3) ** 0.6, 0.5)
+    w_d = torch.as_tensor(w, device="cuda")
+    ones = torch.ones(batch, device="cuda")
+    # ---- 2-layer Q-network (f32 VALU path)
+    h = 128
+    p = (rng.standard_normal(oracle.mlp2_nparams(ns, h, na)) * 0.3).astype(np.float32)
+    tp = (p + rng.standard_normal(p.size).astype(np.float32) * 0.1).astype(np.float32)
+    pd, tpd = torch.as_tensor(p, device="cuda"), torch.as_tensor(tp, device="cuda")
+    ws = dqn.dqn_workspace(ns, h, na, batch)
+    g, loss, td = torch.empty_like(pd), torch.empty(1, device="cuda"), torch.empty(batch, device="cuda")
+
+    def grad2(weights):
+        call("rlhip_dqn_grad_idx_w_f32", C.byref(traces.rb), h, na, 0, ptr(pd), ptr(tpd), batch, ptr(idx_d), ptr(weights), 0.99,
+             1.0, ptr(ws), ptr(g), ptr(loss), ptr(td), stream_ptr())
+        return g.cpu().numpy().copy(), float(loss), td.cpu().numpy().copy()
+
+    gw, lw, tdw = grad2(w_d)
+    ol, og = oracle.dqn_loss_grad(ns, h, na, 0, p, tp, s, a, r, t, sn, 0.99, 1.0, weights=w)
+    assert abs(lw - ol) <= 2e-6 * max(1.0, abs(ol))
+    assert_grad_close(gw, og, F32_GRAD_TOL, "weighted dqn_grad h=128")
+    g1, l1, td1 = grad2(ones)
+    call("rlhip_dqn_grad_idx_f32", C.byref(traces.rb), h, na, 0, ptr(pd), ptr(tpd), batch, ptr(idx_d), 0.99, 1.0, ptr(ws), ptr(g),
+         ptr(loss), ptr(td), stream_ptr())
+    assert np.array_equal(g.cpu().numpy(), g1) and float(loss) == l1 and np.array_equal(td.cpu().numpy(), td1)
+    assert np.array_equal(tdw, td1)  # |Q(s, a) - y| is reported unweighted
+    # ---- 3-layer Q-networks on the MFMA: hidden 128 (dqn3.hip, both tile kernels) and 256 (ppo3w.hip)
+    for hh, bb in ((128, 1000), (128, 20000), (256, 1000)):
+        idx3 = oring.sample_indices(bb, 7, 5)
+        s3, a3, r3, t3, sn3 = oring.gather(idx3)
+        w3 = oracle.per_is_weights((rng.random(bb).astype(np.float32) + 1e-3) ** 0.6, 0.5)
+        p3, tp3 = oracle.mlp3_init(ns, hh, na, 11, 0), oracle.mlp3_init(ns, hh, na, 12, 0)
+        p3d, tp3d = torch.as_tensor(p3, device="cuda"), torch.as_tensor(tp3, device="cuda")
+        pk, tpk = dqn.mlp3_pack(p3d, ns, hh, na), dqn.mlp3_pack(tp3d, ns, hh, na)
+        ws3 = dqn.dqn3_workspace(ns, hh, na, bb)
+        g3, td3 = torch.empty_like(p3d), torch.empty(bb, device="cuda")
+        idx3_d, w3_d = torch.as_tensor(idx3, device="cuda"), torch.as_tensor(w3, device="cuda")  # (named: they must outlive the call)
+        call("rlhip_dqn3_grad_w_f32", C.byref(traces.rb), hh, na, 0, ptr(p3d), ptr(pk), ptr(tp3d), ptr(tpk), bb,
+             ptr(idx3_d), ptr(w3_d), 0.99, 1.0, ptr(ws3), ptr(g3), ptr(loss), ptr(td3), stream_ptr())
+        ol3, og3, _ = oracle.dqn3_loss_grad(ns, hh, na, 0, p3, tp3, s3, a3, r3, t3, sn3, 0.99, 1.0, weights=w3)
+        assert abs(float(loss) - ol3) <= 2e-5 * max(1.0, abs(ol3)), (hh, bb)
+        o = 0
+        for name, sz in (("W1", hh * ns), ("b1", hh), ("W2", hh * hh), ("b2", hh), ("W3", na * hh), ("b3", na)):
+            assert_grad_close(g3.cpu().numpy()[o:o + sz], og3[o:o + sz], BF16_GRAD_TOL, f"weighted dqn3 h={hh} b={bb} {name}")
+            o += sz

@@ -162,3 +162,39 @@ def test_gaussian_sampler_statistics_and_permutation():
         p = oracle.permutation(5, 3, n)
         assert np.array_equal(np.sort(p), np.arange(n))
     assert not np.array_equal(oracle.permutation(5, 3, 1000), oracle.permutation(5, 4, 1000))
+
+
+def test_weighted_dqn_loss_and_is_weights_match_torch():
+    """round 4: importance-sampling weights of prioritized replay -- w = 1 / (p + 1e-10)^beta, normalised by the maximum;
+    loss = mean(w .* huber(td)) (removed Zoo PrioritizedDQN, parity unpinned): oracle vs PyTorch autograd"""
+    rng = np.random.default_rng(7)
+    ns, h, na, B = 4, 24, 2, 128
+    p = (rng.standard_normal(oracle.mlp2_nparams(ns, h, na)) * 0.4).astype(np.float32)
+    pt_ = (p + rng.standard_normal(p.size).astype(np.float32) * 0.1).astype(np.float32)
+    s, sn = rng.standard_normal((ns, B)).astype(np.float32), rng.standard_normal((ns, B)).astype(np.float32)
+    a = rng.integers(0, na, B).astype(np.int32)
+    r = (rng.standard_normal(B) * 2).astype(np.float32)
+    t = rng.random(B) < 0.2
+    prio = (rng.random(B).astype(np.float32) + 1e-3) ** 0.6
+    for beta in (0.4, 1.0):
+        w = oracle.per_is_weights(prio, beta)
+        wt = 1.0 / (torch.tensor(prio, dtype=torch.float64) + 1e-10) ** beta
+        wt = (wt / wt.max()).float()
+        np.testing.assert_allclose(w, wt.numpy(), rtol=2e-7, atol=0)
+        assert w.max() == 1.0 and (w > 0).all()
+        loss, g = oracle.dqn_loss_grad(ns, h, na, 0, p, pt_, s, a, r, t, sn, 0.99, 1.0, weights=w)
+        P = torch.tensor(p, requires_grad=True)
+        q = torch_mlp(P, ns, h, na, 0, torch.tensor(s))[torch.tensor(a, dtype=torch.long), torch.arange(B)]
+        with torch.no_grad():
+            qn = torch_mlp(torch.tensor(pt_), ns, h, na, 0, torch.tensor(sn)).max(0).values
+            G = torch.tensor(r) + 0.99 * (1 - torch.tensor(t, dtype=torch.float32)) * qn
+        ref = (torch.tensor(w) * torch.nn.HuberLoss(delta=1.0, reduction="none")(q, G)).mean()
+        ref.backward()
+        assert loss == pytest.approx(ref.item(), rel=1e-5)
+        np.testing.assert_allclose(g, P.grad.numpy(), rtol=1e-3, atol=1e-6)
+    # beta = 0: all weights 1 -> the unweighted loss, bit for bit
+    w0 = oracle.per_is_weights(prio, 0.0)
+    assert np.array_equal(w0, np.ones(B, np.float32))
+    l0, g0 = oracle.dqn_loss_grad(ns, h, na, 0, p, pt_, s, a, r, t, sn, 0.99, 1.0, weights=w0)
+    l1, g1 = oracle.dqn_loss_grad(ns, h, na, 0, p, pt_, s, a, r, t, sn, 0.99, 1.0)
+    assert l0 == l1 and np.array_equal(g0, g1)
