@@ -130,6 +130,22 @@ enum : uint32_t {
 };
 
 // development switches are read from the environment once per process
+// ---- the memory-system contract of the intra-device hand-offs -------------------------------------------------
+// Several kernels hand data between workgroups of ONE device with relaxed agent-scope atomics instead of release / acquire
+// fences: a partial value IS its own arrival flag (8-byte {epoch, payload} granules stored and polled with relaxed agent-scope
+// atomics), or plain stores are drained with `s_waitcnt vmcnt(0)` before a relaxed agent-scope arrival increment and read by
+// the last arriver with relaxed agent-scope loads (reduce_apply_kernel, dqn_reduce_apply_kernel, d3_apply_kernel,
+// clip_adam_grid_kernel, ppo3w_adam_pack_kernel, sumtree_update_kernel keeps its fences).  That is a data race in the HIP /
+// LLVM memory model; it is correct on gfx942 / gfx950 because (i) vector-memory STORES are counted by vmcnt there (no separate
+// store counter as on gfx10+), (ii) agent-scope atomics and sc1 accesses are performed at the device-coherent L2, past the
+// per-CU L1, and (iii) a wave's plain stores are written through to that L2 in program order once vmcnt reaches 0.
+// The library is built for gfx950 only (build.py); this check turns any other target into a compile error instead of a
+// latent race.  Everything that crosses DEVICES (p2p.hip, the APPLY_XCHG exchange, comm.hip) keeps system-scope release /
+// acquire fences and flags -- DESIGN.md section 6 has the table.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "rlhip: the relaxed intra-device hand-off protocols are only valid on gfx942 / gfx950 (see the comment above)"
+#endif
+
 #define RLHIP_ENV_FLAG(name)                          \
     ([]() -> bool {                                   \
         static const bool v_ = []() {                 \
