@@ -936,6 +936,16 @@ def main():
     if getattr(pol, "_hipcomm", None) is not None:
         # must be false: a peer that never arrived poisons the step with NaN (csrc/comm.hip) -- also visible in final_loss
         result["p2p_timeouts"] = bool(pol._hipcomm.failed())
+    if world > 1:
+        # the sharded learner's invariant, checked on the parameters the timed steps produced: every replica applied the
+        # same reduced gradient in the same order, so the parameter vectors are bit-identical (MIN / MAX all-reduce of a
+        # checksum; outside the timed region)
+        try:
+            from rlhip.dist import params_checksum_equal
+
+            result["replicas_bit_identical"] = bool(params_checksum_equal(pol.params, pg))
+        except Exception as exc:  # noqa: BLE001
+            result["replicas_bit_identical"] = repr(exc)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

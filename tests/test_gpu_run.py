@@ -430,6 +430,7 @@ def test_bench_two_ranks_on_one_device_prints_the_contract_line(form):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["value"] > 0
     assert d["metric"] == "env_steps_per_sec" and d["config"]["n_envs_per_gpu"] == 4096
+    assert d["replicas_bit_identical"] is True  # every rank applied the same reduced gradients: same parameters, bit for bit
     ar = d["allreduce"]
     assert "error" not in ar and ar["world"] == 2 and ar["gradient_bytes"] == 3331 * 4
     assert ar["library_us_at_gradient_size"] > 0 and len(ar["library_sweep"]) == 5
