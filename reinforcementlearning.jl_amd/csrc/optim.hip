@@ -473,7 +473,10 @@ int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlh
     RLHIP_REQUIRE(rho >= 0.0f && rho <= 1.0f, "rho must be in [0,1] (AssertionError in the reference, target_network.jl:50)");
     if (n == 0) return RLHIP_OK;
     if (n >= STREAM_MIN_N && aligned16(dst, src)) {
-        const int grid = grid_for(n / 4, 256, 256 * 16);
+        // one 16-byte chunk per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes
+        // 307 us with 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones, Polyak 118 against 120 - 126
+        // (tools/adam_grid_ab.py); the loops in the kernels only serve vectors beyond the grid cap
+        const int grid = grid_for(n / 4, 256, 1 << 20);
         // ordinary stores: 128 us at 2^26 parameters against 154 with non-temporal ones (the opposite of Adam's seven streams)
         hipLaunchKernelGGL((polyak_vec4_kernel<false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     } else
@@ -504,7 +507,10 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
     RLHIP_REQUIRE(params && grad && m && v && beta_pow && n >= 0, "bad arguments");
     hipStream_t s = as_stream(stream);
     if (n >= STREAM_MIN_N && aligned16(params, grad, m, v)) {
-        const int grid = grid_for(n / 4, 256, 256 * 16);
+        // one 16-byte chunk per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes
+        // 307 us with 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones, Polyak 118 against 120 - 126
+        // (tools/adam_grid_ab.py); the loops in the kernels only serve vectors beyond the grid cap
+        const int grid = grid_for(n / 4, 256, 1 << 20);
         // store policy and unroll by A / B on one box (profiles/r04_pmc.md): non-temporal stores + two chunks per lane 375 us at
         // 2^26 parameters against 412 (ordinary stores, one chunk), 413 (non-temporal, one chunk), 436 (ordinary, two chunks)
         hipLaunchKernelGGL((adam_vec4_kernel<true, 2>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
