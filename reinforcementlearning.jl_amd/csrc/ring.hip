@@ -33,11 +33,15 @@ __global__ __launch_bounds__(256) void copy1_kernel(uint8_t* __restrict__ dst, c
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// streaming launches: one 16-byte chunk per thread (a persistent grid-stride loop measured 20 - 40 % slower on the Adam stream
+// at 2^26 parameters, csrc/optim.hip); the loops in the kernels only serve sizes beyond the cap
+constexpr int STREAM_GRID_CAP = 1 << 20;
+
 static int32_t copy_bytes(void* dst, const void* src, int64_t bytes, hipStream_t s) {
     if (bytes == 0) return RLHIP_OK;
     if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes) & 15) == 0) {
         int64_t n16 = bytes / 16;
-        hipLaunchKernelGGL(copy16_kernel, dim3(grid_for(n16, 256)), dim3(256), 0, s, (uint4*)dst,
+        hipLaunchKernelGGL(copy16_kernel, dim3(grid_for(n16, 256, STREAM_GRID_CAP)), dim3(256), 0, s, (uint4*)dst,
                            (const uint4*)src, n16);
     } else {
         hipLaunchKernelGGL(copy1_kernel, dim3(grid_for(bytes, 256)), dim3(256), 0, s, (uint8_t*)dst,
@@ -444,7 +448,7 @@ int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const i
         if (rb->len_sa < sframes) rb->len_sa += 1;
         else rb->head_sa = (rb->head_sa + 1) % sframes;
         const int64_t n16 = fbytes / 16;
-        hipLaunchKernelGGL(push_transition_kernel, dim3(grid_for(n16 > n ? n16 : n, 256)), dim3(256), 0, s, (uint4*)sdst,
+        hipLaunchKernelGGL(push_transition_kernel, dim3(grid_for(n16 > n ? n16 : n, 256, STREAM_GRID_CAP)), dim3(256), 0, s, (uint4*)sdst,
                            (const uint4*)next_obs, n16, rb->action + phys * n, rb->reward + phys * n,
                            rb->terminal + phys * n, action, reward, terminal, n);
         RLHIP_LAUNCH_CHECK();
@@ -568,7 +572,7 @@ static int32_t maxpool_into_next_state_slot(rlhip_ring* rb, const void* s1, cons
         rb->head_sa = (rb->head_sa + 1) % frames;
     }
     const int64_t n16 = fbytes / 16;
-    hipLaunchKernelGGL(maxpool_u8_kernel, dim3(grid_for(n16, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(maxpool_u8_kernel, dim3(grid_for(n16, 256, STREAM_GRID_CAP)), dim3(256), 0, st,
                        (uint4*)((uint8_t*)rb->state + phys * fbytes), (const uint4*)s1, (const uint4*)s2, n16);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
@@ -606,7 +610,7 @@ int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb, const void* screen1, 
         rb->head_sa = (rb->head_sa + 1) % sframes;
     }
     const int64_t n16 = fbytes / 16;
-    const int grid = grid_for(n16 > n ? n16 : n, 256, 256 * 16);
+    const int grid = grid_for(n16 > n ? n16 : n, 256, STREAM_GRID_CAP);
     uint4* sdst = (uint4*)((uint8_t*)rb->state + sphys * fbytes);
     // non-temporal stores for the write-once ring frame: 57.6 us per 4096 x 28 KB push against 65.8 with ordinary stores
     hipLaunchKernelGGL((push_transition_maxpool_kernel<true>), dim3(grid), dim3(256), 0, s, sdst, (const uint4*)screen1,
