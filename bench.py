@@ -109,7 +109,7 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     del env, actions
     torch.cuda.empty_cache()
     traffic, traffic_note = measured_traffic(n_envs)
-    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal,packed>", "n_envs": n_envs,
+    return {"bound": "hbm", "kernel": "env_step_kernel<CartPole,f32,EPL=4,non-temporal in-place arrays / ordinary stores for reward + done,packed>", "n_envs": n_envs,
             "bytes_per_unit": CARTPOLE_STEP_BYTES, "us_per_launch": main["us_per_launch"],
             "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
             # HBM bytes per launch from the PMC counters (separate rocprofv3 passes: FETCH_SIZE x2 gfx950
@@ -122,9 +122,9 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
             "terminated_per_step": round(done_frac, 4), "without_terminations": no_term}
 
 
-# PMC measurement of the env-step kernel (tools/pmc_env.sh + tools/envstep.py; profiles/r03_pmc.md), valid for
+# PMC measurement of the env-step kernel (tools/pmc_env.sh + tools/envstep.py; profiles/r04_pmc.md), valid for
 # the kernel sources whose sha256 (first 16 hex digits over csrc/envs.hip + csrc/env_device.h) is `sha`
-PMC_TRAFFIC = {"sha": "07354178c3f248c4", "n_envs": 1 << 24, "bytes": 822206566.4, "source": "profiles/r03_pmc.md"}
+PMC_TRAFFIC = {"sha": "7aac317ebcd8563e", "n_envs": 1 << 24, "bytes": 822237696.0, "source": "profiles/r04_pmc.md"}
 
 
 def env_kernel_sha():
@@ -568,9 +568,10 @@ def roofline_hbm_side(torch, rlhip):
         torch.cuda.synchronize()
         ms = event_time_ms(step, 20, lib, s)
         out[f"env_step_{kind}"] = entry(nbytes * n / 1e9, ms, n_envs=n, bytes_per_unit=nbytes,
-                                        kernel=f"env_step_kernel<{kind},f32,EPL=4,non-temporal,packed>",
+                                        kernel=f"env_step_kernel<{kind},f32,EPL=4,non-temporal in-place arrays / ordinary stores for the write-only ones,packed>",
                                         env_steps_per_sec=round(n / (ms * 1e-3), 1),
-                                        note=("state(env) = (cos, sin, thetadot) written by the same launch (obs_out)" if with_obs else
+                                        note=("state(env) = (cos, sin, thetadot) written by the same launch (obs_out); three Float64 trig "
+                                              "evaluations per env-step: the VALU work (not the 45 bytes) bounds this launch" if with_obs else
                                               "state(env) IS the state arrays") + "; uniformly random discrete actions")
         del env, actions, obs
         torch.cuda.empty_cache()

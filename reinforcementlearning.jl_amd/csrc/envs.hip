@@ -65,7 +65,10 @@ __device__ __forceinline__ void stv(T* p, int64_t i, const VecN<T, N>& x) {
 // kernel does not stream anyway.  With a separate episode[] every reset is a scattered 4-byte read-modify-write = one
 // 64-byte sector in and out: at the ~4.8 % of CartPole envs that terminate per step under a random policy more than
 // half of all sectors of episode[] are hit, +9 % HBM traffic over the 49 algorithmic bytes (profiles/r01_pmc_env_step.md).
-template <class P, typename T, int EPL, bool NT, bool PK>
+// NTW: the store policy of the arrays that are WRITTEN ONLY (reward, done, the observation planes).  The in-place arrays
+// (state, step counter) keep non-temporal stores when NT (ordinary stores measured slower there, round 3); a pure write
+// stream is better left to the L2 (GAE, gathers: round 3; this kernel: round 4, numbers in step_impl).
+template <class P, typename T, int EPL, bool NT, bool PK, bool NTW = NT>
 __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int64_t n,
                                                        const void* __restrict__ actions,
                                                        int auto_reset, uint64_t seed,
@@ -189,15 +192,15 @@ __global__ __launch_bounds__(256) void env_step_kernel(P p, EnvArrays<T> st, int
             tv.v[j] = (int32_t)((uint32_t)tv.v[j] | (min(epv[j], 0xFFFFFFFFu >> tbits) << tbits));
     }
     stv<int32_t, EPL, NT>(st.t, base, tv);
-    stv<T, EPL, NT>(st.reward, base, rew);
-    stv<uint8_t, EPL, NT>(st.done, base, dn);
+    stv<T, EPL, NTW>(st.reward, base, rew);
+    stv<uint8_t, EPL, NTW>(st.done, base, dn);
     if (last_obs) {
 #pragma unroll
-        for (int k = 0; k < P::ODIM; ++k) stv<T, EPL, NT>(last_obs + (int64_t)k * n, base, lo[k]);
+        for (int k = 0; k < P::ODIM; ++k) stv<T, EPL, NTW>(last_obs + (int64_t)k * n, base, lo[k]);
     }
     if (obs_out) {
 #pragma unroll
-        for (int k = 0; k < P::ODIM; ++k) stv<T, EPL, NT>(obs_out + (int64_t)k * n, base, oo[k]);
+        for (int k = 0; k < P::ODIM; ++k) stv<T, EPL, NTW>(obs_out + (int64_t)k * n, base, oo[k]);
     }
 }
 
@@ -271,8 +274,15 @@ static int32_t step_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st
         int64_t lanes = n / EPL;
         int grid = (int)((lanes + 255) / 256);
         if (streaming) {
-            if (packed) STEP_LAUNCH(EPL, true, true, grid);
-            else STEP_LAUNCH(EPL, true, false, grid);
+            // in-place arrays non-temporal, write-only arrays ORDINARY stores: same-box A / B at 2^24 envs (round 4,
+            // tools/envstep_wo_ab.py): CartPole 139.5 -> 128.6 - 130.4 us (0.735 -> 0.79 - 0.80 of 8 TB/s), MountainCar
+            // 91.6 -> 84.3 us (0.755 -> 0.82); Pendulum + observation planes unchanged (156 us: its Float64 trig binds it)
+            if (packed)
+                hipLaunchKernelGGL((env_step_kernel<P, T, EPL, true, true, false>), dim3(grid), dim3(256), 0, stream, p, a, n,
+                                   actions, auto_reset, seed, env_id_base, (T*)last_obs, (T*)obs_out, tbits);
+            else
+                hipLaunchKernelGGL((env_step_kernel<P, T, EPL, true, false, false>), dim3(grid), dim3(256), 0, stream, p, a, n,
+                                   actions, auto_reset, seed, env_id_base, (T*)last_obs, (T*)obs_out, tbits);
         } else {
             if (packed) STEP_LAUNCH(EPL, false, true, grid);
             else STEP_LAUNCH(EPL, false, false, grid);
