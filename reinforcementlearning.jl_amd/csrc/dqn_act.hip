@@ -7,7 +7,7 @@
 // It calls the same device functions as dqn_plan_wide_kernel (net_forward, eps_greedy_select1), env_step_kernel
 // (env_step1 / env_reset1 / env_obs1) and the ring push (same slots), so every output is bit-identical to the three
 // separate launches -- it only removes two of them and the HBM round trip of the action / observation arrays.
-// L = H / 16 lanes per env instance, weights in registers (as rollout_wide_kernel).
+// L = H / 16 lanes per env instance, weights in registers (as the PPO rollout kernel, ppo.hip).
 #include "env_device.h"
 #include "mlp_device.h"
 #include "select_device.h"

@@ -15,10 +15,12 @@
 //     Flux.Optimise.update! with Adam (flux_approximator.jl:46) -- optim.hip.
 //
 // Kernel design (gfx950):
-//   rollout_wide_kernel   L = h/16 lanes cooperate on one env: each lane owns 16 hidden units of actor
-//                         and critic with their weights in registers for the whole T-step rollout; the
-//                         <= 4 output sums are combined by an xor-butterfly inside the wavefront.
-//                         4096 envs x 16 lanes = 1024 wavefronts = one per SIMD of the chip; no
+//   rollout_split_kernel  L = h/16 lanes cooperate on one env: each lane owns 16 hidden units with their
+//                         weights in registers for the whole T-step rollout; the <= 4 output sums are
+//                         combined by DPP adds inside the wavefront.  Two wavefronts per env group on one
+//                         SIMD: the actor wave runs the dependent chain (actor, selection, env step), the
+//                         critic wave everything else (critic, trajectory stores, sampling noise, GAE).
+//                         4096 envs x 16 lanes x 2 = 2048 wavefronts = two per SIMD of the chip; no
 //                         inter-workgroup communication at all (envs are independent while the weights
 //                         are frozen), so ONE launch covers T vec-steps.
 //   rollout_scalar_kernel one lane per env, hidden units walked with wave-uniform (scalar-loaded)
@@ -54,100 +56,148 @@ __global__ void counters_advance_kernel(uint32_t* ctr, uint32_t d0, uint32_t d1)
 }
 
 // ---------------------------------------------------------------------------------- rollout ----
-// NOA: actor outputs evaluated (2: two actions or (mu, log sigma); MAXO otherwise); the critic has one
-template <class P, int H, int L, int ACT, int NOA>
-__global__ __launch_bounds__(256, 1) void rollout_wide_kernel(P p, EnvArrays<float> st, int64_t n, int T,
-                                                              PolicyDesc pd, const float* __restrict__ params,
-                                                              uint64_t seed, uint32_t env_id_base,
-                                                              uint32_t vec_step0_in, const uint32_t* __restrict__ ctr, TrajPtrs tr,
-                                                              int store_state) {
+// L = h / 16 lanes cooperate on one env (each owns 16 hidden units, weights in registers for the whole rollout), and the work
+// of an env group is split over TWO wavefronts that share a SIMD (512 threads per workgroup: wave w = actor wave, wave w + 4 =
+// critic wave of the same 256 / L envs; the hardware places wave w and w + 4 of a workgroup on one SIMD:
+// tools/micro/wave_simd_map.hip).  Only obs -> actor -> select -> env step -> obs is a dependent chain; a lone wavefront issues
+// it at ~7 cycles per instruction (56 % VALU-active, profiles/r02_summary.md), so everything that is NOT on the chain sits in
+// the second wave and fills the first one's issue gaps:
+//   actor wave : actor forward, action selection, env step (+ auto reset), one 32-byte step record per env into LDS
+//   critic wave: critic forward, ALL trajectory stores, the Gumbel / normal noise of the next 16-step chunk (Philox + Float64
+//                log / sqrt / sin / cos: depends on (env, step) only, one step per lane of the env's group -- same operations
+//                on the same operands as policy_sample), the bootstrap value and the GAE + returns scan
+// One workgroup barrier per vec-step hands the double-buffered step record over (the critic wave trails by one step).
+// Measured (headline rollout, 4096 CartPole envs x T = 32, same box): one wave doing everything 64.0 us -> 60.4 us with the
+// head known at compile time -> 49.4 us split (profiles/r04_rollout.md).
+// NOA: actor outputs evaluated (2: two actions or (mu, log sigma); MAXO otherwise); the critic has one.
+// HEAD: the head known at compile time -- 2 / 3 = categorical over 2 / 3 actions, 1 = one-dimensional Gaussian, 0 = read
+// pd.cont / pd.na at run time.  With the run-time form the selection is three loops over `na` with a compare-and-select
+// chain per register-array access, and both heads' code sits in the step loop; the compile-time form is the same operations
+// on the same operands, unrolled.
+template <class P, int H, int L, int ACT, int NOA, int HEAD>
+__global__ __launch_bounds__(512, 1) void rollout_split_kernel(P p, EnvArrays<float> st, int64_t n, int T,
+                                                               PolicyDesc pd, const float* __restrict__ params,
+                                                               uint64_t seed, uint32_t env_id_base,
+                                                               uint32_t vec_step0_in, const uint32_t* __restrict__ ctr, TrajPtrs tr,
+                                                               int store_state) {
     const uint32_t vec_step0 = vec_step0_in + (ctr ? ctr[0] : 0u);  // device-resident counter (graph replay)
     constexpr int NS = P::ODIM;
     constexpr int HPL = H / L;
-    int64_t gl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t env = gl / L;
-    int sub = (int)(gl % L);
-    bool active = env < n;
-    if (!active) env = n - 1;  // keep the whole wave on valid data (shuffles stay uniform); no stores
-    bool writer = active && sub == 0;
-    uint32_t id = env_id_base + (uint32_t)env;
-
-    NetRegs<NS, HPL> A, C;
-    load_net<NS, HPL>(A, params, H, pd.nout_a, sub, L);
-    load_net<NS, HPL>(C, params + pd.np_a, H, 1, sub, L);
-
-    LaneState<float> e;
-#pragma unroll
-    for (int k = 0; k < P::SDIM; ++k) e.s[k] = st.s[k][env];
-    e.t = st.t[env];
-    e.episode = st.episode[env];
-    float last_r = 0.0f;
-    bool last_d = false;
-
-    // The random part of the action sampling (Gumbel / normal noise: Philox + Float64 log, sqrt, sin / cos -- 4 of the
-    // 5 logarithms of a categorical step) depends on (env, step) only, not on the actor output: it is evaluated NOISE_CH
-    // steps ahead, one step per lane of the env's L-lane group instead of every step on all L lanes, and handed over
-    // through LDS (the group sits inside one wave: in-order LDS access, no barrier).  Same operations on the same
-    // operands as policy_sample: bit-identical actions and log-probabilities.
+    constexpr int EPB = 256 / L;  // envs per workgroup
     constexpr int NOISE_CH = 16;
-    __shared__ double l_noise[256 / L][NOISE_CH][MAXO];
-    double(*my_noise)[MAXO] = l_noise[threadIdx.x / L];
+    const int cont = HEAD == 0 ? pd.cont : (HEAD == 1 ? 1 : 0);
+    const int na = HEAD == 0 ? pd.na : (HEAD == 1 ? 1 : HEAD);
+    if (HEAD != 0) p.continuous = cont;
+    const int role = (int)(threadIdx.x >> 8);  // 0: actor wave, 1: critic wave
+    const int tl = (int)(threadIdx.x & 255);
+    int64_t gl = (int64_t)blockIdx.x * 256 + tl;
+    int64_t env = gl / L;
+    const int sub = (int)(gl % L);
+    const int eg = tl / L;
+    const bool active = env < n;
+    if (!active) env = n - 1;  // keep the whole wave on valid data (shuffles stay uniform); no stores
+    const bool writer = active && sub == 0;
+    const uint32_t id = env_id_base + (uint32_t)env;
 
-    for (int t = 0; t < T; ++t) {
-        if ((t & (NOISE_CH - 1)) == 0) {
-            for (int i = sub; i < NOISE_CH && t + i < T; i += L) {
-                double nz[MAXO] = {0.0, 0.0, 0.0, 0.0};
-                policy_noise(pd.cont, pd.na, seed, id, vec_step0 + (uint32_t)(t + i), nz);
+    __shared__ double l_noise[2][EPB][NOISE_CH][MAXO];  // noise of two 16-step chunks (the critic wave fills the next one)
+    __shared__ float4 l_step[2][EPB][2];                // {x0..x3}, {logp, action bits, reward, terminal} of step t (t & 1)
+
+    if (role == 0) {
+        __builtin_amdgcn_s_setprio(3);  // the chain goes first whenever both waves of the SIMD are ready
+        NetRegs<NS, HPL> A;
+        load_net<NS, HPL>(A, params, H, pd.nout_a, sub, L);
+        LaneState<float> e;
 #pragma unroll
-                for (int k = 0; k < MAXO; ++k) my_noise[i][k] = nz[k];
+        for (int k = 0; k < P::SDIM; ++k) e.s[k] = st.s[k][env];
+        e.t = st.t[env];
+        e.episode = st.episode[env];
+        float last_r = 0.0f;
+        bool last_d = false;
+        __syncthreads();  // the noise of chunk 0
+        for (int t = 0; t < T; ++t) {
+            double nz[MAXO];  // requested before the forward pass, consumed after it
+#pragma unroll
+            for (int k = 0; k < MAXO; ++k) nz[k] = (k < na) ? l_noise[(t / NOISE_CH) & 1][eg][t & (NOISE_CH - 1)][k] : 0.0;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            env_obs1(p, e, x);  // state(env) at PreActStage (post auto-reset)
+            float oa[MAXO];
+            net_forward<NS, HPL, L, ACT, NOA>(A, x, oa);
+            int32_t ai;
+            float af, lp;
+            policy_select(cont, na, oa, nz, ai, af, lp);
+            env_step1(p, e, ai, af, last_r, last_d);
+            if (last_d) env_reset1(p, e, seed, id);  // MultiThreadEnv auto-reset
+            if (sub == 0) {
+                l_step[t & 1][eg][0] = make_float4(x[0], x[1], x[2], x[3]);
+                l_step[t & 1][eg][1] = make_float4(lp, cont ? af : __int_as_float(ai), last_r, last_d ? 1.0f : 0.0f);
+            }
+            __syncthreads();
+        }
+        {
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            env_obs1(p, e, x);
+            if (sub == 0) l_step[T & 1][eg][0] = make_float4(x[0], x[1], x[2], x[3]);
+            __syncthreads();
+        }
+        if (writer && store_state) {
+#pragma unroll
+            for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
+            st.t[env] = e.t;
+            st.episode[env] = e.episode;
+            if (T > 0) {
+                st.reward[env] = last_r;
+                st.done[env] = (uint8_t)last_d;
             }
         }
-        float x[4];
-        env_obs1(p, e, x);  // state(env) at PreActStage (post auto-reset)
-        float oa[MAXO], oc[MAXO];
-        net_forward<NS, HPL, L, ACT, NOA>(A, x, oa);
-        net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
-        int32_t ai;
-        float af, lp;
-        policy_select(pd.cont, pd.na, oa, my_noise[t & (NOISE_CH - 1)], ai, af, lp);
-        if (writer) {
+    } else {
+        NetRegs<NS, HPL> C;
+        load_net<NS, HPL>(C, params + pd.np_a, H, 1, sub, L);
+        // noise of steps [c0, c0 + NOISE_CH): one step per lane of the env's group (same operations as policy_sample)
+        auto fill_noise = [&](int c0) {
+            for (int i = sub; i < NOISE_CH && c0 + i < T; i += L) {
+                double nz[MAXO] = {0.0, 0.0, 0.0, 0.0};
+                policy_noise(cont, na, seed, id, vec_step0 + (uint32_t)(c0 + i), nz);
 #pragma unroll
-            for (int k = 0; k < NS; ++k) tr.obs[((int64_t)t * NS + k) * n + env] = x[k];
-            tr.value[(int64_t)t * n + env] = oc[0];
-            tr.logp[(int64_t)t * n + env] = lp;
-            if (pd.cont) tr.action_f[(int64_t)t * n + env] = af;
-            else tr.action_i[(int64_t)t * n + env] = ai;
-        }
-        env_step1(p, e, ai, af, last_r, last_d);
-        if (last_d) env_reset1(p, e, seed, id);  // MultiThreadEnv auto-reset
-        if (writer) {
-            tr.reward[(int64_t)t * n + env] = last_r;
-            tr.terminal[(int64_t)t * n + env] = (uint8_t)last_d;
-        }
-    }
-    {
-        float x[4], oc[MAXO];
-        env_obs1(p, e, x);
-        net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
-        if (writer) {
+                for (int k = 0; k < MAXO; ++k) l_noise[(c0 / NOISE_CH) & 1][eg][i][k] = nz[k];
+            }
+        };
+        fill_noise(0);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            // the actor wave is in step t, reading chunk t / 16: the other buffer (last read in step t - 1) takes the next chunk
+            if ((t & (NOISE_CH - 1)) == 0 && t + NOISE_CH < T) fill_noise(t + NOISE_CH);
+            __syncthreads();  // step t's record
+            const float4 xv = l_step[t & 1][eg][0];
+            const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+            float oc[MAXO];
+            net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
+            if (writer) {
+                const float4 rec = l_step[t & 1][eg][1];
 #pragma unroll
-            for (int k = 0; k < NS; ++k) tr.obs[((int64_t)T * NS + k) * n + env] = x[k];
-            tr.value[(int64_t)T * n + env] = oc[0];
+                for (int k = 0; k < NS; ++k) tr.obs[((int64_t)t * NS + k) * n + env] = x[k];
+                tr.value[(int64_t)t * n + env] = oc[0];
+                tr.logp[(int64_t)t * n + env] = rec.x;
+                if (cont) tr.action_f[(int64_t)t * n + env] = rec.y;
+                else tr.action_i[(int64_t)t * n + env] = __float_as_int(rec.y);
+                tr.reward[(int64_t)t * n + env] = rec.z;
+                tr.terminal[(int64_t)t * n + env] = (uint8_t)(rec.w != 0.0f);
+            }
         }
-    }
-    // generalized_advantage_estimation + returns for this env, from the values / rewards this lane just wrote
-    // (fuses rlhip_ppo_gae_f32 into the rollout launch; identical arithmetic, see gae_device.h)
-    if (writer && T > 0 && tr.adv && tr.ret)
-        gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, pd.gamma, pd.lambda);
-    if (writer && store_state) {
+        __syncthreads();  // the state after the last step
+        {
+            const float4 xv = l_step[T & 1][eg][0];
+            const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+            float oc[MAXO];
+            net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
+            if (writer) {
 #pragma unroll
-        for (int k = 0; k < P::SDIM; ++k) st.s[k][env] = e.s[k];
-        st.t[env] = e.t;
-        st.episode[env] = e.episode;
-        if (T > 0) {
-            st.reward[env] = last_r;
-            st.done[env] = (uint8_t)last_d;
+                for (int k = 0; k < NS; ++k) tr.obs[((int64_t)T * NS + k) * n + env] = x[k];
+                tr.value[(int64_t)T * n + env] = oc[0];
+            }
         }
+        // generalized_advantage_estimation + returns for this env, from the values / rewards this lane just wrote
+        if (writer && T > 0 && tr.adv && tr.ret)
+            gae_scan_lane(tr.adv, tr.ret, tr.reward, tr.value, tr.terminal, n, T, env, pd.gamma, pd.lambda);
     }
 }
 
@@ -224,19 +274,20 @@ static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state*
     TrajPtrs tr = TrajPtrs::from(*traj);
     // wide variant while the chip is not yet full of one-lane-per-env wavefronts
     bool wide = (pd.h == 256 || pd.h == 128 || pd.h == 64) && n * 16 <= (int64_t)1 << 22;
-#define LAUNCH_WIDE(H, L)                                                                                  \
-    do {                                                                                                   \
-        if (pd.act == 0 && pd.nout_a <= 2)                                                                 \
-            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0, 2>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
-                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
-        else if (pd.act == 0)                                                                              \
-            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 0, MAXO>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
-                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
-        else                                                                                               \
-            hipLaunchKernelGGL((rollout_wide_kernel<P, H, L, 1, MAXO>), dim3((int)((n * L + 255) / 256)), dim3(256), 0, \
-                               s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);      \
+#define LAUNCH_WIDE_AS(H, L, ACT_, NOA_, HEAD_)                                                                  \
+    hipLaunchKernelGGL((rollout_split_kernel<P, H, L, ACT_, NOA_, HEAD_>), dim3((int)((n * L + 255) / 256)), dim3(512), \
+                       0, s, p, a, n, (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1)
+#define LAUNCH_WIDE(H, L)                                                                     \
+    do {                                                                                      \
+        if (pd.act == 0 && !pd.cont && pd.na == 2) LAUNCH_WIDE_AS(H, L, 0, 2, 2);             \
+        else if (pd.act == 0 && pd.cont && pd.na == 1) LAUNCH_WIDE_AS(H, L, 0, 2, 1);         \
+        else if (pd.act == 0 && !pd.cont && pd.na == 3) LAUNCH_WIDE_AS(H, L, 0, MAXO, 3);     \
+        else if (pd.act == 0) LAUNCH_WIDE_AS(H, L, 0, MAXO, 0);                               \
+        else if (!pd.cont && pd.na == 2) LAUNCH_WIDE_AS(H, L, 1, 2, 2);                       \
+        else if (pd.cont && pd.na == 1) LAUNCH_WIDE_AS(H, L, 1, 2, 1);                        \
+        else LAUNCH_WIDE_AS(H, L, 1, MAXO, 0);                                                \
     } while (0)
-    if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);  // 32 lanes per env (8 units each, 2 waves per SIMD) is slower: +70 us
+    if (wide && pd.h == 256) LAUNCH_WIDE(256, 16);  // 32 lanes per env (8 units each; the serial part replicated on twice the lanes) is slower
     else if (wide && pd.h == 128) LAUNCH_WIDE(128, 8);
     else if (wide && pd.h == 64) LAUNCH_WIDE(64, 4);
     else if (pd.act == 0)
@@ -245,6 +296,7 @@ static int32_t rollout_impl(const typename P::cfg_t* cfg, const rlhip_env_state*
     else
         hipLaunchKernelGGL((rollout_scalar_kernel<P, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, a, n,
                            (int)T, pd, params, seed, env_id_base, vec_step0, ctr, tr, 1);
+#undef LAUNCH_WIDE_AS
 #undef LAUNCH_WIDE
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;

@@ -100,6 +100,38 @@ def test_rollout_fused_equals_stepwise_bit_exact(rl, kind, continuous, hidden):
         assert polA.vec_step == polB.vec_step == (it + 1) * T
 
 
+@pytest.mark.parametrize("kind,continuous,hidden,act,n,T", [
+    ("cartpole", False, 256, 0, 37, 40),      # two-action head; two noise-chunk boundaries (16, 32); n not a multiple of 16
+    ("pendulum", False, 64, 1, 130, 33),      # three-action head, tanh, 4 lanes per env (64 envs per workgroup), one step past 32
+    ("mountaincar", False, 128, 0, 16, 49),   # three chunks + one step; exactly half a workgroup of envs
+    ("pendulum", True, 256, 1, 1000, 17),     # Gaussian head, tanh
+    ("cartpole", True, 128, 0, 5, 16),        # Gaussian head on CartPole; T = exactly one chunk; fewer envs than one workgroup
+    ("cartpole", False, 256, 0, 9, 1),        # a single step
+])
+def test_rollout_two_wave_kernel_equals_stepwise_bit_exact(rl, kind, continuous, hidden, act, n, T):
+    """rollout_split_kernel (actor wave + critic wave per env group, step records and sampling noise handed over through LDS,
+    noise produced one 16-step chunk ahead) against the per-step protocol, which shares none of that machinery: every trace,
+    the env state and the fused GAE scan bit for bit, over chunk boundaries, ragged env counts and all head kinds."""
+    envA, polA, _, _ = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden, act=act)
+    envB, polB, _, _ = make_pair(rl, kind, n, T, continuous=continuous, hidden=hidden, act=act)
+    for it in range(3):
+        polA.rollout_()
+        for t in range(T):
+            a = polB.plan_()
+            polB.push_preact_()
+            envB.act_(a)
+            polB.push_postact_()
+        polB.finish_rollout_()
+        polB.gae_()
+        ta, tb = polA.trajectory, polB.trajectory
+        for name in ("obs", "logp", "value", "reward", "terminal", "adv", "ret"):
+            assert torch.equal(getattr(ta, name), getattr(tb, name)), f"{name} differs (period {it})"
+        assert torch.equal(ta.action, tb.action)
+        assert torch.equal(envA.raw_state(), envB.raw_state())
+        assert torch.equal(envA._t, envB._t) and torch.equal(envA._episode, envB._episode)
+        assert torch.equal(envA.reward(), envB.reward()) and torch.equal(envA._done, envB._done)
+
+
 @pytest.mark.parametrize("kind,continuous", [("cartpole", False), ("mountaincar", False), ("pendulum", True)])
 def test_rollout_vs_oracle(rl, kind, continuous):
     """Free-running comparison with the CPU restatement of the whole rollout: integer traces identical,
