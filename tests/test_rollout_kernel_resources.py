@@ -1,0 +1,53 @@
+"""The two-wave PPO rollout (csrc/ppo.hip rollout_split_kernel) is built on three resource facts: 512-thread workgroups whose
+actor wave and critic wave share a SIMD need <= 256 registers per lane; a spilled register in the step loop is a scratch round
+trip per vec-step on the dependent chain; and the step records + two noise chunks must fit one workgroup's LDS.  CPU only:
+hipcc cross-compiles, llvm-readelf reads the kernel descriptors' metadata of the gfx950 code object."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, "reinforcementlearning.jl_amd", "build", "ppo.o")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_meta(obj, tmp):
+    fat, co = os.path.join(tmp, "ppo.fatbin"), os.path.join(tmp, "ppo.co")
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--input={fat}", f"--output={co}"], check=True, capture_output=True)
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for blk in notes.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        num = lambda key: int(re.search(key + r":\s+(\d+)", blk).group(1))  # noqa: E731
+        out[name] = {"agpr": int(re.match(r":\s+(\d+)", blk).group(1)), "vgpr": num(r"\.vgpr_count"),
+                     "vspill": num(r"\.vgpr_spill_count"), "lds": num(r"\.group_segment_fixed_size"),
+                     "scratch": num(r"\.private_segment_fixed_size"), "wg": num(r"\.max_flat_workgroup_size")}
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-readelf"), reason="no llvm-readelf")
+def test_two_wave_rollout_fits_two_waves_per_simd_without_scratch(tmp_path):
+    import __graft_entry__ as g
+
+    g.build()
+    meta = {k: v for k, v in _kernel_meta(OBJ, str(tmp_path)).items() if "rollout_split_kernel" in k}
+    assert len(meta) >= 3 * 3 * 7, f"expected every env x width x head instantiation, found {len(meta)}"
+    bad = []
+    for name, m in meta.items():
+        regs = m["vgpr"] + m["agpr"]
+        relu_known_head = re.search(r"ELi\d+ELi\d+ELi0ELi\dELi[123]E", name) is not None  # ACT = 0, HEAD != 0
+        if m["wg"] != 512:
+            bad.append(f"{name[:90]}: workgroup bound {m['wg']}")
+        if regs > 256:
+            bad.append(f"{name[:90]}: {regs} registers per lane (two waves per SIMD need <= 256)")
+        if m["lds"] > 160 * 1024:
+            bad.append(f"{name[:90]}: {m['lds']} bytes of LDS")
+        if relu_known_head and (m["vspill"] or m["scratch"]):  # the headline family: nothing of the chain in scratch
+            bad.append(f"{name[:90]}: {m['vspill']} spilled VGPRs, {m['scratch']} B of scratch")
+    assert not bad, "\n".join(bad)
+    # no second copy of the wide rollout in the library (the one-wave kernel was removed with the A / B that retired it)
+    assert not [k for k in _kernel_meta(OBJ, str(tmp_path)) if "rollout_wide_kernel" in k]
