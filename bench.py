@@ -329,6 +329,17 @@ def roofline_extras(torch, rlhip):
         "ms_per_vec_step": round(el / steps_f * 1e3, 4),
         "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then the gradient, then reduce + clip + Adam (3 launches per vec-step) -- bit-identical to the per-step protocol"}
     del agent, policy, learner, net, env
+    # the same two loops from a COMPILED host (tests/abi_host/abi_host.c `time`: no PyTorch, no interpreter -- the position of the
+    # Julia glue's ccalls): what the per-stage protocol costs when the host is not Python
+    try:
+        import subprocess
+
+        host = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "abi_host", "abi_host.bin")
+        r = subprocess.run([host, "time", "2000"], capture_output=True, text=True, timeout=120,
+                           env={k: v for k, v in os.environ.items() if not k.startswith("PYTHON")})
+        out["dqn_cartpole_4096env"]["compiled_host"] = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as exc:  # noqa: BLE001  (the C host is test infrastructure: its absence must not cost the bench line)
+        out["dqn_cartpole_4096env"]["compiled_host"] = {"error": repr(exc)[:200]}
     # the other batch sizes BASELINE config 2 names (32, 4096), fused loop, 2- and 3-layer network
     by_batch = {}
     for layers in (2, 3):

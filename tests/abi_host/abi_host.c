@@ -468,6 +468,90 @@ static int run_comm_rank(int rank, int world, const char* dir, int use_rccl) {
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ timing */
+/* `abi_host.bin time [vec_steps]`: what the reference-shaped loop costs from a COMPILED host (the position of the Julia glue:
+ * one ccall per stage of RLCore/src/core/run.jl:52-67), beside the one-call-per-vec-step fast path -- the same 4096-env
+ * CartPole DQN (4 -> 128 -> 2, batch 512, an update every vec-step) both ways, wall clock around the loop + one final sync.
+ * bench.py times the same two loops from Python (ctypes: ~10 us of interpreter per call on top). */
+#include <time.h>
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static int run_time(int steps) {
+    const int64_t n = 4096, h = 128, na = 2, ns = 4, capacity = 256, batch = 512;
+    const uint64_t seed = 9;
+    rlhip_cartpole_cfg cfg;
+    CK(rlhip_cartpole_default(&cfg));
+    const int64_t np = rlhip_mlp2_nparams(ns, h, na);
+    double us[2] = {0.0, 0.0};
+    float loss_h[2] = {0.f, 0.f};
+    for (int fused = 0; fused < 2; ++fused) {
+        vec_env env = make_cartpole(n, &cfg, seed, 0);
+        float* params = (float*)dmalloc(sizeof(float) * (size_t)np);
+        float* target = (float*)dmalloc(sizeof(float) * (size_t)np);
+        float* m = (float*)dmalloc(sizeof(float) * (size_t)np);
+        float* v = (float*)dmalloc(sizeof(float) * (size_t)np);
+        float* grad = (float*)dmalloc(sizeof(float) * (size_t)np);
+        float* beta_pow = (float*)dmalloc(8);
+        float* loss = (float*)dmalloc(4);
+        float* gn = (float*)dmalloc(4);
+        int32_t* actions = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)n);
+        float* q = (float*)dmalloc(sizeof(float) * (size_t)(na * n));
+        CK(rlhip_mlp2_init_f32(params, ns, h, na, seed, 0, g_stream));
+        CK(rlhip_memcpy_d2d(target, params, sizeof(float) * (size_t)np, g_stream));
+        const float b0[2] = {0.9f, 0.999f};
+        CK(rlhip_memcpy_h2d(beta_pow, b0, 8, g_stream));
+        void* workspace = dmalloc((size_t)rlhip_dqn_workspace_bytes(ns, h, na, batch));
+        rlhip_ring ring;
+        void* r_state = dmalloc(sizeof(float) * (size_t)((capacity + 1) * ns * n));
+        int32_t* r_action = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(capacity * n));
+        float* r_reward = (float*)dmalloc(sizeof(float) * (size_t)(capacity * n));
+        uint8_t* r_term = (uint8_t*)dmalloc((size_t)(capacity * n));
+        CK(rlhip_ring_init(&ring, capacity, n, ns, 4, r_state, r_action, r_reward, r_term));
+        CK(rlhip_ring_push_state(&ring, env.obs, g_stream));
+        rlhip_dqn_step_args a;
+        memset(&a, 0, sizeof(a));
+        a.kind = RLHIP_ENV_CARTPOLE, a.env_cfg = &cfg, a.st = &env.st, a.n = n, a.env_seed = seed, a.obs = env.obs;
+        a.last_obs = env.last_obs, a.ring = &ring, a.layers = 2, a.h = h, a.na = na, a.act = 0, a.params = params;
+        a.target = target, a.m = m, a.v = v, a.beta_pow = beta_pow, a.lr = 1e-3f, a.beta1 = 0.9f, a.beta2 = 0.999f;
+        a.adam_eps = 1e-8f, a.max_grad_norm = 1.0f, a.grad_scale = 1.0f, a.explorer_seed = seed, a.batch = batch;
+        a.gamma = 0.99f, a.huber_delta = 1.0f, a.sampler_seed = seed, a.workspace = workspace, a.grad = grad, a.loss = loss;
+        a.gn = gn, a.actions = actions, a.q = q, a.do_update = 1;
+        double t0 = 0.0;
+        for (int it = -50; it < steps; ++it) { /* 50 untimed vec-steps first */
+            if (it == 0) {
+                CK(rlhip_stream_sync(g_stream));
+                t0 = now_s();
+            }
+            const uint32_t step = (uint32_t)(it + 51);
+            const double eps = rlhip_get_eps(1, 0.01, 1.0, 0, 500, (int64_t)step);
+            if (fused) {
+                a.eps = eps, a.explorer_step = step, a.draw_ctr = step;
+                CK(rlhip_dqn_vec_step_f32(&a, g_stream));
+            } else { /* plan! -> act! (+ state(env)) -> push! -> optimise!: one call per stage */
+                CK(rlhip_dqn_plan_f32(params, ns, h, na, 0, env.obs, n, eps, seed, 0, step, actions, NULL, g_stream));
+                CK(rlhip_env_step(RLHIP_ENV_CARTPOLE, 0, &cfg, &env.st, n, actions, 1, seed, 0, env.last_obs, env.obs, g_stream));
+                CK(rlhip_ring_push_transition(&ring, env.last_obs, actions, (const float*)env.st.reward, env.st.done, g_stream));
+                CK(rlhip_dqn_update_f32(&ring, h, na, 0, params, target, batch, 0.99f, 1.0f, seed, step, workspace, grad, loss, m,
+                                        v, beta_pow, 1.0f, 1.0f, 1e-3f, 0.9f, 0.999f, 1e-8f, gn, g_stream));
+            }
+        }
+        CK(rlhip_stream_sync(g_stream));
+        us[fused] = (now_s() - t0) / steps * 1e6;
+        CK(rlhip_memcpy_d2h(&loss_h[fused], loss, 4, g_stream));
+        void* frees[] = {params, target, m, v, grad, beta_pow, loss, gn, actions, q, workspace, r_state, r_action, r_reward, r_term};
+        for (size_t i = 0; i < sizeof(frees) / sizeof(frees[0]); ++i) CK(rlhip_free(frees[i]));
+        free_env(&env);
+    }
+    printf("{\"workload\": \"dqn_cartpole_4096env, 4->128->2, batch 512, update every vec-step, %d vec-steps, plain-C host\", "
+           "\"per_stage_calls_us_per_vec_step\": %.2f, \"fused_call_us_per_vec_step\": %.2f, \"final_loss\": [%.6g, %.6g]}\n",
+           steps, us[0], us[1], (double)loss_h[0], (double)loss_h[1]);
+    return (isfinite(loss_h[0]) && isfinite(loss_h[1])) ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 5 && strcmp(argv[1], "comm") == 0) {
         int rank = atoi(argv[2]), world = atoi(argv[3]);
@@ -476,8 +560,13 @@ int main(int argc, char** argv) {
         int rc = run_comm_rank(rank, world, argv[4], argc >= 6 && strcmp(argv[5], "rccl") == 0);
         return rc;
     }
+    if (argc >= 2 && strcmp(argv[1], "time") == 0) {
+        CK(rlhip_set_device(0));
+        CK(rlhip_stream_create(&g_stream));
+        return run_time(argc >= 3 ? atoi(argv[2]) : 2000);
+    }
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <out.bin> | comm <rank> <world> <dir> [rccl]\n", argv[0]);
+        fprintf(stderr, "usage: %s <out.bin> | time [vec_steps] | comm <rank> <world> <dir> [rccl]\n", argv[0]);
         return 64;
     }
     if (rlhip_abi_version() != RLHIP_ABI_VERSION) {
