@@ -560,8 +560,11 @@ def roofline_hbm_side(torch, rlhip):
 
     # --- env-step of the other two classic-control envs (same kernel template as `roofline`, same protocol: random actions,
     # episodes de-synchronised before the timed launches, packed episode counters)
-    n = 1 << 24
     for kind, na, nbytes, with_obs in (("pendulum", 3, 45, True), ("mountaincar", 3, 33, False)):
+        # Pendulum: 2^24 + 4352 envs.  state(env) is a (3, n) matrix with pitch n (the ABI's obs_out): at n = 2^24 its three planes
+        # start exactly 64 MB apart and walk the HBM channels in lock-step -- 142 - 163 us per launch depending on where the
+        # allocator put the buffers (tools/pendulum_pitch_ab.py); 4352 more envs stagger the planes like the env's own arrays
+        n = (1 << 24) + (4352 if with_obs else 0)
         env = rlhip.HipVecEnv(kind, n, seed=1, packed_episode=True)
         actions = torch.randint(0, na, (8, n), dtype=torch.int32, device="cuda")
         a_ptrs = [ptr(actions[k]) for k in range(8)]
