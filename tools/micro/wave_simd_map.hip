@@ -38,5 +38,5 @@ int main() {
     }
     printf("workgroups with two waves on every SIMD: %d / %d;  with wave w and w + 4 on the same SIMD: %d / %d\n", per_simd_two, nb,
            paired, nb);
-    return 0;
+    return (paired == nb && per_simd_two == nb) ? 0 : 1;  // rollout_split_kernel stays correct either way; it gets slower
 }
