@@ -44,10 +44,23 @@ CARTPOLE_STEP_BYTES = 49     # 24 B read + 25 B written per env-
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def event_time_ms(fn, iters, lib, stream):
-    """mean milliseconds per call of fn(), measured with HIP events on `stream`."""
+SETTLE_S = 0.05  # see event_time_ms
+
+
+def event_time_ms(fn, iters, lib, stream, settle_s=0.0):
+    """mean milliseconds per call of fn(), measured with HIP events on `stream`.  settle_s > 0: fn() is first repeated for that
+    long (device busy, stream drained every four calls).  The device needs ~20 - 50 ms of work before a kernel runs at its steady
+    rate -- the Pendulum env-step at 2^24 envs reads 159 us after 40 warm-up launches (6 ms), 134 after 300, 129 - 132 from then on
+    (tools/pendulum_pitch_ab.py; same ramp as the timed PPO step's, profiles/r04_rollout.md section 3) -- and a roofline leg is
+    about the kernel, not about where in the process it happens to run."""
     from rlhip._lib import call
 
+    if settle_s > 0.0:
+        t_end = time.perf_counter() + settle_s
+        while time.perf_counter() < t_end:
+            for _ in range(4):
+                fn()
+            call("rlhip_stream_sync", stream)
     e0, e1 = C.c_void_p(), C.c_void_p()
     call("rlhip_event_create", C.byref(e0))
     call("rlhip_event_create", C.byref(e1))
@@ -103,7 +116,7 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
     for _ in range(60):
         step()
     torch.cuda.synchronize()
-    ms = event_time_ms(step, iters, rlhip._lib.lib, stream_ptr())
+    ms = event_time_ms(step, iters, rlhip._lib.lib, stream_ptr(), SETTLE_S)
     done_frac = float(env._done.float().mean())
     main = per_unit(ms)
     del env, actions
@@ -160,7 +173,7 @@ def roofline_extras(torch, rlhip):
     v = torch.randn((T + 1, n), device="cuda")
     term = torch.rand((T, n), device="cuda") < 1 / 200
     ops.gae_returns(r, v, term, 0.99, 0.95)
-    ms = event_time_ms(lambda: ops.gae_returns(r, v, term, 0.99, 0.95), 10, lib, s)
+    ms = event_time_ms(lambda: ops.gae_returns(r, v, term, 0.99, 0.95), 10, lib, s, SETTLE_S)
     gb = (17 * n * T + 4 * n) / 1e9
     out["gae_returns"] = {"bound": "hbm", "n_envs": n, "T": T, "us_per_launch": round(ms * 1e3, 1),
                           "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -205,7 +218,7 @@ def roofline_extras(torch, rlhip):
         smp()
         g()
 
-    ms_s = event_time_ms(smp, 10, lib, s)
+    ms_s = event_time_ms(smp, 10, lib, s, SETTLE_S)
     ms = event_time_ms(fresh_gather, 10, lib, s) - ms_s
     ms_rep = event_time_ms(g, 10, lib, s)
     ms_u = event_time_ms(upd, 10, lib, s)
@@ -293,7 +306,7 @@ def roofline_extras(torch, rlhip):
     def gi():
         rlhip._lib.call("rlhip_ring_sample_indices", C.byref(tr1.rb), batch, 11, cnt[0], ops.ptr(idx1), s)
 
-    ms = event_time_ms(gs, 10, lib, s) - event_time_ms(gi, 10, lib, s)
+    ms = event_time_ms(gs, 10, lib, s, SETTLE_S) - event_time_ms(gi, 10, lib, s)
     gb = (5 * f1 + 8 * f1 + 9 + 9) * batch / 1e9
     out["frame_gather_u8_stack_at_sample"] = {
         "bound": "hbm", "capacity": cap, "frame_bytes": f1, "n_stack": 4, "batch": batch,
@@ -397,7 +410,7 @@ def roofline_extras(torch, rlhip):
                        workspace=ws, grad=gbuf, loss=lbuf)
 
     gk()
-    ms = event_time_ms(gk, 10, lib, s)
+    ms = event_time_ms(gk, 10, lib, s, SETTLE_S)
     tf = 4 * 2 * 128 * 128 * bm / (ms * 1e-3) / 1e12
     out["dqn3_grad_mfma"] = {"bound": "mfma", "kernel": "dqn3_grad32_kernel<4,2,relu,OCC=2> (32-sample tiles, persistent workgroups) + d3_reduce_kernel", "batch": bm,
                              "us_per_launch": round(ms * 1e3, 1), "achieved": round(tf, 1), "peak": 2500.0,
@@ -561,10 +574,7 @@ def roofline_hbm_side(torch, rlhip):
     # --- env-step of the other two classic-control envs (same kernel template as `roofline`, same protocol: random actions,
     # episodes de-synchronised before the timed launches, packed episode counters)
     for kind, na, nbytes, with_obs in (("pendulum", 3, 45, True), ("mountaincar", 3, 33, False)):
-        # Pendulum: 2^24 + 4352 envs.  state(env) is a (3, n) matrix with pitch n (the ABI's obs_out): at n = 2^24 its three planes
-        # start exactly 64 MB apart and walk the HBM channels in lock-step -- 142 - 163 us per launch depending on where the
-        # allocator put the buffers (tools/pendulum_pitch_ab.py); 4352 more envs stagger the planes like the env's own arrays
-        n = (1 << 24) + (4352 if with_obs else 0)
+        n = 1 << 24
         env = rlhip.HipVecEnv(kind, n, seed=1, packed_episode=True)
         actions = torch.randint(0, na, (8, n), dtype=torch.int32, device="cuda")
         a_ptrs = [ptr(actions[k]) for k in range(8)]
@@ -577,10 +587,10 @@ def roofline_hbm_side(torch, rlhip):
             call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, a_ptrs[k[0] & 7], 1, env.seed, 0,
                  None, ptr(obs) if with_obs else None, s)
 
-        for _ in range(40):  # clocks, TLB; the 200-step episodes of 2^24 envs stay synchronised (time limit only) -- see note
+        for _ in range(40):  # TLB; the 200-step episodes of 2^24 envs stay synchronised (time limit only) -- see note
             step()
         torch.cuda.synchronize()
-        ms = event_time_ms(step, 20, lib, s)
+        ms = event_time_ms(step, 20, lib, s, SETTLE_S)
         out[f"env_step_{kind}"] = entry(nbytes * n / 1e9, ms, n_envs=n, bytes_per_unit=nbytes,
                                         kernel=f"env_step_kernel<{kind},f32,EPL=4,non-temporal in-place arrays / ordinary stores for the write-only ones,packed>",
                                         env_steps_per_sec=round(n / (ms * 1e-3), 1),
@@ -598,7 +608,7 @@ def roofline_hbm_side(torch, rlhip):
         v.uniform_(0.01, 1.0)
         bp = torch.tensor([0.9, 0.999], device="cuda")
         ops.adam_(p, g, m, v, bp)
-        ms = event_time_ms(lambda: ops.adam_(p, g, m, v, bp), 20, lib, s)
+        ms = event_time_ms(lambda: ops.adam_(p, g, m, v, bp), 20, lib, s, SETTLE_S)
         out[f"adam_2p{logn}"] = entry(28 * n / 1e9, ms, n_params=n, bytes_per_unit=28,
                                       kernel="adam_vec4_kernel<non-temporal stores, 2 chunks per lane> + beta_pow_advance_kernel (one call = two launches)",
                                       note="2^22 parameters (117 MB per call) fit the 256 MB Infinity Cache: the 2^26 entry is the HBM one" if logn == 22 else "")
@@ -620,7 +630,7 @@ def roofline_hbm_side(torch, rlhip):
     tr.push_state_maxpool_(s1, s2)
     for _ in range(8):
         tr.push_transition_maxpool_(s1, s2, a, r, t)
-    ms = event_time_ms(lambda: tr.push_transition_maxpool_(s1, s2, a, r, t), 10, lib, s)
+    ms = event_time_ms(lambda: tr.push_transition_maxpool_(s1, s2, a, r, t), 10, lib, s, SETTLE_S)
     out["push_transition_maxpool"] = entry((3 * fb + 18) * n_env / 1e9, ms, frame_bytes=fb, transitions_per_launch=n_env,
                                            bytes_per_unit=3 * fb + 18, kernel="push_transition_maxpool_kernel (one launch)",
                                            transitions_per_sec=round(n_env / (ms * 1e-3), 1))
@@ -644,7 +654,7 @@ def roofline_hbm_side(torch, rlhip):
         call("rlhip_ring_gather", C.byref(tr.rb), ptr(idx), batch, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]),
              ptr(bufs[4]), s)
 
-    ms = event_time_ms(sg, 10, lib, s) - event_time_ms(smp, 10, lib, s)
+    ms = event_time_ms(sg, 10, lib, s, SETTLE_S) - event_time_ms(smp, 10, lib, s)
     out["gather_small"] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env,
                                 kernel="gather_small_kernel<float>", samples_per_sec=round(batch / (ms * 1e-3), 1),
                                 note="11 random 4-byte reads per sample out of a 27 MB frame-major ring (Infinity-Cache resident): the 82 B "

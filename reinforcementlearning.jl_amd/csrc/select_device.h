@@ -95,6 +95,33 @@ __device__ __forceinline__ int32_t eps_greedy_select1(const V& q, const M& mk, i
     return (int32_t)randint32(w.z, (uint32_t)na);  // rand(rng, 1:n)
 }
 
+// log(x) in Float64 for the log-sum-exp of the sampling path, whose result is rounded to Float32 once: the classic argument
+// reduction x = 2^k (1 + f), sqrt(1/2) < 1 + f <= sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the
+// degree-7 minimax R of Sun's fdlibm e_log.c (coefficients Lg1..Lg7 and the ln2 split below are that file's; "freely
+// distributable"), error < 1 ulp.  tools/micro/log_sampling.hip runs it on the GPU for EVERY Float32 in [1, 4] (the sum of <= 4
+// exponentials whose largest is 1): the Float32 rounding equals the host libm's -- the oracle's -- in all 2^24 + 1 cases, so the
+// log-probabilities are bit for bit what ocml's log gave.  ocml's log(double) is double-double arithmetic: ~85 Float64
+// instructions against ~45 here, Float64 VALU ops run at half rate, and the log-sum-exp sits on the rollout's dependent chain
+// (profiles/r04_rollout.md).  The Gumbel noise (compared as Float64, off the chain) keeps ocml's log.
+__device__ __forceinline__ double log_f64_sampling(double x) {
+    if (!(x >= 0x1p-1022 && x < __builtin_inf())) return ::log(x);  // zero / subnormal / inf / nan / negative: never on this path
+    int k = __builtin_amdgcn_frexp_exp(x);       // x = m 2^k, 0.5 <= m < 1
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * ::fma(w, ::fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * ::fma(w, ::fma(w, ::fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return ::fma(dk, 6.93147180369123816490e-01, -((hfsq - ::fma(dk, 1.90821492927058770002e-10, s * (hfsq + R))) - f));
+}
+
 // Gumbel noise of action k of (id, step): -log(-log(u_k)), Float64; depends on nothing but the counters, so a rollout
 // kernel may evaluate it for many steps ahead, spread over the lanes that cooperate on an env (ppo.hip)
 __device__ __forceinline__ void gumbel_noise(int na, uint64_t seed, uint32_t id, uint32_t step, double* gn) {
@@ -128,7 +155,7 @@ __device__ __forceinline__ int32_t categorical_select1(const V& l, const M& mk, 
             se += (float)::exp((double)(x - mx));  // Float64 eval, rounded once (libm-independent)
         }
     }
-    float lse = (float)::log((double)se);
+    float lse = (float)log_f64_sampling((double)se);
     int best = 0;
     double bg = 0.0;
     float blp = 0.f;

@@ -5,6 +5,8 @@ cross-compiled by __graft_entry__.build()):
                  b1 + w0 x0 + w1 x1 + ... bit for bit, in both operand orders (layer 1 of ppo3w.hip and of the PPO tile)
   mfma_f32_4x4   the same for v_mfma_f32_4x4x1_16b_f32 (operand images + exactness; measured no faster than the VALU, not used)
   tanh_sel       the PPO tile's branch-free tanh == ocml tanhf for all 2^32 float bit patterns
+  log_sampling   log_f64_sampling (the Float64 log of the sampling path's log-sum-exp, csrc/select_device.h) == the host libm's log
+                 after rounding to Float32 for EVERY Float32 in [1, 4]; within 1 ulp of a long-double reference on 2^24 doubles
   wave_simd_map  wave w and wave w + 4 of a 512-thread workgroup share a SIMD (a PERFORMANCE premise of the two-wave PPO rollout,
                  csrc/ppo.hip: its actor wave and critic wave interleave on one SIMD; results do not depend on it)
 """
@@ -17,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mfma_f32_l1", "mfma_f32_4x4", "tanh_sel", "wave_simd_map"])
+@pytest.mark.parametrize("name", ["mfma_f32_l1", "mfma_f32_4x4", "tanh_sel", "wave_simd_map", "log_sampling"])
 def test_micro_check(name):
     exe = os.path.join(ROOT, "tools", "micro", name + ".bin")
     assert os.path.exists(exe), f"{exe} is missing: run python -c 'import __graft_entry__ as g; g.build()'"

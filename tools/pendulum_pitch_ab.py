@@ -1,5 +1,6 @@
-"""Pendulum env-step at ~2^24 envs: does the pitch of the (3, n) observation planes matter?  n = 2^24 puts the three planes
-exactly 64 MB apart (same HBM channel at the same time); n = 2^24 + 4352 staggers them like the env's own arrays."""
+"""Pendulum env-step at ~2^24 envs in a fresh process: (a) does the pitch of the (3, n) observation planes matter (n = 2^24 puts the
+three planes exactly 64 MB apart, n = 2^24 + 4352 staggers them like the env's own arrays)?  (b) how many launches does the
+first measurement of a process need before it reads the steady value (python tools/pendulum_pitch_ab.py [warmup launches])?"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "reinforcementlearning.jl_amd")); sys.path.insert(0, ROOT)
@@ -20,7 +21,7 @@ for rep in range(2):
         def step():
             k[0] += 1
             call("rlhip_env_step", env.kind, 0, C.byref(env.cfg), C.byref(env._st), env.n, a_ptrs[k[0] & 7], 1, env.seed, 0, None, ptr(obs), s)
-        for _ in range(40):
+        for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
             step()
         torch.cuda.synchronize()
         ms = event_time_ms(step, 20, lib, s)
