@@ -343,6 +343,17 @@ int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
 
+/* Debugging aid ("a debug build that bounds-checks gather indices"; the reference's `traces[inds]` throws a
+ * BoundsError): how many of the flat logical indices idx[0 .. batch) lie outside [0, length(trajectory) * n_env), and the position
+ * of the first one (-1 if none).  One launch and a stream synchronisation: n_bad / first_bad are HOST pointers (first_bad may be
+ * NULL).  A library built with -DRLHIP_BOUNDS_CHECK (RLHIP_EXTRA_FLAGS=-DRLHIP_BOUNDS_CHECK python .../build.py --force;
+ * rlhip_ring_bounds_checked_build() = 1) runs this check inside every entry point that takes caller-supplied indices
+ * (rlhip_ring_gather, rlhip_ring_gather_stacked, rlhip_dqn_grad_idx[_w]_f32, rlhip_dqn3_grad[_w]_f32 with idx) and returns
+ * RLHIP_EINVAL instead of reading outside the ring; the default build does not pay the synchronisation. */
+int32_t rlhip_ring_check_indices(const rlhip_ring* rb_host, const int64_t* idx, int64_t batch, int64_t* n_bad,
+                                 int64_t* first_bad, rlhip_stream_t stream);
+int32_t rlhip_ring_bounds_checked_build(void);
+
 /* ------------------------------------------------------- device-side episode hooks -- */
 /* TotalRewardPerEpisode / BatchStepsPerEpisode / StepsPerEpisode (RLCore/src/core/hooks.jl:64-101, 146-196,
  * 202-231) without a per-step host read: one launch per vec-step (PostActStage) updates the per-instance

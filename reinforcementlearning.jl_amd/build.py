@@ -50,9 +50,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    flags = FLAGS + EXTRA.get(src, []) + os.environ.get("RLHIP_EXTRA_FLAGS", "").split()
+# named variants of the library: (object directory, library file, extra flags).  "bounds" = the debug build of SURVEY.md section 5:
+# every entry point that takes caller-supplied gather indices validates them first (rlhip_ring_check_indices; include/rlhip.h).
+# Use it with RLHIP_LIB_PATH=<...>/lib/librlhip_bounds.so (rlhip/_lib.py) or point the Julia glue's `librlhip` at it.
+VARIANTS = {"bounds": (os.path.join(HERE, "build_bounds"), os.path.join(LIBDIR, "librlhip_bounds.so"), ["-DRLHIP_BOUNDS_CHECK"])}
+
+
+def _compile(src, obj_dir=None, more_flags=()):
+    obj = os.path.join(obj_dir or OBJ, src.replace(".hip", ".o"))
+    flags = FLAGS + EXTRA.get(src, []) + list(more_flags) + os.environ.get("RLHIP_EXTRA_FLAGS", "").split()
     stamp = obj + ".flags"  # an object is also stale when it was built with other flags
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     if not same_flags or _stale(obj, [os.path.join(CSRC, src)] + headers()):
@@ -67,7 +73,9 @@ def _compile(src):
     return obj
 
 
-def build(force=False):
+def build(force=False, variant=None):
+    if variant is not None:
+        return _build_variant(variant, force)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     if force:
@@ -87,5 +95,30 @@ def build(force=False):
     return SO
 
 
+def _build_variant(variant, force=False):
+    """the default library's objects, except for the sources that look at the variant's macro: those are compiled again with it"""
+    obj_dir, so, more = VARIANTS[variant]
+    build(force=False)  # the shared objects
+    os.makedirs(obj_dir, exist_ok=True)
+    if force:
+        for f in os.listdir(obj_dir):
+            os.remove(os.path.join(obj_dir, f))
+    macros = [m[2:].split("=")[0] for m in more if m.startswith("-D")] + ["RLHIP_CHECK_GATHER_INDICES"]
+
+    def affected(src):
+        text = open(os.path.join(CSRC, src)).read()
+        return any(m in text for m in macros)
+
+    objs = []
+    for src in sources():
+        objs.append(_compile(src, obj_dir, more) if affected(src) else os.path.join(OBJ, src.replace(".hip", ".o")))
+    if _stale(so, objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return so
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    variants = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")]
+    print(build(force="--force" in sys.argv, variant=variants[0] if variants else None))

@@ -35,6 +35,28 @@ void set_error(const char* fmt, ...);
 
 #define RLHIP_LAUNCH_CHECK() RLHIP_CHECK_HIP(hipGetLastError())
 
+#ifdef RLHIP_BOUNDS_CHECK
+// the debug build (RLHIP_EXTRA_FLAGS=-DRLHIP_BOUNDS_CHECK python reinforcementlearning.jl_amd/build.py --force): every gather
+// that takes caller-supplied indices validates them first (one more launch and a stream synchronisation per call)
+#define RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream)                                                               \
+    do {                                                                                                                 \
+        int64_t nbad_ = 0, first_ = -1;                                                                                  \
+        int32_t rc_ = rlhip_ring_check_indices(rb, idx, batch, &nbad_, &first_, stream);                                 \
+        if (rc_) return rc_;                                                                                             \
+        if (nbad_) {                                                                                                     \
+            ::rlhip::set_error("%s:%d: %lld of %lld gather indices are outside [0, %lld) (first at position %lld)",      \
+                               __FILE__, __LINE__, (long long)nbad_, (long long)(batch),                                 \
+                               (long long)((rb)->len_rt * (rb)->n_env), (long long)first_);                              \
+            return RLHIP_EINVAL;                                                                                         \
+        }                                                                                                                \
+    } while (0)
+#else
+#define RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream) \
+    do {                                                   \
+    } while (0)
+#endif
+
+
 static inline hipStream_t as_stream(rlhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Grid sizing for streaming kernels: enough workgroups to fill 256 CUs x 8 blocks, grid-stride the

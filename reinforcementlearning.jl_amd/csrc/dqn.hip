@@ -631,7 +631,8 @@ int32_t rlhip_dqn_grad_idx_f32(const rlhip_ring* rb, int64_t h, int64_t na, int3
                                const float* target_params, int64_t batch, const int64_t* idx, float gamma,
                                float huber_delta, void* workspace, float* grad_out, float* loss_out, float* td_out,
                                rlhip_stream_t stream) {
-    RLHIP_REQUIRE(idx != nullptr, "idx is NULL");
+    RLHIP_REQUIRE(idx != nullptr && rb != nullptr, "idx / ring is NULL");
+    RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
     return dqn_grad_impl(rb, h, na, act, params, target_params, batch, idx, gamma, huber_delta, 0, 0, workspace,
                          grad_out, loss_out, td_out, stream);
 }
@@ -640,7 +641,8 @@ int32_t rlhip_dqn_grad_idx_w_f32(const rlhip_ring* rb, int64_t h, int64_t na, in
                                  const float* target_params, int64_t batch, const int64_t* idx, const float* weights,
                                  float gamma, float huber_delta, void* workspace, float* grad_out, float* loss_out,
                                  float* td_out, rlhip_stream_t stream) {
-    RLHIP_REQUIRE(idx != nullptr && weights != nullptr, "idx / weights is NULL");
+    RLHIP_REQUIRE(idx != nullptr && weights != nullptr && rb != nullptr, "idx / weights / ring is NULL");
+    RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
     return dqn_grad_impl(rb, h, na, act, params, target_params, batch, idx, gamma, huber_delta, 0, 0, workspace,
                          grad_out, loss_out, td_out, stream, nullptr, weights);
 }

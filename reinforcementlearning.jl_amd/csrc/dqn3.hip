@@ -1279,6 +1279,7 @@ int32_t rlhip_dqn3_grad_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32_t
                             int64_t batch, const int64_t* idx, float gamma, float huber_delta, uint64_t seed,
                             uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out, float* td_out,
                             rlhip_stream_t stream) {
+    if (idx != nullptr && rb != nullptr) RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
     return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta,
                           seed, draw_ctr, workspace, grad_out, loss_out, td_out, stream, nullptr);
 }
@@ -1288,7 +1289,8 @@ int32_t rlhip_dqn3_grad_w_f32(const rlhip_ring* rb, int64_t h, int64_t na, int32
                               const uint16_t* packed, const float* target_params, const uint16_t* target_packed,
                               int64_t batch, const int64_t* idx, const float* weights, float gamma, float huber_delta,
                               void* workspace, float* grad_out, float* loss_out, float* td_out, rlhip_stream_t stream) {
-    RLHIP_REQUIRE(idx != nullptr && weights != nullptr, "idx / weights is NULL");
+    RLHIP_REQUIRE(idx != nullptr && weights != nullptr && rb != nullptr, "idx / weights / ring is NULL");
+    RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
     return dqn3_grad_impl(rb, h, na, act, params, packed, target_params, target_packed, batch, idx, gamma, huber_delta, 0, 0,
                           workspace, grad_out, loss_out, td_out, stream, nullptr, weights);
 }

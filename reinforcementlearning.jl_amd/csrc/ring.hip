@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void sample_indices_kernel(int64_t* __restrict
     out[b] = (int64_t)__umul64hi(x, total);
 }
 
+// debug aid ("a debug build that bounds-checks gather indices"): how many of the flat logical indices lie
+// outside [0, total); the first offender's position is kept in out[1] (smallest b)
+__global__ __launch_bounds__(256) void check_indices_kernel(const int64_t* __restrict__ idx, int64_t batch, int64_t total,
+                                                            unsigned long long* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int64_t j = idx[b];
+    if (j < 0 || j >= total) {
+        atomicAdd(&out[0], 1ull);
+        atomicMin(&out[1], (unsigned long long)b);
+    }
+}
+
 struct RingView {
     int64_t capacity, n_env, obs_dim, head_sa, head_rt;
     const void* state;
@@ -474,6 +487,38 @@ int32_t rlhip_ring_sample_indices(const rlhip_ring* rb, int64_t batch, uint64_t 
     return RLHIP_OK;
 }
 
+int32_t rlhip_ring_check_indices(const rlhip_ring* rb, const int64_t* idx, int64_t batch, int64_t* n_bad_host,
+                                 int64_t* first_bad_host, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && n_bad_host && batch >= 0 && (idx || batch == 0), "bad arguments");
+    *n_bad_host = 0;
+    if (first_bad_host) *first_bad_host = -1;
+    if (batch == 0) return RLHIP_OK;
+    hipStream_t st = as_stream(stream);
+    unsigned long long* d = nullptr;
+    RLHIP_CHECK_HIP(hipMallocAsync((void**)&d, 2 * sizeof(unsigned long long), st));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    RLHIP_CHECK_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const int64_t total = rb->len_rt * rb->n_env;
+    hipLaunchKernelGGL(check_indices_kernel, dim3((int)((batch + 255) / 256)), dim3(256), 0, st, idx, batch, total, d);
+    unsigned long long h[2] = {0ull, ~0ull};
+    hipError_t e1 = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);  // a debugging call: it is allowed to wait
+    (void)hipFreeAsync(d, st);
+    RLHIP_CHECK_HIP(e1);
+    RLHIP_CHECK_HIP(e2);
+    *n_bad_host = (int64_t)h[0];
+    if (first_bad_host && h[0]) *first_bad_host = (int64_t)h[1];
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ring_bounds_checked_build(void) {
+#ifdef RLHIP_BOUNDS_CHECK
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int32_t rlhip_ring_gather_is_frame_major(const rlhip_ring* rb) {
     if (!rb) return 0;
     int64_t frame_bytes = rb->obs_dim * (int64_t)rb->elem_bytes;
@@ -486,6 +531,7 @@ static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_
 int32_t rlhip_ring_gather(const rlhip_ring* rb, const int64_t* idx, int64_t batch, void* s, int32_t* a,
                           float* r, uint8_t* term, void* s_next, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb && idx && s && a && r && term && s_next && batch >= 0, "bad arguments");
+    RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
     return ring_gather_impl(rb, idx, batch, s, a, r, term, s_next, PrioDraw{}, stream);
 }
 
@@ -551,6 +597,7 @@ int32_t rlhip_ring_gather_stacked(const rlhip_ring* rb, const int64_t* idx, int6
     RLHIP_REQUIRE(frame_bytes % 16 == 0, "frame size must be a multiple of 16 bytes");
     RLHIP_REQUIRE(((((uintptr_t)rb->state | (uintptr_t)s | (uintptr_t)s_next) & 15) == 0), "buffers must be 16-byte aligned");
     if (batch == 0) return RLHIP_OK;
+    RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
     hipLaunchKernelGGL(gather_stacked_kernel, dim3((int)batch), dim3(256), 0, as_stream(stream), view_of(rb), idx, batch,
                        frame_bytes, n_stack, (uint8_t*)s, a, r, term, (uint8_t*)s_next);
     RLHIP_LAUNCH_CHECK();

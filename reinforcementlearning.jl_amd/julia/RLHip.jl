@@ -398,6 +398,23 @@ function Base.iterate(t::HipTrajectory, _ = nothing)
     ((state = t.bs, action = t.ba, reward = t.br, terminal = t.bt, next_state = t.bs_next), nothing)
 end
 
+"""
+    check_indices(t::HipTrajectory, idx::DevBuf{Int64}, n = length(idx)) -> (n_bad, first_bad)
+
+How many of the flat logical indices lie outside `1:length(t) * n_env` (0-based on the device), and the position of the first one
+(-1 if none): the debugging aid behind the bounds-checked build (`lib/librlhip_bounds.so`, `bounds_checked_build()`), where the
+reference's `traces[inds]` would throw a `BoundsError`.  One launch and a stream synchronisation.
+"""
+function check_indices(t::HipTrajectory, idx::DevBuf{Int64}, n::Integer = idx.n)
+    n_bad = Ref{Int64}(0)
+    first_bad = Ref{Int64}(-1)
+    chk(ccall((:rlhip_ring_check_indices, LIB), Int32, (Ref{Ring}, Ptr{Cvoid}, Int64, Ref{Int64}, Ref{Int64}, Ptr{Cvoid}),
+              t.rb, idx.ptr, n, n_bad, first_bad, stream()))
+    (n_bad[], first_bad[])
+end
+"true when `LIB` is the build that validates caller-supplied gather indices inside every call (-DRLHIP_BOUNDS_CHECK)"
+bounds_checked_build() = ccall((:rlhip_ring_bounds_checked_build, LIB), Int32, ()) != 0
+
 # the Agent push protocol on device buffers (no host round trip): agent_base.jl:45-59
 Base.push!(agent::Agent{P,<:HipTrajectory}, ::PreExperimentStage, env::HipVecEnv) where {P} =
     push!(agent.trajectory, (state = device_state(env),))          # the vector env has no episode stages: pushed once

@@ -10,7 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_PKG, "lib", "librlhip.so")
+# RLHIP_LIB_PATH: another build of the SAME library, e.g. lib/librlhip_bounds.so (build.py --variant=bounds: gather indices are
+# validated inside every call that takes them) -- a debugging switch, not a fallback: the file must exist and export the ABI
+LIB_PATH = os.environ.get("RLHIP_LIB_PATH") or os.path.join(_PKG, "lib", "librlhip.so")
 
 
 class RLHipError(RuntimeError):
@@ -166,6 +168,8 @@ _PROTOS = {
     "rlhip_ring_length": (i64, [P(Ring)]),
     "rlhip_ring_sample_indices": (i32, [P(Ring), i64, u64, u32, vp, vp]),
     "rlhip_ring_gather_is_frame_major": (i32, [P(Ring)]),
+    "rlhip_ring_check_indices": (i32, [P(Ring), vp, i64, P(i64), P(i64), vp]),
+    "rlhip_ring_bounds_checked_build": (i32, []),
     "rlhip_ring_gather": (i32, [P(Ring), vp, i64, vp, vp, vp, vp, vp, vp]),
     "rlhip_mlp3_nparams": (i64, [i64, i64, i64]),
     "rlhip_mlp3_packed_elems": (i64, [i64]),
@@ -267,7 +271,8 @@ for _name, (_res, _args) in _PROTOS.items():
     _f.restype = _res
     _f.argtypes = _args
     if _res is i32 and _name not in ("rlhip_abi_version", "rlhip_env_obs_dim", "rlhip_env_state_dim",
-                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported", "rlhip_p2p_can_access"):
+                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported", "rlhip_p2p_can_access",
+                                     "rlhip_ring_bounds_checked_build"):
         _STATUS.add(_name)
 
 

@@ -55,6 +55,13 @@ class CircularArraySARTSTraces:
         call("rlhip_ring_sample_indices", C.byref(self.rb), batch, seed, draw_ctr, ptr(idx), stream_ptr())
         return idx
 
+    def check_indices(self, idx):
+        """(number of flat logical indices outside [0, length * n_env), position of the first one or -1): the debugging aid behind the
+        bounds-checked build (rlhip_ring_check_indices; one launch + a stream synchronisation)."""
+        n_bad, first = C.c_int64(0), C.c_int64(-1)
+        call("rlhip_ring_check_indices", C.byref(self.rb), ptr(idx), idx.numel(), C.byref(n_bad), C.byref(first), stream_ptr())
+        return int(n_bad.value), int(first.value)
+
     def gather(self, idx):
         """traces[inds] -> (state, action0, reward, terminal, next_state)."""
         b = idx.numel()

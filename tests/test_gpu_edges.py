@@ -183,3 +183,73 @@ def test_packed_episode_counter_saturates_and_the_host_refuses_to_get_there():
         env2.act0_(torch.zeros(64, dtype=torch.int32, device="cuda"))
     env2.seed_(5)  # Random.seed! restarts the counters
     env2.act0_(torch.zeros(64, dtype=torch.int32, device="cuda"))
+
+
+def _ring_with_transitions(n_env=3, frames=5):
+    from rlhip.trajectory import CircularArraySARTSTraces
+
+    tr = CircularArraySARTSTraces(capacity=8, n_env=n_env, obs_dim=4)
+    rng = np.random.default_rng(0)
+    tr.push_state_(dev(rng.standard_normal((4, n_env)).astype(np.float32)))
+    for _ in range(frames):
+        tr.push_transition_(dev(rng.standard_normal((4, n_env)).astype(np.float32)), dev(rng.integers(0, 2, n_env).astype(np.int32)),
+                            dev(rng.standard_normal(n_env).astype(np.float32)), dev(rng.integers(0, 2, n_env).astype(np.uint8)))
+    return tr
+
+
+def test_ring_check_indices_counts_what_lies_outside_the_trajectory():
+    """rlhip_ring_check_indices (the debug aid for gather indices; the reference's traces[inds] throws a
+    BoundsError): valid range = [0, length * n_env)."""
+    import torch
+
+    tr = _ring_with_transitions()
+    total = tr.n_transitions()
+    assert total == 15
+    good = tr.sample_indices(64, seed=1, draw_ctr=0)
+    assert tr.check_indices(good) == (0, -1)
+    bad = good.clone()
+    bad[7] = total       # one past the end
+    bad[40] = -1         # negative
+    bad[63] = 1 << 40
+    assert tr.check_indices(bad) == (3, 7)
+    assert tr.check_indices(torch.empty(0, dtype=torch.int64, device="cuda")) == (0, -1)
+
+
+def test_bounds_checked_build_refuses_out_of_range_gathers():
+    """lib/librlhip_bounds.so (build.py --variant=bounds; -DRLHIP_BOUNDS_CHECK): the same program, run against it through
+    RLHIP_LIB_PATH, gets RLHIP_EINVAL from rlhip_ring_gather / rlhip_dqn_grad_idx_f32 for an out-of-range index -- and the same
+    bits as the default build for valid ones."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "reinforcementlearning.jl_amd", "lib", "librlhip_bounds.so")
+    assert os.path.exists(so), "run python -c 'import __graft_entry__ as g; g.build()'"
+    prog = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/reinforcementlearning.jl_amd")
+import rlhip
+from rlhip._lib import RLHipArgumentError, lib
+from test_gpu_edges import _ring_with_transitions
+print("checked_build", lib.rlhip_ring_bounds_checked_build())
+tr = _ring_with_transitions()
+idx = tr.sample_indices(32, seed=3, draw_ctr=0)
+out = tr.gather(idx)
+print("sum", float(sum(float(x.double().sum()) for x in out)))
+bad = idx.clone(); bad[5] = tr.n_transitions()
+try:
+    tr.gather(bad); print("gather: no error")
+except RLHipArgumentError as e:
+    print("gather: EINVAL", "outside" in str(e))
+"""
+    outs = {}
+    for name, env_extra in (("default", {}), ("bounds", {"RLHIP_LIB_PATH": so})):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", prog, root], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = [ln for ln in r.stdout.splitlines() if ln.split(" ")[0] in ("checked_build", "sum", "gather:")]
+    assert outs["default"][0] == "checked_build 0" and outs["bounds"][0] == "checked_build 1"
+    assert outs["default"][1] == outs["bounds"][1], "valid gathers differ between the two builds"
+    assert outs["default"][2] == "gather: no error"  # the default build trusts its caller (no synchronisation per gather)
+    assert outs["bounds"][2] == "gather: EINVAL True"
