@@ -312,7 +312,9 @@ typedef struct {
     int64_t capacity, n_env, obs_dim;
     int64_t head_sa, len_sa, head_rt, len_rt; /* host-side ring counters */
     int32_t elem_bytes;
-    void* state;       /* (capacity + 1) * obs_dim * n_env elements */
+    void* state;       /* (capacity + 1) * obs_dim * n_env elements; Float32 with obs_dim <= 4: TRANSITION-major,
+                        * state[(slot * n_env + e) * obs_dim + k] (the reference's (ns, N, capacity + 1) column-major order: one
+                        * 16-byte read per sampled state); anything else as pushed: state[(slot * obs_dim + k) * n_env + e] */
     int32_t* action;   /* capacity * n_env */
     float* reward;     /* capacity * n_env */
     uint8_t* terminal; /* capacity * n_env */

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             int64_t pt = (g.head_rt + li) % g.capacity;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                gs[k] = g.state[(ps * NS + k) * g.n_env + e];
-                gsn[k] = g.state[(pn * NS + k) * g.n_env + e];
+                gs[k] = g.state[(ps * g.n_env + e) * NS + k];
+                gsn[k] = g.state[(pn * g.n_env + e) * NS + k];
             }
             ga = g.action[pt * g.n_env + e];
             gr = g.reward[pt * g.n_env + e];

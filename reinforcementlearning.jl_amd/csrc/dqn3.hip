@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
         int64_t pt = (g.head_rt + li) % g.capacity;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            l_x[k * TR + tid] = g.state[(ps * NS + k) * g.n_env + e];
-            l_xn[k * TR + tid] = g.state[(pn * NS + k) * g.n_env + e];
+            l_x[k * TR + tid] = g.state[(ps * g.n_env + e) * NS + k];
+            l_xn[k * TR + tid] = g.state[(pn * g.n_env + e) * NS + k];
         }
         l_a[tid] = g.action[pt * g.n_env + e];
         l_r[tid] = g.reward[pt * g.n_env + e];
@@ -472,8 +472,8 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
         int64_t pt = (g.head_rt + li) % g.capacity;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            gs[k] = g.state[(ps * NS + k) * g.n_env + e];
-            gsn[k] = g.state[(pn * NS + k) * g.n_env + e];
+            gs[k] = g.state[(ps * g.n_env + e) * NS + k];
+            gsn[k] = g.state[(pn * g.n_env + e) * NS + k];
         }
         ga = g.action[pt * g.n_env + e];
         gr = g.reward[pt * g.n_env + e];

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void dqn_act_kernel(P p, EnvArrays<float> s
     for (int k = 0; k < NS; ++k) {
         if (obs_out) obs_out[(int64_t)k * n + env] = xn[k];
         if (last_obs) last_obs[(int64_t)k * n + env] = lo[k];
-        rb.state[(rb.state_slot * NS + k) * n + env] = xn[k];
+        rb.state[(rb.state_slot * n + env) * NS + k] = xn[k];
     }
     rb.action[rb.rt_slot * n + env] = a;
     rb.reward[rb.rt_slot * n + env] = r;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void env_act_push_kernel(P p, EnvArrays<float>
     for (int k = 0; k < NS; ++k) {
         if (obs_out) obs_out[(int64_t)k * n + env] = xn[k];
         if (last_obs) last_obs[(int64_t)k * n + env] = lo[k];
-        rb.state[(rb.state_slot * NS + k) * n + env] = xn[k];
+        rb.state[(rb.state_slot * n + env) * NS + k] = xn[k];
     }
     rb.action[rb.rt_slot * n + env] = a;
     rb.reward[rb.rt_slot * n + env] = r;

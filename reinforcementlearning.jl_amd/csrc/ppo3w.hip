@@ -1849,8 +1849,8 @@ __global__ __launch_bounds__(256) void dqn3w_gather_kernel(D3WRing rb, P3WArgs g
     const int64_t pt = (rb.head_rt + li) % rb.capacity;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        g.xg[(int64_t)k * g.npad + q] = rb.state[(ps * NS + k) * rb.n_env + e];
-        g.xg2[(int64_t)k * g.npad + q] = rb.state[(pn * NS + k) * rb.n_env + e];
+        g.xg[(int64_t)k * g.npad + q] = rb.state[(ps * rb.n_env + e) * NS + k];
+        g.xg2[(int64_t)k * g.npad + q] = rb.state[(pn * rb.n_env + e) * NS + k];
     }
     g.sg[(int64_t)g.npad + q] = rb.reward[pt * rb.n_env + e];
     g.sg[2 * (int64_t)g.npad + q] = rb.terminal[pt * rb.n_env + e] ? 1.0f : 0.0f;

@@ -9,8 +9,9 @@
 // In the reference the trajectory always lives in host RAM and the gather is a per-sample strided
 // memcpy followed by an H2D copy of the batch; here the ring never leaves HBM.
 //
-// Layout: frame-major SoA.  state[(slot * obs_dim + k) * n_env + e]; action/reward/terminal
-// [slot * n_env + e].  One push = one contiguous frame per trace (coalesced 16 B/lane copies).
+// Layout: one frame per slot.  Float32 observations with <= 4 components: transition-major, state[(slot * n_env + e) * obs_dim
+// + k] (see ring_transition_major below); everything else as pushed, state[(slot * obs_dim + k) * n_env + e]; action / reward /
+// terminal [slot * n_env + e].  One push = one contiguous frame per trace (coalesced 16 B/lane copies).
 // Gather: the index tile of a workgroup is staged in LDS once (flat index -> physical state slot,
 // next slot, transition slot, env), then
 //   * small observations (CartPole: 4 floats): one lane per (sample, component) pair;
@@ -103,6 +104,47 @@ __global__ __launch_bounds__(256) void check_indices_kernel(const int64_t* __res
         atomicAdd(&out[0], 1ull);
         atomicMin(&out[1], (unsigned long long)b);
     }
+}
+
+// Float32 observations with <= 4 components (the classic-control envs; what the fused learners take) are stored
+// TRANSITION-major: state[(slot * n_env + e) * obs_dim + k] -- the reference's own order (a `(ns, N, capacity + 1)` column-major
+// array: RLTrajectories `CircularArraySARTSTraces(state = Float32 => (ns, N))`), so that one sample's state is one 16-byte read
+// instead of obs_dim reads in obs_dim cache lines.  Everything else (u8 frames, wider observations) keeps the frame as pushed:
+// state[(slot * obs_dim + k) * n_env + e].  The env's observation buffer is component-major (obs_dim x n_env), so the push of a
+// transition-major ring transposes: lane = env, obs_dim coalesced reads, one contiguous obs_dim-float store.
+__host__ __device__ inline bool ring_transition_major(int64_t obs_dim, int32_t elem_bytes) { return elem_bytes == 4 && obs_dim <= 4; }
+
+template <int OD>
+__global__ __launch_bounds__(256) void push_frame_tm_kernel(float* __restrict__ dst, const float* __restrict__ obs, int64_t n,
+                                                            int32_t* __restrict__ a_dst, float* __restrict__ r_dst,
+                                                            uint8_t* __restrict__ t_dst, const int32_t* __restrict__ a,
+                                                            const float* __restrict__ r, const uint8_t* __restrict__ t) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float v[OD];
+#pragma unroll
+    for (int k = 0; k < OD; ++k) v[k] = obs[(int64_t)k * n + e];
+#pragma unroll
+    for (int k = 0; k < OD; ++k) dst[e * OD + k] = v[k];
+    if (a_dst) {
+        a_dst[e] = a[e];
+        r_dst[e] = r[e];
+        t_dst[e] = t[e];
+    }
+}
+
+static int32_t push_frame_tm(float* dst, const float* obs, int64_t n, int64_t od, int32_t* a_dst, float* r_dst, uint8_t* t_dst,
+                             const int32_t* a, const float* r, const uint8_t* t, hipStream_t s) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+#define RLHIP_PUSH_TM(OD_) \
+    hipLaunchKernelGGL((push_frame_tm_kernel<OD_>), grid, dim3(256), 0, s, dst, obs, n, a_dst, r_dst, t_dst, a, r, t)
+    if (od == 4) RLHIP_PUSH_TM(4);
+    else if (od == 3) RLHIP_PUSH_TM(3);
+    else if (od == 2) RLHIP_PUSH_TM(2);
+    else RLHIP_PUSH_TM(1);
+#undef RLHIP_PUSH_TM
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
 }
 
 struct RingView {
@@ -201,13 +243,13 @@ __global__ __launch_bounds__(256) void gather_small_lane_kernel(RingView rb, con
     const int64_t pn = (ps + 1 == rb.capacity + 1) ? 0 : ps + 1;
     const int64_t pt = (rb.head_rt + li) % rb.capacity;
     const E* st = (const E*)rb.state;
-    const E* p0 = st + ps * OD * rb.n_env + e;
-    const E* p1 = st + pn * OD * rb.n_env + e;
+    const E* p0 = st + (ps * rb.n_env + e) * OD;  // transition-major: the OD components of (slot, env) are contiguous
+    const E* p1 = st + (pn * rb.n_env + e) * OD;
     E v0[OD], v1[OD];
 #pragma unroll
     for (int k = 0; k < OD; ++k) {
-        v0[k] = p0[k * rb.n_env];
-        v1[k] = p1[k * rb.n_env];
+        v0[k] = p0[k];
+        v1[k] = p1[k];
     }
     const int64_t o = pt * rb.n_env + e;
     const int32_t av = rb.action[o];
@@ -409,6 +451,9 @@ static int32_t push_state_frame(rlhip_ring* rb, const void* obs, hipStream_t s) 
         phys = rb->head_sa;  // overwrite the oldest frame; it becomes the newest
         rb->head_sa = (rb->head_sa + 1) % frames;
     }
+    if (ring_transition_major(rb->obs_dim, rb->elem_bytes) && rb->n_env > 1)
+        return push_frame_tm((float*)((uint8_t*)rb->state + phys * fbytes), (const float*)obs, rb->n_env, rb->obs_dim, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, s);
     return copy_bytes((uint8_t*)rb->state + phys * fbytes, obs, fbytes, s);
 }
 
@@ -457,6 +502,12 @@ int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const i
     const int64_t sframes = rb->capacity + 1;
     const int64_t fbytes = rb->obs_dim * rb->n_env * (int64_t)rb->elem_bytes;
     uint8_t* sdst = (uint8_t*)rb->state + ((rb->len_sa < sframes) ? (rb->head_sa + rb->len_sa) % sframes : rb->head_sa) * fbytes;
+    if (ring_transition_major(rb->obs_dim, rb->elem_bytes) && n > 1) {  // transposing push + the three per-env traces, one launch
+        if (rb->len_sa < sframes) rb->len_sa += 1;
+        else rb->head_sa = (rb->head_sa + 1) % sframes;
+        return push_frame_tm((float*)sdst, (const float*)next_obs, n, rb->obs_dim, rb->action + phys * n, rb->reward + phys * n,
+                             rb->terminal + phys * n, action, reward, terminal, s);
+    }
     if ((((uintptr_t)sdst | (uintptr_t)next_obs | (uintptr_t)fbytes) & 15) == 0 && fbytes <= (64ll << 20)) {
         if (rb->len_sa < sframes) rb->len_sa += 1;
         else rb->head_sa = (rb->head_sa + 1) % sframes;

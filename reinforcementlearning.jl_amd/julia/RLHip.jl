@@ -360,6 +360,8 @@ end
 function HipTrajectory(; capacity, n_env, obs_dim, batchsize = 32, E = Float32, seed = 0,
                        controller = InsertSampleRatioController())
     rb = Ring()
+    # Float32 observations with <= 4 components: the library keeps this buffer transition-major, i.e. exactly the reference's
+    # (obs_dim, n_env, capacity + 1) column-major array (unsafe_wrap it as such); u8 frames / wider observations: (n_env, obs_dim, capacity + 1)
     st = DevBuf{E}((capacity + 1) * obs_dim * n_env)
     a, r, t = DevBuf{Int32}(capacity * n_env), DevBuf{Float32}(capacity * n_env), DevBuf{UInt8}(capacity * n_env)
     chk(ccall((:rlhip_ring_init, LIB), Int32,

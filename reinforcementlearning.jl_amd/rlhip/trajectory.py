@@ -24,7 +24,12 @@ class CircularArraySARTSTraces:
             raise TypeError("state eltype must be Float32 or UInt8")
         dev = torch.device(device)
         self.capacity, self.n_env, self.obs_dim, self.dtype = capacity, n_env, obs_dim, dtype
-        self.state = torch.zeros((capacity + 1, obs_dim, n_env), dtype=dtype, device=dev)
+        # Float32 observations with <= 4 components are stored transition-major (csrc/ring.hip ring_transition_major): the
+        # tensor's shape says so -- (capacity + 1, n_env, obs_dim) row-major IS the reference's (obs_dim, n_env, capacity + 1)
+        # column-major array, which is what a checkpoint of this tensor hands to JLD2; other rings keep the frame as pushed
+        self.transition_major = dtype == torch.float32 and obs_dim <= 4
+        self.state = torch.zeros((capacity + 1, n_env, obs_dim) if self.transition_major else (capacity + 1, obs_dim, n_env),
+                                 dtype=dtype, device=dev)
         self.action = torch.zeros((capacity, n_env), dtype=torch.int32, device=dev)
         self.reward = torch.zeros((capacity, n_env), dtype=torch.float32, device=dev)
         self.terminal = torch.zeros((capacity, n_env), dtype=torch.uint8, device=dev)
