@@ -59,16 +59,62 @@ __device__ __forceinline__ void sincos_small_f64(double x, double* s, double* c)
     *c = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 
+// sin / cos of a Float32 ARGUMENT, evaluated in Float64 and rounded once by the caller -- what Julia's own sin(::Float32) does
+// (a double-precision kernel behind a Float32 interface) and what the oracle restates as (float) sin((double) x).
+//   |x| <= pi/4      : the kernel polynomials directly (CartPole's theta)
+//   |x| <= 2^16      : x = n pi/2 + r + t with n = rint(x 2/pi); r0 = x - n PIO2_HI is EXACT in one fma (x has 24 significant
+//                      bits, n < 2^17, the difference is below 1 with its last bit at 2^-52 or above); the second term of pi/2 and
+//                      the rounding of its product are carried as a tail t (|t| < 1e-11) and enter to first order:
+//                      sin(r + t) = sin r + t cos r, cos(r + t) = cos r - t sin r.  ~45 Float64 instructions against the ~130 of
+//                      ocml's general sincos (Payne-Hanek branch and all); Pendulum's theta and MountainCar's 3 x live here.
+//   otherwise        : ocml.
+// tools/micro/trig_f32arg.hip runs EVERY Float32 with |x| <= 2^16 (2.4e9 values) on the GPU: the Float32 roundings of sin and
+// cos equal the host libm's -- the oracle's -- for all of them, so the two sides agree by enumeration there, not by accuracy class.
+constexpr double TRIG_PIO2_HI = 1.57079632679489655800e+00;  // RN(pi / 2)
+constexpr double TRIG_PIO2_LO = 6.12323399573676603587e-17;  // RN(pi / 2 - PIO2_HI)
+constexpr double TRIG_2_OVER_PI = 6.36619772367581382433e-01;
+constexpr float TRIG_MEDIUM_MAX = 65536.0f;
+
+__device__ __forceinline__ void sincos_medium_f64(double x, double* s, double* c) {
+    const double n = ::rint(x * TRIG_2_OVER_PI);
+    const double r0 = ::fma(-n, TRIG_PIO2_HI, x);  // exact
+    const double w = n * TRIG_PIO2_LO;
+    const double wl = ::fma(n, TRIG_PIO2_LO, -w);  // the product's rounding error, exact
+    const double r = r0 - w;
+    const double t = ((r0 - r) - w) - wl;
+    double sr, cr;
+    sincos_small_f64(r, &sr, &cr);
+    const double st = ::fma(t, cr, sr), ct = ::fma(-t, sr, cr);
+    const int q = (int)n & 3;  // two's complement: the quadrant of negative n as well
+    const double a = (q & 1) ? ct : st, b = (q & 1) ? st : ct;
+    *s = (q & 2) ? -a : a;                // q: 0 s, 1 c, 2 -s, 3 -c
+    *c = ((q + 1) & 2) ? -b : b;          // q: 0 c, 1 -s, 2 -c, 3 s
+}
+
+__device__ __forceinline__ void sincos_f32arg(float x, double* s, double* c) {
+    const float ax = fabsf(x);
+    if (ax <= 0.78539816f) sincos_small_f64((double)x, s, c);  // (sin(-0) comes out as +0: the one sign libm gives differently)
+    else if (ax <= TRIG_MEDIUM_MAX) sincos_medium_f64((double)x, s, c);
+    else ::sincos((double)x, s, c);
+}
+
 template <typename T>
 struct Trig;
 template <>
 struct Trig<float> {
-    static __device__ __forceinline__ float sin_(float x) { return (float)::sin((double)x); }
-    static __device__ __forceinline__ float cos_(float x) { return (float)::cos((double)x); }
+    static __device__ __forceinline__ float sin_(float x) {
+        double ds, dc;
+        sincos_f32arg(x, &ds, &dc);
+        return (float)ds;
+    }
+    static __device__ __forceinline__ float cos_(float x) {
+        double ds, dc;
+        sincos_f32arg(x, &ds, &dc);
+        return (float)dc;
+    }
     static __device__ __forceinline__ void sincos_(float x, float* s, float* c) {
         double ds, dc;
-        if (fabsf(x) <= 0.78539816f) sincos_small_f64((double)x, &ds, &dc);
-        else ::sincos((double)x, &ds, &dc);
+        sincos_f32arg(x, &ds, &dc);
         *s = (float)ds;
         *c = (float)dc;
     }
@@ -261,6 +307,40 @@ __device__ __forceinline__ double jl_mod(double x, double y) {
     return r;
 }
 
+// the same for a Float32-VALUED x with |x| <= 2^16 and y = 2 pi (angle_normalize of a Float32 Pendulum): fmod(x, y) = x - q y
+// with q = trunc(x / y) is exactly representable, and one fma delivers it exactly once q is right (x has 24 significant
+// bits, q < 2^14, |x - q y| < 8 with its last bit at 2^-50 or above); q from a multiplication by RN(1 / y) can be off by one
+// next to an integer quotient, which the sign / range of the remainder shows.  8 instructions instead of ocml's fmod loop;
+// tools/micro/trig_f32arg.hip compares it with the host's fmod-based jl_mod for every Float32 in the range.
+constexpr double TWO_PI_D = 2.0 * RLHIP_PI;
+__device__ __forceinline__ double jl_mod_2pi_f32arg(float xf) {
+    const double x = (double)xf;
+    if (!(fabsf(xf) <= TRIG_MEDIUM_MAX)) return jl_mod(x, TWO_PI_D);
+    double q = ::trunc(x * (1.0 / TWO_PI_D));
+    double r = ::fma(-q, TWO_PI_D, x);
+    if (x >= 0.0 ? r < 0.0 : r > 0.0) {  // q one too large in magnitude
+        q -= (x >= 0.0 ? 1.0 : -1.0);
+        r = ::fma(-q, TWO_PI_D, x);
+    } else if (::fabs(r) >= TWO_PI_D) {  // q one too small in magnitude
+        q += (x >= 0.0 ? 1.0 : -1.0);
+        r = ::fma(-q, TWO_PI_D, x);
+    }
+    if (r == 0.0) return ::copysign(r, TWO_PI_D);
+    if (r < 0.0) return r + TWO_PI_D;
+    return r;
+}
+
+template <typename T>
+struct AngleMod;
+template <>
+struct AngleMod<float> {
+    static __device__ __forceinline__ double mod_2pi(float x) { return jl_mod_2pi_f32arg(x); }
+};
+template <>
+struct AngleMod<double> {
+    static __device__ __forceinline__ double mod_2pi(double x) { return jl_mod(x, 2.0 * RLHIP_PI); }
+};
+
 // reset!  :84-92
 template <typename T>
 __device__ __forceinline__ void env_reset1(const PendulumParams<T>&, LaneState<T>& e, uint64_t seed,
@@ -292,7 +372,7 @@ __device__ __forceinline__ void env_step1(const PendulumParams<T>& p, LaneState<
     // :104  costs = angle_normalize(th)^2 + 0.1 * thdot^2 + 0.001 * a^2 (Float64);
     //       angle_normalize(x) = mod(x + pi, 2 * pi) - pi  (:71): x + pi is T, 2 * pi is Float64
     T thpi = th + (T)RLHIP_PI;
-    double an = jl_mod((double)thpi, 2.0 * RLHIP_PI) - RLHIP_PI;
+    double an = AngleMod<T>::mod_2pi(thpi) - RLHIP_PI;
     double costs = an * an + 0.1 * (double)(thdot * thdot) + 0.001 * (double)(a * a);
     // :105-110  pure T; sin(th + pi) literally
     T newthdot = thdot + ((T)-3 * p.g / ((T)2 * p.l) * Trig<T>::sin_(thpi) +
