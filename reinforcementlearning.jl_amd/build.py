@@ -53,7 +53,9 @@ def _stale(target, deps):
 # named variants of the library: (object directory, library file, extra flags).  "bounds" = the debug build of SURVEY.md section 5:
 # every entry point that takes caller-supplied gather indices validates them first (rlhip_ring_check_indices; include/rlhip.h).
 # Use it with RLHIP_LIB_PATH=<...>/lib/librlhip_bounds.so (rlhip/_lib.py) or point the Julia glue's `librlhip` at it.
-VARIANTS = {"bounds": (os.path.join(HERE, "build_bounds"), os.path.join(LIBDIR, "librlhip_bounds.so"), ["-DRLHIP_BOUNDS_CHECK"])}
+VARIANTS = {"bounds": (os.path.join(HERE, "build_bounds"), os.path.join(LIBDIR, "librlhip_bounds.so"), ["-DRLHIP_BOUNDS_CHECK"]),
+            # per-phase cycle sums of the two-wave PPO rollout, printed by workgroup 0 (a profiling aid: tools/rollout_one.py)
+            "rollout_timing": (os.path.join(HERE, "build_rt"), os.path.join(LIBDIR, "librlhip_rt.so"), ["-DRLHIP_ROLLOUT_TIMING"])}
 
 
 def _compile(src, obj_dir=None, more_flags=()):

@@ -74,6 +74,32 @@ __global__ void counters_advance_kernel(uint32_t* ctr, uint32_t d0, uint32_t d1)
 // pd.cont / pd.na at run time.  With the run-time form the selection is three loops over `na` with a compare-and-select
 // chain per register-array access, and both heads' code sits in the step loop; the compile-time form is the same operations
 // on the same operands, unrolled.
+// per-phase cycle sums of workgroup 0 (one actor wave, one critic wave), printed at the end of the launch: build with
+// RLHIP_EXTRA_FLAGS=-DRLHIP_ROLLOUT_TIMING (tools/rollout_one.py; proportions -- the stamps cost a few cycles each)
+#ifdef RLHIP_ROLLOUT_TIMING
+#define RT_DECL long long rt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_last_ = 0
+#define RT_START() rt_last_ = (long long)__builtin_amdgcn_s_memtime()
+#define RT_STAMP(k)                                                   \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+        rt_[k] += now_ - rt_last_;                                    \
+        rt_last_ = now_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    } while (0)
+#define RT_PRINT(tag)                                                                                             \
+    do {                                                                                                          \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0)                                                          \
+            printf("%s T=%d: %lld %lld %lld %lld %lld %lld %lld %lld\n", tag, T, rt_[0], rt_[1], rt_[2], rt_[3], rt_[4], \
+                   rt_[5], rt_[6], rt_[7]);                                                                       \
+    } while (0)
+#else
+#define RT_DECL
+#define RT_START()
+#define RT_STAMP(k)
+#define RT_PRINT(tag)
+#endif
+
 template <class P, int H, int L, int ACT, int NOA, int HEAD>
 __global__ __launch_bounds__(512, 1) void rollout_split_kernel(P p, EnvArrays<float> st, int64_t n, int T,
                                                                PolicyDesc pd, const float* __restrict__ params,
@@ -113,26 +139,35 @@ __global__ __launch_bounds__(512, 1) void rollout_split_kernel(P p, EnvArrays<fl
         e.episode = st.episode[env];
         float last_r = 0.0f;
         bool last_d = false;
+        RT_DECL;
         __syncthreads();  // the noise of chunk 0
+        RT_START();
         for (int t = 0; t < T; ++t) {
             double nz[MAXO];  // requested before the forward pass, consumed after it
 #pragma unroll
             for (int k = 0; k < MAXO; ++k) nz[k] = (k < na) ? l_noise[(t / NOISE_CH) & 1][eg][t & (NOISE_CH - 1)][k] : 0.0;
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             env_obs1(p, e, x);  // state(env) at PreActStage (post auto-reset)
+            RT_STAMP(0);  // noise read issued + obs
             float oa[MAXO];
             net_forward<NS, HPL, L, ACT, NOA>(A, x, oa);
+            RT_STAMP(1);  // actor forward
             int32_t ai;
             float af, lp;
             policy_select(cont, na, oa, nz, ai, af, lp);
+            RT_STAMP(2);  // selection
             env_step1(p, e, ai, af, last_r, last_d);
             if (last_d) env_reset1(p, e, seed, id);  // MultiThreadEnv auto-reset
+            RT_STAMP(3);  // env step
             if (sub == 0) {
                 l_step[t & 1][eg][0] = make_float4(x[0], x[1], x[2], x[3]);
                 l_step[t & 1][eg][1] = make_float4(lp, cont ? af : __int_as_float(ai), last_r, last_d ? 1.0f : 0.0f);
             }
+            RT_STAMP(4);  // record
             __syncthreads();
+            RT_STAMP(5);  // barrier
         }
+        RT_PRINT("actor wave: obs/noise | forward | select | env step | record | barrier");
         {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             env_obs1(p, e, x);
@@ -162,15 +197,20 @@ __global__ __launch_bounds__(512, 1) void rollout_split_kernel(P p, EnvArrays<fl
             }
         };
         fill_noise(0);
+        RT_DECL;
         __syncthreads();
+        RT_START();
         for (int t = 0; t < T; ++t) {
             // the actor wave is in step t, reading chunk t / 16: the other buffer (last read in step t - 1) takes the next chunk
             if ((t & (NOISE_CH - 1)) == 0 && t + NOISE_CH < T) fill_noise(t + NOISE_CH);
+            RT_STAMP(0);  // noise of a later chunk
             __syncthreads();  // step t's record
+            RT_STAMP(1);  // barrier
             const float4 xv = l_step[t & 1][eg][0];
             const float x[4] = {xv.x, xv.y, xv.z, xv.w};
             float oc[MAXO];
             net_forward<NS, HPL, L, ACT, 1>(C, x, oc);
+            RT_STAMP(2);  // critic forward
             if (writer) {
                 const float4 rec = l_step[t & 1][eg][1];
 #pragma unroll
@@ -182,7 +222,9 @@ __global__ __launch_bounds__(512, 1) void rollout_split_kernel(P p, EnvArrays<fl
                 tr.reward[(int64_t)t * n + env] = rec.z;
                 tr.terminal[(int64_t)t * n + env] = (uint8_t)(rec.w != 0.0f);
             }
+            RT_STAMP(3);  // trajectory stores issued
         }
+        RT_PRINT("critic wave: noise | barrier | forward | stores");
         __syncthreads();  // the state after the last step
         {
             const float4 xv = l_step[T & 1][eg][0];
