@@ -656,12 +656,12 @@ def roofline_hbm_side(torch, rlhip):
 
     ms = event_time_ms(sg, 10, lib, s, SETTLE_S) - event_time_ms(smp, 10, lib, s)
     out["gather_small"] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env,
-                                kernel="gather_small_lane_kernel<float,4>", samples_per_sec=round(batch / (ms * 1e-3), 1),
-                                note="5 random reads per sample (s and s' as one 16-byte read each out of the transition-major ring -- "
-                                     "round 4, late: the reference's own (ns, N, capacity) order -- plus action, reward, terminal) out of a "
-                                     "27 MB ring (Infinity-Cache resident): the 82 B per sample are the algorithmic bytes, the fabric moves a "
-                                     f"64 B line per read (320 B per sample = {round(320 * batch / (ms * 1e-3) / 1e9, 1)} GB/s of line traffic).  "
-                                     "With the component-major ring of rounds 1 - 4 (11 lines per sample) this launch took 164 - 168 us")
+                                kernel="gather_rec_kernel<4>", samples_per_sec=round(batch / (ms * 1e-3), 1),
+                                note="round 5: the ring stores one 32-byte record {s[4], a, r, t} per (state slot, env) -- the pushed "
+                                     "tuple -- so a sample reads the state half of record(s) and the whole record(s'): two 32-byte sectors "
+                                     "out of a 34 MB ring (Infinity-Cache resident); 82 B per sample are the algorithmic bytes.  Round 4 "
+                                     "(transition-major states + three traces: five 64-byte lines per sample) took 79 us for this launch, "
+                                     "rounds 1 - 3 (component-major: eleven lines) 164 - 168 us")
     return out
 
 

@@ -41,7 +41,12 @@ extern "C" {
 #define RLHIP_ETIMEOUT (-4) /* a peer never arrived at a gradient exchange; the result was overwritten with NaN */
 #define RLHIP_ECOMM (-5)    /* RCCL is missing or one of its calls failed / no transport for this exchange */
 
-#define RLHIP_ABI_VERSION 1
+/* 2 (round 5): rlhip_ring rings of Float32 observations with <= 4 components store 32-byte records (state + action + reward +
+ *    terminal per (slot, env)); `rlhip_ring.layout` names the layout, rlhip_ring_init takes NULL action / reward / terminal for
+ *    them; rlhip_ppo_workspace_init + the capacity check of rlhip_ppo_update_f32; rlhip_eps_greedy_prob_f32.  ABI 1 stored those
+ *    states transition-major with three separate traces (and round 3 component-major): a host built against an older header
+ *    fails rlhip_abi_version() == RLHIP_ABI_VERSION and, if it skips that check, rlhip_ring_init (RLHIP_EINVAL). */
+#define RLHIP_ABI_VERSION 2
 
 typedef void* rlhip_stream_t; /* hipStream_t */
 typedef void* rlhip_event_t;  /* hipEvent_t  */
@@ -307,19 +312,38 @@ int32_t rlhip_td_target_f32(const float* qt_next, int64_t na, int64_t n, int64_t
  * One frame = one vec-step.  state has capacity+1 frames (next_state[i] = state[i+1]), the other traces
  * capacity frames.  Head/length counters are HOST fields updated by the push calls (they are pure
  * functions of the push count, so no device sync is ever needed to know them).
- * elem_bytes: 4 (Float32 observations) or 1 (UInt8 frames, e.g. 84x84x4 Atari stacks).          */
+ * elem_bytes: 4 (Float32 observations) or 1 (UInt8 frames, e.g. 84x84x4 Atari stacks).
+ *
+ * Two storage layouts (`layout`, set by rlhip_ring_init; rlhip_ring_layout() returns it):
+ *   RLHIP_RING_FRAMES   every trace as pushed: state[(slot * obs_dim + k) * n_env + e] (capacity + 1 slots), action / reward /
+ *                       terminal[slot * n_env + e] (capacity slots) -- UInt8 frames and Float32 observations with > 4 components.
+ *   RLHIP_RING_RECORDS  Float32 observations with <= 4 components (the classic-control envs; what the fused DQN learners take):
+ *                       `state` holds (capacity + 1) * n_env RECORDS of 32 bytes,
+ *                           record[slot * n_env + e] = { float s[4]; int32 action; float reward; uint32 terminal; uint32 spare },
+ *                       where (action, reward, terminal) are those of the transition that ARRIVED at state s -- the record is the
+ *                       tuple push!(trajectory, (state = s', action, reward, terminal)) pushes, written once, and a sampled
+ *                       transition reads two 32-byte sectors (round 4: five cache lines).  Logical transition i has s in slot
+ *                       (head_sa + i) mod (capacity + 1) and (s', a, r, t) in the next slot; `action`, `reward`, `terminal` are
+ *                       NULL (a strided view for a host: word 4 / 5 / 6 of each record).  s[k >= obs_dim] = 0.
+ * rlhip_ring_state_bytes() is the size of the `state` allocation for either layout (32-byte aligned for records). */
+#define RLHIP_RING_FRAMES 0
+#define RLHIP_RING_RECORDS 2 /* (1 was ABI 1's transition-major state trace) */
 typedef struct {
     int64_t capacity, n_env, obs_dim;
-    int64_t head_sa, len_sa, head_rt, len_rt; /* host-side ring counters */
+    int64_t head_sa, len_sa, head_rt, len_rt; /* host-side ring counters (head_rt / len_rt count the LOGICAL action / reward /
+                                               * terminal traces in both layouts: lengths, sampler range, sum-tree keys) */
     int32_t elem_bytes;
-    void* state;       /* (capacity + 1) * obs_dim * n_env elements; Float32 with obs_dim <= 4: TRANSITION-major,
-                        * state[(slot * n_env + e) * obs_dim + k] (the reference's (ns, N, capacity + 1) column-major order: one
-                        * 16-byte read per sampled state); anything else as pushed: state[(slot * obs_dim + k) * n_env + e] */
-    int32_t* action;   /* capacity * n_env */
-    float* reward;     /* capacity * n_env */
-    uint8_t* terminal; /* capacity * n_env */
+    int32_t layout;    /* RLHIP_RING_FRAMES | RLHIP_RING_RECORDS */
+    void* state;       /* FRAMES: (capacity + 1) * obs_dim * n_env elements; RECORDS: (capacity + 1) * n_env * 32 bytes */
+    int32_t* action;   /* FRAMES: capacity * n_env; RECORDS: NULL */
+    float* reward;     /* FRAMES: capacity * n_env; RECORDS: NULL */
+    uint8_t* terminal; /* FRAMES: capacity * n_env; RECORDS: NULL */
 } rlhip_ring;
 
+int64_t rlhip_ring_state_bytes(int64_t capacity, int64_t n_env, int64_t obs_dim, int32_t elem_bytes);
+int32_t rlhip_ring_layout(const rlhip_ring* rb_host);
+/* action / reward / terminal: device arrays for RLHIP_RING_FRAMES, NULL for RLHIP_RING_RECORDS (= elem_bytes 4 and obs_dim <= 4;
+ * anything else is RLHIP_EINVAL: a host written for ABI 1 fails here instead of reading transposed data) */
 int32_t rlhip_ring_init(rlhip_ring* rb_host, int64_t capacity, int64_t n_env, int64_t obs_dim,
                         int32_t elem_bytes, void* state, int32_t* action, float* reward,
                         uint8_t* terminal);

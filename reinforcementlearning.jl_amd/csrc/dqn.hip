@@ -17,6 +17,7 @@
 // indices are drawn inline from the SAMPLER Philox stream and the transitions are gathered straight
 // from the HBM ring into LDS -- the sampled batch is never materialised in HBM.
 #include "mlp_device.h"
+#include "ring_device.h"
 #include "optim_device.h"
 #include "select_device.h"
 
@@ -28,11 +29,7 @@ constexpr int DTILE = 64;
 constexpr int DQN_MAX_BLOCKS = 512;
 
 struct DqnArgs {
-    const float* state;
-    const int32_t* action;
-    const float* reward;
-    const uint8_t* terminal;
-    int64_t capacity, n_env, head_sa, head_rt;
+    RingRecs ring;  // record ring (ring_device.h)
     uint64_t total;
     const float* params;
     const float* tparams;
@@ -113,18 +110,15 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                 uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
                 fj = (int64_t)__umul64hi(xr, g.total);
             }
-            int64_t li = fj / g.n_env, e = fj - li * g.n_env;
-            int64_t ps = (g.head_sa + li) % (g.capacity + 1);
-            int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
-            int64_t pt = (g.head_rt + li) % g.capacity;
+            const RingTransition rt = ring_load_transition(g.ring, fj);  // two 32-byte sectors per sample
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                gs[k] = g.state[(ps * g.n_env + e) * NS + k];
-                gsn[k] = g.state[(pn * g.n_env + e) * NS + k];
+                gs[k] = rt.s[k];
+                gsn[k] = rt.sn[k];
             }
-            ga = g.action[pt * g.n_env + e];
-            gr = g.reward[pt * g.n_env + e];
-            gt = g.terminal[pt * g.n_env + e];
+            ga = rt.a;
+            gr = rt.r;
+            gt = (uint8_t)rt.t;
         }
         if (!staged) {  // both networks -> LDS, while the gather is in flight
             for (int q = tid; q < 2 * h; q += 256) {
@@ -541,6 +535,7 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
     RLHIP_REQUIRE(rb && params && target_params && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
+    RLHIP_REQUIRE(rb->layout == RLHIP_RING_RECORDS, "the DQN learner reads a record ring (rlhip_ring_init, ABI 2)");
     RLHIP_REQUIRE(h >= 4 && h <= 256 && h % 4 == 0, "hidden must be a multiple of 4, <= 256");
     RLHIP_REQUIRE(na >= 1 && na <= MAXO, "na must be <= 4");
     RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
@@ -549,14 +544,7 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
     int ns = (int)rb->obs_dim;
     int64_t np = mlp2_nparams(ns, h, na);
     DqnArgs g;
-    g.state = (const float*)rb->state;
-    g.action = rb->action;
-    g.reward = rb->reward;
-    g.terminal = rb->terminal;
-    g.capacity = rb->capacity;
-    g.n_env = rb->n_env;
-    g.head_sa = rb->head_sa;
-    g.head_rt = rb->head_rt;
+    g.ring = {(const uint8_t*)rb->state, rb->capacity, rb->n_env, rb->head_sa};
     g.total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
     g.params = params;
     g.tparams = target_params;

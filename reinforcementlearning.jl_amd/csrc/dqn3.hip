@@ -26,6 +26,7 @@
 // samples = 32 workgroups) the launch is latency-bound -- measured numbers in profiles/ and DESIGN.md.
 #include "mfma_common.h"
 #include "mlp_device.h"
+#include "ring_device.h"
 #include "select_device.h"
 
 namespace rlhip {
@@ -239,11 +240,7 @@ constexpr size_t PLAN32_LDS = (4 * P32 + 8 * 4 * P32 + P32 * LDH2 + SMALLW) * si
 
 // ---------------------------------------------------------------------------------- gradient
 struct Dqn3Args {
-    const float* state;
-    const int32_t* action;
-    const float* reward;
-    const uint8_t* terminal;
-    int64_t capacity, n_env, head_sa, head_rt;
+    RingRecs ring;  // record ring (ring_device.h)
     uint64_t total;
     const int64_t* idx;  // optional explicit flat logical indices (prioritized sampler); NULL = inline uniform draw
     const float* params;
@@ -305,18 +302,15 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
             uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
             fj = (int64_t)__umul64hi(xr, g.total);
         }
-        int64_t li = fj / g.n_env, e = fj - li * g.n_env;
-        int64_t ps = (g.head_sa + li) % (g.capacity + 1);
-        int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
-        int64_t pt = (g.head_rt + li) % g.capacity;
+        const RingTransition rt = ring_load_transition(g.ring, fj);  // two 32-byte sectors per sample
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            l_x[k * TR + tid] = g.state[(ps * g.n_env + e) * NS + k];
-            l_xn[k * TR + tid] = g.state[(pn * g.n_env + e) * NS + k];
+            l_x[k * TR + tid] = rt.s[k];
+            l_xn[k * TR + tid] = rt.sn[k];
         }
-        l_a[tid] = g.action[pt * g.n_env + e];
-        l_r[tid] = g.reward[pt * g.n_env + e];
-        l_t[tid] = g.terminal[pt * g.n_env + e];
+        l_a[tid] = rt.a;
+        l_r[tid] = rt.r;
+        l_t[tid] = rt.t;
     }
     __syncthreads();
 
@@ -466,18 +460,15 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
             fj = (int64_t)__umul64hi(xr, g.total);
         }
-        int64_t li = fj / g.n_env, e = fj - li * g.n_env;
-        int64_t ps = (g.head_sa + li) % (g.capacity + 1);
-        int64_t pn = (g.head_sa + li + 1) % (g.capacity + 1);
-        int64_t pt = (g.head_rt + li) % g.capacity;
+        const RingTransition rt = ring_load_transition(g.ring, fj);  // two 32-byte sectors per sample
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            gs[k] = g.state[(ps * g.n_env + e) * NS + k];
-            gsn[k] = g.state[(pn * g.n_env + e) * NS + k];
+            gs[k] = rt.s[k];
+            gsn[k] = rt.sn[k];
         }
-        ga = g.action[pt * g.n_env + e];
-        gr = g.reward[pt * g.n_env + e];
-        gt = g.terminal[pt * g.n_env + e];
+        ga = rt.a;
+        gr = rt.r;
+        gt = (int32_t)rt.t;
     }
     if (tid < G32) {
 #pragma unroll
@@ -1161,6 +1152,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     RLHIP_REQUIRE(rb && params && packed && target_params && target_packed && workspace && grad_out, "NULL argument");
     RLHIP_REQUIRE(rb->elem_bytes == 4, "the DQN learner expects Float32 observations");
     RLHIP_REQUIRE(rb->obs_dim >= 2 && rb->obs_dim <= 4, "fused DQN kernel supports obs_dim 2..4");
+    RLHIP_REQUIRE(rb->layout == RLHIP_RING_RECORDS, "the DQN learner reads a record ring (rlhip_ring_init, ABI 2)");
     RLHIP_REQUIRE(h == H3 || h == HWIDE, "the MFMA Q-network path is built for hidden = 128 or 256");
     RLHIP_REQUIRE((rb->obs_dim == 4 && na == 2) || (rb->obs_dim == 2 && na == 3) || (rb->obs_dim == 3 && na == 3),
                   "(obs dim, actions) must be (4, 2) CartPole, (2, 3) MountainCar or (3, 3) Pendulum");
@@ -1189,14 +1181,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     const int64_t tiles32 = (batch + G32 - 1) / G32;
     const int nb = small ? (int)(tiles32 < D3_GRAD32_BLOCKS ? tiles32 : D3_GRAD32_BLOCKS) : (int)((batch + TR - 1) / TR);
     Dqn3Args g;
-    g.state = (const float*)rb->state;
-    g.action = rb->action;
-    g.reward = rb->reward;
-    g.terminal = rb->terminal;
-    g.capacity = rb->capacity;
-    g.n_env = rb->n_env;
-    g.head_sa = rb->head_sa;
-    g.head_rt = rb->head_rt;
+    g.ring = {(const uint8_t*)rb->state, rb->capacity, rb->n_env, rb->head_sa};
     g.total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
     g.idx = idx;
     g.params = params;

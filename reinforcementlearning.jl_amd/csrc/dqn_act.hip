@@ -10,17 +10,14 @@
 // L = H / 16 lanes per env instance, weights in registers (as the PPO rollout kernel, ppo.hip).
 #include "env_device.h"
 #include "mlp_device.h"
+#include "ring_device.h"
 #include "select_device.h"
 
 namespace rlhip {
 
 struct ActRing {
-    float* state;      // ring state trace
-    int32_t* action;
-    float* reward;
-    uint8_t* terminal;
-    int64_t state_slot;  // physical frame receiving s'
-    int64_t rt_slot;     // physical frame receiving (a, r, t)
+    void* rec;           // record ring (ring_device.h)
+    int64_t state_slot;  // physical slot receiving the pushed tuple (s', a, r, t)
 };
 
 struct RegQa {
@@ -77,11 +74,10 @@ __global__ __launch_bounds__(256, 1) void dqn_act_kernel(P p, EnvArrays<float> s
     for (int k = 0; k < NS; ++k) {
         if (obs_out) obs_out[(int64_t)k * n + env] = xn[k];
         if (last_obs) last_obs[(int64_t)k * n + env] = lo[k];
-        rb.state[(rb.state_slot * n + env) * NS + k] = xn[k];
     }
-    rb.action[rb.rt_slot * n + env] = a;
-    rb.reward[rb.rt_slot * n + env] = r;
-    rb.terminal[rb.rt_slot * n + env] = (uint8_t)d;
+#pragma unroll
+    for (int k = NS; k < 4; ++k) xn[k] = 0.f;
+    ring_store_record(rb.rec, rb.state_slot, n, env, xn, a, r, d ? 1u : 0u);
 }
 
 template <class P>
@@ -151,28 +147,19 @@ __global__ __launch_bounds__(256) void env_act_push_kernel(P p, EnvArrays<float>
     for (int k = 0; k < NS; ++k) {
         if (obs_out) obs_out[(int64_t)k * n + env] = xn[k];
         if (last_obs) last_obs[(int64_t)k * n + env] = lo[k];
-        rb.state[(rb.state_slot * n + env) * NS + k] = xn[k];
     }
-    rb.action[rb.rt_slot * n + env] = a;
-    rb.reward[rb.rt_slot * n + env] = r;
-    rb.terminal[rb.rt_slot * n + env] = (uint8_t)d;
+#pragma unroll
+    for (int k = NS; k < 4; ++k) xn[k] = 0.f;
+    ring_store_record(rb.rec, rb.state_slot, n, env, xn, a, r, d ? 1u : 0u);
 }
 
 // the slots push!(trajectory, (state = s', action, reward, terminal)) writes (ring.hip); advances the ring counters
 static ActRing claim_slots(rlhip_ring* rb) {
     ActRing ar;
-    ar.state = (float*)rb->state;
-    ar.action = rb->action;
-    ar.reward = rb->reward;
-    ar.terminal = rb->terminal;
+    ar.rec = rb->state;
     const int64_t frames = rb->capacity;
-    if (rb->len_rt < frames) {
-        ar.rt_slot = (rb->head_rt + rb->len_rt) % frames;
-        rb->len_rt += 1;
-    } else {
-        ar.rt_slot = rb->head_rt;
-        rb->head_rt = (rb->head_rt + 1) % frames;
-    }
+    if (rb->len_rt < frames) rb->len_rt += 1;  // the logical action / reward / terminal traces (lengths, sum-tree keys)
+    else rb->head_rt = (rb->head_rt + 1) % frames;
     const int64_t sframes = rb->capacity + 1;
     if (rb->len_sa < sframes) {
         ar.state_slot = (rb->head_sa + rb->len_sa) % sframes;
@@ -218,6 +205,7 @@ extern "C" int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rl
     RLHIP_REQUIRE(rb->elem_bytes == 4 && rb->n_env == n && rb->obs_dim == (kind == 0 ? 4 : (kind == 1 ? 3 : 2)),
                   "ring geometry does not match the env");
     RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
+    RLHIP_REQUIRE(rb->layout == RLHIP_RING_RECORDS, "the fused act + push kernels write a record ring (rlhip_ring_init, ABI 2)");
     ActRing ar = claim_slots(rb);
     hipStream_t s = as_stream(stream);
     if (kind == 0)
@@ -244,6 +232,7 @@ extern "C" int32_t rlhip_env_act_push_f32(int32_t kind, const void* env_cfg, con
     RLHIP_REQUIRE(rb->elem_bytes == 4 && rb->n_env == n && rb->obs_dim == (kind == 0 ? 4 : (kind == 1 ? 3 : 2)),
                   "ring geometry does not match the env");
     RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
+    RLHIP_REQUIRE(rb->layout == RLHIP_RING_RECORDS, "the fused act + push kernels write a record ring (rlhip_ring_init, ABI 2)");
     ActRing ar = claim_slots(rb);
     hipStream_t s = as_stream(stream);
     if (kind == 0)

@@ -36,6 +36,7 @@
 //                     f32 H2 tiles in LDS for the heads.      dqn3w_plan_kernel  plan! of the Q-network (forward + eps-greedy).
 #include "env_device.h"
 #include "ppo_common.h"
+#include "ring_device.h"
 #include "ppo_sample_device.h"
 #include "mlp3_device.h"
 #include "optim_device.h"
@@ -1818,11 +1819,7 @@ int32_t ppo3w_update(int32_t kind, const rlhip_ppo_cfg* cfg, const PolicyDesc& p
 //   ppo3w_bwd_kernel / ppo3w_dw2_kernel, then the reduce (or the two-launch tail with clip + Adam + bf16 re-pack)
 // and dqn3w_plan_kernel is plan!: forward + eps-greedy selection for n env instances.
 struct D3WRing {
-    const float* state;
-    const int32_t* action;
-    const float* reward;
-    const uint8_t* terminal;
-    int64_t capacity, n_env, head_sa, head_rt;
+    RingRecs ring;  // record ring (ring_device.h)
     uint64_t total;
     const int64_t* idx;
     uint64_t seed;
@@ -1843,18 +1840,15 @@ __global__ __launch_bounds__(256) void dqn3w_gather_kernel(D3WRing rb, P3WArgs g
         const uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
         fj = (int64_t)__umul64hi(xr, rb.total);
     }
-    const int64_t li = fj / rb.n_env, e = fj - li * rb.n_env;
-    const int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
-    const int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
-    const int64_t pt = (rb.head_rt + li) % rb.capacity;
+    const RingTransition rt = ring_load_transition(rb.ring, fj);  // two 32-byte sectors per sample
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        g.xg[(int64_t)k * g.npad + q] = rb.state[(ps * rb.n_env + e) * NS + k];
-        g.xg2[(int64_t)k * g.npad + q] = rb.state[(pn * rb.n_env + e) * NS + k];
+        g.xg[(int64_t)k * g.npad + q] = rt.s[k];
+        g.xg2[(int64_t)k * g.npad + q] = rt.sn[k];
     }
-    g.sg[(int64_t)g.npad + q] = rb.reward[pt * rb.n_env + e];
-    g.sg[2 * (int64_t)g.npad + q] = rb.terminal[pt * rb.n_env + e] ? 1.0f : 0.0f;
-    g.sg[3 * (int64_t)g.npad + q] = __int_as_float(rb.action[pt * rb.n_env + e]);
+    g.sg[(int64_t)g.npad + q] = rt.r;
+    g.sg[2 * (int64_t)g.npad + q] = rt.t ? 1.0f : 0.0f;
+    g.sg[3 * (int64_t)g.npad + q] = __int_as_float(rt.a);
 }
 
 // one net's W2 -> bf16 MFMA B fragments, both orientations (the layout of ppo3w_pack_kernel)
@@ -2072,14 +2066,7 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
     hipStream_t s = as_stream(stream);
     char* ws = (char*)workspace;
     D3WRing r;
-    r.state = (const float*)rb->state;
-    r.action = rb->action;
-    r.reward = rb->reward;
-    r.terminal = rb->terminal;
-    r.capacity = rb->capacity;
-    r.n_env = rb->n_env;
-    r.head_sa = rb->head_sa;
-    r.head_rt = rb->head_rt;
+    r.ring = {(const uint8_t*)rb->state, rb->capacity, rb->n_env, rb->head_sa};
     r.total = (uint64_t)rb->len_rt * (uint64_t)rb->n_env;
     r.idx = idx;
     r.seed = seed;

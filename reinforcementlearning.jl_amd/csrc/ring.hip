@@ -9,9 +9,9 @@
 // In the reference the trajectory always lives in host RAM and the gather is a per-sample strided
 // memcpy followed by an H2D copy of the batch; here the ring never leaves HBM.
 //
-// Layout: one frame per slot.  Float32 observations with <= 4 components: transition-major, state[(slot * n_env + e) * obs_dim
-// + k] (see ring_transition_major below); everything else as pushed, state[(slot * obs_dim + k) * n_env + e]; action / reward /
-// terminal [slot * n_env + e].  One push = one contiguous frame per trace (coalesced 16 B/lane copies).
+// Layout: one frame per slot.  Float32 observations with <= 4 components: one 32-byte RECORD per (state slot, env) holding the
+// pushed tuple (s', a, r, t) -- ring_device.h; everything else as pushed, state[(slot * obs_dim + k) * n_env + e] with action /
+// reward / terminal [slot * n_env + e].  One push = one contiguous frame per trace (coalesced 16 B/lane copies).
 // Gather: the index tile of a workgroup is staged in LDS once (flat index -> physical state slot,
 // next slot, transition slot, env), then
 //   * small observations (CartPole: 4 floats): one lane per (sample, component) pair;
@@ -19,6 +19,7 @@
 //     streams the two frames with 16 B/lane loads -- the HBM-bandwidth stress of BASELINE config 5.
 // Algorithmic bytes per sample: 2 * (2 * obs_bytes + 9)  (SURVEY.md 8d).
 #include "common.h"
+#include "ring_device.h"
 
 namespace rlhip {
 
@@ -106,43 +107,31 @@ __global__ __launch_bounds__(256) void check_indices_kernel(const int64_t* __res
     }
 }
 
-// Float32 observations with <= 4 components (the classic-control envs; what the fused learners take) are stored
-// TRANSITION-major: state[(slot * n_env + e) * obs_dim + k] -- the reference's own order (a `(ns, N, capacity + 1)` column-major
-// array: RLTrajectories `CircularArraySARTSTraces(state = Float32 => (ns, N))`), so that one sample's state is one 16-byte read
-// instead of obs_dim reads in obs_dim cache lines.  Everything else (u8 frames, wider observations) keeps the frame as pushed:
-// state[(slot * obs_dim + k) * n_env + e].  The env's observation buffer is component-major (obs_dim x n_env), so the push of a
-// transition-major ring transposes: lane = env, obs_dim coalesced reads, one contiguous obs_dim-float store.
-__host__ __device__ inline bool ring_transition_major(int64_t obs_dim, int32_t elem_bytes) { return elem_bytes == 4 && obs_dim <= 4; }
-
+// Record rings (ring_device.h): the env's observation buffer is component-major (obs_dim x n_env), so the push transposes --
+// lane = env, OD coalesced reads, then the whole 32-byte record (state + the transition that arrived at it) as two 16-byte
+// stores; a wave writes 2 KB contiguous.  a == NULL: push!(trajectory, (state = s,)).
 template <int OD>
-__global__ __launch_bounds__(256) void push_frame_tm_kernel(float* __restrict__ dst, const float* __restrict__ obs, int64_t n,
-                                                            int32_t* __restrict__ a_dst, float* __restrict__ r_dst,
-                                                            uint8_t* __restrict__ t_dst, const int32_t* __restrict__ a,
-                                                            const float* __restrict__ r, const uint8_t* __restrict__ t) {
+__global__ __launch_bounds__(256) void push_record_kernel(void* __restrict__ rec, int64_t slot, const float* __restrict__ obs,
+                                                          int64_t n, const int32_t* __restrict__ a, const float* __restrict__ r,
+                                                          const uint8_t* __restrict__ t) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    float v[OD];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < OD; ++k) v[k] = obs[(int64_t)k * n + e];
-#pragma unroll
-    for (int k = 0; k < OD; ++k) dst[e * OD + k] = v[k];
-    if (a_dst) {
-        a_dst[e] = a[e];
-        r_dst[e] = r[e];
-        t_dst[e] = t[e];
-    }
+    if (a) ring_store_record(rec, slot, n, e, v, a[e], r[e], (uint32_t)t[e]);
+    else ring_store_state_only(rec, slot, n, e, v);
 }
 
-static int32_t push_frame_tm(float* dst, const float* obs, int64_t n, int64_t od, int32_t* a_dst, float* r_dst, uint8_t* t_dst,
-                             const int32_t* a, const float* r, const uint8_t* t, hipStream_t s) {
+static int32_t push_record(void* rec, int64_t slot, const float* obs, int64_t n, int64_t od, const int32_t* a, const float* r,
+                           const uint8_t* t, hipStream_t s) {
     const dim3 grid((unsigned)((n + 255) / 256));
-#define RLHIP_PUSH_TM(OD_) \
-    hipLaunchKernelGGL((push_frame_tm_kernel<OD_>), grid, dim3(256), 0, s, dst, obs, n, a_dst, r_dst, t_dst, a, r, t)
-    if (od == 4) RLHIP_PUSH_TM(4);
-    else if (od == 3) RLHIP_PUSH_TM(3);
-    else if (od == 2) RLHIP_PUSH_TM(2);
-    else RLHIP_PUSH_TM(1);
-#undef RLHIP_PUSH_TM
+#define RLHIP_PUSH_REC(OD_) hipLaunchKernelGGL((push_record_kernel<OD_>), grid, dim3(256), 0, s, rec, slot, obs, n, a, r, t)
+    if (od == 4) RLHIP_PUSH_REC(4);
+    else if (od == 3) RLHIP_PUSH_REC(3);
+    else if (od == 2) RLHIP_PUSH_REC(2);
+    else RLHIP_PUSH_REC(1);
+#undef RLHIP_PUSH_REC
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -226,43 +215,28 @@ __device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingV
     return flat;
 }
 
-// small observations with a compile-time size (OD <= 8 components: the classic-control envs): one LANE per sample, every
-// load of the sample (2 OD state components, action, reward, terminal: 11 for CartPole) issued before the first store --
-// the gather is a chain of dependent cache misses otherwise (the generic kernel above keeps two loads in flight per lane:
-// 163 us for 2^20 CartPole samples; profiles/r04_pmc.md).  Stores are coalesced (consecutive lanes = consecutive samples).
-template <typename E, int OD>
-__global__ __launch_bounds__(256) void gather_small_lane_kernel(RingView rb, const int64_t* __restrict__ idx, int64_t batch,
-                                                                E* __restrict__ s, int32_t* __restrict__ a,
-                                                                float* __restrict__ r, uint8_t* __restrict__ term,
-                                                                E* __restrict__ sn, PrioDraw pd) {
+// record rings (Float32 observations with OD <= 4 components: the classic-control envs): one LANE per sample, the three
+// 16-byte loads of the sample (state half of record(s), whole record(s')) issued before the first store -- two 32-byte
+// sectors per sample (round 4: five 64-byte lines; round 3: eleven).  Stores are coalesced (consecutive lanes = consecutive
+// samples).  Nothing is staged in LDS: a lane owns its sample from index to store (the tile-staged generic kernel above
+// is the route of the layouts without records).
+template <int OD>
+__global__ __launch_bounds__(256) void gather_rec_kernel(RingView rb, const int64_t* __restrict__ idx, int64_t batch,
+                                                         float* __restrict__ s, int32_t* __restrict__ a, float* __restrict__ r,
+                                                         uint8_t* __restrict__ term, float* __restrict__ sn, PrioDraw pd) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const int64_t j = pd.tree ? prio_draw_one(pd, rb, b) : idx[b];
-    const int64_t li = j / rb.n_env, e = j - li * rb.n_env;
-    const int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
-    const int64_t pn = (ps + 1 == rb.capacity + 1) ? 0 : ps + 1;
-    const int64_t pt = (rb.head_rt + li) % rb.capacity;
-    const E* st = (const E*)rb.state;
-    const E* p0 = st + (ps * rb.n_env + e) * OD;  // transition-major: the OD components of (slot, env) are contiguous
-    const E* p1 = st + (pn * rb.n_env + e) * OD;
-    E v0[OD], v1[OD];
+    const RingRecs rr = {(const uint8_t*)rb.state, rb.capacity, rb.n_env, rb.head_sa};
+    const RingTransition t = ring_load_transition(rr, j);
 #pragma unroll
     for (int k = 0; k < OD; ++k) {
-        v0[k] = p0[k];
-        v1[k] = p1[k];
+        s[k * batch + b] = t.s[k];
+        sn[k * batch + b] = t.sn[k];
     }
-    const int64_t o = pt * rb.n_env + e;
-    const int32_t av = rb.action[o];
-    const float rv = rb.reward[o];
-    const uint8_t tv = rb.terminal[o];
-#pragma unroll
-    for (int k = 0; k < OD; ++k) {
-        s[k * batch + b] = v0[k];
-        sn[k * batch + b] = v1[k];
-    }
-    a[b] = av;
-    r[b] = rv;
-    term[b] = tv;
+    a[b] = t.a;
+    r[b] = t.r;
+    term[b] = (uint8_t)t.t;
 }
 
 // large contiguous frames (n_env == 1): one workgroup per sample, 16 B/lane streaming copy.
@@ -451,9 +425,8 @@ static int32_t push_state_frame(rlhip_ring* rb, const void* obs, hipStream_t s) 
         phys = rb->head_sa;  // overwrite the oldest frame; it becomes the newest
         rb->head_sa = (rb->head_sa + 1) % frames;
     }
-    if (ring_transition_major(rb->obs_dim, rb->elem_bytes) && rb->n_env > 1)
-        return push_frame_tm((float*)((uint8_t*)rb->state + phys * fbytes), (const float*)obs, rb->n_env, rb->obs_dim, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, s);
+    if (rb->layout == RLHIP_RING_RECORDS)
+        return push_record(rb->state, phys, (const float*)obs, rb->n_env, rb->obs_dim, nullptr, nullptr, nullptr, s);
     return copy_bytes((uint8_t*)rb->state + phys * fbytes, obs, fbytes, s);
 }
 
@@ -468,7 +441,19 @@ int32_t rlhip_ring_init(rlhip_ring* rb, int64_t capacity, int64_t n_env, int64_t
     RLHIP_REQUIRE(rb != nullptr, "ring is NULL");
     RLHIP_REQUIRE(capacity >= 1 && n_env >= 1 && obs_dim >= 1, "capacity, n_env, obs_dim must be >= 1");
     RLHIP_REQUIRE(elem_bytes == 4 || elem_bytes == 1, "elem_bytes must be 4 (Float32) or 1 (UInt8)");
-    RLHIP_REQUIRE(state && action && reward && terminal, "trace storage is NULL");
+    RLHIP_REQUIRE(state != nullptr, "trace storage is NULL");
+    const bool records = ring_records(obs_dim, elem_bytes);
+    if (records) {
+        // the action / reward / terminal traces live inside the 32-byte records of `state` (ring_device.h): a host built
+        // against the ABI-1 header (separate arrays, transition-major states) must fail here, not read transposed data later
+        RLHIP_REQUIRE(!action && !reward && !terminal,
+                      "record ring (Float32, obs_dim <= 4): pass NULL for action / reward / terminal and a state buffer of "
+                      "rlhip_ring_state_bytes() bytes (ABI 2)");
+        RLHIP_REQUIRE(((uintptr_t)state & 31) == 0, "the record buffer must be 32-byte aligned");
+    } else {
+        RLHIP_REQUIRE(action && reward && terminal, "trace storage is NULL");
+    }
+    rb->layout = records ? RLHIP_RING_RECORDS : RLHIP_RING_FRAMES;
     rb->capacity = capacity;
     rb->n_env = n_env;
     rb->obs_dim = obs_dim;
@@ -480,6 +465,14 @@ int32_t rlhip_ring_init(rlhip_ring* rb, int64_t capacity, int64_t n_env, int64_t
     rb->terminal = terminal;
     return RLHIP_OK;
 }
+
+int64_t rlhip_ring_state_bytes(int64_t capacity, int64_t n_env, int64_t obs_dim, int32_t elem_bytes) {
+    if (capacity < 1 || n_env < 1 || obs_dim < 1 || (elem_bytes != 4 && elem_bytes != 1)) return 0;
+    if (ring_records(obs_dim, elem_bytes)) return (capacity + 1) * n_env * (int64_t)RING_REC_BYTES;
+    return (capacity + 1) * n_env * obs_dim * (int64_t)elem_bytes;
+}
+
+int32_t rlhip_ring_layout(const rlhip_ring* rb) { return rb ? rb->layout : -1; }
 
 int32_t rlhip_ring_push_state(rlhip_ring* rb, const void* obs, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb != nullptr && obs != nullptr, "NULL argument");
@@ -501,12 +494,12 @@ int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const i
     // slot of the new state frame (same bookkeeping as push_state_frame)
     const int64_t sframes = rb->capacity + 1;
     const int64_t fbytes = rb->obs_dim * rb->n_env * (int64_t)rb->elem_bytes;
-    uint8_t* sdst = (uint8_t*)rb->state + ((rb->len_sa < sframes) ? (rb->head_sa + rb->len_sa) % sframes : rb->head_sa) * fbytes;
-    if (ring_transition_major(rb->obs_dim, rb->elem_bytes) && n > 1) {  // transposing push + the three per-env traces, one launch
+    const int64_t sphys = (rb->len_sa < sframes) ? (rb->head_sa + rb->len_sa) % sframes : rb->head_sa;
+    uint8_t* sdst = (uint8_t*)rb->state + sphys * fbytes;
+    if (rb->layout == RLHIP_RING_RECORDS) {  // the pushed tuple IS one record: transposing push, one launch
         if (rb->len_sa < sframes) rb->len_sa += 1;
         else rb->head_sa = (rb->head_sa + 1) % sframes;
-        return push_frame_tm((float*)sdst, (const float*)next_obs, n, rb->obs_dim, rb->action + phys * n, rb->reward + phys * n,
-                             rb->terminal + phys * n, action, reward, terminal, s);
+        return push_record(rb->state, sphys, (const float*)next_obs, n, rb->obs_dim, action, reward, terminal, s);
     }
     if ((((uintptr_t)sdst | (uintptr_t)next_obs | (uintptr_t)fbytes) & 15) == 0 && fbytes <= (64ll << 20)) {
         if (rb->len_sa < sframes) rb->len_sa += 1;
@@ -595,7 +588,7 @@ int32_t rlhip_ring_sample_gather_prioritized(const rlhip_ring* rb, const float* 
     const int64_t n_leaves = rb->capacity * rb->n_env;
     int64_t P = 1;
     while (P < n_leaves) P <<= 1;
-    const bool fused = rlhip_ring_gather_is_frame_major(rb) || (rb->elem_bytes == 4 && rb->obs_dim >= 1 && rb->obs_dim <= 4);
+    const bool fused = rlhip_ring_gather_is_frame_major(rb) || rb->layout == RLHIP_RING_RECORDS;
     if (!fused) {  // layouts without a fused kernel (u8 / wide small observations): the two launches
         int32_t rc = rlhip_ring_sample_prioritized(rb, tree, batch, seed, draw_ctr, idx_out, key_out, prio_out, stream);
         if (rc) return rc;
@@ -619,10 +612,10 @@ static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_
                            (uint8_t*)s, a, r, term, (uint8_t*)s_next, pd);
     } else {
         int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
-        const bool lane = rb->elem_bytes == 4 && rb->obs_dim >= 1 && rb->obs_dim <= 4;
-#define RLHIP_GATHER_LANE(OD)                                                                                             \
-    hipLaunchKernelGGL((gather_small_lane_kernel<float, OD>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v, idx, \
-                       batch, (float*)s, a, r, term, (float*)s_next, pd)
+        const bool lane = rb->layout == RLHIP_RING_RECORDS;
+#define RLHIP_GATHER_LANE(OD)                                                                                      \
+    hipLaunchKernelGGL((gather_rec_kernel<OD>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v, idx, batch, \
+                       (float*)s, a, r, term, (float*)s_next, pd)
         if (lane && rb->obs_dim == 4) RLHIP_GATHER_LANE(4);
         else if (lane && rb->obs_dim == 3) RLHIP_GATHER_LANE(3);
         else if (lane && rb->obs_dim == 2) RLHIP_GATHER_LANE(2);
@@ -643,7 +636,7 @@ int32_t rlhip_ring_gather_stacked(const rlhip_ring* rb, const int64_t* idx, int6
                                   int32_t* a, float* r, uint8_t* term, void* s_next, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb && idx && s && a && r && term && s_next && batch >= 0, "bad arguments");
     RLHIP_REQUIRE(n_stack >= 1 && n_stack <= MAX_STACK, "n_stack must be in 1..8");
-    RLHIP_REQUIRE(rb->n_env == 1, "stack-at-sample gather is defined for single-env frame rings");
+    RLHIP_REQUIRE(rb->n_env == 1 && rb->layout == RLHIP_RING_FRAMES, "stack-at-sample gather is defined for single-env frame rings");
     const int64_t frame_bytes = rb->obs_dim * (int64_t)rb->elem_bytes;
     RLHIP_REQUIRE(frame_bytes % 16 == 0, "frame size must be a multiple of 16 bytes");
     RLHIP_REQUIRE(((((uintptr_t)rb->state | (uintptr_t)s | (uintptr_t)s_next) & 15) == 0), "buffers must be 16-byte aligned");

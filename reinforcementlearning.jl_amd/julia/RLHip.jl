@@ -51,7 +51,7 @@ function __init__()
     n = Ref{Int32}(0)
     chk(ccall((:rlhip_device_count, LIB), Int32, (Ref{Int32},), n))
     n[] >= 1 || error("rlhip: no gfx950 device visible -- there is no CPU fallback for this path")
-    ccall((:rlhip_abi_version, LIB), Int32, ()) == 1 || error("rlhip: ABI version mismatch")
+    ccall((:rlhip_abi_version, LIB), Int32, ()) == 2 || error("rlhip: ABI version mismatch")
     chk(ccall((:rlhip_set_device, LIB), Int32, (Int32,), parse(Int32, get(ENV, "RLHIP_DEVICE", "0"))))
     chk(ccall((:rlhip_stream_create, LIB), Int32, (Ref{Ptr{Cvoid}},), STREAM))
 end
@@ -136,8 +136,9 @@ mutable struct Ring     # rlhip_ring (mutable: the push calls advance its host-s
     capacity::Int64; n_env::Int64; obs_dim::Int64
     head_sa::Int64; len_sa::Int64; head_rt::Int64; len_rt::Int64
     elem_bytes::Int32
+    layout::Int32       # RING_FRAMES | RING_RECORDS (set by rlhip_ring_init)
     state::Ptr{Cvoid}; action::Ptr{Cvoid}; reward::Ptr{Cvoid}; terminal::Ptr{Cvoid}
-    Ring() = new(0, 0, 0, 0, 0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL)
+    Ring() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL)
 end
 struct PPOCfg           # rlhip_ppo_cfg (blog a_practical_introduction_to_RL.jl/index.html:15257-15278)
     gamma::Float32; lambda::Float32; clip_range::Float32; max_grad_norm::Float32
@@ -347,8 +348,15 @@ function on_sample!(c::InsertSampleRatioController)
     false
 end
 
+const RING_FRAMES = Int32(0)     # include/rlhip.h RLHIP_RING_FRAMES: every trace as pushed
+const RING_RECORDS = Int32(2)    # RLHIP_RING_RECORDS: Float32 observations with <= 4 components, one 32-byte record
+                                 # {s[4], action::Int32, reward::Float32, terminal::UInt32, spare} per (state slot, env)
 mutable struct HipTrajectory{E}
     rb::Ring
+    # RING_FRAMES: the four traces; RING_RECORDS: `state` is the record buffer (8 Float32 words per record, (capacity + 1) *
+    # n_env records: unsafe_wrap it as an (8, n_env, capacity + 1) array -- rows 1:obs_dim are the reference's state trace,
+    # rows 5 / 6 / 7 reinterpret as the action / reward / terminal of the transition that arrived at that state) and the
+    # other three are empty
     state::DevBuf{E}; action::DevBuf{Int32}; reward::DevBuf{Float32}; terminal::DevBuf{UInt8}
     batchsize::Int
     sampler_seed::UInt64
@@ -360,13 +368,16 @@ end
 function HipTrajectory(; capacity, n_env, obs_dim, batchsize = 32, E = Float32, seed = 0,
                        controller = InsertSampleRatioController())
     rb = Ring()
-    # Float32 observations with <= 4 components: the library keeps this buffer transition-major, i.e. exactly the reference's
-    # (obs_dim, n_env, capacity + 1) column-major array (unsafe_wrap it as such); u8 frames / wider observations: (n_env, obs_dim, capacity + 1)
-    st = DevBuf{E}((capacity + 1) * obs_dim * n_env)
-    a, r, t = DevBuf{Int32}(capacity * n_env), DevBuf{Float32}(capacity * n_env), DevBuf{UInt8}(capacity * n_env)
+    bytes = ccall((:rlhip_ring_state_bytes, LIB), Int64, (Int64, Int64, Int64, Int32), capacity, n_env, obs_dim, sizeof(E))
+    records = E === Float32 && obs_dim <= 4
+    st = DevBuf{E}(bytes ÷ sizeof(E))
+    a, r, t = records ? (DevBuf{Int32}(0), DevBuf{Float32}(0), DevBuf{UInt8}(0)) :
+              (DevBuf{Int32}(capacity * n_env), DevBuf{Float32}(capacity * n_env), DevBuf{UInt8}(capacity * n_env))
     chk(ccall((:rlhip_ring_init, LIB), Int32,
               (Ref{Ring}, Int64, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-              rb, capacity, n_env, obs_dim, sizeof(E), st.ptr, a.ptr, r.ptr, t.ptr))
+              rb, capacity, n_env, obs_dim, sizeof(E), st.ptr, records ? C_NULL : a.ptr, records ? C_NULL : r.ptr,
+              records ? C_NULL : t.ptr))
+    ccall((:rlhip_ring_layout, LIB), Int32, (Ref{Ring},), rb) == (records ? RING_RECORDS : RING_FRAMES) || error("rlhip: unexpected ring layout")
     HipTrajectory{E}(rb, st, a, r, t, batchsize, UInt64(seed), UInt32(0), controller, DevBuf{Int64}(batchsize),
                      DevBuf{E}(obs_dim * batchsize), DevBuf{E}(obs_dim * batchsize), DevBuf{Int32}(batchsize),
                      DevBuf{Float32}(batchsize), DevBuf{UInt8}(batchsize))

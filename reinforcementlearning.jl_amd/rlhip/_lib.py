@@ -87,7 +87,7 @@ class DqnStepArgs(C.Structure):
 class Ring(C.Structure):
     _fields_ = [(n, i64) for n in ("capacity", "n_env", "obs_dim", "head_sa", "len_sa", "head_rt",
                                    "len_rt")] + \
-               [("elem_bytes", i32), ("state", vp), ("action", vp), ("reward", vp), ("terminal", vp)]
+               [("elem_bytes", i32), ("layout", i32), ("state", vp), ("action", vp), ("reward", vp), ("terminal", vp)]
 
 
 class PPOCfg(C.Structure):
@@ -163,6 +163,8 @@ _PROTOS = {
     "rlhip_huber_f32": (i32, [vp, vp, i64, f32, vp, vp, vp]),
     "rlhip_td_target_f32": (i32, [vp, i64, i64, i64, i64, vp, vp, f32, vp, vp]),
     "rlhip_ring_init": (i32, [P(Ring), i64, i64, i64, i32, vp, vp, vp, vp]),
+    "rlhip_ring_state_bytes": (i64, [i64, i64, i64, i32]),
+    "rlhip_ring_layout": (i32, [P(Ring)]),
     "rlhip_ring_push_state": (i32, [P(Ring), vp, vp]),
     "rlhip_ring_push_transition": (i32, [P(Ring), vp, vp, vp, vp, vp]),
     "rlhip_ring_length": (i64, [P(Ring)]),
@@ -272,8 +274,14 @@ for _name, (_res, _args) in _PROTOS.items():
     _f.argtypes = _args
     if _res is i32 and _name not in ("rlhip_abi_version", "rlhip_env_obs_dim", "rlhip_env_state_dim",
                                      "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported", "rlhip_p2p_can_access",
-                                     "rlhip_ring_bounds_checked_build"):
+                                     "rlhip_ring_bounds_checked_build", "rlhip_ring_layout"):
         _STATUS.add(_name)
+
+# this host is written for ABI 2 (record rings, sized PPO workspaces): a stale in-tree library must not be driven with it
+EXPECTED_ABI = 2
+if lib.rlhip_abi_version() != EXPECTED_ABI:
+    raise ImportError(f"{LIB_PATH} reports ABI {lib.rlhip_abi_version()}, this host needs {EXPECTED_ABI}: rebuild it "
+                      "(python reinforcementlearning.jl_amd/build.py)")
 
 
 def last_error():

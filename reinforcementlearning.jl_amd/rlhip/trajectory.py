@@ -24,19 +24,40 @@ class CircularArraySARTSTraces:
             raise TypeError("state eltype must be Float32 or UInt8")
         dev = torch.device(device)
         self.capacity, self.n_env, self.obs_dim, self.dtype = capacity, n_env, obs_dim, dtype
-        # Float32 observations with <= 4 components are stored transition-major (csrc/ring.hip ring_transition_major): the
-        # tensor's shape says so -- (capacity + 1, n_env, obs_dim) row-major IS the reference's (obs_dim, n_env, capacity + 1)
-        # column-major array, which is what a checkpoint of this tensor hands to JLD2; other rings keep the frame as pushed
-        self.transition_major = dtype == torch.float32 and obs_dim <= 4
-        self.state = torch.zeros((capacity + 1, n_env, obs_dim) if self.transition_major else (capacity + 1, obs_dim, n_env),
-                                 dtype=dtype, device=dev)
-        self.action = torch.zeros((capacity, n_env), dtype=torch.int32, device=dev)
-        self.reward = torch.zeros((capacity, n_env), dtype=torch.float32, device=dev)
-        self.terminal = torch.zeros((capacity, n_env), dtype=torch.uint8, device=dev)
+        # Float32 observations with <= 4 components live in a RECORD ring (csrc/ring_device.h, include/rlhip.h RLHIP_RING_RECORDS):
+        # one 32-byte record {s[4], action, reward, terminal, spare} per (state slot, env) -- the tuple a PostActStage push
+        # writes -- so that a sampled transition is two 32-byte sectors.  `records` is the storage (and what a checkpoint
+        # holds); `state` / `action` / `reward` / `terminal` are strided VIEWS of it, indexed by the record's slot (capacity + 1
+        # slots; action / reward / terminal of a record belong to the transition that ARRIVED at its state).  Other rings
+        # (UInt8 frames, wider observations) keep one tensor per trace, every frame as pushed.
+        self.records_layout = dtype == torch.float32 and obs_dim <= 4
         self.rb = _lib.Ring()
-        call("rlhip_ring_init", C.byref(self.rb), capacity, n_env, obs_dim, 4 if dtype == torch.float32 else 1,
-             ptr(self.state), ptr(self.action), ptr(self.reward), ptr(self.terminal))
+        if self.records_layout:
+            self.records = torch.zeros((capacity + 1, n_env, 8), dtype=torch.float32, device=dev)
+            assert self.records.numel() * 4 == int(_lib.lib.rlhip_ring_state_bytes(capacity, n_env, obs_dim, 4))
+            call("rlhip_ring_init", C.byref(self.rb), capacity, n_env, obs_dim, 4, ptr(self.records), None, None, None)
+        else:
+            self.state = torch.zeros((capacity + 1, obs_dim, n_env), dtype=dtype, device=dev)
+            self.action = torch.zeros((capacity, n_env), dtype=torch.int32, device=dev)
+            self.reward = torch.zeros((capacity, n_env), dtype=torch.float32, device=dev)
+            self.terminal = torch.zeros((capacity, n_env), dtype=torch.uint8, device=dev)
+            call("rlhip_ring_init", C.byref(self.rb), capacity, n_env, obs_dim, 4 if dtype == torch.float32 else 1,
+                 ptr(self.state), ptr(self.action), ptr(self.reward), ptr(self.terminal))
+        assert int(_lib.lib.rlhip_ring_layout(C.byref(self.rb))) == (2 if self.records_layout else 0)
         self.frame_major = bool(_lib.lib.rlhip_ring_gather_is_frame_major(C.byref(self.rb)))
+
+    def __getattr__(self, name):
+        # record rings only (frame rings own real tensors of these names): strided views of `records`
+        if name in ("state", "action", "reward", "terminal") and self.__dict__.get("records_layout"):
+            rec = self.__dict__["records"]
+            if name == "state":
+                return rec[:, :, :self.obs_dim]          # (capacity + 1, n_env, obs_dim)
+            if name == "action":
+                return rec.view(torch.int32)[:, :, 4]    # (capacity + 1, n_env), by the slot of the transition's s'
+            if name == "reward":
+                return rec[:, :, 5]
+            return rec.view(torch.uint8)[:, :, 24]       # low byte of the terminal word
+        raise AttributeError(name)
 
     def push_state_(self, obs):
         """push!(traces, (state = s,))"""

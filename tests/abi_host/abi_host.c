@@ -138,11 +138,15 @@ static void run_dqn(void) {
     void* workspace = dmalloc((size_t)rlhip_dqn_workspace_bytes(ns, h, na, batch)); /* zeroed: ABI contract */
 
     rlhip_ring ring;
-    void* r_state = dmalloc(sizeof(float) * (size_t)((capacity + 1) * ns * n));
-    int32_t* r_action = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(capacity * n));
-    float* r_reward = (float*)dmalloc(sizeof(float) * (size_t)(capacity * n));
-    uint8_t* r_term = (uint8_t*)dmalloc((size_t)(capacity * n));
-    CK(rlhip_ring_init(&ring, capacity, n, ns, 4, r_state, r_action, r_reward, r_term));
+    /* Float32 observations with <= 4 components: a RECORD ring (RLHIP_RING_RECORDS, ABI 2) -- one allocation of
+     * rlhip_ring_state_bytes(), no separate action / reward / terminal traces */
+    const size_t r_bytes = (size_t)rlhip_ring_state_bytes(capacity, n, ns, 4);
+    void* r_state = dmalloc(r_bytes);
+    CK(rlhip_ring_init(&ring, capacity, n, ns, 4, r_state, NULL, NULL, NULL));
+    if (rlhip_ring_layout(&ring) != RLHIP_RING_RECORDS) {
+        fprintf(stderr, "expected a record ring\n");
+        exit(3);
+    }
     /* push!(agent, PreEpisodeStage(), env): the first state (agent_base.jl:45-47) */
     CK(rlhip_ring_push_state(&ring, env.obs, g_stream));
 
@@ -211,10 +215,7 @@ static void run_dqn(void) {
     dump("dqn.m", m, 4, (size_t)np);
     dump("dqn.v", v, 4, (size_t)np);
     dump("dqn.loss", loss, 4, 1);
-    dump("dqn.ring.state", r_state, 4, (size_t)((capacity + 1) * ns * n));
-    dump("dqn.ring.action", r_action, 4, (size_t)(capacity * n));
-    dump("dqn.ring.reward", r_reward, 4, (size_t)(capacity * n));
-    dump("dqn.ring.term", r_term, 1, (size_t)(capacity * n));
+    dump("dqn.ring.records", r_state, 4, r_bytes / 4);
     for (int k = 0; k < 4; ++k) {
         char nm[16];
         snprintf(nm, sizeof(nm), "dqn.env.s%d", k);
@@ -222,7 +223,7 @@ static void run_dqn(void) {
     }
     dump("dqn.env.t", env.st.t, 4, (size_t)n);
     dump("dqn.env.obs", env.obs, 4, (size_t)(4 * n));
-    void* frees[] = {params, target, m, v, grad, beta_pow, loss, gn, actions, q, workspace, r_state, r_action, r_reward, r_term};
+    void* frees[] = {params, target, m, v, grad, beta_pow, loss, gn, actions, q, workspace, r_state};
     for (size_t i = 0; i < sizeof(frees) / sizeof(frees[0]); ++i) CK(rlhip_free(frees[i]));
     free_env(&env);
 }
@@ -506,11 +507,9 @@ static int run_time(int steps) {
         CK(rlhip_memcpy_h2d(beta_pow, b0, 8, g_stream));
         void* workspace = dmalloc((size_t)rlhip_dqn_workspace_bytes(ns, h, na, batch));
         rlhip_ring ring;
-        void* r_state = dmalloc(sizeof(float) * (size_t)((capacity + 1) * ns * n));
-        int32_t* r_action = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(capacity * n));
-        float* r_reward = (float*)dmalloc(sizeof(float) * (size_t)(capacity * n));
-        uint8_t* r_term = (uint8_t*)dmalloc((size_t)(capacity * n));
-        CK(rlhip_ring_init(&ring, capacity, n, ns, 4, r_state, r_action, r_reward, r_term));
+        const size_t r_bytes = (size_t)rlhip_ring_state_bytes(capacity, n, ns, 4);
+        void* r_state = dmalloc(r_bytes);
+        CK(rlhip_ring_init(&ring, capacity, n, ns, 4, r_state, NULL, NULL, NULL));
         CK(rlhip_ring_push_state(&ring, env.obs, g_stream));
         rlhip_dqn_step_args a;
         memset(&a, 0, sizeof(a));
@@ -542,7 +541,7 @@ static int run_time(int steps) {
         CK(rlhip_stream_sync(g_stream));
         us[fused] = (now_s() - t0) / steps * 1e6;
         CK(rlhip_memcpy_d2h(&loss_h[fused], loss, 4, g_stream));
-        void* frees[] = {params, target, m, v, grad, beta_pow, loss, gn, actions, q, workspace, r_state, r_action, r_reward, r_term};
+        void* frees[] = {params, target, m, v, grad, beta_pow, loss, gn, actions, q, workspace, r_state};
         for (size_t i = 0; i < sizeof(frees) / sizeof(frees[0]); ++i) CK(rlhip_free(frees[i]));
         free_env(&env);
     }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_error_reporting():
-    assert _lib.lib.rlhip_abi_version() == 1
+    assert _lib.lib.rlhip_abi_version() == 2 == _lib.EXPECTED_ABI
     # argument validation happens before any HIP call: NULL output pointer -> RLHIP_EINVAL + message
     with pytest.raises(_lib.RLHipArgumentError) as e:
         _lib.call("rlhip_fill_uniform_f32", None, 16, 0, 0, 0, None)

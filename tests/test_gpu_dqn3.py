@@ -190,7 +190,7 @@ def test_dqn3_update_is_bit_identical_to_grad_clip_adam_pack(kind, batch, clip):
     tr.state.normal_()
     tr.action.random_(0, na)
     tr.reward.normal_()
-    tr.terminal.copy_((torch.rand(32, n, device="cuda") < 0.1).to(torch.uint8))
+    tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.1).to(torch.uint8))
     tr.rb.len_sa, tr.rb.len_rt = 33, 32
     tp = dqn.mlp3_init(ns, h, na, 2, 1)
     tpk = dqn.mlp3_pack(tp, ns, h, na)

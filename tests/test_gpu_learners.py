@@ -407,7 +407,7 @@ def test_dqn_grad_on_explicit_indices_and_prioritized_learner():
     tr.state.normal_()
     tr.action.random_(0, na)
     tr.reward.normal_()
-    tr.terminal.copy_((torch.rand(32, n, device="cuda") < 0.1).to(torch.uint8))
+    tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.1).to(torch.uint8))
     tr.rb.len_sa, tr.rb.len_rt = 33, 32
     p, tp = ops.mlp2_init(ns, h, na, 1, 0), ops.mlp2_init(ns, h, na, 2, 0)
     g0, l0 = dqn.dqn_grad(tr, h, na, 0, p, tp, batch, 0.99, 1.0, 9, 4)
@@ -467,7 +467,7 @@ def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip):
     tr.state.normal_()
     tr.action.random_(0, na)
     tr.reward.normal_()
-    tr.terminal.copy_((torch.rand(32, n, device="cuda") < 0.1).to(torch.uint8))
+    tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.1).to(torch.uint8))
     tr.rb.len_sa, tr.rb.len_rt = 33, 32
     tp = ops.mlp2_init(ns, h, na, 2, 0)
     st = []

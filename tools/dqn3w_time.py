@@ -18,7 +18,7 @@ tr = rlhip.CircularArraySARTSTraces(capacity=256, n_env=n, obs_dim=4)
 tr.state.normal_()
 tr.action.random_(0, 2)
 tr.reward.normal_()
-tr.terminal.copy_((torch.rand(256, n, device="cuda") < 0.05).to(torch.uint8))
+tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.05).to(torch.uint8))
 tr.rb.len_sa, tr.rb.len_rt = 257, 256
 net = rlhip.HipApproximator(4, h, 2, seed=5, layers=3)
 tn = rlhip.TargetNetwork(net, sync_freq=100)
