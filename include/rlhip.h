@@ -225,6 +225,14 @@ int32_t rlhip_eps_greedy_select_f32(const float* values, int64_t na, int64_t n, 
                                     int64_t i_stride, const uint8_t* mask, double eps,
                                     int32_t is_break_tie, uint64_t seed, uint32_t env_id_base,
                                     uint32_t step, int32_t* actions, rlhip_stream_t stream);
+/* prob(::EpsilonGreedyExplorer, values[, mask]) for n envs  epsilon_greedy_explorer.jl:141-194 (the vector the reference wraps
+ * in Categorical(probs; check_args = false); pinned by RLCore/test/policies/explorers/epsilon_greedy_explorer.jl:45-73):
+ *   probs[k] = eps / n_legal on legal actions, 0 on masked ones; + (1 - eps) on findmax(values[, mask]) (is_break_tie = 0),
+ *   or + (1 - eps) / c on each of the c entries of find_all_max(values[, mask]) (is_break_tie = 1).
+ * probs: f64, same (k_stride, i_stride) addressing as values.  Float64 like the reference (eps is a Float64). */
+int32_t rlhip_eps_greedy_prob_f32(const float* values, int64_t na, int64_t n, int64_t k_stride, int64_t i_stride,
+                                  const uint8_t* mask, double eps, int32_t is_break_tie, double* probs,
+                                  rlhip_stream_t stream);
 /* get_eps  epsilon_greedy_explorer.jl:69-88 (host-side scalar; kind 0 = linear, 1 = exp) */
 double rlhip_get_eps(int32_t kind, double eps_stable, double eps_init, int64_t warmup_steps,
                      int64_t decay_steps, int64_t step);
@@ -705,9 +713,18 @@ int32_t rlhip_ppo_gae_f32(const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                           const rlhip_ppo_traj* traj_host, rlhip_stream_t stream);
 /* workspace (device) needed by rlhip_ppo_grad_f32 / rlhip_ppo_update_f32, in bytes, for trajectories of up to n x T entries
  * (two-layer nets: partial gradient rows, the unit-record image, and 32 bytes per
- * trajectory entry for the sample records an update call packs once -- none above 2^24 entries).  The caller must
- * ZERO-INITIALISE it once after allocation (it holds counters and epoch words that the kernels maintain themselves). */
+ * trajectory entry for the sample records an update call packs once -- none above 2^24 entries).  It must be zero-initialised
+ * once after allocation (it holds counters and epoch words that the kernels maintain themselves): rlhip_ppo_workspace_init
+ * does that and registers its size. */
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T);
+/* ABI 2: REGISTER a workspace before its first use: zero-fills `bytes` bytes on `stream` (the counters and epoch words the
+ * kernels maintain) and records (pointer -> bytes) in a host-side table.  Every rlhip_ppo_grad* / rlhip_ppo_apply_f32 /
+ * rlhip_ppo_update* call compares rlhip_ppo_workspace_bytes(kind, cfg, n, T) of THAT call with the registered size and returns
+ * RLHIP_EINVAL when it is larger -- or when the workspace was never registered -- instead of writing sample records past the
+ * allocation (ABI 1: "the ABI carries no size to check").  Re-registering a pointer replaces its entry;
+ * rlhip_ppo_workspace_release drops it (call it before freeing the memory). */
+int32_t rlhip_ppo_workspace_init(void* workspace, int64_t bytes, rlhip_stream_t stream);
+int32_t rlhip_ppo_workspace_release(void* workspace);
 /* loss + flat gradient of micro-batch `mb` of epoch `epoch_ctr` (samples = keyed permutation of the
  * T*n transitions).  grad_out: f32[nparams]; losses_out (nullable): f32[4] = loss, actor, critic, entropy */
 int32_t rlhip_ppo_grad_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
@@ -748,7 +765,8 @@ int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, i
  * update calls.  Two-layer networks: one pack launch per call, then two launches per optimiser step (gradient tiles; partial
  * reduction + norm exchange + clip + Adam + record refresh).  WORKSPACE SIZE: the call writes 32 bytes per trajectory entry
  * (n * T of THIS call) of sample records behind the fixed part of the workspace -- the workspace must have been sized by
- * rlhip_ppo_workspace_bytes(kind, cfg, n, T) for the LARGEST n * T it is ever used with; the ABI carries no size to check. */
+ * rlhip_ppo_workspace_bytes(kind, cfg, n, T) for the LARGEST n * T it is ever used with and registered with
+ * rlhip_ppo_workspace_init; a call that needs more than was registered returns RLHIP_EINVAL (ABI 2). */
 int32_t rlhip_ppo_update_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, int64_t n, int64_t T,
                              const rlhip_ppo_traj* traj_host, float* params, float* m, float* v,
                              float* beta_pow, uint64_t seed, uint32_t update_ctr, void* workspace,

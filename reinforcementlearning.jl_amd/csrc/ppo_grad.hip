@@ -19,6 +19,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow,
                                        int64_t n, float grad_scale, float clip_norm, float lr, float beta1,
@@ -541,6 +543,37 @@ static float* workspace_packed(void* workspace, int64_t np) {
     return (float*)pq;
 }
 
+// ---- sized workspaces (ABI 2) --------------------------------------------------------------
+// rlhip_ppo_update_f32 writes 32 bytes of sample records per trajectory entry behind the fixed part of the workspace, and the
+// ABI-1 calls carried no size to check that against.  rlhip_ppo_workspace_init registers (pointer -> bytes) in a host-side table;
+// every entry point that takes a workspace looks its pointer up and compares with rlhip_ppo_workspace_bytes(kind, cfg, n, T) of
+// THIS call: too small, or never registered, is RLHIP_EINVAL instead of a write past the allocation.
+static std::mutex g_ws_mutex;
+static std::unordered_map<const void*, int64_t>& ws_table() {
+    static std::unordered_map<const void*, int64_t> t;
+    return t;
+}
+static int32_t ws_check(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const void* workspace) {
+    RLHIP_REQUIRE(cfg && workspace, "NULL argument");
+    const int64_t need = rlhip_ppo_workspace_bytes(kind, cfg, n, T);
+    RLHIP_REQUIRE(need > 0, "bad configuration");
+    int64_t have = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mutex);
+        auto it = ws_table().find(workspace);
+        if (it != ws_table().end()) have = it->second;
+    }
+    RLHIP_REQUIRE(have >= 0, "this workspace was never registered: call rlhip_ppo_workspace_init(workspace, bytes, stream) once "
+                             "after allocating it (ABI 2)");
+    if (have < need) {
+        set_error("invalid argument: workspace of %lld bytes is too small for n = %lld, T = %lld (needs %lld: size it by "
+                  "rlhip_ppo_workspace_bytes for the largest n * T it is used with)", (long long)have, (long long)n, (long long)T,
+                  (long long)need);
+        return RLHIP_EINVAL;
+    }
+    return RLHIP_OK;
+}
+
 static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T, const rlhip_ppo_traj* traj,
                             const float* params, uint64_t seed, uint32_t epoch_ctr, int32_t mb, void* workspace,
                             GradLaunch* out, const uint32_t* ctr = nullptr) {
@@ -548,6 +581,7 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;
     RLHIP_REQUIRE(traj && params && workspace, "NULL argument");
+    if ((rc = ws_check(kind, cfg, n, T, workspace))) return rc;
     RLHIP_REQUIRE(pd.h <= 256 && pd.h % NW == 0, "the fused gradient kernel supports hidden <= 256, multiple of 8");
     RLHIP_REQUIRE(pd.nout_a <= GMAXO, "the fused gradient kernel supports at most 3 actor outputs");
     RLHIP_REQUIRE(n >= 1 && T >= 1 && n * T <= 0x7FFFFFFFll, "n * T out of range");
@@ -724,6 +758,20 @@ static void pack_for_update(const GradLaunch& L, float4* samples, hipStream_t s)
                        L.g.pd.np_a, ga, samples);
 }
 
+int32_t rlhip_ppo_workspace_init(void* workspace, int64_t bytes, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(workspace != nullptr && bytes > 0, "bad arguments");
+    RLHIP_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)bytes, as_stream(stream)));
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    ws_table()[workspace] = bytes;
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ppo_workspace_release(void* workspace) {
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    ws_table().erase(workspace);
+    return RLHIP_OK;
+}
+
 int64_t rlhip_ppo_workspace_bytes(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int64_t T) {
     if (is_layers3(cfg)) return ppo3_workspace_bytes(kind, cfg, n, T);
     int64_t np = rlhip_ppo_nparams(kind, cfg);
@@ -739,6 +787,7 @@ static int32_t grad_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, int
     RLHIP_REQUIRE(grad_out != nullptr, "grad_out is NULL");
     if (is_layers3(cfg)) {
         RLHIP_REQUIRE(ctr == nullptr, "layers = 3: the device-counter (graph replay) variant is not built");
+        if (int32_t rcw = ws_check(kind, cfg, n, T, workspace)) return rcw;
         return ppo3_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, grad_out, losses_out, true, stream);
     }
     GradLaunch L;
@@ -780,11 +829,10 @@ int32_t rlhip_ppo_apply_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     if (is_layers3(cfg) || np > 16 * 1024)  // generic path: fused clip + Adam; the next grad call re-packs
         return rlhip_clip_adam_f32(params, grad, m, v, beta_pow, np, grad_scale, cfg->max_grad_norm, cfg->lr, cfg->beta1,
                                    cfg->beta2, cfg->adam_eps, gn_out, stream);
-    (void)n;
-    (void)T;
     PolicyDesc pd;
     int32_t rc = make_desc(kind, cfg, &pd);
     if (rc) return rc;
+    if ((rc = ws_check(kind, cfg, n, T, workspace))) return rc;
     const int ns = kind == 0 ? 4 : (kind == 1 ? 3 : 2);
     ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
                  nullptr, nullptr, workspace_packed(workspace, np), pd.h, ns, pd.nout_a, pd.np_a};
@@ -936,6 +984,7 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     RLHIP_REQUIRE(cfg && params && m && v && beta_pow && grad_scratch, "NULL argument");
     if (is_layers3(cfg)) {
         RLHIP_REQUIRE(ctr == nullptr, "layers = 3: the device-counter (graph replay) variant is not built");
+        if (int32_t rcw = ws_check(kind, cfg, n, T, workspace)) return rcw;
         return ppo3_update(kind, cfg, n, T, traj, params, m, v, beta_pow, seed, update_ctr, workspace, grad_scratch,
                            losses_out, stream);
     }

@@ -29,6 +29,53 @@ __global__ __launch_bounds__(256) void eps_greedy_kernel(const float* __restrict
                                     env_id_base + (uint32_t)i, step);
 }
 
+// prob(s::EpsilonGreedyExplorer, values[, mask])  epsilon_greedy_explorer.jl:141-194 for n envs: the Float64 probability vector
+// the reference wraps in `Categorical(probs; check_args = false)` -- eps / n_legal on every legal action (0.0 on masked ones),
+// plus (1 - eps) on findmax (first maximal index; :164, :192) or (1 - eps) / c on each of the c tied maxima (:145-147, :181-184).
+// Same operation order as the oracle (one division, one addition per entry), hence the same bits.
+__global__ __launch_bounds__(256) void eps_greedy_prob_kernel(const float* __restrict__ values, int64_t na, int64_t n,
+                                                              int64_t ks, int64_t is, const uint8_t* __restrict__ mask,
+                                                              double eps, int is_break_tie, double* __restrict__ probs) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StridedValues q{values + i * is, ks};
+    StridedMask mk{mask ? mask + i * is : nullptr, ks};
+    double* out = probs + i * is;
+    int nlegal = 0;
+    for (int k = 0; k < (int)na; ++k) nlegal += (!mk.has() || mk(k)) ? 1 : 0;
+    const double base = eps / (double)nlegal;
+    if (!is_break_tie) {
+        const int best = findmax_first(q, mk, (int)na);
+        for (int k = 0; k < (int)na; ++k) {
+            double pk = (!mk.has() || mk(k)) ? base : 0.0;
+            if (k == best) pk += 1 - eps;
+            out[(int64_t)k * ks] = pk;
+        }
+        return;
+    }
+    bool have = false;  // find_all_max (basic.jl:91-114): the legal maximum, NaN propagating; ties by == (never true for NaN)
+    float v = 0.f;
+    for (int k = 0; k < (int)na; ++k) {
+        if (mk.has() && !mk(k)) continue;
+        const float x = q(k);
+        if (!have) {
+            v = x;
+            have = true;
+        } else if (v == v && (x != x || x > v)) {
+            v = x;
+        }
+    }
+    int c = 0;
+    for (int k = 0; k < (int)na; ++k)
+        if (!(mk.has() && !mk(k)) && q(k) == v) ++c;
+    for (int k = 0; k < (int)na; ++k) {
+        const bool legal = !mk.has() || mk(k);
+        double pk = legal ? base : 0.0;
+        if (legal && have && q(k) == v) pk += (1 - eps) / (double)c;
+        out[(int64_t)k * ks] = pk;
+    }
+}
+
 __global__ __launch_bounds__(256) void categorical_kernel(const float* __restrict__ logits, int64_t na,
                                                           int64_t n, int64_t ks, int64_t is,
                                                           const uint8_t* __restrict__ mask,
@@ -234,6 +281,18 @@ int32_t rlhip_eps_greedy_select_f32(const float* values, int64_t na, int64_t n, 
     hipLaunchKernelGGL(eps_greedy_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
                        values, na, n, k_stride, i_stride, mask, eps, is_break_tie, seed, env_id_base,
                        step, actions);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_eps_greedy_prob_f32(const float* values, int64_t na, int64_t n, int64_t k_stride, int64_t i_stride,
+                                  const uint8_t* mask, double eps, int32_t is_break_tie, double* probs,
+                                  rlhip_stream_t stream) {
+    RLHIP_REQUIRE(values != nullptr && probs != nullptr, "NULL array");
+    RLHIP_REQUIRE(na >= 1 && na <= 0x7FFFFFFF && n >= 0, "bad shape");
+    if (n == 0) return RLHIP_OK;
+    hipLaunchKernelGGL(eps_greedy_prob_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, as_stream(stream), values, na, n,
+                       k_stride, i_stride, mask, eps, is_break_tie, probs);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

@@ -21,11 +21,15 @@ import ReinforcementLearningBase: state, reward, is_terminated, action_space, st
 import ReinforcementLearningCore: _run, check!, forward, target, model, PreExperimentStage, PostExperimentStage,
     PreEpisodeStage, PostEpisodeStage, PreActStage, PostActStage, AbstractLearner, AbstractExplorer, Agent,
     EpsilonGreedyExplorer, get_ϵ
+# `sample` is StatsBase.sample: RLCore's explorers bring it in (`using StatsBase: sample, Weights`, weighted_explorer.jl:4) and
+# RLTrajectories extends the same function with `sample(sampler, traces)`.  The methods below are added to THAT function and the
+# name is not exported from here, so `using RLHip` next to StatsBase / ReinforcementLearning cannot produce two `sample`s (ADVICE r4)
+import ReinforcementLearningCore: sample
 using Random, DomainSets
 
 export HipVecEnv, HipCartPoleEnv, HipPendulumEnv, HipMountainCarEnv, HipAcrobotRK4Env, HipTrajectory, HipApproximator,
     HipTargetNetwork, HipDQNLearner, HipQBasedPolicy, HipPPOPolicy, HipComm, HipEpisodeStats, DevBuf, to_host, to_dev!,
-    HipPrioritizedTraces, HipStackFrames, DevValues, sample
+    HipPrioritizedTraces, HipStackFrames, DevValues
 
 const LIB = get(ENV, "RLHIP_LIB", "librlhip.so")
 
@@ -641,8 +645,9 @@ mutable struct HipPPOPolicy <: AbstractPolicy
     a_i::DevBuf{Int32}; a_f::DevBuf{Float32}; lp::DevBuf{Float32}; val::DevBuf{Float32}    # per-step plan! outputs
     vec_step::UInt32; update_ctr::UInt32; n_pushed::Int
     comm::Any        # nothing or a HipComm: the sharded learner (SURVEY 8e)
+    fused::Bool      # `run` drives one launch per update period instead of the per-step stages (see `_run` below)
 end
-function HipPPOPolicy(env::HipVecEnv; update_freq = 32, seed = env.seed, comm = nothing, kwargs...)
+function HipPPOPolicy(env::HipVecEnv; update_freq = 32, seed = env.seed, comm = nothing, fused = false, kwargs...)
     c = Ref{PPOCfg}()
     chk(ccall((:rlhip_ppo_default, LIB), Int32, (Ref{PPOCfg},), c))
     cfg = Ref(with_kwargs(c[]; continuous = is_continuous(env), kwargs...))
@@ -665,14 +670,18 @@ function HipPPOPolicy(env::HipVecEnv; update_freq = 32, seed = env.seed, comm = 
         end
     end
     ws = ccall((:rlhip_ppo_workspace_bytes, LIB), Int64, (Int32, Ref{PPOCfg}, Int64, Int64), env.kind, cfg, n, T)
+    wsbuf = DevBuf{UInt8}(ws)
+    # registers the size: a later call whose (n, T) needs more than `ws` bytes is an ArgumentError, not a write past the buffer
+    chk(ccall((:rlhip_ppo_workspace_init, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}), wsbuf.ptr, ws, stream()))
+    finalizer(b -> ccall((:rlhip_ppo_workspace_release, LIB), Int32, (Ptr{Cvoid},), b.ptr), wsbuf)
     obs, logp, value = DevBuf{Float32}((T + 1) * ns * n), DevBuf{Float32}(T * n), DevBuf{Float32}((T + 1) * n)
     rew, adv, ret = DevBuf{Float32}(T * n), DevBuf{Float32}(T * n), DevBuf{Float32}(T * n)
     af, ai, term = DevBuf{Float32}(T * na * n), DevBuf{Int32}(T * n), DevBuf{UInt8}(T * n)
     HipPPOPolicy(env.kind, cfg, n, T, ns, na, UInt64(seed), params, DevBuf{Float32}(np), DevBuf{Float32}(np),
                  to_dev!(DevBuf{Float32}(2), Float32[cfg[].beta1, cfg[].beta2]), DevBuf{Float32}(np), DevBuf{Float32}(4),
-                 DevBuf{UInt8}(ws), obs, logp, value, rew, adv, ret, af, ai, term,
+                 wsbuf, obs, logp, value, rew, adv, ret, af, ai, term,
                  Ref(PPOTraj(obs.ptr, logp.ptr, value.ptr, rew.ptr, adv.ptr, ret.ptr, af.ptr, ai.ptr, term.ptr)),
-                 DevBuf{Int32}(n), DevBuf{Float32}(n), DevBuf{Float32}(n), DevBuf{Float32}(n), UInt32(0), UInt32(0), 0, comm)
+                 DevBuf{Int32}(n), DevBuf{Float32}(n), DevBuf{Float32}(n), DevBuf{Float32}(n), UInt32(0), UInt32(0), 0, comm, fused)
 end
 
 "plan!(policy, env): actor + critic forward, Gumbel-max / Gaussian sampling, log-prob -- one launch
@@ -1008,12 +1017,27 @@ plan!(s::ReinforcementLearningCore.WeightedSoftmaxExplorer, v::DevValues, mask =
     _plan_dev(1, v, mask; kw...)                                          # weighted_softmax_explorer.jl:20-26
 plan!(s::ReinforcementLearningCore.GumbelSoftmaxExplorer, v::DevValues, mask = nothing; kw...) =
     _plan_dev(2, v, mask; kw...)                                          # gumbel_softmax_explorer.jl:12-22
-function plan!(s::EpsilonGreedyExplorer, v::DevValues, mask = nothing; seed = 0, env_id_base = 0)
+function plan!(s::EpsilonGreedyExplorer{<:Any,TIE}, v::DevValues, mask = nothing; seed = 0, env_id_base = 0) where {TIE}
     ϵ = get_ϵ(s)                                                          # epsilon_greedy_explorer.jl:69-90
     s.step += 1                                                           # :104, :119: one explorer step per vec-step
     a = DevBuf{Int32}(v.n)
-    plan_eps_greedy!(a, v.values, v.na, v.n, ϵ; mask = mask, seed = seed, env_id_base = env_id_base, step = s.step)
+    plan_eps_greedy!(a, v.values, v.na, v.n, ϵ; mask = mask, is_break_tie = TIE, seed = seed, env_id_base = env_id_base,
+                     step = s.step)
     a
+end
+"""
+    prob(s::EpsilonGreedyExplorer, v::DevValues[, mask]) -> DevBuf{Float64}
+
+`RLBase.prob(s, values[, mask])` (epsilon_greedy_explorer.jl:141-194) for every column of a device `(na, n)` matrix: the
+Float64 probability vectors the reference wraps in `Categorical(probs; check_args = false)`, as a device `(na, n)` SoA matrix
+(`Categorical(to_host(p)[k:n:end]; check_args = false)` is env k's distribution).  `mask`: device `(na, n)` UInt8 matrix.
+"""
+function RLBase.prob(s::EpsilonGreedyExplorer{<:Any,TIE}, v::DevValues, mask = nothing) where {TIE}
+    p = DevBuf{Float64}(v.na * v.n)
+    chk(ccall((:rlhip_eps_greedy_prob_f32, LIB), Int32,
+              (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, Float64, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+              v.values.ptr, v.na, v.n, v.n, 1, mask === nothing ? C_NULL : mask.ptr, get_ϵ(s), TIE, p.ptr, stream()))
+    p
 end
 "UCBExplorer (UCB_explorer.jl:24-28): `counts` is the explorer's per-env action counter on the device (na, n), Float64"
 function plan!(s::ReinforcementLearningCore.UCBExplorer, v::DevValues, counts::DevBuf{Float64}; seed = 0, env_id_base = 0)
@@ -1115,25 +1139,53 @@ function _run(agent::Agent{<:HipQBasedPolicy,<:HipTrajectory}, env::HipVecEnv{K,
     hook
 end
 
-"the PPO loop: per-step protocol through the generic stages, or -- `fused = true` -- one launch per update period"
-function _run(p::HipPPOPolicy, env::HipVecEnv, stop_condition, hook, reset_condition; fused = true)
+"""
+The PPO loop.  Default (`policy.fused == false`): the per-step protocol through the generic stages -- exactly `run.jl:52-67`:
+one `check!(stop_condition, …)` and one `PostActStage` hook push per vec-step, so `StopAfterNSteps(n)` runs n vec-steps
+(`stop_conditions.jl:65-69`) and per-step hooks see every step.
+
+`HipPPOPolicy(env; fused = true)` (or the keyword here): ONE launch per update period of T = `update_freq` vec-steps
+(`rlhip_ppo_rollout_f32`), then the update.  The loop still speaks in vec-steps: after each period the stop condition is
+checked T times and the hook gets T `PostActStage` pushes -- `HipEpisodeStats` reads step t's rewards / terminal flags from row t
+of the policy's trajectory (so its episode log is identical to the per-step run's); any other hook is pushed with the env as it
+stands after the period's last step.  The run ends at the first period boundary at or after the step the stop condition fired
+on: `StopAfterNSteps(n)` runs `ceil(n / T) * T` vec-steps (n itself when T divides n).
+"""
+function _run(p::HipPPOPolicy, env::HipVecEnv, stop_condition, hook, reset_condition; fused = p.fused)
     push!(hook, PreExperimentStage(), p, env)
     while true
         if fused
             rollout!(p, env)
             optimise!(p, PostActStage(), env; fused_rollout = true)
+            stop = false
+            for t in 1:p.T
+                push_period_step!(hook, p, env, t)
+                stop |= check!(stop_condition, p, env)      # run.jl:64, once per vec-step of the period
+            end
+            stop && break
         else
             action = plan!(p, env)
             push!(p, PreActStage(), env)
             act!(env, action)
             push!(p, PostActStage(), env, action)
             optimise!(p, PostActStage(), env)
+            push!(hook, PostActStage(), p, env)
+            check!(stop_condition, p, env) && break
         end
-        push!(hook, PostActStage(), p, env)
-        check!(stop_condition, p, env) && break
     end
     push!(hook, PostExperimentStage(), p, env)
     hook
+end
+"the `PostActStage` hook push of step t (1-based) of a fused update period"
+push_period_step!(hook, p::HipPPOPolicy, env::HipVecEnv, t::Int) = push!(hook, PostActStage(), p, env)
+function push_period_step!(h::HipEpisodeStats, p::HipPPOPolicy, env::HipVecEnv, t::Int)
+    # rewards / terminal flags of step t: row t of the time-major (T, n) traces the rollout launch wrote
+    chk(ccall((:rlhip_hook_episode_stats, LIB), Int32,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+              offset(p.rew, (t - 1) * p.n), offset(p.terminal, (t - 1) * p.n), h.n, h.vec_step, h.steps_acc.ptr, h.ret_acc.ptr,
+              h.log.ptr, h.cap, h.count.ptr, stream()))
+    h.vec_step += 1
+    nothing
 end
 
 end # module

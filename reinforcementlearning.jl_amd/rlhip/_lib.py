@@ -152,6 +152,7 @@ _PROTOS = {
     "rlhip_gae_f64": (i32, [vp, vp, vp, i64, i64, f64, f64, vp, i32, vp]),
     "rlhip_gae_returns_f32": (i32, [vp, vp, vp, vp, vp, i64, i64, f32, f32, vp]),
     "rlhip_eps_greedy_select_f32": (i32, [vp, i64, i64, i64, i64, vp, f64, i32, u64, u32, u32, vp, vp]),
+    "rlhip_eps_greedy_prob_f32": (i32, [vp, i64, i64, i64, i64, vp, f64, i32, vp, vp]),
     "rlhip_get_eps": (f64, [i32, f64, f64, i64, i64, i64]),
     "rlhip_categorical_sample_f32": (i32, [vp, i64, i64, i64, i64, vp, u64, u32, u32, vp, vp, vp]),
     "rlhip_polyak_f32": (i32, [vp, vp, i64, f32, vp]),
@@ -233,6 +234,8 @@ _PROTOS = {
                                     P(PPOTraj), vp]),
     "rlhip_ppo_gae_f32": (i32, [P(PPOCfg), i64, i64, P(PPOTraj), vp]),
     "rlhip_ppo_workspace_bytes": (i64, [i32, P(PPOCfg), i64, i64]),
+    "rlhip_ppo_workspace_init": (i32, [vp, i64, vp]),
+    "rlhip_ppo_workspace_release": (i32, [vp]),
     "rlhip_ppo_grad_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, i32, vp, vp, vp,
                                  vp]),
     "rlhip_ppo_grad_fresh_f32": (i32, [i32, P(PPOCfg), i64, i64, P(PPOTraj), vp, u64, u32, i32, vp, vp, vp,

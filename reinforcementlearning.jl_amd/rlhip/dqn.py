@@ -138,6 +138,14 @@ class EpsilonGreedyExplorer:
         return a0 + 1
 
 
+    def prob(self, values, mask=None):
+        """prob(s, values[, mask])  :141-194 -- the Float64 probability of every action of every env, (na, N) like `values`
+        (the reference returns `Categorical(probs)` per env; the step counter does not advance)."""
+        from .ops import eps_greedy_prob
+
+        return eps_greedy_prob(values, self.get_eps(), mask, self.is_break_tie)
+
+
 class GreedyExplorer(EpsilonGreedyExplorer):
     """GreedyExplorer()  :200-214 -- findmax first-index rule, no randomness."""
 

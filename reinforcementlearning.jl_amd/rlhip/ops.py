@@ -128,6 +128,22 @@ def eps_greedy_select(values, eps, seed, step, env_id_base=0, mask=None, is_brea
     return out
 
 
+def eps_greedy_prob(values, eps, mask=None, is_break_tie=False, soa=True):
+    """prob(::EpsilonGreedyExplorer, values[, mask]) for every env of a (na, n) device tensor: Float64 probabilities in the
+    layout of `values` (epsilon_greedy_explorer.jl:141-194)."""
+    if soa:
+        na, n = values.shape
+        ks, is_ = n, 1
+    else:
+        n, na = values.shape
+        ks, is_ = 1, na
+    out = torch.empty(values.shape, dtype=torch.float64, device=values.device)
+    m8 = _u8(mask)
+    call("rlhip_eps_greedy_prob_f32", ptr(values), na, n, ks, is_, ptr(m8), float(eps), int(is_break_tie), ptr(out),
+         stream_ptr())
+    return out
+
+
 def categorical_sample(logits, seed, step, env_id_base=0, mask=None, soa=True):
     if soa:
         na, n = logits.shape

@@ -100,7 +100,9 @@ class PPOPolicy:
         self.gn = torch.zeros(1, dtype=torch.float32, device=dev)
         self.trajectory = PPOTrajectory(ns, env.n, self.T, env.continuous, dev)
         ws = int(_lib.lib.rlhip_ppo_workspace_bytes(self.kind, C.byref(self.cfg), env.n, self.T))
-        self.workspace = torch.zeros(ws, dtype=torch.uint8, device=dev)  # zero-initialised: ABI contract
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        # zero-fills it and registers its size: every later call checks its own (n, T) against it (ABI 2)
+        call("rlhip_ppo_workspace_init", ptr(self.workspace), ws, stream_ptr())
         self.vec_step = 0      # global vec-step counter (Philox t of the sampling streams)
         self.update_ctr = 0    # number of update_ calls so far
         self.n_pushed = 0      # per-step protocol: vec-steps pushed since the last update

@@ -259,7 +259,9 @@ static void run_ppo(int through_comm) {
     tr.action_f = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
     tr.action_i = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(T * n));
     tr.terminal = (uint8_t*)dmalloc((size_t)(T * n));
-    void* workspace = dmalloc((size_t)rlhip_ppo_workspace_bytes(RLHIP_ENV_CARTPOLE, &cfg, n, T));
+    const int64_t ws_bytes = rlhip_ppo_workspace_bytes(RLHIP_ENV_CARTPOLE, &cfg, n, T);
+    void* workspace = dmalloc((size_t)ws_bytes);
+    CK(rlhip_ppo_workspace_init(workspace, ws_bytes, g_stream)); /* zero-fill + register the size (ABI 2) */
 
     float* p0 = (float*)malloc(sizeof(float) * (size_t)np);
     CK(rlhip_memcpy_d2h(p0, params, sizeof(float) * (size_t)np, g_stream));
@@ -440,7 +442,9 @@ static int run_comm_rank(int rank, int world, const char* dir, int use_rccl) {
     tr.action_f = (float*)dmalloc(sizeof(float) * (size_t)(T * n));
     tr.action_i = (int32_t*)dmalloc(sizeof(int32_t) * (size_t)(T * n));
     tr.terminal = (uint8_t*)dmalloc((size_t)(T * n));
-    void* workspace = dmalloc((size_t)rlhip_ppo_workspace_bytes(RLHIP_ENV_CARTPOLE, &cfg, n, T));
+    const int64_t ws_bytes = rlhip_ppo_workspace_bytes(RLHIP_ENV_CARTPOLE, &cfg, n, T);
+    void* workspace = dmalloc((size_t)ws_bytes);
+    CK(rlhip_ppo_workspace_init(workspace, ws_bytes, g_stream)); /* zero-fill + register the size (ABI 2) */
     for (uint32_t it = 0; it < 2; ++it) {
         CK(rlhip_ppo_rollout_f32(RLHIP_ENV_CARTPOLE, &ecfg, &env.st, n, T, &cfg, params, seed, (uint32_t)(rank * n),
                                  it * (uint32_t)T, &tr, g_stream));

@@ -253,3 +253,45 @@ except RLHipArgumentError as e:
     assert outs["default"][1] == outs["bounds"][1], "valid gathers differ between the two builds"
     assert outs["default"][2] == "gather: no error"  # the default build trusts its caller (no synchronisation per gather)
     assert outs["bounds"][2] == "gather: EINVAL True"
+
+
+def test_ppo_workspace_is_sized_and_checked():
+    """ABI 2: rlhip_ppo_update_f32 writes 32 bytes of sample records per trajectory entry behind the fixed
+    part of the workspace.  A workspace registered for (n, T) is refused for a larger n * T, and a workspace that was never
+    registered is refused outright -- RLHIP_EINVAL (the host's ArgumentError) instead of a write past the allocation."""
+    import ctypes as C
+
+    import rlhip
+    from rlhip import _lib
+    from rlhip._lib import RLHipArgumentError, call
+    from rlhip.ops import ptr, stream_ptr
+
+    env = rlhip.HipVecEnv("cartpole", 256, seed=2)
+    pol = rlhip.PPOPolicy(env, update_freq=8)
+    pol.rollout_()
+    pol.update_()  # registered for 256 x 8: fine
+    need_small = int(_lib.lib.rlhip_ppo_workspace_bytes(pol.kind, C.byref(pol.cfg), 256, 8))
+    need_big = int(_lib.lib.rlhip_ppo_workspace_bytes(pol.kind, C.byref(pol.cfg), 256, 64))
+    assert need_big == need_small + 32 * 256 * (64 - 8) and pol.workspace.numel() == need_small
+    big = rlhip.PPOPolicy(env, update_freq=64, params=pol.params)
+    big.rollout_()
+    args = (pol.kind, C.byref(pol.cfg), 256, 64, C.byref(big.trajectory.c), ptr(pol.params), ptr(pol.m), ptr(pol.v),
+            ptr(pol.beta_pow), pol.seed, 0)
+    p0 = pol.params.clone()
+    with pytest.raises(RLHipArgumentError, match="too small"):  # the 256 x 8 workspace with a 256 x 64 trajectory
+        call("rlhip_ppo_update_f32", *args, ptr(pol.workspace), ptr(pol.grad), ptr(pol.losses), stream_ptr())
+    raw = torch.zeros(need_big, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RLHipArgumentError, match="never registered"):
+        call("rlhip_ppo_update_f32", *args, ptr(raw), ptr(pol.grad), ptr(pol.losses), stream_ptr())
+    with pytest.raises(RLHipArgumentError, match="never registered"):
+        call("rlhip_ppo_grad_f32", pol.kind, C.byref(pol.cfg), 256, 64, C.byref(big.trajectory.c), ptr(pol.params), pol.seed, 0, 0,
+             ptr(raw), ptr(pol.grad), ptr(pol.losses), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(pol.params, p0)  # nothing was enqueued
+    call("rlhip_ppo_workspace_init", ptr(raw), need_big, stream_ptr())
+    call("rlhip_ppo_update_f32", *args, ptr(raw), ptr(pol.grad), ptr(pol.losses), stream_ptr())
+    torch.cuda.synchronize()
+    assert not torch.equal(pol.params, p0) and bool(torch.isfinite(pol.params).all())
+    call("rlhip_ppo_workspace_release", ptr(raw))
+    with pytest.raises(RLHipArgumentError, match="never registered"):
+        call("rlhip_ppo_update_f32", *args, ptr(raw), ptr(pol.grad), ptr(pol.losses), stream_ptr())

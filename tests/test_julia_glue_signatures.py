@@ -224,7 +224,12 @@ def test_f_rows_are_methods_on_the_reference_types_and_match_integration_md():
     for typ, kind in (("WeightedExplorer{N}", 0), ("WeightedSoftmaxExplorer", 1), ("GumbelSoftmaxExplorer", 2)):
         m = re.search(r"plan!\(s::ReinforcementLearningCore\." + re.escape(typ) + r", v::DevValues, mask = nothing; kw\.\.\.\)[^=]*=\s*_plan_dev\((\d)", src)
         assert m and int(m.group(1)) == kind, typ
-    assert "function plan!(s::EpsilonGreedyExplorer, v::DevValues, mask = nothing" in src
+    assert "function plan!(s::EpsilonGreedyExplorer{<:Any,TIE}, v::DevValues, mask = nothing" in src
+    # prob(explorer, values[, mask]): a method of RLBase.prob on the reference's explorer type, break-tie flag
+    # from the type parameter, forwarding to rlhip_eps_greedy_prob_f32
+    pr = src[src.index("function RLBase.prob(s::EpsilonGreedyExplorer{<:Any,TIE}, v::DevValues, mask = nothing) where {TIE}"):]
+    pr = pr[:pr.index("\nend")]
+    assert ":rlhip_eps_greedy_prob_f32" in pr and "get_ϵ(s), TIE" in pr
     assert "function plan!(s::ReinforcementLearningCore.UCBExplorer, v::DevValues, counts::DevBuf{Float64}" in src
     assert "plan!(x::ReinforcementLearningCore.BatchExplorer, v::DevValues, args...; kw...) = plan!(x.explorer, v, args...; kw...)" in src
     # the reference's explorer types really have the fields the methods read
@@ -236,5 +241,12 @@ def test_f_rows_are_methods_on_the_reference_types_and_match_integration_md():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for needle in ("HipPrioritizedTraces(traces; default_priority)", "HipStackFrames(n_stack)", "v::DevValues[, mask]"):
         assert needle in doc, needle
-    for name in ("HipPrioritizedTraces", "HipStackFrames", "DevValues", "sample"):
+    for name in ("HipPrioritizedTraces", "HipStackFrames", "DevValues"):
         assert re.search(r"export[^#]*\b" + name + r"\b", open(GLUE).read(), flags=re.S), name
+    # `sample` extends StatsBase.sample (the function RLCore's explorers and RLTrajectories' samplers share) and is NOT a new
+    # exported generic: imported from RLCore's namespace, where `using StatsBase: sample` put it
+    assert re.search(r"^import ReinforcementLearningCore: sample$", open(GLUE).read(), flags=re.M)
+    export_stmt = re.search(r"^export .*?(?=\n\S)", src, flags=re.S | re.M).group(0)
+    assert "HipVecEnv" in export_stmt and not re.search(r"\bsample\b", export_stmt)
+    assert "using StatsBase: sample, Weights" in open("/root/reference/src/ReinforcementLearningCore/src/policies/explorers/weighted_explorer.jl").read() \
+        if os.path.isdir(ref) else True
