@@ -12,6 +12,7 @@
 // clip_adam_kernel: ONE single-workgroup launch doing [scale] -> global norm -> clip -> Adam with the
 // gradient held in registers between the norm and the update (one read of g instead of three).
 #include "optim_device.h"
+#include <mutex>
 
 namespace rlhip {
 
@@ -67,10 +68,26 @@ __global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ g, in
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= s;
 }
 
+// `bt = bt .* b` of Optimisers.Adam folded into the Adam launch (round 5: was a second, one-thread launch -- 4.7 us for 8 bytes
+// of work): every workgroup read beta_pow before its first update; the one that LEAVES last (agent-scope departure
+// counter, one per stream: launches of one stream never overlap) advances the running powers and re-arms the counter.  No
+// fence: nothing this workgroup stored is read by another workgroup of the launch.
+__device__ __forceinline__ void advance_beta_pow_last_out(float* beta_pow, float b1, float b2, unsigned int* departed) {
+    __syncthreads();  // every thread of this workgroup has read beta_pow
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            beta_pow[0] *= b1;  // bt = bt .* b
+            beta_pow[1] *= b2;
+            __hip_atomic_store(departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ beta_pow, int64_t n, float lr,
-                                                   float b1, float b2, float eps) {
+                                                   float* __restrict__ beta_pow, int64_t n, float lr,
+                                                   float b1, float b2, float eps, unsigned int* __restrict__ departed) {
     float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -80,6 +97,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mi;
         v[i] = vi;
     }
+    advance_beta_pow_last_out(beta_pow, b1, b2, departed);
 }
 
 // Streaming variants for parameter vectors that leave the caches (n >= STREAM_MIN_N floats, 16-byte aligned): four
@@ -87,6 +105,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // scalar kernels (same adam1 per element: bit-identical results).  NT_ST: non-temporal stores as well (chosen per kernel
 // by A / B, see the launches).  Tail elements (n % 4) by the first lanes, scalar.
 constexpr int64_t STREAM_MIN_N = 1 << 16;
+#ifndef RLHIP_ADAM_CHUNKS
+#define RLHIP_ADAM_CHUNKS 1
+#endif
+constexpr int ADAM_CHUNKS = RLHIP_ADAM_CHUNKS;  // 16-byte chunks per thread of adam_vec4_kernel (A / B: tools/adam_grid_ab.py)
 union f32x4_bits {
     nt_u32x4 u;
     float f[4];
@@ -100,8 +122,8 @@ __device__ __forceinline__ void st16(void* p, const f32x4_bits& x) {
 template <bool NT_ST, int U>
 __global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
-                                                        const float* __restrict__ beta_pow, int64_t n, float lr,
-                                                        float b1, float b2, float eps) {
+                                                        float* __restrict__ beta_pow, int64_t n, float lr,
+                                                        float b1, float b2, float eps, unsigned int* __restrict__ departed) {
     const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     // U 16-byte chunks per lane and iteration, `stride` apart (each chunk row stays coalesced): 4 U loads in flight per lane
@@ -137,6 +159,7 @@ __global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, c
         m[t] = mi;
         v[t] = vi;
     }
+    advance_beta_pow_last_out(beta_pow, b1, b2, departed);
 }
 
 template <bool NT_ST>
@@ -438,13 +461,29 @@ __global__ __launch_bounds__(256) void clip_adam_grid_kernel(float* __restrict__
     }
 }
 
+constexpr int DEPART_SLOTS = 64;
 struct Scratch {
     double* partials = nullptr;  // 1024 doubles
     float* scalars = nullptr;    // 4 floats
-    unsigned int* counter = nullptr;  // departure counter of clip_adam_grid_kernel (zero between launches)
+    unsigned int* counter = nullptr;  // departure counters (zero between launches), one 64-byte slot per STREAM: launches of one
+                                      // stream never overlap, launches of two streams must not share a counter
+    hipStream_t stream_of[DEPART_SLOTS] = {};
+    int n_streams = 0;
     int device = -1;
 };
 static Scratch g_scratch[16];
+static std::mutex g_scratch_mutex;
+
+// the departure counter of `stream` on this device; nullptr when more than DEPART_SLOTS streams have asked (callers then take
+// their counter-free route)
+static unsigned int* depart_counter(Scratch& s, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    for (int i = 0; i < s.n_streams; ++i)
+        if (s.stream_of[i] == stream) return s.counter + 16 * i;
+    if (s.n_streams == DEPART_SLOTS) return nullptr;
+    s.stream_of[s.n_streams] = stream;
+    return s.counter + 16 * s.n_streams++;
+}
 
 static int32_t get_scratch(Scratch** out) {
     int dev = 0;
@@ -454,11 +493,30 @@ static int32_t get_scratch(Scratch** out) {
     if (s.device != dev) {
         RLHIP_CHECK_HIP(hipMalloc((void**)&s.partials, 1024 * sizeof(double)));
         RLHIP_CHECK_HIP(hipMalloc((void**)&s.scalars, 4 * sizeof(float)));
-        RLHIP_CHECK_HIP(hipMalloc((void**)&s.counter, 64));
-        RLHIP_CHECK_HIP(hipMemset(s.counter, 0, 64));
+        RLHIP_CHECK_HIP(hipMalloc((void**)&s.counter, 64 * DEPART_SLOTS));
+        RLHIP_CHECK_HIP(hipMemset(s.counter, 0, 64 * DEPART_SLOTS));
         s.device = dev;
     }
     *out = &s;
+    return RLHIP_OK;
+}
+
+// one launch: the update of every parameter AND `bt = bt .* b` (the last workgroup out advances the running powers)
+static int32_t adam_launch(float* params, const float* grad, float* m, float* v, float* beta_pow, int64_t n, float lr, float beta1,
+                           float beta2, float eps, unsigned int* departed, hipStream_t s) {
+    if (n >= STREAM_MIN_N && aligned16(params, grad, m, v)) {
+        // one trip per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes 307 us with
+        // 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones (tools/adam_grid_ab.py); non-temporal stores.
+        // U = 16-byte chunks per thread and array, `stride` apart; the grid is sized so that all U really are in flight (ADVICE
+        // r4: round 4 launched one thread per chunk, which left the second chunk of every thread out of range)
+        constexpr int U = ADAM_CHUNKS;
+        const int grid = grid_for((n / 4 + U - 1) / U, 256, 1 << 20);
+        hipLaunchKernelGGL((adam_vec4_kernel<true, U>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1,
+                           beta2, eps, departed);
+    } else
+        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1,
+                           beta2, eps, departed);
+    RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
 
@@ -506,20 +564,24 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
                        float lr, float beta1, float beta2, float eps, rlhip_stream_t stream) {
     RLHIP_REQUIRE(params && grad && m && v && beta_pow && n >= 0, "bad arguments");
     hipStream_t s = as_stream(stream);
-    if (n >= STREAM_MIN_N && aligned16(params, grad, m, v)) {
-        // one 16-byte chunk per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes
-        // 307 us with 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones, Polyak 118 against 120 - 126
-        // (tools/adam_grid_ab.py); the loops in the kernels only serve vectors beyond the grid cap
-        const int grid = grid_for(n / 4, 256, 1 << 20);
-        // store policy and unroll by A / B on one box (profiles/r04_pmc.md): non-temporal stores + two chunks per lane 375 us at
-        // 2^26 parameters against 412 (ordinary stores, one chunk), 413 (non-temporal, one chunk), 436 (ordinary, two chunks)
-        hipLaunchKernelGGL((adam_vec4_kernel<true, 2>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps);
-    } else if (n > 0)
-        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, params, grad, m, v, beta_pow,
-                           n, lr, beta1, beta2, eps);
-    hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);
-    RLHIP_LAUNCH_CHECK();
-    return RLHIP_OK;
+    Scratch* sc;
+    int32_t rc = get_scratch(&sc);
+    if (rc) return rc;
+    unsigned int* dep = depart_counter(*sc, s);
+    if (n == 0 || !dep) {  // nothing to fold the advance into / no counter slot left for this stream: its own launch
+        if (n > 0) {
+            unsigned int* scratch_ctr = nullptr;
+            RLHIP_CHECK_HIP(hipMallocAsync((void**)&scratch_ctr, 64, s));
+            RLHIP_CHECK_HIP(hipMemsetAsync(scratch_ctr, 0, 64, s));
+            const int rcl = adam_launch(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, scratch_ctr, s);
+            (void)hipFreeAsync(scratch_ctr, s);
+            return rcl;
+        }
+        hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);
+        RLHIP_LAUNCH_CHECK();
+        return RLHIP_OK;
+    }
+    return adam_launch(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, dep, s);
 }
 
 int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow, int64_t n,
@@ -536,8 +598,10 @@ int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, floa
         if (rc) return rc;
         const int nb = grid_for(n, 256, 256);
         hipLaunchKernelGGL(sumsq_scaled_partial_kernel, dim3(nb), dim3(256), 0, s, grad, n, grad_scale, sc->partials);
+        unsigned int* dep = depart_counter(*sc, s);
+        RLHIP_REQUIRE(dep != nullptr, "more than 64 streams drive the optimiser kernels of this device");
         hipLaunchKernelGGL(clip_adam_grid_kernel, dim3(nb), dim3(256), 0, s, params, grad, m, v, beta_pow, n, grad_scale,
-                           clip_norm, lr, beta1, beta2, eps, sc->partials, nb, sc->counter, gn_out);
+                           clip_norm, lr, beta1, beta2, eps, sc->partials, nb, dep, gn_out);
         RLHIP_LAUNCH_CHECK();
         return RLHIP_OK;
     }
