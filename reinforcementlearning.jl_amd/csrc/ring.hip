@@ -220,23 +220,31 @@ __device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingV
 // sectors per sample (round 4: five 64-byte lines; round 3: eleven).  Stores are coalesced (consecutive lanes = consecutive
 // samples).  Nothing is staged in LDS: a lane owns its sample from index to store (the tile-staged generic kernel above
 // is the route of the layouts without records).
-template <int OD>
+template <int OD, bool NT, int SPL>
 __global__ __launch_bounds__(256) void gather_rec_kernel(RingView rb, const int64_t* __restrict__ idx, int64_t batch,
                                                          float* __restrict__ s, int32_t* __restrict__ a, float* __restrict__ r,
                                                          uint8_t* __restrict__ term, float* __restrict__ sn, PrioDraw pd) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const int64_t j = pd.tree ? prio_draw_one(pd, rb, b) : idx[b];
+    const int64_t b0 = ((int64_t)blockIdx.x * SPL) * blockDim.x + threadIdx.x;  // SPL samples per lane, 256 apart (coalesced)
     const RingRecs rr = {(const uint8_t*)rb.state, rb.capacity, rb.n_env, rb.head_sa};
-    const RingTransition t = ring_load_transition(rr, j);
+    RingTransition t[SPL];
 #pragma unroll
-    for (int k = 0; k < OD; ++k) {
-        s[k * batch + b] = t.s[k];
-        sn[k * batch + b] = t.sn[k];
+    for (int u = 0; u < SPL; ++u) {
+        const int64_t b = b0 + 256 * u;
+        if (b < batch) t[u] = ring_load_transition<NT>(rr, pd.tree ? prio_draw_one(pd, rb, b) : idx[b]);
     }
-    a[b] = t.a;
-    r[b] = t.r;
-    term[b] = (uint8_t)t.t;
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+        const int64_t b = b0 + 256 * u;
+        if (b >= batch) continue;
+#pragma unroll
+        for (int k = 0; k < OD; ++k) {
+            s[k * batch + b] = t[u].s[k];
+            sn[k * batch + b] = t[u].sn[k];
+        }
+        a[b] = t[u].a;
+        r[b] = t[u].r;
+        term[b] = (uint8_t)t[u].t;
+    }
 }
 
 // large contiguous frames (n_env == 1): one workgroup per sample, 16 B/lane streaming copy.
@@ -613,9 +621,22 @@ static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_
     } else {
         int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
         const bool lane = rb->layout == RLHIP_RING_RECORDS;
-#define RLHIP_GATHER_LANE(OD)                                                                                      \
-    hipLaunchKernelGGL((gather_rec_kernel<OD>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v, idx, batch, \
-                       (float*)s, a, r, term, (float*)s_next, pd)
+        static const int variant = getenv("RLHIP_GATHER_VARIANT") ? atoi(getenv("RLHIP_GATHER_VARIANT")) : 0;  // A / B hook
+#define RLHIP_GATHER_LANE(OD)                                                                                              \
+    do {                                                                                                                   \
+        if (variant == 1)                                                                                                  \
+            hipLaunchKernelGGL((gather_rec_kernel<OD, true, 1>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v,     \
+                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
+        else if (variant == 2)                                                                                             \
+            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 2>), dim3((int)((batch + 511) / 512)), dim3(256), 0, st, v,    \
+                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
+        else if (variant == 3)                                                                                             \
+            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 4>), dim3((int)((batch + 1023) / 1024)), dim3(256), 0, st, v,  \
+                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
+        else                                                                                                               \
+            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 1>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v,    \
+                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
+    } while (0)
         if (lane && rb->obs_dim == 4) RLHIP_GATHER_LANE(4);
         else if (lane && rb->obs_dim == 3) RLHIP_GATHER_LANE(3);
         else if (lane && rb->obs_dim == 2) RLHIP_GATHER_LANE(2);

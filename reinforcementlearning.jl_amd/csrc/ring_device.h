@@ -39,22 +39,54 @@ struct RingTransition {
     uint32_t t;  // 0 / 1
 };
 
-// the three 16-byte loads of one sampled transition, all issued before the first use
-__device__ __forceinline__ RingTransition ring_load_transition(const RingRecs& rb, int64_t fj) {
-    const int64_t li = fj / rb.n_env, e = fj - li * rb.n_env;
-    const int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
+// byte offsets of record(s) and record(s') of flat logical index fj = li * n_env + e.  No 64-bit division where 32 bits do (a
+// 64-bit div / mod pair is ~300 VALU instructions on this chip, a 32-bit one ~40), and no modulo at all for the ring wrap:
+// head_sa <= capacity and li < capacity, so head_sa + li wraps at most once.
+__device__ __forceinline__ void ring_record_offsets(const RingRecs& rb, int64_t fj, int64_t& off_s, int64_t& off_n) {
+    int64_t li, e;
+    if (((uint64_t)fj | (uint64_t)rb.n_env) >> 32) {
+        li = fj / rb.n_env;
+        e = fj - li * rb.n_env;
+    } else {
+        const uint32_t q = (uint32_t)fj / (uint32_t)rb.n_env;
+        li = q;
+        e = (uint32_t)fj - q * (uint32_t)rb.n_env;
+    }
+    int64_t ps = rb.head_sa + li;
+    if (ps > rb.capacity) ps -= rb.capacity + 1;
     const int64_t pn = (ps == rb.capacity) ? 0 : ps + 1;
-    const uint8_t* r0 = rb.rec + (ps * rb.n_env + e) * RING_REC_BYTES;
-    const uint8_t* r1 = rb.rec + (pn * rb.n_env + e) * RING_REC_BYTES;
-    const float4 s = *reinterpret_cast<const float4*>(r0);
-    const float4 sn = *reinterpret_cast<const float4*>(r1);
-    const int4 w = *reinterpret_cast<const int4*>(r1 + 16);
+    off_s = (ps * rb.n_env + e) * RING_REC_BYTES;
+    off_n = (pn * rb.n_env + e) * RING_REC_BYTES;
+}
+
+union RingChunk {  // one 16-byte half of a record
+    nt_u32x4 u;
+    float f[4];
+};
+
+// the three 16-byte loads of one sampled transition, all issued before the first use
+template <bool NT = false>
+__device__ __forceinline__ RingTransition ring_load_transition(const RingRecs& rb, int64_t fj) {
+    int64_t o0, o1;
+    ring_record_offsets(rb, fj, o0, o1);
+    const uint8_t* r0 = rb.rec + o0;
+    const uint8_t* r1 = rb.rec + o1;
+    RingChunk s, sn, w;
+    if (NT) {
+        s.u = nt_load16(r0);
+        sn.u = nt_load16(r1);
+        w.u = nt_load16(r1 + 16);
+    } else {
+        s.u = *reinterpret_cast<const nt_u32x4*>(r0);
+        sn.u = *reinterpret_cast<const nt_u32x4*>(r1);
+        w.u = *reinterpret_cast<const nt_u32x4*>(r1 + 16);
+    }
     RingTransition t;
-    t.s[0] = s.x, t.s[1] = s.y, t.s[2] = s.z, t.s[3] = s.w;
-    t.sn[0] = sn.x, t.sn[1] = sn.y, t.sn[2] = sn.z, t.sn[3] = sn.w;
-    t.a = w.x;
-    t.r = __int_as_float(w.y);
-    t.t = ((uint32_t)w.z & 0xffu) ? 1u : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t.s[k] = s.f[k], t.sn[k] = sn.f[k];
+    t.a = (int32_t)w.u[0];
+    t.r = w.f[1];
+    t.t = (w.u[2] & 0xffu) ? 1u : 0u;
     return t;
 }
 

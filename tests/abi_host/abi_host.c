@@ -215,7 +215,7 @@ static void run_dqn(void) {
     dump("dqn.m", m, 4, (size_t)np);
     dump("dqn.v", v, 4, (size_t)np);
     dump("dqn.loss", loss, 4, 1);
-    dump("dqn.ring.records", r_state, 4, r_bytes / 4);
+    dump("dqn.ring.rec", r_state, 4, r_bytes / 4);
     for (int k = 0; k < 4; ++k) {
         char nm[16];
         snprintf(nm, sizeof(nm), "dqn.env.s%d", k);
