@@ -828,12 +828,106 @@ def allreduce_report(torch, pol, world):
     return out
 
 
+def preflight(torch, rlhip, rank, local_rank, world, pg, backend):
+    """`bench.py --gpus N --preflight`: everything the first multi-GPU run depends on, reported per rank in ONE JSON line (rank 0
+    prints it) so that a plumbing failure is diagnosable from one log -- and exit status 0 either way (it is a report).
+    Per rank: device, hipDeviceCanAccessPeer towards every peer's device, an IPC round trip with every peer (rlhip_p2p_export /
+    import / probe of a known word / close -- each peer separately, so one bad link names itself), then the product's own set-up
+    (rlhip_comm_init -> rlhip_p2p_setup: mapping, exact self-test, cross-rank agreement) with rlhip_comm_info().why, and one
+    gradient-sized exchange through rlhip_allreduce_grads compared with the rank-order sum computed on the host."""
+    import ctypes as C
+
+    from rlhip import _lib
+    from rlhip._lib import call
+
+    rep = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "backend": backend,
+           "device_name": torch.cuda.get_device_name(), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    if world == 1:
+        rep["note"] = "world = 1: nothing to exchange"
+        print(json.dumps({"preflight": [rep]}), flush=True)
+        return
+    import torch.distributed as dist
+
+    def gather(x):
+        out = [None] * world
+        dist.all_gather_object(out, x, group=pg)
+        return out
+
+    devices = gather(rep["device"])
+    rep["can_access_peer"] = {str(p): (True if devices[p] == rep["device"] else bool(_lib.lib.rlhip_p2p_can_access(devices[p])))
+                              for p in range(world) if p != rank}
+    # one IPC round trip per peer with the building blocks of csrc/p2p.hip
+    buf, hb = C.c_void_p(), (C.c_uint8 * 64)()
+    ipc = {}
+    try:
+        call("rlhip_p2p_alloc", 4096, C.byref(buf))
+        word = torch.tensor([0x5EED0000 + rank], dtype=torch.int32)
+        call("rlhip_memcpy_h2d", buf, C.c_void_p(word.data_ptr()), 4, None)
+        call("rlhip_stream_sync", None)
+        call("rlhip_p2p_export", buf, hb)
+        mine = bytes(hb)
+    except _lib.RLHipError as exc:
+        mine = None
+        ipc["export"] = f"FAILED: {exc}"
+    handles = gather(mine)
+    for p in range(world):
+        if p == rank:
+            continue
+        if handles[p] is None:
+            ipc[str(p)] = "peer could not export"
+            continue
+        q = C.c_void_p()
+        try:
+            call("rlhip_p2p_import", (C.c_uint8 * 64).from_buffer_copy(handles[p]), C.byref(q))
+            val = C.c_uint32(0)
+            call("rlhip_p2p_probe", q, 0, C.byref(val))
+            ipc[str(p)] = "ok" if val.value == 0x5EED0000 + p else f"mapped, but read {val.value:#x} instead of {0x5EED0000 + p:#x}"
+            call("rlhip_p2p_close", q)
+        except _lib.RLHipError as exc:
+            ipc[str(p)] = f"FAILED: {exc}"
+    rep["ipc_round_trip"] = ipc
+    dist.barrier(group=pg)  # nobody frees a buffer a peer still has mapped
+    if buf.value:
+        call("rlhip_p2p_free", buf)
+    # the product's set-up and one exchange
+    try:
+        from rlhip.dist import HipComm
+
+        n = 3331
+        comm = HipComm.create(pg, n, torch.device("cuda"))
+        d = comm.info()
+        rep["comm"] = {"p2p_active": bool(d.p2p_active), "why": d.why.decode(), "rccl_behind_abi": bool(d.rccl_active),
+                       "rccl_path": d.rccl_path.decode(), "setup_error": comm.setup_error, "transport": comm.transport()}
+        x = (torch.arange(n, dtype=torch.float32) % 251 + rank).cuda()  # integers: any summation order gives the same bits
+        want = sum((torch.arange(n, dtype=torch.float32) % 251 + r) for r in range(world))
+        if comm.ok:
+            comm.all_reduce_(x)
+        else:
+            dist.all_reduce(x, group=pg)
+        torch.cuda.synchronize()
+        rep["exchange"] = {"via": "rlhip_allreduce_grads" if comm.ok else "torch.distributed (no transport behind the ABI)",
+                           "correct": bool(torch.equal(x.cpu(), want)), "timeout": bool(comm.failed())}
+        comm.close()
+    except Exception as exc:  # noqa: BLE001 -- a report, not a run
+        rep["comm"] = {"error": repr(exc)}
+    reports = gather(rep)
+    if rank == 0:
+        ok = all(r.get("exchange", {}).get("correct") and not r.get("exchange", {}).get("timeout") for r in reports)
+        print(json.dumps({"preflight": reports, "world": world, "exchange_ok_on_every_rank": ok,
+                          "p2p_active_on_every_rank": all(r.get("comm", {}).get("p2p_active") for r in reports)}), flush=True)
+    dist.barrier(group=pg)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / breakdown legs")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1 plumbing report (< 10 s of GPU work, no timed steps): peer-access matrix, per-peer IPC mapping, the "
+                         "peer-to-peer self-test verdict and why, one exchange through the ABI checked on the host; exits 0")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -876,6 +970,10 @@ def main():
         pg = dist.group.WORLD
 
     import rlhip
+
+    if args.preflight:
+        preflight(torch, rlhip, rank, local_rank, world, pg, backend)
+        return
 
     env = rlhip.HipVecEnv("cartpole", N_ENVS, seed=123, env_id_base=rank * N_ENVS)
     pol = rlhip.PPOPolicy(env, update_freq=T_ROLLOUT, hidden=HIDDEN, seed=123, process_group=pg)

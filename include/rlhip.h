@@ -493,6 +493,11 @@ int32_t rlhip_comm_init(int32_t rank, int32_t world, const uint8_t* unique_id_ho
 int32_t rlhip_comm_export(rlhip_comm_t comm, uint8_t handle_out_host[64], int32_t* device_out);
 int32_t rlhip_p2p_setup(rlhip_comm_t comm, const uint8_t* handles_host /* world x 64 B */,
                         const int32_t* devices_host /* world */, int32_t* active_out);
+/* Switch the peer-to-peer path of this rank off (`why_host` is recorded for rlhip_comm_info): for a host that learns over its own
+ * transport that another rank's set-up FAILED WITH AN ERROR (rlhip_comm_export / rlhip_p2p_setup returned non-zero there, so that
+ * rank took no part in the agreement) -- every rank must then use the same transport.  Not needed after a clean
+ * rlhip_p2p_setup: its verdict is already agreed across the ranks. */
+int32_t rlhip_comm_disable_p2p(rlhip_comm_t comm, const char* why_host);
 int32_t rlhip_allreduce_grads(rlhip_comm_t comm, float* grad, int64_t n, rlhip_stream_t stream);
 int32_t rlhip_comm_check(rlhip_comm_t comm);
 int32_t rlhip_comm_info(rlhip_comm_t comm, rlhip_comm_desc* out_host);

@@ -309,13 +309,22 @@ int32_t rlhip_p2p_setup(rlhip_comm_t comm, const uint8_t* handles_host, const in
             for (int r = 0; r < c->world; ++r) acc += selftest_value(r, k, i);
             want[(size_t)i] = acc;
         }
-        RLHIP_CHECK_HIP(hipMemcpy(c->scratch, x.data(), (size_t)nt * 4, hipMemcpyHostToDevice));
-        rc = rlhip_p2p_allreduce_f32(c->scratch, nt, c->cap, c->rank, c->world, c->peers, ++c->seq, 1ll << 22, c->status,
-                                     nullptr);
-        if (rc) return rc;
-        RLHIP_CHECK_HIP(hipStreamSynchronize(nullptr));
-        RLHIP_CHECK_HIP(hipMemcpy(got.data(), c->scratch, (size_t)nt * 4, hipMemcpyDeviceToHost));
-        if (c->status[0] != 0) {
+        // a HIP error on THIS rank must not end the call here: the peers are (or will be) waiting in the agreement round below,
+        // and with an RCCL communicator that round is a collective -- a rank that returned early would hang all the others.
+        // Record the failure, keep consuming sequence numbers in step with the peers, vote "failed".
+        hipError_t he = hipMemcpy(c->scratch, x.data(), (size_t)nt * 4, hipMemcpyHostToDevice);
+        rc = he == hipSuccess ? rlhip_p2p_allreduce_f32(c->scratch, nt, c->cap, c->rank, c->world, c->peers, ++c->seq, 1ll << 22,
+                                                        c->status, nullptr)
+                              : (++c->seq, RLHIP_EHIP);
+        if (rc == RLHIP_OK) he = hipStreamSynchronize(nullptr);
+        if (rc == RLHIP_OK && he == hipSuccess) he = hipMemcpy(got.data(), c->scratch, (size_t)nt * 4, hipMemcpyDeviceToHost);
+        if (rc != RLHIP_OK || he != hipSuccess) {
+            if (passed)
+                snprintf(c->why, sizeof(c->why), "self-test round %d: %s", k,
+                         rc != RLHIP_OK ? rlhip_last_error() : hipGetErrorString(he));
+            (void)hipGetLastError();
+            passed = false;
+        } else if (c->status[0] != 0) {
             if (passed) snprintf(c->why, sizeof(c->why), "self-test round %d: a peer's flag never arrived (timeout)", k);
             passed = false;
         } else if (memcmp(got.data(), want.data(), (size_t)nt * 4) != 0) {
@@ -330,6 +339,16 @@ int32_t rlhip_p2p_setup(rlhip_comm_t comm, const uint8_t* handles_host, const in
     c->status[0] = 0;  // a failed self-test is not a failure of the run: the library collective takes over
     c->p2p_active = all_ok;
     *active_out = all_ok ? 1 : 0;
+    return RLHIP_OK;
+}
+
+/* a host that learns -- over its own transport -- that some rank failed its set-up switches the peer-to-peer path off on the
+ * ranks where it validated, so that every rank takes the same transport (ncclAllReduce, or the host's own collective) */
+int32_t rlhip_comm_disable_p2p(rlhip_comm_t comm, const char* why_host) {
+    Comm* c = as_comm(comm);
+    RLHIP_REQUIRE(c, "bad communicator");
+    c->p2p_active = false;
+    snprintf(c->why, sizeof(c->why), "%s", why_host && *why_host ? why_host : "switched off by the host");
     return RLHIP_OK;
 }
 

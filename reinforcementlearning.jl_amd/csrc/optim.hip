@@ -78,6 +78,7 @@ constexpr int DEPART_CLASSES = 64;
 constexpr int DEPART_LINE_WORDS = 32;                                          // 128 bytes between two counters
 constexpr int DEPART_BLOCK_WORDS = (DEPART_CLASSES + 1) * DEPART_LINE_WORDS;   // 64 class counters + the top word
 __device__ __forceinline__ void advance_beta_pow_last_out(float* beta_pow, float b1, float b2, unsigned int* departed) {
+    if (!departed) return;  // two-launch form: beta_pow_advance_kernel follows
     __syncthreads();  // every thread of this workgroup has read beta_pow
     if (threadIdx.x != 0) return;
     const unsigned int grid = gridDim.x, cls = blockIdx.x % DEPART_CLASSES;
@@ -576,16 +577,10 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
     Scratch* sc;
     int32_t rc = get_scratch(&sc);
     if (rc) return rc;
-    unsigned int* dep = depart_counter(*sc, s);
-    if (n == 0 || !dep) {  // nothing to fold the advance into / no counter slot left for this stream: its own launch
-        if (n > 0) {
-            unsigned int* scratch_ctr = nullptr;
-            RLHIP_CHECK_HIP(hipMallocAsync((void**)&scratch_ctr, sizeof(unsigned int) * DEPART_BLOCK_WORDS, s));
-            RLHIP_CHECK_HIP(hipMemsetAsync(scratch_ctr, 0, sizeof(unsigned int) * DEPART_BLOCK_WORDS, s));
-            const int rcl = adam_launch(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, scratch_ctr, s);
-            (void)hipFreeAsync(scratch_ctr, s);
-            return rcl;
-        }
+    static const bool fold = getenv("RLHIP_ADAM_FOLD") ? atoi(getenv("RLHIP_ADAM_FOLD")) != 0 : true;  // A / B hook (round 5)
+    unsigned int* dep = fold ? depart_counter(*sc, s) : nullptr;
+    if (n == 0 || !dep) {  // nothing to fold the advance into / two-launch form: the update, then `bt = bt .* b` on its own
+        if (n > 0 && (rc = adam_launch(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, nullptr, s))) return rc;
         hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);
         RLHIP_LAUNCH_CHECK();
         return RLHIP_OK;

@@ -230,7 +230,22 @@ __global__ __launch_bounds__(256) void gather_rec_kernel(RingView rb, const int6
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {
         const int64_t b = b0 + 256 * u;
-        if (b < batch) t[u] = ring_load_transition<NT>(rr, pd.tree ? prio_draw_one(pd, rb, b) : idx[b]);
+        if (b < batch) {
+            if (SPL == 3) {  // TIMING ONLY (A / B hook): the access pattern of a 64-byte transition record -- all three chunks of a
+                             // sample out of ONE 64-byte line (the wrong data: record(s) and its neighbour)
+                int64_t o0, o1;
+                ring_record_offsets(rr, idx[b], o0, o1);
+                o0 &= ~(int64_t)63;
+                RingChunk c0, c1, c2;
+                c0.u = *reinterpret_cast<const nt_u32x4*>(rr.rec + o0);
+                c1.u = *reinterpret_cast<const nt_u32x4*>(rr.rec + o0 + 16);
+                c2.u = *reinterpret_cast<const nt_u32x4*>(rr.rec + o0 + 32);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[u].s[k] = c0.f[k], t[u].sn[k] = c2.f[k];
+                t[u].a = (int32_t)c1.u[0], t[u].r = c1.f[1], t[u].t = c1.u[2] & 1u;
+            } else
+                t[u] = ring_load_transition<NT>(rr, pd.tree ? prio_draw_one(pd, rb, b) : idx[b]);
+        }
     }
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {
@@ -629,6 +644,9 @@ static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_
                                idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
         else if (variant == 2)                                                                                             \
             hipLaunchKernelGGL((gather_rec_kernel<OD, false, 2>), dim3((int)((batch + 511) / 512)), dim3(256), 0, st, v,    \
+                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
+        else if (variant == 4)                                                                                             \
+            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 3>), dim3((int)((batch + 767) / 768)), dim3(256), 0, st, v,    \
                                idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
         else if (variant == 3)                                                                                             \
             hipLaunchKernelGGL((gather_rec_kernel<OD, false, 4>), dim3((int)((batch + 1023) / 1024)), dim3(256), 0, st, v,  \

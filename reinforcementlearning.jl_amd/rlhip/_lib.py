@@ -197,6 +197,7 @@ _PROTOS = {
     "rlhip_comm_init": (i32, [i32, i32, vp, i64, P(vp)]),
     "rlhip_comm_export": (i32, [vp, vp, P(i32)]),
     "rlhip_p2p_setup": (i32, [vp, vp, vp, P(i32)]),
+    "rlhip_comm_disable_p2p": (i32, [vp, C.c_char_p]),
     "rlhip_allreduce_grads": (i32, [vp, vp, i64, vp]),
     "rlhip_comm_check": (i32, [vp]),
     "rlhip_comm_info": (i32, [vp, P(CommDesc)]),

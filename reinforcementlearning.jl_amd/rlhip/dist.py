@@ -114,15 +114,43 @@ class HipComm:
         call("rlhip_comm_init", self.rank, self.world, (C.c_uint8 * 128).from_buffer_copy(uid[0]) if uid[0] else None,
              self.cap, C.byref(h))
         self.h = h
+        # From here on a failure on ONE rank must not strand the others in a collective (round 5): an error
+        # of this rank's export / set-up is caught, reported to every rank through the set-up transport (the object gathers
+        # below), and answered everywhere by "peer-to-peer not active" -- the run continues over ncclAllReduce (or, without an
+        # RCCL communicator, torch.distributed) and says so in `transport()`.
+        self.setup_error = None
         hb, dev_id = (C.c_uint8 * 64)(), _lib.i32(0)
-        call("rlhip_comm_export", h, hb, C.byref(dev_id))
+        try:
+            call("rlhip_comm_export", h, hb, C.byref(dev_id))
+            if os.environ.get("RLHIP_TEST_FAIL_EXPORT_RANK", "") == str(self.rank):  # test hook: tests/test_gpu_run.py
+                raise _lib.RLHipError("injected rlhip_comm_export failure (RLHIP_TEST_FAIL_EXPORT_RANK)")
+            mine = (bytes(hb), int(dev_id.value), None)
+        except _lib.RLHipError as exc:
+            self.setup_error = f"rank {self.rank}: {exc}"
+            mine = (None, -1, self.setup_error)
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (bytes(hb), int(dev_id.value)), group=group)
-        if os.environ.get("RLHIP_NO_P2P", "0") != "1" and self.world > 1:
+        dist.all_gather_object(gathered, mine, group=group)
+        export_errors = [g[2] for g in gathered if g[2]]
+        ran_setup = False
+        if os.environ.get("RLHIP_NO_P2P", "0") != "1" and self.world > 1 and not export_errors:
             handles = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(g[0] for g in gathered))
             devices = (_lib.i32 * self.world)(*[g[1] for g in gathered])
             active = _lib.i32(0)
-            call("rlhip_p2p_setup", h, handles, devices, C.byref(active))
+            ran_setup = True
+            try:
+                call("rlhip_p2p_setup", h, handles, devices, C.byref(active))
+            except _lib.RLHipError as exc:  # (HIP errors inside the set-up are votes, not returns: this is the RCCL agreement itself failing)
+                self.setup_error = f"rank {self.rank}: {exc}"
+        elif export_errors and self.world > 1:
+            call("rlhip_comm_disable_p2p", h, ("a rank could not export its exchange buffer: " + export_errors[0])[:250].encode())
+        if ran_setup:
+            # the verdict of a clean set-up is already agreed inside the library; a rank whose call RAISED took no part in that
+            # agreement, so agree once more over the set-up transport and switch the path off wherever it had validated
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, self.setup_error, group=group)
+            errs = [v for v in verdicts if v]
+            if errs:
+                call("rlhip_comm_disable_p2p", h, ("set-up failed with an error on another rank: " + errs[0])[:250].encode())
         d = self.info()
         if self.world > 1 and not d.p2p_active:
             msg = (f"[rlhip] rank {self.rank}: peer-to-peer gradient exchange NOT active: {d.why.decode()} -> "

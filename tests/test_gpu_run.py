@@ -123,8 +123,9 @@ def _gpu_worker(rank, world, port, q, extra_env=None):
     pol.update_()
     torch.cuda.synchronize()
     same = rdist.params_checksum_equal(pol.params.cpu(), dist.group.WORLD)
+    expect_p2p = os.environ.get("RLHIP_NO_P2P", "0") != "1" and "RLHIP_TEST_FAIL_EXPORT_RANK" not in os.environ
     q.put((rank, pol.params.cpu().numpy(), pol.trajectory.obs.cpu().numpy(), same and (
-        (getattr(pol, "_p2p", None) is not None) == (os.environ.get("RLHIP_NO_P2P", "0") != "1"))))
+        (getattr(pol, "_p2p", None) is not None) == expect_p2p), pol._hipcomm.transport()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -153,7 +154,7 @@ def test_two_ranks_one_gpu_gradient_allreduce(rl, mode):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, p0, obs0, s0), (_, p1, obs1, s1) = res
+    (_, p0, obs0, s0, _t0), (_, p1, obs1, s1, _t1) = res
     assert np.array_equal(p0, p1) and s0 and s1  # replicas bit-identical after 16 all-reduced steps
     # one process owning both shards: same rollouts (global env ids), nearly the same update
     n_per, T = 256, 8
@@ -309,6 +310,91 @@ def test_four_ranks_one_gpu_fused_exchange_keeps_replicas_identical(rl):
     assert all(r[3] for r in res)
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1])
+
+
+def _run_gpu_workers(world, extra):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_eight_ranks_one_gpu_fused_exchange_keeps_replicas_identical(rl):
+    """world = 8, the size of the target node: the fused reduce + peer exchange + clip + Adam kernel with
+    eight slots / eight flags per exchange, eight processes sharing this box's one GPU.  The policy is 4 -> 64 -> {2, 1}
+    (14 spinning workgroups per rank): with the headline's 53 per rank, seven ranks' spinners (371 workgroups of 1024 threads)
+    would hold every CU of the one shared device and starve the eighth rank's gradient launch -- an artefact of eight ranks on
+    ONE device (on the node every rank owns its GPU), bounded by the exchange's timeout but not worth provoking."""
+    import json
+
+    res = _run_gpu_workers(8, {"RLHIP_TEST_PPO_KW": json.dumps({"hidden": 64})})
+    assert all(r[3] for r in res), [r[4] for r in res]
+    assert all(r[4].startswith("p2p") for r in res)
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1])
+
+
+def test_a_rank_that_fails_its_export_switches_every_rank_to_the_fallback(rl):
+    """rank 1's rlhip_comm_export `fails` (injected).  No rank hangs; every rank reports the peer-to-peer path
+    as not active with the failing rank's message, the update runs over the fallback collective and the replicas end
+    bit-identical."""
+    res = _run_gpu_workers(2, {"RLHIP_TEST_FAIL_EXPORT_RANK": "1"})
+    assert all(r[3] for r in res), [r[4] for r in res]
+    for r in res:
+        assert "injected rlhip_comm_export failure" in r[4] and not r[4].startswith("p2p"), r[4]
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_bench_preflight_two_ranks_one_device():
+    """`bench.py --gpus 2 --preflight`: one JSON report with the peer-access row, the per-peer IPC round trip,
+    the set-up verdict with its reason and one exchange checked on the host, per rank; exit status 0; a few seconds."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RLHIP_BENCH_SINGLE_DEVICE="1", RLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--preflight"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["world"] == 2 and len(d["preflight"]) == 2 and d["exchange_ok_on_every_rank"] is True
+    for rk, rep in enumerate(d["preflight"]):
+        peer = str(1 - rk)
+        assert rep["rank"] == rk and rep["can_access_peer"][peer] is True and rep["ipc_round_trip"][peer] == "ok", rep
+        assert rep["comm"]["why"] and rep["comm"]["setup_error"] is None and rep["exchange"]["correct"] and not rep["exchange"]["timeout"]
+    assert d["p2p_active_on_every_rank"] == all(rep["comm"]["p2p_active"] for rep in d["preflight"])
+
+
+def test_bench_eight_ranks_on_one_device_prints_the_contract_line():
+    """bare `python bench.py --gpus 8` with all eight ranks on this box's one GPU: the contract line at the
+    world size of the target node, `p2p_timeouts` false, `replicas_bit_identical` true.  RLHIP_P2P_UNFUSED=1: the exchange runs
+    as its own small kernel instead of inside the 53-workgroup reduce kernel, whose spinners from seven ranks would occupy
+    every CU of the one shared device (see the eight-rank test above)."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RLHIP_BENCH_SINGLE_DEVICE="1", RLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RLHIP_P2P_UNFUSED="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["n_envs_per_gpu"] == 4096 and d["replicas_bit_identical"] is True
+    assert d["p2p_timeouts"] is False and d["gradient_allreduce"].startswith("p2p"), d["gradient_allreduce"]
+    assert np.isfinite(d["final_loss"])
 
 
 @pytest.mark.parametrize("layers,prioritized", [(2, False), (3, False), (2, True)])
