@@ -137,7 +137,46 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
 
 # PMC measurement of the env-step kernel (tools/pmc_env.sh + tools/envstep.py; profiles/r04_pmc.md), valid for
 # the kernel sources whose sha256 (first 16 hex digits over csrc/envs.hip + csrc/env_device.h) is `sha`
-PMC_TRAFFIC = {"sha": "7aac317ebcd8563e", "n_envs": 1 << 24, "bytes": 822237696.0, "source": "profiles/r04_pmc.md"}
+PMC_TRAFFIC = {"sha": "23d6334bde658716", "n_envs": 1 << 24, "bytes": 822223769.6, "source": "profiles/r05_pmc.md"}
+
+# The same for the other HBM-bound kernels of the bench line: HBM bytes per launch from the PMC counters
+# (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, mean of the last launches: tools/r5_pmc.sh), each valid only while the
+# sources of ITS kernel still hash to what was profiled (`files`, sha256[:16] over them) -- otherwise the entry reports null.
+# `fetch_x2: False`: a kernel of scattered 16-byte reads, for which the guide's x 2 streaming calibration of FETCH_SIZE does not
+# hold (profiles/r05_pmc.md: the counter tallies 64 bytes per fabric request whatever its size).
+PMC_SIDE = {
+    # name in the line: (source files, sha, bytes per launch, note)
+}
+PMC_SIDE_SOURCE = "profiles/r05_pmc.md"
+
+
+def sources_sha(files):
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "reinforcementlearning.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def attach_traffic(out):
+    """adds `traffic` (PMC bytes per launch or None), `traffic_ratio` (traffic / algorithmic bytes) and `traffic_source` to the
+    entries of `out` that PMC_SIDE knows"""
+    for name, (files, sha, nbytes, note) in PMC_SIDE.items():
+        e = out.get(name)
+        if not isinstance(e, dict):
+            continue
+        now = sources_sha(files)
+        if nbytes is not None and sha == now:
+            e["traffic"] = nbytes
+            if e.get("algorithmic_bytes"):
+                e["traffic_ratio"] = round(nbytes / e["algorithmic_bytes"], 4)
+            e["traffic_source"] = f"{PMC_SIDE_SOURCE} (sources {'+'.join(files)} sha {now}){'; ' + note if note else ''}"
+        else:
+            e["traffic"] = None
+            e["traffic_source"] = f"not measured for the current kernel sources ({'+'.join(files)} sha {now}; last PMC pass: sha {sha})"
+    return out
 
 
 def env_kernel_sha():
@@ -157,7 +196,7 @@ def measured_traffic(n_envs):
     return None, f"not measured for the current kernel sources (sha {sha}; last PMC pass: sha {PMC_TRAFFIC['sha'] or 'none'})"
 
 
-def roofline_extras(torch, rlhip):
+def roofline_extras(torch, rlhip, hbm_only=False):
     """Side kernels at the sizes BASELINE.json names: GAE scan (2^20 envs x 32), u8 frame gather from the full 2^20-slot
     29.6 GB ring of config 5 (uniform + prioritized + stack-at-sample), the bf16 Dense layer, the DQN vec-step of config 2
     (2- and 3-layer networks, per-step protocol and one-call-per-step), Pendulum PPO of config 3 (2-layer fp32, 3-layer MFMA)."""
@@ -177,7 +216,7 @@ def roofline_extras(torch, rlhip):
     gb = (17 * n * T + 4 * n) / 1e9
     out["gae_returns"] = {"bound": "hbm", "n_envs": n, "T": T, "us_per_launch": round(ms * 1e3, 1),
                           "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+                          "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(gb * 1e9)}
     del r, v, term
     # BASELINE configs[4]: 2^20-slot ring of 84x84x4 u8 frames (29.6 GB of states), prioritized sampling
     # (device sum-tree, priorities U(0,1)^0.6) + frame gather, batch 4096 -> 2 * (2 * 28224 + 9) B per sample
@@ -229,7 +268,7 @@ def roofline_extras(torch, rlhip):
                               "ring_state_gb": round((cap + 1) * fb / 1e9, 2),
                               "us_per_launch": round(ms * 1e3, 1), "achieved": round(gb / (ms * 1e-3), 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4),
-                              "samples_per_sec": round(batch / (ms * 1e-3), 1),
+                              "algorithmic_bytes": int(gb * 1e9), "samples_per_sec": round(batch / (ms * 1e-3), 1),
                               "us_per_launch_repeated_batch": round(ms_rep * 1e3, 1),
                               "prioritized_sample_us": round(ms_s * 1e3, 1),
                               "priority_update_us": round(ms_u * 1e3, 1),
@@ -312,9 +351,12 @@ def roofline_extras(torch, rlhip):
         "bound": "hbm", "capacity": cap, "frame_bytes": f1, "n_stack": 4, "batch": batch,
         "ring_state_gb": round((cap + 1) * f1 / 1e9, 2), "us_per_launch": round(ms * 1e3, 1),
         "achieved": round(gb / (ms * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "samples_per_sec": round(batch / (ms * 1e-3), 1)}
+        "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(gb * 1e9),
+        "samples_per_sec": round(batch / (ms * 1e-3), 1)}
     del tr1, outs, idx1
     torch.cuda.empty_cache()
+    if hbm_only:  # tools/r5_pmc_all.py: the HBM-bound legs alone, for the PMC traffic passes
+        return out
     # BASELINE configs[1]: 4096-way CartPole + QBasedPolicy(DQN, 4->128->2), batch 512, 1 update per vec-step
     n = N_ENVS
     env = rlhip.CartPoleEnv(n, seed=5)
@@ -639,7 +681,7 @@ def roofline_hbm_side(torch, rlhip):
     # --- small-observation gather: CartPole transitions (ns = 4), 2^20 samples from a 256 x 4096 ring
     n_env, cap, batch = 4096, 256, 1 << 20
     tr = CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=4)
-    tr.state.normal_()
+    tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
     tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap
     idx = tr.sample_indices(batch, seed=11, draw_ctr=0)
     bufs = tr.gather(idx)
@@ -657,11 +699,11 @@ def roofline_hbm_side(torch, rlhip):
     ms = event_time_ms(sg, 10, lib, s, SETTLE_S) - event_time_ms(smp, 10, lib, s)
     out["gather_small"] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env,
                                 kernel="gather_rec_kernel<4>", samples_per_sec=round(batch / (ms * 1e-3), 1),
-                                note="round 5: the ring stores one 32-byte record {s[4], a, r, t} per (state slot, env) -- the pushed "
-                                     "tuple -- so a sample reads the state half of record(s) and the whole record(s'): two 32-byte sectors "
-                                     "out of a 34 MB ring (Infinity-Cache resident); 82 B per sample are the algorithmic bytes.  Round 4 "
-                                     "(transition-major states + three traces: five 64-byte lines per sample) took 79 us for this launch, "
-                                     "rounds 1 - 3 (component-major: eleven lines) 164 - 168 us")
+                                note="round 5: the ring stores one 64-byte record {s[4], a, r, t, s'[4]} per (state slot, env) -- the "
+                                     "whole transition in ONE cache line = one fabric request per sample (the kernel is bound by the "
+                                     "L2's 64-byte request rate, ~45 G requests / s: profiles/r05_pmc.md), out of a 67 MB ring "
+                                     "(Infinity-Cache resident); 82 B per sample are the algorithmic bytes.  32-byte records (two lines "
+                                     "per sample) took 43.5 us for this launch, round 4 (five lines) 79 us, rounds 1 - 3 (eleven) 164 - 168 us")
     return out
 
 
@@ -1019,6 +1061,7 @@ def main():
         extras["roofline"] = roofline_env_step(torch, rlhip)
         extras["roofline_extra"] = roofline_extras(torch, rlhip)
         extras["roofline_extra"].update(side)
+        attach_traffic(extras["roofline_extra"])
 
     if want_extras and extras_first:
         run_extras()

@@ -41,8 +41,8 @@ extern "C" {
 #define RLHIP_ETIMEOUT (-4) /* a peer never arrived at a gradient exchange; the result was overwritten with NaN */
 #define RLHIP_ECOMM (-5)    /* RCCL is missing or one of its calls failed / no transport for this exchange */
 
-/* 2 (round 5): rlhip_ring rings of Float32 observations with <= 4 components store 32-byte records (state + action + reward +
- *    terminal per (slot, env)); `rlhip_ring.layout` names the layout, rlhip_ring_init takes NULL action / reward / terminal for
+/* 2 (round 5): rlhip_ring rings of Float32 observations with <= 4 components store 64-byte transition records (s, a, r, t, s'
+ *    per (slot, env)); `rlhip_ring.layout` names the layout, rlhip_ring_init takes NULL action / reward / terminal for
  *    them; rlhip_ppo_workspace_init + the capacity check of rlhip_ppo_update_f32; rlhip_eps_greedy_prob_f32.  ABI 1 stored those
  *    states transition-major with three separate traces (and round 3 component-major): a host built against an older header
  *    fails rlhip_abi_version() == RLHIP_ABI_VERSION and, if it skips that check, rlhip_ring_init (RLHIP_EINVAL). */
@@ -326,14 +326,16 @@ int32_t rlhip_td_target_f32(const float* qt_next, int64_t na, int64_t n, int64_t
  *   RLHIP_RING_FRAMES   every trace as pushed: state[(slot * obs_dim + k) * n_env + e] (capacity + 1 slots), action / reward /
  *                       terminal[slot * n_env + e] (capacity slots) -- UInt8 frames and Float32 observations with > 4 components.
  *   RLHIP_RING_RECORDS  Float32 observations with <= 4 components (the classic-control envs; what the fused DQN learners take):
- *                       `state` holds (capacity + 1) * n_env RECORDS of 32 bytes,
- *                           record[slot * n_env + e] = { float s[4]; int32 action; float reward; uint32 terminal; uint32 spare },
- *                       where (action, reward, terminal) are those of the transition that ARRIVED at state s -- the record is the
- *                       tuple push!(trajectory, (state = s', action, reward, terminal)) pushes, written once, and a sampled
- *                       transition reads two 32-byte sectors (round 4: five cache lines).  Logical transition i has s in slot
- *                       (head_sa + i) mod (capacity + 1) and (s', a, r, t) in the next slot; `action`, `reward`, `terminal` are
- *                       NULL (a strided view for a host: word 4 / 5 / 6 of each record).  s[k >= obs_dim] = 0.
- * rlhip_ring_state_bytes() is the size of the `state` allocation for either layout (32-byte aligned for records). */
+ *                       `state` holds (capacity + 1) * n_env RECORDS of 64 bytes (one cache line = one fabric request),
+ *                           record[slot * n_env + e] = { float s[4]; int32 action; float reward; uint32 terminal; uint32 spare;
+ *                                                        float s_next[4]; uint32 pad[4] },
+ *                       the whole transition (s, a, r, t, s') that LEAVES the state of that slot: a sampled transition is one
+ *                       line (round 4: five; measured in csrc/ring_device.h).  push!(trajectory, (state = s', action, reward,
+ *                       terminal)) completes the previous slot's record and opens the next (s = s': a state is stored twice).
+ *                       Logical transition i lives in slot (head_sa + i) mod (capacity + 1); the newest slot holds a state only.
+ *                       `action`, `reward`, `terminal` are NULL (a strided view for a host: words 4 / 5 / 6 of each 16-word
+ *                       record, s_next at words 8..11).  s[k >= obs_dim] = s_next[k >= obs_dim] = 0.
+ * rlhip_ring_state_bytes() is the size of the `state` allocation for either layout (64-byte aligned for records). */
 #define RLHIP_RING_FRAMES 0
 #define RLHIP_RING_RECORDS 2 /* (1 was ABI 1's transition-major state trace) */
 typedef struct {
@@ -342,7 +344,7 @@ typedef struct {
                                                * terminal traces in both layouts: lengths, sampler range, sum-tree keys) */
     int32_t elem_bytes;
     int32_t layout;    /* RLHIP_RING_FRAMES | RLHIP_RING_RECORDS */
-    void* state;       /* FRAMES: (capacity + 1) * obs_dim * n_env elements; RECORDS: (capacity + 1) * n_env * 32 bytes */
+    void* state;       /* FRAMES: (capacity + 1) * obs_dim * n_env elements; RECORDS: (capacity + 1) * n_env * 64 bytes */
     int32_t* action;   /* FRAMES: capacity * n_env; RECORDS: NULL */
     float* reward;     /* FRAMES: capacity * n_env; RECORDS: NULL */
     uint8_t* terminal; /* FRAMES: capacity * n_env; RECORDS: NULL */

@@ -17,7 +17,8 @@ namespace rlhip {
 
 struct ActRing {
     void* rec;           // record ring (ring_device.h)
-    int64_t state_slot;  // physical slot receiving the pushed tuple (s', a, r, t)
+    int64_t state_slot;  // physical slot opened by s'
+    int64_t prev_slot;   // the slot before it: its record is completed with (a, r, t, s')
 };
 
 struct RegQa {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void dqn_act_kernel(P p, EnvArrays<float> s
     }
 #pragma unroll
     for (int k = NS; k < 4; ++k) xn[k] = 0.f;
-    ring_store_record(rb.rec, rb.state_slot, n, env, xn, a, r, d ? 1u : 0u);
+    ring_push_transition(rb.rec, rb.state_slot, rb.prev_slot, n, env, xn, a, r, d ? 1u : 0u);
 }
 
 template <class P>
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void env_act_push_kernel(P p, EnvArrays<float>
     }
 #pragma unroll
     for (int k = NS; k < 4; ++k) xn[k] = 0.f;
-    ring_store_record(rb.rec, rb.state_slot, n, env, xn, a, r, d ? 1u : 0u);
+    ring_push_transition(rb.rec, rb.state_slot, rb.prev_slot, n, env, xn, a, r, d ? 1u : 0u);
 }
 
 // the slots push!(trajectory, (state = s', action, reward, terminal)) writes (ring.hip); advances the ring counters
@@ -168,6 +169,7 @@ static ActRing claim_slots(rlhip_ring* rb) {
         ar.state_slot = rb->head_sa;
         rb->head_sa = (rb->head_sa + 1) % sframes;
     }
+    ar.prev_slot = (ar.state_slot + sframes - 1) % sframes;
     return ar;
 }
 

@@ -518,7 +518,9 @@ static int32_t adam_launch(float* params, const float* grad, float* m, float* v,
         // one trip per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes 307 us with
         // 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones (tools/adam_grid_ab.py); non-temporal stores.
         // U = 16-byte chunks per thread and array, `stride` apart; the grid is sized so that all U really are in flight (ADVICE
-        // r4: round 4 launched one thread per chunk, which left the second chunk of every thread out of range)
+        // r4: round 4 launched one thread per chunk with U = 2, which left the second chunk of every thread out of range, so its
+        // "two chunks" A / B compared nothing).  Re-measured with the grid halved (tools/r5_b.sh, same box): U = 2 is 1 - 2 %
+        // faster at both sizes (21.2 vs 21.5 us, 333 - 338 vs 341 us) -- inside the run-to-run spread; U stays 1
         constexpr int U = ADAM_CHUNKS;
         const int grid = grid_for((n / 4 + U - 1) / U, 256, 1 << 20);
         hipLaunchKernelGGL((adam_vec4_kernel<true, U>), dim3(grid), dim3(256), 0, s, params, grad, m, v, beta_pow, n, lr, beta1,
@@ -577,8 +579,11 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
     Scratch* sc;
     int32_t rc = get_scratch(&sc);
     if (rc) return rc;
-    static const bool fold = getenv("RLHIP_ADAM_FOLD") ? atoi(getenv("RLHIP_ADAM_FOLD")) != 0 : true;  // A / B hook (round 5)
-    unsigned int* dep = fold ? depart_counter(*sc, s) : nullptr;
+    // `bt = bt .* b` inside the update launch (last workgroup out) up to 2^23 parameters, as its own one-thread launch beyond:
+    // same-box A / B (tools/r5_c.sh): 2^22 parameters 21.2 us folded against 22.05 us in two launches; 2^26 parameters 342.5
+    // against 339.5 -- 65536 departure atomics cost more than the second launch saves, even counted in two levels (with ONE
+    // counter: 771 us)
+    unsigned int* dep = n <= ((int64_t)1 << 23) ? depart_counter(*sc, s) : nullptr;
     if (n == 0 || !dep) {  // nothing to fold the advance into / two-launch form: the update, then `bt = bt .* b` on its own
         if (n > 0 && (rc = adam_launch(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, nullptr, s))) return rc;
         hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);

@@ -9,8 +9,8 @@
 // In the reference the trajectory always lives in host RAM and the gather is a per-sample strided
 // memcpy followed by an H2D copy of the batch; here the ring never leaves HBM.
 //
-// Layout: one frame per slot.  Float32 observations with <= 4 components: one 32-byte RECORD per (state slot, env) holding the
-// pushed tuple (s', a, r, t) -- ring_device.h; everything else as pushed, state[(slot * obs_dim + k) * n_env + e] with action /
+// Layout: one frame per slot.  Float32 observations with <= 4 components: one 64-byte RECORD per (state slot, env) holding the
+// whole transition (s, a, r, t, s') that leaves that state -- ring_device.h; everything else as pushed, state[(slot * obs_dim + k) * n_env + e] with action /
 // reward / terminal [slot * n_env + e].  One push = one contiguous frame per trace (coalesced 16 B/lane copies).
 // Gather: the index tile of a workgroup is staged in LDS once (flat index -> physical state slot,
 // next slot, transition slot, env), then
@@ -108,25 +108,27 @@ __global__ __launch_bounds__(256) void check_indices_kernel(const int64_t* __res
 }
 
 // Record rings (ring_device.h): the env's observation buffer is component-major (obs_dim x n_env), so the push transposes --
-// lane = env, OD coalesced reads, then the whole 32-byte record (state + the transition that arrived at it) as two 16-byte
-// stores; a wave writes 2 KB contiguous.  a == NULL: push!(trajectory, (state = s,)).
+// lane = env, OD coalesced reads, then the record writes of ring_push_transition / ring_push_state (16-byte stores; a wave
+// covers 4 KB of contiguous records).  a == NULL: push!(trajectory, (state = s,)).
 template <int OD>
-__global__ __launch_bounds__(256) void push_record_kernel(void* __restrict__ rec, int64_t slot, const float* __restrict__ obs,
-                                                          int64_t n, const int32_t* __restrict__ a, const float* __restrict__ r,
+__global__ __launch_bounds__(256) void push_record_kernel(void* __restrict__ rec, int64_t slot, int64_t slot_prev,
+                                                          const float* __restrict__ obs, int64_t n,
+                                                          const int32_t* __restrict__ a, const float* __restrict__ r,
                                                           const uint8_t* __restrict__ t) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < OD; ++k) v[k] = obs[(int64_t)k * n + e];
-    if (a) ring_store_record(rec, slot, n, e, v, a[e], r[e], (uint32_t)t[e]);
-    else ring_store_state_only(rec, slot, n, e, v);
+    if (a) ring_push_transition(rec, slot, slot_prev, n, e, v, a[e], r[e], (uint32_t)t[e]);
+    else ring_push_state(rec, slot, n, e, v);
 }
 
-static int32_t push_record(void* rec, int64_t slot, const float* obs, int64_t n, int64_t od, const int32_t* a, const float* r,
-                           const uint8_t* t, hipStream_t s) {
+static int32_t push_record(void* rec, int64_t slot, int64_t slot_prev, const float* obs, int64_t n, int64_t od, const int32_t* a,
+                           const float* r, const uint8_t* t, hipStream_t s) {
     const dim3 grid((unsigned)((n + 255) / 256));
-#define RLHIP_PUSH_REC(OD_) hipLaunchKernelGGL((push_record_kernel<OD_>), grid, dim3(256), 0, s, rec, slot, obs, n, a, r, t)
+#define RLHIP_PUSH_REC(OD_) \
+    hipLaunchKernelGGL((push_record_kernel<OD_>), grid, dim3(256), 0, s, rec, slot, slot_prev, obs, n, a, r, t)
     if (od == 4) RLHIP_PUSH_REC(4);
     else if (od == 3) RLHIP_PUSH_REC(3);
     else if (od == 2) RLHIP_PUSH_REC(2);
@@ -216,50 +218,26 @@ __device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingV
 }
 
 // record rings (Float32 observations with OD <= 4 components: the classic-control envs): one LANE per sample, the three
-// 16-byte loads of the sample (state half of record(s), whole record(s')) issued before the first store -- two 32-byte
-// sectors per sample (round 4: five 64-byte lines; round 3: eleven).  Stores are coalesced (consecutive lanes = consecutive
+// 16-byte loads of the sample's ONE 64-byte record issued before the first store -- one fabric request per sample (round 4:
+// five lines; round 3: eleven; ring_device.h has the measurements).  Stores are coalesced (consecutive lanes = consecutive
 // samples).  Nothing is staged in LDS: a lane owns its sample from index to store (the tile-staged generic kernel above
 // is the route of the layouts without records).
-template <int OD, bool NT, int SPL>
+template <int OD>
 __global__ __launch_bounds__(256) void gather_rec_kernel(RingView rb, const int64_t* __restrict__ idx, int64_t batch,
                                                          float* __restrict__ s, int32_t* __restrict__ a, float* __restrict__ r,
                                                          uint8_t* __restrict__ term, float* __restrict__ sn, PrioDraw pd) {
-    const int64_t b0 = ((int64_t)blockIdx.x * SPL) * blockDim.x + threadIdx.x;  // SPL samples per lane, 256 apart (coalesced)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
     const RingRecs rr = {(const uint8_t*)rb.state, rb.capacity, rb.n_env, rb.head_sa};
-    RingTransition t[SPL];
+    const RingTransition t = ring_load_transition(rr, pd.tree ? prio_draw_one(pd, rb, b) : idx[b]);
 #pragma unroll
-    for (int u = 0; u < SPL; ++u) {
-        const int64_t b = b0 + 256 * u;
-        if (b < batch) {
-            if (SPL == 3) {  // TIMING ONLY (A / B hook): the access pattern of a 64-byte transition record -- all three chunks of a
-                             // sample out of ONE 64-byte line (the wrong data: record(s) and its neighbour)
-                int64_t o0, o1;
-                ring_record_offsets(rr, idx[b], o0, o1);
-                o0 &= ~(int64_t)63;
-                RingChunk c0, c1, c2;
-                c0.u = *reinterpret_cast<const nt_u32x4*>(rr.rec + o0);
-                c1.u = *reinterpret_cast<const nt_u32x4*>(rr.rec + o0 + 16);
-                c2.u = *reinterpret_cast<const nt_u32x4*>(rr.rec + o0 + 32);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[u].s[k] = c0.f[k], t[u].sn[k] = c2.f[k];
-                t[u].a = (int32_t)c1.u[0], t[u].r = c1.f[1], t[u].t = c1.u[2] & 1u;
-            } else
-                t[u] = ring_load_transition<NT>(rr, pd.tree ? prio_draw_one(pd, rb, b) : idx[b]);
-        }
+    for (int k = 0; k < OD; ++k) {
+        s[k * batch + b] = t.s[k];
+        sn[k * batch + b] = t.sn[k];
     }
-#pragma unroll
-    for (int u = 0; u < SPL; ++u) {
-        const int64_t b = b0 + 256 * u;
-        if (b >= batch) continue;
-#pragma unroll
-        for (int k = 0; k < OD; ++k) {
-            s[k * batch + b] = t[u].s[k];
-            sn[k * batch + b] = t[u].sn[k];
-        }
-        a[b] = t[u].a;
-        r[b] = t[u].r;
-        term[b] = (uint8_t)t[u].t;
-    }
+    a[b] = t.a;
+    r[b] = t.r;
+    term[b] = (uint8_t)t.t;
 }
 
 // large contiguous frames (n_env == 1): one workgroup per sample, 16 B/lane streaming copy.
@@ -449,7 +427,7 @@ static int32_t push_state_frame(rlhip_ring* rb, const void* obs, hipStream_t s) 
         rb->head_sa = (rb->head_sa + 1) % frames;
     }
     if (rb->layout == RLHIP_RING_RECORDS)
-        return push_record(rb->state, phys, (const float*)obs, rb->n_env, rb->obs_dim, nullptr, nullptr, nullptr, s);
+        return push_record(rb->state, phys, phys, (const float*)obs, rb->n_env, rb->obs_dim, nullptr, nullptr, nullptr, s);
     return copy_bytes((uint8_t*)rb->state + phys * fbytes, obs, fbytes, s);
 }
 
@@ -467,12 +445,12 @@ int32_t rlhip_ring_init(rlhip_ring* rb, int64_t capacity, int64_t n_env, int64_t
     RLHIP_REQUIRE(state != nullptr, "trace storage is NULL");
     const bool records = ring_records(obs_dim, elem_bytes);
     if (records) {
-        // the action / reward / terminal traces live inside the 32-byte records of `state` (ring_device.h): a host built
+        // the action / reward / terminal traces live inside the 64-byte records of `state` (ring_device.h): a host built
         // against the ABI-1 header (separate arrays, transition-major states) must fail here, not read transposed data later
         RLHIP_REQUIRE(!action && !reward && !terminal,
                       "record ring (Float32, obs_dim <= 4): pass NULL for action / reward / terminal and a state buffer of "
                       "rlhip_ring_state_bytes() bytes (ABI 2)");
-        RLHIP_REQUIRE(((uintptr_t)state & 31) == 0, "the record buffer must be 32-byte aligned");
+        RLHIP_REQUIRE(((uintptr_t)state & 63) == 0, "the record buffer must be 64-byte aligned");
     } else {
         RLHIP_REQUIRE(action && reward && terminal, "trace storage is NULL");
     }
@@ -519,10 +497,12 @@ int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const i
     const int64_t fbytes = rb->obs_dim * rb->n_env * (int64_t)rb->elem_bytes;
     const int64_t sphys = (rb->len_sa < sframes) ? (rb->head_sa + rb->len_sa) % sframes : rb->head_sa;
     uint8_t* sdst = (uint8_t*)rb->state + sphys * fbytes;
-    if (rb->layout == RLHIP_RING_RECORDS) {  // the pushed tuple IS one record: transposing push, one launch
+    if (rb->layout == RLHIP_RING_RECORDS) {  // completes the previous slot's record, opens the new one: transposing push, one launch
+        RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
         if (rb->len_sa < sframes) rb->len_sa += 1;
         else rb->head_sa = (rb->head_sa + 1) % sframes;
-        return push_record(rb->state, sphys, (const float*)next_obs, n, rb->obs_dim, action, reward, terminal, s);
+        return push_record(rb->state, sphys, (sphys + sframes - 1) % sframes, (const float*)next_obs, n, rb->obs_dim, action,
+                           reward, terminal, s);
     }
     if ((((uintptr_t)sdst | (uintptr_t)next_obs | (uintptr_t)fbytes) & 15) == 0 && fbytes <= (64ll << 20)) {
         if (rb->len_sa < sframes) rb->len_sa += 1;
@@ -636,25 +616,9 @@ static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_
     } else {
         int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
         const bool lane = rb->layout == RLHIP_RING_RECORDS;
-        static const int variant = getenv("RLHIP_GATHER_VARIANT") ? atoi(getenv("RLHIP_GATHER_VARIANT")) : 0;  // A / B hook
-#define RLHIP_GATHER_LANE(OD)                                                                                              \
-    do {                                                                                                                   \
-        if (variant == 1)                                                                                                  \
-            hipLaunchKernelGGL((gather_rec_kernel<OD, true, 1>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v,     \
-                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
-        else if (variant == 2)                                                                                             \
-            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 2>), dim3((int)((batch + 511) / 512)), dim3(256), 0, st, v,    \
-                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
-        else if (variant == 4)                                                                                             \
-            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 3>), dim3((int)((batch + 767) / 768)), dim3(256), 0, st, v,    \
-                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
-        else if (variant == 3)                                                                                             \
-            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 4>), dim3((int)((batch + 1023) / 1024)), dim3(256), 0, st, v,  \
-                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
-        else                                                                                                               \
-            hipLaunchKernelGGL((gather_rec_kernel<OD, false, 1>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v,    \
-                               idx, batch, (float*)s, a, r, term, (float*)s_next, pd);                                     \
-    } while (0)
+#define RLHIP_GATHER_LANE(OD)                                                                                      \
+    hipLaunchKernelGGL((gather_rec_kernel<OD>), dim3((int)((batch + 255) / 256)), dim3(256), 0, st, v, idx, batch, \
+                       (float*)s, a, r, term, (float*)s_next, pd)
         if (lane && rb->obs_dim == 4) RLHIP_GATHER_LANE(4);
         else if (lane && rb->obs_dim == 3) RLHIP_GATHER_LANE(3);
         else if (lane && rb->obs_dim == 2) RLHIP_GATHER_LANE(2);

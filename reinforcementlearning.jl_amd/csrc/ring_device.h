@@ -1,29 +1,35 @@
 // ring_device.h -- the RECORD layout of a replay ring with small Float32 observations (round 5).
 //
 // A ring whose observations are Float32 with <= 4 components (the classic-control envs: everything the fused DQN learners take)
-// stores ONE 32-byte record per (state slot, env):
+// stores ONE 64-byte record -- one cache line, one fabric request -- per (state slot, env):
 //
-//     record[slot * n_env + e] = { float s[4];  int32 action;  float reward;  uint32 terminal;  uint32 spare }
+//     record[slot * n_env + e] = { float s[4];  int32 action;  float reward;  uint32 terminal;  uint32 spare;
+//                                  float s_next[4];  uint32 pad[4] }
 //
-// where (action, reward, terminal) belong to the transition that ARRIVED at this state -- i.e. the record is exactly the named
-// tuple the agent pushes at PostActStage, `push!(trajectory, (state = s', action = a, reward = r, terminal = t))`
-// (RLCore/src/policies/agent/agent_base.jl:56-59), so a push is one full-record write and a sampled transition
-// (s, a, r, t, s') is TWO 32-byte sectors: the state half of record(slot of s) and the whole record(slot of s').
-// The layouts before it cost 11 (round 3: component-major frames) and 5 (round 4: transition-major states + three traces)
-// 64-byte lines per 82-byte CartPole sample (profiles/r04_pmc.md: 3.55 x the algorithmic bytes).
+// i.e. the whole transition (s, a, r, t, s') that LEAVES the state of this slot.  A sampled transition is three 16-byte loads
+// out of one line; the push of `(state = s', action, reward, terminal)` (RLCore/src/policies/agent/agent_base.jl:56-59)
+// completes the record of the previous slot (32 bytes: a, r, t, s') and opens the next one (its s = s').
 //
-// Slot arithmetic is the state trace's (capacity + 1 slots, head_sa): logical transition li has
-//     s  in slot ps = (head_sa + li)     mod (capacity + 1)
-//     s', a, r, t in slot pn = (head_sa + li + 1) mod (capacity + 1)
-// The action / reward / terminal traces of RLTrajectories' `CircularArraySARTSTraces` (capacity frames, head_rt) still exist
-// LOGICALLY -- rlhip_ring.head_rt / len_rt keep counting them, the sum-tree keys stay `physical rt slot * n_env + e` -- only their
-// storage moved into the records.  s[k >= obs_dim] and `spare` are zero.
+// Why a whole line.  Measured on the 2^20-sample gather (profiles/r05_pmc.md): this kernel is bound by the number of 64-byte
+// requests the L2 sends to the fabric (TCC_EA0_RDREQ: ~45 G requests / s, the same request rate a streaming kernel reaches with
+// 128-byte requests), not by bytes and not by load instructions:
+//     round 3  component-major frames + three traces          11 lines / sample   164 - 168 us
+//     round 4  transition-major states + three traces          5 lines            79 us
+//     round 5a 32-byte records {s', a, r, t}, s in the slot before   2 lines (1.86 requests measured)   43.5 us
+//     round 5b this layout                                      1 line             26.5 us
+// The price: the state is stored twice (as s of its slot and as s' of the slot before) -- 64 instead of 41 bytes per transition.
+//
+// Slot arithmetic is the state trace's (capacity + 1 slots, head_sa): logical transition li lives in slot
+// (head_sa + li) mod (capacity + 1); the newest slot holds only a state (its transition is not complete yet).  The action /
+// reward / terminal traces of RLTrajectories' `CircularArraySARTSTraces` (capacity frames, head_rt) still exist LOGICALLY --
+// rlhip_ring.head_rt / len_rt keep counting them, the sum-tree keys stay `physical rt slot * n_env + e` -- only their storage
+// moved into the records.  s[k >= obs_dim], s_next[k >= obs_dim], `spare` and `pad` are zero.
 #pragma once
 #include "common.h"
 
 namespace rlhip {
 
-constexpr int RING_REC_BYTES = 32;
+constexpr int RING_REC_BYTES = 64;
 
 __host__ __device__ inline bool ring_records(int64_t obs_dim, int32_t elem_bytes) { return elem_bytes == 4 && obs_dim <= 4; }
 
@@ -39,10 +45,10 @@ struct RingTransition {
     uint32_t t;  // 0 / 1
 };
 
-// byte offsets of record(s) and record(s') of flat logical index fj = li * n_env + e.  No 64-bit division where 32 bits do (a
-// 64-bit div / mod pair is ~300 VALU instructions on this chip, a 32-bit one ~40), and no modulo at all for the ring wrap:
-// head_sa <= capacity and li < capacity, so head_sa + li wraps at most once.
-__device__ __forceinline__ void ring_record_offsets(const RingRecs& rb, int64_t fj, int64_t& off_s, int64_t& off_n) {
+// byte offset of the record of flat logical index fj = li * n_env + e.  No 64-bit division where 32 bits do (a 64-bit div / mod
+// pair is ~300 VALU instructions on this chip, a 32-bit one ~40), and no modulo at all for the ring wrap: head_sa <= capacity
+// and li < capacity, so head_sa + li wraps at most once.
+__device__ __forceinline__ int64_t ring_record_offset(const RingRecs& rb, int64_t fj) {
     int64_t li, e;
     if (((uint64_t)fj | (uint64_t)rb.n_env) >> 32) {
         li = fj / rb.n_env;
@@ -54,33 +60,21 @@ __device__ __forceinline__ void ring_record_offsets(const RingRecs& rb, int64_t 
     }
     int64_t ps = rb.head_sa + li;
     if (ps > rb.capacity) ps -= rb.capacity + 1;
-    const int64_t pn = (ps == rb.capacity) ? 0 : ps + 1;
-    off_s = (ps * rb.n_env + e) * RING_REC_BYTES;
-    off_n = (pn * rb.n_env + e) * RING_REC_BYTES;
+    return (ps * rb.n_env + e) * RING_REC_BYTES;
 }
 
-union RingChunk {  // one 16-byte half of a record
+union RingChunk {  // one 16-byte quarter of a record
     nt_u32x4 u;
     float f[4];
 };
 
-// the three 16-byte loads of one sampled transition, all issued before the first use
-template <bool NT = false>
+// the three 16-byte loads of one sampled transition (one cache line), all issued before the first use
 __device__ __forceinline__ RingTransition ring_load_transition(const RingRecs& rb, int64_t fj) {
-    int64_t o0, o1;
-    ring_record_offsets(rb, fj, o0, o1);
-    const uint8_t* r0 = rb.rec + o0;
-    const uint8_t* r1 = rb.rec + o1;
-    RingChunk s, sn, w;
-    if (NT) {
-        s.u = nt_load16(r0);
-        sn.u = nt_load16(r1);
-        w.u = nt_load16(r1 + 16);
-    } else {
-        s.u = *reinterpret_cast<const nt_u32x4*>(r0);
-        sn.u = *reinterpret_cast<const nt_u32x4*>(r1);
-        w.u = *reinterpret_cast<const nt_u32x4*>(r1 + 16);
-    }
+    const uint8_t* r0 = rb.rec + ring_record_offset(rb, fj);
+    RingChunk s, w, sn;
+    s.u = *reinterpret_cast<const nt_u32x4*>(r0);
+    w.u = *reinterpret_cast<const nt_u32x4*>(r0 + 16);
+    sn.u = *reinterpret_cast<const nt_u32x4*>(r0 + 32);
     RingTransition t;
 #pragma unroll
     for (int k = 0; k < 4; ++k) t.s[k] = s.f[k], t.sn[k] = sn.f[k];
@@ -90,19 +84,30 @@ __device__ __forceinline__ RingTransition ring_load_transition(const RingRecs& r
     return t;
 }
 
-// one whole record (the pushed tuple); x[k >= OD] must be 0
-__device__ __forceinline__ void ring_store_record(void* rec, int64_t slot, int64_t n_env, int64_t e, const float x[4], int32_t a,
-                                                  float r, uint32_t t) {
-    uint8_t* p = (uint8_t*)rec + (slot * n_env + e) * RING_REC_BYTES;
-    *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
-    *reinterpret_cast<int4*>(p + 16) = make_int4(a, __float_as_int(r), (int)(t ? 1u : 0u), 0);
+// push!(trajectory, (state = s', action, reward, terminal)) for one env: completes the record of the previous slot (a, r, t, s':
+// 32 bytes) and opens the record of the new slot (s = s', the rest zero: 64 bytes).  x[k >= OD] must be 0.
+__device__ __forceinline__ void ring_push_transition(void* rec, int64_t slot_new, int64_t slot_prev, int64_t n_env, int64_t e,
+                                                     const float x[4], int32_t a, float r, uint32_t t) {
+    const nt_u32x4 xs = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    const nt_u32x4 z = {0u, 0u, 0u, 0u};
+    uint8_t* pp = (uint8_t*)rec + (slot_prev * n_env + e) * RING_REC_BYTES;
+    *reinterpret_cast<nt_u32x4*>(pp + 16) = nt_u32x4{(uint32_t)a, __float_as_uint(r), t ? 1u : 0u, 0u};
+    *reinterpret_cast<nt_u32x4*>(pp + 32) = xs;
+    uint8_t* pn = (uint8_t*)rec + (slot_new * n_env + e) * RING_REC_BYTES;
+    *reinterpret_cast<nt_u32x4*>(pn) = xs;
+    *reinterpret_cast<nt_u32x4*>(pn + 16) = z;
+    *reinterpret_cast<nt_u32x4*>(pn + 32) = z;
+    *reinterpret_cast<nt_u32x4*>(pn + 48) = z;
 }
 
-// the state half only: push!(trajectory, (state = s,)) at PreEpisodeStage -- no transition arrives at this state
-__device__ __forceinline__ void ring_store_state_only(void* rec, int64_t slot, int64_t n_env, int64_t e, const float x[4]) {
+// push!(trajectory, (state = s,)) at PreEpisodeStage: opens a record, no transition is completed
+__device__ __forceinline__ void ring_push_state(void* rec, int64_t slot, int64_t n_env, int64_t e, const float x[4]) {
+    const nt_u32x4 z = {0u, 0u, 0u, 0u};
     uint8_t* p = (uint8_t*)rec + (slot * n_env + e) * RING_REC_BYTES;
-    *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
-    *reinterpret_cast<int4*>(p + 16) = make_int4(0, 0, 0, 0);
+    *reinterpret_cast<nt_u32x4*>(p) = nt_u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    *reinterpret_cast<nt_u32x4*>(p + 16) = z;
+    *reinterpret_cast<nt_u32x4*>(p + 32) = z;
+    *reinterpret_cast<nt_u32x4*>(p + 48) = z;
 }
 
 }  // namespace rlhip

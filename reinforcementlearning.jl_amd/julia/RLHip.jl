@@ -353,14 +353,14 @@ function on_sample!(c::InsertSampleRatioController)
 end
 
 const RING_FRAMES = Int32(0)     # include/rlhip.h RLHIP_RING_FRAMES: every trace as pushed
-const RING_RECORDS = Int32(2)    # RLHIP_RING_RECORDS: Float32 observations with <= 4 components, one 32-byte record
-                                 # {s[4], action::Int32, reward::Float32, terminal::UInt32, spare} per (state slot, env)
+const RING_RECORDS = Int32(2)    # RLHIP_RING_RECORDS: Float32 observations with <= 4 components, one 64-byte record {s[4],
+                                 # action::Int32, reward::Float32, terminal::UInt32, spare, s_next[4], pad[4]} per (state slot, env)
 mutable struct HipTrajectory{E}
     rb::Ring
-    # RING_FRAMES: the four traces; RING_RECORDS: `state` is the record buffer (8 Float32 words per record, (capacity + 1) *
-    # n_env records: unsafe_wrap it as an (8, n_env, capacity + 1) array -- rows 1:obs_dim are the reference's state trace,
-    # rows 5 / 6 / 7 reinterpret as the action / reward / terminal of the transition that arrived at that state) and the
-    # other three are empty
+    # RING_FRAMES: the four traces; RING_RECORDS: `state` is the record buffer (16 Float32 words per record, (capacity + 1) *
+    # n_env records: unsafe_wrap it as a (16, n_env, capacity + 1) array -- rows 1:obs_dim are the reference's state trace,
+    # rows 5 / 6 / 7 reinterpret as the action / reward / terminal of the transition that LEAVES that state, rows
+    # 9:8+obs_dim its next state) and the other three are empty
     state::DevBuf{E}; action::DevBuf{Int32}; reward::DevBuf{Float32}; terminal::DevBuf{UInt8}
     batchsize::Int
     sampler_seed::UInt64

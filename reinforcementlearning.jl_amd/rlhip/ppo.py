@@ -115,6 +115,13 @@ class PPOPolicy:
         self._logp = torch.zeros(env.n, dtype=torch.float32, device=dev)
         self._value = torch.zeros(env.n, dtype=torch.float32, device=dev)
 
+    def __del__(self):
+        # drop the workspace's entry from the library's size table before the allocator recycles the block
+        try:
+            _lib.lib.rlhip_ppo_workspace_release(ptr(self.workspace))
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     # ----------------------------------------------------------------- per-step protocol (drop-in)
     def plan_(self, env=None):
         """plan!(policy, env): returns the action tensor (1-based ints for discrete envs)."""

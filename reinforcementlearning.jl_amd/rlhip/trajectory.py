@@ -25,15 +25,15 @@ class CircularArraySARTSTraces:
         dev = torch.device(device)
         self.capacity, self.n_env, self.obs_dim, self.dtype = capacity, n_env, obs_dim, dtype
         # Float32 observations with <= 4 components live in a RECORD ring (csrc/ring_device.h, include/rlhip.h RLHIP_RING_RECORDS):
-        # one 32-byte record {s[4], action, reward, terminal, spare} per (state slot, env) -- the tuple a PostActStage push
-        # writes -- so that a sampled transition is two 32-byte sectors.  `records` is the storage (and what a checkpoint
-        # holds); `state` / `action` / `reward` / `terminal` are strided VIEWS of it, indexed by the record's slot (capacity + 1
-        # slots; action / reward / terminal of a record belong to the transition that ARRIVED at its state).  Other rings
-        # (UInt8 frames, wider observations) keep one tensor per trace, every frame as pushed.
+        # one 64-byte record {s[4], action, reward, terminal, spare, s_next[4], pad[4]} per (state slot, env) -- the whole
+        # transition that LEAVES that state -- so that a sampled transition is ONE cache line.  `records` is the storage (and
+        # what a checkpoint holds); `state` / `action` / `reward` / `terminal` / `next_state` are strided VIEWS of it, indexed
+        # by the record's slot (capacity + 1 slots; the newest slot holds a state only).  Other rings (UInt8 frames, wider
+        # observations) keep one tensor per trace, every frame as pushed.
         self.records_layout = dtype == torch.float32 and obs_dim <= 4
         self.rb = _lib.Ring()
         if self.records_layout:
-            self.records = torch.zeros((capacity + 1, n_env, 8), dtype=torch.float32, device=dev)
+            self.records = torch.zeros((capacity + 1, n_env, 16), dtype=torch.float32, device=dev)
             assert self.records.numel() * 4 == int(_lib.lib.rlhip_ring_state_bytes(capacity, n_env, obs_dim, 4))
             call("rlhip_ring_init", C.byref(self.rb), capacity, n_env, obs_dim, 4, ptr(self.records), None, None, None)
         else:
@@ -48,15 +48,17 @@ class CircularArraySARTSTraces:
 
     def __getattr__(self, name):
         # record rings only (frame rings own real tensors of these names): strided views of `records`
-        if name in ("state", "action", "reward", "terminal") and self.__dict__.get("records_layout"):
+        if name in ("state", "action", "reward", "terminal", "next_state") and self.__dict__.get("records_layout"):
             rec = self.__dict__["records"]
             if name == "state":
                 return rec[:, :, :self.obs_dim]          # (capacity + 1, n_env, obs_dim)
+            if name == "next_state":
+                return rec[:, :, 8:8 + self.obs_dim]     # s' of the transition that leaves the slot's state
             if name == "action":
-                return rec.view(torch.int32)[:, :, 4]    # (capacity + 1, n_env), by the slot of the transition's s'
+                return rec.view(torch.int32)[:, :, 4]    # (capacity + 1, n_env), by the slot of the transition's s
             if name == "reward":
                 return rec[:, :, 5]
-            return rec.view(torch.uint8)[:, :, 24]       # low byte of the terminal word
+            return rec.view(torch.uint8)[:, :, 24]       # low byte of the terminal word (byte 24 of the 64-byte record)
         raise AttributeError(name)
 
     def push_state_(self, obs):

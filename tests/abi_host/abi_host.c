@@ -138,7 +138,7 @@ static void run_dqn(void) {
     void* workspace = dmalloc((size_t)rlhip_dqn_workspace_bytes(ns, h, na, batch)); /* zeroed: ABI contract */
 
     rlhip_ring ring;
-    /* Float32 observations with <= 4 components: a RECORD ring (RLHIP_RING_RECORDS, ABI 2) -- one allocation of
+    /* Float32 observations with <= 4 components: a RECORD ring (RLHIP_RING_RECORDS, ABI 2: 64-byte transition records) -- one allocation of
      * rlhip_ring_state_bytes(), no separate action / reward / terminal traces */
     const size_t r_bytes = (size_t)rlhip_ring_state_bytes(capacity, n, ns, 4);
     void* r_state = dmalloc(r_bytes);

@@ -86,7 +86,7 @@ def test_c_host_dqn_run_is_bit_identical_to_the_torch_hosted_mirror(dump):
     for name, t in (("dqn.params", net.params), ("dqn.target", tn.target), ("dqn.m", net.m), ("dqn.v", net.v),
                     ("dqn.loss", learner.loss), ("dqn.ring.rec", traces.records), ("dqn.env.obs", env.state())):
         assert np.array_equal(dump[name], t.cpu().numpy().reshape(-1).view(np.uint32)), name
-    rec = dump["dqn.ring.rec"].reshape(17, n, 8)  # the record ring word for word; its views: action / terminal words
+    rec = dump["dqn.ring.rec"].reshape(17, n, 16)  # the record ring word for word; its views: action / terminal words
     assert np.array_equal(rec[:, :, 4].view(np.int32), traces.action.cpu().numpy())
     assert np.array_equal((rec[:, :, 6] & 0xFF).astype(np.uint8), traces.terminal.cpu().numpy())
     for k in range(4):

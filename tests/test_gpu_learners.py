@@ -404,7 +404,7 @@ def test_dqn_grad_on_explicit_indices_and_prioritized_learner():
 
     n, ns, h, na, batch = 128, 4, 64, 2, 300
     tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
-    tr.state.normal_()
+    tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
     tr.action.random_(0, na)
     tr.reward.normal_()
     tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.1).to(torch.uint8))
@@ -464,7 +464,7 @@ def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip):
 
     n, batch = 64, 700
     tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
-    tr.state.normal_()
+    tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
     tr.action.random_(0, na)
     tr.reward.normal_()
     tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.1).to(torch.uint8))

@@ -219,7 +219,7 @@ def test_fused_sample_gather_equals_the_two_launches(layout):
     if dt == torch.uint8:
         tr.state.random_(0, 256, generator=g)
     else:
-        tr.state.normal_(generator=g)
+        (tr.records if tr.records_layout else tr.state).normal_(generator=g)
     tr.action.random_(0, 3, generator=g)
     tr.reward.normal_(generator=g)
     tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda", generator=g) < 0.1).to(torch.uint8))

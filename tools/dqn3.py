@@ -10,7 +10,7 @@ from bench import event_time_ms
 ns, na, H = 4, 2, 128
 n_env, cap = 4096, 64
 tr = rlhip.CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=ns)
-tr.state.normal_()
+tr.records.normal_()
 tr.action.random_(0, 2)
 tr.reward.normal_()
 tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap

@@ -15,7 +15,7 @@ h = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 bm = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 n = 4096
 tr = rlhip.CircularArraySARTSTraces(capacity=256, n_env=n, obs_dim=4)
-tr.state.normal_()
+tr.records.normal_()
 tr.action.random_(0, 2)
 tr.reward.normal_()
 tr.terminal.copy_((torch.rand(tr.terminal.shape, device="cuda") < 0.05).to(torch.uint8))

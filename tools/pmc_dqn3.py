@@ -6,7 +6,7 @@ import torch, rlhip
 from rlhip import dqn
 ns, na, H = 4, 2, 128
 tr = rlhip.CircularArraySARTSTraces(capacity=64, n_env=4096, obs_dim=ns)
-tr.state.normal_(); tr.action.random_(0, 2); tr.reward.normal_()
+tr.records.normal_(); tr.action.random_(0, 2); tr.reward.normal_()
 tr.rb.len_sa, tr.rb.len_rt = 65, 64
 p, tp = dqn.mlp3_init(ns, H, na, 1), dqn.mlp3_init(ns, H, na, 2)
 pk, tpk = dqn.mlp3_pack(p, ns, H, na), dqn.mlp3_pack(tp, ns, H, na)
