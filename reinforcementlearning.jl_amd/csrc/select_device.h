@@ -98,8 +98,8 @@ __device__ __forceinline__ int32_t eps_greedy_select1(const V& q, const M& mk, i
 // log(x) in Float64 for the log-sum-exp of the sampling path, whose result is rounded to Float32 once: the classic argument
 // reduction x = 2^k (1 + f), sqrt(1/2) < 1 + f <= sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the
 // degree-7 minimax R of Sun's fdlibm e_log.c (coefficients Lg1..Lg7 and the ln2 split below are that file's; "freely
-// distributable"), error < 1 ulp.  tools/micro/log_sampling.hip runs it on the GPU for EVERY Float32 in [1, 4] (the sum of <= 4
-// exponentials whose largest is 1): the Float32 rounding equals the host libm's -- the oracle's -- in all 2^24 + 1 cases, so the
+// distributable"), error < 1 ulp.  tools/micro/log_sampling.hip runs it on the GPU for EVERY Float32 in [1, 64] (the sum of <= 64
+// exponentials whose largest is 1): the Float32 rounding equals the host libm's -- the oracle's -- in all 6 x 2^23 + 1 cases, so the
 // log-probabilities are bit for bit what ocml's log gave.  ocml's log(double) is double-double arithmetic: ~85 Float64
 // instructions against ~45 here, Float64 VALU ops run at half rate, and the log-sum-exp sits on the rollout's dependent chain
 // (profiles/r04_rollout.md).  The Gumbel noise (compared as Float64, off the chain) keeps ocml's log.
@@ -135,7 +135,12 @@ __device__ __forceinline__ void gumbel_noise(int na, uint64_t seed, uint32_t id,
 
 // logsoftmax (NNlib: x - max - log(sum(exp(x - max)))), Float32; Gumbel-max over log-probability + noise in Float64.
 // GN: functor k -> the Gumbel noise of action k
-template <class V, class M, class GN>
+// SHORT_LOG: the log of the log-sum-exp by log_f64_sampling -- bit-equal to the host libm's (the oracle's) after the Float32
+// rounding for EVERY Float32 argument in [1, LOG_SAMPLING_MAX_NA] (tools/micro/log_sampling.hip enumerates them on the GPU), i.e.
+// for up to LOG_SAMPLING_MAX_NA actions; callers with more actions take ocml's log (the claim was enumerated for
+// <= 4 actions only while select.hip's entry points accept any `na`).
+constexpr int LOG_SAMPLING_MAX_NA = 64;
+template <bool SHORT_LOG = true, class V, class M, class GN>
 __device__ __forceinline__ int32_t categorical_select1(const V& l, const M& mk, int na, const GN& gn, float* logp_out) {
     float mx = -INFINITY;
     for (int k = 0; k < na; ++k) {
@@ -155,7 +160,7 @@ __device__ __forceinline__ int32_t categorical_select1(const V& l, const M& mk, 
             se += (float)::exp((double)(x - mx));  // Float64 eval, rounded once (libm-independent)
         }
     }
-    float lse = (float)log_f64_sampling((double)se);
+    float lse = SHORT_LOG ? (float)log_f64_sampling((double)se) : (float)::log((double)se);
     int best = 0;
     double bg = 0.0;
     float blp = 0.f;
@@ -187,7 +192,8 @@ struct GumbelInline {  // the noise evaluated on the spot, one Philox block per 
 template <class V, class M>
 __device__ __forceinline__ int32_t categorical_sample1(const V& l, const M& mk, int na, uint64_t seed,
                                                        uint32_t id, uint32_t step, float* logp_out) {
-    return categorical_select1(l, mk, na, GumbelInline{seed, id, step, u32x4{0, 0, 0, 0}}, logp_out);
+    if (na <= LOG_SAMPLING_MAX_NA) return categorical_select1<true>(l, mk, na, GumbelInline{seed, id, step, u32x4{0, 0, 0, 0}}, logp_out);
+    return categorical_select1<false>(l, mk, na, GumbelInline{seed, id, step, u32x4{0, 0, 0, 0}}, logp_out);
 }
 
 }  // namespace rlhip

@@ -6,7 +6,7 @@ cross-compiled by __graft_entry__.build()):
   mfma_f32_4x4   the same for v_mfma_f32_4x4x1_16b_f32 (operand images + exactness; measured no faster than the VALU, not used)
   tanh_sel       the PPO tile's branch-free tanh == ocml tanhf for all 2^32 float bit patterns
   log_sampling   log_f64_sampling (the Float64 log of the sampling path's log-sum-exp, csrc/select_device.h) == the host libm's log
-                 after rounding to Float32 for EVERY Float32 in [1, 4]; within 1 ulp of a long-double reference on 2^24 doubles
+                 after rounding to Float32 for EVERY Float32 in [1, 64]; within 1 ulp of a long-double reference on 2^24 doubles
   trig_f32arg    sincos_f32arg / jl_mod_2pi_f32arg (csrc/env_device.h: Float64 sin / cos / mod 2 pi of a Float32 argument, ~45 instructions
                  instead of ocml's general routines) == the host libm after rounding, for EVERY Float32 with |x| <= 2^16 (2.4e9 values)
   wave_simd_map  wave w and wave w + 4 of a 512-thread workgroup share a SIMD (a PERFORMANCE premise of the two-wave PPO rollout,

@@ -1,6 +1,7 @@
 // log_sampling.hip -- log_f64_sampling (csrc/select_device.h: the Float64 log of the log-sum-exp, fdlibm-style reduction, < 1 ulp)
 // against the host libm on the GPU:
-//   (a) EVERY Float32 in [1, 4] (the log-sum-exp's argument for <= 4 actions): (float) log_f64_sampling((double) x) must equal
+//   (a) EVERY Float32 in [1, 64] (the log-sum-exp's argument for <= LOG_SAMPLING_MAX_NA = 64 actions, the range in which
+//       categorical_select1 uses it; 6 x 2^23 + 1 arguments): (float) log_f64_sampling((double) x) must equal
 //       (float) log((double) x) bit for bit -- the oracle's rounding, so the rollout's log-probabilities stay bit-identical to it;
 //   (b) its accuracy class on 2^24 doubles in (0, 40): error against a long-double reference <= 1 ulp (informative: no caller
 //       uses it outside (a)'s range).
@@ -22,7 +23,8 @@ __global__ void eval_f64(double* out, const double* in, uint32_t n) {
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
 int main() {
-    const uint32_t b0 = 0x3f800000u, n = 0x40800000u - 0x3f800000u + 1u;
+    const uint32_t b0 = 0x3f800000u, n = 0x42800000u - 0x3f800000u + 1u;  // 1.0f .. 64.0f
+    static_assert(rlhip::LOG_SAMPLING_MAX_NA == 64, "enumerate the range categorical_select1 uses");
     float *d, *h = (float*)malloc(sizeof(float) * n);
     HC(hipMalloc(&d, sizeof(float) * n));
     hipLaunchKernelGGL(eval_f32, dim3((n + 255) / 256), dim3(256), 0, 0, d, b0, n);
@@ -35,7 +37,7 @@ int main() {
         const float ref = (float)log((double)x);
         if (memcmp(&ref, &h[i], 4) != 0 && bad++ < 5) printf("x = %.9g: device %.9g, libm %.9g\n", x, h[i], ref);
     }
-    printf("(a) %u floats in [1, 4]: %ld Float32 roundings differ from libm\n", n, bad);
+    printf("(a) %u floats in [1, 64]: %ld Float32 roundings differ from libm\n", n, bad);
     const uint32_t m = 1u << 24;
     double *hin = (double*)malloc(sizeof(double) * m), *hout = (double*)malloc(sizeof(double) * m), *din, *dout;
     uint64_t st = 88172645463325252ull;
