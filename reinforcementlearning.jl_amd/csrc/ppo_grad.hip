@@ -46,13 +46,13 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     const TeamLds L = team_lds(smem, id.team);
     const int nout = g.pd.nout_a;
     const float* __restrict__ rec = (const float*)__builtin_assume_aligned(g.packed, 64);
-    const float* __restrict__ tailb = rec + REC * h;
 
     // ---- prologue: the first tile's scattered gather is issued first; the unit records go to LDS ----
     // (the record image is requested first -- its address costs nothing; the gather's addresses are ~150 instructions away)
     float* l_rec = reinterpret_cast<float*>(smem + (size_t)NT * grad_team_smem_bytes());
     float4 recv[(NW * 32 * 4) / (512 * NT)];
-    stage_records_load<NT>(recv, rec, h);
+    if (rec) stage_records_load<NT>(recv, rec, h);
+    else stage_records_from_params<NT>(recv, g.params, h, NS, nout, g.pd.np_a);
     const PermKeys pk = g.ctr ? perm_keys(g.seed, g.epoch_local + g.ctr[1] * g.n_epochs, g.total) : g.pk;
     // the first tiles of the workgroup's teams are gathered by its FIRST waves (wave t for team t): waves start ~0.1 us apart,
     // team 1's own wave 0 is the workgroup's ninth
@@ -65,7 +65,17 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     G.zero();
     HeadG Hd;
     Hd.zero();
-    const float b2[4] = {tailb[0], tailb[1], tailb[2], tailb[3]};
+    float b2[4];  // {b2a0, b2a1, b2a2, b2c}: behind the records of the packed image, or from the parameter vector
+    if (rec) {
+        const float* tailb = rec + REC * h;
+        b2[0] = tailb[0], b2[1] = tailb[1], b2[2] = tailb[2], b2[3] = tailb[3];
+    } else {
+        const float* b2a = g.params + h * NS + h + nout * h;
+        b2[0] = b2a[0];
+        b2[1] = (1 < nout) ? b2a[1] : 0.f;
+        b2[2] = (2 < nout) ? b2a[2] : 0.f;
+        b2[3] = g.params[g.pd.np_a + h * NS + h + h];
+    }
 
     long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g.dbg) ts[0] = __builtin_amdgcn_s_memtime();
@@ -92,6 +102,23 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) d[k] = ts[k];
         d[7] = t_entry;
+    }
+    if (g.samples_out && (NT == 1 || id.team != 0)) {
+        // first launch of an update call: this workgroup's slice of the sample records, {x0..x3}, {logp, adv, ret, action bits} per
+        // trajectory entry f, written by the threads that have nothing left to do (the team that does not write the partial row)
+        const uint32_t nthr = NT == 1 ? 512u : 512u * (NT - 1), me = NT == 1 ? (uint32_t)id.tid : (uint32_t)threadIdx.x - 512u;
+        const uint32_t per = (g.total + gridDim.x - 1) / gridDim.x, f0 = blockIdx.x * per;
+        const uint32_t f1 = f0 + per < g.total ? f0 + per : g.total;
+        const uint32_t n = (uint32_t)g.n;
+        for (uint32_t f = f0 + me; f < f1; f += nthr) {
+            const uint32_t t = f / n, i = f - t * n;
+            float xv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NS; ++k) xv[k] = g.obs[((int64_t)t * NS + k) * g.n + i];
+            const float a = g.pd.cont ? g.action_f[f] : __int_as_float(g.action_i[f]);
+            g.samples_out[2 * (int64_t)f] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            g.samples_out[2 * (int64_t)f + 1] = make_float4(g.logp[f], g.adv[f], g.ret[f], a);
+        }
     }
     if (id.team != 0) return;
 
@@ -634,6 +661,7 @@ static int32_t prepare_grad(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
     long long* dbgp = (long long*)(out->counter + 16);  // MAX_GRAD_BLOCKS x 8 words
     g.dbg = RLHIP_ENV_FLAG("RLHIP_GRAD_DEBUG") ? dbgp : nullptr;
     g.samples = nullptr;
+    g.samples_out = nullptr;
     uintptr_t pq = (uintptr_t)(dbgp + (int64_t)MAX_GRAD_BLOCKS * 8);
     pq = (pq + 63) & ~(uintptr_t)63;
     out->packed = (float*)pq;
@@ -886,7 +914,16 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
                 if (rc) return rc;
                 hipStream_t s = as_stream(stream);
                 L.g.samples = samples;
-                if (first) pack_for_update(L, samples, s);
+                if (first) {  // no pack launch: see update_entry
+                    static const bool pack_launch = RLHIP_ENV_FLAG("RLHIP_PPO_PACK_LAUNCH");
+                    if (pack_launch) {
+                        pack_for_update(L, samples, s);
+                    } else {
+                        L.g.packed = nullptr;
+                        L.g.samples = nullptr;
+                        L.g.samples_out = samples;
+                    }
+                }
                 first = false;
                 if ((rc = launch_grad(L, s))) return rc;
                 ApplyArgs ap{params, m, v, beta_pow, cfg->max_grad_norm, cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps,
@@ -998,10 +1035,23 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
             int32_t rc = prepare_grad(kind, cfg, n, T, traj, params, seed, epoch_ctr, mb, workspace, &L, ctr);
             if (rc) return rc;
             if (samples) L.g.samples = samples;
-            if (first) {  // pack the unit records (and the sample records) once per call; the Adam tail refreshes the unit
-                          // records after every step.  The arrival counter needs no per-call memset: the workspace is
-                          // zero-initialised by its owner (ABI contract) and the last-arriving workgroup re-arms it in-kernel.
-                pack_for_update(L, samples, s);
+            if (first) {
+                // Round 5: NO pack launch.  The first gradient launch of a call builds its unit records from the parameter
+                // vector (the packed image may be stale: the host may have written `params`), gathers its samples from the
+                // trajectory planes and -- with the threads of the team that does not write the partial row -- writes the 32-byte
+                // sample records the other 15 steps read; the Adam tail of every step patches the unit-record image for the
+                // step after it.  Same values on both routes, hence the same bits (tests/test_gpu_learners.py compares update_
+                // with the grad_ / apply_ sequence).  RLHIP_PPO_PACK_LAUNCH=1: the round-4 form (pack launch first), for A / B.
+                // The arrival counter needs no per-call memset: the workspace is zero-initialised by its owner (ABI contract)
+                // and the last-arriving workgroup re-arms it in-kernel.
+                static const bool pack_launch = RLHIP_ENV_FLAG("RLHIP_PPO_PACK_LAUNCH");
+                if (pack_launch) {
+                    pack_for_update(L, samples, s);
+                } else {
+                    L.g.packed = nullptr;
+                    L.g.samples = nullptr;
+                    L.g.samples_out = samples;
+                }
                 first = false;
             }
             if ((rc = launch_grad(L, s))) return rc;

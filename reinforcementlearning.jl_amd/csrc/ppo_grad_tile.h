@@ -66,6 +66,8 @@ struct GradArgs {
     const float4* samples; // sample records {x0..x3}, {logp, adv, ret, action bits} per trajectory entry f = t n + i, or NULL:
                            // written once per update call (pack_update_kernel); a shuffled sample is then ONE 32-byte
                            // read instead of eight 4-byte reads from eight planes (eight cache lines)
+    float4* samples_out;   // first launch of an update call (round 5): the kernel gathers from the planes (samples == NULL) and,
+                           // off its critical path, writes the sample records the next 15 steps read -- no pack launch
     long long* dbg;        // RLHIP_GRAD_DEBUG: [workgroup][8] s_memtime stamps of thread 0 (tools/grad_timeline.py), else NULL
 };
 
@@ -238,6 +240,39 @@ __device__ __forceinline__ void stage_records_load(float4 (&v)[(NW * 32 * 4) / (
         const int m = slot & 31, j = (slot >> 5) * hq + m;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m < hq) v[i] = *reinterpret_cast<const float4*>(rec + REC * j + 4 * part);
+    }
+}
+// the same registers straight from the parameter vector (packed == NULL: the first launch of an update call, whose unit-record
+// image may be stale -- the host may have written `params` since the last optimiser step; every later step reads the image the
+// tail of the step before it patched).  Same values as pack_records writes, so the tile computes the same bits.
+template <int NT>
+__device__ __forceinline__ void stage_records_from_params(float4 (&v)[(NW * 32 * 4) / (512 * NT)], const float* __restrict__ params,
+                                                          int h, int ns, int nout, int64_t np_a) {
+    const int hq = h / NW;
+    const float* W1a = params;
+    const float* b1a = W1a + h * ns;
+    const float* W2a = b1a + h;
+    const float* W1c = params + np_a;
+    const float* b1c = W1c + h * ns;
+    const float* W2c = b1c + h;
+#pragma unroll
+    for (int i = 0; i < (NW * 32 * 4) / (512 * NT); ++i) {
+        const int idx = (int)threadIdx.x + 512 * NT * i, slot = idx >> 2, part = idx & 3;
+        const int m = slot & 31, j = (slot >> 5) * hq + m;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < hq) {
+            if (part < 2) {  // {w1a[k], w1c[k], w1a[k + 1], w1c[k + 1]}, k = 2 part
+                const int k = 2 * part;
+                if (k < ns) r.x = W1a[j + h * k], r.y = W1c[j + h * k];
+                if (k + 1 < ns) r.z = W1a[j + h * (k + 1)], r.w = W1c[j + h * (k + 1)];
+            } else if (part == 2) {
+                r = make_float4(b1a[j], b1c[j], W2a[0 + nout * j], W2c[j]);
+            } else {
+                if (nout > 1) r.x = W2a[1 + nout * j];
+                if (nout > 2) r.y = W2a[2 + nout * j];
+            }
+        }
+        v[i] = r;
     }
 }
 template <int NT>
