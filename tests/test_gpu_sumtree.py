@@ -201,7 +201,7 @@ def test_update_block_recompute_paths_bit_exact(n_leaves, n_upd, spread):
     assert tree[0].item() == 0.0  # the arrival counter is re-armed
 
 
-@pytest.mark.parametrize("layout", ["frames_u8", "cartpole_f32", "wide_f32"])
+@pytest.mark.parametrize("layout", ["frames_u8", "frames_u8_big_tree", "cartpole_f32", "wide_f32"])
 def test_fused_sample_gather_equals_the_two_launches(layout):
     """rlhip_ring_sample_gather_prioritized: indices, keys, priorities and the gathered batch are bit-identical to
     rlhip_ring_sample_prioritized + rlhip_ring_gather (frame-major u8 ring, Float32 ring with 4 components = the fused
@@ -210,6 +210,8 @@ def test_fused_sample_gather_equals_the_two_launches(layout):
 
     if layout == "frames_u8":
         cap, n_env, od, dt = 300, 1, 84 * 84, torch.uint8
+    elif layout == "frames_u8_big_tree":  # >= 2^12 leaves: batches <= 512 descend through the LDS copy of the tree's top levels
+        cap, n_env, od, dt = 5000, 1, 84 * 84, torch.uint8
     elif layout == "cartpole_f32":
         cap, n_env, od, dt = 64, 37, 4, torch.float32
     else:
@@ -318,3 +320,36 @@ def test_is_weights_bit_exact_and_weighted_gradients_match_oracle():
         for name, sz in (("W1", hh * ns), ("b1", hh), ("W2", hh * hh), ("b2", hh), ("W3", na * hh), ("b3", na)):
             assert_grad_close(g3.cpu().numpy()[o:o + sz], og3[o:o + sz], BF16_GRAD_TOL, f"weighted dqn3 h={hh} b={bb} {name}")
             o += sz
+
+
+@pytest.mark.parametrize("n_leaves", [2, 3, 96, 1 << 20, (1 << 20) - 5])
+@pytest.mark.parametrize("n_upd", [1, 2, 3, 31, 32, 33, 63, 64])
+def test_small_batch_update_kernel_bit_exact(n_leaves, n_upd):
+    """rlhip_sumtree_update with <= 64 keys takes sumtree_update_small_kernel (one wavefront: sort, election of the last
+    duplicate, the winners' paths walked up together with neighbouring paths merging) -- against the oracle's sequential
+    update, on key patterns that exercise the merging: sibling leaves, whole blocks, one leaf repeated, both ends of the tree,
+    out-of-range keys, ascending and descending order; on top of a filled tree so that untouched siblings carry mass"""
+    rng = np.random.default_rng(n_leaves * 7 + n_upd)
+    ref = oracle.SumTree(n_leaves)
+    tree = _dev_tree(n_leaves)
+    base_k = np.arange(n_leaves)[:: max(1, n_leaves // 5000)]
+    base_p = rng.random(base_k.size).astype(np.float32) + 0.05
+    ref.update(base_k, base_p)
+    _update(tree, n_leaves, base_k, base_p)  # (the general kernel: more than 64 keys, or the small one for tiny trees)
+    assert np.array_equal(tree.cpu().numpy(), ref.tree)
+    c = int(rng.integers(0, n_leaves))
+    patterns = {
+        "random": rng.integers(0, n_leaves, n_upd),
+        "with out-of-range": rng.integers(-3, n_leaves + 3, n_upd),
+        "one block": (c // 64 * 64 + rng.integers(0, 64, n_upd)) % n_leaves,
+        "consecutive ascending": (c + np.arange(n_upd)) % n_leaves,
+        "consecutive descending": (c - np.arange(n_upd)) % n_leaves,
+        "one leaf": np.full(n_upd, c),
+        "both ends": np.where(np.arange(n_upd) % 2 == 0, np.arange(n_upd) // 2, n_leaves - 1 - np.arange(n_upd) // 2) % n_leaves,
+        "sibling pairs": (2 * rng.integers(0, max(1, n_leaves // 2), n_upd) + (np.arange(n_upd) % 2)) % n_leaves,
+    }
+    for name, keys in patterns.items():
+        prio = (rng.random(n_upd).astype(np.float32) ** 0.6) * (rng.random(n_upd) < 0.9)  # some zero priorities
+        ref.update(keys, prio)
+        _update(tree, n_leaves, keys, prio)
+        assert np.array_equal(tree.cpu().numpy(), ref.tree), name

@@ -11,7 +11,7 @@ keys = torch.arange(cap, dtype=torch.int64, device="cuda")
 tr.set_priority_(keys, ops.fill_uniform(cap, 11, 0, 7) ** 0.6)
 s=ops.stream_ptr(); lib=rlhip._lib.lib
 res={}
-for b in (32,512,4096,65536):
+for b in (8,32,64,512,4096,65536):
     idx,key,prio=tr.sample_prioritized(b,11,0)
     f=lambda: rlhip._lib.call("rlhip_sumtree_update", ops.ptr(tr.priorities), cap, ops.ptr(key), ops.ptr(prio), b, s)
     f(); res[b]=round(event_time_ms(f,20,lib,s)*1e3,2)
