@@ -195,17 +195,15 @@ struct PrioDraw {
     int64_t* key_out;  // may be NULL
     float* prio_out;   // may be NULL
 };
-// l_top: optional LDS copy of the tree's first 2^TL nodes (tree[0 .. 2^TL)): the first TL - 1 levels of the descent then cost
-// an LDS read each instead of a dependent ~0.35 us L2 round trip (small batches: the descent IS the launch's critical path)
-__device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingView& rb, int64_t b, const float* l_top = nullptr,
-                                                 int TL = 0) {
+// (Round 5, tried and not kept: an LDS copy of the tree's top 12 levels for batches <= 512, so that thread 0's descent pays L2
+// latency for the remaining levels only -- the fused draw + gather of a 32-sample batch went 11.3 -> 10.9 us: the cooperative
+// 16 KB load and its barrier cost what twelve L2-resident round trips cost; profiles/r05_summary.md.)
+__device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingView& rb, int64_t b) {
     const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
-    float v = u01_f32(w.z) * (l_top ? l_top[1] : pd.tree[1]);
+    float v = u01_f32(w.z) * pd.tree[1];
     int64_t node = 1;
-    const int64_t ltop = l_top ? ((int64_t)1 << (TL - 1)) : 0;  // nodes below this have both children inside the LDS copy
     while (node < pd.P) {  // sumtree_descend (sumtree.hip), restated: never enters a zero-sum subtree
-        const float2 c = node < ltop ? *reinterpret_cast<const float2*>(l_top + 2 * node)
-                                     : *reinterpret_cast<const float2*>(pd.tree + 2 * node);
+        const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * node);
         const bool right = (v > c.x && c.y > 0.0f) || c.x == 0.0f;
         if (right) v -= c.x;
         node = 2 * node + (right ? 1 : 0);
@@ -247,31 +245,15 @@ __global__ __launch_bounds__(256) void gather_rec_kernel(RingView rb, const int6
 
 // large contiguous frames (n_env == 1): one workgroup per sample, 16 B/lane streaming copy.
 // Output layout here is sample-major: s[b * frame_bytes ...] (a frame stays contiguous).
-// TOPLDS (round 5, small prioritized batches): the workgroup first copies the top PRIO_TOP_LEVELS levels of the sum-tree into
-// LDS (one cooperative round trip), so that thread 0's descent pays L2 latency only for the levels below them: at batch 32 the
-// 20 dependent reads of a 2^20-leaf descent (~7 us) were the launch.  Not for large batches (4096 workgroups would each
-// re-read 16 KB of tree).  Same arithmetic on the same values: the same indices.
-constexpr int PRIO_TOP_LEVELS = 12;  // 2^12 nodes = 16 KB
-template <bool TOPLDS>
 __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const int64_t* __restrict__ idx,
                                                             int64_t batch, int64_t frame_bytes,
                                                             uint8_t* __restrict__ s, int32_t* __restrict__ a,
                                                             float* __restrict__ r, uint8_t* __restrict__ term,
                                                             uint8_t* __restrict__ sn, PrioDraw pd) {
     __shared__ int64_t l_off[2];
-    __shared__ __attribute__((aligned(16))) float l_top[TOPLDS ? (1 << PRIO_TOP_LEVELS) : 4];
     int64_t b = blockIdx.x;
-    int TL = 0;
-    if (TOPLDS) {  // (launched with a tree and P >= 2^PRIO_TOP_LEVELS only)
-        TL = PRIO_TOP_LEVELS;
-        const float4* src = reinterpret_cast<const float4*>(pd.tree);
-        float4* dst = reinterpret_cast<float4*>(l_top);
-#pragma unroll
-        for (int q = 0; q < (1 << PRIO_TOP_LEVELS) / 4 / 256; ++q) dst[threadIdx.x + 256 * q] = src[threadIdx.x + 256 * q];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        int64_t li = pd.tree ? prio_draw_one(pd, rb, b, TOPLDS ? l_top : nullptr, TL) : idx[b];
+        int64_t li = pd.tree ? prio_draw_one(pd, rb, b) : idx[b];
         int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
         int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
         int64_t pt = (rb.head_rt + li) % rb.capacity;
@@ -632,13 +614,8 @@ static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_
     if (big) {
         RLHIP_REQUIRE(((((uintptr_t)rb->state | (uintptr_t)s | (uintptr_t)s_next) & 15) == 0),
                       "frame-major gather needs 16-byte aligned buffers");
-        // small prioritized batches descend through an LDS copy of the tree's top levels (gather_frames_kernel<true>)
-        if (pd.tree && batch <= 512 && pd.P >= (1 << PRIO_TOP_LEVELS) && (((uintptr_t)pd.tree) & 15) == 0)
-            hipLaunchKernelGGL((gather_frames_kernel<true>), dim3((int)batch), dim3(256), 0, st, v, idx, batch, frame_bytes,
-                               (uint8_t*)s, a, r, term, (uint8_t*)s_next, pd);
-        else
-            hipLaunchKernelGGL((gather_frames_kernel<false>), dim3((int)batch), dim3(256), 0, st, v, idx, batch, frame_bytes,
-                               (uint8_t*)s, a, r, term, (uint8_t*)s_next, pd);
+        hipLaunchKernelGGL(gather_frames_kernel, dim3((int)batch), dim3(256), 0, st, v, idx, batch, frame_bytes,
+                           (uint8_t*)s, a, r, term, (uint8_t*)s_next, pd);
     } else {
         int grid = (int)((batch + GATHER_TILE - 1) / GATHER_TILE);
         const bool lane = rb->layout == RLHIP_RING_RECORDS;
