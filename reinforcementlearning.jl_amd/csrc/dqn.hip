@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                 uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
                 fj = (int64_t)__umul64hi(xr, g.total);
             }
-            const RingTransition rt = ring_load_transition(g.ring, fj);  // two 32-byte sectors per sample
+            const RingTransition rt = ring_load_transition(g.ring, fj);  // one 64-byte record = one fabric request per sample
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 gs[k] = rt.s[k];

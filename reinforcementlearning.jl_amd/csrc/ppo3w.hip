@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(256) void dqn3w_gather_kernel(D3WRing rb, P3WArgs g
         const uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
         fj = (int64_t)__umul64hi(xr, rb.total);
     }
-    const RingTransition rt = ring_load_transition(rb.ring, fj);  // two 32-byte sectors per sample
+    const RingTransition rt = ring_load_transition(rb.ring, fj);  // one 64-byte record = one fabric request per sample
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         g.xg[(int64_t)k * g.npad + q] = rt.s[k];
