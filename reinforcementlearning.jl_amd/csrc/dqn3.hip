@@ -442,59 +442,43 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     f32x16 dw[4];
     zero_acc(dw);
     bf16x8 bwf[H3 / 16];  // B fragments of this wave's column tile
-    // the tile's transitions (BatchSampler draw + one 64-byte record per sample) are requested ONE TILE AHEAD (round 5): the
-    // dependent chain index -> Philox -> record load is a fabric round trip (~1.5 us of a ~7.6 us tile) that the counters
-    // showed exposed at the top of every tile (profiles/r05_tile_budget.md section 2)
-    struct Tr {
-        float s[NS], sn[NS], r;
-        int32_t a, t;
-    };
-    auto fetch = [&](int tile_) {
-        Tr q;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) q.s[k] = q.sn[k] = 0.f;
-        q.r = 0.f;
-        q.a = q.t = 0;
-        if (tid < G32 && tile_ < g.num_tiles) {
-            int64_t b = (int64_t)tile_ * G32 + tid;
-            bool valid = b < g.batch;
-            int64_t fj;
-            if (g.idx) {
-                fj = g.idx[valid ? b : 0];
-            } else {
-                u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
-                uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
-                fj = (int64_t)__umul64hi(xr, g.total);
-            }
-            const RingTransition rt = ring_load_transition(g.ring, fj);  // one 64-byte record = one fabric request per sample
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                q.s[k] = rt.s[k];
-                q.sn[k] = rt.sn[k];
-            }
-            q.a = rt.a;
-            q.r = rt.r;
-            q.t = (int32_t)rt.t;
-        }
-        return q;
-    };
-    Tr nxt = fetch((int)blockIdx.x);
     for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
 #pragma unroll
     for (int ks = 0; ks < H3 / 16; ++ks)  // target net first
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.tpacked + ((ks * 4 + w) * 64 + lane) * 8);
-    // ---- publish this tile's transitions, request the next tile's ----
-    const Tr cur = nxt;
-    nxt = fetch(tile + (int)gridDim.x);
+    // ---- sample + gather ----
+    float gs[NS], gsn[NS], gr = 0.f;
+    int32_t ga = 0, gt = 0;
+    if (tid < G32) {
+        int64_t b = (int64_t)tile * G32 + tid;
+        bool valid = b < g.batch;
+        int64_t fj;
+        if (g.idx) {
+            fj = g.idx[valid ? b : 0];
+        } else {
+            u32x4 wd = philox4x32_10(g.seed, (uint32_t)(valid ? b : 0), 0, g.draw_ctr, TAG_SAMPLER);
+            uint64_t xr = ((uint64_t)wd.x << 32) | (uint64_t)wd.y;
+            fj = (int64_t)__umul64hi(xr, g.total);
+        }
+        const RingTransition rt = ring_load_transition(g.ring, fj);  // one 64-byte record = one fabric request per sample
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            gs[k] = rt.s[k];
+            gsn[k] = rt.sn[k];
+        }
+        ga = rt.a;
+        gr = rt.r;
+        gt = (int32_t)rt.t;
+    }
     if (tid < G32) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            l_x[k * G32 + tid] = cur.s[k];
-            l_xn[k * G32 + tid] = cur.sn[k];
+            l_x[k * G32 + tid] = gs[k];
+            l_xn[k * G32 + tid] = gsn[k];
         }
-        l_a[tid] = cur.a;
-        l_r[tid] = cur.r;
-        l_t[tid] = cur.t;
+        l_a[tid] = ga;
+        l_r[tid] = gr;
+        l_t[tid] = gt;
     }
     __syncthreads();
 
