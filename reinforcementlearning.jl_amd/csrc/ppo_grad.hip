@@ -160,26 +160,8 @@ __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restric
     pack_records(params, packed, h, ns, nout, np_a, threadIdx.x, blockDim.x);
 }
 
-// Once per update call: workgroup 0 packs the unit records (pack_params_kernel), the others write one 32-byte record per
-// trajectory entry f = t n + i -- {x0..x3}, {logp, adv, ret, action bits} -- from the eight planes of the trajectory (coalesced
-// reads and writes).  The 16 optimiser steps then gather a shuffled sample with two 16-byte reads of ONE cache line instead
-// of eight 4-byte reads of eight lines: 32768 samples x 8 lines x 64 B = 16.8 MB through the fabric per step otherwise.
-__global__ __launch_bounds__(256) void pack_update_kernel(const float* __restrict__ params, float* __restrict__ packed, int h,
-                                                          int ns, int nout, int64_t np_a, GradArgs g, float4* __restrict__ samples) {
-    if (blockIdx.x == 0) {
-        pack_records(params, packed, h, ns, nout, np_a, threadIdx.x, blockDim.x);
-        return;
-    }
-    const uint32_t n = (uint32_t)g.n;
-    for (uint32_t f = (blockIdx.x - 1) * 256 + threadIdx.x; f < g.total; f += (gridDim.x - 1) * 256) {
-        const uint32_t t = f / n, i = f - t * n;
-        float xv[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < ns; ++k) xv[k] = g.obs[((int64_t)t * ns + k) * g.n + i];
-        const float a = g.pd.cont ? g.action_f[f] : __int_as_float(g.action_i[f]);
-        samples[2 * (int64_t)f] = make_float4(xv[0], xv[1], xv[2], xv[3]);
-        samples[2 * (int64_t)f + 1] = make_float4(g.logp[f], g.adv[f], g.ret[f], a);
-    }
-}
+// (Round 3 - 4: `pack_update_kernel` wrote one 32-byte sample record per trajectory entry once per update call; since round 5 the
+// first gradient launch of the call does it with its idle team -- ppo_grad_kernel, `samples_out`.)
 
 // ------------------------------------------------------------------------- reduce (+ apply) ----
 struct ApplyArgs {
@@ -756,7 +738,7 @@ using namespace rlhip;
 extern "C" {
 
 // bytes of the carve of prepare_grad (256-byte aligned); behind it the sample records of an update call
-// (pack_update_kernel): 32 B per trajectory entry, up to 2^24 entries (512 MB); beyond that the steps gather from the planes
+// (written by the first gradient launch of the call): 32 B per trajectory entry, up to 2^24 entries (512 MB); beyond that the steps gather from the planes
 static int64_t sample_record_bytes(int64_t n, int64_t T) {
     const int64_t total = n * T;
     return (total >= 1 && total <= ((int64_t)1 << 24)) ? 32 * total : 0;
@@ -773,19 +755,6 @@ static float4* update_samples_ptr(int32_t kind, const rlhip_ppo_cfg* cfg, int64_
     if (sample_record_bytes(n, T) <= 0 || np_ <= 0) return nullptr;
     return (float4*)((char*)workspace + grad_workspace_bytes(np_));
 }
-// first launch of an update call: unit records (+ the sample records, same launch)
-static void pack_for_update(const GradLaunch& L, float4* samples, hipStream_t s) {
-    if (!samples) {
-        launch_pack(L, s);
-        return;
-    }
-    const int nblk = 1 + (int)std::min<int64_t>(((int64_t)L.g.total + 255) / 256, 2048);
-    GradArgs ga = L.g;
-    ga.samples = nullptr;
-    hipLaunchKernelGGL(pack_update_kernel, dim3(nblk), dim3(256), 0, s, L.g.params, L.packed, L.g.pd.h, L.ns, L.g.pd.nout_a,
-                       L.g.pd.np_a, ga, samples);
-}
-
 int32_t rlhip_ppo_workspace_init(void* workspace, int64_t bytes, rlhip_stream_t stream) {
     RLHIP_REQUIRE(workspace != nullptr && bytes > 0, "bad arguments");
     RLHIP_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)bytes, as_stream(stream)));
@@ -915,14 +884,9 @@ int32_t rlhip_ppo_update_p2p_f32(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t
                 hipStream_t s = as_stream(stream);
                 L.g.samples = samples;
                 if (first) {  // no pack launch: see update_entry
-                    static const bool pack_launch = RLHIP_ENV_FLAG("RLHIP_PPO_PACK_LAUNCH");
-                    if (pack_launch) {
-                        pack_for_update(L, samples, s);
-                    } else {
-                        L.g.packed = nullptr;
-                        L.g.samples = nullptr;
-                        L.g.samples_out = samples;
-                    }
+                    L.g.packed = nullptr;
+                    L.g.samples = nullptr;
+                    L.g.samples_out = samples;
                 }
                 first = false;
                 if ((rc = launch_grad(L, s))) return rc;
@@ -1041,17 +1005,13 @@ static int32_t update_entry(int32_t kind, const rlhip_ppo_cfg* cfg, int64_t n, i
                 // trajectory planes and -- with the threads of the team that does not write the partial row -- writes the 32-byte
                 // sample records the other 15 steps read; the Adam tail of every step patches the unit-record image for the
                 // step after it.  Same values on both routes, hence the same bits (tests/test_gpu_learners.py compares update_
-                // with the grad_ / apply_ sequence).  RLHIP_PPO_PACK_LAUNCH=1: the round-4 form (pack launch first), for A / B.
+                // with the grad_ / apply_ sequence; same-box A / B against the round-4 form with its pack launch: 0.4012 ->
+                // 0.3970 ms per iteration, profiles/raw_r05/pack_launch_ab.txt).
                 // The arrival counter needs no per-call memset: the workspace is zero-initialised by its owner (ABI contract)
                 // and the last-arriving workgroup re-arms it in-kernel.
-                static const bool pack_launch = RLHIP_ENV_FLAG("RLHIP_PPO_PACK_LAUNCH");
-                if (pack_launch) {
-                    pack_for_update(L, samples, s);
-                } else {
-                    L.g.packed = nullptr;
-                    L.g.samples = nullptr;
-                    L.g.samples_out = samples;
-                }
+                L.g.packed = nullptr;
+                L.g.samples = nullptr;
+                L.g.samples_out = samples;
                 first = false;
             }
             if ((rc = launch_grad(L, s))) return rc;

@@ -64,7 +64,7 @@ struct GradArgs {
     uint64_t seed;         //     epoch = epoch_local + ctr[1] * n_epochs  (HIP-graph replayable)
     uint32_t epoch_local, n_epochs;
     const float4* samples; // sample records {x0..x3}, {logp, adv, ret, action bits} per trajectory entry f = t n + i, or NULL:
-                           // written once per update call (pack_update_kernel); a shuffled sample is then ONE 32-byte
+                           // written once per update call (by its first gradient launch: samples_out); a shuffled sample is then ONE 32-byte
                            // read instead of eight 4-byte reads from eight planes (eight cache lines)
     float4* samples_out;   // first launch of an update call (round 5): the kernel gathers from the planes (samples == NULL) and,
                            // off its critical path, writes the sample records the next 15 steps read -- no pack launch

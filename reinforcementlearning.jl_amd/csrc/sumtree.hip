@@ -501,7 +501,7 @@ int32_t rlhip_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf,
     RLHIP_REQUIRE(n < (1ll << 31), "too many keys in one update");
     const int64_t P = pow2_ge(n_leaves);
     const int logP = log2_of(P);
-    if (n <= SMALL_UPDATE_MAX && n_leaves < (1ll << 31) && logP <= SMALL_MAXL && !RLHIP_ENV_FLAG("RLHIP_SUMTREE_NO_SMALL")) {
+    if (n <= SMALL_UPDATE_MAX && n_leaves < (1ll << 31) && logP <= SMALL_MAXL) {
         // one wavefront, two round trips (sumtree_update_small_kernel): 32 keys on a 2^20-leaf tree 10.6 -> ~6 us
         hipLaunchKernelGGL(sumtree_update_small_kernel, dim3(1), dim3(64), 0, as_stream(stream), tree, P, logP, n_leaves, leaf, prio,
                            (int)n);

@@ -78,7 +78,8 @@ def test_row_operand_fetch_order_matches_the_register_order():
 
 
 def test_sample_records_are_the_planes_transposed():
-    """pack_update_kernel: record f = t n + i holds {obs[(t ns + k) n + i], k < ns; 0 ...}, {logp[f], adv[f], ret[f], action[f]}:
+    """the sample records (written by the first gradient launch of an update call, ppo_grad_kernel `samples_out`; rounds 3 - 4:
+    pack_update_kernel): record f = t n + i holds {obs[(t ns + k) n + i], k < ns; 0 ...}, {logp[f], adv[f], ret[f], action[f]}:
     gathering record f equals gathering the eight planes at (t, i) -- for every ns the fused learner supports"""
     rng = np.random.default_rng(3)
     for ns in (2, 3, 4):

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the RLHIP_* A / B hook this script toggles was removed once the result was in profiles/raw_r05/)
 # round 5, fifth contact: the update call without its pack launch -- learner parity suites + same-box A / B of the headline step
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export GRAFT_REPO_ROOT=$PWD TMPDIR=/tmp

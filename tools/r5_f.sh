@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the RLHIP_* A / B hook this script toggles was removed once the result was in profiles/raw_r05/)
 # round 5, sixth contact: small-batch prioritized path (one-wave sum-tree update, LDS-cached descent) -- sum-tree suites + the bench's small-batch numbers
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export GRAFT_REPO_ROOT=$PWD TMPDIR=/tmp
