@@ -198,16 +198,8 @@ struct PrioDraw {
 // (Round 5, tried and not kept: an LDS copy of the tree's top 12 levels for batches <= 512, so that thread 0's descent pays L2
 // latency for the remaining levels only -- the fused draw + gather of a 32-sample batch went 11.3 -> 10.9 us: the cooperative
 // 16 KB load and its barrier cost what twelve L2-resident round trips cost; profiles/r05_summary.md.)
-__device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingView& rb, int64_t b) {
-    const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
-    float v = u01_f32(w.z) * pd.tree[1];
-    int64_t node = 1;
-    while (node < pd.P) {  // sumtree_descend (sumtree.hip), restated: never enters a zero-sum subtree
-        const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * node);
-        const bool right = (v > c.x && c.y > 0.0f) || c.x == 0.0f;
-        if (right) v -= c.x;
-        node = 2 * node + (right ? 1 : 0);
-    }
+// the bookkeeping behind a descent that ended at heap position `node`: key, priority, logical flat index
+__device__ __forceinline__ int64_t prio_draw_finish(const PrioDraw& pd, const RingView& rb, int64_t b, int64_t node) {
     int64_t leaf = node - pd.P;
     if (leaf >= pd.n_leaves) leaf = pd.n_leaves - 1;
     if (pd.key_out) pd.key_out[b] = leaf;
@@ -218,6 +210,52 @@ __device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingV
     const int64_t flat = li * rb.n_env + e;
     pd.idx_out[b] = flat;
     return flat;
+}
+__device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingView& rb, int64_t b) {
+    const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
+    float v = u01_f32(w.z) * pd.tree[1];
+    int64_t node = 1;
+    while (node < pd.P) {  // sumtree_descend (sumtree.hip), restated: never enters a zero-sum subtree
+        const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * node);
+        const bool right = (v > c.x && c.y > 0.0f) || c.x == 0.0f;
+        if (right) v -= c.x;
+        node = 2 * node + (right ? 1 : 0);
+    }
+    return prio_draw_finish(pd, rb, b, node);
+}
+// The same draw by a whole wavefront, FOUR tree levels per memory round trip (round 5: the 20 dependent 8-byte reads of a
+// 2^20-leaf descent, ~7 us, were the critical path of a small prioritized batch): lanes 0 .. 14 request the 15 child pairs of the
+// depth-4 subtree below the current node at once, then the four decisions are taken from those registers (the pair of relative
+// node i on sub-level a sits in lane 2^a - 1 + i) -- the same comparisons on the same values in the same order as
+// prio_draw_one, hence the same leaf.  Called by all 64 lanes of one wave (uniform control flow); lane 0 does the bookkeeping.
+__device__ __forceinline__ int64_t prio_draw_wave(const PrioDraw& pd, const RingView& rb, int64_t b) {
+    const int lane = (int)threadIdx.x & 63;
+    const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
+    float v = u01_f32(w.z) * pd.tree[1];
+    int64_t node = 1;
+    int rem = 0;
+    for (int64_t t = 1; t < pd.P; t <<= 1) ++rem;  // levels below the root
+    while (rem > 0) {
+        const int L = rem < 4 ? rem : 4;
+        float cx = 0.0f, cy = 0.0f;
+        if (lane < (1 << L) - 1) {
+            const int a = 31 - __clz(lane + 1), i = lane + 1 - (1 << a);
+            const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * ((node << a) + i));
+            cx = c.x;
+            cy = c.y;
+        }
+        int i = 0;
+        for (int a = 0; a < L; ++a) {
+            const int src = (1 << a) - 1 + i;
+            const float lx = __shfl(cx, src, 64), ly = __shfl(cy, src, 64);
+            const bool right = (v > lx && ly > 0.0f) || lx == 0.0f;
+            if (right) v -= lx;
+            i = 2 * i + (right ? 1 : 0);
+        }
+        node = (node << L) + i;
+        rem -= L;
+    }
+    return lane == 0 ? prio_draw_finish(pd, rb, b, node) : 0;
 }
 
 // record rings (Float32 observations with OD <= 4 components: the classic-control envs): one LANE per sample, the three
@@ -252,8 +290,10 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
                                                             uint8_t* __restrict__ sn, PrioDraw pd) {
     __shared__ int64_t l_off[2];
     int64_t b = blockIdx.x;
+    int64_t drawn = 0;
+    if (pd.tree && threadIdx.x < 64) drawn = prio_draw_wave(pd, rb, b);  // wave 0, four tree levels per round trip
     if (threadIdx.x == 0) {
-        int64_t li = pd.tree ? prio_draw_one(pd, rb, b) : idx[b];
+        int64_t li = pd.tree ? drawn : idx[b];
         int64_t ps = (rb.head_sa + li) % (rb.capacity + 1);
         int64_t pn = (rb.head_sa + li + 1) % (rb.capacity + 1);
         int64_t pt = (rb.head_rt + li) % rb.capacity;
