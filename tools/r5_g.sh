@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, contact g: dqn3_grad32_kernel with the next tile's transitions requested one tile ahead -- parity suites + same-box A / B
+# round 5, contact g (re-used for the five-barrier form of dqn3_grad32_kernel): parity suites + same-box A / B of two library builds
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export GRAFT_REPO_ROOT=$PWD TMPDIR=/tmp
 O=gpurun_out/r5_g; mkdir -p $O
