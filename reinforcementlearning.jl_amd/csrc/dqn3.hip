@@ -406,33 +406,22 @@ constexpr int LDT = G32 + 8;  // bf16 pitch of the transposed tiles [k][sample]
 // ~30 spilled: two workgroups interleave their phases, which wins from 65536 samples up)
 template <int NS, int NA, int ACT, int OCC>
 __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
-    // Round 5: FIVE workgroup barriers per 32-sample tile instead of nine (the counters of the round-4 form: 825 VALU instructions
-    // and 32 MFMAs in 15 960 cycles per wave-tile -- the tile waited, profiles/r05_tile_budget.md):
-    //   * layer 1 of BOTH nets in front of one barrier (the target's H1 tile shares its memory with the dZ2 row tile, whose
-    //     first write comes two barriers later);
-    //   * the head is folded per WAVE: a wave transposes its own 32 x 32 block of H2 through a private LDS block (LDS
-    //     instructions of one wave execute in order: no workgroup barrier) and writes the partial sums of its 32 columns,
-    //     so "H2 tile complete" is no longer a workgroup event;
-    //   * the TD target / Huber line is evaluated by EVERY wave from the four partial rows (a few dozen instructions) into the
-    //     wave's own dL/dq slice, instead of by wave 0 behind one more barrier.
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     constexpr int na = NA;
-    constexpr int TPW32 = 36;                                         // f32 pitch of a wave's private transposition block
     float* l_x = reinterpret_cast<float*>(smem3);                     // [4][G32]
     float* l_xn = l_x + 4 * G32;                                      // [4][G32]
-    float* l_dqw = l_xn + 4 * G32;                                    // [4 waves][MAXO][G32] dL/dq, one slice per wave
-    float* l_r = l_dqw + 4 * MAXO * G32;                              // [G32]
-    float* l_part = l_r + G32;                                        // [4 waves][4][G32] online head partials
-    float* l_partn = l_part + 4 * 4 * G32;                            // [4 waves][4][G32] target head partials
-    int32_t* l_a = reinterpret_cast<int32_t*>(l_partn + 4 * 4 * G32); // [G32]
+    float* l_dq = l_xn + 4 * G32;                                     // [MAXO][G32]
+    float* l_r = l_dq + MAXO * G32;                                   // [G32]
+    float* l_part = l_r + G32;                                        // [8][4][G32] online head partials
+    float* l_partn = l_part + 8 * 4 * G32;                            // [8][4][G32] target head partials
+    int32_t* l_a = reinterpret_cast<int32_t*>(l_partn + 8 * 4 * G32); // [G32]
     int32_t* l_t = l_a + G32;                                         // [G32]
-    float* l_tw = reinterpret_cast<float*>(l_t + G32);                // [4 waves][G32][TPW32] wave-private H2 blocks
-    float* l_w = l_tw + 4 * G32 * TPW32;                              // [2][SMALLW]
-    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + 2 * SMALLW);    // online H1 [row][k]
+    float* l_h2 = reinterpret_cast<float*>(l_t + G32);                // [G32][LDH2] f32 H2 of the current net
+    float* l_w = l_h2 + G32 * LDH2;                                   // [2][SMALLW]
+    uint16_t* l_H = reinterpret_cast<uint16_t*>(l_w + 2 * SMALLW);    // H1 [row][k]
     uint16_t* l_HT = l_H + G32 * LDH;                                 // online H1^T [k][row]
-    uint16_t* l_Z = l_HT + H3 * LDT;                                  // dZ2 [row][j]; before that: the TARGET net's H1 [row][k]
+    uint16_t* l_Z = l_HT + H3 * LDT;                                  // dZ2 [row][j]
     uint16_t* l_ZT = l_Z + G32 * LDH;                                 // dZ2^T [j][row]
-    uint16_t* l_Ht = l_Z;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -440,12 +429,10 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     const int col = 32 * w + r;  // the hidden unit / column this lane owns in every D-layout phase
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
     const int oW1 = 0, ob1 = H3 * NS, oW2 = ob1 + H3, ob2 = oW2 + H3 * H3, oW3 = ob2 + H3, ob3 = oW3 + na * H3;
-    float* l_twv = l_tw + w * G32 * TPW32;
-    float* l_dq = l_dqw + w * MAXO * G32;
 
     const Mlp3 m = stage_small_weights(g.params, NS, na, l_w, tid);
     const Mlp3 mt = stage_small_weights(g.tparams, NS, na, l_w + SMALLW, tid);
-    const int row1 = tid & 31, u0 = 16 * (tid >> 5);
+    const int row1 = tid & 31, u0 = 16 * (tid >> 5), part = tid >> 5;
     // gradient accumulators of this workgroup over ALL its tiles (tile, tile + gridDim.x, ...): every sum below is per
     // lane already (a lane owns its column in each D-layout phase), so a persistent workgroup costs no extra traffic and
     // writes ONE partial row however large the batch is
@@ -493,10 +480,10 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
         l_r[tid] = gr;
         l_t[tid] = gt;
     }
-    __syncthreads();  // (1) the tile's transitions
+    __syncthreads();
 
-    // layer 1 of one net for (row1, units u0 .. u0 + 15): bf16 into dstH [row][k] and, for the online net, l_HT [k][row]
-    auto layer1 = [&](const Mlp3& mm, const float* lx, uint16_t* dstH, bool transposed_too) {
+    // layer 1 of one net for (row1, units u0 .. u0 + 15): bf16 into l_H [row][k] and, for the online net, l_HT [k][row]
+    auto layer1 = [&](const Mlp3& mm, const float* lx, bool transposed_too) {
         float x[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = lx[i * G32 + row1];
@@ -519,82 +506,74 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) hv[4 * q4 + c] = act_fwd_t<ACT>(z[c]);
             }
-            *reinterpret_cast<uint4*>(dstH + row1 * LDH + u0 + 8 * h8) = pack8_bf16(hv);
+            *reinterpret_cast<uint4*>(l_H + row1 * LDH + u0 + 8 * h8) = pack8_bf16(hv);
             if (transposed_too) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) l_HT[(u0 + 8 * h8 + c) * LDT + row1] = f32_to_bf16_rne(hv[c]);
             }
         }
     };
-    // layer 2 for this wave's 32 columns from srcH: activated H2 in the D layout, and into the wave's private block [row][r]
-    auto layer2w = [&](const uint16_t* srcH, const float* b2, f32x16& h2) {
+    // layer 2 for this wave's 32 columns: activated H2 in the D layout (+ the f32 tile for the head)
+    auto layer2w = [&](const float* b2, f32x16& h2) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) h2[q] = 0.0f;
-        const uint16_t* ap = srcH + r * LDH + 8 * kb;
+        const uint16_t* ap = l_H + r * LDH + 8 * kb;
 #pragma unroll
         for (int ks = 0; ks < H3 / 16; ++ks) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * ks);
             h2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwf[ks], h2, 0, 0, 0);
         }
         const float bv = b2[col];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the block's previous readers (this wave) are done: program order
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             h2[q] = act_fwd_t<ACT>(h2[q] + bv);
-            l_twv[mfma_row(q, kb) * TPW32 + r] = h2[q];
+            l_h2[mfma_row(q, kb) * LDH2 + col] = h2[q];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // head partials of this wave's 32 columns: lane (r, kb) folds row r over columns 32 w + 16 kb .. + 15, the two halves meet by
-    // one shuffle; lp[(w * 4 + o) * G32 + row]
+    // head partials of thread (row1, part) over 16 columns of its H2 row
     auto head = [&](const Mlp3& mm, float* lp) {
         float pq[NA];
 #pragma unroll
         for (int o = 0; o < NA; ++o) pq[o] = 0.0f;
-        const float* hp = l_twv + r * TPW32 + 16 * kb;
+        const float* hp = l_h2 + row1 * LDH2 + 16 * part;
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             const float4 v = *reinterpret_cast<const float4*>(hp + 4 * c4);
             const float hv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int j = 32 * w + 16 * kb + 4 * c4 + c;
+                const int j = 16 * part + 4 * c4 + c;
 #pragma unroll
                 for (int o = 0; o < NA; ++o) pq[o] = fmaf(mm.W3[o + NA * j], hv[c], pq[o]);
             }
         }
 #pragma unroll
-        for (int o = 0; o < NA; ++o) {
-            const float other = __shfl_xor(pq[o], 32, 64);
-            const float sum = kb == 0 ? pq[o] + other : other + pq[o];  // columns 0..15 first on both halves: the same bits
-            if (kb == 0) lp[(w * 4 + o) * G32 + r] = sum;
-        }
+        for (int o = 0; o < NA; ++o) lp[(part * 4 + o) * G32 + row1] = pq[o];
     };
 
-    // ---- layer 1 of both nets (the target's H1 tile lives where dZ2's row tile will) ----
-    layer1(mt, l_xn, l_Ht, false);
-    layer1(m, l_x, l_H, true);
-    __syncthreads();  // (2) both H1 tiles
     // ---- target network on s' ----
     f32x16 h2;
-    layer2w(l_Ht, mt.b2, h2);
+    layer1(mt, l_xn, false);
+    __syncthreads();
+    layer2w(mt.b2, h2);
 #pragma unroll
-    for (int ks = 0; ks < H3 / 16; ++ks)  // the online network's fragments: in flight during the target's head
+    for (int ks = 0; ks < H3 / 16; ++ks)  // the online network's fragments: in flight during the head and its layer 1
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.packed + ((ks * 4 + w) * 64 + lane) * 8);
+    __syncthreads();
     head(mt, l_partn);
     // ---- online network on s (its H2 stays in registers for the backward pass) ----
-    layer2w(l_H, m.b2, h2);
+    layer1(m, l_x, true);  // l_H was last read before the barrier above
+    __syncthreads();       // also: every thread is done reading the target's H2 tile
+    layer2w(m.b2, h2);
 #pragma unroll
     for (int ks = 0; ks < H3 / 16; ++ks)  // W2kj fragments (ks over j, this wave's k tile) for dH1
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.packed + H3 * H3 + ((ks * 4 + w) * 64 + lane) * 8);
+    __syncthreads();
     head(m, l_part);
-    __syncthreads();  // (3) the partial sums of all four waves, both nets
-    // ---- TD target, Huber loss, dL/dq per sample: every wave for itself (lane (r, kb) takes row r; the halves duplicate) ----
-    {
-        const int s = r;
+    __syncthreads();
+    // ---- TD target, Huber loss, dL/dq per sample ----
+    if (tid < G32) {
+        const int s = tid;
         const int64_t b = (int64_t)tile * G32 + s;
         const bool valid = b < g.batch;
         float q[MAXO], qn[MAXO];
@@ -604,7 +583,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             if (o < na) {
                 float a1 = l_part[o * G32 + s], a2 = l_partn[o * G32 + s];
 #pragma unroll
-                for (int pp = 1; pp < 4; ++pp) {
+                for (int pp = 1; pp < 8; ++pp) {
                     a1 += l_part[(pp * 4 + o) * G32 + s];
                     a2 += l_partn[(pp * 4 + o) * G32 + s];
                 }
@@ -634,29 +613,25 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             gi = 0.f;
             l = 0.f;
         }
-        if (valid && g.td_out && w == 0 && kb == 0) g.td_out[b] = e;
+        if (valid && g.td_out) g.td_out[b] = e;
         float red[MAXO + 1];
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) {
             float dl = (o == a) ? gi : 0.f;
-            if (kb == 0) l_dq[o * G32 + s] = dl;
+            l_dq[o * G32 + s] = dl;
             red[o] = dl;
         }
         red[MAXO] = l;
-        if (w == 0) {  // the output-bias gradients and the loss sum: once per workgroup (lanes 0..31 of wave 0)
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1)
+        for (int off = 16; off >= 1; off >>= 1)  // lanes 0..31 of wave 0
 #pragma unroll
-                for (int o = 0; o <= MAXO; ++o) red[o] += __shfl_down(red[o], off, 64);
-            if (lane == 0) {
+            for (int o = 0; o <= MAXO; ++o) red[o] += __shfl_down(red[o], off, 64);
+        if (lane == 0) {
 #pragma unroll
-                for (int o = 0; o <= MAXO; ++o) acc_b3[o] += red[o];
-            }
+            for (int o = 0; o <= MAXO; ++o) acc_b3[o] += red[o];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own dL/dq slice: written above, read below
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    __syncthreads();
     // ---- head backward in the D layout (this wave's 32 columns): dW3, db2, dZ2 -> bf16 tiles [row][j] and [j][row] ----
     {
         float w3[MAXO], accw[MAXO], accb = 0.0f;
@@ -697,7 +672,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) acc_w3[o] += accw[o];
     }
-    __syncthreads();  // (4) dZ2 in both layouts
+    __syncthreads();
     // ---- dH1 = dZ2 W2 (MFMA, this wave's 32 hidden units k), dz1 = dH1 act'(z1), dW1 / db1 ----
     {
         f32x16 dh1;
@@ -751,7 +726,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             }
         }
     }
-    __syncthreads();  // (5) the next tile's gather and layer 1 rewrite l_x / l_a / the H1 and dZ2 tiles that the phases above read
+    __syncthreads();  // the next tile's gather rewrites l_x / l_a / ... that the phases above read
     }  // tiles
     // ---- this workgroup's partial row ----
     if (tid == 0) {
@@ -771,7 +746,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
         for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
 }
 
-constexpr size_t GRAD32_LDS = (4 * G32 * 2 + 4 * MAXO * G32 + G32 + 2 * 4 * 4 * G32 + 2 * G32 + 4 * G32 * 36 + 2 * SMALLW) *
+constexpr size_t GRAD32_LDS = (4 * G32 * 2 + MAXO * G32 + G32 + 2 * 8 * 4 * G32 + 2 * G32 + G32 * LDH2 + 2 * SMALLW) *
                                   sizeof(float) +
                               (2 * G32 * LDH + 2 * H3 * LDT) * sizeof(uint16_t);
 
