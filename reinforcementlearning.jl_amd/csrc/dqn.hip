@@ -27,6 +27,17 @@ namespace rlhip {
 
 constexpr int DTILE = 64;
 constexpr int DQN_MAX_BLOCKS = 512;
+constexpr int DQN_FUSE_MAX_BLOCKS = 64;  // dqn_grad_kernel<..., FUSE>: partial rows the last workgroup folds alone
+
+struct DqnApply {
+    float* p;
+    float* m;
+    float* v;
+    float* beta_pow;
+    float* gn_out;
+    unsigned int* counter;  // arrival counter in the workspace tail: zero before the first launch, re-armed here
+    float grad_scale, clip_norm, lr, b1, b2, eps;
+};
 
 struct DqnArgs {
     RingRecs ring;  // record ring (ring_device.h)
@@ -43,7 +54,137 @@ struct DqnArgs {
     const int64_t* idx;  // optional explicit flat logical indices (prioritized sampler); NULL = inline uniform draw
     float* td_out;       // optional |Q(s,a) - y| per sample (priority write-back)
     const float* isw;    // optional importance-sampling weights per sample (prioritized replay, beta > 0): loss = mean(w .* huber)
+    // FUSE form only (dqn_grad_kernel<..., true>): the optimise! tail runs in the workgroup that departs last
+    DqnApply ap;
+    float* grad;
+    float* loss;
 };
+
+// a partial-row store: plain when a later LAUNCH reads it, device-scope (write-through) when the last workgroup of THIS launch does
+template <bool FUSE>
+__device__ __forceinline__ void publish(float* p, float v) {
+    if constexpr (FUSE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// optimise! tail inside the gradient launch, run by the 256 threads of the workgroup that departed last: the arithmetic of
+// dqn_reduce_apply_kernel (= dqn_reduce_kernel, then clip_adam_kernel<4> of optim.hip) element for element and IN ITS ORDER --
+//   gradient   four groups of partial rows, ascending inside a group, then ((g0 + g1) + g2) + g3;
+//   norm       clip_adam_kernel<4> runs 1024 threads, thread t owning elements t + 1024 k: this thread stands in for the four
+//              virtual threads tid + 256 q (its wave for the virtual waves w + 4 q), sums each one's squares in Float64, reduces each
+//              virtual wave with the same shuffle tree and adds the sixteen wave sums in ascending order;
+//   Adam       elementwise --
+// so parameters, moments, gradient and loss are bit-identical to the two- and three-launch forms (tests/test_gpu_dqn.py).
+// l_x: >= 4096 floats of LDS (the weight records, dead by now); np <= 4096.
+__device__ __forceinline__ void dqn_fused_tail(const DqnArgs& g, float* l_x, double* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb = gridDim.x, np = g.np;
+    const DqnApply& ap = g.ap;
+    const int per = (nb + 3) / 4;
+    const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
+    const bool single = np <= 1024;  // one chunk of 1024 elements (the 4 -> 128 -> 2 net: 898): its Adam operands are requested
+    float pr[4], mr[4], vr[4];       // up front and arrive under the partial rows
+    if (single) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            pr[q] = i < np ? ap.p[i] : 0.0f;
+            mr[q] = i < np ? ap.m[i] : 0.0f;
+            vr[q] = i < np ? ap.v[i] : 0.0f;
+        }
+    }
+    float lp = 0.f;
+    if (w == 1 && lane < nb) lp = __hip_atomic_load(g.loss_partials + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nb <= 64
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; 1024 * k < np; ++k) {
+        // the partial rows of this thread's four elements: 4 elements x 4 groups x 4 rows = 64 independent device-scope loads per
+        // round trip (row index clamped instead of predicated: no branch between the loads; a + 0.0f == a for every a this sum can
+        // reach, since it starts from +0), added in dqn_reduce_kernel's order
+        float a4[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) a4[q][grp] = 0.f;
+        for (int r0 = 0; r0 < per; r0 += 4) {
+            float v[4][4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = min(tid + 256 * q + 1024 * k, np - 1);
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int b = min(grp * per + r0 + r, nb - 1);
+                        v[q][grp][r] = __hip_atomic_load(g.partials + (int64_t)b * np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int b = grp * per + r0 + r;
+                        a4[q][grp] += (r0 + r < per && b < nb) ? v[q][grp][r] : 0.0f;
+                    }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q + 1024 * k;
+            float x = 0.0f;
+            if (i < np) {
+                x = (((a4[q][0] + a4[q][1]) + a4[q][2]) + a4[q][3]) * ap.grad_scale;
+                l_x[i] = x;  // read back by this thread only
+            }
+            acc[q] += (double)x * (double)x;
+        }
+    }
+    if (w == 1 && g.loss != nullptr) {  // dqn_reduce_kernel's loss line: lane-strided, then the shuffle tree
+        float a = 0.f + lp;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) g.loss[0] = a * g.inv_b;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) scratch[w + 4 * q] = v;
+    }
+    __syncthreads();
+    double t = 0.0;
+    for (int vw = 0; vw < 16; ++vw) t += scratch[vw];
+    const float gn = (float)sqrt(t);
+    const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
+    for (int k = 0; 1024 * k < np; ++k) {
+        if (!single) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + 256 * q + 1024 * k;
+                pr[q] = i < np ? ap.p[i] : 0.0f;
+                mr[q] = i < np ? ap.m[i] : 0.0f;
+                vr[q] = i < np ? ap.v[i] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q + 1024 * k;
+            if (i < np) {
+                const float x = l_x[i];
+                const float gi = (scale == 1.0f) ? x : x * scale;
+                adam1(pr[q], gi, mr[q], vr[q], ap.lr, ap.b1, ap.b2, ap.eps, c1, c2);
+                ap.p[i] = pr[q];
+                ap.m[i] = mr[q];
+                ap.v[i] = vr[q];
+                g.grad[i] = gi;
+            }
+        }
+    }
+    if (tid == 0) {
+        if (ap.gn_out) ap.gn_out[0] = gn;
+        ap.beta_pow[0] *= ap.b1;  // every thread read beta_pow before the barrier above
+        ap.beta_pow[1] *= ap.b2;
+    }
+}
 
 // One workgroup = one 64-sample tile (a 512-sample batch is 8 workgroups, so the kernel is a latency chain, not a
 // throughput problem -- measured 19.5 us per launch for the first version, which walked the hidden units with
@@ -56,7 +197,10 @@ struct DqnArgs {
 //   phase 2   lane = hidden unit (weights in registers), samples stream from LDS as broadcast reads; when 2 h <= 256
 //             the two halves of the tile go to two lane groups and are added in a fixed order at the end
 // Gradient partials per workgroup, summed in a fixed order by dqn_reduce[_apply]_kernel: run-to-run deterministic.
-template <int NS, int ACT>
+//
+// FUSE (round 5): the whole optimise! in ONE launch -- every workgroup publishes its partial row with device-scope stores and
+// counts itself out; the workgroup that departs last runs dqn_fused_tail (reduce -> clip -> Adam).  Host: nb <= DQN_FUSE_MAX_BLOCKS.
+template <int NS, int ACT, bool FUSE>
 __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
     // LDS: everything a later phase reads as a unit is ONE 16-byte vector (a broadcast or a conflict-free b128 read):
     //   l_rec[net][j] = {W1[j, 0..3]}, {b1[j], W2[0..2, j]}, {W2[3, j], -, -, -}   (rows beyond NS / na are zeros)
@@ -69,6 +213,8 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
     __shared__ uint8_t l_t[DTILE];
     __shared__ float l_part[4][2 * MAXO][DTILE];
     __shared__ float4 l_rec[2][HMAX][3];
+    __shared__ double l_scratch[16];
+    __shared__ int l_last;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,11 +439,11 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
     if (owner && half == 0) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) out[j + h * k] = gw1[k];
-        out[h * NS + j] = gb1;
+        for (int k = 0; k < NS; ++k) publish<FUSE>(out + j + h * k, gw1[k]);
+        publish<FUSE>(out + h * NS + j, gb1);
 #pragma unroll
         for (int o = 0; o < MAXO; ++o)
-            if (o < na) out[h * NS + h + o + na * j] = gw2[o];
+            if (o < na) publish<FUSE>(out + h * NS + h + o + na * j, gw2[o]);
     }
     if (tid < DTILE) {
 #pragma unroll
@@ -307,9 +453,21 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             s_loss += __shfl_down(s_loss, off, 64);
         }
         if (tid == 0) {
-            for (int o = 0; o < na; ++o) out[h * NS + h + na * h + o] = gb2[o];
-            g.loss_partials[blockIdx.x] = s_loss;
+            for (int o = 0; o < na; ++o) publish<FUSE>(out + h * NS + h + na * h + o, gb2[o]);
+            publish<FUSE>(g.loss_partials + blockIdx.x, s_loss);
         }
+    }
+    if constexpr (FUSE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's row stores have reached the L2 / fabric
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int prev = __hip_atomic_fetch_add(g.ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l_last = (prev == gridDim.x - 1) ? 1 : 0;
+            if (l_last) __hip_atomic_store(g.ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        }
+        __syncthreads();
+        if (!l_last) return;
+        dqn_fused_tail(g, reinterpret_cast<float*>(&l_rec[0][0][0]), l_scratch);
     }
 }
 
@@ -343,15 +501,6 @@ __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict
 // last -- the body of clip_adam_kernel<4> (optim.hip): same element-to-thread mapping (thread t owns t + 1024 k),
 // same Float64 block sum, same Adam expression order, so parameters / moments / gradient are bit-identical to
 // "rlhip_dqn_grad_f32 then rlhip_clip_adam_f32".  Host: np <= 4096 only (the <4> regime of rlhip_clip_adam_f32).
-struct DqnApply {
-    float* p;
-    float* m;
-    float* v;
-    float* beta_pow;
-    float* gn_out;
-    unsigned int* counter;  // arrival counter in the workspace tail: zero before the first launch, re-armed here
-    float grad_scale, clip_norm, lr, b1, b2, eps;
-};
 
 __global__ __launch_bounds__(1024) void dqn_reduce_apply_kernel(const float* __restrict__ partials,
                                                                 const float* __restrict__ loss_partials, int nb,
@@ -566,11 +715,28 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
     g.partials = (float*)workspace;
     g.loss_partials = g.partials + (int64_t)DQN_MAX_BLOCKS * np;
     hipStream_t s = as_stream(stream);
-#define LAUNCH_DG(NS_, ACT_) hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_>), dim3(nb), dim3(256), 0, s, g)
+    // one launch for the whole optimise! while a single workgroup can fold the partial rows quickly (<= 64 rows = a 4096-sample
+    // batch); beyond that the tail stays its own launch, 64 parameters per workgroup
+    const bool fuse = apply != nullptr && nb <= DQN_FUSE_MAX_BLOCKS && !RLHIP_ENV_FLAG("RLHIP_DQN_NO_FUSE");
+    if (fuse) {
+        g.ap = *apply;
+        g.ap.counter = (unsigned int*)(g.loss_partials + DQN_MAX_BLOCKS);
+        g.grad = grad_out;
+        g.loss = loss_out;
+    }
+#define LAUNCH_DG(NS_, ACT_)                                                                              \
+    do {                                                                                                  \
+        if (fuse) hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_, true>), dim3(nb), dim3(256), 0, s, g);   \
+        else hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_, false>), dim3(nb), dim3(256), 0, s, g);       \
+    } while (0)
     if (ns == 4) { if (act == 0) LAUNCH_DG(4, 0); else LAUNCH_DG(4, 1); }
     else if (ns == 3) { if (act == 0) LAUNCH_DG(3, 0); else LAUNCH_DG(3, 1); }
     else { if (act == 0) LAUNCH_DG(2, 0); else LAUNCH_DG(2, 1); }
 #undef LAUNCH_DG
+    if (fuse) {
+        RLHIP_LAUNCH_CHECK();
+        return RLHIP_OK;
+    }
     if (apply) {
         apply->counter = (unsigned int*)(g.loss_partials + DQN_MAX_BLOCKS);
         hipLaunchKernelGGL(dqn_reduce_apply_kernel, dim3((int)((np + 63) / 64)), dim3(1024), 0, s, g.partials,

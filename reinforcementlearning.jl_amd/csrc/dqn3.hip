@@ -404,6 +404,20 @@ constexpr int D3_GRAD32_BLOCKS = 512;  // persistent workgroups of the 32-sample
 constexpr int LDT = G32 + 8;  // bf16 pitch of the transposed tiles [k][sample]
 // OCC = workgroups per CU asked of the compiler: 1 (280 VGPRs, no spills: the latency-bound small batches) or 2 (256 VGPRs,
 // ~30 spilled: two workgroups interleave their phases, which wins from 65536 samples up)
+// per-phase wall-clock stamps of the LAST tile of workgroup 0 (steady state when it has several), thread 0 -- -DRLHIP_D3_TIMING only
+// (tools/d3g32_timeline.py)
+#ifdef RLHIP_D3_TIMING
+#define G32_STAMP(k)                                                                                             \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tile + (int)gridDim.x >= g.num_tiles) g_d3_stamps[12 + (k)] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define G32_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
 template <int NS, int NA, int ACT, int OCC>
 __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
@@ -443,6 +457,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     zero_acc(dw);
     bf16x8 bwf[H3 / 16];  // B fragments of this wave's column tile
     for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
+    G32_STAMP(0);
 #pragma unroll
     for (int ks = 0; ks < H3 / 16; ++ks)  // target net first
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.tpacked + ((ks * 4 + w) * 64 + lane) * 8);
@@ -480,7 +495,9 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
         l_r[tid] = gr;
         l_t[tid] = gt;
     }
+    G32_STAMP(1);
     __syncthreads();
+    G32_STAMP(2);
 
     // layer 1 of one net for (row1, units u0 .. u0 + 15): bf16 into l_H [row][k] and, for the online net, l_HT [k][row]
     auto layer1 = [&](const Mlp3& mm, const float* lx, bool transposed_too) {
@@ -554,23 +571,34 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     // ---- target network on s' ----
     f32x16 h2;
     layer1(mt, l_xn, false);
+    G32_STAMP(3);
     __syncthreads();
+    G32_STAMP(4);
     layer2w(mt.b2, h2);
+    G32_STAMP(5);
 #pragma unroll
     for (int ks = 0; ks < H3 / 16; ++ks)  // the online network's fragments: in flight during the head and its layer 1
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.packed + ((ks * 4 + w) * 64 + lane) * 8);
     __syncthreads();
+    G32_STAMP(6);
     head(mt, l_partn);
+    G32_STAMP(7);
     // ---- online network on s (its H2 stays in registers for the backward pass) ----
     layer1(m, l_x, true);  // l_H was last read before the barrier above
+    G32_STAMP(8);
     __syncthreads();       // also: every thread is done reading the target's H2 tile
+    G32_STAMP(9);
     layer2w(m.b2, h2);
+    G32_STAMP(10);
 #pragma unroll
     for (int ks = 0; ks < H3 / 16; ++ks)  // W2kj fragments (ks over j, this wave's k tile) for dH1
         bwf[ks] = *reinterpret_cast<const bf16x8*>(g.packed + H3 * H3 + ((ks * 4 + w) * 64 + lane) * 8);
     __syncthreads();
+    G32_STAMP(11);
     head(m, l_part);
+    G32_STAMP(12);
     __syncthreads();
+    G32_STAMP(13);
     // ---- TD target, Huber loss, dL/dq per sample ----
     if (tid < G32) {
         const int s = tid;
@@ -631,7 +659,9 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             for (int o = 0; o <= MAXO; ++o) acc_b3[o] += red[o];
         }
     }
+    G32_STAMP(14);
     __syncthreads();
+    G32_STAMP(15);
     // ---- head backward in the D layout (this wave's 32 columns): dW3, db2, dZ2 -> bf16 tiles [row][j] and [j][row] ----
     {
         float w3[MAXO], accw[MAXO], accb = 0.0f;
@@ -672,7 +702,9 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) acc_w3[o] += accw[o];
     }
+    G32_STAMP(16);
     __syncthreads();
+    G32_STAMP(17);
     // ---- dH1 = dZ2 W2 (MFMA, this wave's 32 hidden units k), dz1 = dH1 act'(z1), dW1 / db1 ----
     {
         f32x16 dh1;
@@ -713,6 +745,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) acc_w1[i] += acc1[i];
     }
+    G32_STAMP(18);
     // ---- dW2^T[k][j] = sum_s H1[s][k] dZ2[s][j] (MFMA, K = the 32 samples); stored as Flux W2[j + H3 k] ----
     {
         const uint16_t* ap = l_HT + (32 * w + r) * LDT + 8 * kb;
@@ -726,6 +759,7 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             }
         }
     }
+    G32_STAMP(19);
     __syncthreads();  // the next tile's gather rewrites l_x / l_a / ... that the phases above read
     }  // tiles
     // ---- this workgroup's partial row ----

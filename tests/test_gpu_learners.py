@@ -454,15 +454,17 @@ def test_rollout_writes_gae_and_returns_bit_identical_to_the_scan(kind, layers, 
     assert torch.equal(adv, pol.trajectory.adv) and torch.equal(ret, pol.trajectory.ret)
 
 
-@pytest.mark.parametrize("ns,h,na,clip", [(4, 64, 2, 0.5), (4, 64, 2, 0.0), (2, 100, 3, 1e6), (3, 256, 3, 0.05),
-                                           (4, 252, 4, 0.5), (4, 256, 4, 0.5)])
-def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip):
-    """rlhip_dqn_update_f32 (gradient, then reduce + clip + Adam in the last-arriving workgroup) == rlhip_dqn_grad_f32
-    followed by rlhip_clip_adam_f32, bit for bit, over repeated calls (the arrival counter re-arms itself)"""
+@pytest.mark.parametrize("ns,h,na,clip,batch", [(4, 64, 2, 0.5, 700), (4, 64, 2, 0.0, 700), (2, 100, 3, 1e6, 700), (3, 256, 3, 0.05, 700),
+                                                 (4, 252, 4, 0.5, 700), (4, 256, 4, 0.5, 700), (4, 128, 2, 0.5, 32), (4, 128, 2, 0.5, 512),
+                                                 (4, 128, 2, 0.5, 4096), (4, 256, 4, 0.5, 4096), (4, 128, 2, 0.5, 4097), (3, 256, 3, 0.5, 40000)])
+def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip, batch):
+    """rlhip_dqn_update_f32 == rlhip_dqn_grad_f32 followed by rlhip_clip_adam_f32, bit for bit, over repeated calls (the departure
+    counter re-arms itself).  Up to 64 tiles (4096 samples) the whole optimise! is ONE launch (dqn_grad_kernel<..., FUSE>: the
+    workgroup that departs last folds the partial rows, clips, steps); beyond that the tail is dqn_reduce_apply_kernel."""
     import rlhip
     from rlhip import dqn, ops
 
-    n, batch = 64, 700
+    n = 64
     tr = rlhip.CircularArraySARTSTraces(capacity=32, n_env=n, obs_dim=ns)
     tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
     tr.action.random_(0, na)
