@@ -25,9 +25,30 @@ extern "C" int64_t rlhip_mlp2_nparams(int64_t n_in, int64_t h, int64_t n_out);
 
 namespace rlhip {
 
+// per-workgroup phase stamps (thread 0) -- -DRLHIP_DQN_TIMING only, read with rlhip_debug_dqn_stamps (tools/dqn_timeline.py)
+#ifdef RLHIP_DQN_TIMING
+__device__ long long g_dqn_stamps[64][16];  // [..][14], [..][15]: s_memtime (shader clock) at stamps 0 and 7 -> the clock the launch ran at
+#define DQN_STAMP(k)                                                                   \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 64) {                                     \
+            g_dqn_stamps[blockIdx.x][k] = wall_clock64();                              \
+            if ((k) == 0) g_dqn_stamps[blockIdx.x][14] = clock64();                    \
+            if ((k) == 7) g_dqn_stamps[blockIdx.x][15] = clock64();                    \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#else
+#define DQN_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
+
 constexpr int DTILE = 64;
+constexpr int DTHREADS = 1024, DWAVES = DTHREADS / 64;  // dqn_grad_kernel's workgroup
 constexpr int DQN_MAX_BLOCKS = 512;
-constexpr int DQN_FUSE_MAX_BLOCKS = 64;  // dqn_grad_kernel<..., FUSE>: partial rows the last workgroup folds alone
+constexpr int DQN_FUSE_MAX_BLOCKS = 32;  // dqn_grad_kernel<..., FUSE>: partial rows the last workgroup folds alone (measured: a
+                                         // 2048-sample batch still gains 0.2 us per vec-step, a 4096-sample one loses 2)
 
 struct DqnApply {
     float* p;
@@ -67,181 +88,181 @@ __device__ __forceinline__ void publish(float* p, float v) {
     else *p = v;
 }
 
-// optimise! tail inside the gradient launch, run by the 256 threads of the workgroup that departed last: the arithmetic of
+// wave_sum (optim_device.h) with the same addition tree -- v[i] + v[i + o] for o = 32, 16, 8, 4, 2, 1 -- where the four steps inside
+// a 16-lane row are DPP row shifts instead of ds_bpermute round trips.  Lane 0 holds the total (the only lane block_sum reads).
+template <int N>
+__device__ __forceinline__ double dpp_row_shl_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x100 | N, 0xF, 0xF, true),
+                            __builtin_amdgcn_update_dpp(0, lo, 0x100 | N, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double wave_sum_lane0(double v) {
+    v += __shfl_down(v, 32, 64);
+    v += __shfl_down(v, 16, 64);
+    v += dpp_row_shl_f64<8>(v);
+    v += dpp_row_shl_f64<4>(v);
+    v += dpp_row_shl_f64<2>(v);
+    v += dpp_row_shl_f64<1>(v);
+    return v;
+}
+
+// optimise! tail inside the gradient launch, run by the 1024 threads of the workgroup that departed last: the arithmetic of
 // dqn_reduce_apply_kernel (= dqn_reduce_kernel, then clip_adam_kernel<4> of optim.hip) element for element and IN ITS ORDER --
 //   gradient   four groups of partial rows, ascending inside a group, then ((g0 + g1) + g2) + g3;
-//   norm       clip_adam_kernel<4> runs 1024 threads, thread t owning elements t + 1024 k: this thread stands in for the four
-//              virtual threads tid + 256 q (its wave for the virtual waves w + 4 q), sums each one's squares in Float64, reduces each
-//              virtual wave with the same shuffle tree and adds the sixteen wave sums in ascending order;
+//   norm       thread t owns elements t + 1024 k, sums their squares in Float64, block_sum (optim_device.h);
 //   Adam       elementwise --
-// so parameters, moments, gradient and loss are bit-identical to the two- and three-launch forms (tests/test_gpu_dqn.py).
-// l_x: >= 4096 floats of LDS (the weight records, dead by now); np <= 4096.
-__device__ __forceinline__ void dqn_fused_tail(const DqnArgs& g, float* l_x, double* scratch) {
+// so parameters, moments, gradient and loss are bit-identical to the two- and three-launch forms (tests/test_gpu_learners.py).
+// np <= 4096.
+__device__ __forceinline__ void dqn_fused_tail(const DqnArgs& g, double* scratch) {
+    constexpr int PER_THREAD = 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb = gridDim.x, np = g.np;
     const DqnApply& ap = g.ap;
     const int per = (nb + 3) / 4;
     const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
-    const bool single = np <= 1024;  // one chunk of 1024 elements (the 4 -> 128 -> 2 net: 898): its Adam operands are requested
-    float pr[4], mr[4], vr[4];       // up front and arrive under the partial rows
-    if (single) {
+    float pr[PER_THREAD], mr[PER_THREAD], vr[PER_THREAD], gr[PER_THREAD];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 256 * q;
-            pr[q] = i < np ? ap.p[i] : 0.0f;
-            mr[q] = i < np ? ap.m[i] : 0.0f;
-            vr[q] = i < np ? ap.v[i] : 0.0f;
-        }
+    for (int k = 0; k < PER_THREAD; ++k) {  // the Adam operands: requested first, they arrive under the partial rows
+        const int i = k * 1024 + tid;
+        const bool in = i < np;
+        pr[k] = in ? ap.p[i] : 0.0f;
+        mr[k] = in ? ap.m[i] : 0.0f;
+        vr[k] = in ? ap.v[i] : 0.0f;
     }
     float lp = 0.f;
     if (w == 1 && lane < nb) lp = __hip_atomic_load(g.loss_partials + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nb <= 64
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int k = 0; 1024 * k < np; ++k) {
-        // the partial rows of this thread's four elements: 4 elements x 4 groups x 4 rows = 64 independent device-scope loads per
-        // round trip (row index clamped instead of predicated: no branch between the loads; a + 0.0f == a for every a this sum can
-        // reach, since it starts from +0), added in dqn_reduce_kernel's order
-        float a4[4][4];
+    double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp) a4[q][grp] = 0.f;
-        for (int r0 = 0; r0 < per; r0 += 4) {
-            float v[4][4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = min(tid + 256 * q + 1024 * k, np - 1);
-#pragma unroll
-                for (int grp = 0; grp < 4; ++grp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int b = min(grp * per + r0 + r, nb - 1);
-                        v[q][grp][r] = __hip_atomic_load(g.partials + (int64_t)b * np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
+    for (int k = 0; k < PER_THREAD; ++k) {
+        gr[k] = 0.0f;
+        if (1024 * k < np) {  // (uniform)
+            // this element's partial rows: up to 4 groups x 4 rows of independent device-scope loads per round trip.  The row
+            // predicates are uniform (scalar branches around the loads); a skipped row adds +0.0f, the identity for every value
+            // this sum can reach (it starts from +0, so it is never -0)
+            const int i = k * 1024 + tid;
+            const bool in = i < np;
+            const float* col = g.partials + (in ? i : np - 1);
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r0 = 0; r0 < per; r0 += 4) {
+                float v[4][4];
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int b = grp * per + r0 + r;
-                        a4[q][grp] += (r0 + r < per && b < nb) ? v[q][grp][r] : 0.0f;
+                        v[grp][r] = 0.0f;
+                        if (r0 + r < per && b < nb)
+                            v[grp][r] = __hip_atomic_load(col + (int64_t)b * np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 256 * q + 1024 * k;
-            float x = 0.0f;
-            if (i < np) {
-                x = (((a4[q][0] + a4[q][1]) + a4[q][2]) + a4[q][3]) * ap.grad_scale;
-                l_x[i] = x;  // read back by this thread only
+                for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[grp] += v[grp][r];
             }
-            acc[q] += (double)x * (double)x;
+            gr[k] = in ? (((a4[0] + a4[1]) + a4[2]) + a4[3]) * ap.grad_scale : 0.0f;
         }
+        acc += (double)gr[k] * (double)gr[k];
     }
+    DQN_STAMP(8);
     if (w == 1 && g.loss != nullptr) {  // dqn_reduce_kernel's loss line: lane-strided, then the shuffle tree
         float a = 0.f + lp;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
         if (lane == 0) g.loss[0] = a * g.inv_b;
     }
+    {  // block_sum (optim_device.h) of 1024 threads, its tree and order
+        const double ws = wave_sum_lane0(acc);
+        if (lane == 0) scratch[w] = ws;
+        __syncthreads();
+        acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const double v = wave_sum(acc[q]);
-        if (lane == 0) scratch[w + 4 * q] = v;
+        for (int vw = 0; vw < 16; ++vw) acc += scratch[vw];
     }
-    __syncthreads();
-    double t = 0.0;
-    for (int vw = 0; vw < 16; ++vw) t += scratch[vw];
-    const float gn = (float)sqrt(t);
+    const float gn = (float)sqrt(acc);
+    DQN_STAMP(9);
     const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
-    for (int k = 0; 1024 * k < np; ++k) {
-        if (!single) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = tid + 256 * q + 1024 * k;
-                pr[q] = i < np ? ap.p[i] : 0.0f;
-                mr[q] = i < np ? ap.m[i] : 0.0f;
-                vr[q] = i < np ? ap.v[i] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 256 * q + 1024 * k;
-            if (i < np) {
-                const float x = l_x[i];
-                const float gi = (scale == 1.0f) ? x : x * scale;
-                adam1(pr[q], gi, mr[q], vr[q], ap.lr, ap.b1, ap.b2, ap.eps, c1, c2);
-                ap.p[i] = pr[q];
-                ap.m[i] = mr[q];
-                ap.v[i] = vr[q];
-                g.grad[i] = gi;
-            }
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = k * 1024 + tid;
+        if (i < np) {
+            const float gi = (scale == 1.0f) ? gr[k] : gr[k] * scale;
+            adam1(pr[k], gi, mr[k], vr[k], ap.lr, ap.b1, ap.b2, ap.eps, c1, c2);
+            ap.p[i] = pr[k];
+            ap.m[i] = mr[k];
+            ap.v[i] = vr[k];
+            g.grad[i] = gi;
         }
     }
     if (tid == 0) {
         if (ap.gn_out) ap.gn_out[0] = gn;
-        ap.beta_pow[0] *= ap.b1;  // every thread read beta_pow before the barrier above
+        ap.beta_pow[0] *= ap.b1;  // every thread read beta_pow before the block_sum barrier
         ap.beta_pow[1] *= ap.b2;
     }
 }
 
-// One workgroup = one 64-sample tile (a 512-sample batch is 8 workgroups, so the kernel is a latency chain, not a
-// throughput problem -- measured 19.5 us per launch for the first version, which walked the hidden units with
-// dependent global loads):
-//   phase 0   64 lanes draw their sample (BatchSampler Philox draw or explicit index), issue the 11 scattered ring
-//             loads and keep them in registers; meanwhile ALL lanes stage both networks' weights into LDS
-//             (component-major: a hidden unit's weights are broadcast reads later) -- one overlapped round trip
-//   phase 1a  lane = sample, wave w walks its quarter of the hidden units for Q(s) and Q_target(s') from LDS
-//   phase 1b  64 lanes: TD target, Huber loss, dL/dq
-//   phase 2   lane = hidden unit (weights in registers), samples stream from LDS as broadcast reads; when 2 h <= 256
-//             the two halves of the tile go to two lane groups and are added in a fixed order at the end
-// Gradient partials per workgroup, summed in a fixed order by dqn_reduce[_apply]_kernel: run-to-run deterministic.
+// One workgroup of 1024 threads = one 64-sample tile (a 512-sample batch is 8 workgroups: the kernel is a latency chain, not a
+// throughput problem -- every phase is a few hundred dependent instructions between two LDS round trips).  Round 5 rebuilt it
+// around the 16-lane DPP row: a sum over sixteen lanes of a row is four VALU instructions (group_sum_dpp), where the round-1..4
+// form (256 threads; partial sums per wave in LDS, a 64-lane TD line that added them up, lane groups combined through LDS) paid an
+// LDS round trip per partial -- stamped timeline in profiles/r05_dqn_vec_step.md:
+//   phase 0   64 lanes draw their sample (BatchSampler Philox draw or explicit index), request its 64-byte record and keep it in
+//             registers; meanwhile ALL lanes stage both networks' weights into LDS (one record per hidden unit) -- one overlapped
+//             round trip
+//   phase 1   row = sample (wave w owns samples 4 w .. 4 w + 3), lane c of the row walks hidden units c, c + 16, ... for Q(s) and
+//             Q_target(s'); row sums by DPP; then the TD target, Huber loss and dL/dq of the sample in the same lanes
+//   phase 2   row = hidden unit (wave w owns units 4 w + u + 64 p), lane c of the row walks samples c, c + 16, c + 32, c + 48 of the
+//             tile; the weight-gradient sums stay per lane over ALL tiles of the workgroup and meet in one DPP row sum at the end
+// Gradient partials per workgroup, summed in a fixed order by dqn_reduce[_apply]_kernel / dqn_fused_tail: run-to-run deterministic.
 //
 // FUSE (round 5): the whole optimise! in ONE launch -- every workgroup publishes its partial row with device-scope stores and
 // counts itself out; the workgroup that departs last runs dqn_fused_tail (reduce -> clip -> Adam).  Host: nb <= DQN_FUSE_MAX_BLOCKS.
-template <int NS, int ACT, bool FUSE>
-__global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
-    // LDS: everything a later phase reads as a unit is ONE 16-byte vector (a broadcast or a conflict-free b128 read):
+// UPL: hidden units per lane in phase 2 = ceil(h / 64) rounded up to 2 or 4 (a template parameter: its accumulators are registers).
+template <int NS, int ACT, bool FUSE, int UPL>
+__global__ __launch_bounds__(DTHREADS) void dqn_grad_kernel(DqnArgs g) {
+    // LDS: everything a later phase reads as a unit is ONE 16-byte vector:
     //   l_rec[net][j] = {W1[j, 0..3]}, {b1[j], W2[0..2, j]}, {W2[3, j], -, -, -}   (rows beyond NS / na are zeros)
     //   l_s4 / l_sn4 [sample] = state / next state, l_dL4[sample] = dL/dq
     constexpr int HMAX = 256;
-    static_assert(NS <= 4 && MAXO == 4, "record layout");
+    static_assert(NS <= 4 && MAXO == 4 && DWAVES * 4 == DTILE, "record layout / one row per sample");
+    __shared__ float4 l_rec[2][HMAX][3];
     __shared__ float4 l_s4[DTILE], l_sn4[DTILE], l_dL4[DTILE];
     __shared__ float l_r[DTILE];
     __shared__ int32_t l_a[DTILE];
     __shared__ uint8_t l_t[DTILE];
-    __shared__ float l_part[4][2 * MAXO][DTILE];
-    __shared__ float4 l_rec[2][HMAX][3];
+    __shared__ float l_fin[MAXO + 1][DTILE];
     __shared__ double l_scratch[16];
     __shared__ int l_last;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = g.h, na = g.na, hq = h >> 2;
+    const int row = lane >> 4, c = lane & 15;
+    const int h = g.h, na = g.na;
     const float* b2 = g.params + h * NS + h + na * h;
     const float* tb2 = g.tparams + h * NS + h + na * h;
+    const int smp = 4 * w + row;  // phase 1: this row's sample of the tile
 
-    // phase-2 ownership: lane group `half` of hidden unit j
-    const int halves = (2 * h <= 256) ? 2 : 1;
-    const int half = tid / h;
-    const bool owner = half < halves;
-    const int j = owner ? tid - half * h : 0;
-    const int s_lo = (halves == 2) ? half * (DTILE / 2) : 0;
-    const int s_hi = (halves == 2) ? s_lo + DTILE / 2 : DTILE;
-
-    float gw1[NS], gw2[MAXO], gb1 = 0.f;
+    float gw1[UPL][NS], gw2[UPL][MAXO], gb1[UPL];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) gw1[k] = 0.f;
+    for (int p = 0; p < UPL; ++p) {
+        gb1[p] = 0.f;
 #pragma unroll
-    for (int o = 0; o < MAXO; ++o) gw2[o] = 0.f;
-    float gb2[MAXO] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NS; ++k) gw1[p][k] = 0.f;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) gw2[p][o] = 0.f;
+    }
+    float gb2[MAXO] = {0.f, 0.f, 0.f, 0.f};  // (every lane of a row carries its sample's sums; lane c == 0 hands them over)
     float s_loss = 0.f;
-    float rw1[NS], rw2[MAXO], rb1 = 0.f;
     bool staged = false;
 
+    DQN_STAMP(0);
     for (int tile = blockIdx.x; tile < g.num_tiles; tile += gridDim.x) {
         // ---- phase 0: gather into registers ----
+        float bq[MAXO], btq[MAXO];  // the output biases of both nets: requested first, in flight across the staging and the barrier
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            bq[o] = (o < na) ? b2[o] : 0.f;
+            btq[o] = (o < na) ? tb2[o] : 0.f;
+        }
         float gs[NS], gsn[NS], gr = 0.f;
         int32_t ga = 0;
         uint8_t gt = 0;
@@ -267,7 +288,8 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             gt = (uint8_t)rt.t;
         }
         if (!staged) {  // both networks -> LDS, while the gather is in flight
-            for (int q = tid; q < 2 * h; q += 256) {
+            staged = true;
+            for (int q = tid; q < 2 * h; q += DTHREADS) {
                 const int net = q >= h ? 1 : 0, u = q - net * h;
                 const float* P = net ? g.tparams : g.params;
                 float w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -295,25 +317,17 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
             l_t[tid] = gt;
         }
         __syncthreads();
-        if (!staged) {
-            staged = true;
-            const float4 r0 = l_rec[0][j][0], r1 = l_rec[0][j][1], r2 = l_rec[0][j][2];
-            const float t1[4] = {r0.x, r0.y, r0.z, r0.w};
-#pragma unroll
-            for (int k = 0; k < NS; ++k) rw1[k] = t1[k];
-            rb1 = r1.x;
-            rw2[0] = r1.y;
-            rw2[1] = r1.z;
-            rw2[2] = r1.w;
-            rw2[3] = r2.x;
-        }
-        // ---- phase 1a ----
+        DQN_STAMP(1);
+        // ---- phase 1: Q(s), Q_target(s') of sample `smp`, then its TD line ----
         {
-            const float4 xs = l_s4[lane], xns = l_sn4[lane];
+            const float4 xs = l_s4[smp], xns = l_sn4[smp];
+            const float sr = l_r[smp];
+            const int a = l_a[smp];
+            const float cont = l_t[smp] ? 0.f : 1.f;
             const float x[4] = {xs.x, xs.y, xs.z, xs.w}, xn[4] = {xns.x, xns.y, xns.z, xns.w};
             float acc[MAXO] = {0.f, 0.f, 0.f, 0.f}, acn[MAXO] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int jj = w * hq; jj < (w + 1) * hq; ++jj) {
+#pragma unroll 2
+            for (int jj = c; jj < h; jj += 16) {
                 const float4 a0 = l_rec[0][jj][0], a1 = l_rec[0][jj][1], c0 = l_rec[1][jj][0], c1 = l_rec[1][jj][1];
                 const float wa[4] = {a0.x, a0.y, a0.z, a0.w}, wc[4] = {c0.x, c0.y, c0.z, c0.w};
                 float z = a1.x, zn = c1.x;
@@ -323,60 +337,51 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                     zn = fmaf(wc[k], xn[k], zn);
                 }
                 const float hv = act_fwd_t<ACT>(z), hn = act_fwd_t<ACT>(zn);
-                acc[0] = fmaf(a1.y, hv, acc[0]);  // rows o >= na are staged as zeros
+                acc[0] = fmaf(a1.y, hv, acc[0]);
                 acn[0] = fmaf(c1.y, hn, acn[0]);
-                acc[1] = fmaf(a1.z, hv, acc[1]);
+                acc[1] = fmaf(a1.z, hv, acc[1]);  // (rows o >= na are staged as zeros)
                 acn[1] = fmaf(c1.z, hn, acn[1]);
-                acc[2] = fmaf(a1.w, hv, acc[2]);
-                acn[2] = fmaf(c1.w, hn, acn[2]);
+                if (na > 2) {  // (uniform)
+                    acc[2] = fmaf(a1.w, hv, acc[2]);
+                    acn[2] = fmaf(c1.w, hn, acn[2]);
+                }
                 if (na == 4) {
                     acc[3] = fmaf(l_rec[0][jj][2].x, hv, acc[3]);
                     acn[3] = fmaf(l_rec[1][jj][2].x, hn, acn[3]);
                 }
             }
-#pragma unroll
-            for (int o = 0; o < MAXO; ++o) {
-                l_part[w][o][lane] = acc[o];
-                l_part[w][MAXO + o][lane] = acn[o];
-            }
-        }
-        __syncthreads();
-        // ---- phase 1b ----
-        if (tid < DTILE) {
-            const int s = tid;
-            bool valid = ((int64_t)tile * DTILE + s) < g.batch;
             float q[MAXO], qn[MAXO];
 #pragma unroll
             for (int o = 0; o < MAXO; ++o) {
-                q[o] = (((l_part[0][o][s] + l_part[1][o][s]) + l_part[2][o][s]) + l_part[3][o][s]) +
-                       ((o < na) ? b2[o] : 0.f);
-                qn[o] = (((l_part[0][MAXO + o][s] + l_part[1][MAXO + o][s]) + l_part[2][MAXO + o][s]) +
-                         l_part[3][MAXO + o][s]) +
-                        ((o < na) ? tb2[o] : 0.f);
+                q[o] = 0.f, qn[o] = 0.f;
+                if (o < na) {  // (uniform)
+                    q[o] = group_sum_dpp<16>(acc[o]) + bq[o];
+                    qn[o] = group_sum_dpp<16>(acn[o]) + btq[o];
+                }
             }
+            const int64_t b = (int64_t)tile * DTILE + smp;
+            const bool valid = b < g.batch;
             float mx = qn[0];
             for (int k = 1; k < na; ++k) mx = fmaxf(mx, qn[k]);
-            float cont = l_t[s] ? 0.f : 1.f;
-            float G = l_r[s] + g.gamma * cont * mx;
-            int a = l_a[s];
+            const float G = sr + g.gamma * cont * mx;
             float qa = 0.f;
             for (int k = 0; k < na; ++k)
                 if (k == a) qa = q[k];
-            float d = qa - G;
-            float e = fabsf(d);
+            const float d = qa - G;
+            const float e = fabsf(d);
             float l = (e < g.delta) ? (e * e) * 0.5f : g.delta * (e - 0.5f * g.delta);
             float gi = (e < g.delta) ? d : (d > 0.f ? g.delta : (d < 0.f ? -g.delta : 0.f));
             gi *= g.inv_b;
             if (valid && g.isw) {  // PrioritizedDQN: the weighted batch loss  mean(w .* huber(td))
-                const float wis = g.isw[(int64_t)tile * DTILE + s];
+                const float wis = g.isw[b];
                 gi *= wis;
                 l *= wis;
             }
             if (!valid) {
                 gi = 0.f;
                 l = 0.f;
-            } else if (g.td_out) {
-                g.td_out[(int64_t)tile * DTILE + s] = e;
+            } else if (g.td_out && c == 0) {
+                g.td_out[b] = e;
             }
             s_loss += l;
             float dl[MAXO];
@@ -385,89 +390,99 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(DqnArgs g) {
                 dl[o] = (o == a) ? gi : 0.f;
                 gb2[o] += dl[o];
             }
-            l_dL4[s] = make_float4(dl[0], dl[1], dl[2], dl[3]);
-        }
-        __syncthreads();
-        // ---- phase 2 ----
-        if (owner) {
-#pragma unroll 4
-            for (int s = s_lo; s < s_hi; ++s) {
-                const float4 xs = l_s4[s], d4 = l_dL4[s];
-                const float x[4] = {xs.x, xs.y, xs.z, xs.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-                float z = rb1;
+            if (c == 0) {
+                l_dL4[smp] = make_float4(dl[0], dl[1], dl[2], dl[3]);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) z = fmaf(rw1[k], x[k], z);
-                float hv = act_fwd_t<ACT>(z);
-                float dh = 0.f;
-#pragma unroll
-                for (int o = 0; o < MAXO; ++o) {
-                    const float d = dd[o];
-                    gw2[o] = fmaf(d, hv, gw2[o]);
-                    dh = fmaf(d, rw2[o], dh);
-                }
-                float dz = dh * act_bwd_t<ACT>(z, hv);
-                gb1 += dz;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) gw1[k] = fmaf(dz, x[k], gw1[k]);
+                for (int o = 0; o < MAXO; ++o) l_fin[o][smp] = gb2[o];  // running sums over this workgroup's tiles: complete after
+                l_fin[MAXO][smp] = s_loss;                              // the last one, read by wave 0 behind the tile loop
             }
         }
         __syncthreads();
-    }
-    // second lane group -> LDS -> first lane group (fixed order: first + second); l_rec[1] is free now
-    if (halves == 2) {
-        if (owner && half == 1) {
-            float t1[4] = {0.f, 0.f, 0.f, 0.f};
+        DQN_STAMP(3);
+        // ---- phase 2: weight gradients of units 4 w + row + 64 p over samples c, c + 16, c + 32, c + 48 ----
+        {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) t1[k] = gw1[k];
-            l_rec[1][j][0] = make_float4(t1[0], t1[1], t1[2], t1[3]);
-            l_rec[1][j][1] = make_float4(gb1, gw2[0], gw2[1], gw2[2]);
-            l_rec[1][j][2] = make_float4(gw2[3], 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        if (owner && half == 0) {
-            const float4 r0 = l_rec[1][j][0], r1 = l_rec[1][j][1], r2 = l_rec[1][j][2];
-            const float t1[4] = {r0.x, r0.y, r0.z, r0.w};
+            for (int p = 0; p < UPL; ++p) {
+                const int j = 4 * w + row + 64 * p;
+                if (64 * p < h && j < h) {
+                    const float4 r0 = l_rec[0][j][0], r1 = l_rec[0][j][1], r2 = l_rec[0][j][2];
+                    const float rw1[4] = {r0.x, r0.y, r0.z, r0.w}, rw2[4] = {r1.y, r1.z, r1.w, r2.x};
+                    const float rb1 = r1.x;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) gw1[k] += t1[k];
-            gb1 += r1.x;
-            gw2[0] += r1.y;
-            gw2[1] += r1.z;
-            gw2[2] += r1.w;
-            gw2[3] += r2.x;
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 xs = l_s4[c + 16 * i], d4 = l_dL4[c + 16 * i];
+                        const float x[4] = {xs.x, xs.y, xs.z, xs.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                        float z = rb1;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) z = fmaf(rw1[k], x[k], z);
+                        const float hv = act_fwd_t<ACT>(z);
+                        float dh = 0.f;
+#pragma unroll
+                        for (int o = 0; o < MAXO; ++o) {
+                            const float d = dd[o];
+                            gw2[p][o] = fmaf(d, hv, gw2[p][o]);
+                            dh = fmaf(d, rw2[o], dh);
+                        }
+                        const float dz = dh * act_bwd_t<ACT>(z, hv);
+                        gb1[p] += dz;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) gw1[p][k] = fmaf(dz, x[k], gw1[p][k]);
+                    }
+                }
+            }
         }
+        __syncthreads();  // the next tile's gather rewrites l_s4 / l_dL4
     }
+    DQN_STAMP(4);
+    // the sixteen sample slices of a unit meet in its row; lane c == 0 publishes
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
-    if (owner && half == 0) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) publish<FUSE>(out + j + h * k, gw1[k]);
-        publish<FUSE>(out + h * NS + j, gb1);
+    for (int p = 0; p < UPL; ++p) {
+        const int j = 4 * w + row + 64 * p;
+        if (64 * p < h) {  // (uniform: the DPP sums run with whole rows)
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-            if (o < na) publish<FUSE>(out + h * NS + h + o + na * j, gw2[o]);
-    }
-    if (tid < DTILE) {
+            for (int k = 0; k < NS; ++k) gw1[p][k] = group_sum_dpp<16>(gw1[p][k]);
+            gb1[p] = group_sum_dpp<16>(gb1[p]);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
+            for (int o = 0; o < MAXO; ++o)
+                if (o < na) gw2[p][o] = group_sum_dpp<16>(gw2[p][o]);
+            if (c == 0 && j < h) {
 #pragma unroll
-            for (int o = 0; o < MAXO; ++o) gb2[o] += __shfl_down(gb2[o], off, 64);
-            s_loss += __shfl_down(s_loss, off, 64);
+                for (int k = 0; k < NS; ++k) publish<FUSE>(out + j + h * k, gw1[p][k]);
+                publish<FUSE>(out + h * NS + j, gb1[p]);
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o)
+                    if (o < na) publish<FUSE>(out + h * NS + h + o + na * j, gw2[p][o]);
+            }
         }
+    }
+    // db2 and the loss: one slot per sample of the tile -> wave 0 (fixed order)
+    if (tid < DTILE) {  // wave 0
+        float f[MAXO + 1];
+#pragma unroll
+        for (int o = 0; o <= MAXO; ++o) f[o] = wave_sum_f32(l_fin[o][tid]);
         if (tid == 0) {
-            for (int o = 0; o < na; ++o) publish<FUSE>(out + h * NS + h + na * h + o, gb2[o]);
-            publish<FUSE>(g.loss_partials + blockIdx.x, s_loss);
+            for (int o = 0; o < na; ++o) publish<FUSE>(out + h * NS + h + na * h + o, f[o]);
+            publish<FUSE>(g.loss_partials + blockIdx.x, f[MAXO]);
         }
     }
+    DQN_STAMP(5);
     if constexpr (FUSE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's row stores have reached the L2 / fabric
         __syncthreads();
+        DQN_STAMP(6);
         if (tid == 0) {
             const unsigned int prev = __hip_atomic_fetch_add(g.ap.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             l_last = (prev == gridDim.x - 1) ? 1 : 0;
             if (l_last) __hip_atomic_store(g.ap.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
         }
         __syncthreads();
+        DQN_STAMP(7);
         if (!l_last) return;
-        dqn_fused_tail(g, reinterpret_cast<float*>(&l_rec[0][0][0]), l_scratch);
+        dqn_fused_tail(g, l_scratch);
+        DQN_STAMP(11);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DQN_STAMP(12);
     }
 }
 
@@ -669,6 +684,13 @@ using namespace rlhip;
 
 extern "C" {
 
+#ifdef RLHIP_DQN_TIMING
+int32_t rlhip_debug_dqn_stamps(long long* out1024) {
+    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_dqn_stamps), sizeof(long long) * 64 * 16));
+    return RLHIP_OK;
+}
+#endif
+
 int64_t rlhip_dqn_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {
     (void)batch;
     int64_t np = mlp2_nparams(ns, h, na);
@@ -715,7 +737,7 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
     g.partials = (float*)workspace;
     g.loss_partials = g.partials + (int64_t)DQN_MAX_BLOCKS * np;
     hipStream_t s = as_stream(stream);
-    // one launch for the whole optimise! while a single workgroup can fold the partial rows quickly (<= 64 rows = a 4096-sample
+    // one launch for the whole optimise! while a single workgroup can fold the partial rows quickly (<= 32 rows = a 2048-sample
     // batch); beyond that the tail stays its own launch, 64 parameters per workgroup
     const bool fuse = apply != nullptr && nb <= DQN_FUSE_MAX_BLOCKS && !RLHIP_ENV_FLAG("RLHIP_DQN_NO_FUSE");
     if (fuse) {
@@ -724,15 +746,21 @@ static int32_t dqn_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32_
         g.grad = grad_out;
         g.loss = loss_out;
     }
-#define LAUNCH_DG(NS_, ACT_)                                                                              \
-    do {                                                                                                  \
-        if (fuse) hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_, true>), dim3(nb), dim3(256), 0, s, g);   \
-        else hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_, false>), dim3(nb), dim3(256), 0, s, g);       \
+#define LAUNCH_DG4(NS_, ACT_, FUSE_)                                                                                    \
+    do {                                                                                                                 \
+        if (h <= 128) hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_, FUSE_, 2>), dim3(nb), dim3(DTHREADS), 0, s, g);     \
+        else hipLaunchKernelGGL((dqn_grad_kernel<NS_, ACT_, FUSE_, 4>), dim3(nb), dim3(DTHREADS), 0, s, g);              \
+    } while (0)
+#define LAUNCH_DG(NS_, ACT_)                     \
+    do {                                         \
+        if (fuse) LAUNCH_DG4(NS_, ACT_, true);   \
+        else LAUNCH_DG4(NS_, ACT_, false);       \
     } while (0)
     if (ns == 4) { if (act == 0) LAUNCH_DG(4, 0); else LAUNCH_DG(4, 1); }
     else if (ns == 3) { if (act == 0) LAUNCH_DG(3, 0); else LAUNCH_DG(3, 1); }
     else { if (act == 0) LAUNCH_DG(2, 0); else LAUNCH_DG(2, 1); }
 #undef LAUNCH_DG
+#undef LAUNCH_DG4
     if (fuse) {
         RLHIP_LAUNCH_CHECK();
         return RLHIP_OK;

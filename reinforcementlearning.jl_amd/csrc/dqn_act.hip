@@ -21,6 +21,20 @@ struct ActRing {
     int64_t prev_slot;   // the slot before it: its record is completed with (a, r, t, s')
 };
 
+#ifdef RLHIP_DQN_TIMING  // start / end of workgroup 0, thread 0 (tools/dqn_timeline.py)
+__device__ long long g_act_stamps[4];
+#define ACT_STAMP(k)                                                                 \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_act_stamps[k] = wall_clock64();   \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+    } while (0)
+#else
+#define ACT_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
+
 struct RegQa {
     const float* q;
     __device__ __forceinline__ float operator()(int k) const { return q[k]; }
@@ -34,6 +48,7 @@ __global__ __launch_bounds__(256, 1) void dqn_act_kernel(P p, EnvArrays<float> s
                                                          float* __restrict__ obs_out, float* __restrict__ last_obs) {
     constexpr int NS = P::ODIM;
     constexpr int HPL = H / L;
+    ACT_STAMP(0);
     int64_t gl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t env = gl / L;
     const int sub = (int)(gl % L);
@@ -79,6 +94,7 @@ __global__ __launch_bounds__(256, 1) void dqn_act_kernel(P p, EnvArrays<float> s
 #pragma unroll
     for (int k = NS; k < 4; ++k) xn[k] = 0.f;
     ring_push_transition(rb.rec, rb.state_slot, rb.prev_slot, n, env, xn, a, r, d ? 1u : 0u);
+    ACT_STAMP(1);
 }
 
 template <class P>
@@ -191,6 +207,13 @@ static int32_t act_push_impl(const typename P::cfg_t* cfg, const rlhip_env_state
 }  // namespace rlhip
 
 using namespace rlhip;
+
+#ifdef RLHIP_DQN_TIMING
+extern "C" int32_t rlhip_debug_act_stamps(long long* out4) {
+    RLHIP_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(rlhip::g_act_stamps), sizeof(long long) * 4));
+    return RLHIP_OK;
+}
+#endif
 
 extern "C" int32_t rlhip_dqn_act_supported(int32_t kind, int64_t n, int64_t h) {
     return (kind >= 0 && kind <= 2 && (h == 256 || h == 128 || h == 64) && n >= 1 && n * 16 <= ((int64_t)1 << 22)) ? 1 : 0;

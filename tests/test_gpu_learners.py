@@ -456,10 +456,11 @@ def test_rollout_writes_gae_and_returns_bit_identical_to_the_scan(kind, layers, 
 
 @pytest.mark.parametrize("ns,h,na,clip,batch", [(4, 64, 2, 0.5, 700), (4, 64, 2, 0.0, 700), (2, 100, 3, 1e6, 700), (3, 256, 3, 0.05, 700),
                                                  (4, 252, 4, 0.5, 700), (4, 256, 4, 0.5, 700), (4, 128, 2, 0.5, 32), (4, 128, 2, 0.5, 512),
-                                                 (4, 128, 2, 0.5, 4096), (4, 256, 4, 0.5, 4096), (4, 128, 2, 0.5, 4097), (3, 256, 3, 0.5, 40000)])
+                                                 (4, 128, 2, 0.5, 2048), (4, 256, 4, 0.5, 2048), (4, 128, 2, 0.5, 2049), (4, 128, 2, 0.5, 4096),
+                                                 (3, 256, 3, 0.5, 40000), (2, 8, 1, 0.5, 100), (4, 200, 2, 0.5, 300)])
 def test_dqn_update_is_bit_identical_to_grad_then_clip_adam(ns, h, na, clip, batch):
     """rlhip_dqn_update_f32 == rlhip_dqn_grad_f32 followed by rlhip_clip_adam_f32, bit for bit, over repeated calls (the departure
-    counter re-arms itself).  Up to 64 tiles (4096 samples) the whole optimise! is ONE launch (dqn_grad_kernel<..., FUSE>: the
+    counter re-arms itself).  Up to 32 tiles (2048 samples) the whole optimise! is ONE launch (dqn_grad_kernel<..., FUSE>: the
     workgroup that departs last folds the partial rows, clips, steps); beyond that the tail is dqn_reduce_apply_kernel."""
     import rlhip
     from rlhip import dqn, ops
