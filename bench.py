@@ -395,7 +395,7 @@ def roofline_extras(torch, rlhip, hbm_only=False):
     out["dqn_cartpole_4096env"]["fused_vec_step"] = {
         "env_steps_per_sec": round(n * steps_f / el, 1), "updates_per_sec": round(steps_f / el, 1),
         "ms_per_vec_step": round(el / steps_f * 1e3, 4),
-        "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then the gradient, then reduce + clip + Adam (3 launches per vec-step) -- bit-identical to the per-step protocol"}
+        "note": "rlhip_dqn_vec_step_f32: ONE C-ABI call per vec-step; plan! + act! + push! in one launch (dqn_act.hip), then the whole optimise! (gradient; the workgroup that departs last reduces, clips, steps) in a second one -- 2 launches per vec-step up to 2048 samples, 3 beyond; bit-identical to the per-step protocol"}
     del agent, policy, learner, net, env
     # the same two loops from a COMPILED host (tests/abi_host/abi_host.c `time`: no PyTorch, no interpreter -- the position of the
     # Julia glue's ccalls): what the per-stage protocol costs when the host is not Python

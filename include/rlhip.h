@@ -810,9 +810,10 @@ int32_t rlhip_dqn_grad_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int
                            float gamma, float huber_delta, uint64_t seed, uint32_t draw_ctr,
                            void* workspace, float* grad_out, float* loss_out,
                            rlhip_stream_t stream);
-/* optimise!(learner, batch) complete -- gradient, then reduce + clip-by-global-norm + Adam -- in two launches;
+/* optimise!(learner, batch) complete -- gradient, then reduce + clip-by-global-norm + Adam -- in ONE launch up to 2048
+ * samples (the gradient workgroup that departs last folds the partial rows, clips and steps), in two launches beyond;
  * bit-identical to rlhip_dqn_grad_f32 followed by rlhip_clip_adam_f32 (which is what runs for > 4096 parameters).
- * The last 64 bytes of `workspace` are its arrival counters: zero before the first call, re-armed by every call. */
+ * The last 64 bytes of `workspace` are its departure counters: zero before the first call, re-armed by every call. */
 int32_t rlhip_dqn_update_f32(const rlhip_ring* rb_host, int64_t h, int64_t na, int32_t act, float* params,
                              const float* target_params, int64_t batch, float gamma, float huber_delta,
                              uint64_t seed, uint32_t draw_ctr, void* workspace, float* grad_out, float* loss_out,

@@ -26,7 +26,7 @@ def dqn_workspace(ns, h, na, batch, device="cuda"):
 
 def dqn_update(traces, h, na, act, params, target_params, batch, gamma, delta, seed, draw_ctr, workspace, grad, loss, m, v,
                beta_pow, grad_scale, max_grad_norm, lr, beta1, beta2, eps, gn=None):
-    """optimise!(learner, batch) in two launches: gradient partials, then reduce + clip + Adam (in place)."""
+    """optimise!(learner, batch) in place: ONE launch up to 2048 samples (gradient; the workgroup that departs last reduces, clips, steps), two beyond."""
     call("rlhip_dqn_update_f32", C.byref(traces.rb), h, na, act, ptr(params), ptr(target_params), batch, gamma, delta,
          seed, draw_ctr, ptr(workspace), ptr(grad), ptr(loss), ptr(m), ptr(v), ptr(beta_pow), grad_scale, max_grad_norm,
          lr, beta1, beta2, eps, ptr(gn) if gn is not None else None, stream_ptr())
