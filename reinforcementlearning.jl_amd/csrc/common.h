@@ -202,6 +202,41 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // all 64 lanes
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Float64 cross-lane sums with the SAME addition trees as the __shfl loops they replace (bit-identical results), where the four
+// steps inside a 16-lane row are DPP moves of the two halves of the double instead of ds_bpermute round trips (each shuffled double
+// is two ds_bpermute_b32 with a dependent wait: ~1 us per six-step chain in the optimiser tails, profiles/r05_dqn_vec_step.md).
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_mov_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+// v += __shfl_down(v, o) for o = 32, 16, 8, 4, 2, 1: the total is valid in LANE 0 only (the lanes an out-of-row shift leaves alone
+// hold partial garbage, as the upper lanes of the shuffle loop do)
+__device__ __forceinline__ double wave_sum_down_f64_lane0(double v) {
+    v += __shfl_down(v, 32, 64);
+    v += __shfl_down(v, 16, 64);
+    v += dpp_mov_f64<0x108, 0xF>(v, v);  // row_shl:8  lane i <- lane i + 8
+    v += dpp_mov_f64<0x104, 0xF>(v, v);  // row_shl:4
+    v += dpp_mov_f64<0x102, 0xF>(v, v);  // row_shl:2
+    v += dpp_mov_f64<0x101, 0xF>(v, v);  // row_shl:1
+    return v;
+}
+// v += __shfl_xor(v, o) for o = 32, 16, 8, 4, 2, 1: every lane ends with the total
+__device__ __forceinline__ double wave_sum_xor_f64(double v) {
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += dpp_mov_f64<0x128, 0xF>(v, v);  // row_ror:8  lane i <- lane (i + 8) % 16 = i ^ 8
+    {
+        double t = dpp_mov_f64<0x104, 0x5>(v, v);  // banks 0, 2 (lanes 0-3, 8-11 of a row) <- lane i + 4
+        t = dpp_mov_f64<0x114, 0xA>(t, v);         // banks 1, 3 <- lane i - 4 (row_shr:4): t[i] = v[i ^ 4]
+        v += t;
+    }
+    v += dpp_mov_f64<0x4E, 0xF>(v, v);  // quad_perm [2,3,0,1] = i ^ 2
+    v += dpp_mov_f64<0xB1, 0xF>(v, v);  // quad_perm [1,0,3,2] = i ^ 1
+    return v;
+}
+
 // 16-byte non-temporal accesses for pure streaming kernels (every byte touched once, working set >> caches)
 typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ nt_u32x4 nt_load16(const void* p) {

@@ -88,24 +88,6 @@ __device__ __forceinline__ void publish(float* p, float v) {
     else *p = v;
 }
 
-// wave_sum (optim_device.h) with the same addition tree -- v[i] + v[i + o] for o = 32, 16, 8, 4, 2, 1 -- where the four steps inside
-// a 16-lane row are DPP row shifts instead of ds_bpermute round trips.  Lane 0 holds the total (the only lane block_sum reads).
-template <int N>
-__device__ __forceinline__ double dpp_row_shl_f64(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x100 | N, 0xF, 0xF, true),
-                            __builtin_amdgcn_update_dpp(0, lo, 0x100 | N, 0xF, 0xF, true));
-}
-__device__ __forceinline__ double wave_sum_lane0(double v) {
-    v += __shfl_down(v, 32, 64);
-    v += __shfl_down(v, 16, 64);
-    v += dpp_row_shl_f64<8>(v);
-    v += dpp_row_shl_f64<4>(v);
-    v += dpp_row_shl_f64<2>(v);
-    v += dpp_row_shl_f64<1>(v);
-    return v;
-}
-
 // optimise! tail inside the gradient launch, run by the 1024 threads of the workgroup that departed last: the arithmetic of
 // dqn_reduce_apply_kernel (= dqn_reduce_kernel, then clip_adam_kernel<4> of optim.hip) element for element and IN ITS ORDER --
 //   gradient   four groups of partial rows, ascending inside a group, then ((g0 + g1) + g2) + g3;
@@ -171,7 +153,7 @@ __device__ __forceinline__ void dqn_fused_tail(const DqnArgs& g, double* scratch
         if (lane == 0) g.loss[0] = a * g.inv_b;
     }
     {  // block_sum (optim_device.h) of 1024 threads, its tree and order
-        const double ws = wave_sum_lane0(acc);
+        const double ws = wave_sum_down_f64_lane0(acc);  // wave_sum's tree, in-row steps on DPP (common.h)
         if (lane == 0) scratch[w] = ws;
         __syncthreads();
         acc = 0.0;

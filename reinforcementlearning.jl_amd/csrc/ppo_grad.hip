@@ -315,8 +315,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
         // after the next exchange; the host sees the status word (rlhip_comm_check)
         if (fail) gx = __builtin_nanf("");
         double sq = (double)gx * (double)gx;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
+        sq = wave_sum_down_f64_lane0(sq);  // (the __shfl_down tree, in-row steps on DPP: common.h)
         // the rank-local exchange of the sums of squares: like APPLY_GRID, each partial is its own arrival flag -- two 8-byte
         // {epoch, half of the double} granules in their own part of the sumsq area, polled directly by every workgroup.
         // The epoch is a WORKSPACE-resident word (counter[4] = launches of this variant on this workspace so far; advanced by
@@ -343,8 +342,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             }
             part += __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        part = wave_sum_xor_f64(part);  // (the __shfl_xor butterfly, in-row steps on DPP: common.h)
         const float gn = (float)sqrt(part);
         const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
         if (own) {
@@ -377,8 +375,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
     // per-block partial sum of squares (threads 0..RP-1 of wave 0 hold this block's gradient values)
     if (wv == 0) {
         double sq = (grp == 0) ? (double)gsum * (double)gsum : 0.0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_down(sq, off, 64);
+        sq = wave_sum_down_f64_lane0(sq);  // (the __shfl_down tree, in-row steps on DPP: common.h)
         if (lane == 0) {
             if (APPLY == APPLY_GRID) {
                 // the partial IS its own arrival flag: two 8-byte {epoch, half of the double} granules, write-through
@@ -423,8 +420,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
             part += __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
         }
         if (ap.dbg) ts[4] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        part = wave_sum_xor_f64(part);  // (the __shfl_xor butterfly, in-row steps on DPP: common.h)
         const float gn = (float)sqrt(part);
         const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
         if (own) {
@@ -475,8 +471,7 @@ __global__ __launch_bounds__(1024) void reduce_apply_kernel(const float* __restr
     double part = 0.0;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x)
         part += __hip_atomic_load(ap.sumsq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+    part = wave_sum_down_f64_lane0(part);
     if (lane == 0) l_d[wv] = part;
     __syncthreads();
     double tot = 0.0;
