@@ -642,22 +642,16 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
             l = 0.f;
         }
         if (valid && g.td_out) g.td_out[b] = e;
-        float red[MAXO + 1];
+        // db3 and the loss stay per lane (= per row slot of the tile) over ALL tiles of this workgroup and meet once behind the
+        // tile loop: the per-tile form cost 25 ds_bpermute round trips in the one wave every other wave waits for (0.7 of the
+        // tile's 6.6 us, profiles/r05_tile_budget.md section 2)
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) {
             float dl = (o == a) ? gi : 0.f;
             l_dq[o * G32 + s] = dl;
-            red[o] = dl;
+            acc_b3[o] += dl;
         }
-        red[MAXO] = l;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1)  // lanes 0..31 of wave 0
-#pragma unroll
-            for (int o = 0; o <= MAXO; ++o) red[o] += __shfl_down(red[o], off, 64);
-        if (lane == 0) {
-#pragma unroll
-            for (int o = 0; o <= MAXO; ++o) acc_b3[o] += red[o];
-        }
+        acc_b3[MAXO] += l;
     }
     G32_STAMP(14);
     __syncthreads();
@@ -763,6 +757,12 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
     __syncthreads();  // the next tile's gather rewrites l_x / l_a / ... that the phases above read
     }  // tiles
     // ---- this workgroup's partial row ----
+    if (tid < G32) {  // lanes 0..31 of wave 0: the row slots' db3 / loss sums (fixed tree)
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+            for (int o = 0; o <= MAXO; ++o) acc_b3[o] += __shfl_down(acc_b3[o], off, 64);
+    }
     if (tid == 0) {
         for (int o = 0; o < na; ++o) out[ob3 + o] = acc_b3[o];
         g.loss_partials[blockIdx.x] = acc_b3[MAXO];
