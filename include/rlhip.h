@@ -570,6 +570,15 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
                             int32_t act, const float* obs, int64_t n, double eps, uint64_t seed,
                             uint32_t env_id_base, uint32_t step, int32_t* actions, float* q_out,
                             rlhip_stream_t stream);
+/* plan! + act! + push! of one DQN vec-step of the 3-layer Q-network (hidden 128) in ONE launch: rlhip_dqn3_plan_f32 followed by
+ * rlhip_env_act_push_f32, bit for bit (the lane that selects env e's action goes on with its env step, auto-reset and ring push);
+ * the 3-layer counterpart of rlhip_dqn_act_f32, used by rlhip_dqn_vec_step_f32.  obs: (ns, n) device -- this step's observation on
+ * entry, the next one's on return.  Supported: the three classic-control envs with their discrete action sets, n <= 32768. */
+int32_t rlhip_dqn3_act_supported(int32_t kind, int64_t n, int64_t h, int64_t na);
+int32_t rlhip_dqn3_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, const float* params,
+                           const uint16_t* packed, int64_t h, int64_t na, int32_t act, double eps, uint64_t explorer_seed,
+                           uint32_t explorer_step, uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb, int32_t* actions,
+                           float* q_out, float* obs, float* last_obs, rlhip_stream_t stream);
 int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch);
 /* optimise!(learner, batch) up to the gradient, as rlhip_dqn_grad_f32.  idx: optional explicit flat logical
  * indices (e.g. from rlhip_ring_sample_prioritized); NULL = the uniform BatchSampler draw of

@@ -237,6 +237,20 @@ __device__ __forceinline__ double wave_sum_xor_f64(double v) {
     return v;
 }
 
+// block_sum of optim_device.h (wave sums by the __shfl_down tree, the wave totals added in ascending order; result in every
+// thread) with the wave sums on wave_sum_down_f64_lane0: the same additions in the same order, bit-identical.  scratch: >= 16 doubles.
+__device__ __forceinline__ double block_sum_f64_dpp(double v, double* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum_down_f64_lane0(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += scratch[w];
+    __syncthreads();
+    return t;
+}
+
 // 16-byte non-temporal accesses for pure streaming kernels (every byte touched once, working set >> caches)
 typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ nt_u32x4 nt_load16(const void* p) {

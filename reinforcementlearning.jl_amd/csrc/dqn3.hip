@@ -48,6 +48,9 @@ __device__ long long g_d3_stamps[32];
 
 }  // namespace rlhip
 
+#include <type_traits>
+
+#include "act_device.h"
 #include "mlp3_device.h"
 #include "optim_device.h"
 
@@ -117,12 +120,27 @@ __global__ __launch_bounds__(256) void mlp3_plan_kernel(const float* __restrict_
 // bf16 roundings, same k order); the head sums run in a different fixed order (inside the stated tolerance).
 constexpr int P32 = 32;
 constexpr int LDH2 = H3 + 4;  // f32 pitch of the H2 tile
-template <int NS, int NA, int ACT>
+//
+// TAIL (round 5): NoActTail = plan! alone; ActTail<P> = the lane that selected env e's action goes on with act!(env, a) (auto-reset)
+// and push!(trajectory, (state = s', action, reward, terminal)) -- env_act_push1, the body of env_act_push_kernel, same slots:
+// bit-identical to the two launches, one launch and one round trip of the action array fewer per vec-step.  `obs` is then
+// read (this step's observation) and rewritten (the next one's) by the same lane.
+struct NoActTail {};
+template <class P>
+struct ActTail {
+    P p;
+    EnvArrays<float> st;
+    uint64_t env_seed;
+    ActRing rb;
+    float* obs_out;
+    float* last_obs;
+};
+template <int NS, int NA, int ACT, class TAIL>
 __global__ __launch_bounds__(256) void mlp3_plan32_kernel(const float* __restrict__ params,
                                                           const uint16_t* __restrict__ packed,
-                                                          const float* __restrict__ obs, int64_t n, double eps,
+                                                          const float* obs, int64_t n, double eps,
                                                           uint64_t seed, uint32_t env_id_base, uint32_t step,
-                                                          int32_t* __restrict__ actions, float* __restrict__ q_out) {
+                                                          int32_t* __restrict__ actions, float* __restrict__ q_out, TAIL tail) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     constexpr int na = NA;
     float* l_x = reinterpret_cast<float*>(smem3);               // [4][P32]
@@ -231,8 +249,12 @@ __global__ __launch_bounds__(256) void mlp3_plan32_kernel(const float* __restric
         }
         if (q_out)
             for (int o = 0; o < na; ++o) q_out[(int64_t)o * n + e] = q[o];
-        if (actions)
-            actions[e] = eps_greedy_select1(RegQ3{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)e, step);
+        if (actions) {
+            const int32_t a = eps_greedy_select1(RegQ3{q}, NoMask{}, na, eps, false, seed, env_id_base + (uint32_t)e, step);
+            actions[e] = a;
+            if constexpr (!std::is_same<TAIL, NoActTail>::value)
+                env_act_push1(tail.p, tail.st, n, e, a, tail.env_seed, env_id_base, tail.rb, tail.obs_out, tail.last_obs);
+        }
     }
 }
 
@@ -970,7 +992,7 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
     // sumsq_scaled_partial_kernel (one element per lane at this size)
     const float x = own ? g * ap.grad_scale : 0.0f;
     double acc = own ? (double)x * (double)x : 0.0;
-    acc = block_sum(acc, scratch);
+    acc = block_sum_f64_dpp(acc, scratch);
     typedef unsigned long long u64;
     double tot = 0.0;
     if (gran) {
@@ -1007,7 +1029,7 @@ __global__ __launch_bounds__(256) void d3_apply_kernel(const float* __restrict__
         for (int q = tid; q < (int)gridDim.x; q += 256)
             tot += __hip_atomic_load(ap.sumsq + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    tot = block_sum(tot, scratch);
+    tot = block_sum_f64_dpp(tot, scratch);
     const float gn = (float)sqrt(tot);
     const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
     if (own) {
@@ -1085,6 +1107,25 @@ constexpr size_t PLAN_LDS = (4 * TR + MAXO * TR + SMALLW) * sizeof(float) + TILE
 constexpr size_t GRAD_LDS = (8 * TR + 3 * MAXO * TR + TR + 16 + 2 * TR + 4 * 5 * H3 + 2 * SMALLW) * sizeof(float) +
                             3 * TILE_ELEMS * sizeof(uint16_t);
 
+template <class P, int NA>
+static int32_t dqn3_act_impl(const typename P::cfg_t* cfg, const rlhip_env_state* st, int64_t n, const float* params,
+                             const uint16_t* packed, int act, double eps, uint64_t explorer_seed, uint32_t step,
+                             uint64_t env_seed, uint32_t env_id_base, ActRing rb, int32_t* actions, float* q_out, float* obs,
+                             float* last_obs, hipStream_t s) {
+    typename P::cfg_t c2 = *cfg;
+    c2.continuous = 0;
+    ActTail<P> tail{P::make(c2), EnvArrays<float>::from(*st), env_seed, rb, obs, last_obs};
+    const dim3 grid32((unsigned)((n + P32 - 1) / P32));
+    if (act == 0)
+        hipLaunchKernelGGL((mlp3_plan32_kernel<P::ODIM, NA, 0, ActTail<P>>), grid32, dim3(256), PLAN32_LDS, s, params, packed, obs,
+                           n, eps, explorer_seed, env_id_base, step, actions, q_out, tail);
+    else
+        hipLaunchKernelGGL((mlp3_plan32_kernel<P::ODIM, NA, 1, ActTail<P>>), grid32, dim3(256), PLAN32_LDS, s, params, packed, obs,
+                           n, eps, explorer_seed, env_id_base, step, actions, q_out, tail);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
 template <typename K>
 static int32_t allow_lds(K kernel, size_t bytes, unsigned long long* done) { return allow_big_lds(kernel, bytes, done); }
 
@@ -1145,8 +1186,8 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
 #define LAUNCH_P(NS_, NA_, ACT_)                                                                               \
     do {                                                                                                       \
         if (small) {                                                                                           \
-            hipLaunchKernelGGL((mlp3_plan32_kernel<NS_, NA_, ACT_>), grid32, dim3(256), PLAN32_LDS, s, params,  \
-                               packed, obs, n, eps, seed, env_id_base, step, actions, q_out);                  \
+            hipLaunchKernelGGL((mlp3_plan32_kernel<NS_, NA_, ACT_, NoActTail>), grid32, dim3(256), PLAN32_LDS, s,  \
+                               params, packed, obs, n, eps, seed, env_id_base, step, actions, q_out, NoActTail{}); \
             break;                                                                                             \
         }                                                                                                      \
         static unsigned long long done_ = 0;                                                                             \
@@ -1162,6 +1203,41 @@ int32_t rlhip_dqn3_plan_f32(const float* params, const uint16_t* packed, int64_t
 #undef LAUNCH_P
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
+}
+
+int32_t rlhip_dqn3_act_supported(int32_t kind, int64_t n, int64_t h, int64_t na) {
+    const int64_t want = kind == 0 ? 2 : 3;  // CartPole (4, 2), Pendulum (3, 3), MountainCar (2, 3): the shapes the plan kernels are built for
+    return (kind >= 0 && kind <= 2 && h == H3 && na == want && n >= 1 && n <= (1 << 15)) ? 1 : 0;
+}
+
+/* plan! + act! + push! of one vec-step of the 3-layer Q-network in ONE launch (mlp3_plan32_kernel<..., ActTail>): what
+ * rlhip_dqn3_plan_f32 followed by rlhip_env_act_push_f32 computes, bit for bit */
+int32_t rlhip_dqn3_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, const float* params,
+                           const uint16_t* packed, int64_t h, int64_t na, int32_t act, double eps, uint64_t explorer_seed,
+                           uint32_t explorer_step, uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb, int32_t* actions,
+                           float* q_out, float* obs, float* last_obs, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(env_cfg && st && params && packed && rb && actions && obs, "NULL argument");
+    RLHIP_REQUIRE(rlhip_dqn3_act_supported(kind, n, h, na), "unsupported (kind, n, hidden, actions) for the fused 3-layer act kernel");
+    RLHIP_REQUIRE(act == 0 || act == 1, "act must be 0 (relu) or 1 (tanh)");
+    RLHIP_REQUIRE((((uintptr_t)packed) & 15) == 0, "packed weights must be 16-byte aligned");
+    RLHIP_REQUIRE(st->episode, "this entry point needs the separate episode[] array (packed step / episode words are an rlhip_env_step / rlhip_env_reset mode)");
+    RLHIP_REQUIRE(rb->elem_bytes == 4 && rb->n_env == n && rb->obs_dim == (kind == 0 ? 4 : (kind == 1 ? 3 : 2)),
+                  "ring geometry does not match the env");
+    RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
+    RLHIP_REQUIRE(rb->layout == RLHIP_RING_RECORDS, "the fused act + push kernels write a record ring (rlhip_ring_init, ABI 2)");
+    const ActRing ar = claim_slots(rb);
+    hipStream_t s = as_stream(stream);
+    if (kind == 0)
+        return dqn3_act_impl<CartPoleParams<float>, 2>((const rlhip_cartpole_cfg*)env_cfg, st, n, params, packed, act, eps,
+                                                       explorer_seed, explorer_step, env_seed, env_id_base, ar, actions, q_out, obs,
+                                                       last_obs, s);
+    if (kind == 1)
+        return dqn3_act_impl<PendulumParams<float>, 3>((const rlhip_pendulum_cfg*)env_cfg, st, n, params, packed, act, eps,
+                                                       explorer_seed, explorer_step, env_seed, env_id_base, ar, actions, q_out, obs,
+                                                       last_obs, s);
+    return dqn3_act_impl<MountainCarParams<float>, 3>((const rlhip_mountaincar_cfg*)env_cfg, st, n, params, packed, act, eps,
+                                                      explorer_seed, explorer_step, env_seed, env_id_base, ar, actions, q_out, obs,
+                                                      last_obs, s);
 }
 
 int64_t rlhip_dqn3_workspace_bytes(int64_t ns, int64_t h, int64_t na, int64_t batch) {

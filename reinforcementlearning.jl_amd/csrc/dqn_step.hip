@@ -39,6 +39,11 @@ int64_t rlhip_mlp2_nparams(int64_t, int64_t, int64_t);
 int64_t rlhip_mlp3_nparams(int64_t, int64_t, int64_t);
 int32_t rlhip_env_obs_dim(int32_t kind);
 int32_t rlhip_dqn_act_supported(int32_t kind, int64_t n, int64_t h);
+int32_t rlhip_dqn3_act_supported(int32_t kind, int64_t n, int64_t h, int64_t na);
+int32_t rlhip_dqn3_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, const float* params,
+                           const uint16_t* packed, int64_t h, int64_t na, int32_t act, double eps, uint64_t explorer_seed,
+                           uint32_t explorer_step, uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb, int32_t* actions,
+                           float* q_out, float* obs, float* last_obs, rlhip_stream_t stream);
 int32_t rlhip_dqn_act_f32(int32_t kind, const void* env_cfg, const rlhip_env_state* st, int64_t n, const float* params,
                           int64_t h, int64_t na, int32_t act, double eps, uint64_t explorer_seed, uint32_t explorer_step,
                           uint64_t env_seed, uint32_t env_id_base, rlhip_ring* rb, int32_t* actions, float* q_out,
@@ -60,6 +65,12 @@ extern "C" int32_t rlhip_dqn_vec_step_f32(rlhip_dqn_step_args* a, rlhip_stream_t
         rc = rlhip_dqn_act_f32(a->kind, a->env_cfg, a->st, a->n, a->params, a->h, a->na, a->act, a->eps,
                                a->explorer_seed, a->explorer_step, a->env_seed, a->env_id_base, a->ring, a->actions,
                                a->q, a->obs, a->last_obs, stream);
+        if (rc) return rc;
+    } else if (a->layers == 3 && rlhip_dqn3_act_supported(a->kind, a->n, a->h, a->na)) {
+        // the same for the 3-layer Q-network (dqn3.hip: the plan kernel's selecting lane goes on with act! + push!)
+        rc = rlhip_dqn3_act_f32(a->kind, a->env_cfg, a->st, a->n, a->params, a->packed, a->h, a->na, a->act, a->eps,
+                                a->explorer_seed, a->explorer_step, a->env_seed, a->env_id_base, a->ring, a->actions, a->q,
+                                a->obs, a->last_obs, stream);
         if (rc) return rc;
     } else {
     // plan!(policy, env): Q forward + eps-greedy on the current observation

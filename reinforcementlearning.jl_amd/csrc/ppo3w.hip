@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(1024) void ppo3w_reduce_sumsq_kernel(const float* _
         __syncthreads();
     }
     // block_sum of a 256-thread workgroup, on waves 0..3
-    acc = wave_sum(acc);
+    acc = wave_sum_down_f64_lane0(acc);  // (wave_sum's tree; only lane 0 is read)
     if (qtr == 0 && lane == 0) scratch[wv] = acc;
     __syncthreads();
     if (tid == 0) sumsq[blockIdx.x] = ((0.0 + scratch[0]) + scratch[1] + scratch[2]) + scratch[3];
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
     __shared__ double scratch[16];
     double acc = 0.0;
     for (int i = threadIdx.x; i < npart; i += blockDim.x) acc += sumsq[i];
-    acc = block_sum(acc, scratch);
+    acc = block_sum_f64_dpp(acc, scratch);
     const float gn = (float)sqrt(acc);
     const float scale = (clip_norm > 0.0f && clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
     const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];

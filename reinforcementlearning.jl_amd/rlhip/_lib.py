@@ -210,6 +210,8 @@ _PROTOS = {
     "rlhip_dqn_act_supported": (i32, [i32, i64, i64]),
     "rlhip_dqn_act_f32": (i32, [i32, vp, vp, i64, vp, i64, i64, i32, f64, u64, u32, u64, u32, P(Ring), vp, vp, vp, vp,
                                 vp]),
+    "rlhip_dqn3_act_supported": (i32, [i32, i64, i64, i64]),
+    "rlhip_dqn3_act_f32": (i32, [i32, vp, vp, i64, vp, vp, i64, i64, i32, f64, u64, u32, u64, u32, P(Ring), vp, vp, vp, vp, vp]),
     "rlhip_hook_episode_stats": (i32, [vp, vp, i64, u32, vp, vp, vp, u32, vp, vp]),
     "rlhip_explorer_select_f32": (i32, [i32, vp, i64, i64, i64, i64, vp, i32, u64, u32, u32, vp, vp]),
     "rlhip_ucb_select_f32": (i32, [vp, i64, i64, i64, i64, f64, vp, i64, u64, u32, vp, vp]),
@@ -277,7 +279,7 @@ for _name, (_res, _args) in _PROTOS.items():
     _f.restype = _res
     _f.argtypes = _args
     if _res is i32 and _name not in ("rlhip_abi_version", "rlhip_env_obs_dim", "rlhip_env_state_dim",
-                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported", "rlhip_p2p_can_access",
+                                     "rlhip_ring_gather_is_frame_major", "rlhip_dqn_act_supported", "rlhip_dqn3_act_supported", "rlhip_p2p_can_access",
                                      "rlhip_ring_bounds_checked_build", "rlhip_ring_layout"):
         _STATUS.add(_name)
 

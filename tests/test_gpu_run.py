@@ -172,7 +172,7 @@ def test_two_ranks_one_gpu_gradient_allreduce(rl, mode):
 
 
 @pytest.mark.parametrize("layers,kind,hidden", [(2, "cartpole", 128), (3, "cartpole", 128), (2, "mountaincar", 128),
-                                                (3, "mountaincar", 128), (3, "cartpole", 256)])
+                                                (3, "mountaincar", 128), (3, "cartpole", 256), (3, "pendulum", 128), (2, "pendulum", 128)])
 def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, kind, hidden):
     """rlhip_dqn_vec_step_f32 (one C call per vec-step) against run(): same kernels in the same order, so the
     parameters, target network, replay ring, env state and every counter must end bit-identical."""
@@ -180,7 +180,7 @@ def test_fused_dqn_vec_step_is_bit_identical_to_the_per_step_protocol(layers, ki
 
     def build():
         n = 192
-        env = rlhip.HipVecEnv(kind, n, seed=4)
+        env = rlhip.HipVecEnv(kind, n, seed=4, continuous=False)
         na = len(env.action_space())
         net = rlhip.HipApproximator(env.odim, hidden, na, seed=4, layers=layers)
         tn = rlhip.TargetNetwork(net, sync_freq=7)
