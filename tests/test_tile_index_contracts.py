@@ -120,3 +120,61 @@ def test_norm_partial_granules_round_trip_and_never_match_a_stale_epoch():
             assert int(stale >> np.uint64(32)) != epoch
     # a zero-initialised workspace never matches the first launch (epoch = stored count + 1 >= 1)
     assert int(np.uint64(0) >> np.uint64(32)) != 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The two-layer DQN learner tile (csrc/dqn.hip, round 5: 1024 threads around the 16-lane DPP row).  Same idea: the maps the kernel
+# comments state, checked for exact coverage.
+DQN_THREADS, DQN_TILE = 1024, 64
+
+
+@pytest.mark.parametrize("h", [4, 8, 64, 100, 128, 200, 252, 256])
+def test_dqn_phase_1_every_sample_unit_pair_belongs_to_one_lane_and_a_row_is_one_sample(h):
+    """phase 1: wave w, row = lane >> 4, c = lane & 15: sample 4 w + row, hidden units c, c + 16, ... < h; the DPP row sum
+    (group_sum_dpp<16>) adds the sixteen lanes of ONE sample"""
+    seen = np.zeros((DQN_TILE, h), np.int32)
+    for tid in range(DQN_THREADS):
+        w, lane = tid >> 6, tid & 63
+        row, c = lane >> 4, lane & 15
+        smp = 4 * w + row
+        assert (lane // 16) * 16 <= lane < (lane // 16) * 16 + 16  # the row is an aligned group of sixteen lanes
+        for jj in range(c, h, 16):
+            seen[smp, jj] += 1
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("h", [4, 8, 64, 100, 128, 200, 252, 256])
+def test_dqn_phase_2_every_sample_unit_pair_belongs_to_one_lane_and_a_row_is_one_unit(h):
+    """phase 2: unit j = 4 w + row + 64 p for p < UPL = 2 (h <= 128) or 4, samples c, c + 16, c + 32, c + 48; only lane c == 0
+    of a row publishes, every unit exactly once"""
+    upl = 2 if h <= 128 else 4
+    seen = np.zeros((DQN_TILE, h), np.int32)
+    publishers = []
+    for tid in range(DQN_THREADS):
+        w, lane = tid >> 6, tid & 63
+        row, c = lane >> 4, lane & 15
+        for p in range(upl):
+            j = 4 * w + row + 64 * p
+            if 64 * p < h and j < h:
+                for i in range(4):
+                    seen[c + 16 * i, j] += 1
+                if c == 0:
+                    publishers.append(j)
+    assert (seen == 1).all()
+    assert sorted(publishers) == list(range(h))
+
+
+@pytest.mark.parametrize("nb", [1, 2, 3, 8, 9, 31, 32])
+def test_dqn_fused_tail_fold_visits_every_partial_row_once_in_the_reduce_kernels_order(nb):
+    """dqn_fused_tail: four groups of per = ceil(nb / 4) rows, chunks of four rows, predicates r0 + r < per and b < nb -- the rows
+    of a group in ascending order, every row exactly once (= dqn_reduce_kernel's b0 .. b1 ranges)"""
+    per = (nb + 3) // 4
+    order = [[] for _ in range(4)]
+    for r0 in range(0, per, 4):
+        for grp in range(4):
+            for r in range(4):
+                b = grp * per + r0 + r
+                if r0 + r < per and b < nb:
+                    order[grp].append(b)
+    ref = [list(range(g * per, min(nb, g * per + per))) for g in range(4)]
+    assert order == ref and sorted(sum(order, [])) == list(range(nb))
