@@ -559,7 +559,7 @@ __global__ __launch_bounds__(1024) void dqn_reduce_apply_kernel(const float* __r
         acc += (double)x * (double)x;
     }
     const float c1 = 1.0f - ap.beta_pow[0], c2 = 1.0f - ap.beta_pow[1];
-    acc = block_sum(acc, scratch);
+    acc = block_sum_f64_dpp(acc, scratch);  // block_sum's tree, in-row steps on DPP (common.h): bit-identical
     const float gn = (float)sqrt(acc);
     const float scale = (ap.clip_norm > 0.0f && ap.clip_norm <= gn) ? ap.clip_norm / fmaxf(ap.clip_norm, gn) : 1.0f;
 #pragma unroll
