@@ -141,6 +141,20 @@ def test_three_layer_widths_accepted_by_the_host_side_of_the_abi():
         assert 0 < a < b
 
 
+def test_fused_act_entry_points_say_what_they_support_and_refuse_the_rest_before_touching_a_device():
+    """rlhip_dqn_act_supported / rlhip_dqn3_act_supported (pure host predicates) and the argument checks of rlhip_dqn3_act_f32:
+    the vec-step call falls back to the separate launches exactly where these say no"""
+    sup2, sup3 = _lib.lib.rlhip_dqn_act_supported, _lib.lib.rlhip_dqn3_act_supported
+    assert sup2(0, 4096, 128) == 1 and sup2(1, 4096, 64) == 1 and sup2(2, 1, 256) == 1
+    assert sup2(0, 4096, 100) == 0 and sup2(3, 4096, 128) == 0 and sup2(0, 0, 128) == 0
+    # 3-layer net: hidden 128 only, the three classic-control envs with their discrete action sets, up to 32768 envs
+    assert sup3(0, 4096, 128, 2) == 1 and sup3(1, 192, 128, 3) == 1 and sup3(2, 32768, 128, 3) == 1
+    assert sup3(0, 4096, 256, 2) == 0 and sup3(0, 4096, 128, 3) == 0 and sup3(1, 4096, 128, 2) == 0
+    assert sup3(2, 32769, 128, 3) == 0 and sup3(3, 4096, 128, 2) == 0 and sup3(0, 0, 128, 2) == 0
+    rc = _lib.lib.rlhip_dqn3_act_f32(0, None, None, 4096, None, None, 128, 2, 0, 0.1, 1, 0, 1, 0, None, None, None, None, None, None)
+    assert rc != 0 and "NULL" in _lib.last_error()
+
+
 def test_get_eps_host_function_golden():
     with open(os.path.join(G, "select.json")) as f:
         S = json.load(f)
