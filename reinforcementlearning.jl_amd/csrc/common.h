@@ -202,6 +202,18 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // all 64 lanes
     return v + __shfl_xor(v, 32, 64);
 }
 
+// A store of a result that the NEXT launch reads (partial gradient rows, above all): device-scope write-through (sc1) instead of a
+// plain store.  With plain stores a kernel leaves its output as dirty lines in the eight L2s, and the end of the kernel has to write
+// them back before the next launch may start: measured on the headline's gradient kernel (3.4 MB of partial rows per launch), the
+// same bits in -3.2 % of the step (profiles/raw_r05/partial_row_store_policy_ab.txt; non-temporal stores: no gain).
+__device__ __forceinline__ void store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... where the rows are MANY: with 16 rows (1 MB, the 3-layer DQN learner at batch 512) the plain form was 0.6 us per vec-step faster, with
+// 128 rows (9 MB, batch 4096) the write-through form 1.0 us (profiles/raw_r05/dqn_partial_row_store_policy_ab.txt).  wt: uniform.
+__device__ __forceinline__ void store_row(float* p, float v, bool wt) {
+    if (wt) store_wt(p, v);
+    else *p = v;
+}
+
 // Float64 cross-lane sums with the SAME addition trees as the __shfl loops they replace (bit-identical results), where the four
 // steps inside a 16-lane row are DPP moves of the two halves of the double instead of ds_bpermute round trips (each shuffled double
 // is two ds_bpermute_b32 with a dependent wait: ~1 us per six-step chain in the optimiser tails, profiles/r05_dqn_vec_step.md).

@@ -279,6 +279,7 @@ struct Dqn3Args {
     float gamma, delta, inv_b;
     uint64_t seed;
     uint32_t draw_ctr;
+    int wt_rows;              // dqn3_grad32_kernel: partial rows stored write-through (many rows) or plainly (few): common.h store_row
 };
 
 template <int NS, int NA, int ACT>
@@ -405,8 +406,8 @@ __global__ __launch_bounds__(256) void dqn3_grad_kernel(Dqn3Args g) {
     }
     __syncthreads();
     if (tid == 0) {
-        for (int o = 0; o < na; ++o) out[ob3 + o] = l_small[o] + l_small[8 + o];
-        g.loss_partials[blockIdx.x] = l_small[MAXO] + l_small[8 + MAXO];
+        for (int o = 0; o < na; ++o) store_wt(&out[ob3 + o], l_small[o] + l_small[8 + o]);
+        store_wt(&g.loss_partials[blockIdx.x], l_small[MAXO] + l_small[8 + MAXO]);
     }
 
     D3_STAMP(8);
@@ -785,21 +786,22 @@ __global__ __launch_bounds__(256, OCC) void dqn3_grad32_kernel(Dqn3Args g) {
 #pragma unroll
             for (int o = 0; o <= MAXO; ++o) acc_b3[o] += __shfl_down(acc_b3[o], off, 64);
     }
+    const bool wt = g.wt_rows != 0;
     if (tid == 0) {
-        for (int o = 0; o < na; ++o) out[ob3 + o] = acc_b3[o];
-        g.loss_partials[blockIdx.x] = acc_b3[MAXO];
+        for (int o = 0; o < na; ++o) store_row(&out[ob3 + o], acc_b3[o], wt);
+        store_row(&g.loss_partials[blockIdx.x], acc_b3[MAXO], wt);
     }
     if (kb == 0) {
-        out[ob2 + col] = acc_b2;
-        for (int o = 0; o < na; ++o) out[oW3 + o + na * col] = acc_w3[o];
-        out[ob1 + col] = acc_b1;
+        store_row(&out[ob2 + col], acc_b2, wt);
+        for (int o = 0; o < na; ++o) store_row(&out[oW3 + o + na * col], acc_w3[o], wt);
+        store_row(&out[ob1 + col], acc_b1, wt);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) out[oW1 + col + H3 * i] = acc_w1[i];
+        for (int i = 0; i < NS; ++i) store_row(&out[oW1 + col + H3 * i], acc_w1[i], wt);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
+        for (int q = 0; q < 16; ++q) store_row(&out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))], dw[t][q], wt);
 }
 
 constexpr size_t GRAD32_LDS = (4 * G32 * 2 + MAXO * G32 + G32 + 2 * 8 * 4 * G32 + 2 * G32 + G32 * LDH2 + 2 * SMALLW) *
@@ -1311,6 +1313,7 @@ static int32_t dqn3_grad_impl(const rlhip_ring* rb, int64_t h, int64_t na, int32
     g.inv_b = 1.0f / (float)batch;
     g.seed = seed;
     g.draw_ctr = draw_ctr;
+    g.wt_rows = (int64_t)nb * np * (int64_t)sizeof(float) >= ((int64_t)4 << 20) ? 1 : 0;  // (measured: 1 MB plain, 9 MB write-through)
     hipStream_t s = as_stream(stream);
 #define LAUNCH_G(NS_, NA_, ACT_)                                                                        \
     do {                                                                                                \

@@ -325,8 +325,8 @@ __device__ __forceinline__ void mlp3_backward_tile(const Mlp3& m, const uint16_t
     }
     __syncthreads();
     if (tid < H3) {
-        out[ob2 + tid] = sum_waves<MAXO + 1>(l_red, 0, tid);
-        for (int o = 0; o < na; ++o) out[oW3 + o + na * tid] = sum_waves<MAXO + 1>(l_red, 1 + o, tid);
+        store_wt(&out[ob2 + tid], sum_waves<MAXO + 1>(l_red, 0, tid));
+        for (int o = 0; o < na; ++o) store_wt(&out[oW3 + o + na * tid], sum_waves<MAXO + 1>(l_red, 1 + o, tid));
     }
     __syncthreads();  // l_red is reused below
 
@@ -370,9 +370,9 @@ __device__ __forceinline__ void mlp3_backward_tile(const Mlp3& m, const uint16_t
     }
     __syncthreads();
     if (tid < H3) {
-        out[ob1 + tid] = sum_waves<NS + 1>(l_red, 0, tid);
+        store_wt(&out[ob1 + tid], sum_waves<NS + 1>(l_red, 0, tid));
 #pragma unroll
-        for (int i = 0; i < NS; ++i) out[oW1 + tid + H3 * i] = sum_waves<NS + 1>(l_red, 1 + i, tid);
+        for (int i = 0; i < NS; ++i) store_wt(&out[oW1 + tid + H3 * i], sum_waves<NS + 1>(l_red, 1 + i, tid));
     }
 
     // ---- dW2^T[k][j] = sum_r H1[r][k] dZ2[r][j] (MFMA); stored as Flux W2[j + h k] ----
@@ -383,7 +383,7 @@ __device__ __forceinline__ void mlp3_backward_tile(const Mlp3& m, const uint16_t
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))] = dw[t][q];
+            for (int q = 0; q < 16; ++q) store_wt(&out[oW2 + (r + 32 * t) + H3 * (32 * w + mfma_row(q, kb))], dw[t][q]);
     }
 }
 

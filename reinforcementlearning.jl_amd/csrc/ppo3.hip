@@ -557,9 +557,9 @@ __global__ __launch_bounds__(256) void ppo3_grad_kernel(P3Args g) {
     }
     __syncthreads();
     if (tid == 0) {
-        for (int o = 0; o < NOUT_A; ++o) out[ob3a + o] = l_small[o] + l_small[8 + o];
-        g.loss_partials[(int64_t)blockIdx.x * 4 + 0] = l_small[MAXO] + l_small[8 + MAXO];
-        g.loss_partials[(int64_t)blockIdx.x * 4 + 2] = l_small[MAXO + 1] + l_small[8 + MAXO + 1];
+        for (int o = 0; o < NOUT_A; ++o) store_wt(&out[ob3a + o], l_small[o] + l_small[8 + o]);
+        store_wt(&g.loss_partials[(int64_t)blockIdx.x * 4 + 0], l_small[MAXO] + l_small[8 + MAXO]);
+        store_wt(&g.loss_partials[(int64_t)blockIdx.x * 4 + 2], l_small[MAXO + 1] + l_small[8 + MAXO + 1]);
     }
     mlp3_backward_tile<NS, NOUT_A, ACT>(ma, g.packed + H3 * H3, h2, l_x, l_dq, l_red, l_A, l_B, l_C, out, tid);
     __syncthreads();  // the actor's tiles, l_red and l_small are free again
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void ppo3_grad_kernel(P3Args g) {
     float* outc = out + g.np_a;
     if (tid == 0) {
         outc[ob3c] = l_small[0] + l_small[8];
-        g.loss_partials[(int64_t)blockIdx.x * 4 + 1] = l_small[1] + l_small[9];
+        store_wt(&g.loss_partials[(int64_t)blockIdx.x * 4 + 1], l_small[1] + l_small[9]);
     }
     mlp3_backward_tile<NS, 1, ACT>(mc, pkc + H3 * H3, h2, l_x, l_dq, l_red, l_A, l_B, l_C, outc, tid);
 }

@@ -596,7 +596,7 @@ __device__ __forceinline__ void ppo3T_body(const P3Args& g, int wg, int nwg, int
 #pragma unroll
     for (int tu = 0; tu < 4; ++tu)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[oW2 + (32 * w + c) + H3 * (32 * tu + t3_row(q, kb))] = accW2[tu][q];
+        for (int q = 0; q < 16; ++q) store_wt(&out[oW2 + (32 * w + c) + H3 * (32 * tu + t3_row(q, kb))], accW2[tu][q]);
     // per-lane sums: the two halves of a wave hold different samples, the four waves as well -> LDS, fixed order
     constexpr int NV = 2 + NOUT + NS;  // db2, db1, dW3[o], dW1[i]
     float* l_red = reinterpret_cast<float*>(l_XH);  // [4 waves][NV][H3]  (the exchange slabs are free now)
@@ -631,23 +631,23 @@ __device__ __forceinline__ void ppo3T_body(const P3Args& g, int wg, int nwg, int
             return ((l_red[(0 * NV + v) * H3 + u] + l_red[(1 * NV + v) * H3 + u]) + l_red[(2 * NV + v) * H3 + u]) +
                    l_red[(3 * NV + v) * H3 + u];
         };
-        out[ob2 + u] = sum4(0);
-        out[ob1 + u] = sum4(1);
+        store_wt(&out[ob2 + u], sum4(0));
+        store_wt(&out[ob1 + u], sum4(1));
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) out[oW3 + o + NOUT * u] = sum4(2 + o);
+        for (int o = 0; o < NOUT; ++o) store_wt(&out[oW3 + o + NOUT * u], sum4(2 + o));
 #pragma unroll
-        for (int i = 0; i < NS; ++i) out[u + H3 * i] = sum4(2 + NOUT + i);
+        for (int i = 0; i < NS; ++i) store_wt(&out[u + H3 * i], sum4(2 + NOUT + i));
     }
     if (tid == 0) {
         auto s4 = [&](int o) { return ((l_small[o] + l_small[8 + o]) + l_small[16 + o]) + l_small[24 + o]; };
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) out[ob3 + o] = s4(o);
+        for (int o = 0; o < NOUT; ++o) store_wt(&out[ob3 + o], s4(o));
         float* lo = g.loss_partials + (int64_t)wg * 4;
         if (!CRITIC) {
-            lo[0] = s4(NOUT);
-            lo[2] = s4(NOUT + 1);
+            store_wt(&lo[0], s4(NOUT));
+            store_wt(&lo[2], s4(NOUT + 1));
         } else {
-            lo[1] = s4(NOUT);
+            store_wt(&lo[1], s4(NOUT));
         }
     }
 }

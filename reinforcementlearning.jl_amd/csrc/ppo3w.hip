@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[j + HW * ((HW / 2) * kh + 32 * kt + mfma_row(q, kb))] = acc[kt][q];
+        for (int q = 0; q < 16; ++q) store_wt(&out[j + HW * ((HW / 2) * kh + 32 * kt + mfma_row(q, kb))], acc[kt][q]);
     W3_MARK(2, 11, net == 0);
 }
 

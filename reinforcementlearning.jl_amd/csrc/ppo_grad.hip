@@ -123,6 +123,11 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
     if (id.team != 0) return;
 
     // ---- epilogue: this workgroup's partial gradient (fixed layout = parameter layout) ----
+    // The row is read by the NEXT launch (reduce_apply_kernel), not by this one -- and yet the stores are device-scope write-through
+    // (sc1) ones (store_wt, common.h): with plain stores the 256 workgroups leave 3.4 MB of dirty lines in the eight L2s, which the end of the kernel
+    // has to write back before the next launch may start.  Same-box A / B of the headline, three alternations, bit-identical
+    // (profiles/raw_r05/partial_row_store_policy_ab.txt): 0.3931 / 0.3910 / 0.3908 -> 0.3769 / 0.3806 / 0.3791 ms per step
+    // (-3.2 %); non-temporal stores: no gain.
     float* out = g.partials + (int64_t)blockIdx.x * g.np;
     if (id.owner && id.shalf == 0) {
         const int j = id.uidx;
@@ -130,26 +135,26 @@ __global__ __launch_bounds__(512 * NT) void ppo_grad_kernel(GradArgs g) {
         float* oc_ = out + g.pd.np_a;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            oa_[j + h * k] = G.w1[k].x;
-            oc_[j + h * k] = G.w1[k].y;
+            store_wt(&oa_[j + h * k], G.w1[k].x);
+            store_wt(&oc_[j + h * k], G.w1[k].y);
         }
-        oa_[h * NS + j] = G.b1.x;
-        oc_[h * NS + j] = G.b1.y;
-        oa_[h * NS + h + 0 + nout * j] = G.w2p.x;
-        if (1 < nout) oa_[h * NS + h + 1 + nout * j] = G.w2a1;
-        if (2 < nout) oa_[h * NS + h + 2 + nout * j] = G.w2a2;
-        oc_[h * NS + h + j] = G.w2p.y;
+        store_wt(&oa_[h * NS + j], G.b1.x);
+        store_wt(&oc_[h * NS + j], G.b1.y);
+        store_wt(&oa_[h * NS + h + 0 + nout * j], G.w2p.x);
+        if (1 < nout) store_wt(&oa_[h * NS + h + 1 + nout * j], G.w2a1);
+        if (2 < nout) store_wt(&oa_[h * NS + h + 2 + nout * j], G.w2a2);
+        store_wt(&oc_[h * NS + h + j], G.w2p.y);
     }
     if (id.w == 0 && id.lane == 0) {
 #pragma unroll
         for (int o = 0; o < GMAXO; ++o)
-            if (o < nout) out[h * NS + h + nout * h + o] = Hd.b2a[o];
-        out[g.pd.np_a + h * NS + h + h] = Hd.b2c;
+            if (o < nout) store_wt(&out[h * NS + h + nout * h + o], Hd.b2a[o]);
+        store_wt(&out[g.pd.np_a + h * NS + h + h], Hd.b2c);
         float* lo_ = g.loss_partials + (int64_t)blockIdx.x * 4;
-        lo_[0] = Hd.s_actor;
-        lo_[1] = Hd.s_critic;
-        lo_[2] = Hd.s_ent;
-        lo_[3] = 0.f;
+        store_wt(&lo_[0], Hd.s_actor);
+        store_wt(&lo_[1], Hd.s_critic);
+        store_wt(&lo_[2], Hd.s_ent);
+        store_wt(&lo_[3], 0.f);
     }
 }
 
