@@ -778,8 +778,8 @@ int32_t rlhip_ppo_update_comm_f32(int32_t kind, const rlhip_ppo_cfg* cfg_host, i
                                   float* grad_scratch, float* losses_out, rlhip_comm_t comm, rlhip_stream_t stream);
 /* n_epochs x n_microbatches of { grad -> clip_by_global_norm! -> Adam } (single-GPU optimise!; multi-GPU hosts call
  * rlhip_ppo_update_comm_f32, or rlhip_ppo_grad_f32, all-reduce, rlhip_ppo_apply_f32).  update_ctr = number of previous
- * update calls.  Two-layer networks: one pack launch per call, then two launches per optimiser step (gradient tiles; partial
- * reduction + norm exchange + clip + Adam + record refresh).  WORKSPACE SIZE: the call writes 32 bytes per trajectory entry
+ * update calls.  Two-layer networks: two launches per optimiser step (gradient tiles -- the first one of a call also builds its
+ * weight records from `params` and writes the sample records; then partial reduction + norm exchange + clip + Adam + record refresh).  WORKSPACE SIZE: the call writes 32 bytes per trajectory entry
  * (n * T of THIS call) of sample records behind the fixed part of the workspace -- the workspace must have been sized by
  * rlhip_ppo_workspace_bytes(kind, cfg, n, T) for the LARGEST n * T it is ever used with and registered with
  * rlhip_ppo_workspace_init; a call that needs more than was registered returns RLHIP_EINVAL (ABI 2). */
