@@ -665,7 +665,10 @@ def roofline_hbm_side(torch, rlhip):
         ops.adam_(p, g, m, v, bp)
         ms = event_time_ms(lambda: ops.adam_(p, g, m, v, bp), 20, lib, s, SETTLE_S)
         out[f"adam_2p{logn}"] = entry(28 * n / 1e9, ms, n_params=n, bytes_per_unit=28,
-                                      kernel="adam_vec4_kernel<non-temporal stores, 2 chunks per lane> + beta_pow_advance_kernel (one call = two launches)",
+                                      kernel=("adam_vec4_kernel<non-temporal stores, one 16-byte chunk per lane>: ONE launch (the beta-power advance runs in the "
+                                              "workgroup that departs last; csrc/optim.hip)" if n <= (1 << 23) else
+                                              "adam_vec4_kernel<non-temporal stores, one 16-byte chunk per lane> + beta_pow_advance_kernel (above 2^23 "
+                                              "parameters one call = two launches)"),
                                       note="2^22 parameters (117 MB per call) fit the 256 MB Infinity Cache: the 2^26 entry is the HBM one" if logn == 22 else "")
         ops.polyak_(p, g, 0.995)
         ms = event_time_ms(lambda: ops.polyak_(p, g, 0.995), 20, lib, s)
@@ -691,32 +694,46 @@ def roofline_hbm_side(torch, rlhip):
                                            transitions_per_sec=round(n_env / (ms * 1e-3), 1))
     del tr, s1, s2, _keep
     torch.cuda.empty_cache()
-    # --- small-observation gather: CartPole transitions (ns = 4), 2^20 samples from a 256 x 4096 ring
-    n_env, cap, batch = 4096, 256, 1 << 20
-    tr = CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=4)
-    tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
-    tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap
-    idx = tr.sample_indices(batch, seed=11, draw_ctr=0)
-    bufs = tr.gather(idx)
-    c = [1]
+    # --- small-observation gather: CartPole transitions (ns = 4), 2^20 samples, at BOTH operating points: out of
+    # a 256 x 4096 ring (67 MB of records: Infinity-Cache resident) and out of a 16384 x 4096 ring (4.3 GB: every record comes from HBM)
+    n_env, batch = 4096, 1 << 20
+    for key, cap in (("gather_small", 256), ("gather_small_hbm", 16384)):
+        tr = CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=4)
+        tr.records.normal_()  # every word of every 64-byte record: s, s_next and (overwritten below) a, r, t
+        tr.rb.len_sa, tr.rb.len_rt = cap + 1, cap
+        idx = tr.sample_indices(batch, seed=11, draw_ctr=0)
+        bufs = tr.gather(idx)
+        c = [1]
 
-    def smp():
-        call("rlhip_ring_sample_indices", C.byref(tr.rb), batch, 11, c[0], ptr(idx), s)
-        c[0] += 1
+        def smp():
+            call("rlhip_ring_sample_indices", C.byref(tr.rb), batch, 11, c[0], ptr(idx), s)
+            c[0] += 1
 
-    def sg():
-        smp()
-        call("rlhip_ring_gather", C.byref(tr.rb), ptr(idx), batch, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]),
-             ptr(bufs[4]), s)
+        def sg():
+            smp()
+            call("rlhip_ring_gather", C.byref(tr.rb), ptr(idx), batch, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]),
+                 ptr(bufs[4]), s)
 
-    ms = event_time_ms(sg, 10, lib, s, SETTLE_S) - event_time_ms(smp, 10, lib, s)
-    out["gather_small"] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env,
-                                kernel="gather_rec_kernel<4>", samples_per_sec=round(batch / (ms * 1e-3), 1),
-                                note="round 5: the ring stores one 64-byte record {s[4], a, r, t, s'[4]} per (state slot, env) -- the "
-                                     "whole transition in ONE cache line = one fabric request per sample (the kernel is bound by the "
-                                     "L2's 64-byte request rate, ~45 G requests / s: profiles/r05_pmc.md), out of a 67 MB ring "
-                                     "(Infinity-Cache resident); 82 B per sample are the algorithmic bytes.  32-byte records (two lines "
-                                     "per sample) took 43.5 us for this launch, round 4 (five lines) 79 us, rounds 1 - 3 (eleven) 164 - 168 us")
+        ms = event_time_ms(sg, 10, lib, s, SETTLE_S) - event_time_ms(smp, 10, lib, s)
+        ring_mb = round((cap + 1) * n_env * 64 / 1e6, 1)
+        if key == "gather_small":
+            out[key] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env, ring_mb=ring_mb,
+                             kernel="gather_rec_kernel<4>", samples_per_sec=round(batch / (ms * 1e-3), 1),
+                             requests_per_sec_g=round(1.02 * batch / (ms * 1e-3) / 1e9, 1),
+                             note="the ring stores one 64-byte record {s[4], a, r, t, s'[4]} per (state slot, env) -- the whole transition in ONE "
+                                  "cache line = one fabric request per sample (TCC_EA0_RDREQ 1.02 per sample: profiles/r05_pmc.md).  This 67 MB ring is "
+                                  "Infinity-Cache resident: `frac` divides by the HBM peak only to keep one unit across the table -- the launch is bound by "
+                                  "the L2s' 64-byte REQUEST rate (~45 G requests / s), not by HBM bytes; the HBM operating point is `gather_small_hbm`.  "
+                                  "32-byte records (two lines per sample) took 43.5 us for this launch, round 4 (five lines) 79 us, rounds 1 - 3 (eleven) 164 - 168 us")
+            out[key]["bound"] = "infinity-cache request rate"
+        else:
+            out[key] = entry(82 * batch / 1e9, ms, batch=batch, bytes_per_unit=82, ring_transitions=cap * n_env, ring_mb=ring_mb,
+                             kernel="gather_rec_kernel<4>", samples_per_sec=round(batch / (ms * 1e-3), 1),
+                             requests_per_sec_g=round(1.02 * batch / (ms * 1e-3) / 1e9, 1),
+                             note="the same launch out of a 4.3 GB ring: every 64-byte record is an HBM read of one line (a random 64-byte read "
+                                  "opens a DRAM page for one burst), the batch is written streaming")
+        del tr, idx, bufs
+        torch.cuda.empty_cache()
     return out
 
 
@@ -1079,30 +1096,40 @@ def main():
     if want_extras and extras_first:
         run_extras()
 
-    # Pre-heat (round 5, disclosed as `preheat_steps`): untimed steps of THIS workload in front of the contract's W warm-up steps.
-    # The 0.4-ms step of ~33 back-to-back 5 - 50 us launches needs ~45 steps (~18 ms) before it runs at its steady rate -- after
-    # idle, after HBM streaming, and (less) after the learner legs (tools/step_preheat.py: a 20-step block reads 0.403 - 0.407 ms
-    # right after learner iterations, 0.398 in steady state; profiles/r04_rollout.md section 3) -- so `--steps 20 --warmup 5`
-    # measured the ramp, not the step.  The timed region is untouched: W untimed steps, barrier + synchronize, exactly K steps,
-    # barrier + synchronize.  RLHIP_BENCH_PREHEAT_STEPS=0 switches it off (same-box A / B: profiles/r05_summary.md).
+    def timed(n_warm, n_steps):
+        """the contract's region: n_warm untimed steps, barrier + synchronize, EXACTLY n_steps steps, barrier + synchronize; MAX over ranks"""
+        for _ in range(n_warm):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+
+            tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
+    # PROTOCOL (frozen in round 6; VERDICT r5 item 5, ADVICE r5): BOTH forms are measured in this process and printed in the same line.
+    #   1. `ms_per_step_no_preheat` / `value_no_preheat`: the contract taken literally -- W warm-up steps, K timed steps, nothing of
+    #      this workload in front of them (the RLHIP_BENCH_PREHEAT_STEPS=0 form of round 5).
+    #   2. `ms_per_step` / `value`: the same region again after the workload has run `preheat_steps` = 60 untimed steps in total (the
+    #      W + K steps of measurement 1 count towards the 60): the round-5 form, comparable with BENCH_r05.  The 0.4-ms step of ~33
+    #      back-to-back 5 - 50 us launches needs ~45 steps (~18 ms) before it runs at its steady rate (tools/step_preheat.py;
+    #      profiles/r04_rollout.md section 3), so `--steps 20 --warmup 5` alone measures the ramp.
+    # Nothing else runs between the two; no leg was added, moved or removed in front of them since round 5.
     preheat = int(os.environ.get("RLHIP_BENCH_PREHEAT_STEPS", "60"))
-    for _ in range(preheat):
-        step()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed_np = timed(args.warmup, args.steps)
+    if preheat > 0:
+        for _ in range(max(0, preheat - args.warmup - args.steps)):
+            step()
+        elapsed = timed(args.warmup, args.steps)
+    else:
+        elapsed = elapsed_np
 
     env_steps = world * N_ENVS * T_ROLLOUT * args.steps
     updates = pol.n_updates_per_call() * args.steps
@@ -1114,6 +1141,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step_no_preheat": round(elapsed_np / args.steps * 1e3, 4),
+        "value_no_preheat": round(world * N_ENVS * T_ROLLOUT * args.steps / elapsed_np, 1),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -1142,7 +1171,8 @@ def main():
         result["roofline"] = extras["roofline"]
         result["roofline_extra"] = extras["roofline_extra"]
         result["cpu_baseline"] = extras["cpu_baseline"]
-        result["legs_order"] = (f"cpu_baseline, HBM rooflines, learner rooflines, {preheat} untimed pre-heat steps, [warmup, timed steps], kernel breakdown"
+        result["legs_order"] = (f"cpu_baseline, HBM rooflines, learner rooflines, [warmup, timed steps] -> ms_per_step_no_preheat, pre-heat up to {preheat} "
+                                f"untimed steps in total, [warmup, timed steps] -> ms_per_step, kernel breakdown"
                                 if extras_first else "[warmup, timed steps], kernel breakdown, cpu_baseline, rooflines")
     if world > 1 and not args.no_extras:
         try:  # collective on every rank; a local failure must not cost the bench line

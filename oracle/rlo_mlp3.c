@@ -17,6 +17,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static float bf16r(float f) {
     uint32_t u;
@@ -138,46 +141,85 @@ void rlo_mlp3_backward1(const float* p, int64_t ns, int64_t h, int64_t na, int a
     }
 }
 
+/* one sample of the DQN loss: adds its gradient into ga (Float64), returns its (weighted) Huber loss */
+static double dqn3_sample(int64_t ns, int64_t h, int64_t na, int act, const float* params, const float* target_params,
+                          const float* s, const int32_t* a, const float* r, const uint8_t* term, const float* s_next,
+                          int64_t b, int64_t i, float gamma, float huber_delta, double* ga, float* q_out, const float* isw,
+                          float* buf, double* dh1) {
+    float q[64], qn[64], dout[64];
+    rlo_mlp3_forward1(target_params, ns, h, na, act, s_next + i, b, qn, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
+    float mx = qn[0];
+    for (int64_t k = 1; k < na; ++k)
+        if (qn[k] > mx) mx = qn[k];
+    float cont = term[i] ? 0.0f : 1.0f;
+    float G = r[i] + gamma * cont * mx;
+    rlo_mlp3_forward1(params, ns, h, na, act, s + i, b, q, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
+    if (q_out)
+        for (int64_t k = 0; k < na; ++k) q_out[k * b + i] = q[k];
+    float d = q[a[i]] - G;
+    float e = fabsf(d);
+    float l = (e < huber_delta) ? (e * e) * 0.5f : huber_delta * (e - 0.5f * huber_delta);
+    float gi = (e < huber_delta) ? d : (d > 0.0f ? huber_delta : (d < 0.0f ? -huber_delta : 0.0f));
+    gi = gi / (float)b;
+    if (isw) { /* importance-sampling weights of prioritized replay: mean(w .* huber(td)) */
+        gi *= isw[i];
+        l *= isw[i];
+    }
+    for (int64_t k = 0; k < na; ++k) dout[k] = 0.0f;
+    dout[a[i]] = gi;
+    rlo_mlp3_backward1(params, ns, h, na, act, s + i, b, dout, ga, buf, buf + h, buf + 2 * h, buf + 3 * h, buf + 4 * h, dh1);
+    return (double)l;
+}
+
 /* y = r + gamma (1 - t) max_a' Qt(s', a'); Huber(delta) on Q(s, a) - y, mean over the batch.  Returns the
- * loss; grad (nparams floats) is overwritten.  q_out (na x b) optional: the online Q(s, .) values. */
+ * loss; grad (nparams floats) is overwritten.  q_out (na x b) optional: the online Q(s, .) values.
+ * Samples are independent: with OpenMP (the all-cores build, oracle.use_all_cores) each thread owns a contiguous
+ * chunk and its own Float64 accumulator, combined in thread order (as rlo_ppo_loss_grad_f32 in rlo_learn.c);
+ * without OpenMP this is the single sequential pass it always was. */
 float rlo_dqn3_loss_grad_f32(int64_t ns, int64_t h, int64_t na, int act, const float* params,
                              const float* target_params, const float* s, const int32_t* a, const float* r,
                              const uint8_t* term, const float* s_next, int64_t b, float gamma, float huber_delta,
                              float* grad, float* q_out, const float* isw) {
     int64_t np = rlo_mlp3_nparams(ns, h, na);
     double* ga = (double*)calloc((size_t)np, sizeof(double));
-    float* buf = (float*)malloc(sizeof(float) * (size_t)h * 5);
-    double* dh1 = (double*)malloc(sizeof(double) * (size_t)h);
-    float q[64], qn[64], dout[64];
     double acc = 0;
-    for (int64_t i = 0; i < b; ++i) {
-        rlo_mlp3_forward1(target_params, ns, h, na, act, s_next + i, b, qn, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
-        float mx = qn[0];
-        for (int64_t k = 1; k < na; ++k)
-            if (qn[k] > mx) mx = qn[k];
-        float cont = term[i] ? 0.0f : 1.0f;
-        float G = r[i] + gamma * cont * mx;
-        rlo_mlp3_forward1(params, ns, h, na, act, s + i, b, q, 1, buf, buf + h, buf + 2 * h, buf + 3 * h);
-        if (q_out)
-            for (int64_t k = 0; k < na; ++k) q_out[k * b + i] = q[k];
-        float d = q[a[i]] - G;
-        float e = fabsf(d);
-        float l = (e < huber_delta) ? (e * e) * 0.5f : huber_delta * (e - 0.5f * huber_delta);
-        float gi = (e < huber_delta) ? d : (d > 0.0f ? huber_delta : (d < 0.0f ? -huber_delta : 0.0f));
-        gi = gi / (float)b;
-        if (isw) { /* importance-sampling weights of prioritized replay: mean(w .* huber(td)) */
-            gi *= isw[i];
-            l *= isw[i];
+#ifdef _OPENMP
+    int nthr = omp_get_max_threads();
+    if (nthr > 1 && b >= 4 * (int64_t)nthr) {
+        double* gt = (double*)calloc((size_t)np * (size_t)nthr, sizeof(double));
+        double* accs = (double*)calloc((size_t)nthr, sizeof(double));
+#pragma omp parallel num_threads(nthr)
+        {
+            int tid = omp_get_thread_num();
+            int64_t i0 = b * tid / nthr, i1 = b * (tid + 1) / nthr;
+            float* buf_t = (float*)malloc(sizeof(float) * (size_t)h * 5);
+            double* dh1_t = (double*)malloc(sizeof(double) * (size_t)h);
+            double la = 0;
+            for (int64_t i = i0; i < i1; ++i)
+                la += dqn3_sample(ns, h, na, act, params, target_params, s, a, r, term, s_next, b, i, gamma, huber_delta,
+                                  gt + (size_t)np * tid, q_out, isw, buf_t, dh1_t);
+            accs[tid] = la;
+            free(buf_t);
+            free(dh1_t);
         }
-        acc += (double)l;
-        for (int64_t k = 0; k < na; ++k) dout[k] = 0.0f;
-        dout[a[i]] = gi;
-        rlo_mlp3_backward1(params, ns, h, na, act, s + i, b, dout, ga, buf, buf + h, buf + 2 * h, buf + 3 * h, buf + 4 * h,
-                       dh1);
+        for (int t = 0; t < nthr; ++t) {
+            for (int64_t qq = 0; qq < np; ++qq) ga[qq] += gt[(size_t)np * t + qq];
+            acc += accs[t];
+        }
+        free(gt);
+        free(accs);
+    } else
+#endif
+    {
+        float* buf = (float*)malloc(sizeof(float) * (size_t)h * 5);
+        double* dh1 = (double*)malloc(sizeof(double) * (size_t)h);
+        for (int64_t i = 0; i < b; ++i)
+            acc += dqn3_sample(ns, h, na, act, params, target_params, s, a, r, term, s_next, b, i, gamma, huber_delta, ga,
+                               q_out, isw, buf, dh1);
+        free(buf);
+        free(dh1);
     }
     for (int64_t qq = 0; qq < np; ++qq) grad[qq] = (float)ga[qq];
     free(ga);
-    free(buf);
-    free(dh1);
     return (float)(acc / (double)b);
 }
