@@ -357,7 +357,13 @@ int32_t rlhip_ring_layout(const rlhip_ring* rb_host);
 int32_t rlhip_ring_init(rlhip_ring* rb_host, int64_t capacity, int64_t n_env, int64_t obs_dim,
                         int32_t elem_bytes, void* state, int32_t* action, float* reward,
                         uint8_t* terminal);
-/* push!(trajectory, (state = s,))   Agent PreEpisodeStage  agent_base.jl:45-47 */
+/* push!(trajectory, (state = s,))   Agent PreEpisodeStage  agent_base.jl:45-47.
+ * Protocol (checked before any counter of rb_host moves: a rejected call leaves the ring unchanged): the FIRST push is a state, every
+ * later push a transition -- rlhip_ring_push_transition[_maxpool] without an open state and rlhip_ring_push_state[_maxpool] while
+ * one is open (len_sa == len_rt + 1) return RLHIP_EINVAL.  The reference's EpisodesBuffer accepts a second PreEpisodeStage push by
+ * padding the (a, r, t) slot between the two episodes and excluding it from sampling; this ring has no such mask.  Vector envs
+ * auto-reset (one PreEpisode push per run); a single-instance host pushes the post-reset observation as s' of the terminal
+ * transition (which `terminal = 1` cuts from the TD target and from stacked histories). */
 int32_t rlhip_ring_push_state(rlhip_ring* rb_host, const void* obs, rlhip_stream_t stream);
 /* push!(trajectory, (state = s', action = a, reward = r, terminal = t))   PostActStage  :56-59 */
 int32_t rlhip_ring_push_transition(rlhip_ring* rb_host, const void* next_obs, const int32_t* action,

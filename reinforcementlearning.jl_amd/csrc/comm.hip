@@ -321,7 +321,7 @@ int32_t rlhip_p2p_setup(rlhip_comm_t comm, const uint8_t* handles_host, const in
         if (rc != RLHIP_OK || he != hipSuccess) {
             if (passed)
                 snprintf(c->why, sizeof(c->why), "self-test round %d: %s", k,
-                         rc != RLHIP_OK ? rlhip_last_error() : hipGetErrorString(he));
+                         he != hipSuccess ? hipGetErrorString(he) : rlhip_last_error());  // a failed copy set rc by hand: its text is HIP's
             (void)hipGetLastError();
             passed = false;
         } else if (c->status[0] != 0) {

@@ -202,6 +202,13 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // all 64 lanes
     return v + __shfl_xor(v, 32, 64);
 }
 
+// A word that ANOTHER workgroup of the same launch overwrites once every workgroup has counted its departure (the running powers
+// of Adam: read by all, advanced by the last one out).  The read-before-count order must hold in the instruction stream too: a
+// plain load of a __restrict__ pointer may legally be re-issued by the compiler BEHIND the relaxed departure atomic.
+// An atomic load is performed exactly once, where it stands; `depart_barrier()` keeps every earlier access in front of the count.
+__device__ __forceinline__ float load_once(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void depart_barrier() { asm volatile("" ::: "memory"); }
+
 // A store of a result that the NEXT launch reads (partial gradient rows, above all): device-scope write-through (sc1) instead of a
 // plain store.  With plain stores a kernel leaves its output as dirty lines in the eight L2s, and the end of the kernel has to write
 // them back before the next launch may start: measured on the headline's gradient kernel (3.4 MB of partial rows per launch), the

@@ -81,6 +81,7 @@ __device__ __forceinline__ void advance_beta_pow_last_out(float* beta_pow, float
     if (!departed) return;  // two-launch form: beta_pow_advance_kernel follows
     __syncthreads();  // every thread of this workgroup has read beta_pow
     if (threadIdx.x != 0) return;
+    depart_barrier();
     const unsigned int grid = gridDim.x, cls = blockIdx.x % DEPART_CLASSES;
     const unsigned int in_class = (grid - cls + DEPART_CLASSES - 1) / DEPART_CLASSES;  // workgroups b < grid with b mod 64 == cls
     unsigned int* c = departed + cls * DEPART_LINE_WORDS;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ beta_pow, int64_t n, float lr,
                                                    float b1, float b2, float eps, unsigned int* __restrict__ departed) {
-    float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    float c1 = 1.0f - load_once(beta_pow), c2 = 1.0f - load_once(beta_pow + 1);
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float pi = p[i], mi = m[i], vi = v[i];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         float* __restrict__ beta_pow, int64_t n, float lr,
                                                         float b1, float b2, float eps, unsigned int* __restrict__ departed) {
-    const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    const float c1 = 1.0f - load_once(beta_pow), c2 = 1.0f - load_once(beta_pow + 1);
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     // U 16-byte chunks per lane and iteration, `stride` apart (each chunk row stays coalesced): 4 U loads in flight per lane
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += (int64_t)U * stride) {
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void clip_adam_grid_kernel(float* __restrict__
     acc = block_sum(acc, scratch);
     const float gn = (float)sqrt(acc);
     const float scale = (clip_norm > 0.0f && clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
-    const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    const float c1 = 1.0f - load_once(beta_pow), c2 = 1.0f - load_once(beta_pow + 1);
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * grad_scale;
@@ -462,20 +463,26 @@ __global__ __launch_bounds__(256) void clip_adam_grid_kernel(float* __restrict__
         if (blockIdx.x == 0 && gn_out) gn_out[0] = gn;
         // (no release fence: nothing this workgroup stored is read by another workgroup of the launch, and an L2 write-back
         // on every workgroup's tail costs ~1 us per launch -- measured on reduce_apply_kernel, profiles/r03_tile_mfma.md)
-        unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
-            beta_pow[0] *= b1;
-            beta_pow[1] *= b2;
-            __hip_atomic_store(departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (departed) {  // (nullptr: no departure counter for this stream -- beta_pow_advance_kernel follows as its own launch)
+            depart_barrier();
+            unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
+                beta_pow[0] *= b1;
+                beta_pow[1] *= b2;
+                __hip_atomic_store(departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
 constexpr int DEPART_SLOTS = 64;
+constexpr int PARTIALS_PER_SLOT = 1024;
 struct Scratch {
-    double* partials = nullptr;  // 1024 doubles
-    float* scalars = nullptr;    // 4 floats
-    unsigned int* counter = nullptr;  // departure counters (zero between launches), one 64-byte slot per STREAM: launches of one
+    // one block of 1024 doubles per stream slot + a last, SHARED block for the streams beyond the slots (one buffer per
+    // device made two streams running the clipped update at once race on the norm partials)
+    double* partials = nullptr;
+    float* scalars = nullptr;    // 4 floats per slot (+ the shared block)
+    unsigned int* counter = nullptr;  // departure counters (zero between launches), one block per STREAM slot: launches of one
                                       // stream never overlap, launches of two streams must not share a counter
     hipStream_t stream_of[DEPART_SLOTS] = {};
     int n_streams = 0;
@@ -484,16 +491,20 @@ struct Scratch {
 static Scratch g_scratch[16];
 static std::mutex g_scratch_mutex;
 
-// the departure counter of `stream` on this device; nullptr when more than DEPART_SLOTS streams have asked (callers then take
-// their counter-free route)
-static unsigned int* depart_counter(Scratch& s, hipStream_t stream) {
+// the slot of `stream` on this device, -1 when more than DEPART_SLOTS distinct streams have asked.  A slot is never recycled (a
+// kernel of its stream may still be in flight); the callers of a slot-less stream take their counter-free, two-launch routes and
+// the shared scratch block -- slower, still correct for one slot-less stream at a time.
+static int stream_slot(Scratch& s, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     for (int i = 0; i < s.n_streams; ++i)
-        if (s.stream_of[i] == stream) return s.counter + (size_t)DEPART_BLOCK_WORDS * i;
-    if (s.n_streams == DEPART_SLOTS) return nullptr;
+        if (s.stream_of[i] == stream) return i;
+    if (s.n_streams == DEPART_SLOTS) return -1;
     s.stream_of[s.n_streams] = stream;
-    return s.counter + (size_t)DEPART_BLOCK_WORDS * s.n_streams++;
+    return s.n_streams++;
 }
+static unsigned int* slot_counter(Scratch& s, int slot) { return slot < 0 ? nullptr : s.counter + (size_t)DEPART_BLOCK_WORDS * slot; }
+static double* slot_partials(Scratch& s, int slot) { return s.partials + (size_t)PARTIALS_PER_SLOT * (slot < 0 ? DEPART_SLOTS : slot); }
+static float* slot_scalars(Scratch& s, int slot) { return s.scalars + 4 * (size_t)(slot < 0 ? DEPART_SLOTS : slot); }
 
 static int32_t get_scratch(Scratch** out) {
     int dev = 0;
@@ -501,8 +512,8 @@ static int32_t get_scratch(Scratch** out) {
     RLHIP_REQUIRE(dev >= 0 && dev < 16, "device index out of range");
     Scratch& s = g_scratch[dev];
     if (s.device != dev) {
-        RLHIP_CHECK_HIP(hipMalloc((void**)&s.partials, 1024 * sizeof(double)));
-        RLHIP_CHECK_HIP(hipMalloc((void**)&s.scalars, 4 * sizeof(float)));
+        RLHIP_CHECK_HIP(hipMalloc((void**)&s.partials, (size_t)PARTIALS_PER_SLOT * (DEPART_SLOTS + 1) * sizeof(double)));
+        RLHIP_CHECK_HIP(hipMalloc((void**)&s.scalars, 4 * (DEPART_SLOTS + 1) * sizeof(float)));
         RLHIP_CHECK_HIP(hipMalloc((void**)&s.counter, sizeof(unsigned int) * DEPART_BLOCK_WORDS * DEPART_SLOTS));
         RLHIP_CHECK_HIP(hipMemset(s.counter, 0, sizeof(unsigned int) * DEPART_BLOCK_WORDS * DEPART_SLOTS));
         s.device = dev;
@@ -562,12 +573,13 @@ int32_t rlhip_clip_by_global_norm_f32(float* grad, int64_t n, float clip_norm, f
     int32_t rc = get_scratch(&sc);
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
+    const int slot = stream_slot(*sc, s);
+    double* partials = slot_partials(*sc, slot);
+    float* scalars = slot_scalars(*sc, slot);
     int nb = grid_for(n > 0 ? n : 1, 256, 1024);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grad, n, sc->partials);
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, s, sc->partials, nb, clip_norm, gn_out,
-                       sc->scalars);
-    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n > 0 ? n : 1, 256)), dim3(256), 0, s, grad, n,
-                       sc->scalars);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grad, n, partials);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, s, partials, nb, clip_norm, gn_out, scalars);
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n > 0 ? n : 1, 256)), dim3(256), 0, s, grad, n, scalars);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
@@ -583,7 +595,7 @@ int32_t rlhip_adam_f32(float* params, const float* grad, float* m, float* v, flo
     // same-box A / B (tools/r5_c.sh): 2^22 parameters 21.2 us folded against 22.05 us in two launches; 2^26 parameters 342.5
     // against 339.5 -- 65536 departure atomics cost more than the second launch saves, even counted in two levels (with ONE
     // counter: 771 us)
-    unsigned int* dep = n <= ((int64_t)1 << 23) ? depart_counter(*sc, s) : nullptr;
+    unsigned int* dep = n <= ((int64_t)1 << 23) ? slot_counter(*sc, stream_slot(*sc, s)) : nullptr;
     if (n == 0 || !dep) {  // nothing to fold the advance into / two-launch form: the update, then `bt = bt .* b` on its own
         if (n > 0 && (rc = adam_launch(params, grad, m, v, beta_pow, n, lr, beta1, beta2, eps, nullptr, s))) return rc;
         hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);
@@ -606,11 +618,14 @@ int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, floa
         int32_t rc = get_scratch(&sc);
         if (rc) return rc;
         const int nb = grid_for(n, 256, 256);
-        hipLaunchKernelGGL(sumsq_scaled_partial_kernel, dim3(nb), dim3(256), 0, s, grad, n, grad_scale, sc->partials);
-        unsigned int* dep = depart_counter(*sc, s);
-        RLHIP_REQUIRE(dep != nullptr, "more than 64 streams drive the optimiser kernels of this device");
+        const int slot = stream_slot(*sc, s);  // resolved BEFORE anything is enqueued
+        double* partials = slot_partials(*sc, slot);
+        unsigned int* dep = slot_counter(*sc, slot);
+        hipLaunchKernelGGL(sumsq_scaled_partial_kernel, dim3(nb), dim3(256), 0, s, grad, n, grad_scale, partials);
         hipLaunchKernelGGL(clip_adam_grid_kernel, dim3(nb), dim3(256), 0, s, params, grad, m, v, beta_pow, n, grad_scale,
-                           clip_norm, lr, beta1, beta2, eps, sc->partials, nb, dep, gn_out);
+                           clip_norm, lr, beta1, beta2, eps, partials, nb, dep, gn_out);
+        if (!dep)  // a 65th stream: no departure counter -- `bt = bt .* b` as its own launch behind the update
+            hipLaunchKernelGGL(beta_pow_advance_kernel, dim3(1), dim3(1), 0, s, beta_pow, beta1, beta2);
         RLHIP_LAUNCH_CHECK();
         return RLHIP_OK;
     }
@@ -665,8 +680,9 @@ int32_t rlhip_huber_f32(const float* q, const float* target, int64_t n, float de
     if (rc) return rc;
     hipStream_t s = as_stream(stream);
     int nb = grid_for(n, 256, 1024);
-    hipLaunchKernelGGL(huber_partial_kernel, dim3(nb), dim3(256), 0, s, q, target, n, delta, dq, sc->partials);
-    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, s, sc->partials, nb, n, loss_out);
+    double* partials = slot_partials(*sc, stream_slot(*sc, s));
+    hipLaunchKernelGGL(huber_partial_kernel, dim3(nb), dim3(256), 0, s, q, target, n, delta, dq, partials);
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, s, partials, nb, n, loss_out);
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }

@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
     acc = block_sum_f64_dpp(acc, scratch);
     const float gn = (float)sqrt(acc);
     const float scale = (clip_norm > 0.0f && clip_norm <= gn) ? clip_norm / fmaxf(clip_norm, gn) : 1.0f;
-    const float c1 = 1.0f - beta_pow[0], c2 = 1.0f - beta_pow[1];
+    const float c1 = 1.0f - load_once(beta_pow), c2 = 1.0f - load_once(beta_pow + 1);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < np; i0 += W3T_EPT * stride) {
         float gv[W3T_EPT], pv[W3T_EPT], mv[W3T_EPT], vv[W3T_EPT];
@@ -1263,6 +1263,7 @@ __global__ __launch_bounds__(256) void ppo3w_adam_pack_kernel(float* __restrict_
     if (threadIdx.x == 0) {
         if (blockIdx.x == 0 && gn_out) gn_out[0] = gn;
         // (no release fence: nothing this workgroup stored is read by another workgroup of the launch)
+        depart_barrier();
         const unsigned int prev = __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {  // last one out: nobody reads beta_pow any more
             beta_pow[0] *= b1;

@@ -518,14 +518,30 @@ int64_t rlhip_ring_state_bytes(int64_t capacity, int64_t n_env, int64_t obs_dim,
 
 int32_t rlhip_ring_layout(const rlhip_ring* rb) { return rb ? rb->layout : -1; }
 
+// The push protocol (RLCore/src/policies/agent/agent_base.jl:45-59; length semantics RLCore/test/policies/agent.jl:27-34), checked
+// BEFORE any host counter moves so that a rejected call leaves the ring as it was:
+//   * a transition completes the open state: the first push must be a state (len_sa == len_rt + 1 holds from then on);
+//   * a second state push while one is open would shift `next_state[i] = state[i + 1]` for every later transition and leave a
+//     sampleable slot whose (a, r, t, s') were never written.  The reference's EpisodesBuffer pads such a slot and marks it
+//     non-sampleable; this ring has no such mask, so the call is rejected: vector envs auto-reset (one PreEpisode push for the
+//     whole run), and a single env pushes the post-reset observation as s' of its terminal transition.
+#define RLHIP_RING_REQUIRE_OPEN_STATE(rb) \
+    RLHIP_REQUIRE((rb)->len_sa == (rb)->len_rt + 1, "push the first state (rlhip_ring_push_state) before the first transition")
+#define RLHIP_RING_REQUIRE_NO_OPEN_STATE(rb)                                                                                   \
+    RLHIP_REQUIRE((rb)->len_sa == (rb)->len_rt,                                                                                \
+                  "a state is already open (len_sa == len_rt + 1): complete it with rlhip_ring_push_transition; this ring has no " \
+                  "pad-and-exclude slot for a second PreEpisodeStage push (see include/rlhip.h)")
+
 int32_t rlhip_ring_push_state(rlhip_ring* rb, const void* obs, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb != nullptr && obs != nullptr, "NULL argument");
+    RLHIP_RING_REQUIRE_NO_OPEN_STATE(rb);
     return push_state_frame(rb, obs, as_stream(stream));
 }
 
 int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const int32_t* action,
                                    const float* reward, const uint8_t* terminal, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb && next_obs && action && reward && terminal, "NULL argument");
+    RLHIP_RING_REQUIRE_OPEN_STATE(rb);
     hipStream_t s = as_stream(stream);
     int64_t frames = rb->capacity, n = rb->n_env, phys;
     if (rb->len_rt < frames) {
@@ -541,7 +557,6 @@ int32_t rlhip_ring_push_transition(rlhip_ring* rb, const void* next_obs, const i
     const int64_t sphys = (rb->len_sa < sframes) ? (rb->head_sa + rb->len_sa) % sframes : rb->head_sa;
     uint8_t* sdst = (uint8_t*)rb->state + sphys * fbytes;
     if (rb->layout == RLHIP_RING_RECORDS) {  // completes the previous slot's record, opens the new one: transposing push, one launch
-        RLHIP_REQUIRE(rb->len_sa >= 1, "push the first state before the first transition");
         if (rb->len_sa < sframes) rb->len_sa += 1;
         else rb->head_sa = (rb->head_sa + 1) % sframes;
         return push_record(rb->state, sphys, (sphys + sframes - 1) % sframes, (const float*)next_obs, n, rb->obs_dim, action,
@@ -717,6 +732,7 @@ static int32_t maxpool_into_next_state_slot(rlhip_ring* rb, const void* s1, cons
 
 int32_t rlhip_ring_push_state_maxpool(rlhip_ring* rb, const void* screen1, const void* screen2, rlhip_stream_t stream) {
     RLHIP_REQUIRE(rb && screen1 && screen2, "NULL argument");
+    RLHIP_RING_REQUIRE_NO_OPEN_STATE(rb);
     return maxpool_into_next_state_slot(rb, screen1, screen2, as_stream(stream));
 }
 
@@ -729,6 +745,7 @@ int32_t rlhip_ring_push_transition_maxpool(rlhip_ring* rb, const void* screen1, 
     const int64_t fbytes = rb->obs_dim * rb->n_env;
     RLHIP_REQUIRE(fbytes % 16 == 0 && ((((uintptr_t)screen1 | (uintptr_t)screen2 | (uintptr_t)rb->state) & 15) == 0),
                   "frames must be 16-byte aligned multiples of 16 bytes");
+    RLHIP_RING_REQUIRE_OPEN_STATE(rb);
     int64_t frames = rb->capacity, n = rb->n_env, phys;
     if (rb->len_rt < frames) {
         phys = (rb->head_rt + rb->len_rt) % frames;

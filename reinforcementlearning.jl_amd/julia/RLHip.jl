@@ -373,7 +373,7 @@ function HipTrajectory(; capacity, n_env, obs_dim, batchsize = 32, E = Float32, 
                        controller = InsertSampleRatioController())
     rb = Ring()
     bytes = ccall((:rlhip_ring_state_bytes, LIB), Int64, (Int64, Int64, Int64, Int32), capacity, n_env, obs_dim, sizeof(E))
-    records = E === Float32 && obs_dim <= 4
+    records = sizeof(E) == 4 && obs_dim <= 4   # the C side's rule (csrc/ring_device.h ring_records: elem_bytes == 4 && obs_dim <= 4)
     st = DevBuf{E}(bytes ÷ sizeof(E))
     a, r, t = records ? (DevBuf{Int32}(0), DevBuf{Float32}(0), DevBuf{UInt8}(0)) :
               (DevBuf{Int32}(capacity * n_env), DevBuf{Float32}(capacity * n_env), DevBuf{UInt8}(capacity * n_env))

@@ -296,3 +296,78 @@ def test_ppo_workspace_is_sized_and_checked():
     call("rlhip_ppo_workspace_release", ptr(raw))
     with pytest.raises(RLHipArgumentError, match="never registered"):
         call("rlhip_ppo_update_f32", *args, ptr(raw), ptr(pol.grad), ptr(pol.losses), stream_ptr())
+
+
+def test_optimiser_kernels_on_more_streams_than_departure_slots():
+    """the optimiser kernels keep one departure-counter slot (and, since round 6, one block of norm partials) per
+    stream; a 65th distinct stream used to fail `rlhip_clip_adam_f32` with EINVAL after its first launch was already enqueued
+    (and `rlhip_adam_f32` silently changed form).  Now every call resolves its slot before it enqueues anything and a slot-less
+    stream takes the counter-free two-launch route: 70 streams, each result bit-identical to the default stream's."""
+    from rlhip import ops
+
+    n_big, n_small = 50000, 3000   # clip_adam's grid route (> 12 k parameters) / adam's folded beta-power advance
+    g = torch.Generator(device="cpu").manual_seed(3)
+    p0, g0 = torch.randn(n_big, generator=g).cuda(), torch.randn(n_big, generator=g).cuda()
+
+    def run(stream):
+        with torch.cuda.stream(stream):
+            p, gr, m, v = p0.clone(), g0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+            bp, gn = torch.tensor([0.9, 0.999], device="cuda"), torch.zeros(1, device="cuda")
+            for _ in range(3):
+                ops.clip_adam_(p, gr, m, v, bp, 0.5, 1.0, 1e-2, 0.9, 0.999, 1e-8, gn)
+            q, mq, vq = p0[:n_small].clone(), torch.zeros(n_small, device="cuda"), torch.zeros(n_small, device="cuda")
+            bq = torch.tensor([0.9, 0.999], device="cuda")
+            for _ in range(2):
+                ops.adam_(q, g0[:n_small].contiguous(), mq, vq, bq)
+            g2 = g0.clone()
+            gn2 = ops.clip_by_global_norm_(g2, 0.7) if hasattr(ops, "clip_by_global_norm_") else None
+        stream.synchronize()
+        return p, m, v, bp, gn, q, bq, g2
+
+    ref = run(torch.cuda.current_stream())
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    for s in streams:
+        out = run(s)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    assert abs(float(ref[3][0]) - 0.9 ** 4) < 1e-6 and abs(float(ref[6][0]) - 0.9 ** 3) < 1e-6
+
+
+def test_rejected_push_leaves_the_ring_untouched():
+    """the push protocol is checked before any host counter moves (a transition without an open state, a second state
+    while one is open -> RLHIP_EINVAL, counters as before), for both ring layouts and the max-pool pushes."""
+    import rlhip
+    from rlhip._lib import RLHipError
+
+    for kw, frame in ((dict(obs_dim=4), torch.zeros((4, 3), device="cuda")),
+                      (dict(obs_dim=32, dtype=torch.uint8), torch.zeros((32, 3), dtype=torch.uint8, device="cuda"))):
+        tr = rlhip.CircularArraySARTSTraces(capacity=5, n_env=3, **kw)
+        a = torch.zeros(3, dtype=torch.int32, device="cuda")
+        r = torch.zeros(3, device="cuda")
+        t = torch.zeros(3, dtype=torch.uint8, device="cuda")
+
+        def counters():
+            return (tr.rb.head_sa, tr.rb.len_sa, tr.rb.head_rt, tr.rb.len_rt)
+
+        with pytest.raises(RLHipError):
+            tr.push_transition_(frame, a, r, t)          # no state yet
+        assert counters() == (0, 0, 0, 0) and len(tr) == 0
+        tr.push_state_(frame)
+        assert counters() == (0, 1, 0, 0) and len(tr) == 0   # RLCore/test/policies/agent.jl:27-34
+        with pytest.raises(RLHipError):
+            tr.push_state_(frame)                        # a state is already open
+        assert counters() == (0, 1, 0, 0)
+        for _ in range(7):                               # past the wrap
+            tr.push_transition_(frame, a, r, t)
+        before = counters()
+        with pytest.raises(RLHipError):
+            tr.push_state_(frame)
+        assert counters() == before and len(tr) == 5
+        if kw.get("dtype") == torch.uint8:
+            with pytest.raises(RLHipError):
+                tr.push_state_maxpool_(frame, frame)
+            assert counters() == before
+            tr2 = rlhip.CircularArraySARTSTraces(capacity=5, n_env=3, **kw)
+            with pytest.raises(RLHipError):
+                tr2.push_transition_maxpool_(frame, frame, a, r, t)
+            assert (tr2.rb.len_sa, tr2.rb.len_rt) == (0, 0)

@@ -1,0 +1,76 @@
+"""The learners LEARN ("next round" item 4): until round 6 only the Float32 two-layer PPO (tests/test_gpu_learners.py) and
+the three-layer PPO on CartPole (tests/test_gpu_ppo3w.py) asserted an improving policy; the DQN tests checked counters and "the
+parameters moved", and neither bf16 learner was shown to learn Pendulum.  Everything here is deterministic (Philox streams, fixed
+summation orders): the curves below are reproduced bit for bit on every run of the same build.
+
+  DQN     BASELINE configs[1]: 4096 CartPole envs, QBasedPolicy(DQN), eps-greedy exp (eps_stable 0.01, decay 500), gamma 0.99, Huber 1,
+          Adam 1e-3, ring of 256 x 4096 transitions, batch 512, one update per vec-step, hard target sync every 100 -- through the fused
+          vec-step (`rlhip_dqn_vec_step_f32`), two-layer Float32 and three-layer bf16-MFMA Q-networks.  Mean episode length of the last
+          256 vec-steps (ring content) against a uniformly random policy's on the same env (~22 steps).
+  PPO     BASELINE configs[2]: 4096 Pendulum envs, T = 128, clip 0.1, 4 x 4 micro-batches of 131072, three-layer actor / critic of
+          width 128 (`ppo3_gradT_kernel`) and 256 (csrc/ppo3w.hip).  Mean reward per step of an iteration's 524288 transitions
+          (x 200 = the mean episode return).
+Measured curves (round 6, `tools/r6_learn_probe.py`) are in profiles/r06_parity_margins.md."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from test_gpu_bench_shapes import note  # noqa: E402
+
+
+def _random_policy_episode_length(rl, n=4096, steps=256):
+    env = rl.CartPoleEnv(n, seed=5)
+    hook = rl.DeviceEpisodeStats(n)
+    rl.run(rl.RandomPolicy(env.action_space(), seed=5), env, rl.StopAfterNSteps(steps), hook)
+    rec = hook.records()
+    return float(rec["steps"].mean())
+
+
+@pytest.mark.parametrize("layers,vec_steps", [(2, 6500), (3, 3000)])
+def test_dqn_learns_cartpole(layers, vec_steps):
+    import rlhip as rl
+
+    n, cap, chunk = 4096, 256, 500
+    base = _random_policy_episode_length(rl)
+    assert 15.0 < base < 30.0, base
+    env = rl.CartPoleEnv(n, seed=5)
+    net = rl.HipApproximator(4, 128, 2, seed=5, layers=layers)
+    learner = rl.DQNLearner(rl.TargetNetwork(net, sync_freq=100), batchsize=512, min_replay_history=n, seed=5)
+    policy = rl.QBasedPolicy(learner, rl.EpsilonGreedyExplorer(0.01, kind="exp", decay_steps=500, seed=5))
+    tr = rl.CircularArraySARTSTraces(capacity=cap, n_env=n, obs_dim=4)
+    agent = rl.Agent(policy, rl.Trajectory(tr))
+    curve = []
+    for _ in range(vec_steps // chunk):
+        rl.run_fused_dqn(agent, env, rl.StopAfterNSteps(chunk))
+        idx = torch.arange(len(tr) * n, device="cuda")
+        term = tr.gather(idx)[3]
+        curve.append(round(len(tr) * n / max(1.0, float(term.sum())), 1))
+    note(f"DQN learns CartPole, layers={layers}", random_policy_ep_len=round(base, 1), ep_len_per_500_vec_steps=curve,
+         updates=learner.n_updates)
+    assert learner.n_updates == (vec_steps // chunk) * chunk and torch.isfinite(net.params).all()
+    best = max(curve)
+    assert best >= 2.0 * base, f"mean episode length never reached 2 x the random policy's {base:.1f}: {curve}"
+    assert sum(c >= 2.0 * base for c in curve) >= 3, f"fewer than three 500-step windows above 2 x random ({base:.1f}): {curve}"
+
+
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_three_layer_ppo_learns_pendulum(hidden):
+    import rlhip as rl
+
+    n, T, iters = 4096, 128, 60
+    env = rl.HipVecEnv("pendulum", n, seed=7)
+    pol = rl.PPOPolicy(env, update_freq=T, hidden=hidden, seed=7, clip_range=0.1, layers=3)
+    rew = []
+    for _ in range(iters):
+        pol.rollout_()
+        pol.update_()
+        rew.append(float(pol.trajectory.reward.mean()))
+    first, last = sum(rew[:3]) / 3, sum(rew[-10:]) / 10
+    note(f"3-layer PPO learns Pendulum, hidden={hidden}", mean_reward_per_step_first3=round(first, 3), last10=round(last, 3),
+         mean_return_first3=round(200 * first, 1), mean_return_last10=round(200 * last, 1),
+         every_5th=[round(r, 3) for r in rew[::5]])
+    assert torch.isfinite(pol.params).all()
+    assert first < -5.0, first                      # an untrained policy: ~ -6 per step (~ -1200 per 200-step episode)
+    assert last > 0.6 * first, f"mean reward per step {first:.2f} -> {last:.2f} over {iters} iterations"

@@ -210,7 +210,7 @@ def test_fused_sample_gather_equals_the_two_launches(layout):
 
     if layout == "frames_u8":
         cap, n_env, od, dt = 300, 1, 84 * 84, torch.uint8
-    elif layout == "frames_u8_big_tree":  # >= 2^12 leaves: batches <= 512 descend through the LDS copy of the tree's top levels
+    elif layout == "frames_u8_big_tree":  # >= 2^12 leaves: a 13-level tree, drawn by a whole wavefront four levels per round trip (csrc/ring.hip)
         cap, n_env, od, dt = 5000, 1, 84 * 84, torch.uint8
     elif layout == "cartpole_f32":
         cap, n_env, od, dt = 64, 37, 4, torch.float32
