@@ -140,12 +140,12 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
 PMC_TRAFFIC = {"sha": "23d6334bde658716", "n_envs": 1 << 24, "bytes": 822221824.0, "source": "profiles/r05_pmc.md"}
 
 # The same for the other HBM-bound kernels of the bench line: HBM bytes per launch from the PMC counters
-# (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, mean of the last launches: tools/r5_pmc.sh), each valid only while the
+# (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, mean of the last launches: tools/pmc_all.sh), each valid only while the
 # sources of ITS kernel still hash to what was profiled (`files`, sha256[:16] over them) -- otherwise the entry reports null.
 # `fetch_x2: False`: a kernel of scattered 16-byte reads, for which the guide's x 2 streaming calibration of FETCH_SIZE does not
 # hold (profiles/r05_pmc.md: the counter tallies 64 bytes per fabric request whatever its size).
 PMC_SIDE = {
-    # name in the line: (source files, sha over them, bytes per launch, note)      -- tools/r5_pmc.sh on the final sources of round 5
+    # name in the line: (source files, sha over them, bytes per launch, note)      -- tools/pmc_all.sh on the final sources of round 5
     "gae_returns": (["scans.hip", "gae_device.h"], "a163648c638b5c15", 574705664.0, ""),
     "frame_gather_u8": (["ring.hip", "ring_device.h"], "6dc223a112b6b8e4", 474173542.4, ""),
     "frame_gather_u8_stack_at_sample": (["ring.hip", "ring_device.h"], "6dc223a112b6b8e4", 387112857.6, ""),
@@ -368,7 +368,7 @@ def roofline_extras(torch, rlhip, hbm_only=False):
         "samples_per_sec": round(batch / (ms * 1e-3), 1)}
     del tr1, outs, idx1
     torch.cuda.empty_cache()
-    if hbm_only:  # tools/r5_pmc_all.py: the HBM-bound legs alone, for the PMC traffic passes
+    if hbm_only:  # tools/pmc_all.py: the HBM-bound legs alone, for the PMC traffic passes
         return out
     # BASELINE configs[1]: 4096-way CartPole + QBasedPolicy(DQN, 4->128->2), batch 512, 1 update per vec-step
     n = N_ENVS

@@ -312,6 +312,14 @@ int32_t rlhip_td_target_f32(const float* qt_next, int64_t na, int64_t n, int64_t
                             int64_t i_stride, const float* reward, const uint8_t* terminal,
                             float gamma, float* target, rlhip_stream_t stream);
 
+/* n-step form (R = r + gamma^n (1 - t) max_a' Qt(s_{i+n}, a')): reward = the n-step returns, terminal = any terminal
+ * inside the window (both from rlhip_ring_fold_nstep), gamma^n = rlhip_gamma_pow(gamma, n_step) */
+int32_t rlhip_td_target_n_f32(const float* qt_next, int64_t na, int64_t n, int64_t k_stride,
+                              int64_t i_stride, const float* reward, const uint8_t* terminal,
+                              float gamma, int32_t n_step, float* target, rlhip_stream_t stream);
+/* gamma^n as the n-step learners use it: evaluated in Float64 and rounded once (Julia's `gamma^n` for a Float32 gamma) */
+float rlhip_gamma_pow(float gamma, int32_t n);
+
 /* -------------------------------------------------------------------------- replay ring -- */
 /* CircularArraySARTSTraces(; capacity, state = Float32 => (obs_dim, n_env), action = Int32 => (n_env,),
  * reward = Float32 => (n_env,), terminal = Bool => (n_env,)) resident in HBM
@@ -384,6 +392,24 @@ int32_t rlhip_ring_gather_is_frame_major(const rlhip_ring* rb_host);
 int32_t rlhip_ring_gather(const rlhip_ring* rb_host, const int64_t* idx, int64_t batch, void* s,
                           int32_t* a, float* r, uint8_t* term, void* s_next,
                           rlhip_stream_t stream);
+
+/* n-step transitions -- NStepBatchSampler(n, gamma, batchsize) of RLTrajectories 0.4 (un-vendored: PARITY UNPINNED; the published
+ * algorithm is restated in oracle/rlo_buffer.c).  Record rings only (Float32 observations with <= 4 components).
+ *   rlhip_ring_sample_indices_nstep   inds = rand(rng, 1:(length - n + 1), batchsize) per env: flat logical START indices
+ *                                     (li * n_env + e with li <= length - n_step), same Philox draw as rlhip_ring_sample_indices.
+ *   rlhip_ring_fold_nstep             for every start index the window li .. li + ns - 1 (ns = n_step, or up to and including the
+ *                                     first terminal step) folded into ONE transition {s_li, a_li, R, any(terminal), s_{li + ns}},
+ *                                     R = discount_rewards_reduced(rewards[window], gamma) (RLCore/src/utils/basic.jl:237-319:
+ *                                     r_0 + gamma (r_1 + gamma (...)), Float32), written as the `batch` records of slot 0 of `folded`
+ *                                     -- a record ring from rlhip_ring_init(capacity >= 1, n_env = batch, obs_dim) whose host
+ *                                     counters are set to "one stored vec-step".  Every DQN gradient entry point then runs unchanged:
+ *                                         rlhip_dqn_grad_idx_f32(folded, ..., idx = iota_out, gamma = rlhip_gamma_pow(gamma, n_step), ...)
+ *                                     (likewise _idx_w_, rlhip_dqn3_grad[_w]_f32 with idx).  iota_out (nullable): 0 .. batch - 1.
+ *                                     n_step in 1..32; n_step = 1 reproduces the stored transitions bit for bit. */
+int32_t rlhip_ring_sample_indices_nstep(const rlhip_ring* rb_host, int64_t batch, int32_t n_step, uint64_t seed,
+                                        uint32_t draw_ctr, int64_t* idx_out, rlhip_stream_t stream);
+int32_t rlhip_ring_fold_nstep(const rlhip_ring* rb_host, const int64_t* idx, int64_t batch, int32_t n_step, float gamma,
+                              rlhip_ring* folded_host, int64_t* iota_out, rlhip_stream_t stream);
 
 /* Debugging aid ("a debug build that bounds-checks gather indices"; the reference's `traces[inds]` throws a
  * BoundsError): how many of the flat logical indices idx[0 .. batch) lie outside [0, length(trajectory) * n_env), and the position

@@ -29,11 +29,11 @@ class DQNRun:
     def __init__(self, kind="cartpole", n=4096, ns=4, na=2, hidden=128, act=0, env_seed=5, net_seed=5, explorer_seed=5,
                  sampler_seed=5, capacity=256, batch=512, gamma=0.99, huber_delta=1.0, lr=1e-3, beta1=0.9, beta2=0.999,
                  adam_eps=1e-8, max_grad_norm=0.0, sync_freq=100, rho=0.0, min_replay_history=None, update_freq=1,
-                 eps_stable=0.01, eps_kind="exp", eps_init=1.0, warmup_steps=0, decay_steps=500, env_id_base=0, params=None, layers=2):
+                 eps_stable=0.01, eps_kind="exp", eps_init=1.0, warmup_steps=0, decay_steps=500, env_id_base=0, params=None, layers=2, n_step=1):
         """layers = 3: the blog's Chain(Dense(ns, h, act), Dense(h, h, act), Dense(h, na)) with the bf16 hidden layer of rlo_mlp3.c"""
         self.env = B.VecEnv(kind, n, seed=env_seed, env_id_base=env_id_base, continuous=False)
         self.n, self.ns, self.na, self.h, self.act = n, ns, na, hidden, act
-        self.layers = layers
+        self.layers, self.n_step = layers, n_step   # n_step > 1: NStepBatchSampler + gamma^n target (rlo_buffer.c)
         self._init, self._fwd = (B.mlp2_init, B.mlp2_forward) if layers == 2 else (B.mlp3_init, B.mlp3_forward)
         self.params = self._init(ns, hidden, na, net_seed, 0) if params is None else np.array(params, np.float32)
         self.target = self.params.copy()                      # TargetNetwork: deepcopy of the model (target_network.jl:56-58)
@@ -91,13 +91,21 @@ class DQNRun:
         self.vec_steps += 1
         updated = False
         if len(self.ring) * self.n >= self.min_replay_history and self.vec_steps % self.update_freq == 0 and self._controller_allows():
-            idx = self.ring.sample_indices(self.batch, self.sampler_seed, self.draw_ctr)
-            self.draw_ctr += 1
-            s, a, r, t, sn = self.ring.gather(idx)
-            if self.layers == 2:
-                loss, g = B.dqn_loss_grad(self.ns, self.h, self.na, self.act, self.params, self.target, s, a, r, t, sn, self.gamma, self.delta)
+            if self.n_step > 1 and len(self.ring) < self.n_step:
+                return False
+            gamma = self.gamma
+            if self.n_step > 1:
+                idx = B.ring_sample_indices_nstep(self.ring, self.batch, self.n_step, self.sampler_seed, self.draw_ctr)
+                s, a, r, t, sn = B.ring_gather_nstep(self.ring, idx, self.n_step, self.gamma)
+                gamma = B.gamma_pow(self.gamma, self.n_step)
             else:
-                loss, g, _ = B.dqn3_loss_grad(self.ns, self.h, self.na, self.act, self.params, self.target, s, a, r, t, sn, self.gamma, self.delta)
+                idx = self.ring.sample_indices(self.batch, self.sampler_seed, self.draw_ctr)
+                s, a, r, t, sn = self.ring.gather(idx)
+            self.draw_ctr += 1
+            if self.layers == 2:
+                loss, g = B.dqn_loss_grad(self.ns, self.h, self.na, self.act, self.params, self.target, s, a, r, t, sn, gamma, self.delta)
+            else:
+                loss, g, _ = B.dqn3_loss_grad(self.ns, self.h, self.na, self.act, self.params, self.target, s, a, r, t, sn, gamma, self.delta)
             if self.max_grad_norm > 0.0:
                 B.clip_by_global_norm(g, self.max_grad_norm)
             B.adam(self.params, g, self.m, self.v, self.lr, self.beta1, self.beta2, self.adam_eps, self.n_updates + 1)

@@ -487,6 +487,30 @@ class Ring:
         return s, a, r, t, sn
 
 
+def ring_sample_indices_nstep(ring, batch, n_step, seed, draw_ctr):
+    idx = np.empty(batch, np.int64)
+    lib().rlo_ring_sample_indices_nstep(C.byref(ring.rb), C.c_int64(batch), C.c_int64(n_step), C.c_uint64(seed),
+                                        C.c_uint32(draw_ctr), _p(idx))
+    return idx
+
+
+def ring_gather_nstep(ring, idx, n_step, gamma):
+    """-> (s, a, R, t, s_n): the n-step transitions starting at the flat logical indices idx (NStepBatchSampler)"""
+    b, d = len(idx), ring.rb.obs_dim
+    s, sn = np.empty((d, b), np.float32), np.empty((d, b), np.float32)
+    a, r, t = np.empty(b, np.int32), np.empty(b, np.float32), np.empty(b, np.uint8)
+    idx = np.ascontiguousarray(idx, np.int64)
+    lib().rlo_ring_gather_nstep(C.byref(ring.rb), _p(idx), C.c_int64(b), C.c_int64(n_step), C.c_float(gamma), _p(s), _p(a),
+                                _p(r), _p(t), _p(sn))
+    return s, a, r, t, sn
+
+
+def gamma_pow(gamma, n):
+    f = lib().rlo_gamma_pow
+    f.restype = C.c_float
+    return float(f(C.c_float(gamma), C.c_int64(n)))
+
+
 class SumTree:
     """priority sum-tree (rlo_buffer.c); leaves keyed 0-based"""
 

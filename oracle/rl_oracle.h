@@ -301,6 +301,12 @@ void rlo_ring_sample_prioritized(const rlo_ring* rb, const float* tree, int64_t 
                                  uint32_t draw_ctr, int64_t* flat_idx, int64_t* key_out, float* prio_out);
 
 /* stack-at-sample gather for single-env frame rings (StackFrames semantics, rlo_buffer.c) */
+/* n-step transitions (NStepBatchSampler; rlo_buffer.c) */
+void rlo_ring_sample_indices_nstep(const rlo_ring* rb, int64_t batch, int64_t n_step, uint64_t seed, uint32_t draw_ctr,
+                                   int64_t* flat_idx);
+void rlo_ring_gather_nstep(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, int64_t n_step, float gamma, float* s,
+                           int32_t* a, float* r, uint8_t* term, float* s_next);
+float rlo_gamma_pow(float gamma, int64_t n);
 void rlo_ring_gather_stacked(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, int64_t n_stack, float* s,
                              int32_t* a, float* r, uint8_t* term, float* s_next);
 

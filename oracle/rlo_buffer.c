@@ -97,6 +97,56 @@ void rlo_ring_gather(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch,
     }
 }
 
+/* ------------------------------------------------------------------ n-step transitions --
+ * NStepBatchSampler(n, gamma, batchsize) of RLTrajectories 0.4 (un-vendored; PARITY UNPINNED -- spec: SURVEY.md row L2
+ * `R = r + gamma^n (1 - t) max Qt(s')`, blog an_introduction_.../index.md:320-331).  Published algorithm restated:
+ *   valid start indices are those with n transitions ahead of them: inds = rand(rng, 1:(length - n + 1), batchsize);
+ *   state, action        of the start step;
+ *   the window           steps i .. i + ns - 1, ns = n unless a terminal flag cuts it short (its step is the last one);
+ *   reward               foldr((x, y) -> x + gamma * y, rewards[window])  = discount_rewards_reduced over the window
+ *                        (RLCore/src/utils/basic.jl:237-319: gain = r[i] + gamma * gain from the window's end, Float32);
+ *   terminal             any(terminal[window]);
+ *   next_state           state[i + ns].
+ * Vector-env ring: start li in [0, len_rt - n], env e; the draw is the uniform sampler's over (len_rt - n + 1) * n_env. */
+void rlo_ring_sample_indices_nstep(const rlo_ring* rb, int64_t batch, int64_t n_step, uint64_t seed, uint32_t draw_ctr,
+                                   int64_t* flat_idx) {
+    uint64_t total = (uint64_t)(rb->len_rt - n_step + 1) * (uint64_t)rb->n_env;
+    for (int64_t b = 0; b < batch; ++b) {
+        uint32_t w[4];
+        rlo_philox4x32_10(seed, (uint32_t)b, 0, draw_ctr, RLO_TAG_SAMPLER, w);
+        uint64_t x = ((uint64_t)w[0] << 32) | (uint64_t)w[1];
+        flat_idx[b] = (int64_t)(((unsigned __int128)x * (unsigned __int128)total) >> 64);
+    }
+}
+
+void rlo_ring_gather_nstep(const rlo_ring* rb, const int64_t* flat_idx, int64_t batch, int64_t n_step, float gamma, float* s,
+                           int32_t* a, float* r, uint8_t* term, float* s_next) {
+    int64_t n = rb->n_env, d = rb->obs_dim;
+    for (int64_t b = 0; b < batch; ++b) {
+        int64_t li = flat_idx[b] / n, e = flat_idx[b] % n;
+        int64_t ns = 0;
+        uint8_t t = 0;
+        while (ns < n_step && li + ns < rb->len_rt) { /* (a window never runs past the newest stored transition) */
+            t = rb->terminal[((rb->head_rt + li + ns) % rb->capacity) * n + e];
+            ns += 1;
+            if (t) break;
+        }
+        float gain = 0.0f;
+        for (int64_t k = ns - 1; k >= 0; --k) gain = rb->reward[((rb->head_rt + li + k) % rb->capacity) * n + e] + gamma * gain;
+        int64_t ps = (rb->head_sa + li) % (rb->capacity + 1), pn = (rb->head_sa + li + ns) % (rb->capacity + 1);
+        for (int64_t k = 0; k < d; ++k) {
+            s[k * batch + b] = rb->state[(ps * d + k) * n + e];
+            s_next[k * batch + b] = rb->state[(pn * d + k) * n + e];
+        }
+        a[b] = rb->action[((rb->head_rt + li) % rb->capacity) * n + e];
+        r[b] = gain;
+        term[b] = t;
+    }
+}
+
+/* gamma^n of the n-step target: Julia's `gamma^n` for Float32 gamma and Int n is evaluated through Float64 and rounded once */
+float rlo_gamma_pow(float gamma, int64_t n) { return (float)pow((double)gamma, (double)n); }
+
 /* ---------------------------------------------------------------- priority sum-tree --
  * Published algorithm of CircularArrayBuffers.SumTree (un-vendored, compat "0.1.12", RLCore/Project.toml:30):
  *   tree = zeros(nparents + capacity), nparents = 2^ceil(log2(capacity)) - 1; leaf i at nparents + i;

@@ -698,4 +698,13 @@ int32_t rlhip_td_target_f32(const float* qt_next, int64_t na, int64_t n, int64_t
     return RLHIP_OK;
 }
 
+/* the n-step form (R = r + gamma^n (1 - t) max Qt(s')): `reward` holds the n-step returns of the sampled windows
+ * (rlhip_ring_fold_nstep), `terminal` any(terminal[window]), qt_next the target values of s_{i + n}; gamma^n = rlhip_gamma_pow */
+int32_t rlhip_td_target_n_f32(const float* qt_next, int64_t na, int64_t n, int64_t k_stride, int64_t i_stride,
+                              const float* reward, const uint8_t* terminal, float gamma, int32_t n_step, float* target,
+                              rlhip_stream_t stream) {
+    RLHIP_REQUIRE(n_step >= 1, "n_step must be >= 1");
+    return rlhip_td_target_f32(qt_next, na, n, k_stride, i_stride, reward, terminal, rlhip_gamma_pow(gamma, n_step), target, stream);
+}
+
 }  // extern "C"

@@ -20,6 +20,7 @@
 // Algorithmic bytes per sample: 2 * (2 * obs_bytes + 9)  (SURVEY.md 8d).
 #include "common.h"
 #include "ring_device.h"
+#include <cmath>
 
 namespace rlhip {
 
@@ -453,6 +454,55 @@ __global__ __launch_bounds__(256) void push_transition_maxpool_kernel(uint4* __r
     }
 }
 
+// ---- n-step transitions (NStepBatchSampler of RLTrajectories 0.4: un-vendored, PARITY UNPINNED; oracle/rlo_buffer.c states the
+// published algorithm).  One lane per sample folds the window li .. li + ns - 1 of its env -- ns = n_step unless a terminal flag
+// ends it earlier -- into ONE transition {s_li, a_li, R = r_0 + gamma (r_1 + gamma (...)), any(terminal), s_{li + ns}} and writes it as
+// a complete 64-byte record of a batch-sized record ring.  The return is discount_rewards_reduced over the window
+// (RLCore/src/utils/basic.jl:237-319: gain = r[i] + gamma * gain from the window's end, Float32, no contraction).  Every DQN
+// gradient entry point then runs UNCHANGED on the folded ring with gamma^n as its discount: the record IS the learner's input
+// format, so n-step costs one small launch (n_step lines read per sample) and no second copy of the tuned kernels.
+constexpr int MAX_NSTEP = 32;
+__global__ __launch_bounds__(256) void fold_nstep_kernel(RingView rb, int64_t len_rt, const int64_t* __restrict__ idx, int64_t batch,
+                                                         int n_step, float gamma, uint8_t* __restrict__ out, int64_t* __restrict__ iota) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const RingRecs rr = {(const uint8_t*)rb.state, rb.capacity, rb.n_env, rb.head_sa};
+    const int64_t fj = idx[b];
+    const int64_t li = fj / rb.n_env;
+    RingTransition first = ring_load_transition(rr, fj);
+    float rew[MAX_NSTEP];
+    float sn[4] = {first.sn[0], first.sn[1], first.sn[2], first.sn[3]};
+    rew[0] = first.r;
+    uint32_t term = first.t;
+    int ns = 1;
+    bool open = true;  // the window still grows (no `break`: the loop unrolls, rew[] stays in registers)
+#pragma unroll
+    for (int k = 1; k < MAX_NSTEP; ++k) {
+        open = open && k < n_step && !term && li + k < len_rt;  // (a window never runs past the newest stored transition)
+        if (open) {
+            const RingTransition t = ring_load_transition(rr, fj + (int64_t)k * rb.n_env);
+            rew[k] = t.r;
+            term = t.t;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sn[c] = t.sn[c];
+            ns = k + 1;
+        } else {
+            rew[k] = 0.0f;
+        }
+    }
+    float gain = 0.0f;
+#pragma unroll
+    for (int k = MAX_NSTEP - 1; k >= 0; --k)
+        if (k < ns) gain = rew[k] + gamma * gain;
+    uint8_t* o = out + b * RING_REC_BYTES;
+    *reinterpret_cast<nt_u32x4*>(o) = nt_u32x4{__float_as_uint(first.s[0]), __float_as_uint(first.s[1]), __float_as_uint(first.s[2]),
+                                               __float_as_uint(first.s[3])};
+    *reinterpret_cast<nt_u32x4*>(o + 16) = nt_u32x4{(uint32_t)first.a, __float_as_uint(gain), term ? 1u : 0u, 0u};
+    *reinterpret_cast<nt_u32x4*>(o + 32) = nt_u32x4{__float_as_uint(sn[0]), __float_as_uint(sn[1]), __float_as_uint(sn[2]), __float_as_uint(sn[3])};
+    *reinterpret_cast<nt_u32x4*>(o + 48) = nt_u32x4{0u, 0u, 0u, 0u};
+    if (iota) iota[b] = b;
+}
+
 static RingView view_of(const rlhip_ring* rb) {
     return {rb->capacity, rb->n_env, rb->obs_dim, rb->head_sa, rb->head_rt,
             rb->state,    rb->action, rb->reward, rb->terminal};
@@ -591,6 +641,45 @@ int32_t rlhip_ring_sample_indices(const rlhip_ring* rb, int64_t batch, uint64_t 
     RLHIP_LAUNCH_CHECK();
     return RLHIP_OK;
 }
+
+int32_t rlhip_ring_sample_indices_nstep(const rlhip_ring* rb, int64_t batch, int32_t n_step, uint64_t seed, uint32_t draw_ctr,
+                                        int64_t* idx_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && idx_out && batch >= 0, "bad arguments");
+    RLHIP_REQUIRE(n_step >= 1 && n_step <= MAX_NSTEP, "n_step must be in 1..32");
+    RLHIP_REQUIRE(rb->len_rt >= n_step, "the trajectory holds fewer than n_step transitions");
+    if (batch == 0) return RLHIP_OK;
+    const uint64_t total = (uint64_t)(rb->len_rt - n_step + 1) * (uint64_t)rb->n_env;
+    hipLaunchKernelGGL(sample_indices_kernel, dim3((int)((batch + 255) / 256)), dim3(256), 0, as_stream(stream), idx_out, batch,
+                       total, seed, draw_ctr);
+    RLHIP_LAUNCH_CHECK();
+    return RLHIP_OK;
+}
+
+int32_t rlhip_ring_fold_nstep(const rlhip_ring* rb, const int64_t* idx, int64_t batch, int32_t n_step, float gamma,
+                              rlhip_ring* folded, int64_t* iota_out, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && idx && folded && batch >= 1, "bad arguments");
+    RLHIP_REQUIRE(n_step >= 1 && n_step <= MAX_NSTEP, "n_step must be in 1..32");
+    RLHIP_REQUIRE(rb->layout == RLHIP_RING_RECORDS, "n-step folding is defined for record rings (Float32 observations, obs_dim <= 4)");
+    RLHIP_REQUIRE(folded->layout == RLHIP_RING_RECORDS && folded->state != nullptr && folded->capacity >= 1 && folded->n_env == batch &&
+                      folded->obs_dim == rb->obs_dim,
+                  "`folded` must be a record ring initialised with rlhip_ring_init(capacity >= 1, n_env = batch, the source's obs_dim)");
+    RLHIP_REQUIRE(folded->state != rb->state, "`folded` must not alias the source ring");
+    RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
+    RLHIP_CHECK_GATHER_INDICES(rb, idx, batch, stream);
+    hipStream_t st = as_stream(stream);
+    // (records are obs_dim-agnostic: components >= obs_dim are zero in the source and copied as such)
+    hipLaunchKernelGGL(fold_nstep_kernel, dim3((int)((batch + 255) / 256)), dim3(256), 0, st, view_of(rb), rb->len_rt, idx, batch,
+                       (int)n_step, gamma, (uint8_t*)folded->state, iota_out);
+    RLHIP_LAUNCH_CHECK();
+    // slot 0 of `folded` now holds `batch` complete transitions: one stored vec-step of a `batch`-env ring
+    folded->head_sa = 0;
+    folded->len_sa = 2;
+    folded->head_rt = 0;
+    folded->len_rt = 1;
+    return RLHIP_OK;
+}
+
+float rlhip_gamma_pow(float gamma, int32_t n) { return (float)pow((double)gamma, (double)n); }
 
 int32_t rlhip_ring_check_indices(const rlhip_ring* rb, const int64_t* idx, int64_t batch, int64_t* n_bad_host,
                                  int64_t* first_bad_host, rlhip_stream_t stream) {

@@ -416,6 +416,25 @@ function Base.iterate(t::HipTrajectory, _ = nothing)
 end
 
 """
+    sample_nstep!(t::HipTrajectory{Float32}, folded::HipTrajectory{Float32}, iota::DevBuf{Int64}, n, γ) -> γⁿ
+
+`NStepBatchSampler(n, γ, batchsize)` of RLTrajectories 0.4 on the device: draws `t.batchsize` start indices that have `n` transitions
+ahead of them and folds each window (cut at its first terminal step) into ONE transition `(s_i, a_i, R, any(terminal), s_{i+ns})`
+with `R = discount_rewards_reduced(r_i … r_{i+ns-1}, γ)` (`RLCore/src/utils/basic.jl:237-319`), written as the records of `folded` --
+a `HipTrajectory(capacity = 1, n_env = t.batchsize, obs_dim = …)`.  The DQN gradient `ccall`s then take `folded.rb`, `iota` (0-based
+`0:batchsize-1`) and the returned `γⁿ` instead of `t.rb`, the sampled indices and `γ`: `R + γⁿ·(1−t)·max Qₜ(s_{i+n})` (SURVEY row L2).
+"""
+function sample_nstep!(t::HipTrajectory{Float32}, folded::HipTrajectory{Float32}, iota::DevBuf{Int64}, n::Integer, γ::Float32)
+    chk(ccall((:rlhip_ring_sample_indices_nstep, LIB), Int32, (Ref{Ring}, Int64, Int32, UInt64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, t.batchsize, n, t.sampler_seed, t.draw_ctr, t.idx.ptr, stream()))
+    t.draw_ctr += 1
+    chk(ccall((:rlhip_ring_fold_nstep, LIB), Int32,
+              (Ref{Ring}, Ptr{Cvoid}, Int64, Int32, Float32, Ref{Ring}, Ptr{Cvoid}, Ptr{Cvoid}),
+              t.rb, t.idx.ptr, t.batchsize, n, γ, folded.rb, iota.ptr, stream()))
+    ccall((:rlhip_gamma_pow, LIB), Float32, (Float32, Int32), γ, n)
+end
+
+"""
     check_indices(t::HipTrajectory, idx::DevBuf{Int64}, n = length(idx)) -> (n_bad, first_bad)
 
 How many of the flat logical indices lie outside `1:length(t) * n_env` (0-based on the device), and the position of the first one

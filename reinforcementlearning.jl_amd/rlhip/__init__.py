@@ -18,7 +18,7 @@ from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint, state
 from .timing import disable_debug_timings, enable_debug_timings, timer  # noqa: F401
 from .heads import CategoricalNetwork, GaussianNetwork, SoftGaussianNetwork  # noqa: F401
 from .ppo import PPOPolicy, PPOTrajectory, make_ppo_cfg  # noqa: F401
-from .trajectory import (BatchSampler, CircularArraySARTSTraces, CircularPrioritizedTraces,  # noqa: F401
+from .trajectory import (BatchSampler, CircularArraySARTSTraces, CircularPrioritizedTraces, NStepBatchSampler,  # noqa: F401
                          InsertSampleRatioController, Trajectory)
 
 ABI_VERSION = _lib.lib.rlhip_abi_version()

@@ -170,6 +170,10 @@ _PROTOS = {
     "rlhip_ring_push_transition": (i32, [P(Ring), vp, vp, vp, vp, vp]),
     "rlhip_ring_length": (i64, [P(Ring)]),
     "rlhip_ring_sample_indices": (i32, [P(Ring), i64, u64, u32, vp, vp]),
+    "rlhip_ring_sample_indices_nstep": (i32, [P(Ring), i64, i32, u64, u32, vp, vp]),
+    "rlhip_ring_fold_nstep": (i32, [P(Ring), vp, i64, i32, f32, P(Ring), vp, vp]),
+    "rlhip_td_target_n_f32": (i32, [vp, i64, i64, i64, i64, vp, vp, f32, i32, vp, vp]),
+    "rlhip_gamma_pow": (f32, [f32, i32]),
     "rlhip_ring_gather_is_frame_major": (i32, [P(Ring)]),
     "rlhip_ring_check_indices": (i32, [P(Ring), vp, i64, P(i64), P(i64), vp]),
     "rlhip_ring_bounds_checked_build": (i32, []),

@@ -382,8 +382,8 @@ def run_fused_dqn(agent, env, stop_condition=None, hook=None):
     net = tn.network
     traces = traj.container
     if ex.is_break_tie or env.continuous or env.is_f64 or hasattr(traces, "sample_prioritized") \
-            or learner.process_group is not None:
-        raise NotImplementedError("fused DQN step: plain eps-greedy, Float32 discrete env, uniform replay, 1 GPU")
+            or learner.process_group is not None or getattr(learner, "n_step", 1) != 1:
+        raise NotImplementedError("fused DQN step: plain eps-greedy, Float32 discrete env, uniform 1-step replay, 1 GPU")
     stop_condition = stop_condition or StopAfterNSteps(1)
     hook = hook or EmptyHook()
     hook.push_(PRE_EXPERIMENT_STAGE, agent, env)

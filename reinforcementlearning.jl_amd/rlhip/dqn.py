@@ -244,7 +244,15 @@ class DQNLearner:
     per_beta = 0, the default, is the proportional-sampling variant without weights)."""
 
     def __init__(self, approximator, batchsize=32, gamma=0.99, huber_delta=1.0, min_replay_history=100,
-                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None, per_eps=1e-6, per_alpha=0.6, per_beta=0.0):
+                 update_freq=1, max_grad_norm=0.0, seed=0, process_group=None, per_eps=1e-6, per_alpha=0.6, per_beta=0.0, n_step=1):
+        """n_step > 1: batches come from NStepBatchSampler(n_step, gamma, batchsize) -- the window folded on the device into one
+        transition -- and the TD target is R + gamma^n (1 - t) max Qt(s_{i+n}); uniform replay, per-stage loop."""
+        self.n_step = int(n_step)
+        self._nstep = None
+        if self.n_step > 1:
+            from .trajectory import NStepBatchSampler
+
+            self._nstep = NStepBatchSampler(self.n_step, gamma, batchsize, seed=seed)
         self.per_eps, self.per_alpha, self.per_beta = float(per_eps), float(per_alpha), per_beta
         self.approximator = approximator  # a TargetNetwork
         net = approximator.network
@@ -282,6 +290,24 @@ class DQNLearner:
             return False
         net = self.approximator.network
         prioritized = hasattr(traces, "sample_prioritized")
+        if self._nstep is not None:
+            if prioritized:
+                raise NotImplementedError("n-step targets: uniform replay only")
+            if len(traces) < self.n_step:  # not one full window yet
+                return False
+            folded, iota = self._nstep.fold(traces, self._nstep.sample_indices(traces, self.draw_ctr))
+            if net.layers == 3:
+                dqn3_grad(folded, net.hidden, net.n_out, net.act, net.params, net.packed, self.approximator.target,
+                          self.approximator.target_packed, self.batchsize, self._nstep.gamma_n, self.delta, self.seed, self.draw_ctr,
+                          iota, self.workspace, self.grad, self.loss, self.td)
+            else:
+                call("rlhip_dqn_grad_idx_f32", C.byref(folded.rb), net.hidden, net.n_out, net.act, ptr(net.params),
+                     ptr(self.approximator.target), self.batchsize, ptr(iota), self._nstep.gamma_n, self.delta, ptr(self.workspace),
+                     ptr(self.grad), ptr(self.loss), ptr(self.td), stream_ptr())
+            self.draw_ctr += 1
+            self.approximator.optimise_(self.grad, clip_norm=self.max_grad_norm, grad_scale=1.0)
+            self.n_updates += 1
+            return True
         beta = 0.0
         if prioritized:
             beta = float(self.per_beta(self.n_updates)) if callable(self.per_beta) else float(self.per_beta)

@@ -216,6 +216,45 @@ class BatchSampler:
         return dict(state=s, action=a + 1, reward=r, terminal=t.view(torch.bool), next_state=sn, **extra)
 
 
+class NStepBatchSampler:
+    """NStepBatchSampler(n, gamma, batchsize; rng) of RLTrajectories 0.4 (un-vendored; oracle/rlo_buffer.c restates it): start
+    indices with n transitions ahead of them, each window folded on the device into ONE transition
+    (s_i, a_i, R = discount_rewards_reduced(r_i .. r_{i+ns-1}, gamma), any(terminal), s_{i+ns}) -- ns = n unless a terminal flag
+    ends the window earlier.  `sample` returns the batch dictionary of BatchSampler; `fold` returns the folded record ring +
+    indices the DQN gradient entry points take unchanged (with gamma^n = `gamma_n` as their discount).  Record rings only."""
+
+    def __init__(self, n, gamma, batchsize, seed=0):
+        if not 1 <= int(n) <= 32:
+            raise ValueError("n must be in 1..32")
+        self.n, self.gamma, self.batchsize, self.seed, self.draw_ctr = int(n), float(gamma), int(batchsize), seed, 0
+        self.gamma_n = float(_lib.lib.rlhip_gamma_pow(self.gamma, self.n))
+        self._folded = None
+
+    def sample_indices(self, traces, draw_ctr=None):
+        ctr = self.draw_ctr if draw_ctr is None else draw_ctr
+        idx = torch.empty(self.batchsize, dtype=torch.int64, device=traces.state.device)
+        call("rlhip_ring_sample_indices_nstep", C.byref(traces.rb), self.batchsize, self.n, self.seed, ctr, ptr(idx), stream_ptr())
+        return idx
+
+    def fold(self, traces, idx=None):
+        """-> (folded traces: a CircularArraySARTSTraces of capacity 1 x batchsize envs holding the n-step transitions, iota)"""
+        if idx is None:
+            idx = self.sample_indices(traces)
+            self.draw_ctr += 1
+        b = idx.numel()
+        if self._folded is None or self._folded.n_env != b or self._folded.obs_dim != traces.obs_dim:
+            self._folded = CircularArraySARTSTraces(capacity=1, n_env=b, obs_dim=traces.obs_dim, device=traces.state.device)
+            self._iota = torch.empty(b, dtype=torch.int64, device=traces.state.device)
+        call("rlhip_ring_fold_nstep", C.byref(traces.rb), ptr(idx), b, self.n, self.gamma, C.byref(self._folded.rb), ptr(self._iota),
+             stream_ptr())
+        return self._folded, self._iota
+
+    def sample(self, traces):
+        folded, iota = self.fold(traces)
+        s, a, r, t, sn = folded.gather(iota)
+        return dict(state=s, action=a + 1, reward=r, terminal=t.view(torch.bool), next_state=sn)
+
+
 class InsertSampleRatioController:
     """InsertSampleRatioController(ratio, threshold; n_inserted = 0, n_sampled = 0): sampling is allowed
     once n_inserted >= threshold and while n_sampled <= (n_inserted - threshold) * ratio

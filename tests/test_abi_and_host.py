@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and every declared function has a ctypes prototype in the Python glue
     assert not [s for s in syms if s not in _lib._PROTOS]
+    # INTEGRATION.md quotes the number of entry points (it said 141 while the header had grown): keep it honest
+    import re
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"\((\d+) `extern \"C\"` entry points", text)
+    assert m and int(m.group(1)) == len(syms), (m and m.group(1), len(syms))
 
 
 def test_abi_version_and_error_reporting():

@@ -39,7 +39,7 @@ def c_type_class(decl):
 
 def header_prototypes():
     protos = {}
-    for ret, name, params in re.findall(r"\b(int32_t|int64_t|double|const char\s*\*)\s+(rlhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;",
+    for ret, name, params in re.findall(r"\b(int32_t|int64_t|double|float|const char\s*\*)\s+(rlhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;",
                                         _header_src()):
         params = params.strip()
         plist = [] if params in ("", "void") else [c_type_class(p) for p in params.split(",")]

@@ -1,4 +1,4 @@
-"""round 5: every HBM-bound kernel of the bench line at the bench's sizes, for the PMC traffic passes of tools/r5_pmc.sh
+"""every HBM-bound kernel of the bench line at the bench's sizes, for the PMC traffic passes of tools/pmc_all.sh
 (bench.roofline_extras(hbm_only = True): GAE + returns, the u8 frame gathers; bench.roofline_hbm_side: Pendulum / MountainCar
 env-step, Adam / Polyak, the max-pool push, the small gather).  The CartPole env-step has its own script (tools/envstep.py)."""
 import os, sys

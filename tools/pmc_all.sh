@@ -1,14 +1,14 @@
 #!/bin/bash
-# round 5 PMC traffic passes (FETCH_SIZE / WRITE_SIZE in SEPARATE rocprofv3 passes, kernel-trace only) of every HBM-bound kernel in
+# PMC traffic passes (FETCH_SIZE / WRITE_SIZE in SEPARATE rocprofv3 passes, kernel-trace only) of every HBM-bound kernel in
 # the bench line; prints the PMC_TRAFFIC / PMC_SIDE entries for bench.py (2 x FETCH + WRITE, mean of the last launches)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export GRAFT_REPO_ROOT=$PWD TMPDIR=/tmp
-R=$PWD; O=gpurun_out/r5_pmc; mkdir -p $O
-bash tools/pmc_env.sh r5final 2>&1 | tail -3
-cp gpurun_out/pmc_env_r5final.txt $O/env.txt
+R=$PWD; O=gpurun_out/pmc_all; mkdir -p $O
+bash tools/pmc_env.sh final 2>&1 | tail -3
+cp gpurun_out/pmc_env_final.txt $O/env.txt
 : > $O/side.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/side_$c -o pmc -- python $R/tools/r5_pmc_all.py > $R/$O/side_$c.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/side_$c -o pmc -- python $R/tools/pmc_all.py > $R/$O/side_$c.log 2>&1)
   for k in gae_vec4_kernel "env_step_kernel<rlhip::Pendulum" "env_step_kernel<rlhip::MountainCar" push_transition_maxpool_kernel gather_rec_kernel; do
     python3 tools/pmc_last.py $O/side_$c "$k" 8 >> $O/side.txt
   done
