@@ -119,7 +119,10 @@ constexpr int64_t STREAM_MIN_N = 1 << 16;
 #ifndef RLHIP_ADAM_CHUNKS
 #define RLHIP_ADAM_CHUNKS 1
 #endif
-constexpr int ADAM_CHUNKS = RLHIP_ADAM_CHUNKS;  // 16-byte chunks per thread of adam_vec4_kernel (A / B: tools/adam_grid_ab.py)
+constexpr int ADAM_CHUNKS = RLHIP_ADAM_CHUNKS;
+#ifndef RLHIP_POLYAK_ROWS
+#define RLHIP_POLYAK_ROWS 2
+#endif  // 16-byte chunks per thread of adam_vec4_kernel (A / B: tools/adam_grid_ab.py)
 union f32x4_bits {
     nt_u32x4 u;
     float f[4];
@@ -173,18 +176,35 @@ __global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, c
     advance_beta_pow_last_out(beta_pow, b1, b2, departed);
 }
 
-template <bool NT_ST>
+// ROWS 1 KB rows (64 lanes x 16 bytes) per wave, CONTIGUOUS in memory: with two arrays in flight a wave that covers 2 KB of each
+// reads 0.99 of the HBM peak in tools/micro/adam_stream.hip against 0.92 with one row (round 6); with seven arrays (Adam) the row
+// count makes no difference (profiles/r06_adam.md).  Every load of the wave is issued before the first use.
+template <bool NT_ST, int ROWS>
 __global__ __launch_bounds__(256) void polyak_vec4_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                           int64_t n, float rho) {
     const float om = 1.0f - rho;
-    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4_bits d, x;
-        d.u = nt_load16(dst + 4 * i);
-        x.u = nt_load16(src + 4 * i);
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x * ROWS;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (int64_t i0 = wave0 * (64 * ROWS) + lane; i0 < n4; i0 += stride) {
+        f32x4_bits d[ROWS], x[ROWS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d.f[k] = rho * d.f[k] + om * x.f[k];
-        st16<NT_ST>(dst + 4 * i, d);
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 + 64 * r;
+            if (i < n4) {
+                d[r].u = nt_load16(dst + 4 * i);
+                x[r].u = nt_load16(src + 4 * i);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 + 64 * r;
+            if (i < n4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[r].f[k] = rho * d[r].f[k] + om * x[r].f[k];
+                st16<NT_ST>(dst + 4 * i, d[r]);
+            }
+        }
     }
     const int64_t t = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dst[t] = rho * dst[t] + om * src[t];
@@ -557,9 +577,10 @@ int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlh
         // one 16-byte chunk per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes
         // 307 us with 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones, Polyak 118 against 120 - 126
         // (tools/adam_grid_ab.py); the loops in the kernels only serve vectors beyond the grid cap
-        const int grid = grid_for(n / 4, 256, 1 << 20);
+        constexpr int ROWS = RLHIP_POLYAK_ROWS;
+        const int grid = grid_for((n / 4 + ROWS - 1) / ROWS, 256, 1 << 20);
         // ordinary stores: 128 us at 2^26 parameters against 154 with non-temporal ones (the opposite of Adam's seven streams)
-        hipLaunchKernelGGL((polyak_vec4_kernel<false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
+        hipLaunchKernelGGL((polyak_vec4_kernel<false, ROWS>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     } else
         hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     RLHIP_LAUNCH_CHECK();

@@ -134,8 +134,9 @@ def test_td_target_n_vs_oracle():
     r = rng.standard_normal(n).astype(np.float32)
     t = (rng.random(n) < 0.3).astype(np.uint8)
     out = torch.empty(n, device="cuda")
+    dq, dr, dt = dev(q), dev(r), dev(t)   # (kept alive across the launches)
     for n_step in (1, 3, 10):
-        call("rlhip_td_target_n_f32", ptr(dev(q)), na, n, n, 1, ptr(dev(r)), ptr(dev(t)), 0.99, n_step, ptr(out), stream_ptr())
+        call("rlhip_td_target_n_f32", ptr(dq), na, n, n, 1, ptr(dr), ptr(dt), 0.99, n_step, ptr(out), stream_ptr())
         ref = oracle.td_target(q, r, t, oracle.gamma_pow(0.99, n_step))
         assert np.array_equal(host(out), ref)
 
