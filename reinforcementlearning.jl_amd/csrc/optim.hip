@@ -121,7 +121,7 @@ constexpr int64_t STREAM_MIN_N = 1 << 16;
 #endif
 constexpr int ADAM_CHUNKS = RLHIP_ADAM_CHUNKS;
 #ifndef RLHIP_POLYAK_ROWS
-#define RLHIP_POLYAK_ROWS 2
+#define RLHIP_POLYAK_ROWS 1
 #endif  // 16-byte chunks per thread of adam_vec4_kernel (A / B: tools/adam_grid_ab.py)
 union f32x4_bits {
     nt_u32x4 u;
@@ -176,9 +176,8 @@ __global__ __launch_bounds__(256) void adam_vec4_kernel(float* __restrict__ p, c
     advance_beta_pow_last_out(beta_pow, b1, b2, departed);
 }
 
-// ROWS 1 KB rows (64 lanes x 16 bytes) per wave, CONTIGUOUS in memory: with two arrays in flight a wave that covers 2 KB of each
-// reads 0.99 of the HBM peak in tools/micro/adam_stream.hip against 0.92 with one row (round 6); with seven arrays (Adam) the row
-// count makes no difference (profiles/r06_adam.md).  Every load of the wave is issued before the first use.
+// ROWS 1 KB rows (64 lanes x 16 bytes) per wave, CONTIGUOUS in memory, every load of the wave issued before the first use.  ROWS = 1
+// is shipped: two rows per wave measured the same with ordinary stores and 7 % slower with non-temporal ones (see the launch).
 template <bool NT_ST, int ROWS>
 __global__ __launch_bounds__(256) void polyak_vec4_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                           int64_t n, float rho) {
@@ -577,9 +576,12 @@ int32_t rlhip_polyak_f32(float* dst, const float* src, int64_t n, float rho, rlh
         // one 16-byte chunk per thread (no persistent grid-stride loop below 2^30 parameters): at 2^26 parameters Adam takes
         // 307 us with 65536 workgroups against 371 - 429 us with 1024 - 16384 looping ones, Polyak 118 against 120 - 126
         // (tools/adam_grid_ab.py); the loops in the kernels only serve vectors beyond the grid cap
+        // one 1 KB row per wave and array, ordinary stores.  Round 6 A / B on one box, 2^26 parameters (tools/polyak_ab.py, three
+        // alternations): one row + ordinary stores 115.9 - 116.1 us, two contiguous rows + ordinary 116.0 - 116.3, one row + NT
+        // 116.0 - 116.1, two rows + NT 124.5 - 125.1.  (A stand-alone twin of this launch read 101 us with two rows + NT stores --
+        // on the all-zero data of a hipMemset; on random floats the same twin reads 116.5 / 120.1 us: profiles/r06_adam.md section 5.)
         constexpr int ROWS = RLHIP_POLYAK_ROWS;
         const int grid = grid_for((n / 4 + ROWS - 1) / ROWS, 256, 1 << 20);
-        // ordinary stores: 128 us at 2^26 parameters against 154 with non-temporal ones (the opposite of Adam's seven streams)
         hipLaunchKernelGGL((polyak_vec4_kernel<false, ROWS>), dim3(grid), dim3(256), 0, as_stream(stream), dst, src, n, rho);
     } else
         hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, src, n, rho);

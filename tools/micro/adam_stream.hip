@@ -172,6 +172,17 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
     }
 }
 
+// pseudo-random finite floats (the sweeps otherwise stream the zeros of hipMemset: constant data)
+__global__ void fill_random(uint32_t* p, size_t n32) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + 12345u;
+        h ^= h >> 15;
+        h *= 2246822519u;
+        h ^= h >> 13;
+        p[i] = (h & 0x807fffffu) | 0x3f000000u;  // +-[0.5, 1)
+    }
+}
+
 // every x of a 2^32 sweep: Markstein quotient by c against the IEEE division
 __global__ void sweep_div(float c, unsigned long long* bad) {
     const float r = 1.0f / c;
@@ -435,7 +446,8 @@ int main(int argc, char** argv) {
         const size_t pitch2 = (bytes + stag2 + 255) / 256 * 256;
         uint8_t* b2;
         CK(hipMalloc((void**)&b2, pitch2 * 12 + 256));
-        CK(hipMemset(b2, 0, pitch2 * 12));
+        if (getenv("ADAM_STREAM_ZEROS")) CK(hipMemset(b2, 0, pitch2 * 12));
+        else hipLaunchKernelGGL(fill_random, dim3(8192), dim3(256), 0, 0, (uint32_t*)b2, pitch2 * 12 / 4);
         time_mix<1, 3, 0>(b2, pitch2, n, "(Adam: g | p m v)");
         if (stag2 == 4352) {
             time_mix2<1, 3, 1, false>(b2, pitch2, n, "Adam, 1 KB per wave and array (= shipped)");
