@@ -319,6 +319,15 @@ def roofline_extras(torch, rlhip, hbm_only=False):
             sg_b()
             u_b()
 
+        sync_b = torch.zeros(2, dtype=torch.int32, device="cuda")
+        uk_b, up_b = key_b.clone(), prio_b.clone()  # the PREVIOUS batch's keys / priorities: written back inside the next launch
+
+        def fused_b():  # round 6: write-back + draw + gather in ONE launch (<= 64 keys; otherwise the two calls behind the same entry)
+            rlhip._lib.call("rlhip_ring_update_sample_gather_prioritized", C.byref(tr.rb), ops.ptr(tr.priorities), ops.ptr(uk_b),
+                            ops.ptr(up_b), b, b, 11, cb[0], ops.ptr(idx_b), ops.ptr(key_b), ops.ptr(prio_b), ops.ptr(bufs_b[0]),
+                            ops.ptr(bufs_b[1]), ops.ptr(bufs_b[2]), ops.ptr(bufs_b[3]), ops.ptr(bufs_b[4]), ops.ptr(sync_b), s)
+            cb[0] += 1
+
         def fresh_b():
             smp_b()
             g_b()
@@ -327,13 +336,18 @@ def roofline_extras(torch, rlhip, hbm_only=False):
         t_g = event_time_ms(fresh_b, 20, lib, s) - t_s
         t_u = event_time_ms(u_b, 20, lib, s)
         t_all = event_time_ms(all_b, 20, lib, s)
+        fused_b()
+        t_fused = event_time_ms(fused_b, 20, lib, s)
         gbb = 2 * (2 * fb + 9) * b / 1e9
         small[str(b)] = {"batch": b, "us_per_launch": round(t_g * 1e3, 1), "achieved": round(gbb / (t_g * 1e-3), 1),
                          "unit": "GB/s", "frac": round(gbb / (t_g * 1e-3) / HBM_PEAK_GBS, 4),
                          "prioritized_sample_us": round(t_s * 1e3, 1), "priority_update_us": round(t_u * 1e3, 1),
                          "sample_gather_update_us": round(t_all * 1e3, 1),
-                         "prioritized_samples_per_sec": round(b / (t_all * 1e-3), 1)}
-        del idx_b, key_b, prio_b, bufs_b
+                         "update_sample_gather_one_call_us": round(t_fused * 1e3, 1),
+                         "update_sample_gather_note": ("rlhip_ring_update_sample_gather_prioritized: ONE launch (<= 64 keys)" if b <= 64 else
+                                                       "rlhip_ring_update_sample_gather_prioritized: > 64 keys -> the two launches behind the same entry point"),
+                         "prioritized_samples_per_sec": round(b / (min(t_all, t_fused) * 1e-3), 1)}
+        del idx_b, key_b, prio_b, bufs_b, uk_b, up_b, sync_b
     out["frame_gather_u8"]["small_batches"] = small
     del key, prio, keys
     del tr, bufs, idx

@@ -684,6 +684,19 @@ int32_t rlhip_ring_sample_gather_prioritized(const rlhip_ring* rb_host, const fl
                                              void* s, int32_t* a, float* r, uint8_t* term, void* s_next,
                                              rlhip_stream_t stream);
 
+/* The priority write-back of the PREVIOUS batch, the prioritized draw of the next one and the gather of its frames in ONE launch
+ * (round 6): `trajectory[:priority, upd_key] = upd_prio` (as rlhip_sumtree_update: the last duplicate wins) is applied by one
+ * wavefront of the launch before any workgroup draws; results -- the tree, idx / key / priority, the gathered batch -- are
+ * bit-identical to rlhip_sumtree_update followed by rlhip_ring_sample_gather_prioritized, which is also what runs when the
+ * combination has no fused form (n_upd > 64, n_upd == 0, rings that are not frame-major, sync == NULL).  `sync`: two device
+ * words owned by the caller, zero before the first call and re-armed by every call (one pair per concurrently used stream).
+ * The DQN-Atari step then is: plan! / act! / push! -> THIS -> gradient (which leaves the new priorities for the next call). */
+int32_t rlhip_ring_update_sample_gather_prioritized(const rlhip_ring* rb_host, float* tree, const int64_t* upd_key,
+                                                    const float* upd_prio, int64_t n_upd, int64_t batch, uint64_t seed,
+                                                    uint32_t draw_ctr, int64_t* idx_out, int64_t* key_out, float* prio_out,
+                                                    void* s, int32_t* a, float* r, uint8_t* term, void* s_next,
+                                                    uint32_t* sync, rlhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------- MLP -- */
 /* Chain(Dense(n_in, h, act), Dense(h, n_out)) with flat parameters in Flux.destructure order:
  *   W1 (h x n_in col-major) | b1 (h) | W2 (n_out x h col-major) | b2 (n_out).   act: 0 relu, 1 tanh.

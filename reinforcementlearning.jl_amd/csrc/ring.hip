@@ -20,6 +20,7 @@
 // Algorithmic bytes per sample: 2 * (2 * obs_bytes + 9)  (SURVEY.md 8d).
 #include "common.h"
 #include "ring_device.h"
+#include "sumtree_device.h"
 #include <cmath>
 
 namespace rlhip {
@@ -195,7 +196,26 @@ struct PrioDraw {
     int64_t* idx_out;
     int64_t* key_out;  // may be NULL
     float* prio_out;   // may be NULL
+    // round 6: a pending priority write-back of <= 64 keys applied INSIDE the launch, before any draw (rlhip_ring_update_sample_
+    // gather_prioritized): wave 0 of workgroup 0 runs the one-wavefront update (sumtree_device.h) with write-through stores and
+    // raises sync[0]; the drawing wave of every workgroup waits for it and then reads the tree with device-scope loads.
+    // upd_n == 0: no update, plain loads (the round-4 / 5 launch, unchanged).
+    const int64_t* upd_key;
+    const float* upd_prio;
+    int upd_n, logP;
+    unsigned int* sync;  // [0] "tree updated", [1] departures; both 0 between launches
 };
+// a tree word for the draw: plain (nothing in this launch writes the tree) or device-scope (after the in-launch update)
+__device__ __forceinline__ float tree_ld(const PrioDraw& pd, const float* p) {
+    return pd.upd_n > 0 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+__device__ __forceinline__ float2 tree_ld2(const PrioDraw& pd, const float* p) {  // the child pair (2 node, 2 node + 1): 8-byte aligned
+    if (pd.upd_n > 0) {
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
+    }
+    return *reinterpret_cast<const float2*>(p);
+}
 // (Round 5, tried and not kept: an LDS copy of the tree's top 12 levels for batches <= 512, so that thread 0's descent pays L2
 // latency for the remaining levels only -- the fused draw + gather of a 32-sample batch went 11.3 -> 10.9 us: the cooperative
 // 16 KB load and its barrier cost what twelve L2-resident round trips cost; profiles/r05_summary.md.)
@@ -204,7 +224,7 @@ __device__ __forceinline__ int64_t prio_draw_finish(const PrioDraw& pd, const Ri
     int64_t leaf = node - pd.P;
     if (leaf >= pd.n_leaves) leaf = pd.n_leaves - 1;
     if (pd.key_out) pd.key_out[b] = leaf;
-    if (pd.prio_out) pd.prio_out[b] = pd.tree[pd.P + leaf];
+    if (pd.prio_out) pd.prio_out[b] = tree_ld(pd, pd.tree + pd.P + leaf);
     const int64_t pt = leaf / rb.n_env, e = leaf - pt * rb.n_env;
     int64_t li = pt - rb.head_rt;
     if (li < 0) li += rb.capacity;
@@ -214,10 +234,10 @@ __device__ __forceinline__ int64_t prio_draw_finish(const PrioDraw& pd, const Ri
 }
 __device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingView& rb, int64_t b) {
     const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
-    float v = u01_f32(w.z) * pd.tree[1];
+    float v = u01_f32(w.z) * tree_ld(pd, pd.tree + 1);
     int64_t node = 1;
     while (node < pd.P) {  // sumtree_descend (sumtree.hip), restated: never enters a zero-sum subtree
-        const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * node);
+        const float2 c = tree_ld2(pd, pd.tree + 2 * node);
         const bool right = (v > c.x && c.y > 0.0f) || c.x == 0.0f;
         if (right) v -= c.x;
         node = 2 * node + (right ? 1 : 0);
@@ -227,12 +247,13 @@ __device__ __forceinline__ int64_t prio_draw_one(const PrioDraw& pd, const RingV
 // The same draw by a whole wavefront, FOUR tree levels per memory round trip (round 5: the 20 dependent 8-byte reads of a
 // 2^20-leaf descent, ~7 us, were the critical path of a small prioritized batch): lanes 0 .. 14 request the 15 child pairs of the
 // depth-4 subtree below the current node at once, then the four decisions are taken from those registers (the pair of relative
-// node i on sub-level a sits in lane 2^a - 1 + i) -- the same comparisons on the same values in the same order as
+// node i on sub-level a sits in lane 2^a - 1 + i; round 6 tried SEVEN levels per trip -- 127 pairs, two loads per lane, three trips
+// instead of five: parity-green, batch 32 read 17.8 / 17.1 us against 17.5 / 16.9: no gain, not kept) -- the same comparisons on the same values in the same order as
 // prio_draw_one, hence the same leaf.  Called by all 64 lanes of one wave (uniform control flow); lane 0 does the bookkeeping.
 __device__ __forceinline__ int64_t prio_draw_wave(const PrioDraw& pd, const RingView& rb, int64_t b) {
     const int lane = (int)threadIdx.x & 63;
     const u32x4 w = philox4x32_10(pd.seed, (uint32_t)b, 0, pd.draw_ctr, TAG_SAMPLER);
-    float v = u01_f32(w.z) * pd.tree[1];
+    float v = u01_f32(w.z) * tree_ld(pd, pd.tree + 1);
     int64_t node = 1;
     int rem = 0;
     for (int64_t t = 1; t < pd.P; t <<= 1) ++rem;  // levels below the root
@@ -241,7 +262,7 @@ __device__ __forceinline__ int64_t prio_draw_wave(const PrioDraw& pd, const Ring
         float cx = 0.0f, cy = 0.0f;
         if (lane < (1 << L) - 1) {
             const int a = 31 - __clz(lane + 1), i = lane + 1 - (1 << a);
-            const float2 c = *reinterpret_cast<const float2*>(pd.tree + 2 * ((node << a) + i));
+            const float2 c = tree_ld2(pd, pd.tree + 2 * ((node << a) + i));
             cx = c.x;
             cy = c.y;
         }
@@ -292,6 +313,22 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
     __shared__ int64_t l_off[2];
     int64_t b = blockIdx.x;
     int64_t drawn = 0;
+    if (pd.upd_n > 0 && threadIdx.x < 64) {  // (uniform per wave) the pending write-back first: see PrioDraw
+        __shared__ SmallUpdateLds l_upd;
+        if (blockIdx.x == 0) {
+            sumtree_update_small_wave<true>(const_cast<float*>(pd.tree), pd.P, pd.logP, pd.n_leaves, pd.upd_key, pd.upd_prio, pd.upd_n, l_upd);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have reached the device-coherent level
+            if (threadIdx.x == 0) __hip_atomic_store(pd.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // workgroups are dispatched in index order, so workgroup 0 is resident before any other can spin here; the bound turns a
+        // broken assumption into a loud launch failure instead of a hang (~1 s of polling)
+        unsigned int polls = 0;
+        while (__hip_atomic_load(pd.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1u << 24)) __builtin_trap();
+        }
+        asm volatile("" ::: "memory");
+    }
     if (pd.tree && threadIdx.x < 64) drawn = prio_draw_wave(pd, rb, b);  // wave 0, four tree levels per round trip
     if (threadIdx.x == 0) {
         int64_t li = pd.tree ? drawn : idx[b];
@@ -331,6 +368,12 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(RingView rb, const i
                 *reinterpret_cast<nt_u32x4*>(d0 + i) = x[u];
                 *reinterpret_cast<nt_u32x4*>(d1 + i) = y[u];
             }
+        }
+    }
+    if (pd.upd_n > 0 && threadIdx.x == 0) {  // re-arm the two words: the workgroup that departs last (every one has passed its wait)
+        if (__hip_atomic_fetch_add(pd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(pd.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pd.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -745,7 +788,39 @@ int32_t rlhip_ring_sample_gather_prioritized(const rlhip_ring* rb, const float* 
         return rlhip_ring_gather(rb, idx_out, batch, s, a, r, term, s_next, stream);
     }
     return ring_gather_impl(rb, idx_out, batch, s, a, r, term, s_next,
-                            PrioDraw{tree, P, n_leaves, seed, draw_ctr, idx_out, key_out, prio_out}, stream);
+                            PrioDraw{tree, P, n_leaves, seed, draw_ctr, idx_out, key_out, prio_out, nullptr, nullptr, 0, 0, nullptr}, stream);
+}
+
+extern "C" int32_t rlhip_sumtree_update(float* tree, int64_t n_leaves, const int64_t* leaf, const float* prio, int64_t n,
+                                        rlhip_stream_t stream);
+
+int32_t rlhip_ring_update_sample_gather_prioritized(const rlhip_ring* rb, float* tree, const int64_t* upd_key, const float* upd_prio,
+                                                    int64_t n_upd, int64_t batch, uint64_t seed, uint32_t draw_ctr, int64_t* idx_out,
+                                                    int64_t* key_out, float* prio_out, void* s, int32_t* a, float* r, uint8_t* term,
+                                                    void* s_next, uint32_t* sync, rlhip_stream_t stream) {
+    RLHIP_REQUIRE(rb && tree && idx_out && s && a && r && term && s_next && batch >= 0 && n_upd >= 0, "bad arguments");
+    RLHIP_REQUIRE(n_upd == 0 || (upd_key && upd_prio), "NULL write-back arrays");
+    RLHIP_REQUIRE(rb->len_rt >= 1, "cannot sample from an empty trajectory");
+    const int64_t n_leaves = rb->capacity * rb->n_env;
+    int64_t P = 1;
+    int logP = 0;
+    while (P < n_leaves) P <<= 1, ++logP;
+    // ONE launch where the write-back fits the one-wavefront form and the gather is the frame-major one; anything else is the
+    // two calls it stands for (same results either way)
+    const bool one = n_upd >= 1 && n_upd <= SMALL_UPDATE_MAX && batch >= 1 && sync != nullptr && logP <= SMALL_MAXL &&
+                     n_leaves < (1ll << 31) && rlhip_ring_gather_is_frame_major(rb);
+    if (!one) {
+        if (n_upd > 0) {
+            int32_t rc = rlhip_sumtree_update(tree, n_leaves, upd_key, upd_prio, n_upd, stream);
+            if (rc) return rc;
+        }
+        return rlhip_ring_sample_gather_prioritized(rb, tree, batch, seed, draw_ctr, idx_out, key_out, prio_out, s, a, r, term, s_next,
+                                                    stream);
+    }
+    return ring_gather_impl(rb, idx_out, batch, s, a, r, term, s_next,
+                            PrioDraw{tree, P, n_leaves, seed, draw_ctr, idx_out, key_out, prio_out, upd_key, upd_prio, (int)n_upd, logP,
+                                     sync},
+                            stream);
 }
 
 static int32_t ring_gather_impl(const rlhip_ring* rb, const int64_t* idx, int64_t batch, void* s, int32_t* a, float* r,

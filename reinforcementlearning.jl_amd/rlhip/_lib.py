@@ -231,6 +231,7 @@ _PROTOS = {
     "rlhip_ring_push_priority": (i32, [P(Ring), vp, f32, vp]),
     "rlhip_ring_sample_prioritized": (i32, [P(Ring), vp, i64, u64, u32, vp, vp, vp, vp]),
     "rlhip_ring_sample_gather_prioritized": (i32, [P(Ring), vp, i64, u64, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "rlhip_ring_update_sample_gather_prioritized": (i32, [P(Ring), vp, vp, vp, i64, i64, u64, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rlhip_mlp2_nparams": (i64, [i64, i64, i64]),
     "rlhip_mlp2_forward_f32": (i32, [vp, i64, i64, i64, i32, vp, i64, vp, vp]),
     "rlhip_mlp2_init_f32": (i32, [vp, i64, i64, i64, u64, u32, vp]),

@@ -181,6 +181,30 @@ class CircularPrioritizedTraces(CircularArraySARTSTraces):
              ptr(key), ptr(prio), ptr(s), ptr(a), ptr(r), ptr(t), ptr(sn), stream_ptr())
         return (idx, key, prio), (s, a, r, t, sn)
 
+    def update_sample_gather_prioritized(self, upd_keys, upd_prio, batch, seed, draw_ctr):
+        """`trajectory[:priority, upd_keys] = upd_prio`, then the prioritized draw and the gather of its batch -- ONE launch for
+        <= 64 keys on a frame-major ring (bit-identical to set_priority_ + sample_gather_prioritized, which is what runs otherwise)
+        -> (idx, key, priority), (state, action0, reward, terminal, next_state)"""
+        dev = self.state.device
+        if not hasattr(self, "_sync"):
+            self._sync = torch.zeros(2, dtype=torch.int32, device=dev)  # zero before the first call; every call re-arms it
+        n_upd = 0 if upd_keys is None else upd_keys.numel()
+        if n_upd and (upd_keys.dtype != torch.int64 or upd_prio.dtype != torch.float32 or upd_prio.numel() != n_upd):
+            raise TypeError("keys must be int64 and priorities float32 of the same length")
+        idx = torch.empty(batch, dtype=torch.int64, device=dev)
+        key = torch.empty(batch, dtype=torch.int64, device=dev)
+        prio = torch.empty(batch, dtype=torch.float32, device=dev)
+        shape = (batch, self.obs_dim) if self.frame_major else (self.obs_dim, batch)
+        s = torch.empty(shape, dtype=self.dtype, device=dev)
+        sn = torch.empty(shape, dtype=self.dtype, device=dev)
+        a = torch.empty(batch, dtype=torch.int32, device=dev)
+        r = torch.empty(batch, dtype=torch.float32, device=dev)
+        t = torch.empty(batch, dtype=torch.uint8, device=dev)
+        call("rlhip_ring_update_sample_gather_prioritized", C.byref(self.rb), ptr(self.priorities), ptr(upd_keys) if n_upd else None,
+             ptr(upd_prio) if n_upd else None, n_upd, batch, seed, draw_ctr, ptr(idx), ptr(key), ptr(prio), ptr(s), ptr(a), ptr(r), ptr(t),
+             ptr(sn), ptr(self._sync), stream_ptr())
+        return (idx, key, prio), (s, a, r, t, sn)
+
     def set_priority_(self, keys, prio):
         """trajectory[:priority, keys] = prio  (sequential semantics: the last duplicate key wins)"""
         if keys.dtype != torch.int64 or prio.dtype != torch.float32:

@@ -208,6 +208,17 @@ def test_prioritized_draw_gather_and_priority_round_trip(full):
             phys = (tr.rb.head_sa + oidx) % (CAP + 1)
             assert (phys < four_gib_slot).any() and (phys > four_gib_slot).any()
             assert (oidx >= CAP - EXTRA).any(), "no sample from the wrapped part of the ring"
+    # round 6: the write-back of the previous batch inside the next batch's launch (<= 64 keys), on the 2^21-node tree
+    for batch in (32, 512):
+        uk = rng.integers(0, CAP, 32).astype(np.int64)
+        up = oracle.per_priority(rng.standard_normal(32).astype(np.float32), 1e-6, 0.6)
+        (idx, key, pr), got = tr.update_sample_gather_prioritized(torch.as_tensor(uk).cuda(), torch.as_tensor(up).cuda(), batch, 11, ctr)
+        f.ost.update(uk, up)
+        assert np.array_equal(host(tr.priorities), f.ost.tree), "tree differs after the fused write-back"
+        oidx, okey, oprio = oracle.ring_sample_prioritized(f.oring, f.ost, batch, 11, ctr)
+        assert np.array_equal(host(idx), oidx) and np.array_equal(host(key), okey) and np.array_equal(host(pr), oprio)
+        check_gather(f, oidx, got, f"fused write-back + draw + gather, batch {batch}")
+        ctr += 1
     note("config5 prioritized", draws=ctr, total_priority=float(tr.priorities[1]))
 
 

@@ -353,3 +353,59 @@ def test_small_batch_update_kernel_bit_exact(n_leaves, n_upd):
         ref.update(keys, prio)
         _update(tree, n_leaves, keys, prio)
         assert np.array_equal(tree.cpu().numpy(), ref.tree), name
+
+
+@pytest.mark.parametrize("cap,n_upd,batch", [(300, 32, 32), (5000, 64, 32), (5000, 1, 512), (300, 7, 4096), (5000, 65, 32), (5000, 0, 32)])
+def test_fused_update_sample_gather_equals_the_two_calls_and_the_oracle(cap, n_upd, batch):
+    """rlhip_ring_update_sample_gather_prioritized (round 6): the previous batch's priority write-back, the draw and the frame gather in
+    ONE launch for <= 64 keys (n_upd = 65 / 0: the documented two-call route behind the same entry point).  Tree, indices, keys,
+    priorities and the gathered batch bit-identical to set_priority_ + sample_gather_prioritized on a copy of the same ring, and to
+    the oracle's SumTree.update + ring_sample_prioritized; duplicates among the keys (the last one wins); repeated calls re-arm the
+    two sync words."""
+    import rlhip
+
+    od = 84 * 84
+    g = torch.Generator(device="cuda").manual_seed(cap + n_upd)
+    rng = np.random.default_rng(cap + n_upd + batch)
+    trs = []
+    for _ in range(2):
+        tr = rlhip.CircularPrioritizedTraces(capacity=cap, n_env=1, obs_dim=od, dtype=torch.uint8, default_priority=1.0)
+        trs.append(tr)
+    a, b = trs
+    a.state.random_(0, 256, generator=g)
+    a.action.random_(0, 3, generator=g)
+    a.reward.normal_(generator=g)
+    a.terminal.copy_((torch.rand(a.terminal.shape, device="cuda", generator=g) < 0.1).to(torch.uint8))
+    for name in ("state", "action", "reward", "terminal"):
+        getattr(b, name).copy_(getattr(a, name))
+    prio0 = torch.rand(cap, device="cuda", generator=g) + 0.05
+    keys0 = torch.arange(cap, dtype=torch.int64, device="cuda")
+    for tr in trs:
+        tr.rb.len_sa, tr.rb.len_rt, tr.rb.head_rt, tr.rb.head_sa = cap + 1, cap, 17 % cap, 17 % (cap + 1)
+        tr.set_priority_(keys0, prio0)
+    ost = oracle.SumTree(cap)
+    ost.update(np.arange(cap, dtype=np.int64), prio0.cpu().numpy())
+    oring = oracle.Ring(cap, 1, 1)
+    oring.rb.len_sa, oring.rb.len_rt, oring.rb.head_rt, oring.rb.head_sa = cap + 1, cap, 17 % cap, 17 % (cap + 1)
+    assert np.array_equal(a.priorities.cpu().numpy(), ost.tree)
+    for call_no in range(3):
+        uk = rng.integers(0, cap, n_upd).astype(np.int64)
+        if n_upd >= 4:
+            uk[-1] = uk[0]          # a duplicate: the last occurrence wins
+            uk[1] = -1 if call_no == 1 else uk[1]   # an out-of-range key is ignored (as rlhip_sumtree_update)
+        up = (rng.random(n_upd) * 3 + 0.01).astype(np.float32)
+        dk, dp = torch.as_tensor(uk).cuda(), torch.as_tensor(up).cuda()
+        (i1, k1, p1), got1 = a.update_sample_gather_prioritized(dk if n_upd else None, dp if n_upd else None, batch, 9, call_no)
+        if n_upd:
+            b.set_priority_(dk, dp)
+        (i2, k2, p2), got2 = b.sample_gather_prioritized(batch, 9, call_no)
+        assert torch.equal(a.priorities, b.priorities), f"call {call_no}: the trees differ"
+        assert torch.equal(i1, i2) and torch.equal(k1, k2) and torch.equal(p1, p2)
+        for x, y in zip(got1, got2):
+            assert torch.equal(x, y)
+        if n_upd:
+            ost.update(uk, up)
+        assert np.array_equal(a.priorities.cpu().numpy(), ost.tree)
+        oi, ok_, op = oracle.ring_sample_prioritized(oring, ost, batch, 9, call_no)
+        assert np.array_equal(i1.cpu().numpy(), oi) and np.array_equal(k1.cpu().numpy(), ok_) and np.array_equal(p1.cpu().numpy(), op)
+        assert a._sync.tolist() == [0, 0]
