@@ -137,7 +137,7 @@ def roofline_env_step(torch, rlhip, n_envs=1 << 24, iters=20):
 
 # PMC measurement of the env-step kernel (tools/pmc_env.sh + tools/envstep.py; profiles/r04_pmc.md), valid for
 # the kernel sources whose sha256 (first 16 hex digits over csrc/envs.hip + csrc/env_device.h) is `sha`
-PMC_TRAFFIC = {"sha": "23d6334bde658716", "n_envs": 1 << 24, "bytes": 822221824.0, "source": "profiles/r05_pmc.md"}
+PMC_TRAFFIC = {"sha": "23d6334bde658716", "n_envs": 1 << 24, "bytes": 822223052.8, "source": "profiles/r06_pmc.md"}
 
 # The same for the other HBM-bound kernels of the bench line: HBM bytes per launch from the PMC counters
 # (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, mean of the last launches: tools/pmc_all.sh), each valid only while the
@@ -145,22 +145,23 @@ PMC_TRAFFIC = {"sha": "23d6334bde658716", "n_envs": 1 << 24, "bytes": 822221824.
 # `fetch_x2: False`: a kernel of scattered 16-byte reads, for which the guide's x 2 streaming calibration of FETCH_SIZE does not
 # hold (profiles/r05_pmc.md: the counter tallies 64 bytes per fabric request whatever its size).
 PMC_SIDE = {
-    # name in the line: (source files, sha over them, bytes per launch, note)      -- tools/pmc_all.sh on the final sources of round 5
-    "gae_returns": (["scans.hip", "gae_device.h"], "a163648c638b5c15", 574705664.0, ""),
-    "frame_gather_u8": (["ring.hip", "ring_device.h"], "6dc223a112b6b8e4", 474173542.4, ""),
-    "frame_gather_u8_stack_at_sample": (["ring.hip", "ring_device.h"], "6dc223a112b6b8e4", 387112857.6, ""),
-    "env_step_pendulum": (["envs.hip", "env_device.h"], "23d6334bde658716", 755441049.6, ""),
-    "env_step_mountaincar": (["envs.hip", "env_device.h"], "23d6334bde658716", 553799987.2, ""),
-    "adam_2p26": (["optim.hip", "optim_device.h"], "d111d4a74bb9a142", 1879104512.0, ""),
-    "adam_2p22": (["optim.hip", "optim_device.h"], "d111d4a74bb9a142", 117666918.4, ""),
-    "polyak_2p26": (["optim.hip", "optim_device.h"], "d111d4a74bb9a142", 805315584.0, ""),
-    "polyak_2p22": (["optim.hip", "optim_device.h"], "d111d4a74bb9a142", 50340864.0, ""),
-    "push_transition_maxpool": (["ring.hip", "ring_device.h"], "6dc223a112b6b8e4", 346919321.6, ""),
-    "gather_small": (["ring.hip", "ring_device.h"], "6dc223a112b6b8e4", 111646310.4,
-                     "FETCH_SIZE not doubled: scattered 16-byte reads reach the fabric as 64-byte requests, which the counter tallies "
-                     "at 64 bytes (TCC_EA0_RDREQ = 1.02 requests per sample, none of them 32-byte)"),
+    # name in the line: (source files, sha over them, bytes per launch, note)      -- tools/pmc_all.sh on the final sources of round 6
+    "gae_returns": (["scans.hip", "gae_device.h"], "a163648c638b5c15", 574705766.4, ""),
+    "frame_gather_u8": (["ring.hip", "ring_device.h", "sumtree_device.h"], "c150ec0211a5e8a3", 473958707.2, ""),
+    "frame_gather_u8_stack_at_sample": (["ring.hip", "ring_device.h", "sumtree_device.h"], "c150ec0211a5e8a3", 387121459.2, ""),
+    "env_step_pendulum": (["envs.hip", "env_device.h"], "23d6334bde658716", 755415244.8, ""),
+    "env_step_mountaincar": (["envs.hip", "env_device.h"], "23d6334bde658716", 553800192.0, ""),
+    "adam_2p26": (["optim.hip", "optim_device.h"], "13f7cbf603a83f38", 1879104512.0, ""),
+    "adam_2p22": (["optim.hip", "optim_device.h"], "13f7cbf603a83f38", 117662822.4, ""),
+    "polyak_2p26": (["optim.hip", "optim_device.h"], "13f7cbf603a83f38", 805315584.0, ""),
+    "polyak_2p22": (["optim.hip", "optim_device.h"], "13f7cbf603a83f38", 50340864.0, ""),
+    "push_transition_maxpool": (["ring.hip", "ring_device.h", "sumtree_device.h"], "c150ec0211a5e8a3", 346919219.2, ""),
+    "gather_small": (["ring.hip", "ring_device.h", "sumtree_device.h"], "c150ec0211a5e8a3", 111666892.8,
+                     "FETCH_SIZE not doubled: scattered 16-byte reads reach the fabric as 64-byte requests, which the counter tallies at 64 bytes (TCC_EA0_RDREQ = 1.02 requests per sample, none of them 32-byte)"),
+    "gather_small_hbm": (["ring.hip", "ring_device.h", "sumtree_device.h"], "c150ec0211a5e8a3", 114353049.6,
+                     "FETCH_SIZE not doubled (as gather_small)"),
 }
-PMC_SIDE_SOURCE = "profiles/r05_pmc.md"
+PMC_SIDE_SOURCE = "profiles/r06_pmc.md"
 
 
 def sources_sha(files):
