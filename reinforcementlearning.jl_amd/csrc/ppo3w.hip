@@ -15,17 +15,21 @@
 //                     H1 tile in LDS -> MFMA -> H2 in registers -> head through a wave-private LDS transposition of the
 //                     wave's own 64 x 32 block -> loss line per sample on wave 0 (modes: PPO actor, PPO critic, DQN target
 //                     network = forward only, DQN online network) -> dZ2 in the MFMA D layout; db2 / dW3 / db3 and the loss
-//                     sums stay in registers across tiles.  dZ2 leaves as bf16 twice: row-major (A operand of dH1 = dZ2 W2;
-//                     64-byte row segments through the wave's private block) and in MFMA B-fragment order (B operand of dW2 =
-//                     H1^T dZ2: the D layout holds 4 consecutive samples of one column per register group, which IS 8 of
-//                     the 16 bytes of a fragment slot -- 512 B contiguous per store instruction, no transposition).
+//                     sums stay in registers across tiles.  dZ2 leaves as bf16 ONCE since round 6: row-major (A operand of dH1 =
+//                     dZ2 W2; 64-byte row segments through the wave's private block), one buffer per net, kept until the dW2
+//                     launch.  (Rounds 2 - 5 wrote it a second time in MFMA B-fragment order for dW2 = H1^T dZ2 -- 512 B
+//                     contiguous per store instruction, no transposition, but half of the kernel's store bytes: the tile's
+//                     stores are a serialised ~2000-cycle resource of the CU, and dropping that image took 4 us off each
+//                     forward launch; RLHIP_W3_DZ_ONCE = 0 restores it.)
 //   ppo3w_bwd_kernel  W2^T fragments resident.  dZ2 rows tile -> LDS (double-buffered, register-staged two passes ahead) ->
 //                     MFMA -> dH1 in registers; z1 is recomputed from the observation (ns <= 4 FMAs per element: cheaper
 //                     than 2 bytes of HBM), dz1, db1 / dW1 in registers across tiles; one barrier per pass.
 //   ppo3w_dw2_kernel  the f32 accumulator resident: a workgroup owns one half of the k range (128 x 256 outputs = 64
 //                     registers per lane) for a strided set of sample tiles; A = H1^T recomputed into LDS in [k][sample]
-//                     order, B = the dZ2 fragments straight from global memory (two register sets in flight); the two
-//                     halves of a sample range run on ONE XCD so that its L2 serves the second read.
+//                     order, B = the dZ2 fragments gathered out of the ROW image: the tile's rows go global -> registers (two
+//                     tiles in flight) -> LDS in front of the pass's one barrier, and a lane builds its fragment (8 consecutive
+//                     samples of one column) with two transposing LDS reads (ds_read_b64_tr_b16); the two halves of a sample
+//                     range run on ONE XCD so that its L2 serves the second read.
 // Tile inputs come from a once-per-step gather in sample order (ppo3w_gather*_kernel / dqn3w_gather_kernel) as coalesced
 // wave loads at addresses that depend on the tile index only, issued unconditionally by every wave (see load_x).
 // Partial gradients are rows (one per persistent workgroup) summed in a fixed order (ppo3w_reduce_kernel, or the two-launch
@@ -66,6 +70,13 @@ __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { retur
 // per-phase cycle stamps of one steady-state tile (workgroup 0, thread 0, its second / third tile): -DRLHIP_W3_TIMING.
 // PROPORTIONS ONLY: the stamps change the register allocation (the backward kernel spilled 584 bytes per lane in one timing
 // build and ran 4x slower than the shipped one) -- kernel times come from rocprofv3 on the normal build.
+// RLHIP_W3_DZ_ONCE (round 6, VERDICT r5 item 2 "dZ2 written once"): the forward kernel writes dZ2 in ONE layout, the bf16 row image
+// (one buffer per net, kept until the dW2 launch); the dW2 kernel gathers its B fragments -- 8 consecutive samples of one column --
+// from that image with 2-byte loads (8 per fragment, two tiles ahead, packed right before the MFMAs) instead of reading a second,
+// fragment-ordered image: -128 MB written and -128 MB read per optimiser step of a PPO pair, half the forward kernel's store bytes.
+#ifndef RLHIP_W3_DZ_ONCE
+#define RLHIP_W3_DZ_ONCE 1  // shipped since round 6 (0 = the two-image form of rounds 2 - 5, kept for A / B)
+#endif
 #ifdef RLHIP_W3_TIMING
 __device__ long long g_w3_stamps[3][16];
 #define W3_STAMP(kern, k)                                                                                  \
@@ -652,6 +663,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
             // fragment order: samples 32 rt + 8 gq + 4 kb + {0..3} of column `col` = bytes 8 kb .. 8 kb + 7 of slot
             // (k-step 2 rt + (gq >> 1), column tile w, lane 32 (gq & 1) + r)
+#if !RLHIP_W3_DZ_ONCE
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 v2;
@@ -660,6 +672,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 const int64_t slot = (((int64_t)tile * (RW / 16) + 2 * rt + (gq >> 1)) * WV + w) * 64 + 32 * (gq & 1) + r;
                 *reinterpret_cast<uint2*>(g.dz_frag + (NET == 1 ? g.frag_stride : 0) + slot * 8 + 4 * kb) = v2;
             }
+#endif
         }
         W3_STAMP(0, 6);
         wave_lds_fence();
@@ -891,13 +904,37 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
 }
 
 // ------------------------------------------------------------------------------------------------ dW2 = H1^T dZ2
-constexpr size_t DW2W_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * (HW / 2) * PT * sizeof(uint16_t);
+constexpr size_t DW2W_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * (HW / 2) * PT * sizeof(uint16_t)
+#if RLHIP_W3_DZ_ONCE
+                            + (size_t)2 * RW * PW * sizeof(uint16_t)  // the tile's dZ2 ROWS, double-buffered (as ppo3w_bwd_kernel stages them)
+#endif
+    ;
 
 __device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_frag, int tile, int w, int lane,
                                               bf16x8 (&b)[RW / 16]) {
 #pragma unroll
     for (int ks = 0; ks < RW / 16; ++ks)
         b[ks] = *reinterpret_cast<const bf16x8*>(dz_frag + ((((int64_t)tile * (RW / 16) + ks) * WV + w) * 64 + lane) * 8);
+}
+
+// RLHIP_W3_DZ_ONCE: the same fragments out of the ROW image dz[tile * RW + sample][HW].  The tile's rows travel global -> registers
+// (16-byte coalesced loads two passes ahead: load_dz_tile) -> LDS [RW][PW] in front of the pass's one barrier (store_dz_tile), and a
+// lane gathers the fragment of k-step ks -- samples 16 ks + 8 kb + 0 .. 7 of column 32 w + r -- out of it.
+// (First form tried: eight 2-byte reads per fragment straight from global memory, no LDS: ppo3w_dw2_kernel 43.8 -> 57.4 us; tools/r6_m.sh.)
+// Two transposing LDS reads per fragment (ds_read_b64_tr_b16; semantics pinned by tools/micro/tr16_probe.hip: within a 16-lane group,
+// lane g passes the address of M[R0 + (g >> 2)][C0 + 4 (g & 3)] and receives M[R0 .. R0 + 3][C0 + g]): group G = lane >> 4 covers columns
+// 32 w + 16 (G & 1) + 0 .. 15 of the k half kb = G >> 1, rows 16 ks + 8 kb + {0 .. 3 | 4 .. 7}.
+// (Second form tried: eight 2-byte LDS reads + four packs per fragment: 42.1 -> 53.0 us.)
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 gather_dz_col(const uint16_t* lD, int ks, int w, int lane) {
+    const int G = lane >> 4, g = lane & 15;
+    const uint16_t* src = lD + (16 * ks + 8 * (G >> 1) + (g >> 2)) * PW + 32 * w + 16 * (G & 1) + 4 * (g & 3);
+    typedef __attribute__((address_space(3))) tr_v4s* lds_v4s_ptr;
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(src));
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(src + 4 * PW));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);  // (whole registers: no 16-bit shuffling)
+    const nt_u32x4 u = {l2.x, l2.y, h2.x, h2.y};
+    return __builtin_bit_cast(bf16x8, u);
 }
 
 template <int NS, int ACT>
@@ -938,7 +975,12 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
     // the tile of pass it + 2 right after its MFMAs (two passes in flight); the gather alternates between waves 7 and 6
     // observations: set it & 1 holds tile + 1 at the top of pass `it`, lands in the other LDS copy, is re-issued with tile + 3
     // (indices clamped to the last tile instead of branching: unconditional loads keep the vmcnt bookkeeping exact)
+#if RLHIP_W3_DZ_ONCE
+    nt_u32x4 dzs[2][4];  // this thread's four 16-byte chunks of a tile's rows, two tiles in flight
+    uint16_t* l_dz = l_T + 2 * (HW / 2) * PT;  // [2][RW][PW]
+#else
     bf16x8 bq[2][RW / 16];
+#endif
     float xr[2][NS];
     const int last = g.ntiles - 1;
     {
@@ -951,9 +993,15 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
 #pragma unroll
         for (int i = 0; i < NWL; ++i) wv[i] = (tid + NTW * i < HW * NS + HW) ? pnet[tid + NTW * i] : 0.0f;
         load_x<NS>(g, min(sr + nsr, last), lane, xr[0]);
+#if RLHIP_W3_DZ_ONCE
+        load_dz_tile(dzf, min(sr, last), tid, dzs[0]);
+        load_x<NS>(g, min(sr + 2 * nsr, last), lane, xr[1]);
+        load_dz_tile(dzf, min(sr + nsr, last), tid, dzs[1]);
+#else
         load_dz_frags(dzf, min(sr, last), w, lane, bq[0]);
         load_x<NS>(g, min(sr + 2 * nsr, last), lane, xr[1]);
         load_dz_frags(dzf, min(sr + nsr, last), w, lane, bq[1]);
+#endif
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
             if (tid + NTW * i < HW * NS + HW) l_w[tid + NTW * i] = wv[i];
@@ -983,6 +1031,11 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
         uint16_t* lT = l_T + p * (HW / 2) * PT;
         store_x<NS>(l_xw + (p ^ 1) * WV * 4 * RW, lane, xr[p]);
         load_x<NS>(g, min(tile + 3 * nsr, last), lane, xr[p]);
+#if RLHIP_W3_DZ_ONCE
+        uint16_t* lD = l_dz + p * RW * PW;
+        store_dz_tile(lD, tid, dzs[p]);  // this pass's rows (requested two passes ago); read behind the pass's barrier
+        load_dz_tile(dzf, min(tile + 2 * nsr, last), tid, dzs[p]);
+#endif
         wave_lds_fence();
         W3_STAMP(2, 1);
         // ---- layer 1 in [k][sample] order for the 128 hidden units of this half, on the f32 MFMA (bit-identical to the
@@ -1008,15 +1061,32 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
         }
         __syncthreads();  // the one barrier of a pass
         W3_STAMP(2, 2);
+#if RLHIP_W3_DZ_ONCE
+        bf16x8 bnx = gather_dz_col(lD, 0, w, lane);
+#endif
 #pragma unroll
-        for (int ks = 0; ks < RW / 16; ++ks)
+        for (int ks = 0; ks < RW / 16; ++ks) {
+#if RLHIP_W3_DZ_ONCE
+            // the fragment of k-step ks + 1 is requested in front of the MFMAs of k-step ks; the scheduling barrier keeps the scheduler from
+            // hoisting all 24 LDS reads of a pass to its top (256 registers + spills without it)
+            const bf16x8 bfr = bnx;
+            if (ks + 1 < RW / 16) bnx = gather_dz_col(lD, ks + 1, w, lane);
+            if (ks == 2) __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(lT + (32 * kt + r) * PT + 16 * ks + 8 * kb);
+#if RLHIP_W3_DZ_ONCE
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[kt], 0, 0, 0);
+#else
                 acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[p][ks], acc[kt], 0, 0, 0);
+#endif
             }
+        }
         W3_STAMP(2, 3);
+#if !RLHIP_W3_DZ_ONCE
         load_dz_frags(dzf, min(tile + 2 * nsr, last), w, lane, bq[p]);
+#endif
         W3_STAMP(2, 4);
     };
     const int npass = (g.ntiles - sr + nsr - 1) / nsr;
@@ -1730,8 +1800,10 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>, FWDW_LDS, &d1_))) return rc_;                \
         if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                             \
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                             \
+        if (RLHIP_W3_DZ_ONCE) g.dz_rows = g.dz_frag; /* one row image per net, kept for the dW2 launch */              \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                \
+        if (RLHIP_W3_DZ_ONCE) g.dz_rows = g.dz_frag + g.frag_stride;                                                  \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 1);                \
         hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr, 2), dim3(NTW), DW2W_LDS, s, g, -1, nsr);      \
@@ -2113,6 +2185,7 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>, FWDW_LDS, &d1_))) return rc_;                   \
         if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                              \
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                              \
+        if (RLHIP_W3_DZ_ONCE) g.dz_rows = g.dz_frag; /* the one dZ2 image (rows), read by bwd AND dw2 */                \
         hipLaunchKernelGGL((dqn3w_gather_kernel<NS_>), dim3(gb), dim3(256), 0, s, r, g);                               \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
