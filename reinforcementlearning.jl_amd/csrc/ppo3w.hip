@@ -15,21 +15,19 @@
 //                     H1 tile in LDS -> MFMA -> H2 in registers -> head through a wave-private LDS transposition of the
 //                     wave's own 64 x 32 block -> loss line per sample on wave 0 (modes: PPO actor, PPO critic, DQN target
 //                     network = forward only, DQN online network) -> dZ2 in the MFMA D layout; db2 / dW3 / db3 and the loss
-//                     sums stay in registers across tiles.  dZ2 leaves as bf16 ONCE since round 6: row-major (A operand of dH1 =
-//                     dZ2 W2; 64-byte row segments through the wave's private block), one buffer per net, kept until the dW2
-//                     launch.  (Rounds 2 - 5 wrote it a second time in MFMA B-fragment order for dW2 = H1^T dZ2 -- 512 B
-//                     contiguous per store instruction, no transposition, but half of the kernel's store bytes: the tile's
-//                     stores are a serialised ~2000-cycle resource of the CU, and dropping that image took 4 us off each
-//                     forward launch; RLHIP_W3_DZ_ONCE = 0 restores it.)
-//   ppo3w_bwd_kernel  W2^T fragments resident.  dZ2 rows tile -> LDS (double-buffered, register-staged two passes ahead) ->
-//                     MFMA -> dH1 in registers; z1 is recomputed from the observation (ns <= 4 FMAs per element: cheaper
-//                     than 2 bytes of HBM), dz1, db1 / dW1 in registers across tiles; one barrier per pass.
+//                     sums stay in registers across tiles.  dZ2 leaves as bf16 ONCE since round 6, in MFMA fragment order (the
+//                     D registers as they are: 512 B contiguous per store instruction, no transposition), one buffer per net, kept
+//                     until the dW2 launch.  (Rounds 2 - 5 wrote a row-major image for the backward kernel as well -- half of
+//                     the kernel's store bytes: the tile's stores are a serialised ~2000-cycle resource of the CU, and one image
+//                     less took 7 us off each forward launch; RLHIP_W3_DZ_ONCE above.)
+//   ppo3w_bwd_kernel  W2^T fragments resident.  dZ2 fragment tile -> LDS, copied lane-linear (double-buffered, register-staged two
+//                     passes ahead); the A operand (lane = sample row) is read out of it TRANSPOSED: two ds_read_b64_tr_b16 per
+//                     fragment -> MFMA -> dH1 in registers; z1 is recomputed from the observation (ns <= 4 FMAs per element:
+//                     cheaper than 2 bytes of HBM), dz1, db1 / dW1 in registers across tiles; one barrier per pass.
 //   ppo3w_dw2_kernel  the f32 accumulator resident: a workgroup owns one half of the k range (128 x 256 outputs = 64
 //                     registers per lane) for a strided set of sample tiles; A = H1^T recomputed into LDS in [k][sample]
-//                     order, B = the dZ2 fragments gathered out of the ROW image: the tile's rows go global -> registers (two
-//                     tiles in flight) -> LDS in front of the pass's one barrier, and a lane builds its fragment (8 consecutive
-//                     samples of one column) with two transposing LDS reads (ds_read_b64_tr_b16); the two halves of a sample
-//                     range run on ONE XCD so that its L2 serves the second read.
+//                     order, B = the dZ2 fragments as the forward kernel stored them (16-byte loads, two tiles in flight); the two
+//                     halves of a sample range run on ONE XCD so that its L2 serves the second read.
 // Tile inputs come from a once-per-step gather in sample order (ppo3w_gather*_kernel / dqn3w_gather_kernel) as coalesced
 // wave loads at addresses that depend on the tile index only, issued unconditionally by every wave (see load_x).
 // Partial gradients are rows (one per persistent workgroup) summed in a fixed order (ppo3w_reduce_kernel, or the two-launch
@@ -70,12 +68,24 @@ __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { retur
 // per-phase cycle stamps of one steady-state tile (workgroup 0, thread 0, its second / third tile): -DRLHIP_W3_TIMING.
 // PROPORTIONS ONLY: the stamps change the register allocation (the backward kernel spilled 584 bytes per lane in one timing
 // build and ran 4x slower than the shipped one) -- kernel times come from rocprofv3 on the normal build.
-// RLHIP_W3_DZ_ONCE (round 6, VERDICT r5 item 2 "dZ2 written once"): the forward kernel writes dZ2 in ONE layout, the bf16 row image
-// (one buffer per net, kept until the dW2 launch); the dW2 kernel gathers its B fragments -- 8 consecutive samples of one column --
-// from that image with 2-byte loads (8 per fragment, two tiles ahead, packed right before the MFMAs) instead of reading a second,
-// fragment-ordered image: -128 MB written and -128 MB read per optimiser step of a PPO pair, half the forward kernel's store bytes.
+// RLHIP_W3_DZ_ONCE (round 6, VERDICT r5 item 2 "dZ2 written once"): the forward kernel writes dZ2 in ONE layout (rounds 2 - 5: two, rows
+// for the backward kernel and MFMA B-fragment order for the dW2 kernel; -128 MB written and -128 MB read per optimiser step of a PPO pair,
+// half of the forward kernel's store bytes -- and the tile's stores are what that kernel's passes wait for).  Which one:
+//   2 (shipped)  the FRAGMENT image: the forward kernel's D registers leave as they are (no transposition through the wave's private LDS
+//                block), the dW2 kernel loads its B operand as in rounds 2 - 5, and the BACKWARD kernel -- whose A operand is the transposed
+//                view, lane = sample row -- copies the tile lane-linear into LDS and reads it with ds_read_b64_tr_b16 (two per fragment)
+//   1            the ROW image: forward transposes, backward reads rows as in rounds 2 - 5, the dW2 kernel stages the rows in LDS and
+//                gathers its fragments with the transposing reads (first form of the round; 9 - 12 us per optimiser step slower than 2)
+//   0            both images (rounds 2 - 5), kept for A / B
+// RLHIP_W3_DZF_PAD (mode 2): four 16-byte slots of padding behind every 32 of the backward kernel's LDS copy make the transposing reads
+// bank-conflict free: the kernel -3 us per launch (30.5 -> 27.5), 5 % fewer cycles per optimiser step -- and on two of three boxes the
+// firmware then runs the whole step at a LOWER clock (2.11 vs 2.29 GHz at 1.05 vs 1.16 kW under a 1.4 kW cap) and the step is 2 - 3 %
+// SLOWER; on the third (no throttling) it is 4.5 % faster.  Off by default; profiles/r06_ppo3w.md section 6 has the three boxes.
 #ifndef RLHIP_W3_DZ_ONCE
-#define RLHIP_W3_DZ_ONCE 1  // shipped since round 6 (0 = the two-image form of rounds 2 - 5, kept for A / B)
+#define RLHIP_W3_DZ_ONCE 2
+#endif
+#ifndef RLHIP_W3_DZF_PAD
+#define RLHIP_W3_DZF_PAD 0
 #endif
 #ifdef RLHIP_W3_TIMING
 __device__ long long g_w3_stamps[3][16];
@@ -95,6 +105,8 @@ __device__ long long g_w3_stamps[3][16];
     do {                     \
     } while (0)
 #endif
+
+typedef short tr_v4s __attribute__((ext_vector_type(4)));  // ds_read_b64_tr_b16 result: four 16-bit elements
 
 struct Mlp3W {
     const float *W1, *b1, *b2, *W3, *b3;
@@ -659,11 +671,13 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
                 const float dz = dh * act_bwd_t<ACT>(hv, hv);  // relu: h2 > 0 <=> z2 > 0
                 a_db2 += dz;
                 h2[rt][q] = dz;  // the register is free: keep dz for the packed stores below
+#if RLHIP_W3_DZ_ONCE != 2
                 l_zw[row * ZPW + r] = f32_to_bf16_rne(dz);
+#endif
             }
             // fragment order: samples 32 rt + 8 gq + 4 kb + {0..3} of column `col` = bytes 8 kb .. 8 kb + 7 of slot
             // (k-step 2 rt + (gq >> 1), column tile w, lane 32 (gq & 1) + r)
-#if !RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE != 1
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 v2;
@@ -675,6 +689,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 #endif
         }
         W3_STAMP(0, 6);
+#if RLHIP_W3_DZ_ONCE != 2
         wave_lds_fence();
         {
             uint16_t* dst = g.dz_rows + (int64_t)tile * RW * HW + 32 * w;
@@ -685,6 +700,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
         }
         wave_lds_fence();
+#endif
         W3_STAMP(0, 7);
         // no barrier: the next pass writes l_H (last read before barrier C) and this wave's private block in program order
     }
@@ -722,7 +738,17 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------ dH1 -> dW1 / db1
-constexpr size_t BWDW_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * RW * PW * sizeof(uint16_t);
+#if RLHIP_W3_DZ_ONCE == 2
+#if RLHIP_W3_DZF_PAD
+constexpr int DZF_G = 72, DZF_H = 36;  // 16-byte slots per 64-slot group / per 32-slot half of the LDS copy of a fragment tile, padded
+#else
+constexpr int DZF_G = 64, DZF_H = 32;
+#endif
+constexpr int BWD_TILE_ELEMS = (RW / 16) * WV * DZF_G * 8;  // the LDS copy of a fragment tile (32 KB; 36 KB padded)
+#else
+constexpr int BWD_TILE_ELEMS = RW * PW;
+#endif
+constexpr size_t BWDW_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * BWD_TILE_ELEMS * sizeof(uint16_t);
 
 // this thread's four 16-byte chunks of a 64 x 256 bf16 tile: chunk c = tid + 512 i -> row c >> 5, column 8 (c & 31)
 __device__ __forceinline__ void load_dz_tile(const uint16_t* __restrict__ dz_rows, int tile, int tid, nt_u32x4 (&d)[4]) {
@@ -740,6 +766,49 @@ __device__ __forceinline__ void store_dz_tile(uint16_t* lH, int tid, const nt_u3
         *reinterpret_cast<nt_u32x4*>(lH + row * PW + 8 * cc) = d[i];
     }
 }
+
+#if RLHIP_W3_DZ_ONCE == 2
+// RLHIP_W3_DZ_ONCE == 2: the ONE image of dZ2 is the fragment image [tile][k-step s >> 4][column tile j >> 5][slot 32 ((s >> 3) & 1) +
+// (j & 31)][u = s & 7] (what the forward kernel's D registers store without any transposition, and what the dW2 kernel loads as its B
+// operand).  This kernel needs the transposed view -- A operand of dH1 = dZ2 W2: lane = sample row, 8 consecutive columns j -- and takes
+// it from a lane-linear LDS copy of the tile with two transposing reads per fragment: in 16-lane group G (rows 16 (G & 1) + 0 .. 15 of
+// the 32-row half rt, k half kb = G >> 1) lane 4 i + q addresses samples 4 q .. 4 q + 3 of column 16 ks + 8 kb + 4 h + i and lane g
+// receives its own sample's four columns (tools/micro/tr16_probe.hip).
+__device__ __forceinline__ void load_dzf_tile(const uint16_t* __restrict__ dz_frag, int tile, int tid, nt_u32x4 (&d)[4]) {
+    const uint16_t* src = dz_frag + (int64_t)tile * RW * HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const nt_u32x4*>(src + 8 * (tid + NTW * i));
+}
+// LDS copy of the tile: the 16-byte slots in image order.  With RLHIP_W3_DZF_PAD, FOUR slots of padding behind every 32 (slot c -> 72 (c >> 6)
+// + 36 ((c >> 5) & 1) + (c & 31)): the 16 segments a 16-lane group addresses in one transposing read -- columns i = 0 .. 3 (16 bytes apart),
+// sample quads q = 0 .. 3 (8 bytes apart for q & 1, the other 32-slot half for q >> 1) -- then fall on 16 different bank pairs (without the
+// padding the two halves are 512 bytes apart: the same banks, a two-way conflict)
+__device__ __forceinline__ void store_dzf_tile(uint16_t* lF, int tid, const nt_u32x4 (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTW * i;
+        *reinterpret_cast<nt_u32x4*>(lF + 8 * (DZF_G * (c >> 6) + DZF_H * ((c >> 5) & 1) + (c & 31))) = d[i];
+    }
+}
+__device__ __forceinline__ int dzf_lane_base(int lane) {  // element offset of this lane's segment for (rt, ks, h) = (0, 0, 0)
+    const int G = lane >> 4, g = lane & 15, i = g >> 2, q = g & 3;
+    return (((G & 1) * WV * DZF_G) + DZF_H * (q >> 1) + 8 * (G >> 1) + i) * 8 + 4 * (q & 1);
+}
+__device__ __forceinline__ bf16x8 dzf_a_frag(const uint16_t* lF, int base, int rt, int ks) {
+    typedef __attribute__((address_space(3))) tr_v4s* lds_v4s_ptr;
+    const uint16_t* src = lF + base + (2 * rt * WV * DZF_G + (ks >> 1) * DZF_G + 16 * (ks & 1)) * 8;
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(src));
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(src + 4 * 8));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    const nt_u32x4 u = {l2.x, l2.y, h2.x, h2.y};
+    return __builtin_bit_cast(bf16x8, u);
+}
+#define W3_LOAD_DZ(tile_, d_) load_dzf_tile(g.dz_frag + (net ? g.frag_stride : 0), tile_, tid, d_)
+#define W3_STORE_DZ(l_, d_) store_dzf_tile(l_, tid, d_)
+#else
+#define W3_LOAD_DZ(tile_, d_) load_dz_tile(g.dz_rows, tile_, tid, d_)
+#define W3_STORE_DZ(l_, d_) store_dz_tile(l_, tid, d_)
+#endif
 
 template <int NS, int ACT>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
@@ -770,20 +839,20 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
         float x0[NS];
         // issue order = the steady state of the pass loop (older: everything the prologue itself consumes; then set 0, then
         // set 1), so that the loop is entered with exactly the outstanding loads its back edge carries
-        load_dz_tile(g.dz_rows, t0, tid, d0);
+        W3_LOAD_DZ(t0, d0);
         load_x<NS>(g, t0, lane, x0);
         constexpr int NWL = (HW * NS + HW + NTW - 1) / NTW;
         float wv[NWL];
 #pragma unroll
         for (int i = 0; i < NWL; ++i) wv[i] = (tid + NTW * i < HW * NS + HW) ? pnet[tid + NTW * i] : 0.0f;
-        load_dz_tile(g.dz_rows, min(t0 + stride, last), tid, dzs[0]);
+        W3_LOAD_DZ(min(t0 + stride, last), dzs[0]);
         load_x<NS>(g, min(t0 + stride, last), lane, xr[0]);
-        load_dz_tile(g.dz_rows, min(t0 + 2 * stride, last), tid, dzs[1]);
+        W3_LOAD_DZ(min(t0 + 2 * stride, last), dzs[1]);
         load_x<NS>(g, min(t0 + 2 * stride, last), lane, xr[1]);
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
             if (tid + NTW * i < HW * NS + HW) l_w[tid + NTW * i] = wv[i];
-        store_dz_tile(l_H, tid, d0);
+        W3_STORE_DZ(l_H, d0);
         store_x<NS>(l_xw, lane, x0);
     }
     __syncthreads();
@@ -802,13 +871,13 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
         constexpr int p = decltype(PC)::value;
         W3_STAMP(1, 0);
         const float* lx = l_xw + p * WV * 4 * RW;
-        const uint16_t* lH = l_H + p * RW * PW;
+        const uint16_t* lH = l_H + p * BWD_TILE_ELEMS;
         {
             int t3 = tile + 3 * stride;  // past the end: re-read this workgroup's OWN first tile (never one tile for all)
             if (t3 > last) t3 = blockIdx.x;
-            store_dz_tile(l_H + (p ^ 1) * RW * PW, tid, dzs[p]);
+            W3_STORE_DZ(l_H + (p ^ 1) * BWD_TILE_ELEMS, dzs[p]);
             store_x<NS>(l_xw + (p ^ 1) * WV * 4 * RW, lane, xr[p]);
-            load_dz_tile(g.dz_rows, t3, tid, dzs[p]);
+            W3_LOAD_DZ(t3, dzs[p]);
             load_x<NS>(g, t3, lane, xr[p]);
         }
         W3_STAMP(1, 1);
@@ -818,6 +887,18 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) dh[rt][q] = 0.0f;
         {
+#if RLHIP_W3_DZ_ONCE == 2
+            const int abase = dzf_lane_base(lane);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                if ((ks & 3) == 0 && ks) __builtin_amdgcn_sched_barrier(0);  // (as in the dW2 kernel: bounds how far the LDS reads are hoisted)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const bf16x8 a = dzf_a_frag(lH, abase, rt, ks);
+                    dh[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], dh[rt], 0, 0, 0);
+                }
+            }
+#else
             const uint16_t* ap = lH + r * PW + 8 * kb;
 #pragma unroll
             for (int ks = 0; ks < KSW; ++ks)
@@ -826,6 +907,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PW + 16 * ks);
                     dh[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], dh[rt], 0, 0, 0);
                 }
+#endif
         }
         W3_STAMP(1, 2);
         // z1 = b1 + W1 x of the tile in the layout of dH1 (lane = hidden unit, registers = sample rows) on the f32 MFMA:
@@ -905,7 +987,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
 
 // ------------------------------------------------------------------------------------------------ dW2 = H1^T dZ2
 constexpr size_t DW2W_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * (HW / 2) * PT * sizeof(uint16_t)
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
                             + (size_t)2 * RW * PW * sizeof(uint16_t)  // the tile's dZ2 ROWS, double-buffered (as ppo3w_bwd_kernel stages them)
 #endif
     ;
@@ -925,7 +1007,6 @@ __device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_fr
 // lane g passes the address of M[R0 + (g >> 2)][C0 + 4 (g & 3)] and receives M[R0 .. R0 + 3][C0 + g]): group G = lane >> 4 covers columns
 // 32 w + 16 (G & 1) + 0 .. 15 of the k half kb = G >> 1, rows 16 ks + 8 kb + {0 .. 3 | 4 .. 7}.
 // (Second form tried: eight 2-byte LDS reads + four packs per fragment: 42.1 -> 53.0 us.)
-typedef short tr_v4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 gather_dz_col(const uint16_t* lD, int ks, int w, int lane) {
     const int G = lane >> 4, g = lane & 15;
     const uint16_t* src = lD + (16 * ks + 8 * (G >> 1) + (g >> 2)) * PW + 32 * w + 16 * (G & 1) + 4 * (g & 3);
@@ -975,7 +1056,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
     // the tile of pass it + 2 right after its MFMAs (two passes in flight); the gather alternates between waves 7 and 6
     // observations: set it & 1 holds tile + 1 at the top of pass `it`, lands in the other LDS copy, is re-issued with tile + 3
     // (indices clamped to the last tile instead of branching: unconditional loads keep the vmcnt bookkeeping exact)
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
     nt_u32x4 dzs[2][4];  // this thread's four 16-byte chunks of a tile's rows, two tiles in flight
     uint16_t* l_dz = l_T + 2 * (HW / 2) * PT;  // [2][RW][PW]
 #else
@@ -993,7 +1074,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
 #pragma unroll
         for (int i = 0; i < NWL; ++i) wv[i] = (tid + NTW * i < HW * NS + HW) ? pnet[tid + NTW * i] : 0.0f;
         load_x<NS>(g, min(sr + nsr, last), lane, xr[0]);
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
         load_dz_tile(dzf, min(sr, last), tid, dzs[0]);
         load_x<NS>(g, min(sr + 2 * nsr, last), lane, xr[1]);
         load_dz_tile(dzf, min(sr + nsr, last), tid, dzs[1]);
@@ -1031,7 +1112,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
         uint16_t* lT = l_T + p * (HW / 2) * PT;
         store_x<NS>(l_xw + (p ^ 1) * WV * 4 * RW, lane, xr[p]);
         load_x<NS>(g, min(tile + 3 * nsr, last), lane, xr[p]);
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
         uint16_t* lD = l_dz + p * RW * PW;
         store_dz_tile(lD, tid, dzs[p]);  // this pass's rows (requested two passes ago); read behind the pass's barrier
         load_dz_tile(dzf, min(tile + 2 * nsr, last), tid, dzs[p]);
@@ -1061,12 +1142,12 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
         }
         __syncthreads();  // the one barrier of a pass
         W3_STAMP(2, 2);
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
         bf16x8 bnx = gather_dz_col(lD, 0, w, lane);
 #endif
 #pragma unroll
         for (int ks = 0; ks < RW / 16; ++ks) {
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
             // the fragment of k-step ks + 1 is requested in front of the MFMAs of k-step ks; the scheduling barrier keeps the scheduler from
             // hoisting all 24 LDS reads of a pass to its top (256 registers + spills without it)
             const bf16x8 bfr = bnx;
@@ -1076,7 +1157,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(lT + (32 * kt + r) * PT + 16 * ks + 8 * kb);
-#if RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE == 1
                 acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[kt], 0, 0, 0);
 #else
                 acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[p][ks], acc[kt], 0, 0, 0);
@@ -1084,7 +1165,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_dw2_kernel(P3WArgs g, int net_ar
             }
         }
         W3_STAMP(2, 3);
-#if !RLHIP_W3_DZ_ONCE
+#if RLHIP_W3_DZ_ONCE != 1
         load_dz_frags(dzf, min(tile + 2 * nsr, last), w, lane, bq[p]);
 #endif
         W3_STAMP(2, 4);
@@ -1800,10 +1881,10 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>, FWDW_LDS, &d1_))) return rc_;                \
         if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                             \
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                             \
-        if (RLHIP_W3_DZ_ONCE) g.dz_rows = g.dz_frag; /* one row image per net, kept for the dW2 launch */              \
+        if (RLHIP_W3_DZ_ONCE == 1) g.dz_rows = g.dz_frag; /* one row image per net, kept for the dW2 launch */              \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                \
-        if (RLHIP_W3_DZ_ONCE) g.dz_rows = g.dz_frag + g.frag_stride;                                                  \
+        if (RLHIP_W3_DZ_ONCE == 1) g.dz_rows = g.dz_frag + g.frag_stride;                                                  \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
         hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 1);                \
         hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr, 2), dim3(NTW), DW2W_LDS, s, g, -1, nsr);      \
@@ -2185,7 +2266,7 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>, FWDW_LDS, &d1_))) return rc_;                   \
         if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                              \
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                              \
-        if (RLHIP_W3_DZ_ONCE) g.dz_rows = g.dz_frag; /* the one dZ2 image (rows), read by bwd AND dw2 */                \
+        if (RLHIP_W3_DZ_ONCE == 1) g.dz_rows = g.dz_frag; /* the one dZ2 image (rows), read by bwd AND dw2 */                \
         hipLaunchKernelGGL((dqn3w_gather_kernel<NS_>), dim3(gb), dim3(256), 0, s, r, g);                               \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
