@@ -1002,7 +1002,7 @@ __device__ __forceinline__ void load_dz_frags(const uint16_t* __restrict__ dz_fr
 // RLHIP_W3_DZ_ONCE: the same fragments out of the ROW image dz[tile * RW + sample][HW].  The tile's rows travel global -> registers
 // (16-byte coalesced loads two passes ahead: load_dz_tile) -> LDS [RW][PW] in front of the pass's one barrier (store_dz_tile), and a
 // lane gathers the fragment of k-step ks -- samples 16 ks + 8 kb + 0 .. 7 of column 32 w + r -- out of it.
-// (First form tried: eight 2-byte reads per fragment straight from global memory, no LDS: ppo3w_dw2_kernel 43.8 -> 57.4 us; tools/r6_m.sh.)
+// (First form tried: eight 2-byte reads per fragment straight from global memory, no LDS: ppo3w_dw2_kernel 43.8 -> 57.4 us; tools/contacts_r06/r6_m.sh.)
 // Two transposing LDS reads per fragment (ds_read_b64_tr_b16; semantics pinned by tools/micro/tr16_probe.hip: within a 16-lane group,
 // lane g passes the address of M[R0 + (g >> 2)][C0 + 4 (g & 3)] and receives M[R0 .. R0 + 3][C0 + g]): group G = lane >> 4 covers columns
 // 32 w + 16 (G & 1) + 0 .. 15 of the k half kb = G >> 1, rows 16 ks + 8 kb + {0 .. 3 | 4 .. 7}.

@@ -10,7 +10,7 @@ summation orders): the curves below are reproduced bit for bit on every run of t
   PPO     BASELINE configs[2]: 4096 Pendulum envs, T = 128, clip 0.1, 4 x 4 micro-batches of 131072, three-layer actor / critic of
           width 128 (`ppo3_gradT_kernel`) and 256 (csrc/ppo3w.hip).  Mean reward per step of an iteration's 524288 transitions
           (x 200 = the mean episode return).
-Measured curves (round 6, `tools/r6_learn_probe.py`) are in profiles/r06_parity_margins.md."""
+Measured curves (round 6, `tools/learn_probe.py`) are in profiles/r06_parity_margins.md."""
 import pytest
 
 pytestmark = pytest.mark.gpu

@@ -6,7 +6,7 @@ O=gpurun_out/r6_b; mkdir -p $O
 rm -f gpurun_out/bench_shape_margins.jsonl
 ( time timeout 900 python -m pytest tests/test_gpu_dqn_agent_vs_oracle.py -x -q -m gpu 2>&1 | tail -30 ) > $O/tests.log 2>&1; cat $O/tests.log
 cp gpurun_out/bench_shape_margins.jsonl $O/ 2>/dev/null; cat $O/bench_shape_margins.jsonl
-timeout 900 python tools/r6_learn_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/learn_probe.txt
+timeout 900 python tools/learn_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/learn_probe.txt
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err; tail -c 400 $O/bench_driver_form.err
 python - <<PY
 import json

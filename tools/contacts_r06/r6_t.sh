@@ -26,6 +26,6 @@ PY
   rm -rf $O/prof_$v
 done
 for v in F I J F I J; do
-  RLHIP_LIB_PATH=$PWD/gpurun_ab/lib$v.so timeout 300 python tools/r6_power_probe.py 4 ppo3w > $O/probe_ppo3w_$v.txt 2>&1
+  RLHIP_LIB_PATH=$PWD/gpurun_ab/lib$v.so timeout 300 python tools/power_probe.py 4 ppo3w > $O/probe_ppo3w_$v.txt 2>&1
   grep -E "STEADY" $O/probe_ppo3w_$v.txt | tee -a $O/steady.txt
 done

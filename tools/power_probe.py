@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the 256-wide learner's optimiser step running under the power cap?  Samples the GPU's hwmon power / sclk files from a thread while
 the main thread runs update_() back to back for a few seconds, and prints the per-iteration update time beside them.
-usage: python tools/r6_power_probe.py [seconds] [mode: ppo3w|dqn3w|idle]"""
+usage: python tools/power_probe.py [seconds] [mode: ppo3w|dqn3w|idle]"""
 import glob
 import os
 import sys
