@@ -784,6 +784,91 @@ def kernel_breakdown(torch, rlhip, pol, env):
     return out
 
 
+def sustained_clock_probe(torch, rlhip, pol, env, seconds=1.5):
+    """AFTER the timed region (nothing of the protocol in front of it changes): the chip's clock and socket power while (a) the headline step and
+    (b) the 256-wide PPO optimiser step run back to back for `seconds` each -- hwmon freq1_input / power1_input of THIS device (matched by PCI
+    address), sampled every 20 ms from a thread; steady state = the second half of each window.  Why it is in the line: on two of three
+    boxes of round 6 the 256-wide learner ran under a firmware limiter (2.11 - 2.35 of 2.4 GHz at 1.05 - 1.16 kW, cap 1.4 kW) whose clock depends
+    on the kernel mix (profiles/r06_ppo3w.md section 5; tools/power_probe.py is the stand-alone form), and a 16-ms burst after an idle gap
+    reads 3 - 5 % slower than the same work sustained: a learner number is only comparable together with the clock it ran at."""
+    import glob
+    import threading
+
+    pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+    want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+    files = {}
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if os.path.basename(os.path.realpath(d)).startswith(want):
+            for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                for name in ("freq1_input", "power1_input", "power1_average", "power1_cap", "temp2_input"):
+                    f = os.path.join(h, name)
+                    if os.path.exists(f):
+                        files.setdefault(name, f)
+    if "freq1_input" not in files:
+        return {"error": f"no hwmon freq1_input for PCI device {want}*"}
+
+    def rd(name):
+        try:
+            with open(files[name]) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError, KeyError):
+            return float("nan")
+
+    def window(burst, per_burst):
+        samples, marks, stop = [], [], [False]
+
+        def sampler():
+            while not stop[0]:
+                samples.append((time.perf_counter(), rd("freq1_input"), rd("power1_input" if "power1_input" in files else "power1_average"),
+                                rd("temp2_input")))
+                time.sleep(0.02)
+
+        th = threading.Thread(target=sampler)
+        th.start()
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            burst()
+            torch.cuda.synchronize()
+            marks.append((t0, (time.perf_counter() - t0) / per_burst * 1e6))
+        stop[0] = True
+        th.join()
+        t_a = marks[len(marks) // 2][0]
+        ss = [x for x in samples if x[0] >= t_a]
+        us = sorted(u for t, u in marks if t >= t_a)
+
+        def mean(i, scale):
+            v = [x[i] for x in ss if x[i] == x[i]]
+            return round(sum(v) / len(v) / scale, 1) if v else None
+
+        return {"sclk_mhz": mean(1, 1e6), "socket_w": mean(2, 1e6), "junction_c": mean(3, 1e3), "us_median": round(us[len(us) // 2], 1),
+                "us_min": round(us[0], 1), "bursts": len(us)}
+
+    out = {"power_cap_w": round(rd("power1_cap") / 1e6, 1) if "power1_cap" in files else None, "window_s": seconds,
+           "note": "after the timed region; steady state = second half of each window; sclk tops out at 2400 MHz"}
+
+    def head():
+        for _ in range(20):
+            pol.rollout_()
+            pol.update_()
+
+    out["headline_step"] = window(head, 20)
+    penv = rlhip.HipVecEnv("pendulum", 4096, seed=7)
+    ppol = rlhip.PPOPolicy(penv, update_freq=128, hidden=256, seed=7, clip_range=0.1, layers=3)
+    ppol.rollout_()
+    ppol.update_()
+    torch.cuda.synchronize()
+    nup = ppol.n_updates_per_call()
+
+    def upd():
+        for _ in range(5):
+            ppol._adv_ready = True
+            ppol.update_()
+
+    out["ppo3w_optimiser_step"] = window(upd, 5 * nup)
+    return out
+
+
 def _oracle_ppo_iterations(oracle, np, n, budget_s, max_iters):
     env = oracle.VecEnv("cartpole", n, seed=1)
     cfg = oracle.ppo_default(hidden=HIDDEN)
@@ -1181,13 +1266,18 @@ def main():
     }
     if want_extras:
         result["kernels"] = kernel_breakdown(torch, rlhip, pol, env)
+        if os.environ.get("RLHIP_BENCH_CLOCK_PROBE", "1") == "1":
+            try:  # a sensor that cannot be read must not cost the bench line
+                result["sustained_clock"] = sustained_clock_probe(torch, rlhip, pol, env)
+            except Exception as exc:  # noqa: BLE001
+                result["sustained_clock"] = {"error": repr(exc)}
         if not extras_first:
             run_extras()
         result["roofline"] = extras["roofline"]
         result["roofline_extra"] = extras["roofline_extra"]
         result["cpu_baseline"] = extras["cpu_baseline"]
         result["legs_order"] = (f"cpu_baseline, HBM rooflines, learner rooflines, [warmup, timed steps] -> ms_per_step_no_preheat, pre-heat up to {preheat} "
-                                f"untimed steps in total, [warmup, timed steps] -> ms_per_step, kernel breakdown"
+                                f"untimed steps in total, [warmup, timed steps] -> ms_per_step, kernel breakdown, sustained clock probe"
                                 if extras_first else "[warmup, timed steps], kernel breakdown, cpu_baseline, rooflines")
     if world > 1 and not args.no_extras:
         try:  # collective on every rank; a local failure must not cost the bench line
