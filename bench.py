@@ -866,6 +866,21 @@ def sustained_clock_probe(torch, rlhip, pol, env, seconds=1.5):
             ppol.update_()
 
     out["ppo3w_optimiser_step"] = window(upd, 5 * nup)
+    # the same step with the backward kernel's bank-conflict-free LDS copy (csrc/ppo3w.hip RLHIP_W3_DZF_PAD: bit-identical, 3 us per launch
+    # faster, off by default because two of three boxes of round 6 then clocked the whole step 6 - 8 % lower): which one wins on THIS box
+    try:
+        import ctypes as C
+
+        from rlhip._lib import lib as _l
+
+        _l.rlhip_debug_w3_dzf_pad.restype, _l.rlhip_debug_w3_dzf_pad.argtypes = C.c_int32, [C.c_int32]
+        prev = _l.rlhip_debug_w3_dzf_pad(1)
+        try:
+            out["ppo3w_optimiser_step_padded_lds_copy"] = window(upd, 5 * nup)
+        finally:
+            _l.rlhip_debug_w3_dzf_pad(prev)
+    except Exception as exc:  # noqa: BLE001
+        out["ppo3w_optimiser_step_padded_lds_copy"] = {"error": repr(exc)}
     return out
 
 

@@ -80,7 +80,8 @@ __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { retur
 // RLHIP_W3_DZF_PAD (mode 2): four 16-byte slots of padding behind every 32 of the backward kernel's LDS copy make the transposing reads
 // bank-conflict free: the kernel -3 us per launch (30.5 -> 27.5), 5 % fewer cycles per optimiser step -- and on two of three boxes the
 // firmware then runs the whole step at a LOWER clock (2.11 vs 2.29 GHz at 1.05 vs 1.16 kW under a 1.4 kW cap) and the step is 2 - 3 %
-// SLOWER; on the third (no throttling) it is 4.5 % faster.  Off by default; profiles/r06_ppo3w.md section 6 has the three boxes.
+// SLOWER; on the third (no throttling) it is 4.5 % faster.  Off by default (the macro is the DEFAULT of a run-time switch: environment variable RLHIP_W3_DZF_PAD, w3_dzf_pad() below; both kernels are
+// always built); profiles/r06_ppo3w.md section 5 has the boxes.
 #ifndef RLHIP_W3_DZ_ONCE
 #define RLHIP_W3_DZ_ONCE 2
 #endif
@@ -349,7 +350,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // ------------------------------------------------------------------------------------------------ forward + loss + dZ2
 constexpr int TPW = 36;  // f32 pitch of a wave's private 64 x 32 transposition block (144 B rows)
-constexpr int ZPW = 40;  // bf16 pitch of the same block when it holds the wave's dZ2 columns (80 B rows)
+[[maybe_unused]] constexpr int ZPW = 40;  // bf16 pitch of the same block when it holds the wave's dZ2 columns (80 B rows)
 constexpr size_t FWDW_LDS = (MAXO * RW + WV * MAXO * RW + SMALLWW + WV * RW * TPW) * sizeof(float) +
                             (size_t)RW * PW * sizeof(uint16_t);
 
@@ -372,7 +373,9 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     const int r = lane & 31, kb = lane >> 5;
     const int col = 32 * w + r;
     float* l_tw = l_t + w * RW * TPW;
-    uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);
+#if RLHIP_W3_DZ_ONCE != 2
+    uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);  // the wave's dZ2 columns as bf16 rows (the row image's copy-out)
+#endif
     const float* pnet = NET == 2 ? g.tparams : g.params + ((NET == 1 || NET == 4) ? g.np_a : 0);
     const float* xsrc = NET == 2 ? g.xg2 : g.xg;
     // every global load of the prologue is issued before the first wait: fragments, tile 0's inputs, the small tensors
@@ -738,17 +741,17 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------ dH1 -> dW1 / db1
+// PAD (template parameter of the backward kernel, chosen per launch: w3_dzf_pad()): the padded LDS copy of the fragment tile, see RLHIP_W3_DZF_PAD
+template <bool PAD>
+struct Dzf {
 #if RLHIP_W3_DZ_ONCE == 2
-#if RLHIP_W3_DZF_PAD
-constexpr int DZF_G = 72, DZF_H = 36;  // 16-byte slots per 64-slot group / per 32-slot half of the LDS copy of a fragment tile, padded
+    static constexpr int G = PAD ? 72 : 64, H = PAD ? 36 : 32;  // 16-byte slots per 64-slot group / per 32-slot half of the LDS copy
+    static constexpr int TILE = (RW / 16) * WV * G * 8;         // elements of one copy (32 KB; 36 KB padded)
 #else
-constexpr int DZF_G = 64, DZF_H = 32;
+    static constexpr int TILE = RW * PW;
 #endif
-constexpr int BWD_TILE_ELEMS = (RW / 16) * WV * DZF_G * 8;  // the LDS copy of a fragment tile (32 KB; 36 KB padded)
-#else
-constexpr int BWD_TILE_ELEMS = RW * PW;
-#endif
-constexpr size_t BWDW_LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * BWD_TILE_ELEMS * sizeof(uint16_t);
+    static constexpr size_t LDS = (2 * WV * 4 * RW + HW * 4 + HW) * sizeof(float) + (size_t)2 * TILE * sizeof(uint16_t);
+};
 
 // this thread's four 16-byte chunks of a 64 x 256 bf16 tile: chunk c = tid + 512 i -> row c >> 5, column 8 (c & 31)
 __device__ __forceinline__ void load_dz_tile(const uint16_t* __restrict__ dz_rows, int tile, int tid, nt_u32x4 (&d)[4]) {
@@ -783,20 +786,23 @@ __device__ __forceinline__ void load_dzf_tile(const uint16_t* __restrict__ dz_fr
 // + 36 ((c >> 5) & 1) + (c & 31)): the 16 segments a 16-lane group addresses in one transposing read -- columns i = 0 .. 3 (16 bytes apart),
 // sample quads q = 0 .. 3 (8 bytes apart for q & 1, the other 32-slot half for q >> 1) -- then fall on 16 different bank pairs (without the
 // padding the two halves are 512 bytes apart: the same banks, a two-way conflict)
+template <bool PAD>
 __device__ __forceinline__ void store_dzf_tile(uint16_t* lF, int tid, const nt_u32x4 (&d)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + NTW * i;
-        *reinterpret_cast<nt_u32x4*>(lF + 8 * (DZF_G * (c >> 6) + DZF_H * ((c >> 5) & 1) + (c & 31))) = d[i];
+        *reinterpret_cast<nt_u32x4*>(lF + 8 * (Dzf<PAD>::G * (c >> 6) + Dzf<PAD>::H * ((c >> 5) & 1) + (c & 31))) = d[i];
     }
 }
+template <bool PAD>
 __device__ __forceinline__ int dzf_lane_base(int lane) {  // element offset of this lane's segment for (rt, ks, h) = (0, 0, 0)
     const int G = lane >> 4, g = lane & 15, i = g >> 2, q = g & 3;
-    return (((G & 1) * WV * DZF_G) + DZF_H * (q >> 1) + 8 * (G >> 1) + i) * 8 + 4 * (q & 1);
+    return (((G & 1) * WV * Dzf<PAD>::G) + Dzf<PAD>::H * (q >> 1) + 8 * (G >> 1) + i) * 8 + 4 * (q & 1);
 }
+template <bool PAD>
 __device__ __forceinline__ bf16x8 dzf_a_frag(const uint16_t* lF, int base, int rt, int ks) {
     typedef __attribute__((address_space(3))) tr_v4s* lds_v4s_ptr;
-    const uint16_t* src = lF + base + (2 * rt * WV * DZF_G + (ks >> 1) * DZF_G + 16 * (ks & 1)) * 8;
+    const uint16_t* src = lF + base + (2 * rt * WV * Dzf<PAD>::G + (ks >> 1) * Dzf<PAD>::G + 16 * (ks & 1)) * 8;
     const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(src));
     const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(src + 4 * 8));
     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -804,14 +810,15 @@ __device__ __forceinline__ bf16x8 dzf_a_frag(const uint16_t* lF, int base, int r
     return __builtin_bit_cast(bf16x8, u);
 }
 #define W3_LOAD_DZ(tile_, d_) load_dzf_tile(g.dz_frag + (net ? g.frag_stride : 0), tile_, tid, d_)
-#define W3_STORE_DZ(l_, d_) store_dzf_tile(l_, tid, d_)
+#define W3_STORE_DZ(l_, d_) store_dzf_tile<PAD>(l_, tid, d_)
 #else
 #define W3_LOAD_DZ(tile_, d_) load_dz_tile(g.dz_rows, tile_, tid, d_)
 #define W3_STORE_DZ(l_, d_) store_dz_tile(l_, tid, d_)
 #endif
 
-template <int NS, int ACT>
+template <int NS, int ACT, bool PAD>
 __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
+    constexpr int BWD_TILE_ELEMS = Dzf<PAD>::TILE;
     extern __shared__ __attribute__((aligned(16))) char smw[];
     float* l_x = reinterpret_cast<float*>(smw);  // [2][WV][4][RW]: every wave keeps its own copy of the tile's observations
     float* l_w = l_x + 2 * WV * 4 * RW;          // W1 | b1
@@ -888,13 +895,13 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_bwd_kernel(P3WArgs g, int net) {
             for (int q = 0; q < 16; ++q) dh[rt][q] = 0.0f;
         {
 #if RLHIP_W3_DZ_ONCE == 2
-            const int abase = dzf_lane_base(lane);
+            const int abase = dzf_lane_base<PAD>(lane);
 #pragma unroll
             for (int ks = 0; ks < KSW; ++ks) {
                 if ((ks & 3) == 0 && ks) __builtin_amdgcn_sched_barrier(0);  // (as in the dW2 kernel: bounds how far the LDS reads are hoisted)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const bf16x8 a = dzf_a_frag(lH, abase, rt, ks);
+                    const bf16x8 a = dzf_a_frag<PAD>(lH, abase, rt, ks);
                     dh[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], dh[rt], 0, 0, 0);
                 }
             }
@@ -1690,6 +1697,35 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     return L;
 }
 
+// which LDS copy the backward kernel uses (RLHIP_W3_DZF_PAD above): the environment variable of the same name, read once; the compile-time
+// macro is the default.  rlhip_debug_w3_dzf_pad(on) switches at run time (on < 0: query only) and returns the previous setting -- for A / B
+// runs inside ONE process (tools/power_probe.py, bench.py's sustained_clock leg); not part of the ABI
+static int g_w3_dzf_pad = -1;
+static bool w3_dzf_pad() {
+    if (g_w3_dzf_pad < 0) {
+        const char* e = getenv("RLHIP_W3_DZF_PAD");
+        g_w3_dzf_pad = e != nullptr && e[0] != 0 ? (e[0] != '0') : (RLHIP_W3_DZF_PAD != 0);
+    }
+    return RLHIP_W3_DZ_ONCE == 2 && g_w3_dzf_pad != 0;
+}
+extern "C" int32_t rlhip_debug_w3_dzf_pad(int32_t on) {
+    const int32_t prev = w3_dzf_pad() ? 1 : 0;
+    if (on >= 0) g_w3_dzf_pad = on != 0;
+    return prev;
+}
+#define W3_LAUNCH_BWD(NS_, ACT_, net_)                                                                                               \
+    do {                                                                                                                             \
+        static unsigned long long dp0_ = 0, dp1_ = 0;                                                                                \
+        int32_t rcb_;                                                                                                                \
+        if (w3_dzf_pad()) {                                                                                                          \
+            if ((rcb_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_, true>, Dzf<true>::LDS, &dp1_))) return rcb_;                         \
+            hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_, true>), dim3(nrowsS), dim3(NTW), Dzf<true>::LDS, s, g, net_);            \
+        } else {                                                                                                                     \
+            if ((rcb_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_, false>, Dzf<false>::LDS, &dp0_))) return rcb_;                       \
+            hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_, false>), dim3(nrowsS), dim3(NTW), Dzf<false>::LDS, s, g, net_);          \
+        }                                                                                                                            \
+    } while (0)
+
 #ifdef RLHIP_W3_TIMING
 extern "C" int32_t rlhip_debug_w3_stamps(long long* out_host) {
     RLHIP_CHECK_HIP(hipDeviceSynchronize());
@@ -1875,18 +1911,17 @@ static int32_t ppo3w_grad_impl(int32_t kind, const rlhip_ppo_cfg* cfg, const Pol
     const int nsr = (int)(L.ntiles < rows_w ? L.ntiles : rows_w);
 #define LAUNCH_GW(NS_, ACT_, CONT_)                                                                                   \
     do {                                                                                                              \
-        static unsigned long long d0_ = 0, d1_ = 0, d2_ = 0, d3_ = 0;                                               \
+        static unsigned long long d0_ = 0, d1_ = 0, d3_ = 0;                                                       \
         int32_t rc_;                                                                                                  \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>, FWDW_LDS, &d0_))) return rc_;                \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>, FWDW_LDS, &d1_))) return rc_;                \
-        if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                             \
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                             \
         if (RLHIP_W3_DZ_ONCE == 1) g.dz_rows = g.dz_frag; /* one row image per net, kept for the dW2 launch */              \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 2, ACT_, CONT_, 0>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
-        hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                \
+        W3_LAUNCH_BWD(NS_, ACT_, 0);                                                                                  \
         if (RLHIP_W3_DZ_ONCE == 1) g.dz_rows = g.dz_frag + g.frag_stride;                                                  \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, 1, ACT_, CONT_, 1>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);      \
-        hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 1);                \
+        W3_LAUNCH_BWD(NS_, ACT_, 1);                                                                                  \
         hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr, 2), dim3(NTW), DW2W_LDS, s, g, -1, nsr);      \
     } while (0)
     if (kind == 0) {
@@ -2260,17 +2295,16 @@ int32_t dqn3w_grad(const rlhip_ring* rb, int64_t na, int32_t act, const float* p
     const int gb = (g.npad + 255) / 256;
 #define LAUNCH_DW(NS_, NA_, ACT_)                                                                                      \
     do {                                                                                                               \
-        static unsigned long long d0_ = 0, d1_ = 0, d2_ = 0, d3_ = 0;                                                \
+        static unsigned long long d0_ = 0, d1_ = 0, d3_ = 0;                                                        \
         int32_t rc_;                                                                                                   \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>, FWDW_LDS, &d0_))) return rc_;                   \
         if ((rc_ = allow_lds_w(ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>, FWDW_LDS, &d1_))) return rc_;                   \
-        if ((rc_ = allow_lds_w(ppo3w_bwd_kernel<NS_, ACT_>, BWDW_LDS, &d2_))) return rc_;                              \
         if ((rc_ = allow_lds_w(ppo3w_dw2_kernel<NS_, ACT_>, DW2W_LDS, &d3_))) return rc_;                              \
         if (RLHIP_W3_DZ_ONCE == 1) g.dz_rows = g.dz_frag; /* the one dZ2 image (rows), read by bwd AND dw2 */                \
         hipLaunchKernelGGL((dqn3w_gather_kernel<NS_>), dim3(gb), dim3(256), 0, s, r, g);                               \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 2>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
         hipLaunchKernelGGL((ppo3w_fwd_kernel<NS_, NA_, ACT_, 0, 3>), dim3(nrowsS), dim3(NTW), FWDW_LDS, s, g);         \
-        hipLaunchKernelGGL((ppo3w_bwd_kernel<NS_, ACT_>), dim3(nrowsS), dim3(NTW), BWDW_LDS, s, g, 0);                 \
+        W3_LAUNCH_BWD(NS_, ACT_, 0);                                                                                   \
         hipLaunchKernelGGL((ppo3w_dw2_kernel<NS_, ACT_>), dim3(2 * nsr), dim3(NTW), DW2W_LDS, s, g, 0, nsr);           \
     } while (0)
     if (ns == 4 && na == 2) { if (act == 0) LAUNCH_DW(4, 2, 0); else LAUNCH_DW(4, 2, 1); }

@@ -149,6 +149,37 @@ def test_dqn3w_grad_vs_oracle(batch, ns, na, act):
         assert (terr <= 1e-4).mean() >= 0.999 and terr.max() <= 5e-3, ((terr <= 1e-4).mean(), terr.max())
 
 
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("batch,ns,na", [(1000, 4, 2), (20000, 4, 2), (300, 2, 3), (300, 3, 3)])
+def test_dqn3w_padded_lds_copy_of_the_backward_kernel_is_bit_identical(batch, ns, na, act):
+    """ppo3w_bwd_kernel<.., PAD = true> (rlhip_debug_w3_dzf_pad: the bank-conflict-free LDS copy, off by default) on the DQN learner's
+    instantiations: same gradient, bit for bit"""
+    import ctypes as C
+
+    import rlhip
+    from rlhip import _lib, dqn
+
+    fn = _lib.lib.rlhip_debug_w3_dzf_pad
+    fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
+    n_env, cap = 64, 40
+    rng = np.random.default_rng(batch + act)
+    traces = rlhip.CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=ns)
+    oring = oracle.Ring(cap, n_env, ns)
+    _fill_ring(traces, oring, ns, n_env, 57, rng, na)
+    pd, tpd = torch.as_tensor(_net(ns, na, 11), device="cuda"), torch.as_tensor(_net(ns, na, 12), device="cuda")
+    packed, tpacked = dqn.mlp3_pack(pd, ns, H, na), dqn.mlp3_pack(tpd, ns, H, na)
+    prev = fn(0)
+    try:
+        g0, l0 = dqn.dqn3_grad(traces, H, na, act, pd, packed, tpd, tpacked, batch, 0.99, 1.0, 7, 3)
+        g0, l0 = g0.clone(), l0.clone()
+        fn(1)
+        g1, l1 = dqn.dqn3_grad(traces, H, na, act, pd, packed, tpd, tpacked, batch, 0.99, 1.0, 7, 3)
+        g1, l1 = g1.clone(), l1.clone()
+    finally:
+        fn(prev)
+    assert torch.equal(g0, g1) and torch.equal(l0, l1) and float(g0.abs().max()) > 0
+
+
 def test_dqn3w_learner_trains_and_prioritized_write_back():
     """QBasedPolicy with the 3-layer net on CartPole: plan!/optimise! run, the target network re-packs on sync,
     priorities are written back for the sampled keys."""

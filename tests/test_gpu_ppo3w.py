@@ -119,6 +119,40 @@ def test_grad_matches_oracle(kind, cont, act):
     assert np.array_equal(pol.grad.cpu().numpy(), g)
 
 
+def _w3_pad(on):
+    """run-time switch of the backward kernel's LDS copy (csrc/ppo3w.hip: rlhip_debug_w3_dzf_pad; not part of the ABI); returns the previous setting"""
+    import ctypes as C
+
+    from rlhip import _lib
+
+    fn = _lib.lib.rlhip_debug_w3_dzf_pad
+    fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
+    return fn(on)
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+@pytest.mark.parametrize("kind,n,T", [("cartpole", 96, 9), ("pendulum", 2048, 40)])
+def test_padded_lds_copy_of_the_backward_kernel_is_bit_identical(kind, n, T, act):
+    """ppo3w_bwd_kernel<.., PAD = true> (bank-conflict-free transposing reads; profiles/r06_ppo3w.md section 5) reads the same fragments in the
+    same order as the default: the whole gradient, bit for bit -- a ragged 432-sample micro-batch and 640 tiles"""
+    a = {"relu": 0, "tanh": 1}[act]
+    env, pol = _setup(kind, n, T, n_microbatches=2, act=a)
+    pol.rollout_()
+    pol.gae_()
+    prev = _w3_pad(0)
+    try:
+        pol.grad_(1, 1)
+        g0, l0 = pol.grad.clone(), pol.losses.clone()
+        assert _w3_pad(1) == 0
+        pol.grad_(1, 1)
+        g1, l1 = pol.grad.clone(), pol.losses.clone()
+        assert _w3_pad(-1) == 1
+    finally:
+        _w3_pad(prev)
+    assert torch.equal(g0, g1) and torch.equal(l0, l1)
+    assert float(g0.abs().max()) > 0
+
+
 def test_grad_many_tiles_per_workgroup_matches_oracle():
     """2048 envs x 40 steps / 2 micro-batches = 40960 samples = 640 tiles: the 512 persistent forward / backward
     workgroups walk one or two tiles each, the 128 sample ranges of the dW2 kernel five tiles each"""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the 256-wide learner's optimiser step running under the power cap?  Samples the GPU's hwmon power / sclk files from a thread while
 the main thread runs update_() back to back for a few seconds, and prints the per-iteration update time beside them.
-usage: python tools/power_probe.py [seconds] [mode: ppo3w|dqn3w|idle]"""
+usage: python tools/power_probe.py [seconds] [mode: ppo3w|dqn3w|headline|envstep|idle] [pad: 0|1 -- the backward kernel's LDS copy, csrc/ppo3w.hip RLHIP_W3_DZF_PAD]"""
 import glob
 import os
 import sys
@@ -16,6 +16,11 @@ import rlhip  # noqa: E402
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 mode = sys.argv[2] if len(sys.argv) > 2 else "ppo3w"
+if len(sys.argv) > 3:
+    import ctypes as C
+    from rlhip import _lib
+    _lib.lib.rlhip_debug_w3_dzf_pad.argtypes = [C.c_int32]
+    _lib.lib.rlhip_debug_w3_dzf_pad(int(sys.argv[3]))
 
 
 def my_device_dirs():
@@ -186,7 +191,7 @@ for k in sorted(b):
 if marks:
     t_a, t_b = marks[len(marks) // 2][0], marks[-1][0]
     ss = [v for t, v in samples if t_a <= t <= t_b]
-    line = [f"STEADY mode={mode} lib={os.path.basename(os.environ.get('RLHIP_LIB_PATH', 'default'))}"]
+    line = [f"STEADY mode={mode} lib={os.path.basename(os.environ.get('RLHIP_LIB_PATH', 'default'))} pad={sys.argv[3] if len(sys.argv) > 3 else 'default'}"]
     for i, name in enumerate(keys):
         vals = [float(v[i]) for v in ss if not v[i].startswith("err")]
         if vals:
