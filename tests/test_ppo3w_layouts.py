@@ -39,6 +39,68 @@ def test_dz_fragment_store_is_the_mfma_b_operand_of_dw2():
                     assert tuple(buf[e]) == (16 * ks + 8 * (l >> 5) + u, 32 * w + (l & 31))
 
 
+def _tr16_b64(seg_of_lane):
+    """ds_read_b64_tr_b16 as pinned on the GPU by tools/micro/tr16_probe.hip: within a 16-lane group, lane g passes the address of a
+    4-element segment and receives out[g][i] = segment of lane 4 i + (g >> 2), element g & 3."""
+    out = [None] * 64
+    for base in range(0, 64, 16):
+        for g in range(16):
+            out[base + g] = [seg_of_lane[base + 4 * i + (g >> 2)][g & 3] for i in range(4)]
+    return out
+
+
+def _dzf_copy_slot(c, pad):  # store_dzf_tile: 16-byte slot c of the fragment tile -> slot of the LDS copy
+    G, Hh = (72, 36) if pad else (64, 32)
+    return G * (c >> 6) + Hh * ((c >> 5) & 1) + (c & 31)
+
+
+def test_bwd_transposing_reads_of_the_fragment_tile_are_the_mfma_a_operand_of_dh1():
+    """round 6: dZ2 leaves the forward kernel ONLY as the fragment image; ppo3w_bwd_kernel copies a tile's 2048 16-byte slots into LDS
+    (store_dzf_tile, optionally padded) and builds its A operand -- lane (m = sample row 32 rt + (l & 31), k half l >> 5), eight consecutive
+    columns 16 ks + 8 (l >> 5) + 0 .. 7 -- with two transposing reads per fragment (dzf_lane_base / dzf_a_frag).  Restated here with the
+    instruction's lane map: every fragment element is the right (sample, column), for both LDS layouts; and the padded layout puts the
+    16 segments of a 16-lane group on 16 different 8-byte bank pairs of the 64-bank LDS where the unpadded one puts them on 8."""
+    # the fragment tile as the forward kernel stores it (tile-relative): element -> (sample, col)
+    img = -np.ones((RW // 16 * WV * 64 * 8, 2), dtype=np.int64)
+    for w in range(WV):
+        for lane in range(64):
+            r, kb = lane & 31, lane >> 5
+            for rt in range(2):
+                for gq in range(4):
+                    slot = ((2 * rt + (gq >> 1)) * WV + w) * 64 + 32 * (gq & 1) + r
+                    for i in range(4):
+                        img[slot * 8 + 4 * kb + i] = (32 * rt + mfma_row(4 * gq + i, kb), 32 * w + r)
+    assert (img[:, 0] >= 0).all()
+    for pad in (False, True):
+        G, Hh = (72, 36) if pad else (64, 32)
+        lds = -np.ones(((RW // 16) * WV * G * 8, 2), dtype=np.int64)
+        for c in range(2048):
+            lds[8 * _dzf_copy_slot(c, pad):8 * _dzf_copy_slot(c, pad) + 8] = img[8 * c:8 * c + 8]
+        worst = 0
+        for rt in range(2):
+            for ks in range(HW // 16):
+                const = (2 * rt * WV * G + (ks >> 1) * G + 16 * (ks & 1)) * 8
+                frag = [[None] * 8 for _ in range(64)]
+                for h in range(2):  # the two reads of a fragment: + 4 slots
+                    addr = []
+                    for lane in range(64):
+                        Gq, g = lane >> 4, lane & 15
+                        i, q = g >> 2, g & 3
+                        base = (((Gq & 1) * WV * G) + Hh * (q >> 1) + 8 * (Gq >> 1) + i) * 8 + 4 * (q & 1)
+                        addr.append(base + const + 4 * 8 * h)
+                    got = _tr16_b64([[tuple(lds[a + e]) for e in range(4)] for a in addr])
+                    for lane in range(64):
+                        for e in range(4):
+                            frag[lane][4 * h + e] = got[lane][e]
+                    for b16 in range(0, 64, 16):  # bank pairs (8-byte granules of the 256-byte bank row) hit by one 16-lane group
+                        pairs = {(2 * a // 8) % 32 for a in addr[b16:b16 + 16]}
+                        worst = max(worst, 16 // len(pairs))
+                for lane in range(64):
+                    for u in range(8):
+                        assert frag[lane][u] == (32 * rt + (lane & 31), 16 * ks + 8 * (lane >> 5) + u), (pad, rt, ks, lane, u)
+        assert worst == (1 if pad else 2), (pad, worst)
+
+
 def test_w2_fragment_images_pack_kernel_equals_parameter_centric_repack():
     # ppo3w_pack_kernel: element q of an image -> which W2[j + HW k] it holds
     q = np.arange(HW * HW)
