@@ -606,7 +606,11 @@ def roofline_extras(torch, rlhip, hbm_only=False):
                    "ppo3w_rollout_kernel",
         "learner_mfma_tflops": round(mf / (per_step_us * 1e-6) / 1e12, 1),
         "frac_of_bf16_peak": round(mf / (per_step_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "final_loss": float(ppol.losses[0])}
+        "final_loss": float(ppol.losses[0]),
+        "note": "a burst of two update calls behind an idle gap; this learner's speed depends on the box's clock limiter (sustained_clock in this "
+                "line times 1.5 s of the same step with the chip's clock beside it).  Round 6 vs round 5 is a SAME-BOX A / B in "
+                "profiles/r06_ppo3w.md section 4: 212 -> 202 us per step (dZ2 written once, as the MFMA fragment image); boxes differ by "
+                "+-4 % for the same code"}
     return out
 
 
