@@ -788,7 +788,7 @@ def kernel_breakdown(torch, rlhip, pol, env):
     return out
 
 
-def sustained_clock_probe(torch, rlhip, pol, env, seconds=1.5):
+def sustained_clock_probe(torch, rlhip, pol, env, seconds=1.5):  # noqa: C901
     """AFTER the timed region (nothing of the protocol in front of it changes): the chip's clock and socket power while (a) the headline step and
     (b) the 256-wide PPO optimiser step run back to back for `seconds` each -- hwmon freq1_input / power1_input of THIS device (matched by PCI
     address), sampled every 20 ms from a thread; steady state = the second half of each window.  Why it is in the line: on two of three
@@ -870,19 +870,34 @@ def sustained_clock_probe(torch, rlhip, pol, env, seconds=1.5):
             ppol.update_()
 
     out["ppo3w_optimiser_step"] = window(upd, 5 * nup)
-    # the same step with the backward kernel's bank-conflict-free LDS copy (csrc/ppo3w.hip RLHIP_W3_DZF_PAD: bit-identical, 3 us per launch
-    # faster, off by default because two of three boxes of round 6 then clocked the whole step 6 - 8 % lower): which one wins on THIS box
+    # the same step with each of the backward kernel's two LDS copies forced (csrc/ppo3w.hip RLHIP_W3_DZF_PAD: bit-identical kernels; the padded copy
+    # is 3 us per launch faster and, on boxes with an active clock limiter, costs 6 - 8 % of the clock), then 3 s in the default mode (the host
+    # picks by the device's clock reading): which kernel wins on THIS box, and what the default picked
     try:
         import ctypes as C
 
         from rlhip._lib import lib as _l
 
-        _l.rlhip_debug_w3_dzf_pad.restype, _l.rlhip_debug_w3_dzf_pad.argtypes = C.c_int32, [C.c_int32]
-        prev = _l.rlhip_debug_w3_dzf_pad(1)
+        fn = _l.rlhip_debug_w3_dzf_pad_info
+        fn.restype, fn.argtypes = C.c_int32, [C.c_int32, C.POINTER(C.c_double)]
+        info = (C.c_double * 6)()
+        fn(-1, info)
+        mode0 = int(info[0])
+        out["ppo3w_optimiser_step"]["lds_copy_of_the_backward_kernel"] = {"mode": mode0, "padded": int(info[1])}
         try:
+            fn(0, info)
+            out["ppo3w_optimiser_step_unpadded_lds_copy"] = window(upd, 5 * nup)
+            fn(1, info)
             out["ppo3w_optimiser_step_padded_lds_copy"] = window(upd, 5 * nup)
+            fn(2, info)
+            seconds = 3.0
+            w = window(upd, 5 * nup)
+            fn(-1, info)
+            w.update({"picked_padded": int(info[1]), "switches": int(info[4]), "sensor": bool(info[5]), "last_reading_mhz": round(info[2], 1),
+                      "top_mhz": round(info[3], 1)})
+            out["ppo3w_optimiser_step_auto_3s"] = w
         finally:
-            _l.rlhip_debug_w3_dzf_pad(prev)
+            fn(mode0, info)
     except Exception as exc:  # noqa: BLE001
         out["ppo3w_optimiser_step_padded_lds_copy"] = {"error": repr(exc)}
     return out

@@ -43,6 +43,12 @@
 #include "mlp3_device.h"
 #include "optim_device.h"
 #include <type_traits>
+#include <mutex>
+#include <dirent.h>
+#include <unistd.h>
+#include <time.h>
+#include <ctype.h>
+#include <string.h>
 
 extern "C" int32_t rlhip_clip_adam_f32(float* params, float* grad, float* m, float* v, float* beta_pow, int64_t n,
                                        float grad_scale, float clip_norm, float lr, float beta1, float beta2,
@@ -78,15 +84,15 @@ __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { retur
 //                gathers its fragments with the transposing reads (first form of the round; 9 - 12 us per optimiser step slower than 2)
 //   0            both images (rounds 2 - 5), kept for A / B
 // RLHIP_W3_DZF_PAD (mode 2): four 16-byte slots of padding behind every 32 of the backward kernel's LDS copy make the transposing reads
-// bank-conflict free: the kernel -3 us per launch (30.5 -> 27.5), 5 % fewer cycles per optimiser step -- and on two of three boxes the
-// firmware then runs the whole step at a LOWER clock (2.11 vs 2.29 GHz at 1.05 vs 1.16 kW under a 1.4 kW cap) and the step is 2 - 3 %
-// SLOWER; on the third (no throttling) it is 4.5 % faster.  Off by default (the macro is the DEFAULT of a run-time switch: environment variable RLHIP_W3_DZF_PAD, w3_dzf_pad() below; both kernels are
-// always built); profiles/r06_ppo3w.md section 5 has the boxes.
+// bank-conflict free: the kernel -3 us per launch (30.5 -> 27.5), 5 % fewer cycles per optimiser step.  On boxes without an active clock limiter
+// that is -9 us per step (188.5 -> 179.3); on the others the firmware then runs the whole step at a LOWER clock (2.11 - 2.21 vs 2.29 - 2.35 GHz at
+// 1.05 vs 1.16 kW under a 1.4 kW cap) and the step is 2 - 3 % SLOWER.  Both kernels are always built; the macro / the environment variable of
+// the same name select 0 = unpadded, 1 = padded, 2 ("auto", the default) = by the chip's clock (W3Pad below); profiles/r06_ppo3w.md section 5.
 #ifndef RLHIP_W3_DZ_ONCE
 #define RLHIP_W3_DZ_ONCE 2
 #endif
 #ifndef RLHIP_W3_DZF_PAD
-#define RLHIP_W3_DZF_PAD 0
+#define RLHIP_W3_DZF_PAD 2
 #endif
 #ifdef RLHIP_W3_TIMING
 __device__ long long g_w3_stamps[3][16];
@@ -1697,20 +1703,124 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
     return L;
 }
 
-// which LDS copy the backward kernel uses (RLHIP_W3_DZF_PAD above): the environment variable of the same name, read once; the compile-time
-// macro is the default.  rlhip_debug_w3_dzf_pad(on) switches at run time (on < 0: query only) and returns the previous setting -- for A / B
-// runs inside ONE process (tools/power_probe.py, bench.py's sustained_clock leg); not part of the ABI
-static int g_w3_dzf_pad = -1;
-static bool w3_dzf_pad() {
-    if (g_w3_dzf_pad < 0) {
-        const char* e = getenv("RLHIP_W3_DZF_PAD");
-        g_w3_dzf_pad = e != nullptr && e[0] != 0 ? (e[0] != '0') : (RLHIP_W3_DZF_PAD != 0);
+// ---- which LDS copy the backward kernel uses (RLHIP_W3_DZF_PAD above): 0 / 1 forced, 2 = chosen by the chip's clock ----------------------------
+// The two kernels are bit-identical; which one is faster is a property of the BOX (profiles/r06_ppo3w.md section 5): the padded copy needs 5 % fewer
+// cycles per optimiser step, and on boxes whose firmware limiter is active it is given a 6 - 8 % lower clock for it.  Measured model (nine
+// contacts): unpadded runs at >= 0.985 of the top clock exactly on the boxes where padded holds >= 0.94 of it, and padded wins iff its clock stays
+// above 0.946 of the unpadded one.  Mode 2 follows that model with the device's own hwmon reading: every 512 backward launches (~50 ms of a
+// training loop) the host reads freq1_input (one sysfs read, ~10 us, no GPU work); six consecutive dense readings >= 0.985 top -> padded; four
+// consecutive dense readings < 0.94 top while padded -> back, and padded is not tried again for 2 s x 2^k.  Readings across a gap (> 0.25 s
+// since the last one: rollouts, host stalls, the ramp after idle) are ignored.  No sensor -> unpadded.
+struct W3Pad {
+    int mode = -1;     // -1 not initialised; 0 / 1 forced; 2 automatic
+    int variant = 0;   // what the next launch uses
+    char path[320] = {0};
+    double top_mhz = 0.0, last_mhz = 0.0, last_t = 0.0;
+    unsigned long long launches = 0, next_check = 512, probation_until = 0;
+    int hi_run = 0, lo_run = 0, settle = 0, backoff = 0, switches = 0;
+};
+static W3Pad g_w3pad;
+static std::mutex g_w3pad_mu;
+
+static double w3pad_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void w3pad_find_sensor(W3Pad& P) {
+    int dev = 0, khz = 0;
+    char bus[64] = {0};
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) return;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev) == hipSuccess) P.top_mhz = khz * 1e-3;
+    for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+    char dir[160];
+    snprintf(dir, sizeof(dir), "/sys/bus/pci/devices/%s/hwmon", bus);
+    DIR* d = opendir(dir);
+    if (d == nullptr) return;
+    while (dirent* e = readdir(d)) {
+        if (strncmp(e->d_name, "hwmon", 5) != 0) continue;
+        char f[320];
+        snprintf(f, sizeof(f), "%s/%s/freq1_input", dir, e->d_name);
+        if (access(f, R_OK) == 0) {
+            snprintf(P.path, sizeof(P.path), "%s", f);
+            break;
+        }
     }
-    return RLHIP_W3_DZ_ONCE == 2 && g_w3_dzf_pad != 0;
+    closedir(d);
+    if (P.top_mhz < 500.0) P.path[0] = 0;  // no usable top clock: stay with the default kernel
+}
+static double w3pad_read_mhz(const W3Pad& P) {
+    FILE* f = fopen(P.path, "r");
+    if (f == nullptr) return 0.0;
+    long long hz = 0;
+    const int n = fscanf(f, "%lld", &hz);
+    fclose(f);
+    return n == 1 ? (double)hz * 1e-6 : 0.0;
+}
+static void w3pad_init(W3Pad& P) {
+    const char* e = getenv("RLHIP_W3_DZF_PAD");
+    int m = RLHIP_W3_DZF_PAD;
+    if (e != nullptr && e[0] != 0) m = (e[0] == 'a' || e[0] == '2') ? 2 : (e[0] != '0' ? 1 : 0);
+    P.mode = m;
+    P.variant = m == 1 ? 1 : 0;
+    if (m == 2) w3pad_find_sensor(P);
+}
+// one call per backward launch
+static bool w3_dzf_pad() {
+    if (RLHIP_W3_DZ_ONCE != 2) return false;
+    std::lock_guard<std::mutex> lk(g_w3pad_mu);
+    W3Pad& P = g_w3pad;
+    if (P.mode < 0) w3pad_init(P);
+    if (P.mode != 2 || P.path[0] == 0) return P.variant != 0;
+    if (++P.launches < P.next_check) return P.variant != 0;
+    P.next_check = P.launches + 512;
+    const double t = w3pad_now(), mhz = w3pad_read_mhz(P);
+    const bool dense = P.last_t > 0.0 && t - P.last_t < 0.25;
+    P.last_t = t;
+    P.last_mhz = mhz;
+    if (!dense || mhz <= 0.0) {
+        P.hi_run = P.lo_run = 0;
+        return P.variant != 0;
+    }
+    if (P.settle > 0) {  // the firmware takes a few tenths of a second to answer a change of the kernel mix
+        --P.settle;
+        return P.variant != 0;
+    }
+    if (P.variant == 0) {
+        P.hi_run = mhz >= 0.985 * P.top_mhz ? P.hi_run + 1 : 0;
+        if (P.hi_run >= 6 && P.launches >= P.probation_until) {
+            P.variant = 1, P.hi_run = 0, P.lo_run = 0, P.settle = 8, ++P.switches;
+        }
+    } else {
+        P.lo_run = mhz < 0.94 * P.top_mhz ? P.lo_run + 1 : 0;
+        if (P.lo_run >= 4) {
+            P.variant = 0, P.hi_run = 0, P.lo_run = 0, P.settle = 8, ++P.switches;
+            P.probation_until = P.launches + (20480ull << (P.backoff < 8 ? P.backoff : 8));  // ~2 s of launches, doubling
+            ++P.backoff;
+        }
+    }
+    return P.variant != 0;
+}
+// not part of the ABI: on = 0 / 1 force a kernel, 2 automatic, < 0 query; returns the kernel the next launch uses (0 / 1).  `info` (may be null)
+// receives {mode, variant, last reading in MHz, top clock in MHz, switches so far, sensor found}
+extern "C" int32_t rlhip_debug_w3_dzf_pad_info(int32_t on, double* info) {
+    std::lock_guard<std::mutex> lk(g_w3pad_mu);
+    W3Pad& P = g_w3pad;
+    if (P.mode < 0) w3pad_init(P);
+    if (on >= 0) {
+        P.mode = on > 1 ? 2 : on;
+        if (P.mode != 2) P.variant = P.mode;
+        else if (P.path[0] == 0 && P.top_mhz == 0.0) w3pad_find_sensor(P);
+        P.hi_run = P.lo_run = P.settle = 0, P.last_t = 0.0;
+    }
+    if (info != nullptr) {
+        info[0] = P.mode, info[1] = P.variant, info[2] = P.last_mhz, info[3] = P.top_mhz, info[4] = P.switches, info[5] = P.path[0] != 0;
+    }
+    return RLHIP_W3_DZ_ONCE == 2 ? P.variant : 0;
 }
 extern "C" int32_t rlhip_debug_w3_dzf_pad(int32_t on) {
-    const int32_t prev = w3_dzf_pad() ? 1 : 0;
-    if (on >= 0) g_w3_dzf_pad = on != 0;
+    const int32_t prev = rlhip_debug_w3_dzf_pad_info(-1, nullptr);
+    if (on >= 0) rlhip_debug_w3_dzf_pad_info(on, nullptr);
     return prev;
 }
 #define W3_LAUNCH_BWD(NS_, ACT_, net_)                                                                                               \

@@ -159,8 +159,13 @@ def test_dqn3w_padded_lds_copy_of_the_backward_kernel_is_bit_identical(batch, ns
     import rlhip
     from rlhip import _lib, dqn
 
-    fn = _lib.lib.rlhip_debug_w3_dzf_pad
-    fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
+    fn_ = _lib.lib.rlhip_debug_w3_dzf_pad_info
+    fn_.restype, fn_.argtypes = C.c_int32, [C.c_int32, C.POINTER(C.c_double)]
+    info = (C.c_double * 6)()
+
+    def fn(on):
+        return fn_(on, info)
+
     n_env, cap = 64, 40
     rng = np.random.default_rng(batch + act)
     traces = rlhip.CircularArraySARTSTraces(capacity=cap, n_env=n_env, obs_dim=ns)
@@ -168,7 +173,9 @@ def test_dqn3w_padded_lds_copy_of_the_backward_kernel_is_bit_identical(batch, ns
     _fill_ring(traces, oring, ns, n_env, 57, rng, na)
     pd, tpd = torch.as_tensor(_net(ns, na, 11), device="cuda"), torch.as_tensor(_net(ns, na, 12), device="cuda")
     packed, tpacked = dqn.mlp3_pack(pd, ns, H, na), dqn.mlp3_pack(tpd, ns, H, na)
-    prev = fn(0)
+    fn(-1)
+    prev = int(info[0])  # the mode (2 = by the chip's clock, the default), restored below
+    fn(0)
     try:
         g0, l0 = dqn.dqn3_grad(traces, H, na, act, pd, packed, tpd, tpacked, batch, 0.99, 1.0, 7, 3)
         g0, l0 = g0.clone(), l0.clone()

@@ -120,37 +120,69 @@ def test_grad_matches_oracle(kind, cont, act):
 
 
 def _w3_pad(on):
-    """run-time switch of the backward kernel's LDS copy (csrc/ppo3w.hip: rlhip_debug_w3_dzf_pad; not part of the ABI); returns the previous setting"""
+    """run-time choice of the backward kernel's LDS copy (csrc/ppo3w.hip: rlhip_debug_w3_dzf_pad_info; not part of the ABI): 0 / 1 force a
+    kernel, 2 = by the chip's clock (the default), < 0 query.  Returns (kernel of the next launch, [mode, variant, MHz read last, top MHz,
+    switches, sensor found])"""
     import ctypes as C
 
     from rlhip import _lib
 
-    fn = _lib.lib.rlhip_debug_w3_dzf_pad
-    fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
-    return fn(on)
+    fn = _lib.lib.rlhip_debug_w3_dzf_pad_info
+    fn.restype, fn.argtypes = C.c_int32, [C.c_int32, C.POINTER(C.c_double)]
+    info = (C.c_double * 6)()
+    v = fn(on, info)
+    return v, list(info)
 
 
 @pytest.mark.parametrize("act", ["relu", "tanh"])
 @pytest.mark.parametrize("kind,n,T", [("cartpole", 96, 9), ("pendulum", 2048, 40)])
 def test_padded_lds_copy_of_the_backward_kernel_is_bit_identical(kind, n, T, act):
     """ppo3w_bwd_kernel<.., PAD = true> (bank-conflict-free transposing reads; profiles/r06_ppo3w.md section 5) reads the same fragments in the
-    same order as the default: the whole gradient, bit for bit -- a ragged 432-sample micro-batch and 640 tiles"""
+    same order as the unpadded one: the whole gradient, bit for bit -- a ragged 432-sample micro-batch and 640 tiles.  (Which of the two a
+    training loop runs is chosen by the chip's clock by default: bit-identity is what makes that choice invisible.)"""
     a = {"relu": 0, "tanh": 1}[act]
     env, pol = _setup(kind, n, T, n_microbatches=2, act=a)
     pol.rollout_()
     pol.gae_()
-    prev = _w3_pad(0)
+    mode0 = int(_w3_pad(-1)[1][0])
     try:
+        assert _w3_pad(0)[0] == 0
         pol.grad_(1, 1)
         g0, l0 = pol.grad.clone(), pol.losses.clone()
-        assert _w3_pad(1) == 0
+        assert _w3_pad(1)[0] == 1
         pol.grad_(1, 1)
         g1, l1 = pol.grad.clone(), pol.losses.clone()
-        assert _w3_pad(-1) == 1
+        assert _w3_pad(-1)[0] == 1
     finally:
-        _w3_pad(prev)
+        _w3_pad(mode0)
+    assert int(_w3_pad(-1)[1][0]) == mode0
     assert torch.equal(g0, g1) and torch.equal(l0, l1)
     assert float(g0.abs().max()) > 0
+
+
+def test_clock_aware_choice_of_the_backward_kernel_runs_and_reports():
+    """mode 2 (the default): the host reads the device's hwmon clock every 512 backward launches and picks the kernel; whatever it picks, the
+    update is the same bits as with either kernel forced, and the report is sane (sensor found on these boxes, top clock >= 1 GHz, at most a
+    few switches in a second of updates)"""
+    env, pol = _setup("pendulum", 2048, 40, n_microbatches=2)
+    pol.rollout_()
+    pol.gae_()
+    mode0 = int(_w3_pad(-1)[1][0])
+    try:
+        _w3_pad(0)
+        pol.grad_(1, 1)
+        g0 = pol.grad.clone()
+        _w3_pad(2)
+        for _ in range(1500):  # ~1500 x 2 backward launches: several readings
+            pol.grad_(1, 1)
+        torch.cuda.synchronize()
+        v, info = _w3_pad(-1)
+        assert torch.equal(pol.grad, g0)
+        assert int(info[0]) == 2 and v in (0, 1) and int(info[1]) == v
+        if info[5]:
+            assert info[3] >= 1000.0 and 0.0 <= info[2] <= 1.05 * info[3] and info[4] <= 4, info
+    finally:
+        _w3_pad(mode0)
 
 
 def test_grad_many_tiles_per_workgroup_matches_oracle():
