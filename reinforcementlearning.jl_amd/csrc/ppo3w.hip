@@ -1710,14 +1710,15 @@ static P3WLayout p3w_layout(int ns, int nout_a, const rlhip_ppo_cfg* c, int64_t 
 // above 0.946 of the unpadded one.  Mode 2 follows that model with the device's own hwmon reading: every 512 backward launches (~50 ms of a
 // training loop) the host reads freq1_input (one sysfs read, ~10 us, no GPU work); six consecutive dense readings >= 0.985 top -> padded; four
 // consecutive dense readings < 0.94 top while padded -> back, and padded is not tried again for 2 s x 2^k.  Readings across a gap (> 0.25 s
-// since the last one: rollouts, host stalls, the ramp after idle) are ignored.  No sensor -> unpadded.
+// since the last one: rollouts, host stalls) and the first eight readings behind a gap (the ramp from the sleep clock) are ignored.  The start is
+// optimistic (padded) when the sensor is there; no sensor -> unpadded.
 struct W3Pad {
     int mode = -1;     // -1 not initialised; 0 / 1 forced; 2 automatic
     int variant = 0;   // what the next launch uses
     char path[320] = {0};
     double top_mhz = 0.0, last_mhz = 0.0, last_t = 0.0;
     unsigned long long launches = 0, next_check = 512, probation_until = 0;
-    int hi_run = 0, lo_run = 0, settle = 0, backoff = 0, switches = 0;
+    int hi_run = 0, lo_run = 0, dense_run = 0, settle = 0, backoff = 0, switches = 0;
 };
 static W3Pad g_w3pad;
 static std::mutex g_w3pad_mu;
@@ -1763,7 +1764,11 @@ static void w3pad_init(W3Pad& P) {
     if (e != nullptr && e[0] != 0) m = (e[0] == 'a' || e[0] == '2') ? 2 : (e[0] != '0' ? 1 : 0);
     P.mode = m;
     P.variant = m == 1 ? 1 : 0;
-    if (m == 2) w3pad_find_sensor(P);
+    if (m == 2) {
+        w3pad_find_sensor(P);
+        P.variant = P.path[0] != 0;  // optimistic start: padded until the clock says otherwise (a burst is 5 % faster with it where the chip has
+                                     // headroom and 1 % slower where it has not; sustained, the readings decide within ~0.6 s)
+    }
 }
 // one call per backward launch
 static bool w3_dzf_pad() {
@@ -1779,9 +1784,10 @@ static bool w3_dzf_pad() {
     P.last_t = t;
     P.last_mhz = mhz;
     if (!dense || mhz <= 0.0) {
-        P.hi_run = P.lo_run = 0;
+        P.hi_run = P.lo_run = P.dense_run = 0;
         return P.variant != 0;
     }
+    if (++P.dense_run < 8) return P.variant != 0;  // the first ~0.4 s of load after a gap are the ramp from the sleep clock, not the limiter
     if (P.settle > 0) {  // the firmware takes a few tenths of a second to answer a change of the kernel mix
         --P.settle;
         return P.variant != 0;
@@ -1811,7 +1817,7 @@ extern "C" int32_t rlhip_debug_w3_dzf_pad_info(int32_t on, double* info) {
         P.mode = on > 1 ? 2 : on;
         if (P.mode != 2) P.variant = P.mode;
         else if (P.path[0] == 0 && P.top_mhz == 0.0) w3pad_find_sensor(P);
-        P.hi_run = P.lo_run = P.settle = 0, P.last_t = 0.0;
+        P.hi_run = P.lo_run = P.dense_run = P.settle = 0, P.last_t = 0.0;
     }
     if (info != nullptr) {
         info[0] = P.mode, info[1] = P.variant, info[2] = P.last_mhz, info[3] = P.top_mhz, info[4] = P.switches, info[5] = P.path[0] != 0;
