@@ -94,6 +94,9 @@ __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { retur
 #ifndef RLHIP_W3_DZF_PAD
 #define RLHIP_W3_DZF_PAD 2
 #endif
+#ifndef RLHIP_W3_FWD_T
+#define RLHIP_W3_FWD_T 1  // the forward-only modes of ppo3w_fwd_kernel compute layer 2 transposed: the head in-lane, no LDS transposition (0: as the others)
+#endif
 #ifdef RLHIP_W3_TIMING
 __device__ long long g_w3_stamps[3][16];
 #define W3_STAMP(kern, k)                                                                                  \
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int col = 32 * w + r;
+    constexpr bool FWD_T = RLHIP_W3_FWD_T && (NET == 2 || NET == 4);  // forward-only modes compute layer 2 transposed (see the MFMA loop)
     float* l_tw = l_t + w * RW * TPW;
 #if RLHIP_W3_DZ_ONCE != 2
     uint16_t* l_zw = reinterpret_cast<uint16_t*>(l_tw);  // the wave's dZ2 columns as bf16 rows (the row image's copy-out)
@@ -489,9 +493,49 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 32 * rt * PW + 16 * ks);
-                    h2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], h2[rt], 0, 0, 0);
+                    // FWD_T: the operands swapped -- the same products summed over k in the same order, D = H2^T (lane = sample row, registers
+                    // = this wave's columns 8 (q >> 2) + 4 kb + (q & 3)): the register image of the B operand IS the A operand's and vice versa
+                    if (FWD_T) h2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ks], a, h2[rt], 0, 0, 0);
+                    else h2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], h2[rt], 0, 0, 0);
                 }
         }
+        if (FWD_T) {
+            // ---- forward-only modes (DQN target network, the rollout's batched value pass): with lane = sample the head is IN-LANE -- 16 FMAs per
+            //      output and row tile against this lane's 16 columns of W3, one add across the two k halves -- instead of the wave's 64 x 32
+            //      block of H2 going through its private LDS block (the largest phase of the tile: profiles/r06_ppo3w.md section 4) ----
+            float pa[2][NOUT];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) pa[rt][o] = 0.0f;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c0 = 32 * w + 8 * g4 + 4 * kb;  // this lane's columns c0 .. c0 + 3 of register group g4
+                const float4 bb = *reinterpret_cast<const float4*>(m.b2 + c0);
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+                float wv[4 * NOUT];
+#pragma unroll
+                for (int i = 0; i < 4 * NOUT; ++i) wv[i] = m.W3[NOUT * c0 + i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const float hv = act_fwd_t<ACT>(h2[rt][4 * g4 + i] + bv[i]);
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o) pa[rt][o] = fmaf(wv[NOUT * i + o], hv, pa[rt][o]);
+                    }
+            }
+            W3_STAMP(0, 3);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const uint32_t u = __float_as_uint(pa[rt][o]);
+                    const auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // t[0] + t[1]: the kb = 0 half first, in every lane
+                    const float sum = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+                    if (kb == 0) l_part[(w * MAXO + o) * RW + 32 * rt + r] = sum;
+                }
+        } else {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -523,6 +567,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) l_part[(w * MAXO + o) * RW + lane] = pa[o];
+        }
         }
         wave_lds_fence();
         __syncthreads();  // C: every wave's partial sums
