@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the 256-wide learner's optimiser step running under the power cap?  Samples the GPU's hwmon power / sclk files from a thread while
 the main thread runs update_() back to back for a few seconds, and prints the per-iteration update time beside them.
-usage: python tools/power_probe.py [seconds] [mode: ppo3w|dqn3w|headline|envstep|idle] [pad: 0|1 -- the backward kernel's LDS copy, csrc/ppo3w.hip RLHIP_W3_DZF_PAD]"""
+usage: python tools/power_probe.py [seconds] [mode: ppo3w|dqn3w|headline|envstep|adam|polyak|idle] [pad: 0|1 -- the backward kernel's LDS copy, csrc/ppo3w.hip RLHIP_W3_DZF_PAD]"""
 import glob
 import os
 import sys
@@ -161,6 +161,23 @@ elif mode == "envstep":  # the HBM-bound roofline kernel: 2^24 CartPole envs ste
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         marks.append((t0, (t1 - t0) / 50 * 1e6))
+elif mode in ("adam", "polyak"):  # the 2^26-parameter streaming launches of bench.roofline_hbm_side (28 / 12 bytes per parameter)
+    from rlhip import ops
+    n = 1 << 26
+    p_, g_, m_ = (torch.randn(n, device="cuda") for _ in range(3))
+    v_ = torch.rand(n, device="cuda") * 0.99 + 0.01
+    bp = torch.tensor([0.9, 0.999], device="cuda")
+    fn = (lambda: ops.adam_(p_, g_, m_, v_, bp)) if mode == "adam" else (lambda: ops.polyak_(p_, g_, 0.995))
+    fn()
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + secs
+    while time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        marks.append((t0, (t1 - t0) / 20 * 1e6))
 elif mode == "idle":
     time.sleep(secs)
 time.sleep(0.3)
