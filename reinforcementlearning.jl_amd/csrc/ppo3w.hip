@@ -97,6 +97,9 @@ __host__ __device__ __forceinline__ int mlp3w_ns_small(int ns, int nout) { retur
 #ifndef RLHIP_W3_FWD_T
 #define RLHIP_W3_FWD_T 1  // the forward-only modes of ppo3w_fwd_kernel compute layer 2 transposed: the head in-lane, no LDS transposition (0: as the others)
 #endif
+#ifndef RLHIP_W3_TIMING_NET
+#define RLHIP_W3_TIMING_NET 0  // which mode of ppo3w_fwd_kernel a -DRLHIP_W3_TIMING build stamps (0 PPO actor ... 2 DQN target network, forward only)
+#endif
 #ifdef RLHIP_W3_TIMING
 __device__ long long g_w3_stamps[3][16];
 #define W3_STAMP(kern, k)                                                                                  \
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     // (the rollout's batched value pass: V(s) -> sg[q], sg = the value trace; W2 fragments converted from the f32 master
     // weights, no packed image needed).  Per-sample inputs sg[0..3]: PPO {old log-prob, advantage, return,
     // action}; DQN {y, reward, terminal (0 / 1), action bits}
-    W3_MARK(0, 8, NET == 0);
+    W3_MARK(0, 8, NET == RLHIP_W3_TIMING_NET);
     extern __shared__ __attribute__((aligned(16))) char smw[];
     float* l_dq = reinterpret_cast<float*>(smw);  // [MAXO][RW] dL/d(head outputs)
     float* l_part = l_dq + MAXO * RW;            // [WV][MAXO][RW] head partial sums per wave
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
     load_s(blockIdx.x);
     const Mlp3W m = stage_small_w2<NS, NOUT>(pnet, l_w, tid);
     __syncthreads();
-    W3_MARK(0, 9, NET == 0);
+    W3_MARK(0, 9, NET == RLHIP_W3_TIMING_NET);
     const float b2v = m.b2[col];
     float w3[NOUT];
 #pragma unroll
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) b1q[q] = m.b1[u0 + mfma_row(q, kb)];
 
-#define W3_STRIDE (NET == 0 ? gridDim.x : 0x7fffffff)
+#define W3_STRIDE (NET == RLHIP_W3_TIMING_NET ? gridDim.x : 0x7fffffff)
     int it = 0;
     for (int tile = blockIdx.x; tile < g.ntiles; tile += stride, ++it) {
         W3_STAMP(0, 0);
@@ -702,7 +705,10 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
             }
         }
         load_s(tnext);  // the next tile's loss inputs (every wave: uniform streams; wave 0 uses them)
-        if (NET == 2 || NET == 4) continue;  // forward only: the other waves are already in the next pass's layer 1
+        if (NET == 2 || NET == 4) {
+            W3_STAMP(0, 5);
+            continue;
+        }  // forward only: the other waves are already in the next pass's layer 1
         __syncthreads();  // D: dL/d(head outputs) of the tile
         W3_STAMP(0, 5);
         // ---- head backward in the MFMA D layout: dW3, dh2 -> dz2 (f32) -> db2; dz2 -> bf16: fragments straight to global,
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(NTW, 2) void ppo3w_fwd_kernel(P3WArgs g) {
         // no barrier: the next pass writes l_H (last read before barrier C) and this wave's private block in program order
     }
 #undef W3_STRIDE
-    W3_MARK(0, 10, NET == 0);
+    W3_MARK(0, 10, NET == RLHIP_W3_TIMING_NET);
     if (NET == 2 || NET == 4) return;
     // ---- this workgroup's partial row: b2, W3, b3 and the loss sums ----
     const int sb2 = HW * NS + HW, sW3 = sb2 + HW, sb3 = sW3 + NOUT * HW;
